@@ -1,0 +1,340 @@
+"""ctypes front-end of the CPU oracle (oracle/qbnn_oracle.c) plus the model-level
+restatement of the reference's int8 forward graph.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by quantised_bayesian_nets_amd/.
+
+Model graph follows /root/reference/src/models/stochastic/bbb/models_bbb.py:
+  ConvNetwork_ResNet.forward :226-245, BasicBlock.forward :170-183,
+and the MC loop of /root/reference/experiments/utils.py:342-355.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+NOISE_SCALE = float(0.02362204724)   # reference: bbb/quantized/__init__.py:1
+NOISE_ZERO_POINT = 0                 # :2
+UINT_BOUNDS = {8: (0, 255), 7: (0, 127), 6: (0, 63), 5: (0, 31), 4: (0, 15), 3: (0, 7), 2: (0, 3)}   # src/utils.py:18
+INT_BOUNDS = {8: (-128, 127), 7: (-64, 63), 6: (-32, 31), 5: (-16, 15), 4: (-8, 7), 3: (-4, 3), 2: (-2, 1)}  # :19-20
+
+
+class SampleParams(C.Structure):
+    _fields_ = [("inv_noise_scale", C.c_float), ("mul_multiplier", C.c_float),
+                ("z_sigma", C.c_int32), ("z_mul", C.c_int32),
+                ("s_w", C.c_float), ("nzs_w", C.c_float),
+                ("s_mul", C.c_float), ("nzs_mul", C.c_float),
+                ("inv_s_add", C.c_float), ("z_add", C.c_int32),
+                ("w_lo", C.c_int32), ("w_hi", C.c_int32)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("z_x", C.c_int32), ("z_w", C.c_int32),
+                ("s_x", C.c_float), ("s_w", C.c_float), ("s_y", C.c_float),
+                ("z_y", C.c_int32), ("relu", C.c_int32), ("a_hi", C.c_int32)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libqbnn_oracle.so")
+    src = os.path.join(_HERE, "qbnn_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.qbo_num_threads.restype = C.c_int
+    return _LIB
+
+
+def _p(a, t=None):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def f32(x):
+    return np.float32(x)
+
+
+# ---------------------------------------------------------------- RNG ------
+def philox(ctr, key):
+    out = np.zeros(4, np.uint32)
+    lib().qbo_philox4x32_10(_p(np.asarray(ctr, np.uint32)), _p(np.asarray(key, np.uint32)), _p(out))
+    return out
+
+
+def fill_normal(n, seed, layer, sample):
+    eps = np.empty(n, np.float32)
+    lib().qbo_fill_normal(_p(eps), C.c_int64(n), C.c_uint64(seed), C.c_uint32(layer), C.c_uint32(sample))
+    return eps
+
+
+def fill_uniform(n, seed, layer, sample):
+    u = np.empty(n, np.float32)
+    lib().qbo_fill_uniform(_p(u), C.c_int64(n), C.c_uint64(seed), C.c_uint32(layer), C.c_uint32(sample))
+    return u
+
+
+# ------------------------------------------------------------ int8 ops -----
+def sample_params(s_w, z_w, s_sigma, z_sigma, s_mul, z_mul, s_add, z_add, w_bits):
+    p = SampleParams()
+    p.inv_noise_scale = f32(1.0) / f32(NOISE_SCALE)
+    p.mul_multiplier = f32(np.float64(s_sigma) * np.float64(NOISE_SCALE) / np.float64(s_mul))
+    p.z_sigma = int(z_sigma)
+    p.z_mul = int(z_mul)
+    p.s_w = f32(s_w)
+    p.nzs_w = f32(-int(z_w)) * f32(s_w)
+    p.s_mul = f32(s_mul)
+    p.nzs_mul = f32(-int(z_mul)) * f32(s_mul)
+    p.inv_s_add = f32(1.0) / f32(s_add)
+    p.z_add = int(z_add)
+    p.w_lo, p.w_hi = INT_BOUNDS[w_bits]
+    return p
+
+
+def quantize_eps(eps):
+    eps = np.ascontiguousarray(eps, np.float32)
+    out = np.empty(eps.shape, np.int8)
+    lib().qbo_quantize_eps(_p(eps), C.c_int64(eps.size), C.c_float(f32(1.0) / f32(NOISE_SCALE)), _p(out))
+    return out
+
+
+def sample_weights_i8(mu_q, sigma_q, eps, p, want_t=False):
+    mu_q = np.ascontiguousarray(mu_q, np.int8)
+    sigma_q = np.ascontiguousarray(sigma_q, np.int8)
+    eps = np.ascontiguousarray(eps, np.float32)
+    w = np.empty(mu_q.shape, np.int8)
+    t = np.empty(mu_q.shape, np.int8) if want_t else None
+    lib().qbo_sample_weights_i8(_p(mu_q), _p(sigma_q), _p(eps), C.c_int64(mu_q.size), C.byref(p), _p(t), _p(w))
+    return (t, w) if want_t else w
+
+
+def sample_weights_i8_philox(mu_q, sigma_q, p, seed, layer, sample):
+    mu_q = np.ascontiguousarray(mu_q, np.int8)
+    sigma_q = np.ascontiguousarray(sigma_q, np.int8)
+    w = np.empty(mu_q.shape, np.int8)
+    lib().qbo_sample_weights_i8_philox(_p(mu_q), _p(sigma_q), C.c_int64(mu_q.size), C.byref(p),
+                                       C.c_uint64(seed), C.c_uint32(layer), C.c_uint32(sample), _p(w))
+    return w
+
+
+def conv2d_i8(x, w_ohwi, bias, stride, pad, s_x, z_x, s_w, z_w, s_y, z_y, relu, a_hi):
+    """x [B,H,W,Cin] uint8; w [Cout,KH,KW,Cin] int8; returns [B,Ho,Wo,Cout] uint8."""
+    x = np.ascontiguousarray(x, np.uint8)
+    w = np.ascontiguousarray(w_ohwi, np.int8)
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    p = ConvParams(B, H, W, Cin, Cout, KH, KW, stride, pad, int(z_x), int(z_w),
+                   f32(s_x), f32(s_w), f32(s_y), int(z_y), int(bool(relu)), int(a_hi))
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    y = np.empty((B, Ho, Wo, Cout), np.uint8)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    lib().qbo_conv2d_i8(_p(x), _p(w), _p(b), C.byref(p), _p(y))
+    return y
+
+
+def linear_i8(x, w, bias, s_x, z_x, s_w, z_w, s_y, z_y, relu, a_hi):
+    B, K = x.shape
+    N = w.shape[0]
+    y = conv2d_i8(x.reshape(B, 1, 1, K), w.reshape(N, 1, 1, K), bias, 1, 0, s_x, z_x, s_w, z_w, s_y, z_y, relu, a_hi)
+    return y.reshape(B, N)
+
+
+def qadd_relu(a, s_a, z_a, b, s_b, z_b, s_o, z_o, relu, a_hi):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.empty(a.shape, np.uint8)
+    lib().qbo_qadd_relu(_p(a), C.c_float(f32(s_a)), C.c_int32(int(z_a)), _p(b), C.c_float(f32(s_b)), C.c_int32(int(z_b)),
+                        C.c_float(f32(s_o)), C.c_int32(int(z_o)), C.c_int32(int(bool(relu))), C.c_int32(int(a_hi)),
+                        C.c_int64(a.size), _p(out))
+    return out
+
+
+def quantize_input_nchw(x, s, z, a_hi):
+    x = np.ascontiguousarray(x, np.float32)
+    B, Cc, H, W = x.shape
+    out = np.empty((B, H, W, Cc), np.uint8)
+    lib().qbo_quantize_input_nchw(_p(x), B, Cc, H, W, C.c_float(f32(s)), C.c_int32(int(z)), C.c_int32(int(a_hi)), _p(out))
+    return out
+
+
+def avgpool_q(x, k, z, a_hi):
+    x = np.ascontiguousarray(x, np.uint8)
+    B, H, W, Cc = x.shape
+    out = np.empty((B, H // k, W // k, Cc), np.uint8)
+    lib().qbo_avgpool_q(_p(x), B, H, W, Cc, k, C.c_int32(int(z)), C.c_int32(int(a_hi)), _p(out))
+    return out
+
+
+def maxpool2_q(x):
+    x = np.ascontiguousarray(x, np.uint8)
+    B, H, W, Cc = x.shape
+    out = np.empty((B, H // 2, W // 2, Cc), np.uint8)
+    lib().qbo_maxpool2_q(_p(x), B, H, W, Cc, _p(out))
+    return out
+
+
+def dequant_softmax(q, s, z):
+    q = np.ascontiguousarray(q, np.uint8)
+    B, Cc = q.shape
+    out = np.empty((B, Cc), np.float32)
+    lib().qbo_dequant_softmax(_p(q), B, Cc, C.c_float(f32(s)), C.c_int32(int(z)), _p(out))
+    return out
+
+
+# ------------------------------------------------------------- fp32 ops ----
+def softplus(rho):
+    rho = np.ascontiguousarray(rho, np.float32)
+    out = np.empty(rho.shape, np.float32)
+    lib().qbo_softplus(_p(rho), C.c_int64(rho.size), _p(out))
+    return out
+
+
+def sample_weights_f32(mu, sigma, eps):
+    mu = np.ascontiguousarray(mu, np.float32)
+    sigma = np.ascontiguousarray(sigma, np.float32)
+    eps = np.ascontiguousarray(eps, np.float32)
+    w = np.empty(mu.shape, np.float32)
+    lib().qbo_sample_weights_f32(_p(mu), _p(sigma), _p(eps), C.c_int64(mu.size), _p(w))
+    return w
+
+
+def conv2d_f32(x, w_ohwi, bias, stride, pad, relu=False):
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w_ohwi, np.float32)
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    y = np.empty((B, Ho, Wo, Cout), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    lib().qbo_conv2d_f32(_p(x), _p(w), _p(b), B, H, W, Cin, Cout, KH, KW, stride, pad, int(bool(relu)), _p(y))
+    return y
+
+
+# ----------------------------------------------------- model-level graph ---
+def oihw_to_ohwi(w):
+    return np.ascontiguousarray(np.transpose(w, (0, 2, 3, 1))) if w.ndim == 4 else np.ascontiguousarray(w)
+
+
+def ohwi_to_oihw(w):
+    return np.ascontiguousarray(np.transpose(w, (0, 3, 1, 2))) if w.ndim == 4 else np.ascontiguousarray(w)
+
+
+def resnet_layer_table():
+    """Execution (= eps draw) order of the 21 stochastic layers of conv_resnet_bbb
+    (models_bbb.py:171-178 runs the stem before the shortcut).
+    Returns list of (prefix, stride, pad, relu)."""
+    t = [("layers.0.", 1, 1, True)]
+    for li, first_stride in ((3, 1), (4, 2), (5, 2), (6, 2)):
+        for bi in (0, 1):
+            st = first_stride if bi == 0 else 1
+            t.append((f"layers.{li}.{bi}.stem.0.", st, 1, True))
+            t.append((f"layers.{li}.{bi}.stem.3.", 1, 1, False))
+            if bi == 0 and li != 3:
+                t.append((f"layers.{li}.{bi}.shortcut.0.", st, 0, False))
+    t.append(("layers.9.", 1, 0, False))
+    return t
+
+
+class Int8Layer:
+    """One converted int8 BBB layer in the reference's state-dict vocabulary
+    (conv_q.py:72-78 / linear_q.py:40-46)."""
+
+    def __init__(self, state, prefix, layer_id, stride, pad, relu, w_bits):
+        g = lambda k: state[prefix + k]
+        self.prefix, self.layer_id, self.stride, self.pad, self.relu = prefix, layer_id, stride, pad, relu
+        self.mu_q = oihw_to_ohwi(np.asarray(g("weight"), np.int8))
+        self.sigma_q = oihw_to_ohwi(np.asarray(g("std"), np.int8))
+        self.s_w, self.z_w = float(g("weight.q_scale")), int(g("weight.q_zero_point"))
+        self.s_sigma, self.z_sigma = float(g("std.q_scale")), int(g("std.q_zero_point"))
+        self.s_mul, self.z_mul = float(g("mul_noise.scale")), int(g("mul_noise.zero_point"))
+        self.s_add, self.z_add = float(g("add_weight.scale")), int(g("add_weight.zero_point"))
+        self.s_y, self.z_y = float(g("scale")), int(g("zero_point"))
+        b = state.get(prefix + "bias_", None)
+        self.bias = None if b is None or np.asarray(b).size == 0 else np.asarray(b, np.float32)
+        self.sp = sample_params(self.s_w, self.z_w, self.s_sigma, self.z_sigma, self.s_mul, self.z_mul,
+                                self.s_add, self.z_add, w_bits)
+
+    def sample(self, seed, sample, eps=None):
+        if eps is None:
+            return sample_weights_i8_philox(self.mu_q, self.sigma_q, self.sp, seed, self.layer_id, sample)
+        return sample_weights_i8(self.mu_q, self.sigma_q, eps, self.sp)
+
+    def forward(self, x, s_x, z_x, w_q, a_hi):
+        if w_q.ndim == 2:
+            return linear_i8(x, w_q, self.bias, s_x, z_x, self.s_add, self.z_add, self.s_y, self.z_y, self.relu, a_hi)
+        return conv2d_i8(x, w_q, self.bias, self.stride, self.pad, s_x, z_x, self.s_add, self.z_add,
+                         self.s_y, self.z_y, self.relu, a_hi)
+
+
+class Int8ResNetOracle:
+    """conv_resnet_bbb after prepare_model -> convert (quant_utils.py:62-147), int8 path."""
+
+    def __init__(self, state, a_bits=7, w_bits=8):
+        self.state = state
+        self.a_hi = UINT_BOUNDS[a_bits][1]
+        self.w_bits = w_bits
+        self.table = resnet_layer_table()
+        self.layers = {pfx: Int8Layer(state, pfx, i, st, pd, rl, w_bits) for i, (pfx, st, pd, rl) in enumerate(self.table)}
+        self.s_in, self.z_in = float(np.asarray(state["quant.scale"]).reshape(-1)[0]), int(np.asarray(state["quant.zero_point"]).reshape(-1)[0])
+
+    def n_weights(self):
+        return sum(l.mu_q.size for l in self.layers.values())
+
+    def forward(self, x_nchw, seed, sample, eps=None, record=None):
+        """One stochastic forward (one MC sample).  eps: optional dict prefix -> fp32 OHWI eps (parity mode)."""
+        st, a_hi = self.state, self.a_hi
+
+        def run(pfx, x, s_x, z_x):
+            L = self.layers[pfx]
+            w_q = L.sample(seed, sample, None if eps is None else eps[pfx])
+            y = L.forward(x, s_x, z_x, w_q, a_hi)
+            if record is not None:
+                record[pfx + "w_q"] = w_q
+                record[pfx + "out"] = y
+            return y, L.s_y, L.z_y
+
+        x = quantize_input_nchw(x_nchw, self.s_in, self.z_in, a_hi)
+        if record is not None:
+            record["quant.out"] = x
+        x, s, z = run("layers.0.", x, self.s_in, self.z_in)
+        for li in (3, 4, 5, 6):
+            for bi in (0, 1):
+                p = f"layers.{li}.{bi}."
+                o, so, zo = run(p + "stem.0.", x, s, z)
+                o, so, zo = run(p + "stem.3.", o, so, zo)
+                if (p + "shortcut.0.") in self.layers:
+                    sc, ss, zs = run(p + "shortcut.0.", x, s, z)
+                else:
+                    sc, ss, zs = x, s, z
+                sa, za = float(st[p + "add.add.scale"]), int(st[p + "add.add.zero_point"])
+                x = qadd_relu(o, so, zo, sc, ss, zs, sa, za, True, a_hi)
+                s, z = sa, za
+                if record is not None:
+                    record[p + "out"] = x
+        x = avgpool_q(x, 4, z, a_hi)
+        if record is not None:
+            record["avgpool.out"] = x
+        x = x.reshape(x.shape[0], -1)
+        x, s, z = run("layers.9.", x, s, z)
+        return dequant_softmax(x, s, z)
+
+    def mc_predict(self, x_nchw, samples, seed, sample_offset=0, eps_fn=None):
+        """experiments/utils.py:342-355 (classification branch): mean over S of softmax probs.
+        Returns (mean, per_sample_probs)."""
+        ps = []
+        for s in range(samples):
+            e = None if eps_fn is None else eps_fn(sample_offset + s)
+            ps.append(self.forward(x_nchw, seed, sample_offset + s, e))
+        ps = np.stack(ps, 0)
+        return ps.mean(0, dtype=np.float64).astype(np.float32), ps

@@ -1,0 +1,33 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    d = np.load(os.path.join(GOLDEN, name))
+    state = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    rec = {k[len("rec/"):]: d[k] for k in d.files if k.startswith("rec/")}
+    meta = {k[len("meta."):]: int(d[k]) for k in d.files if k.startswith("meta.")}
+    return dict(state=state, rec=rec, meta=meta, x=d["x"], probs=d["probs"], mean_probs=d["mean_probs"])
+
+
+@pytest.fixture(scope="session", params=["resnet_bbb_a7w8.npz", "resnet_bbb_a7w4.npz"])
+def golden(request):
+    return load_golden(request.param)
+
+
+@pytest.fixture(scope="session")
+def golden_w8():
+    return load_golden("resnet_bbb_a7w8.npz")

@@ -1,0 +1,73 @@
+"""The oracle (oracle/qbnn_oracle.c) against the golden vectors recorded from the real reference
+(tests/golden/make_golden.py).  Integer tensors must match bit-for-bit; fp32 probabilities to 1e-5 rel."""
+import numpy as np
+
+from oracle import oracle as orc
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32-10
+    assert [hex(v) for v in orc.philox([0, 0, 0, 0], [0, 0])] == ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+    assert [hex(v) for v in orc.philox([0xffffffff] * 4, [0xffffffff] * 2)] == ['0x408f276d', '0x41c83b0e', '0xa20bc7c6', '0x6d5451fd']
+    assert [hex(v) for v in orc.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])] == \
+        ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
+
+
+def test_normal_stream_is_standard_normal():
+    e = orc.fill_normal(1 << 20, 3, 5, 7).astype(np.float64)
+    assert abs(e.mean()) < 4e-3 and abs(e.std() - 1) < 4e-3 and abs((e ** 4).mean() - 3) < 0.05
+    # ragged tail: n not a multiple of 4 gives a prefix of the same stream
+    assert np.array_equal(orc.fill_normal(1003, 3, 5, 7), orc.fill_normal(1 << 20, 3, 5, 7)[:1003])
+    # streams are keyed by (seed, layer, sample)
+    assert not np.array_equal(orc.fill_normal(64, 3, 5, 7), orc.fill_normal(64, 3, 5, 8))
+    assert not np.array_equal(orc.fill_normal(64, 3, 5, 7), orc.fill_normal(64, 3, 6, 7))
+    assert not np.array_equal(orc.fill_normal(64, 3, 5, 7), orc.fill_normal(64, 4, 5, 7))
+
+
+def test_eps_quantisation_ties_round_half_even():
+    # reference: quantize_per_tensor(eps, 3/127, 0, qint8) == clamp(rne(eps * (1/s)), -128, 127)  (conv_q.py:115)
+    s = np.float32(orc.NOISE_SCALE)
+    e = np.array([0.5 * s, 1.5 * s, -0.5 * s, 2.5 * s, 10.0, -10.0, 3.0], np.float32)
+    q = orc.quantize_eps(e)
+    inv = np.float32(1.0) / s
+    ref = np.clip(np.rint(e * inv), -128, 127).astype(np.int8)
+    assert np.array_equal(q, ref) and q[4] == 127 and q[5] == -128
+
+
+def test_layers_and_graph_bit_exact(golden):
+    net = orc.Int8ResNetOracle(golden["state"], golden["meta"]["a_bits"], golden["meta"]["w_bits"])
+    assert net.n_weights() == 1571592
+    rec, orec = golden["rec"], {}
+    p0 = net.forward(golden["x"], golden["meta"]["philox_seed"], 0, record=orec)
+    lo, hi = orc.INT_BOUNDS[golden["meta"]["w_bits"]]
+    for pfx, *_ in net.table:
+        n = pfx[:-1]
+        assert np.array_equal(orec[pfx + "w_q"], rec[n + ".w_q"]), n
+        assert rec[n + ".w_q"].min() >= lo and rec[n + ".w_q"].max() <= hi
+        assert np.array_equal(orec[pfx + "out"], rec[n + ".out"].reshape(orec[pfx + "out"].shape)), n
+    for li in (3, 4, 5, 6):
+        for bi in (0, 1):
+            assert np.array_equal(orec[f"layers.{li}.{bi}.out"], rec[f"layers.{li}.{bi}.out"])
+    assert np.array_equal(orec["quant.out"], rec["quant.out"])
+    assert np.array_equal(orec["avgpool.out"], rec["layers.7.out"])
+    np.testing.assert_allclose(p0, golden["probs"][0], rtol=1e-5, atol=1e-8)
+
+
+def test_mc_reduction_matches_reference(golden):
+    net = orc.Int8ResNetOracle(golden["state"], golden["meta"]["a_bits"], golden["meta"]["w_bits"])
+    S = golden["probs"].shape[0]
+    mean, ps = net.mc_predict(golden["x"], S, golden["meta"]["philox_seed"])
+    np.testing.assert_allclose(ps, golden["probs"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(mean, golden["mean_probs"], rtol=1e-5, atol=1e-8)
+    # stochastic: samples differ
+    assert np.abs(ps[0] - ps[1]).max() > 1e-3
+
+
+def test_injected_eps_equals_philox_path(golden_w8):
+    g = golden_w8
+    net = orc.Int8ResNetOracle(g["state"], 7, 8)
+    eps = {pfx: orc.fill_normal(net.layers[pfx].mu_q.size, 3, i, 1).reshape(net.layers[pfx].mu_q.shape)
+           for i, (pfx, *_) in enumerate(net.table)}
+    a = net.forward(g["x"], 3, 1, eps=eps)
+    b = net.forward(g["x"], 3, 1)
+    assert np.array_equal(a, b)
