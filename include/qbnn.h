@@ -1,0 +1,132 @@
+/*
+ * qbnn.h -- C ABI of libqbnn_hip.so: the MI355X (gfx950) Monte-Carlo inference path for
+ * quantised Bayesian networks.
+ *
+ * The reference (martinferianc/quantised-bayesian-nets) is pure Python on PyTorch: its
+ * "FFI" for this path is the set of torch ops its layer classes call.  Each entry point
+ * below names the reference call sites (file:line under the reference root) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; the caller owns all buffers;
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *     without synchronising; the library keeps no mutable global state except the
+ *     thread-local error string;
+ *   - return value 0 = ok, negative = error (QBNN_E_*); text via qbnn_last_error();
+ *   - activations: uint8 NHWC, one tensor per MC sample: [S][B][H][W][C]; a sample stride
+ *     of 0 means "shared by all samples";
+ *   - sampled weights: int8 in the MFMA-fragment-packed layout described at
+ *     qbnn_packed_weight_bytes(), one slab per MC sample.
+ */
+#ifndef QBNN_H_
+#define QBNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QBNN_OK 0
+#define QBNN_E_INVALID (-1)     /* bad argument / unsupported shape   */
+#define QBNN_E_LAUNCH (-2)      /* HIP launch error                   */
+
+#define QBNN_LAYOUT_MFMA32 0    /* [NT][KS][64 lanes][16 B] fragments */
+#define QBNN_LAYOUT_ROWMAJOR 1  /* [Cout][K]                          */
+
+/* Scalars of the int8 weight-sampling chain
+ *   noise  = quantize_per_tensor(eps, NOISE_SCALE, 0, qint8)      conv_q.py:113-115, linear_q.py:86-88
+ *   t      = mul_noise.mul(std, noise)                            conv_q.py:118,     linear_q.py:91
+ *   weight = add_weight.add(weight, t)                            (same lines)
+ *   weight = clamp_weight(weight, args)                           conv_q.py:119; src/utils.py:32-37
+ * derived on the host exactly as ATen derives them (see DESIGN.md "Arithmetic contracts"). */
+typedef struct qbnn_sample_params {
+  float inv_noise_scale;   /* 1.0f / (float)NOISE_SCALE                                   */
+  float mul_multiplier;    /* (float)((double)s_std * (double)NOISE_SCALE / (double)s_mul) */
+  int32_t z_sigma;         /* std.q_zero_point()                                          */
+  int32_t z_mul;           /* mul_noise.zero_point                                        */
+  float s_w, nzs_w;        /* weight.q_scale(), (float)(-z_w) * s_w                       */
+  float s_mul, nzs_mul;    /* mul_noise.scale,  (float)(-z_mul) * s_mul                   */
+  float inv_s_add;         /* 1.0f / add_weight.scale                                     */
+  int32_t z_add;           /* add_weight.zero_point                                       */
+  int32_t w_lo, w_hi;      /* INT_BOUNDS[weight_precision], src/utils.py:19-20            */
+} qbnn_sample_params;
+
+/* Bytes of one sample's weights for a [cout][k] layer in `layout`. */
+size_t qbnn_packed_weight_bytes(int32_t cout, int32_t k, int32_t layout);
+
+/* Host helper: pack a logical int8 [cout][k] matrix (OHWI flattening of the reference's OIHW
+ * weight: k = (kh*KW + kw)*Cin + c) into `layout`.  Pad entries are written as 0. */
+int qbnn_pack_weights_host(const int8_t* host_src, int32_t cout, int32_t k, int32_t layout, int8_t* host_dst);
+
+/* Fused MC-batched weight sampler.  Replaces, per layer and per MC sample, the chain
+ * normal_() -> quantize_per_tensor -> quantized::mul -> quantized::add -> clamp_weight
+ * (conv_q.py:113-119, :198-205; linear_q.py:86-92, :160-167).
+ *   mu_packed / sigma_packed : the layer's qint8 `weight` / `std` in `layout`
+ *   eps for element i (OHWI flat index) of sample s comes from the Philox stream
+ *     philox4x32_10(ctr = {i >> 2, layer_id, sample_begin + s, 0}, key = seed)[i & 3]
+ *   unless eps_in != NULL: then eps_in[s * cout * k + i] (fp32) is used (parity mode).
+ *   w_out + s * w_sample_stride receives sample s in `layout`. */
+int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* sigma_packed, int32_t cout, int32_t k,
+                           int32_t layout, const qbnn_sample_params* host_params, uint64_t seed,
+                           uint32_t layer_id, uint32_t sample_begin, int32_t n_samples, const float* eps_in,
+                           int8_t* w_out, int64_t w_sample_stride, void* stream);
+
+/* One int8 stochastic conv layer for S MC samples, including everything the reference model
+ * applies between this conv and the next one:
+ *   quantized.functional.conv2d / quantized::conv2d_relu      conv_q.py:120-125, :206-209
+ *   clamp_activation                                          src/utils.py:25-30 (models_bbb.py:173-174)
+ *   and, when has_res: Add (quantized::add) -> clamp -> ReLU -> clamp   models_bbb.py:179-182
+ * Supported geometries: the conv_resnet_bbb layers. */
+typedef struct qbnn_conv_desc {
+  int32_t B, H, W, Cin, Cout, ksize, stride, pad;
+  float s_x; int32_t z_x;          /* input activation qparams                                  */
+  float s_w; int32_t z_w;          /* sampled weight qparams = add_weight.scale / .zero_point   */
+  float s_y; int32_t z_y;          /* layer output qparams (module .scale / .zero_point)        */
+  int32_t relu;                    /* ConvReLU2d: lower clamp = z_y                             */
+  int32_t a_hi;                    /* UINT_BOUNDS[activation_precision][1]                      */
+  int32_t has_bias;
+  int32_t has_res;                 /* fuse residual add + ReLU of BasicBlock                    */
+  float s_r; int32_t z_r;          /* residual operand qparams                                  */
+  float s_o; int32_t z_o;          /* Add output qparams (add.add.scale / zero_point)           */
+  int32_t x_is_centered_im2col;    /* layer 0 only: x is the int8 im2col tensor of qbnn_im2col3x3_c3 */
+} qbnn_conv_desc;
+
+int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w_packed, int64_t w_sample_stride,
+                      const float* bias, const uint8_t* res, int64_t res_sample_stride, uint8_t* y,
+                      int64_t y_sample_stride, int32_t n_samples, const qbnn_conv_desc* host_desc, void* stream);
+
+/* QuantStub + clamp_activation (models_bbb.py:227-229): fp32 NCHW -> uint8 NHWC. */
+int qbnn_quantize_input_nchw(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, float scale,
+                             int32_t zero_point, int32_t a_hi, uint8_t* out, void* stream);
+
+/* Layer-0 helper: 3x3/pad-1 patches of a [B][H][W][3] uint8 image, centred by z_x, as int8
+ * [B][H*W][32] (27 taps in (kh,kw,c) order + 5 zero bytes).  Shared by all MC samples. */
+int qbnn_im2col3x3_c3(const uint8_t* x, int32_t B, int32_t H, int32_t W, int32_t z_x, int8_t* out, void* stream);
+
+/* Network head for S samples: AvgPool2d(k) -> clamp -> Flatten -> int8 Linear -> clamp ->
+ * DeQuantStub -> softmax     (models_bbb.py:209-211, :240-243; linear_q.py:80-94).
+ *   x [S][B][k][k][C] uint8, w_rowmajor [S][N][C] int8 (QBNN_LAYOUT_ROWMAJOR), probs [S][B][N] fp32. */
+typedef struct qbnn_head_desc {
+  int32_t B, k, C, N;
+  float s_x; int32_t z_x;
+  float s_w; int32_t z_w;
+  float s_y; int32_t z_y;
+  int32_t a_hi;
+  int32_t has_bias;
+} qbnn_head_desc;
+
+int qbnn_head_i8_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w_rowmajor, int64_t w_sample_stride,
+                    const float* bias, float* probs, int32_t n_samples, const qbnn_head_desc* host_desc, void* stream);
+
+/* MC reduction (experiments/utils.py:342-355): sum over the S per-sample outputs of p and p*p,
+ * in sample order (deterministic).  moments[0][n] (+)= sum_s p, moments[1][n] (+)= sum_s p^2. */
+int qbnn_reduce_moments(const float* probs, int32_t n_samples, int64_t n, int32_t accumulate, float* moments, void* stream);
+
+const char* qbnn_last_error(void);
+int qbnn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QBNN_H_ */

@@ -1,0 +1,8 @@
+"""quantised_bayesian_nets_amd -- MI355X-native Monte-Carlo inference path for quantised Bayesian networks.
+
+Drop-in for the hot path of martinferianc/quantised-bayesian-nets (reference file:line citations in each module).
+"""
+from .layers import Conv2d, ConvReLU2d, Linear, LinearReLU, MCQTensor, QFunctional, mc_context  # noqa: F401
+from .models import BasicBlock, ConvNetwork_ResNet, ModelFactory  # noqa: F401
+from .mc import mc_predict, shard_samples, finalize_moments, reduce_moments  # noqa: F401
+from .quant import UINT_BOUNDS, INT_BOUNDS, NOISE_SCALE, NOISE_ZERO_POINT  # noqa: F401

@@ -1,0 +1,85 @@
+"""ctypes binding of libqbnn_hip.so (C ABI: include/qbnn.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+
+class SampleParams(C.Structure):
+    _fields_ = [("inv_noise_scale", C.c_float), ("mul_multiplier", C.c_float),
+                ("z_sigma", C.c_int32), ("z_mul", C.c_int32),
+                ("s_w", C.c_float), ("nzs_w", C.c_float),
+                ("s_mul", C.c_float), ("nzs_mul", C.c_float),
+                ("inv_s_add", C.c_float), ("z_add", C.c_int32),
+                ("w_lo", C.c_int32), ("w_hi", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("s_x", C.c_float), ("z_x", C.c_int32),
+                ("s_w", C.c_float), ("z_w", C.c_int32),
+                ("s_y", C.c_float), ("z_y", C.c_int32),
+                ("relu", C.c_int32), ("a_hi", C.c_int32), ("has_bias", C.c_int32), ("has_res", C.c_int32),
+                ("s_r", C.c_float), ("z_r", C.c_int32),
+                ("s_o", C.c_float), ("z_o", C.c_int32),
+                ("x_is_centered_im2col", C.c_int32)]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("k", C.c_int32), ("C", C.c_int32), ("N", C.c_int32),
+                ("s_x", C.c_float), ("z_x", C.c_int32),
+                ("s_w", C.c_float), ("z_w", C.c_int32),
+                ("s_y", C.c_float), ("z_y", C.c_int32),
+                ("a_hi", C.c_int32), ("has_bias", C.c_int32)]
+
+
+EXPORTS = ["qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_conv2d_i8_mc",
+           "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_head_i8_mc", "qbnn_reduce_moments",
+           "qbnn_last_error", "qbnn_version"]
+
+
+def lib_path():
+    return _build.LIB
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback for the qbnn HIP path)")
+        L = C.CDLL(path)
+        L.qbnn_last_error.restype = C.c_char_p
+        L.qbnn_packed_weight_bytes.restype = C.c_size_t
+        L.qbnn_packed_weight_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+        vp, i32, i64, u32, u64, f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+        L.qbnn_pack_weights_host.argtypes = [vp, i32, i32, i32, vp]
+        L.qbnn_sample_weights_i8.argtypes = [vp, vp, i32, i32, i32, C.POINTER(SampleParams), u64, u32, u32, i32, vp, vp, i64, vp]
+        L.qbnn_conv2d_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, C.POINTER(ConvDesc), vp]
+        L.qbnn_quantize_input_nchw.argtypes = [vp, i32, i32, i32, i32, f, i32, i32, vp, vp]
+        L.qbnn_im2col3x3_c3.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+        L.qbnn_head_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i32, C.POINTER(HeadDesc), vp]
+        L.qbnn_reduce_moments.argtypes = [vp, i32, i64, i32, vp, vp]
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"qbnn error {rc}: {lib().qbnn_last_error().decode()}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,327 @@
+"""int8 Bayes-by-backprop layers behind the reference's layer API.
+
+Host-side mirror of reference src/models/stochastic/bbb/quantized/conv_q.py (Conv2d :22-177, ConvReLU2d :179-225)
+and linear_q.py (Linear :13-145, LinearReLU :147-185): same constructor arguments, attribute names
+(`weight`, `std`, `bias_`, `scale`, `zero_point`, `add_weight`, `mul_noise`, `std_prior`, `args`) and state-dict
+keys.  The arithmetic runs in libqbnn_hip.so (HIP, gfx950); there is no CPU path.
+
+Difference by design: a forward call processes S Monte-Carlo samples at once.  Activations travel as
+`MCQTensor` ([S, B, H, W, C] uint8, NHWC) instead of one torch quint8 tensor per sample, and the weight noise comes
+from the Philox stream (seed, layer_id, sample) instead of torch's global generator.
+"""
+import contextlib
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .quant import INT_BOUNDS, UINT_BOUNDS, make_sample_params
+
+LAYOUT_MFMA32, LAYOUT_ROWMAJOR = 0, 1
+
+
+# ------------------------------------------------------------------ MC context
+class _MCState:
+    samples, seed, sample_begin, eps = 1, 0, 0, None
+
+
+_MC = _MCState()
+
+
+@contextlib.contextmanager
+def mc_context(samples, seed, sample_begin=0, eps=None):
+    """Number of MC samples a layer call evaluates, and the Philox (seed, first global sample index).
+    `eps`: optional {layer_id: fp32 tensor [S, n_weights] in OHWI order} -- parity mode (injected noise)."""
+    old = (_MC.samples, _MC.seed, _MC.sample_begin, _MC.eps)
+    _MC.samples, _MC.seed, _MC.sample_begin, _MC.eps = int(samples), int(seed), int(sample_begin), eps
+    try:
+        yield
+    finally:
+        _MC.samples, _MC.seed, _MC.sample_begin, _MC.eps = old
+
+
+class MCQTensor:
+    """Quantised activations of S MC samples: `data` uint8 [S or 1, B, ...] channels-last, per-tensor (scale, zp).
+    S == 1 with shared=True means "identical for every sample" (the network input)."""
+
+    def __init__(self, data, scale, zero_point, shared=False):
+        assert data.dtype == torch.uint8
+        self.data, self.scale, self.zero_point, self.shared = data, float(scale), int(zero_point), bool(shared)
+
+    @property
+    def samples(self):
+        return self.data.shape[0]
+
+    def sample_stride(self):
+        return 0 if self.shared else self.data[0].numel()
+
+    def q_scale(self):
+        return self.scale
+
+    def q_zero_point(self):
+        return self.zero_point
+
+    def int_repr(self):
+        return self.data
+
+    def dequantize(self):
+        return (self.data.to(torch.float32) - float(self.zero_point)) * np.float32(self.scale)
+
+
+class QFunctional:
+    """Stand-in for torch.nn.quantized.QFunctional: only the (scale, zero_point) the reference reads."""
+
+    def __init__(self, scale=1.0, zero_point=0):
+        self.scale, self.zero_point = float(scale), int(zero_point)
+
+
+class QuantizedParam:
+    """A per-tensor-affine qint8 parameter (reference: torch qint8 tensor): integer values + (scale, zp)."""
+
+    def __init__(self, int_repr, scale, zero_point):
+        self._int = np.ascontiguousarray(int_repr, dtype=np.int8)
+        self._scale, self._zp = float(scale), int(zero_point)
+
+    def int_repr(self):
+        return self._int
+
+    def q_scale(self):
+        return self._scale
+
+    def q_zero_point(self):
+        return self._zp
+
+    @property
+    def shape(self):
+        return self._int.shape
+
+
+def _as_qparam(t):
+    if isinstance(t, QuantizedParam):
+        return t
+    if isinstance(t, torch.Tensor) and t.is_quantized:      # a reference module's qint8 tensor
+        return QuantizedParam(t.int_repr().cpu().numpy(), t.q_scale(), t.q_zero_point())
+    raise TypeError("expected a quantised parameter")
+
+
+def _stream():
+    return _lib.current_stream()
+
+
+# ------------------------------------------------------------------ base class
+class _BBBInt8(nn.Module):
+    layout = LAYOUT_MFMA32
+
+    def _init_common(self, w_shape, bias, args):
+        self.weight = QuantizedParam(np.zeros(w_shape, np.int8), 1.0, 0)
+        self.std = QuantizedParam(np.zeros(w_shape, np.int8), 1.0, 0)
+        self.bias_ = torch.zeros(w_shape[0], dtype=torch.float) if bias else None
+        self.std_prior = nn.Parameter(torch.ones((1,)), requires_grad=False)
+        self.scale, self.zero_point = 1.0, 0
+        self.add_weight, self.mul_noise = QFunctional(), QFunctional()
+        self.args = args
+        self.layer_id = 0
+        self._packed = None
+
+    def bias(self):
+        return self.bias_
+
+    # ---- state (reference keys: conv_q.py:72-99, linear_q.py:40-67)
+    def load_reference_state(self, state, prefix):
+        g = lambda k: state[prefix + k]
+        self.weight = QuantizedParam(g("weight"), g("weight.q_scale"), g("weight.q_zero_point"))
+        self.std = QuantizedParam(g("std"), g("std.q_scale"), g("std.q_zero_point"))
+        b = state.get(prefix + "bias_", None)
+        self.bias_ = None if b is None or np.asarray(b).size == 0 else torch.from_numpy(np.asarray(b, np.float32).copy())
+        self.scale, self.zero_point = float(g("scale")), int(g("zero_point"))
+        self.add_weight = QFunctional(g("add_weight.scale"), g("add_weight.zero_point"))
+        self.mul_noise = QFunctional(g("mul_noise.scale"), g("mul_noise.zero_point"))
+        self._packed = None
+        return self
+
+    def reference_state(self, prefix=""):
+        d = {prefix + "weight": self.weight.int_repr(), prefix + "weight.q_scale": np.float64(self.weight.q_scale()),
+             prefix + "weight.q_zero_point": np.int64(self.weight.q_zero_point()),
+             prefix + "std": self.std.int_repr(), prefix + "std.q_scale": np.float64(self.std.q_scale()),
+             prefix + "std.q_zero_point": np.int64(self.std.q_zero_point()),
+             prefix + "scale": np.float32(self.scale), prefix + "zero_point": np.int64(self.zero_point),
+             prefix + "add_weight.scale": np.float32(self.add_weight.scale),
+             prefix + "add_weight.zero_point": np.int64(self.add_weight.zero_point),
+             prefix + "mul_noise.scale": np.float32(self.mul_noise.scale),
+             prefix + "mul_noise.zero_point": np.int64(self.mul_noise.zero_point)}
+        if self.bias_ is not None:
+            d[prefix + "bias_"] = self.bias_.cpu().numpy()
+        return d
+
+    @classmethod
+    def _from_converted(cls, mod, *ctor):
+        q = cls(*ctor, args=getattr(mod, "args", None))
+        q.weight, q.std = _as_qparam(mod.weight), _as_qparam(mod.std)
+        b = mod.bias() if callable(getattr(mod, "bias", None)) else getattr(mod, "bias_", None)
+        q.bias_ = None if b is None else b.detach().float().cpu().clone()
+        q.scale, q.zero_point = float(mod.scale), int(mod.zero_point)
+        q.add_weight = QFunctional(mod.add_weight.scale, mod.add_weight.zero_point)
+        q.mul_noise = QFunctional(mod.mul_noise.scale, mod.mul_noise.zero_point)
+        return q
+
+    # ---- device-side parameter images
+    def _logical_ohwi(self, qp):
+        w = qp.int_repr()
+        return np.ascontiguousarray(w.transpose(0, 2, 3, 1)) if w.ndim == 4 else w
+
+    def _ensure_packed(self, device):
+        if self._packed is not None and self._packed["device"] == device:
+            return self._packed
+        L = _lib.lib()
+        mu, sg = self._logical_ohwi(self.weight), self._logical_ohwi(self.std)
+        cout, k = mu.shape[0], int(np.prod(mu.shape[1:]))
+        nbytes = L.qbnn_packed_weight_bytes(cout, k, self.layout)
+        out = []
+        for src in (mu, sg):
+            dst = np.zeros(nbytes, np.int8)
+            src = np.ascontiguousarray(src.reshape(cout, k))
+            _lib.check(L.qbnn_pack_weights_host(src.ctypes.data_as(C.c_void_p), cout, k, self.layout, dst.ctypes.data_as(C.c_void_p)))
+            out.append(torch.from_numpy(dst).to(device))
+        wp = getattr(self.args, "weight_precision", 8)
+        sp = make_sample_params(self.weight.q_scale(), self.weight.q_zero_point(), self.std.q_scale(), self.std.q_zero_point(),
+                                self.mul_noise.scale, self.mul_noise.zero_point, self.add_weight.scale,
+                                self.add_weight.zero_point, wp)
+        bias = None if self.bias_ is None else self.bias_.to(device=device, dtype=torch.float32).contiguous()
+        self._packed = dict(device=device, mu=out[0], sigma=out[1], cout=cout, k=k, nbytes=int(nbytes), sp=sp, bias=bias)
+        return self._packed
+
+    def sample_weights(self, device, samples=None, seed=None, sample_begin=None, eps=None):
+        """W_q for S samples in this layer's packed layout: int8 [S, nbytes]  (conv_q.py:113-119 chain, fused)."""
+        S = _MC.samples if samples is None else samples
+        seed = _MC.seed if seed is None else seed
+        sb = _MC.sample_begin if sample_begin is None else sample_begin
+        if eps is None and _MC.eps is not None:
+            eps = _MC.eps.get(self.layer_id)
+        pk = self._ensure_packed(device)
+        w = torch.empty((S, pk["nbytes"]), dtype=torch.int8, device=device)
+        if eps is not None:
+            eps = eps.to(device=device, dtype=torch.float32).contiguous()
+            assert eps.numel() == S * pk["cout"] * pk["k"]
+        _lib.check(_lib.lib().qbnn_sample_weights_i8(_lib.ptr(pk["mu"]), _lib.ptr(pk["sigma"]), pk["cout"], pk["k"], self.layout,
+                                                     C.byref(pk["sp"]), seed, self.layer_id, sb, S, _lib.ptr(eps),
+                                                     _lib.ptr(w), pk["nbytes"], _stream()))
+        return w
+
+    def _a_hi(self):
+        return UINT_BOUNDS[getattr(self.args, "activation_precision", 7)][1]
+
+
+# ------------------------------------------------------------------ conv
+class Conv2d(_BBBInt8):
+    """reference conv_q.Conv2d (conv_q.py:22-177): sampled int8 conv, output quint8 in [0, 255] then the model's
+    clamp_activation -- fused here, with the optional residual Add+ReLU of BasicBlock."""
+    relu = False
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=False,
+                 padding_mode='zeros', args=None):
+        super().__init__()
+        if padding_mode != 'zeros':
+            raise NotImplementedError("Currently only zero-padding is supported by quantized conv")
+        if in_channels % groups != 0:
+            raise ValueError('in_channels must be divisible by groups')
+        if out_channels % groups != 0:
+            raise ValueError('out_channels must be divisible by groups')
+        pair = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = pair(kernel_size), pair(stride), pair(padding), pair(dilation)
+        self.groups, self.padding_mode = groups, padding_mode
+        if groups != 1 or self.dilation != (1, 1):
+            raise NotImplementedError("groups/dilation other than 1 are not on the hot path")
+        self._init_common((out_channels, in_channels) + self.kernel_size, bias, args)
+
+    def _get_name(self):
+        return 'QuantizedConv2d'
+
+    def forward(self, x, residual=None, add_qparams=None):
+        """x: MCQTensor.  residual/add_qparams: fuse `Add` + ReLU of BasicBlock (models_bbb.py:179-182)."""
+        if x.data.dim() != 5:
+            raise ValueError("Input shape must be `(S, N, H, W, C)`!")
+        dev = x.data.device
+        if dev.type != "cuda":
+            raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
+        S = _MC.samples
+        w = self.sample_weights(dev)
+        return self._conv(x, w, S, residual, add_qparams)
+
+    def _conv(self, x, w, S, residual=None, add_qparams=None, im2col=None):
+        pk = self._ensure_packed(x.data.device)
+        _, B, H, W, Cin = x.data.shape
+        ks, st, pd = self.kernel_size[0], self.stride[0], self.padding[0]
+        Ho, Wo = (H + 2 * pd - ks) // st + 1, (W + 2 * pd - ks) // st + 1
+        y = torch.empty((S, B, Ho, Wo, self.out_channels), dtype=torch.uint8, device=x.data.device)
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.pad = B, H, W, Cin, self.out_channels, ks, st, pd
+        d.s_x, d.z_x = x.scale, x.zero_point
+        d.s_w, d.z_w = self.add_weight.scale, self.add_weight.zero_point
+        d.s_y, d.z_y = self.scale, self.zero_point
+        d.relu, d.a_hi, d.has_bias = int(self.relu), self._a_hi(), int(pk["bias"] is not None)
+        xin, xss = x.data, x.sample_stride()
+        if im2col is not None:       # layer 0: K = 27 taps of the 3-channel image, pre-gathered once per batch
+            xin, xss = im2col, 0
+            d.Cin, d.ksize, d.pad, d.x_is_centered_im2col = 32, 1, 0, 1
+        res_ss = 0
+        if residual is not None:
+            d.has_res = 1
+            d.s_r, d.z_r = residual.scale, residual.zero_point
+            d.s_o, d.z_o = add_qparams
+            res_ss = residual.sample_stride()
+            assert residual.data.shape[1:] == y.shape[1:]
+        _lib.check(_lib.lib().qbnn_conv2d_i8_mc(_lib.ptr(xin), xss, _lib.ptr(w), w.shape[1], _lib.ptr(pk["bias"]),
+                                                _lib.ptr(None if residual is None else residual.data), res_ss,
+                                                _lib.ptr(y), y[0].numel(), S, C.byref(d), _stream()))
+        if residual is not None:
+            return MCQTensor(y, add_qparams[0], add_qparams[1])
+        return MCQTensor(y, self.scale, self.zero_point)
+
+    @classmethod
+    def from_float(cls, mod):
+        """Accepts an already converted reference module (conv_q.Conv2d / ConvReLU2d instance)."""
+        if hasattr(mod, 'weight_fake_quant'):
+            raise NotImplementedError("QAT -> int8 conversion (reference conv_q.py:127-177) is not built yet; "
+                                      "convert with the reference and pass the converted module")
+        return cls._from_converted(mod, mod.in_channels, mod.out_channels, mod.kernel_size, mod.stride, mod.padding,
+                                   mod.dilation, mod.groups, mod.bias() is not None, mod.padding_mode)
+
+
+class ConvReLU2d(Conv2d):
+    """reference conv_q.ConvReLU2d (conv_q.py:179-225)."""
+    relu = True
+
+    def _get_name(self):
+        return 'QuantizedConvReLU2d'
+
+
+# ------------------------------------------------------------------ linear
+class Linear(_BBBInt8):
+    """reference linear_q.Linear (linear_q.py:13-145)."""
+    relu = False
+    layout = LAYOUT_ROWMAJOR
+
+    def __init__(self, in_features, out_features, bias_=False, args=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self._init_common((out_features, in_features), bias_, args)
+
+    def _get_name(self):
+        return 'QuantizedLinear'
+
+    @classmethod
+    def from_float(cls, mod):
+        if hasattr(mod, 'weight_fake_quant'):
+            raise NotImplementedError("QAT -> int8 conversion (reference linear_q.py:105-145) is not built yet")
+        return cls._from_converted(mod, mod.in_features, mod.out_features, mod.bias() is not None)
+
+
+class LinearReLU(Linear):
+    """reference linear_q.LinearReLU (linear_q.py:147-185)."""
+    relu = True
+
+    def _get_name(self):
+        return 'QuantizedLinearReLU'

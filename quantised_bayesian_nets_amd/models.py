@@ -1,0 +1,199 @@
+"""int8 conv_resnet_bbb behind the reference's model API.
+
+Mirror of reference src/models/stochastic/bbb/models_bbb.py: BasicBlock (:146-188) and ConvNetwork_ResNet
+(:191-256) *after* quant_utils.prepare_model -> convert, i.e. the graph the reference's MC evaluation executes
+(SURVEY.md section 3.1).  Module names / state-dict keys are the reference's (`layers.4.0.stem.3.weight`, ...), so
+a converted reference checkpoint loads by key.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .layers import Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_context
+from .quant import UINT_BOUNDS, check_bits
+
+
+class Add(nn.Module):
+    """reference src/utils.py:49-55 (`Add`, a FloatFunctional -> QFunctional add).  Fused into stem.3's epilogue."""
+
+    def __init__(self):
+        super().__init__()
+        self.add = QFunctional()
+
+
+class BasicBlock(nn.Module):
+    """reference models_bbb.py:146-188 after fuse_model(): stem.0 = ConvReLU2d, stem.3 = Conv2d,
+    shortcut.0 = Conv2d (1x1, stride 2) where the shape changes; add; end ReLU."""
+    expansion = 1
+
+    def __init__(self, in_planes, planes, stride=1, q=True, args=None):
+        super().__init__()
+        self.args, self.q = args, q
+        ident = nn.Identity
+        self.stem = nn.ModuleList([ConvReLU2d(in_planes, planes, 3, stride=stride, padding=1, bias=True, args=args), ident(), ident(),
+                                   Conv2d(planes, planes, 3, stride=1, padding=1, bias=True, args=args), ident()])
+        self.shortcut = nn.ModuleList([])
+        if stride != 1 or in_planes != self.expansion * planes:
+            self.shortcut.append(Conv2d(in_planes, self.expansion * planes, 1, stride=stride, bias=True, args=args))
+            self.shortcut.append(ident())
+        self.add = Add()
+        self.end = nn.ReLU()
+
+    def forward(self, x):
+        S = _MC.samples
+        dev = x.data.device
+        w0 = self.stem[0].sample_weights(dev)
+        w3 = self.stem[3].sample_weights(dev)
+        out = self.stem[0]._conv(x, w0, S)
+        if len(self.shortcut):
+            ws = self.shortcut[0].sample_weights(dev)
+            sc = self.shortcut[0]._conv(x, ws, S)
+        else:
+            sc = x
+        return self.stem[3]._conv(out, w3, S, residual=sc, add_qparams=(self.add.add.scale, self.add.add.zero_point))
+
+
+class QuantStub(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.scale, self.zero_point = 1.0, 0
+
+
+class ConvNetwork_ResNet(nn.Module):
+    """reference models_bbb.py:191-256 (narrow ResNet-18: 24/48/96/192), converted int8 form."""
+
+    def __init__(self, input_size, output_size, q, args):
+        super().__init__()
+        if not q:
+            raise NotImplementedError("only the converted int8 model (q=True) is built so far")
+        check_bits(args)
+        self.args, self.q = args, q
+        self.in_planes = 24
+        self.init_channels = input_size[1]
+        self.output_size = int(output_size)
+        ident = nn.Identity
+        self.layers = nn.ModuleList([])
+        self.layers.append(ConvReLU2d(self.init_channels, 24, 3, stride=1, padding=1, bias=True, args=args))
+        self.layers.append(ident())
+        self.layers.append(ident())
+        self.layers.append(self._make_layer(24, 2, 1))
+        self.layers.append(self._make_layer(48, 2, 2))
+        self.layers.append(self._make_layer(96, 2, 2))
+        self.layers.append(self._make_layer(192, 2, 2))
+        self.layers.append(nn.AvgPool2d(4))
+        self.layers.append(ident())            # Flatten
+        self.layers.append(Linear(192 * BasicBlock.expansion, output_size, bias_=False, args=args))
+        self.quant = QuantStub()
+        self.dequant = ident()
+        # Philox tensor ids = execution order of the stochastic layers
+        for i, m in enumerate(self.stochastic_layers()):
+            m.layer_id = i
+
+    def _make_layer(self, planes, num_blocks, stride):
+        strides = [stride] + [1] * (num_blocks - 1)
+        blocks = []
+        for st in strides:
+            blocks.append(BasicBlock(self.in_planes, planes, st, self.q, self.args))
+            self.in_planes = planes * BasicBlock.expansion
+        return nn.ModuleList(blocks)
+
+    def stochastic_layers(self):
+        out = [self.layers[0]]
+        for li in (3, 4, 5, 6):
+            for blk in self.layers[li]:
+                out += [blk.stem[0], blk.stem[3]] + ([blk.shortcut[0]] if len(blk.shortcut) else [])
+        out.append(self.layers[9])
+        return out
+
+    def stochastic_layer_names(self):
+        names = ["layers.0"]
+        for li in (3, 4, 5, 6):
+            for bi, blk in enumerate(self.layers[li]):
+                names += [f"layers.{li}.{bi}.stem.0", f"layers.{li}.{bi}.stem.3"]
+                if len(blk.shortcut):
+                    names.append(f"layers.{li}.{bi}.shortcut.0")
+        names.append("layers.9")
+        return names
+
+    # ---- reference-format checkpoint ingestion (flat numpy dict; see tests/golden/make_golden.py:flat_state)
+    def load_reference_state(self, state):
+        for name, m in zip(self.stochastic_layer_names(), self.stochastic_layers()):
+            m.load_reference_state(state, name + ".")
+        for li in (3, 4, 5, 6):
+            for bi, blk in enumerate(self.layers[li]):
+                p = f"layers.{li}.{bi}.add.add."
+                blk.add.add = QFunctional(state[p + "scale"], state[p + "zero_point"])
+        self.quant.scale = float(np.asarray(state["quant.scale"]).reshape(-1)[0])
+        self.quant.zero_point = int(np.asarray(state["quant.zero_point"]).reshape(-1)[0])
+        return self
+
+    def n_weights(self):
+        return sum(int(np.prod(m.weight.shape)) for m in self.stochastic_layers())
+
+    # ---- forward
+    def quantize_input(self, x):
+        """QuantStub + clamp_activation (models_bbb.py:227-229): fp32 NCHW -> MCQTensor shared by all samples."""
+        if x.device.type != "cuda":
+            raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
+        x = x.to(torch.float32).contiguous()
+        B, Cc, H, W = x.shape
+        out = torch.empty((1, B, H, W, Cc), dtype=torch.uint8, device=x.device)
+        a_hi = UINT_BOUNDS[self.args.activation_precision][1]
+        _lib.check(_lib.lib().qbnn_quantize_input_nchw(_lib.ptr(x), B, Cc, H, W, self.quant.scale, self.quant.zero_point, a_hi,
+                                                       _lib.ptr(out), _lib.current_stream()))
+        return MCQTensor(out, self.quant.scale, self.quant.zero_point, shared=True)
+
+    def forward_mc(self, x, record=None):
+        """All S samples of the current mc_context: returns per-sample softmax probabilities [S, B, classes]."""
+        S = _MC.samples
+        L = _lib.lib()
+        xq = self.quantize_input(x)
+        dev = x.device
+        _, B, H, W, Cc = xq.data.shape
+        if record is not None:
+            record["quant.out"] = xq.data[0]
+        if Cc != 3 or H != 32 or W != 32:
+            raise NotImplementedError("conv_resnet_bbb expects 3x32x32 inputs")
+        col = torch.empty((B, H * W, 32), dtype=torch.int8, device=dev)
+        _lib.check(L.qbnn_im2col3x3_c3(_lib.ptr(xq.data), B, H, W, xq.zero_point, _lib.ptr(col), _lib.current_stream()))
+        l0 = self.layers[0]
+        h = l0._conv(xq, l0.sample_weights(dev), S, im2col=col)
+        if record is not None:
+            record["layers.0.out"] = h.data
+        for li in (3, 4, 5, 6):
+            for bi, blk in enumerate(self.layers[li]):
+                h = blk(h)
+                if record is not None:
+                    record[f"layers.{li}.{bi}.out"] = h.data
+        fc = self.layers[9]
+        wfc = fc.sample_weights(dev)
+        pk = fc._ensure_packed(dev)
+        probs = torch.empty((S, B, self.output_size), dtype=torch.float32, device=dev)
+        d = _lib.HeadDesc()
+        d.B, d.k, d.C, d.N = B, h.data.shape[2], h.data.shape[4], self.output_size
+        d.s_x, d.z_x = h.scale, h.zero_point
+        d.s_w, d.z_w = fc.add_weight.scale, fc.add_weight.zero_point
+        d.s_y, d.z_y = fc.scale, fc.zero_point
+        d.a_hi, d.has_bias = UINT_BOUNDS[self.args.activation_precision][1], int(pk["bias"] is not None)
+        _lib.check(L.qbnn_head_i8_mc(_lib.ptr(h.data), h.sample_stride(), _lib.ptr(wfc), wfc.shape[1], _lib.ptr(pk["bias"]),
+                                     _lib.ptr(probs), S, C.byref(d), _lib.current_stream()))
+        return probs
+
+    def forward(self, x):
+        """Reference call contract: one stochastic forward -> probs [B, classes] (models_bbb.py:226-245).
+        Under mc_context(samples=S) it evaluates sample `sample_begin` only; use forward_mc for all S."""
+        with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
+            return self.forward_mc(x)[0]
+
+
+class ModelFactory:
+    """reference src/models/__init__.py:12-40 (names kept)."""
+
+    @staticmethod
+    def get_model(model, input_size, output_size, q, args, training_mode=True):
+        if model == "conv_resnet_bbb":
+            return ConvNetwork_ResNet(input_size, output_size, q, args)
+        raise NotImplementedError("Other models not implemented")

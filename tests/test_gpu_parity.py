@@ -1,0 +1,205 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of libqbnn_hip.so, against
+(a) the golden vectors recorded from the real reference and (b) the CPU oracle on the same seeded inputs.
+Integer tensors: bit-exact.  fp32 probabilities / moments: 1e-5 relative (BASELINE.json north_star)."""
+import ctypes as C
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def _args(g):
+    return types.SimpleNamespace(activation_precision=g["meta"]["a_bits"], weight_precision=g["meta"]["w_bits"])
+
+
+def _model(g):
+    import quantised_bayesian_nets_amd as q
+    m = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, _args(g))
+    return m.load_reference_state(g["state"])
+
+
+def _pack(layer, w_logical):
+    """logical OHWI int8 -> the layer's device layout, via the C ABI host helper."""
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    cout = w_logical.shape[0]
+    k = int(np.prod(w_logical.shape[1:]))
+    n = L.qbnn_packed_weight_bytes(cout, k, layer.layout)
+    dst = np.zeros(n, np.int8)
+    src = np.ascontiguousarray(w_logical.reshape(cout, k))
+    _lib.check(L.qbnn_pack_weights_host(src.ctypes.data_as(C.c_void_p), cout, k, layer.layout, dst.ctypes.data_as(C.c_void_p)))
+    return dst
+
+
+def test_library_is_the_hip_one():
+    from quantised_bayesian_nets_amd import _lib
+    assert _lib.lib().qbnn_version() >= 1
+    assert torch.cuda.is_available()
+
+
+def test_sampler_philox_matches_oracle_and_golden(golden):
+    from oracle import oracle as orc
+    g = golden
+    m = _model(g)
+    net = orc.Int8ResNetOracle(g["state"], g["meta"]["a_bits"], g["meta"]["w_bits"])
+    seed = g["meta"]["philox_seed"]
+    S = 3
+    for name, layer, (pfx, *_r) in zip(m.stochastic_layer_names(), m.stochastic_layers(), net.table):
+        w = layer.sample_weights("cuda", samples=S, seed=seed, sample_begin=0).cpu().numpy()
+        for s in range(S):
+            ref = net.layers[pfx].sample(seed, s)
+            assert np.array_equal(w[s], _pack(layer, ref)), (name, s)
+        # sample 0 is also what the real reference produced with this eps injected
+        assert np.array_equal(w[0], _pack(layer, g["rec"][name + ".w_q"])), name
+        # sample_begin offsets the global sample index
+        w1 = layer.sample_weights("cuda", samples=1, seed=seed, sample_begin=2).cpu().numpy()
+        assert np.array_equal(w1[0], w[2]), name
+
+
+def test_sampler_injected_eps_equals_philox(golden_w8):
+    from oracle import oracle as orc
+    m = _model(golden_w8)
+    for layer in (m.layers[0], m.layers[4][0].shortcut[0], m.layers[6][1].stem[3], m.layers[9]):
+        n = int(np.prod(layer.weight.shape))
+        eps = np.stack([orc.fill_normal(n, 11, layer.layer_id, s) for s in (5, 6)])
+        a = layer.sample_weights("cuda", samples=2, seed=11, sample_begin=5)
+        b = layer.sample_weights("cuda", samples=2, seed=0, sample_begin=0, eps=torch.from_numpy(eps))
+        assert torch.equal(a, b)
+
+
+def test_each_conv_layer_matches_golden(golden):
+    """Layer-level: golden input activations + golden sampled weights -> golden output (real layer shapes, B=4)."""
+    from quantised_bayesian_nets_amd.layers import MCQTensor
+    from quantised_bayesian_nets_amd import _lib
+    g = golden
+    m = _model(g)
+    rec, st = g["rec"], g["state"]
+    dev = "cuda"
+
+    def act(name, scale_key):
+        s, z = float(np.asarray(st[scale_key + "scale"]).reshape(-1)[0]), int(np.asarray(st[scale_key + "zero_point"]).reshape(-1)[0])
+        return MCQTensor(torch.from_numpy(rec[name]).to(dev)[None].contiguous(), s, z)
+
+    x0 = act("quant.out", "quant.")
+    # layer 0 (im2col path)
+    l0 = m.layers[0]
+    B, H, W, _ = rec["quant.out"].shape
+    col = torch.empty((B, H * W, 32), dtype=torch.int8, device=dev)
+    _lib.check(_lib.lib().qbnn_im2col3x3_c3(_lib.ptr(x0.data), B, H, W, x0.zero_point, _lib.ptr(col), _lib.current_stream()))
+    w = torch.from_numpy(_pack(l0, rec["layers.0.w_q"])).to(dev)[None]
+    y = l0._conv(x0, w, 1, im2col=col)
+    assert np.array_equal(y.data[0].cpu().numpy(), rec["layers.0.out"]), "layers.0"
+
+    prev, prev_key = "layers.0.out", "layers.0."
+    for li in (3, 4, 5, 6):
+        for bi, blk in enumerate(m.layers[li]):
+            p = f"layers.{li}.{bi}."
+            xin = act(prev, prev_key)
+            w0 = torch.from_numpy(_pack(blk.stem[0], rec[p + "stem.0.w_q"])).to(dev)[None]
+            o = blk.stem[0]._conv(xin, w0, 1)
+            assert np.array_equal(o.data[0].cpu().numpy(), rec[p + "stem.0.out"]), p + "stem.0"
+            w3 = torch.from_numpy(_pack(blk.stem[3], rec[p + "stem.3.w_q"])).to(dev)[None]
+            o3 = blk.stem[3]._conv(act(p + "stem.0.out", p + "stem.0."), w3, 1)
+            assert np.array_equal(o3.data[0].cpu().numpy(), rec[p + "stem.3.out"]), p + "stem.3"
+            if len(blk.shortcut):
+                ws = torch.from_numpy(_pack(blk.shortcut[0], rec[p + "shortcut.0.w_q"])).to(dev)[None]
+                sc = blk.shortcut[0]._conv(xin, ws, 1)
+                assert np.array_equal(sc.data[0].cpu().numpy(), rec[p + "shortcut.0.out"]), p + "shortcut.0"
+            else:
+                sc = xin
+            fused = blk.stem[3]._conv(act(p + "stem.0.out", p + "stem.0."), w3, 1, residual=sc,
+                                      add_qparams=(blk.add.add.scale, blk.add.add.zero_point))
+            assert np.array_equal(fused.data[0].cpu().numpy(), rec[p[:-1] + ".out"]), p + "add/relu"
+            prev, prev_key = p[:-1] + ".out", p + "add.add."
+
+
+def test_resnet_end_to_end_matches_reference(golden):
+    import quantised_bayesian_nets_amd as q
+    g = golden
+    m = _model(g)
+    x = torch.from_numpy(g["x"]).cuda()
+    S = g["probs"].shape[0]
+    rec = {}
+    with q.mc_context(S, g["meta"]["philox_seed"], 0):
+        probs = m.forward_mc(x, record=rec)
+    assert np.array_equal(rec["quant.out"].cpu().numpy(), g["rec"]["quant.out"])
+    assert np.array_equal(rec["layers.0.out"][0].cpu().numpy(), g["rec"]["layers.0.out"])
+    for li in (3, 4, 5, 6):
+        for bi in (0, 1):
+            k = f"layers.{li}.{bi}.out"
+            assert np.array_equal(rec[k][0].cpu().numpy(), g["rec"][k]), k
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=RTOL, atol=1e-8)
+    mean, var = q.mc_predict(m, x, S, g["meta"]["philox_seed"], return_var=True)
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean_probs"], rtol=RTOL, atol=1e-8)
+    ref_var = torch.from_numpy(g["probs"]).var(dim=0).numpy()
+    np.testing.assert_allclose(var.cpu().numpy(), ref_var, rtol=1e-3, atol=1e-7)
+    # reference single-forward call contract
+    with q.mc_context(1, g["meta"]["philox_seed"], 1):
+        p1 = m(x)
+    np.testing.assert_allclose(p1.cpu().numpy(), g["probs"][1], rtol=RTOL, atol=1e-8)
+
+
+def test_full_size_against_oracle_and_properties(golden_w8):
+    """BASELINE config 3 shape (B=256): one sample against the CPU oracle bit-for-bit on the logits path, and
+    size-independent properties: chunking / sharding invariance, batch-permutation equivariance, determinism."""
+    import quantised_bayesian_nets_amd as q
+    from oracle import oracle as orc
+    g = golden_w8
+    m = _model(g)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(256, 3, 32, 32, generator=gen)
+    xc = x.cuda()
+    S, seed = 6, 3
+    with q.mc_context(S, seed, 0):
+        rec = {}
+        probs = m.forward_mc(xc, record=rec)
+    net = orc.Int8ResNetOracle(g["state"], 7, 8)
+    orec = {}
+    p_or = net.forward(x.numpy(), seed, 4, record=orec)
+    for k in ["layers.0.out", "layers.3.1.out", "layers.4.0.out", "layers.5.1.out", "layers.6.1.out"]:
+        kk = k if k.startswith("layers.0") else k
+        ok = orec["layers.0.out"] if k == "layers.0.out" else orec[k]
+        assert np.array_equal(rec[kk][4].cpu().numpy(), ok), k
+    np.testing.assert_allclose(probs[4].cpu().numpy(), p_or, rtol=RTOL, atol=1e-8)
+    # probabilities are normalised
+    np.testing.assert_allclose(probs.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
+    # chunking / sharding invariance: samples [0,6) in one launch == [0,2) + [2,6)
+    with q.mc_context(2, seed, 0):
+        pa = m.forward_mc(xc)
+    with q.mc_context(4, seed, 2):
+        pb = m.forward_mc(xc)
+    assert torch.equal(torch.cat([pa, pb]), probs)
+    # determinism
+    with q.mc_context(S, seed, 0):
+        assert torch.equal(m.forward_mc(xc), probs)
+    # batch permutation equivariance (each image is independent given the sample's weights)
+    perm = torch.randperm(256, generator=gen)
+    with q.mc_context(S, seed, 0):
+        pp = m.forward_mc(xc[perm.cuda()])
+    assert torch.equal(pp, probs[:, perm.cuda()])
+    # ragged batch (not a multiple of the per-workgroup image group)
+    with q.mc_context(2, seed, 0):
+        pr = m.forward_mc(xc[:37])
+    assert torch.equal(pr, probs[:2, :37])
+    # mc_predict == mean over samples, chunked or not
+    mean = q.mc_predict(m, xc, S, seed)
+    mean_c = q.mc_predict(m, xc, S, seed, chunk=4)
+    np.testing.assert_allclose(mean.cpu().numpy(), probs.mean(0).cpu().numpy(), rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(mean_c.cpu().numpy(), mean.cpu().numpy(), rtol=RTOL, atol=1e-8)
+
+
+def test_errors_are_loud():
+    from quantised_bayesian_nets_amd import _lib
+    d = _lib.ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.pad, d.a_hi = 1, 7, 7, 5, 9, 3, 1, 1, 127
+    d.s_x = d.s_w = d.s_y = 1.0
+    t = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    rc = _lib.lib().qbnn_conv2d_i8_mc(_lib.ptr(t), 0, _lib.ptr(t), 0, None, None, 0, _lib.ptr(t), 0, 1, C.byref(d), _lib.current_stream())
+    assert rc < 0 and b"unsupported geometry" in _lib.lib().qbnn_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.check(rc)
