@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: MC forward samples/sec, ResNet-18 BBB int8 (A7/W8), batch 256 (BASELINE.json).
+
+One step = one pass of the Monte-Carlo evaluation over one batch: S stochastic forwards of the same 256 CIFAR-shaped
+images (weight sampling + 20 int8 convs + head per sample) reduced to predictive moments.  With N GPUs every rank
+evaluates `--samples` samples (weak scaling: global S = N * samples, Philox subsequence = global sample index) and the
+[2,B,C] partial moments are summed with one RCCL all-reduce per step.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--samples S] [--batch B]
+  (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the one with the largest share of GPU time in
+the timed region), measured with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (a port of the
+reference algorithm, bit-identical to it on the golden vectors) on this host's cores over a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_I8_PEAK_TOPS = 5000.0   # int8 dense = 2x bf16 (2.5 PF)
+
+
+def conv_algorithmic_bytes(S, B, H, Cin, Cout, ks, stride, nweights):
+    """SURVEY.md 8(d) byte model: each conv reads its input and writes its output once (1 B/element) and reads its
+    parameters (mu_q, sigma_q: 2 B/weight) once per sample."""
+    Ho = H // stride
+    return S * (B * (H * H * Cin + Ho * Ho * Cout) + 2 * nweights)
+
+
+def conv_ops(S, B, H, Cin, Cout, ks, stride):
+    Ho = H // stride
+    return 2 * S * B * Ho * Ho * Cout * Cin * ks * ks
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=100, help="MC samples per GPU per step (BASELINE config 3: 100)")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--w-bits", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=0, help="oracle samples to time (0 = auto, about 10-30 s)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import quantised_bayesian_nets_amd as q
+    from quantised_bayesian_nets_amd import layers as qlayers
+    from conftest import load_golden
+
+    g = load_golden(f"resnet_bbb_a7w{a.w_bits}.npz")   # random-init, calibrated, converted int8 conv_resnet_bbb
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=a.w_bits)
+    model = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args).load_reference_state(g["state"])
+    gen = torch.Generator().manual_seed(2)
+    x_host = torch.randn(a.batch, 3, 32, 32, generator=gen)     # synthetic CIFAR-shaped, normalised
+    x = x_host.cuda()
+    S_local, S_global, seed = a.samples, a.samples * world, 3
+
+    def step():
+        return q.mc_predict(model, x, S_global, seed, return_var=True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    qlayers.PROFILE = prof = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        mean, var = step()
+    fence()
+    dt = time.perf_counter() - t0
+    qlayers.PROFILE = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # ---- per-kernel times from the HIP events recorded around each launch in the timed region
+    agg = {}
+    for key, meta, e0, e1 in prof:
+        d = agg.setdefault(key, dict(ms=0.0, n=0, meta=meta))
+        d["ms"] += e0.elapsed_time(e1)
+        d["n"] += 1
+    total_ms = sum(d["ms"] for d in agg.values())
+    roof = None
+    conv_keys = [k for k in agg if k.startswith("conv")]
+    if conv_keys:
+        dom = max(conv_keys, key=lambda k: agg[k]["ms"])
+        d = agg[dom]
+        m = d["meta"]
+        avg_s = d["ms"] / d["n"] * 1e-3
+        abytes = conv_algorithmic_bytes(S_local, a.batch, m["H"], m["Cin"], m["Cout"], m["ks"], m["stride"], m["nweights"])
+        ops = conv_ops(S_local, a.batch, m["H"], m["Cin"], m["Cout"], m["ks"], m["stride"])
+        gbs = abytes / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_s * 1e3, 4), "launches": d["n"], "share_of_gpu_time": round(d["ms"] / total_ms, 3),
+                "algorithmic_bytes_per_launch": abytes,
+                "mfma_achieved_tops": round(ops / avg_s / 1e12, 1), "mfma_frac_of_i8_peak": round(ops / avg_s / 1e12 / MFMA_I8_PEAK_TOPS, 4)}
+    kernels = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["n"] // a.steps} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+
+    # ---- whole-path roofline view (layer-granular byte model of SURVEY 8(d): 126.66 MB / sample at B=256, int8)
+    value = S_global * a.steps / dt
+    bytes_per_sample = 126.66e6 * a.batch / 256
+    path = {"algorithmic_GBps_per_gpu": round(value / world * bytes_per_sample / 1e9, 1),
+            "frac_of_hbm_peak": round(value / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4),
+            "int8_TOPS_per_gpu": round(value / world * 40.203e9 * a.batch / 256 / 1e12, 1)}
+
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        from oracle import oracle as orc
+        net = orc.Int8ResNetOracle(g["state"], 7, a.w_bits)
+        xn = x_host.numpy()
+        t = time.perf_counter()
+        p_or = net.forward(xn, seed, 0)
+        one = time.perf_counter() - t
+        n_cpu = a.cpu_samples or max(1, min(8, int(15.0 / max(one, 1e-3))))
+        t = time.perf_counter()
+        for s in range(1, 1 + n_cpu):
+            net.forward(xn, seed, s)
+        el = time.perf_counter() - t
+        cpu = {"value": round(n_cpu / el, 4), "unit": "MC samples/s", "cores": orc.lib().qbo_num_threads(), "kind": "port",
+               "sample": f"{n_cpu} MC samples of the same batch ({a.batch} images) through oracle/qbnn_oracle.c (OpenMP), after 1 warm-up sample",
+               "host_cpus": os.cpu_count()}
+        # the oracle's sample 0 doubles as an in-run parity check of the GPU result
+        with q.mc_context(1, seed, 0):
+            p_gpu = model.forward_mc(x)[0].cpu().numpy()
+        cpu["gpu_matches_oracle_sample0"] = bool(np.allclose(p_gpu, p_or, rtol=1e-5, atol=1e-8))
+
+    if rank == 0:
+        out = {"metric": "MC forward samples/sec, ResNet-18 BBB int8 batch=256", "value": round(value, 2), "unit": "MC samples/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+               "config": {"workload": "configs[2]: CIFAR-10-shaped ResNet-18 (24/48/96/192) Bayes-by-backprop, A7/W%d int8, "
+                                      "%d MC samples per GPU per step, batch=%d" % (a.w_bits, S_local, a.batch),
+                          "samples_per_gpu": S_local, "global_samples": S_global, "batch": a.batch,
+                          "image_samples_per_s": round(value * a.batch, 1), "parallelism": f"mc-sample-shard x{world}"},
+               "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "kernels": kernels}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,22 @@ from .quant import INT_BOUNDS, UINT_BOUNDS, make_sample_params
 
 LAYOUT_MFMA32, LAYOUT_ROWMAJOR = 0, 1
 
+# bench.py sets this to a list: every kernel launch then appends (key, meta, start_event, end_event), HIP events
+# recorded on the launch stream (torch's current stream).
+PROFILE = None
+
+
+@contextlib.contextmanager
+def timed(key, meta=None):
+    if PROFILE is None:
+        yield
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    yield
+    e1.record()
+    PROFILE.append((key, meta, e0, e1))
+
 
 # ------------------------------------------------------------------ MC context
 class _MCState:
@@ -204,9 +220,10 @@ class _BBBInt8(nn.Module):
         if eps is not None:
             eps = eps.to(device=device, dtype=torch.float32).contiguous()
             assert eps.numel() == S * pk["cout"] * pk["k"]
-        _lib.check(_lib.lib().qbnn_sample_weights_i8(_lib.ptr(pk["mu"]), _lib.ptr(pk["sigma"]), pk["cout"], pk["k"], self.layout,
-                                                     C.byref(pk["sp"]), seed, self.layer_id, sb, S, _lib.ptr(eps),
-                                                     _lib.ptr(w), pk["nbytes"], _stream()))
+        with timed("sample_weights_i8"):
+            _lib.check(_lib.lib().qbnn_sample_weights_i8(_lib.ptr(pk["mu"]), _lib.ptr(pk["sigma"]), pk["cout"], pk["k"], self.layout,
+                                                         C.byref(pk["sp"]), seed, self.layer_id, sb, S, _lib.ptr(eps),
+                                                         _lib.ptr(w), pk["nbytes"], _stream()))
         return w
 
     def _a_hi(self):
@@ -273,9 +290,12 @@ class Conv2d(_BBBInt8):
             d.s_o, d.z_o = add_qparams
             res_ss = residual.sample_stride()
             assert residual.data.shape[1:] == y.shape[1:]
-        _lib.check(_lib.lib().qbnn_conv2d_i8_mc(_lib.ptr(xin), xss, _lib.ptr(w), w.shape[1], _lib.ptr(pk["bias"]),
-                                                _lib.ptr(None if residual is None else residual.data), res_ss,
-                                                _lib.ptr(y), y[0].numel(), S, C.byref(d), _stream()))
+        key = "conv_i8 %dx%d %d->%d k%d s%d%s" % (H, W, Cin, self.out_channels, ks, st, " +res" if residual is not None else "")
+        meta = dict(H=H, Cin=Cin, Cout=self.out_channels, ks=ks, stride=st, nweights=pk["cout"] * pk["k"])
+        with timed(key, meta):
+            _lib.check(_lib.lib().qbnn_conv2d_i8_mc(_lib.ptr(xin), xss, _lib.ptr(w), w.shape[1], _lib.ptr(pk["bias"]),
+                                                    _lib.ptr(None if residual is None else residual.data), res_ss,
+                                                    _lib.ptr(y), y[0].numel(), S, C.byref(d), _stream()))
         if residual is not None:
             return MCQTensor(y, add_qparams[0], add_qparams[1])
         return MCQTensor(y, self.scale, self.zero_point)

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .layers import mc_context
+from .layers import mc_context, timed
 
 
 def shard_samples(samples, rank, world_size):
@@ -27,8 +27,9 @@ def reduce_moments(probs, accumulate_into=None):
     S = probs.shape[0]
     n = probs[0].numel()
     mom = accumulate_into if accumulate_into is not None else torch.empty((2,) + tuple(probs.shape[1:]), dtype=torch.float32, device=probs.device)
-    _lib.check(_lib.lib().qbnn_reduce_moments(_lib.ptr(probs.contiguous()), S, n, int(accumulate_into is not None), _lib.ptr(mom),
-                                              _lib.current_stream()))
+    with timed("reduce_moments"):
+        _lib.check(_lib.lib().qbnn_reduce_moments(_lib.ptr(probs.contiguous()), S, n, int(accumulate_into is not None), _lib.ptr(mom),
+                                                  _lib.current_stream()))
     return mom
 
 

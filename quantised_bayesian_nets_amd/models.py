@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .layers import Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_context
+from .layers import Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_context, timed
 from .quant import UINT_BOUNDS, check_bits
 
 
@@ -142,8 +142,9 @@ class ConvNetwork_ResNet(nn.Module):
         B, Cc, H, W = x.shape
         out = torch.empty((1, B, H, W, Cc), dtype=torch.uint8, device=x.device)
         a_hi = UINT_BOUNDS[self.args.activation_precision][1]
-        _lib.check(_lib.lib().qbnn_quantize_input_nchw(_lib.ptr(x), B, Cc, H, W, self.quant.scale, self.quant.zero_point, a_hi,
-                                                       _lib.ptr(out), _lib.current_stream()))
+        with timed("quantize_input"):
+            _lib.check(_lib.lib().qbnn_quantize_input_nchw(_lib.ptr(x), B, Cc, H, W, self.quant.scale, self.quant.zero_point, a_hi,
+                                                           _lib.ptr(out), _lib.current_stream()))
         return MCQTensor(out, self.quant.scale, self.quant.zero_point, shared=True)
 
     def forward_mc(self, x, record=None):
@@ -158,7 +159,8 @@ class ConvNetwork_ResNet(nn.Module):
         if Cc != 3 or H != 32 or W != 32:
             raise NotImplementedError("conv_resnet_bbb expects 3x32x32 inputs")
         col = torch.empty((B, H * W, 32), dtype=torch.int8, device=dev)
-        _lib.check(L.qbnn_im2col3x3_c3(_lib.ptr(xq.data), B, H, W, xq.zero_point, _lib.ptr(col), _lib.current_stream()))
+        with timed("im2col3x3_c3"):
+            _lib.check(L.qbnn_im2col3x3_c3(_lib.ptr(xq.data), B, H, W, xq.zero_point, _lib.ptr(col), _lib.current_stream()))
         l0 = self.layers[0]
         h = l0._conv(xq, l0.sample_weights(dev), S, im2col=col)
         if record is not None:
@@ -178,8 +180,9 @@ class ConvNetwork_ResNet(nn.Module):
         d.s_w, d.z_w = fc.add_weight.scale, fc.add_weight.zero_point
         d.s_y, d.z_y = fc.scale, fc.zero_point
         d.a_hi, d.has_bias = UINT_BOUNDS[self.args.activation_precision][1], int(pk["bias"] is not None)
-        _lib.check(L.qbnn_head_i8_mc(_lib.ptr(h.data), h.sample_stride(), _lib.ptr(wfc), wfc.shape[1], _lib.ptr(pk["bias"]),
-                                     _lib.ptr(probs), S, C.byref(d), _lib.current_stream()))
+        with timed("head_i8"):
+            _lib.check(L.qbnn_head_i8_mc(_lib.ptr(h.data), h.sample_stride(), _lib.ptr(wfc), wfc.shape[1], _lib.ptr(pk["bias"]),
+                                         _lib.ptr(probs), S, C.byref(d), _lib.current_stream()))
         return probs
 
     def forward(self, x):
