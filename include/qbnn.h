@@ -52,12 +52,14 @@ typedef struct qbnn_sample_params {
   int32_t w_lo, w_hi;      /* INT_BOUNDS[weight_precision], src/utils.py:19-20            */
 } qbnn_sample_params;
 
-/* Bytes of one sample's weights for a [cout][k] layer in `layout`. */
-size_t qbnn_packed_weight_bytes(int32_t cout, int32_t k, int32_t layout);
+/* Bytes of one sample's weights for a [cout][k] layer in `layout`.
+ * QBNN_LAYOUT_MFMA32 (see csrc/qbnn_kernels.hip "Packed weight layout"): k = rows * krow, every kernel row of
+ * krow = KW*Cin bytes is padded to a multiple of 32; a ragged cout (cout % 32 != 0) carries an extra all-ones row. */
+size_t qbnn_packed_weight_bytes(int32_t cout, int32_t k, int32_t krow, int32_t layout);
 
 /* Host helper: pack a logical int8 [cout][k] matrix (OHWI flattening of the reference's OIHW
  * weight: k = (kh*KW + kw)*Cin + c) into `layout`.  Pad entries are written as 0. */
-int qbnn_pack_weights_host(const int8_t* host_src, int32_t cout, int32_t k, int32_t layout, int8_t* host_dst);
+int qbnn_pack_weights_host(const int8_t* host_src, int32_t cout, int32_t k, int32_t krow, int32_t layout, int8_t* host_dst);
 
 /* Fused MC-batched weight sampler.  Replaces, per layer and per MC sample, the chain
  * normal_() -> quantize_per_tensor -> quantized::mul -> quantized::add -> clamp_weight
@@ -67,7 +69,7 @@ int qbnn_pack_weights_host(const int8_t* host_src, int32_t cout, int32_t k, int3
  *     philox4x32_10(ctr = {i >> 2, layer_id, sample_begin + s, 0}, key = seed)[i & 3]
  *   unless eps_in != NULL: then eps_in[s * cout * k + i] (fp32) is used (parity mode).
  *   w_out + s * w_sample_stride receives sample s in `layout`. */
-int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* sigma_packed, int32_t cout, int32_t k,
+int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* sigma_packed, int32_t cout, int32_t k, int32_t krow,
                            int32_t layout, const qbnn_sample_params* host_params, uint64_t seed,
                            uint32_t layer_id, uint32_t sample_begin, int32_t n_samples, const float* eps_in,
                            int8_t* w_out, int64_t w_sample_stride, void* stream);
@@ -95,6 +97,24 @@ typedef struct qbnn_conv_desc {
 int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w_packed, int64_t w_sample_stride,
                       const float* bias, const uint8_t* res, int64_t res_sample_stride, uint8_t* y,
                       int64_t y_sample_stride, int32_t n_samples, const qbnn_conv_desc* host_desc, void* stream);
+
+/* A chain of 1 or 2 identity BasicBlocks (models_bbb.py:170-183, no shortcut conv) fused in one persistent kernel:
+ *   per block: stem.0 ConvReLU2d -> clamp -> stem.3 Conv2d -> clamp -> Add(block input) -> clamp -> ReLU -> clamp.
+ * Activations stay in LDS between the convs; HBM traffic is one read of x and one write of y per image.
+ * Same results as the corresponding sequence of qbnn_conv2d_i8_mc calls. */
+typedef struct qbnn_block_desc {
+  const int8_t* w_a; int64_t w_a_sample_stride; const float* bias_a;   /* stem.0 sampled weights (MFMA32 layout), bias */
+  float s_wa; int32_t z_wa;                                            /* stem.0 add_weight.scale / zero_point        */
+  float s_a; int32_t z_a;                                              /* stem.0 output qparams                       */
+  const int8_t* w_b; int64_t w_b_sample_stride; const float* bias_b;   /* stem.3                                      */
+  float s_wb; int32_t z_wb;
+  float s_b; int32_t z_b;
+  float s_o; int32_t z_o;                                              /* add.add.scale / zero_point                  */
+} qbnn_block_desc;
+
+int qbnn_block_chain_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x, int32_t z_x, int32_t B, int32_t H,
+                           int32_t C, int32_t a_hi, const qbnn_block_desc* host_blocks, int32_t n_blocks, uint8_t* y,
+                           int64_t y_sample_stride, int32_t n_samples, void* stream);
 
 /* QuantStub + clamp_activation (models_bbb.py:227-229): fp32 NCHW -> uint8 NHWC. */
 int qbnn_quantize_input_nchw(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, float scale,

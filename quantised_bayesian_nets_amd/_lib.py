@@ -30,6 +30,14 @@ class ConvDesc(C.Structure):
                 ("x_is_centered_im2col", C.c_int32)]
 
 
+class BlockDesc(C.Structure):
+    _fields_ = [("w_a", C.c_void_p), ("w_a_sample_stride", C.c_int64), ("bias_a", C.c_void_p),
+                ("s_wa", C.c_float), ("z_wa", C.c_int32), ("s_a", C.c_float), ("z_a", C.c_int32),
+                ("w_b", C.c_void_p), ("w_b_sample_stride", C.c_int64), ("bias_b", C.c_void_p),
+                ("s_wb", C.c_float), ("z_wb", C.c_int32), ("s_b", C.c_float), ("z_b", C.c_int32),
+                ("s_o", C.c_float), ("z_o", C.c_int32)]
+
+
 class HeadDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("k", C.c_int32), ("C", C.c_int32), ("N", C.c_int32),
                 ("s_x", C.c_float), ("z_x", C.c_int32),
@@ -39,6 +47,7 @@ class HeadDesc(C.Structure):
 
 
 EXPORTS = ["qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_conv2d_i8_mc",
+           "qbnn_block_chain_i8_mc",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_head_i8_mc", "qbnn_reduce_moments",
            "qbnn_last_error", "qbnn_version"]
 
@@ -57,11 +66,12 @@ def lib():
         L = C.CDLL(path)
         L.qbnn_last_error.restype = C.c_char_p
         L.qbnn_packed_weight_bytes.restype = C.c_size_t
-        L.qbnn_packed_weight_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+        L.qbnn_packed_weight_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         vp, i32, i64, u32, u64, f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
-        L.qbnn_pack_weights_host.argtypes = [vp, i32, i32, i32, vp]
-        L.qbnn_sample_weights_i8.argtypes = [vp, vp, i32, i32, i32, C.POINTER(SampleParams), u64, u32, u32, i32, vp, vp, i64, vp]
+        L.qbnn_pack_weights_host.argtypes = [vp, i32, i32, i32, i32, vp]
+        L.qbnn_sample_weights_i8.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(SampleParams), u64, u32, u32, i32, vp, vp, i64, vp]
         L.qbnn_conv2d_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, C.POINTER(ConvDesc), vp]
+        L.qbnn_block_chain_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(BlockDesc), i32, vp, i64, i32, vp]
         L.qbnn_quantize_input_nchw.argtypes = [vp, i32, i32, i32, i32, f, i32, i32, vp, vp]
         L.qbnn_im2col3x3_c3.argtypes = [vp, i32, i32, i32, i32, vp, vp]
         L.qbnn_head_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i32, C.POINTER(HeadDesc), vp]

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/qbnn.h"
 #include "qbnn_rng.cuh"
@@ -36,27 +37,49 @@ QBNN_EXPORT const char* qbnn_last_error(void) { return g_err; }
 QBNN_EXPORT int qbnn_version(void) { return 1; }
 
 // =====================================================================================
-// Packed weight layout (QBNN_LAYOUT_MFMA32): the B operand of v_mfma_i32_32x32x32_i8.
-//   tile (nt, ks) covers output channels [32 nt, 32 nt + 32) and k in [32 ks, 32 ks + 32)
-//   lane l of the wave holds, as 16 consecutive bytes, W[n = 32 nt + (l & 31)][k = 32 ks + 16 (l >> 5) + j]
-//   byte offset = ((nt * KS + ks) * 64 + l) * 16 + j ; pad entries (n >= cout or k >= K) are 0.
+// Packed weight layout (QBNN_LAYOUT_MFMA32): the weight operand of v_mfma_i32_32x32x32_i8.
+//   logical matrix [cout][k], k = kh * krow + j, j = kw * Cin + c  (krow = KW * Cin bytes per kernel row)
+//   packed K axis: every kernel row is padded to RBP = roundup32(krow) bytes: kp = kh * RBP + j   (pads are 0), so
+//       that inside a row the activation bytes of one k-step are 32 contiguous LDS bytes (immediate offsets);
+//   tile (nt, ks) covers output channels [32 nt, 32 nt + 32) and kp in [32 ks, 32 ks + 32);
+//   lane l of the wave holds, as 16 consecutive bytes, W[n = 32 nt + (l & 31)][kp = 32 ks + 16 (l >> 5) + b];
+//   byte offset = ((nt * KS + ks) * 64 + l) * 16 + b.
+//   Ragged cout (cout % 32 != 0): row n = cout is the "ones row" (1 at every valid k, 0 at pads); the MFMA then
+//       delivers the activation window sum R in that output row for free.
 // =====================================================================================
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-QBNN_EXPORT size_t qbnn_packed_weight_bytes(int32_t cout, int32_t k, int32_t layout) {
-  if (layout == QBNN_LAYOUT_ROWMAJOR) return ((size_t)cout * k + 15) / 16 * 16;
-  return (size_t)ceil_div(cout, 32) * ceil_div(k, 32) * 1024;
+struct PackGeom { int cout, k, krow, rows, rbp, kp, KS, NT; };
+static inline PackGeom pack_geom(int cout, int k, int krow) {
+  PackGeom g;
+  g.cout = cout; g.k = k; g.krow = krow; g.rows = k / krow; g.rbp = ceil_div(krow, 32) * 32;
+  g.kp = g.rows * g.rbp; g.KS = g.kp / 32; g.NT = ceil_div(cout, 32);
+  return g;
 }
 
-QBNN_EXPORT int qbnn_pack_weights_host(const int8_t* src, int32_t cout, int32_t k, int32_t layout, int8_t* dst) {
+QBNN_EXPORT size_t qbnn_packed_weight_bytes(int32_t cout, int32_t k, int32_t krow, int32_t layout) {
+  if (layout == QBNN_LAYOUT_ROWMAJOR) return ((size_t)cout * k + 15) / 16 * 16;
+  if (krow <= 0 || k % krow) return 0;
+  const PackGeom g = pack_geom(cout, k, krow);
+  return (size_t)g.NT * g.KS * 1024;
+}
+
+QBNN_EXPORT int qbnn_pack_weights_host(const int8_t* src, int32_t cout, int32_t k, int32_t krow, int32_t layout, int8_t* dst) {
   if (!src || !dst || cout <= 0 || k <= 0) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: bad argument%s");
-  memset(dst, 0, qbnn_packed_weight_bytes(cout, k, layout));
-  if (layout == QBNN_LAYOUT_ROWMAJOR) { memcpy(dst, src, (size_t)cout * k); return QBNN_OK; }
-  const int KS = ceil_div(k, 32);
-  for (int n = 0; n < cout; ++n)
+  if (layout == QBNN_LAYOUT_ROWMAJOR) {
+    memset(dst, 0, qbnn_packed_weight_bytes(cout, k, krow, layout));
+    memcpy(dst, src, (size_t)cout * k);
+    return QBNN_OK;
+  }
+  if (krow <= 0 || k % krow) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: k must be a multiple of krow%s");
+  const PackGeom g = pack_geom(cout, k, krow);
+  memset(dst, 0, (size_t)g.NT * g.KS * 1024);
+  const bool ones = (cout % 32) != 0;
+  for (int n = 0; n < cout + (ones ? 1 : 0); ++n)
     for (int kk = 0; kk < k; ++kk) {
-      const int nt = n >> 5, col = n & 31, ks = kk >> 5, half = (kk >> 4) & 1, j = kk & 15;
-      dst[(((size_t)nt * KS + ks) * 64 + half * 32 + col) * 16 + j] = src[(size_t)n * k + kk];
+      const int kp = (kk / krow) * g.rbp + kk % krow;
+      const int nt = n >> 5, col = n & 31, ks = kp >> 5, half = (kp >> 4) & 1, b = kp & 15;
+      dst[(((size_t)nt * g.KS + ks) * 64 + half * 32 + col) * 16 + b] = n < cout ? src[(size_t)n * k + kk] : (int8_t)1;
     }
   return QBNN_OK;
 }
@@ -85,23 +108,21 @@ __device__ __forceinline__ int sample_one(int mu_q, int sigma_q, float eps, cons
 }
 
 __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
-    const v4i* __restrict__ mu, const v4i* __restrict__ sigma, int cout, int K, int layout, int n_chunks,
-    qbnn_sample_params p, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_id, uint32_t sample_begin,
+    const v4i* __restrict__ mu, const v4i* __restrict__ sigma, int cout, int K, int krow, int rbp, int KS, int layout,
+    int n_chunks, qbnn_sample_params p, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_id, uint32_t sample_begin,
     const float* __restrict__ eps_in, int8_t* __restrict__ w_out, int64_t w_sample_stride) {
   const int chunk = blockIdx.x * 256 + threadIdx.x;
   if (chunk >= n_chunks) return;
   const int s = blockIdx.y;
-  int n, k0;
+  int n = 0, kh = 0, j0 = 0;       // MFMA32: output row, kernel row, first byte within the (padded) kernel row
   if (layout == QBNN_LAYOUT_MFMA32) {
-    const int KS = (K + 31) >> 5;
     const int lane = chunk & 63, tile = chunk >> 6;
     const int nt = tile / KS, ks = tile - nt * KS;
     n = nt * 32 + (lane & 31);
-    k0 = ks * 32 + (lane >> 5) * 16;
-  } else {
-    const int flat = chunk * 16;           // row-major [cout][K] flat index
-    n = flat / K; k0 = flat - n * K;       // may straddle rows: handled per element below
+    const int kp0 = ks * 32 + (lane >> 5) * 16;
+    kh = kp0 / rbp; j0 = kp0 - kh * rbp;
   }
+  const bool ones_row = (layout == QBNN_LAYOUT_MFMA32) && (cout & 31) && n == cout;
   const v4i m4 = mu[chunk], s4 = sigma[chunk];
   int mw[4] = {m4.x, m4.y, m4.z, m4.w}, sw[4] = {s4.x, s4.y, s4.z, s4.w};
   uint32_t ow[4] = {0u, 0u, 0u, 0u};
@@ -113,8 +134,9 @@ __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
     int64_t idx;
     bool valid;
     if (layout == QBNN_LAYOUT_MFMA32) {
-      valid = (n < cout) && (k0 + j < K);
-      idx = (int64_t)n * K + k0 + j;
+      valid = (n < cout) && (j0 + j < krow);
+      idx = (int64_t)n * K + kh * krow + j0 + j;
+      if (ones_row && j0 + j < krow) ow[j >> 2] |= 1u << (8 * (j & 3));
     } else {
       idx = (int64_t)chunk * 16 + j;
       valid = idx < total;
@@ -143,20 +165,23 @@ __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
 }
 
 QBNN_EXPORT int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* sigma_packed, int32_t cout, int32_t k,
-                                       int32_t layout, const qbnn_sample_params* hp, uint64_t seed, uint32_t layer_id,
-                                       uint32_t sample_begin, int32_t n_samples, const float* eps_in, int8_t* w_out,
-                                       int64_t w_sample_stride, void* stream) {
+                                       int32_t krow, int32_t layout, const qbnn_sample_params* hp, uint64_t seed,
+                                       uint32_t layer_id, uint32_t sample_begin, int32_t n_samples, const float* eps_in,
+                                       int8_t* w_out, int64_t w_sample_stride, void* stream) {
   if (!mu_packed || !sigma_packed || !hp || !w_out || cout <= 0 || k <= 0 || n_samples <= 0)
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: bad argument%s");
   if (layout != QBNN_LAYOUT_MFMA32 && layout != QBNN_LAYOUT_ROWMAJOR)
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: unknown layout%s");
-  const size_t bytes = qbnn_packed_weight_bytes(cout, k, layout);
+  if (layout == QBNN_LAYOUT_MFMA32 && (krow <= 0 || k % krow))
+    return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: k must be a multiple of krow%s");
+  const size_t bytes = qbnn_packed_weight_bytes(cout, k, krow, layout);
   if ((size_t)w_sample_stride < bytes || (w_sample_stride & 15))
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: w_sample_stride too small or not 16-byte aligned%s");
   const int n_chunks = (int)(bytes / 16);
+  PackGeom g = pack_geom(cout, k, layout == QBNN_LAYOUT_MFMA32 ? krow : k);
   dim3 grid(ceil_div(n_chunks, 256), n_samples);
   hipLaunchKernelGGL(sample_weights_i8_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                     (const v4i*)mu_packed, (const v4i*)sigma_packed, cout, k, layout, n_chunks, *hp,
+                     (const v4i*)mu_packed, (const v4i*)sigma_packed, cout, k, g.krow, g.rbp, g.KS, layout, n_chunks, *hp,
                      (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out, w_sample_stride);
   return check_launch("qbnn_sample_weights_i8");
 }
@@ -164,35 +189,39 @@ QBNN_EXPORT int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* si
 // =====================================================================================
 // int8 implicit-GEMM convolution on v_mfma_i32_32x32x32_i8, whole images resident in LDS.
 //
-//   GEMM view: M = G images * HO*HO output pixels, N = COUT, K = KSZ*KSZ*CIN in (kh,kw,c) order.
-//   A (activations): the workgroup stages G centred images x' = x_q - z_x (int8, zero halo) in LDS;
-//       because (kw,c) is contiguous in NHWC, the K axis of one output pixel is KSZ runs of
-//       KSZ*CIN bytes; a lane's 16-byte A fragment is two 8-byte pieces addressed independently.
-//   B (weights): pre-packed fragments streamed from L2 (qbnn_sample_weights_i8 wrote them).
-//   acc = sum x' * W_q ;  sum x' (W_q - z_w) = acc - z_w * R,  R = window sum of x' (dot4 on the A
-//       fragments the wave already holds).
-//   Epilogue: FBGEMM requantisation + clamp_activation (+ residual quantized::add + ReLU), written
-//       to an LDS staging tile and stored to HBM as full 16-byte lines.
+//   GEMM view: D[channel][pixel] = sum_k W[channel][k] * X'[k][pixel]
+//       A operand = sampled weights (rows = output channels), pre-packed fragments streamed from L2;
+//       B operand = activations: the workgroup stages G centred images x' = x_q - z_x (int8, zero halo) in LDS;
+//           K is ordered (kh,kw,c), so with NHWC tiles the K axis of one output pixel is KSZ runs of KSZ*CIN
+//           contiguous bytes; a lane's 16-byte fragment is two independently addressed 8-byte pieces.
+//   Result layout: lane l owns pixel (l & 31) of the 32-pixel tile and, in registers 4g..4g+3, the four consecutive
+//       channels 8g + 4(l>>5) + {0..3}: one dword of NHWC output per register group.
+//   sum x' (W_q - z_w) = acc - z_w * R, R = window sum of x' = dot4 over the fragments the lane already holds
+//       (+ the other k-half from lane l^32).
+//   Epilogue functors implement FBGEMM requantisation + clamp_activation (+ quantized::add + ReLU) and write packed
+//       dwords either to a dense quint8 staging buffer (stored to HBM as full 16-byte lines) or, centred, into the
+//       halo'd LDS tile that feeds the next conv of a fused block.
 // =====================================================================================
-struct ConvArgs {
-  const uint8_t* x; int64_t x_ss;
-  const int8_t* w; int64_t w_ss;
-  const float* bias;
-  const uint8_t* res; int64_t res_ss;
-  uint8_t* y; int64_t y_ss;
-  int B;
-  int z_x, z_w, z_y, lo, a_hi;
-  float rcp, mult;
-  // residual add
-  float s_y, nzs_y, s_r, nzs_r, inv_s_o;
-  int z_o;
+struct QConv {             // one conv layer's scalars (by value in kernel arguments)
+  const int8_t* w; int64_t w_ss;   // sampled weights: base, per-MC-sample stride
+  const float* bias;               // fp32 [COUT] or null
+  int z_x, z_w, z_y;
+  float rcp, mult;                 // FBGEMM act_times_w_rcp, output multiplier
+  float vlo, vhi;                  // clamp of v = xf*mult before rounding: lo - z_y, min(255, a_hi) - z_y
+  float s_y, nzs_y;                // output qparams as a quantized::add operand
+};
+struct QAdd {              // BasicBlock Add + ReLU (models_bbb.py:179-182)
+  float s_r, nzs_r; int z_r;       // residual operand qparams
+  float inv_s_o; int z_o;          // add output qparams
+  float vhi;                       // min(255, a_hi) - z_o ; lower bound is 0 (ReLU: q >= z_o)
 };
 
-template <int CIN_, int COUT_, int KSZ_, int STRIDE_, int HIN_, int HALO_, int G_, int MB_, int NB_, bool PRESUB_>
+#define QBNN_MAGIC 12582912.0f     // 1.5 * 2^23: (v + MAGIC) has rne(v) in its low mantissa bits for |v| < 2^22
+
+template <int CIN_, int COUT_, int KSZ_, int STRIDE_, int HIN_, int HALO_, int G_, int MB_, int NB_>
 struct ConvCfg {
   static constexpr int CIN = CIN_, COUT = COUT_, KSZ = KSZ_, STRIDE = STRIDE_, HIN = HIN_, HALO = HALO_;
   static constexpr int G = G_, MB = MB_, NB = NB_;
-  static constexpr bool PRESUB = PRESUB_;
   static constexpr int PAD = (KSZ - 1) / 2;
   static constexpr int OFF0 = HALO - PAD;
   static constexpr int HO = HIN / STRIDE;
@@ -200,96 +229,138 @@ struct ConvCfg {
   static constexpr int PITCH = TW * CIN;
   static constexpr int TILE_BYTES = (TW * TW * CIN + 15) / 16 * 16;
   static constexpr int ROWB = HIN * CIN;                  // bytes of one image row in HBM
-  static constexpr int K = KSZ * KSZ * CIN;
-  static constexpr int PIECES = K / 8;
-  static constexpr int PPR = KSZ * CIN / 8;               // 8-byte pieces per kernel row
-  static constexpr int KS = (K + 31) / 32;
+  static constexpr int RB = KSZ * CIN;                    // bytes of one kernel row: (kw, c) contiguous in NHWC
+  static constexpr int RBP = (RB + 31) / 32 * 32;         // padded to whole 32-byte k-steps (weights are 0 there)
+  static constexpr int SPR = RBP / 32;                    // k-steps per kernel row
+  static constexpr int KS = KSZ * SPR;
+  // k-steps per unrolled chunk: the largest divisor of a kernel row that keeps <= 12 weight fragments in flight
+  static constexpr int pick_chunk() { int best = 1; for (int d = 1; d <= SPR; ++d) if (SPR % d == 0 && d * NB_ <= 12) best = d; return best; }
+  static constexpr int KCHUNK = pick_chunk();
   static constexpr int NT = (COUT + 31) / 32;
+  static constexpr bool USE_ONES = (COUT % 32) != 0;      // window sum from the packed layout's ones row
+  static constexpr int ONES_TILE = COUT / 32, ONES_REG = 4 * ((COUT % 32) / 8);
   static constexpr int M = G * HO * HO;
   static constexpr int MT = M / 32;
   static constexpr int MBLKS = MT / MB, NBLKS = NT / NB;
   static constexpr int NPASS = MBLKS * NBLKS;
   static constexpr int OUT_BYTES = (M * COUT + 15) / 16 * 16;
-  static constexpr int RSCR_BYTES = 4 * MB * 32 * 4;
-  static constexpr int LDS_BYTES = G * TILE_BYTES + OUT_BYTES + RSCR_BYTES;
-  static_assert(K % 8 == 0, "K must be a multiple of 8");
+  static constexpr int TILE_SLACK = 32;                   // the last k-step of a row over-reads < 32 bytes
   static_assert(ROWB % 16 == 0, "image rows must be 16-byte multiples");
   static_assert(M % 32 == 0 && MT % MB == 0 && NT % NB == 0, "tile blocking must divide the problem");
   static_assert((HO & (HO - 1)) == 0, "HO must be a power of two");
-  static_assert((CIN % 8) == 0, "CIN must be a multiple of 8");
-  static constexpr int piece_off(int p) { return p < PIECES ? (p / PPR) * PITCH + (p % PPR) * 8 : 0; }
-  static constexpr bool piece_valid(int p) { return p < PIECES; }
+  static_assert((CIN % 8) == 0 && (COUT % 8) == 0, "channels must be multiples of 8");
+  static_assert(COUT % 32 == 0 || NBLKS == 1, "ragged COUT needs all n-tiles (incl. the ones row) in one pass");
+  static_assert(SPR % KCHUNK == 0, "k-chunks must not straddle kernel rows");
+  // byte offset (from the lane's base) of k-step ks, and validity of the 8-byte piece `i` of k-half `h`
+  static constexpr int step_off(int ks) { return (ks / SPR) * PITCH + (ks % SPR) * 32; }
+  static constexpr bool piece_valid(int ks, int h, int i) { return (ks % SPR) * 32 + 16 * h + 8 * i < RB; }
 };
 
-// (x_q bytes) - z  for four packed bytes, no cross-byte borrow: x in [0,127], z in [0,127]
+// per-byte (x - z) for x in [0,127], z in [0,127]: no cross-byte borrow
 __device__ __forceinline__ uint32_t sub_bytes(uint32_t x, uint32_t z4) {
   return ((x | 0x80808080u) - z4) ^ 0x80808080u;
 }
+// per-byte (x' + z) for the inverse map (result in [0,127])
+__device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t z4) {
+  return ((a & 0x7f7f7f7fu) + z4) ^ (a & 0x80808080u);
+}
+// low bytes of four fp32 bit patterns -> one dword (channel c0 in byte 0)
+__device__ __forceinline__ uint32_t pack_low_bytes(float t0, float t1, float t2, float t3) {
+  const uint32_t p01 = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x0c0c0400u);
+  const uint32_t p23 = __builtin_amdgcn_perm(__float_as_uint(t3), __float_as_uint(t2), 0x04000c0cu);
+  return p01 | p23;
+}
+__device__ __forceinline__ float med3f(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 
-template <class C, bool HAS_RES>
-__global__ __launch_bounds__(256) void conv_i8_kernel(const ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* tile = smem;
-  uint8_t* outb = smem + C::G * C::TILE_BYTES;
-  int* rscr = reinterpret_cast<int*>(outb + C::OUT_BYTES);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int s = blockIdx.y;
-  const int img0 = blockIdx.x * C::G;
-
-  // ---- 1. zero the halo'd tiles (halo must read as x' = 0)
-  if (C::HALO > 0) {
-    v4i z = {0, 0, 0, 0};
-    for (int i = tid; i < C::G * C::TILE_BYTES / 16; i += 256) reinterpret_cast<v4i*>(tile)[i] = z;
-    __syncthreads();
-  }
-  // ---- 2. stage G images: HBM (16 B / lane, coalesced) -> centre -> LDS (2 x 8 B)
-  {
-    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
-    constexpr int CPR = C::ROWB / 16;                     // 16-byte chunks per image row
-    constexpr int CPI = C::HIN * CPR;                     // per image
-    const uint32_t z4 = (uint32_t)a.z_x * 0x01010101u;
-    for (int i = tid; i < C::G * CPI; i += 256) {
-      const int g = i / CPI, rem = i - g * CPI;
-      const int row = rem / CPR, within = rem - row * CPR;
-      if (img0 + g < a.B) {
-        v4i v = *reinterpret_cast<const v4i*>(xs + ((int64_t)(img0 + g) * C::HIN + row) * C::ROWB + within * 16);
-        if (!C::PRESUB) {
-          v.x = sub_bytes(v.x, z4); v.y = sub_bytes(v.y, z4); v.z = sub_bytes(v.z, z4); v.w = sub_bytes(v.w, z4);
-        }
-        uint8_t* d = tile + g * C::TILE_BYTES + (row + C::HALO) * C::PITCH + C::HALO * C::CIN + within * 16;
-        *reinterpret_cast<v2i*>(d) = v2i{v.x, v.y};
-        *reinterpret_cast<v2i*>(d + 8) = v2i{v.z, v.w};
-      }
+// zero the halo ring of G tiles of geometry (TW x TW x CH), 8-byte stores
+template <int TW, int CH, int TILE_BYTES, int G, int NTHR = 256>
+__device__ __forceinline__ void zero_halo(uint8_t* tile, int tid) {
+  constexpr int PITCH = TW * CH;
+  constexpr int ROW8 = PITCH / 8;                 // 8-byte words per full row
+  constexpr int COL8 = CH / 8;
+  constexpr int PER = 2 * ROW8 + 2 * (TW - 2) * COL8;
+  const v2i z = {0, 0};
+  for (int i = tid; i < G * PER; i += NTHR) {
+    const int g = i / PER;
+    int j = i - g * PER;
+    int off;
+    if (j < ROW8) off = j * 8;
+    else if (j < 2 * ROW8) off = (TW - 1) * PITCH + (j - ROW8) * 8;
+    else {
+      j -= 2 * ROW8;
+      const int row = 1 + j / (2 * COL8), q = j % (2 * COL8);
+      off = row * PITCH + (q < COL8 ? q * 8 : (TW - 1) * CH + (q - COL8) * 8);
     }
+    *reinterpret_cast<v2i*>(tile + g * TILE_BYTES + off) = z;
   }
-  // ---- 3. residual operand -> output staging tile (the epilogue updates it in place)
-  if (HAS_RES) {
-    const uint8_t* rs = a.res + (int64_t)s * a.res_ss;
-    constexpr int IMG_OUT = C::HO * C::HO * C::COUT;
-    for (int i = tid; i < C::M * C::COUT / 16; i += 256) {
-      const int g = (i * 16) / IMG_OUT;
-      if (img0 + g < a.B)
-        reinterpret_cast<v4i*>(outb)[i] = *reinterpret_cast<const v4i*>(rs + (int64_t)img0 * IMG_OUT + (int64_t)i * 16);
-    }
-  }
-  __syncthreads();
+}
 
-  // ---- 4. MFMA passes
+// HBM quint8 NHWC images -> centred int8 halo'd tiles in LDS (16 B / lane loads, 2 x 8 B LDS stores)
+template <class C, bool PRESUB>
+__device__ __forceinline__ void load_tiles(uint8_t* tile, const uint8_t* xs, int img0, int B, int z_x, int tid) {
+  constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR;
+  const uint32_t z4 = (uint32_t)z_x * 0x01010101u;
+  for (int i = tid; i < C::G * CPI; i += 256) {
+    const int g = i / CPI, rem = i - g * CPI;
+    const int row = rem / CPR, within = rem - row * CPR;
+    v4i v = {0, 0, 0, 0};
+    if (img0 + g < B) {
+      v = *reinterpret_cast<const v4i*>(xs + ((int64_t)(img0 + g) * C::HIN + row) * C::ROWB + within * 16);
+      if (!PRESUB) { v.x = sub_bytes(v.x, z4); v.y = sub_bytes(v.y, z4); v.z = sub_bytes(v.z, z4); v.w = sub_bytes(v.w, z4); }
+    }
+    uint8_t* d = tile + g * C::TILE_BYTES + (row + C::HALO) * C::PITCH + C::HALO * C::CIN + within * 16;
+    *reinterpret_cast<v2i*>(d) = v2i{v.x, v.y};
+    *reinterpret_cast<v2i*>(d + 8) = v2i{v.z, v.w};
+  }
+}
+
+// bias -> LDS (zeros when the layer has none: fma(0, rcp, x) == x exactly)
+template <int COUT, int NTHR = 256>
+__device__ __forceinline__ void load_bias(float* dst, const float* bias, int tid) {
+  for (int i = tid; i < COUT; i += NTHR) dst[i] = bias ? bias[i] : 0.0f;
+}
+
+// All MFMA passes of one conv over LDS-resident tiles.
+// Epilogue functor interface:  pre = epi.load(m, c0)   (residual dword or 0; issued ahead of the arithmetic)
+//                              epi.store(m, c0, v0..v3, pre)
+// with, for tile pixel m and the four consecutive output channels c0..c0+3,
+//   v = fma(bias, rcp, float(acc - z_w R)) * mult  (un-clamped, un-rounded).
+// Software pipeline: the weight and activation fragments of K-chunk kc+1 are in flight (L2 -> VGPR, LDS -> VGPR) while
+// the MFMAs of chunk kc issue; inside a chunk every offset is an immediate.
+template <class C, class Epi, int NWAVES = 4>
+__device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* wq, const float* bias_lds, const QConv& p,
+                                            Epi& epi, int wave, int lane) {
   const int r = lane & 31, h = lane >> 5;
-  const int8_t* wq = a.w + (int64_t)s * a.w_ss;
-  int* myr = rscr + wave * C::MB * 32;
-  for (int pass = wave; pass < C::NPASS; pass += 4) {
+  constexpr int U = C::KCHUNK, NCHUNK = C::KS / U;
+  struct Frags { v4i w[U][C::NB]; v4i x[U][C::MB]; };
+  for (int pass = wave; pass < C::NPASS; pass += NWAVES) {
     const int mblk = pass / C::NBLKS, nblk = pass - mblk * C::NBLKS;
-    int abase[C::MB];
+    const uint8_t* ap[C::MB];
 #pragma unroll
     for (int mb = 0; mb < C::MB; ++mb) {
       const int m = (mblk * C::MB + mb) * 32 + r;
       const int g = m / (C::HO * C::HO), rem = m % (C::HO * C::HO);
       const int oh = rem / C::HO, ow = rem % C::HO;
-      abase[mb] = g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::CIN;
+      ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::CIN + 16 * h;
     }
+    const int8_t* wbase = wq + ((int64_t)(nblk * C::NB) * C::KS * 64 + lane) * 16;
+    auto load_chunk = [&](Frags& f, int kc) {
+      const int ks0 = kc * U;
+      const int kh = ks0 / C::SPR, t0 = ks0 - kh * C::SPR;
+      const int aoff = kh * C::PITCH + t0 * 32;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+          f.w[u][nb] = *reinterpret_cast<const v4i*>(wbase + ((int64_t)(nb * C::KS + ks0 + u) * 64) * 16);
+#pragma unroll
+        for (int mb = 0; mb < C::MB; ++mb) {
+          const v2i lo = *reinterpret_cast<const v2i*>(ap[mb] + aoff + u * 32);
+          const v2i hi = *reinterpret_cast<const v2i*>(ap[mb] + aoff + u * 32 + 8);
+          f.x[u][mb] = v4i{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+    };
     v16i acc[C::MB][C::NB];
     int rsum[C::MB];
 #pragma unroll
@@ -300,117 +371,400 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0;
     }
+    auto mfma_chunk = [&](const Frags& f, int kc) {
+      const int t0 = (kc * U) % C::SPR;
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-      v4i bf[C::NB];
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (int nb = 0; nb < C::NB; ++nb)
-        bf[nb] = *reinterpret_cast<const v4i*>(wq + ((int64_t)((nblk * C::NB + nb) * C::KS + ks) * 64 + lane) * 16);
-      const int o0 = h ? C::piece_off(4 * ks + 2) : C::piece_off(4 * ks + 0);
-      const int o1 = h ? C::piece_off(4 * ks + 3) : C::piece_off(4 * ks + 1);
-      // dot4 masks: pad pieces (k >= K) hold unrelated bytes and must not enter R
-      const int m0 = h ? (C::piece_valid(4 * ks + 2) ? 0x01010101 : 0) : (C::piece_valid(4 * ks + 0) ? 0x01010101 : 0);
-      const int m1 = h ? (C::piece_valid(4 * ks + 3) ? 0x01010101 : 0) : (C::piece_valid(4 * ks + 1) ? 0x01010101 : 0);
+        for (int mb = 0; mb < C::MB; ++mb) {
+          if (!C::USE_ONES) {
+            // window sum on the fragments the lane holds; pad bytes of a ragged kernel row are unrelated data
+            const bool v0ok = (C::RB % 32 == 0) || ((t0 + u) * 32 + 16 * h + 0 < C::RB);
+            const bool v1ok = (C::RB % 32 == 0) || ((t0 + u) * 32 + 16 * h + 8 < C::RB);
+            const int m0 = v0ok ? 0x01010101 : 0, m1 = v1ok ? 0x01010101 : 0;
+            int rs_ = rsum[mb];
+            rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].x, m0, rs_, false);
+            rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].y, m0, rs_, false);
+            rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].z, m1, rs_, false);
+            rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].w, m1, rs_, false);
+            rsum[mb] = rs_;
+          }
 #pragma unroll
-      for (int mb = 0; mb < C::MB; ++mb) {
-        const v2i lo = *reinterpret_cast<const v2i*>(tile + abase[mb] + o0);
-        const v2i hi = *reinterpret_cast<const v2i*>(tile + abase[mb] + o1);
-        const v4i af = {lo.x, lo.y, hi.x, hi.y};
-        int rs_ = rsum[mb];
-        rs_ = __builtin_amdgcn_sdot4(lo.x, m0, rs_, false);
-        rs_ = __builtin_amdgcn_sdot4(lo.y, m0, rs_, false);
-        rs_ = __builtin_amdgcn_sdot4(hi.x, m1, rs_, false);
-        rs_ = __builtin_amdgcn_sdot4(hi.y, m1, rs_, false);
-        rsum[mb] = rs_;
+          for (int nb = 0; nb < C::NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[u][nb], f.x[u][mb], acc[mb][nb], 0, 0, 0);
+        }
+      }
+    };
+    // bias of this pass's channels -> registers, ahead of the K loop (LDS latency off the epilogue's critical path)
+    float4 b4[C::NB][4];
 #pragma unroll
-        for (int nb = 0; nb < C::NB; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[nb], acc[mb][nb], 0, 0, 0);
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+        b4[nb][g4] = *reinterpret_cast<const float4*>(bias_lds + (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
+      }
+    Frags f0, f1;
+    load_chunk(f0, 0);
+    if (NCHUNK <= 4) {
+      // short K (fully unrolled)
+#pragma unroll
+      for (int kc = 0; kc < NCHUNK; ++kc) {
+        Frags& cur = (kc & 1) ? f1 : f0;
+        Frags& nxt = (kc & 1) ? f0 : f1;
+        if (kc + 1 < NCHUNK) load_chunk(nxt, kc + 1);
+        mfma_chunk(cur, kc);
+      }
+    } else {
+      int kc = 0;
+#pragma unroll 1
+      while (true) {
+        if (kc + 1 < NCHUNK) load_chunk(f1, kc + 1);
+        mfma_chunk(f0, kc);
+        if (++kc >= NCHUNK) break;
+        if (kc + 1 < NCHUNK) load_chunk(f0, kc + 1);
+        mfma_chunk(f1, kc);
+        if (++kc >= NCHUNK) break;
       }
     }
-    // window sums: both k-halves, then transpose lane-row -> register-row through LDS
 #pragma unroll
     for (int mb = 0; mb < C::MB; ++mb) {
-      const int tot = rsum[mb] + __shfl_xor(rsum[mb], 32);
-      if (h == 0) myr[mb * 32 + r] = tot;
-    }
-    // ---- epilogue
-#pragma unroll
-    for (int mb = 0; mb < C::MB; ++mb) {
-      v4i rr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rr[i] = *reinterpret_cast<const v4i*>(myr + mb * 32 + 8 * i + 4 * h);
+      int R;
+      if (C::USE_ONES) {                 // output row COUT of the ones tile holds R; it lives in the h == 0 lanes
+        const int rv = acc[mb][C::ONES_TILE % C::NB][C::ONES_REG];
+        const int ro = __shfl_xor(rv, 32);
+        R = h ? ro : rv;
+      } else {
+        R = rsum[mb] + __shfl_xor(rsum[mb], 32);
+      }
+      const int zwr = p.z_w * R;
+      const int m = (mblk * C::MB + mb) * 32 + r;
 #pragma unroll
       for (int nb = 0; nb < C::NB; ++nb) {
-        const int n = (nblk * C::NB + nb) * 32 + r;
-        const bool nvalid = n < C::COUT;
-        const float bias = (a.bias && nvalid) ? a.bias[n] : 0.0f;
+        uint32_t pre[4];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          const int m = (mblk * C::MB + mb) * 32 + row;
-          const int av = acc[mb][nb][reg] - a.z_w * rr[reg >> 2][reg & 3];
-          float xf = (float)av;
-          if (a.bias) xf = __builtin_fmaf(bias, a.rcp, xf);
-          int q = a.z_y + rne_sat(xf * a.mult);
-          q = min(max(q, a.lo), 255);
-          q = min(q, a.a_hi);
-          if (nvalid) {
-            uint8_t* o = outb + m * C::COUT + n;
-            if (HAS_RES) {
-              const float da = __builtin_fmaf(a.s_y, (float)q, a.nzs_y);
-              const float db = __builtin_fmaf(a.s_r, (float)(int)(*o), a.nzs_r);
-              int q2 = min(max(a.z_o + rne_sat((da + db) * a.inv_s_o), 0), 255);
-              q2 = min(q2, a.a_hi);
-              q2 = max(q2, a.z_o);
-              q = q2;
-            }
-            *o = (uint8_t)q;
-          }
+        for (int g4 = 0; g4 < 4; ++g4) {
+          // ragged COUT (24, 48): NBLKS == 1, so nb is the tile index and this test folds at compile time
+          if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+          pre[g4] = epi.load(m, (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+          const int c0 = (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h;
+          const float4 bb = b4[nb][g4];
+          const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(acc[mb][nb][4 * g4 + 0] - zwr)) * p.mult;
+          const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(acc[mb][nb][4 * g4 + 1] - zwr)) * p.mult;
+          const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(acc[mb][nb][4 * g4 + 2] - zwr)) * p.mult;
+          const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(acc[mb][nb][4 * g4 + 3] - zwr)) * p.mult;
+          epi.store(m, c0, v0, v1, v2, v3, pre[g4]);
         }
       }
     }
   }
-  __syncthreads();
-  // ---- 5. LDS staging tile -> HBM, 16 B / lane
-  {
-    uint8_t* ys = a.y + (int64_t)s * a.y_ss;
-    constexpr int IMG_OUT = C::HO * C::HO * C::COUT;
-    for (int i = tid; i < C::M * C::COUT / 16; i += 256) {
-      const int g = (i * 16) / IMG_OUT;
-      if (img0 + g < a.B)
-        *reinterpret_cast<v4i*>(ys + (int64_t)img0 * IMG_OUT + (int64_t)i * 16) = reinterpret_cast<const v4i*>(outb)[i];
-    }
-  }
 }
 
-template <class C>
+// ---- epilogue functors -----------------------------------------------------------------------------------------
+// (a) quint8 into a dense [M][COUT] staging buffer; optional quantized::add + ReLU against the quint8 residual that
+//     already sits at the same address (updated in place).
+template <int COUT, bool HAS_RES>
+struct EpiDense {
+  uint8_t* outb; QConv p; QAdd a;
+  __device__ __forceinline__ uint32_t load(int m, int c0) const {
+    return HAS_RES ? *reinterpret_cast<const uint32_t*>(outb + m * COUT + c0) : 0u;
+  }
+  __device__ __forceinline__ void store(int m, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
+    uint32_t* o = reinterpret_cast<uint32_t*>(outb + m * COUT + c0);
+    v0 = med3f(v0, p.vlo, p.vhi); v1 = med3f(v1, p.vlo, p.vhi); v2 = med3f(v2, p.vlo, p.vhi); v3 = med3f(v3, p.vlo, p.vhi);
+    const float zy = (float)p.z_y;
+    if (!HAS_RES) {
+      // round with the (even) magic constant first, then add z_y exactly: folding an odd z_y into the constant
+      // would flip round-half-even ties
+      *o = pack_low_bytes((v0 + QBNN_MAGIC) + zy, (v1 + QBNN_MAGIC) + zy, (v2 + QBNN_MAGIC) + zy, (v3 + QBNN_MAGIC) + zy);
+    } else {
+      const float zo = (float)a.z_o;
+      float t[4];
+      const float vv[4] = {v0, v1, v2, v3};
+      const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float qf = __builtin_rintf(vv[i]) + zy;                       // the conv output integer, exactly
+        const float da = __builtin_fmaf(p.s_y, qf, p.nzs_y);
+        const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
+        t[i] = (med3f((da + db) * a.inv_s_o, 0.0f, a.vhi) + QBNN_MAGIC) + zo;
+      }
+      *o = pack_low_bytes(t[0], t[1], t[2], t[3]);
+    }
+  }
+};
+
+template <int HO, int COUT, int TILE_BYTES>
+__device__ __forceinline__ int tile_px_off(int m, int c0) {
+  const int g = m / (HO * HO), rem = m % (HO * HO), oh = rem / HO, ow = rem % HO;
+  return g * TILE_BYTES + ((oh + 1) * (HO + 2) + ow + 1) * COUT + c0;
+}
+
+// (b) centred int8 (q - z_y) into the halo'd tile feeding the next conv (geometry HO x HO x COUT, halo 1)
+template <int HO, int COUT, int TILE_BYTES>
+struct EpiTile {
+  uint8_t* dst; QConv p;
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int m, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
+    uint32_t* o = reinterpret_cast<uint32_t*>(dst + tile_px_off<HO, COUT, TILE_BYTES>(m, c0));
+    const float mg = QBNN_MAGIC;
+    *o = pack_low_bytes(med3f(v0, p.vlo, p.vhi) + mg, med3f(v1, p.vlo, p.vhi) + mg, med3f(v2, p.vlo, p.vhi) + mg,
+                        med3f(v3, p.vlo, p.vhi) + mg);
+  }
+};
+
+// (c) conv -> Add(residual) -> ReLU, residual read as centred int8 (x' = q_r - z_r) from a halo'd tile of the same
+//     geometry and overwritten in place with the centred block output (q_o - z_o).
+template <int HO, int COUT, int TILE_BYTES>
+struct EpiTileResInPlace {
+  uint8_t* xt; QConv p; QAdd a;
+  __device__ __forceinline__ uint32_t load(int m, int c0) const {
+    return *reinterpret_cast<const uint32_t*>(xt + tile_px_off<HO, COUT, TILE_BYTES>(m, c0));
+  }
+  __device__ __forceinline__ void store(int m, int c0, float v0, float v1, float v2, float v3, uint32_t rqu) const {
+    uint32_t* o = reinterpret_cast<uint32_t*>(xt + tile_px_off<HO, COUT, TILE_BYTES>(m, c0));
+    const int rq = (int)rqu;
+    const float zy = (float)p.z_y, zr = (float)a.z_r;
+    const float vv[4] = {v0, v1, v2, v3};
+    const float rf[4] = {(float)((rq << 24) >> 24) + zr, (float)((rq << 16) >> 24) + zr, (float)((rq << 8) >> 24) + zr,
+                         (float)(rq >> 24) + zr};
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float qf = __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)) + zy;
+      const float da = __builtin_fmaf(p.s_y, qf, p.nzs_y);
+      const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
+      t[i] = med3f((da + db) * a.inv_s_o, 0.0f, a.vhi) + QBNN_MAGIC;
+    }
+    *o = pack_low_bytes(t[0], t[1], t[2], t[3]);
+  }
+};
+
+// ---- single-conv kernel (layer-level C ABI entry) ---------------------------------------------------------------
+struct ConvArgs {
+  const uint8_t* x; int64_t x_ss;
+  const uint8_t* res; int64_t res_ss;
+  uint8_t* y; int64_t y_ss;
+  int B;
+  QConv p; QAdd a;
+};
+
+template <class C, bool HAS_RES, bool PRESUB>
+__global__ __launch_bounds__(256) void conv_i8_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* tile = smem;
+  uint8_t* outb = smem + C::G * C::TILE_BYTES + C::TILE_SLACK;
+  float* bias_lds = reinterpret_cast<float*>(outb + C::OUT_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.y, img0 = blockIdx.x * C::G;
+
+  if (C::HALO > 0) zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G>(tile, tid);
+  load_tiles<C, PRESUB>(tile, a.x + (int64_t)s * a.x_ss, img0, a.B, a.p.z_x, tid);
+  load_bias<C::COUT>(bias_lds, a.p.bias, tid);
+  constexpr int IMG_OUT = C::HO * C::HO * C::COUT;
+  if (HAS_RES) {
+    const uint8_t* rs = a.res + (int64_t)s * a.res_ss;
+    for (int i = tid; i < C::M * C::COUT / 16; i += 256)
+      if (img0 + (i * 16) / IMG_OUT < a.B)
+        reinterpret_cast<v4i*>(outb)[i] = *reinterpret_cast<const v4i*>(rs + (int64_t)img0 * IMG_OUT + (int64_t)i * 16);
+  }
+  __syncthreads();
+  EpiDense<C::COUT, HAS_RES> epi{outb, a.p, a.a};
+  conv_passes<C>(tile, a.p.w + (int64_t)s * a.p.w_ss, bias_lds, a.p, epi, wave, lane);
+  __syncthreads();
+  uint8_t* ys = a.y + (int64_t)s * a.y_ss;
+  for (int i = tid; i < C::M * C::COUT / 16; i += 256)
+    if (img0 + (i * 16) / IMG_OUT < a.B)
+      *reinterpret_cast<v4i*>(ys + (int64_t)img0 * IMG_OUT + (int64_t)i * 16) = reinterpret_cast<const v4i*>(outb)[i];
+}
+
+template <class C, bool PRESUB>
 static int launch_conv(const ConvArgs& a, int n_samples, bool has_res, hipStream_t st) {
-  static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
+  constexpr int LDS = C::G * C::TILE_BYTES + C::TILE_SLACK + C::OUT_BYTES + C::COUT * 4;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
   dim3 grid(ceil_div(a.B, C::G), n_samples);
   if (has_res) {
     static bool attr_r = false;
-    if (!attr_r) { hipFuncSetAttribute((const void*)conv_i8_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); attr_r = true; }
-    hipLaunchKernelGGL((conv_i8_kernel<C, true>), grid, dim3(256), C::LDS_BYTES, st, a);
+    if (!attr_r) { hipFuncSetAttribute((const void*)conv_i8_kernel<C, true, PRESUB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_r = true; }
+    hipLaunchKernelGGL((conv_i8_kernel<C, true, PRESUB>), grid, dim3(256), LDS, st, a);
   } else {
     static bool attr_n = false;
-    if (!attr_n) { hipFuncSetAttribute((const void*)conv_i8_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); attr_n = true; }
-    hipLaunchKernelGGL((conv_i8_kernel<C, false>), grid, dim3(256), C::LDS_BYTES, st, a);
+    if (!attr_n) { hipFuncSetAttribute((const void*)conv_i8_kernel<C, false, PRESUB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_n = true; }
+    hipLaunchKernelGGL((conv_i8_kernel<C, false, PRESUB>), grid, dim3(256), LDS, st, a);
   }
   return check_launch("qbnn_conv2d_i8_mc");
 }
 
-//                      CIN COUT K  S  HIN HALO G  MB NB PRESUB
-using Cfg_c0     = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1, true>;    // layers.0 on the im2col tensor (K = 27 -> 32)
-using Cfg_24_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1, false>;   // layers.3.*
-using Cfg_24_48s = ConvCfg<24, 48, 3, 2, 32, 1, 1, 2, 2, false>;   // layers.4.0.stem.0
-using Cfg_24_48p = ConvCfg<24, 48, 1, 2, 32, 1, 1, 2, 2, false>;   // layers.4.0.shortcut.0
-using Cfg_48_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2, false>;   // layers.4.*
-using Cfg_48_96s = ConvCfg<48, 96, 3, 2, 16, 1, 2, 1, 3, false>;   // layers.5.0.stem.0
-using Cfg_48_96p = ConvCfg<48, 96, 1, 2, 16, 1, 2, 1, 3, false>;   // layers.5.0.shortcut.0
-using Cfg_96_96  = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, false>;    // layers.5.*
-using Cfg_96_192s = ConvCfg<96, 192, 3, 2, 8, 1, 4, 1, 3, false>;  // layers.6.0.stem.0
-using Cfg_96_192p = ConvCfg<96, 192, 1, 2, 8, 1, 4, 1, 3, false>;  // layers.6.0.shortcut.0
-using Cfg_192_192 = ConvCfg<192, 192, 3, 1, 4, 1, 4, 1, 3, false>; // layers.6.*
+// =====================================================================================
+// Fused BasicBlock kernels (models_bbb.py:170-183): persistent workgroups, activations never leave LDS between
+// the block's convs.
+//
+//   identity chain  : NBLK x [ stem.0 (3x3, ReLU) -> stem.3 (3x3) -> Add(x) -> ReLU ]   on one X/T tile pair
+//       X tile: centred block input, overwritten in place by the centred block output (residual read + write by
+//       the same lane); T tile: centred stem.0 output.
+//   Work item = (MC sample s, group of G images).  Each workgroup walks items blockIdx.x, +gridDim.x, ... ; items
+//   of one sample are adjacent, so the sample's weight slab stays hot in every XCD's L2.  The next item's input is
+//   fetched into registers while the current one computes (issue-early / write-late), so HBM latency is off the
+//   critical path.
+// =====================================================================================
+constexpr int BLK_THREADS = 512, BLK_WAVES = 8;
+
+struct BlockParams { QConv a, b; QAdd add; };       // stem.0, stem.3, add
+
+template <int NBLK>
+struct ChainArgs {
+  const uint8_t* x; int64_t x_ss;     // block-chain input  [S][B][H][H][C] quint8
+  uint8_t* y; int64_t y_ss;           // block-chain output [S][B][H][H][C] quint8
+  int B, n_samples;
+  int z_in;                           // zero point of x
+  BlockParams blk[NBLK];
+};
+
+template <class C, int NBLK>
+__global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const ChainArgs<NBLK> a) {
+  static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
+  uint8_t* xt = smem;
+  uint8_t* tt = smem + TILES;
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * TILES);        // [NBLK][2][COUT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
+  constexpr int PER_T = (NCH + BLK_THREADS - 1) / BLK_THREADS;
+  const int groups = (a.B + C::G - 1) / C::G;
+  const int n_items = a.n_samples * groups;
+
+  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, BLK_THREADS>(xt, tid);
+  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, BLK_THREADS>(tt, tid);
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) {
+    load_bias<C::COUT, BLK_THREADS>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
+    load_bias<C::COUT, BLK_THREADS>(bias_lds + (2 * k + 1) * C::COUT, a.blk[k].b.bias, tid);
+  }
+
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = tid + j * BLK_THREADS;
+      pre[j] = v4i{0, 0, 0, 0};
+      if (i < NCH) {
+        const int g = i / CPI, rem = i - g * CPI;
+        if (img0 + g < a.B) pre[j] = *reinterpret_cast<const v4i*>(xs + ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16);
+      }
+    }
+  };
+  int item = blockIdx.x;
+  if (item < n_items) fetch(item);
+  for (; item < n_items; item += gridDim.x) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    // ---- write-late: registers -> centred X tile interior
+    {
+      const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+#pragma unroll
+      for (int j = 0; j < PER_T; ++j) {
+        const int i = tid + j * BLK_THREADS;
+        if (i < NCH) {
+          const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+          const v4i v = pre[j];
+          uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+          *reinterpret_cast<v2i*>(d) = v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)};
+          *reinterpret_cast<v2i*>(d + 8) = v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)};
+        }
+      }
+    }
+    // ---- issue-early: next item's input travels while this one computes
+    if (item + (int)gridDim.x < n_items) fetch(item + gridDim.x);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+      const BlockParams& bp = a.blk[k];
+      {
+        EpiTile<C::HO, C::COUT, C::TILE_BYTES> epi{tt, bp.a};
+        conv_passes<C, decltype(epi), BLK_WAVES>(xt, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
+      }
+      __syncthreads();
+      {
+        EpiTileResInPlace<C::HO, C::COUT, C::TILE_BYTES> epi{xt, bp.b, bp.add};
+        conv_passes<C, decltype(epi), BLK_WAVES>(tt, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
+      }
+      __syncthreads();
+    }
+    // ---- X tile interior (centred by the last add's zero point) -> quint8 -> HBM
+    {
+      const uint32_t z4 = (uint32_t)a.blk[NBLK - 1].add.z_o * 0x01010101u;
+      uint8_t* ys = a.y + (int64_t)s * a.y_ss;
+      for (int i = tid; i < NCH; i += BLK_THREADS) {
+        const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+        if (img0 + g < a.B) {
+          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+          const v2i lo = *reinterpret_cast<const v2i*>(d), hi = *reinterpret_cast<const v2i*>(d + 8);
+          v4i v = {(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
+          *reinterpret_cast<v4i*>(ys + ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16) = v;
+        }
+      }
+    }
+    __syncthreads();      // X tile free for the next item
+  }
+}
+
+template <class C, int NBLK>
+static int launch_block_chain(const ChainArgs<NBLK>& a, hipStream_t st) {
+  constexpr int LDS = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + NBLK * 2 * C::COUT * 4;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)block_chain_i8_kernel<C, NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  const int groups = (a.B + C::G - 1) / C::G;
+  const int n_items = a.n_samples * groups;
+  const int per_cu = (160 * 1024) / LDS >= 2 ? 2 : 1;
+  int grid = 256 * per_cu;
+  if (grid > n_items) grid = n_items;
+  hipLaunchKernelGGL((block_chain_i8_kernel<C, NBLK>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
+  return check_launch("qbnn_block_chain_i8_mc");
+}
+
+//                        CIN COUT K  S  HIN HALO G  MB NB
+using Cfg_c0      = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;    // layers.0 on the im2col tensor (K = 27 -> 32)
+using Cfg_24_24   = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;    // layers.3.*
+using Cfg_24_48s  = ConvCfg<24, 48, 3, 2, 32, 1, 1, 2, 2>;    // layers.4.0.stem.0
+using Cfg_24_48p  = ConvCfg<24, 48, 1, 2, 32, 1, 1, 2, 2>;    // layers.4.0.shortcut.0
+using Cfg_48_48   = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;    // layers.4.*
+using Cfg_48_96s  = ConvCfg<48, 96, 3, 2, 16, 1, 2, 1, 3>;    // layers.5.0.stem.0
+using Cfg_48_96p  = ConvCfg<48, 96, 1, 2, 16, 1, 2, 1, 3>;    // layers.5.0.shortcut.0
+using Cfg_96_96   = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3>;     // layers.5.*
+using Cfg_96_192s = ConvCfg<96, 192, 3, 2, 8, 1, 4, 1, 3>;    // layers.6.0.stem.0
+using Cfg_96_192p = ConvCfg<96, 192, 1, 2, 8, 1, 4, 1, 3>;    // layers.6.0.shortcut.0
+using Cfg_192_192 = ConvCfg<192, 192, 3, 1, 4, 1, 4, 1, 3>;   // layers.6.*
+
+static int fill_qconv(QConv& p, const int8_t* w, int64_t w_ss, const float* bias, const qbnn_conv_desc* d) {
+  if (d->z_x < 0 || d->z_x > 127 || d->a_hi > 127 || d->a_hi < 1 || d->z_y < 0 || d->z_y > 127)
+    return fail(QBNN_E_INVALID, "qbnn conv: activations must be <= 7 bit with zero points in [0,127] (reference quant_utils.py:120)%s");
+  p.w = w; p.w_ss = w_ss; p.bias = d->has_bias ? bias : nullptr;
+  p.z_x = d->z_x; p.z_w = d->z_w; p.z_y = d->z_y;
+  const float atw = d->s_x * d->s_w;     // qconv.cpp GetQuantizationParams: float * float
+  p.rcp = 1.0f / atw;                    // FBGEMM act_times_w_rcp
+  p.mult = atw / d->s_y;                 // output_multiplier_float
+  const int lo = d->relu ? d->z_y : 0, hi = d->a_hi < 255 ? d->a_hi : 255;
+  p.vlo = (float)(lo - d->z_y); p.vhi = (float)(hi - d->z_y);
+  p.s_y = d->s_y; p.nzs_y = (float)(-d->z_y) * d->s_y;
+  return QBNN_OK;
+}
+
+static int fill_qadd(QAdd& a, const qbnn_conv_desc* d) {
+  if (d->z_o < 0 || d->z_o > 127 || d->z_r < 0 || d->z_r > 127)
+    return fail(QBNN_E_INVALID, "qbnn conv: add zero points must be in [0,127]%s");
+  a.s_r = d->s_r; a.nzs_r = (float)(-d->z_r) * d->s_r; a.z_r = d->z_r;
+  a.inv_s_o = 1.0f / d->s_o; a.z_o = d->z_o;
+  a.vhi = (float)((d->a_hi < 255 ? d->a_hi : 255) - d->z_o);
+  return QBNN_OK;
+}
 
 QBNN_EXPORT int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* w_packed, int64_t w_ss, const float* bias,
                                   const uint8_t* res, int64_t res_ss, uint8_t* y, int64_t y_ss, int32_t n_samples,
@@ -419,24 +773,18 @@ QBNN_EXPORT int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* 
   if (d->has_res && !res) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_mc: has_res set but res is NULL%s");
   if (d->has_bias && !bias) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_mc: has_bias set but bias is NULL%s");
   if (d->H != d->W) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_mc: only square inputs are supported%s");
-  if (d->z_x < 0 || d->z_x > 127 || d->a_hi > 127 || d->a_hi < 1)
-    return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_mc: activations must be <= 7 bit (reference quant_utils.py:120)%s");
   ConvArgs a;
-  a.x = x; a.x_ss = x_ss; a.w = w_packed; a.w_ss = w_ss; a.bias = d->has_bias ? bias : nullptr;
-  a.res = res; a.res_ss = res_ss; a.y = y; a.y_ss = y_ss; a.B = d->B;
-  a.z_x = d->z_x; a.z_w = d->z_w; a.z_y = d->z_y; a.lo = d->relu ? d->z_y : 0; a.a_hi = d->a_hi;
-  const float atw = d->s_x * d->s_w;     // qconv.cpp GetQuantizationParams: float * float
-  a.rcp = 1.0f / atw;                    // FBGEMM act_times_w_rcp
-  a.mult = atw / d->s_y;                 // output_multiplier_float
-  a.s_y = d->s_y; a.nzs_y = (float)(-d->z_y) * d->s_y;
-  a.s_r = d->s_r; a.nzs_r = (float)(-d->z_r) * d->s_r;
-  a.inv_s_o = d->has_res ? 1.0f / d->s_o : 0.f; a.z_o = d->z_o;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.x_ss = x_ss; a.res = res; a.res_ss = res_ss; a.y = y; a.y_ss = y_ss; a.B = d->B;
+  int rc = fill_qconv(a.p, w_packed, w_ss, bias, d);
+  if (rc) return rc;
+  if (d->has_res && (rc = fill_qadd(a.a, d))) return rc;
   hipStream_t st = (hipStream_t)stream;
   const bool hr = d->has_res != 0;
 #define QBNN_CASE(CFG, cin, cout, ks, sd, hin, im2c)                                                      \
   if (d->Cin == (cin) && d->Cout == (cout) && d->ksize == (ks) && d->stride == (sd) && d->H == (hin) &&   \
       d->pad == ((ks) - 1) / 2 && (d->x_is_centered_im2col != 0) == (im2c))                                \
-    return launch_conv<CFG>(a, n_samples, hr, st);
+    return launch_conv<CFG, im2c>(a, n_samples, hr, st);
   QBNN_CASE(Cfg_c0, 32, 24, 1, 1, 32, true)
   QBNN_CASE(Cfg_24_24, 24, 24, 3, 1, 32, false)
   QBNN_CASE(Cfg_24_48s, 24, 48, 3, 2, 32, false)
@@ -450,6 +798,53 @@ QBNN_EXPORT int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* 
   QBNN_CASE(Cfg_192_192, 192, 192, 3, 1, 4, false)
 #undef QBNN_CASE
   return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_mc: unsupported geometry%s Cin=%ld Cout=%ld", "", d->Cin, d->Cout);
+}
+
+//                          CIN COUT K  S  HIN HALO G  MB NB
+using Blk_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;
+using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;
+using Blk_96  = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3>;
+using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3>;
+
+template <int NBLK>
+static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
+                                int32_t a_hi, const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples,
+                                hipStream_t st) {
+  ChainArgs<NBLK> a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = B; a.n_samples = n_samples; a.z_in = z_x;
+  float s_in = s_x; int z_in = z_x;
+  for (int k = 0; k < NBLK; ++k) {
+    const qbnn_block_desc& b = blk[k];
+    qbnn_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.a_hi = a_hi;
+    d.s_x = s_in; d.z_x = z_in; d.s_w = b.s_wa; d.z_w = b.z_wa; d.s_y = b.s_a; d.z_y = b.z_a; d.relu = 1; d.has_bias = b.bias_a != nullptr;
+    int rc = fill_qconv(a.blk[k].a, b.w_a, b.w_a_sample_stride, b.bias_a, &d);
+    if (rc) return rc;
+    d.s_x = b.s_a; d.z_x = b.z_a; d.s_w = b.s_wb; d.z_w = b.z_wb; d.s_y = b.s_b; d.z_y = b.z_b; d.relu = 0; d.has_bias = b.bias_b != nullptr;
+    if ((rc = fill_qconv(a.blk[k].b, b.w_b, b.w_b_sample_stride, b.bias_b, &d))) return rc;
+    d.s_r = s_in; d.z_r = z_in; d.s_o = b.s_o; d.z_o = b.z_o;
+    if ((rc = fill_qadd(a.blk[k].add, &d))) return rc;
+    s_in = b.s_o; z_in = b.z_o;
+  }
+  if (Cc == 24 && H == 32) return launch_block_chain<Blk_24, NBLK>(a, st);
+  if (Cc == 48 && H == 16) return launch_block_chain<Blk_48, NBLK>(a, st);
+  if (Cc == 96 && H == 8) return launch_block_chain<Blk_96, NBLK>(a, st);
+  if (Cc == 192 && H == 4) return launch_block_chain<Blk_192, NBLK>(a, st);
+  return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
+}
+
+QBNN_EXPORT int qbnn_block_chain_i8_mc(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
+                                       int32_t a_hi, const qbnn_block_desc* host_blocks, int32_t n_blocks, uint8_t* y,
+                                       int64_t y_ss, int32_t n_samples, void* stream) {
+  if (!x || !y || !host_blocks || n_samples <= 0 || B <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: bad argument%s");
+  for (int k = 0; k < n_blocks; ++k)
+    if (!host_blocks[k].w_a || !host_blocks[k].w_b) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: NULL weights%s");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_blocks == 1) return block_chain_dispatch<1>(x, x_ss, s_x, z_x, B, H, Cc, a_hi, host_blocks, y, y_ss, n_samples, st);
+  if (n_blocks == 2) return block_chain_dispatch<2>(x, x_ss, s_x, z_x, B, H, Cc, a_hi, host_blocks, y, y_ss, n_samples, st);
+  return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: 1 or 2 blocks per launch%s");
 }
 
 // =====================================================================================

@@ -193,20 +193,28 @@ class _BBBInt8(nn.Module):
         L = _lib.lib()
         mu, sg = self._logical_ohwi(self.weight), self._logical_ohwi(self.std)
         cout, k = mu.shape[0], int(np.prod(mu.shape[1:]))
-        nbytes = L.qbnn_packed_weight_bytes(cout, k, self.layout)
+        krow = self._krow(mu)
+        nbytes = L.qbnn_packed_weight_bytes(cout, k, krow, self.layout)
         out = []
         for src in (mu, sg):
             dst = np.zeros(nbytes, np.int8)
             src = np.ascontiguousarray(src.reshape(cout, k))
-            _lib.check(L.qbnn_pack_weights_host(src.ctypes.data_as(C.c_void_p), cout, k, self.layout, dst.ctypes.data_as(C.c_void_p)))
+            _lib.check(L.qbnn_pack_weights_host(src.ctypes.data_as(C.c_void_p), cout, k, krow, self.layout, dst.ctypes.data_as(C.c_void_p)))
             out.append(torch.from_numpy(dst).to(device))
         wp = getattr(self.args, "weight_precision", 8)
         sp = make_sample_params(self.weight.q_scale(), self.weight.q_zero_point(), self.std.q_scale(), self.std.q_zero_point(),
                                 self.mul_noise.scale, self.mul_noise.zero_point, self.add_weight.scale,
                                 self.add_weight.zero_point, wp)
         bias = None if self.bias_ is None else self.bias_.to(device=device, dtype=torch.float32).contiguous()
-        self._packed = dict(device=device, mu=out[0], sigma=out[1], cout=cout, k=k, nbytes=int(nbytes), sp=sp, bias=bias)
+        self._packed = dict(device=device, mu=out[0], sigma=out[1], cout=cout, k=k, krow=krow, nbytes=int(nbytes), sp=sp, bias=bias)
         return self._packed
+
+    def _krow(self, w_ohwi):
+        """Bytes of one kernel row (kw, c) in the OHWI weight: the unit the packed K axis is padded by.  The 3-channel
+        first layer runs as a 1x1 conv over 27-tap im2col patches, so its whole K is one row."""
+        if w_ohwi.ndim == 4 and w_ohwi.shape[3] % 8 == 0:
+            return int(w_ohwi.shape[2] * w_ohwi.shape[3])
+        return int(np.prod(w_ohwi.shape[1:]))
 
     def sample_weights(self, device, samples=None, seed=None, sample_begin=None, eps=None):
         """W_q for S samples in this layer's packed layout: int8 [S, nbytes]  (conv_q.py:113-119 chain, fused)."""
@@ -221,7 +229,7 @@ class _BBBInt8(nn.Module):
             eps = eps.to(device=device, dtype=torch.float32).contiguous()
             assert eps.numel() == S * pk["cout"] * pk["k"]
         with timed("sample_weights_i8"):
-            _lib.check(_lib.lib().qbnn_sample_weights_i8(_lib.ptr(pk["mu"]), _lib.ptr(pk["sigma"]), pk["cout"], pk["k"], self.layout,
+            _lib.check(_lib.lib().qbnn_sample_weights_i8(_lib.ptr(pk["mu"]), _lib.ptr(pk["sigma"]), pk["cout"], pk["k"], pk["krow"], self.layout,
                                                          C.byref(pk["sp"]), seed, self.layer_id, sb, S, _lib.ptr(eps),
                                                          _lib.ptr(w), pk["nbytes"], _stream()))
         return w

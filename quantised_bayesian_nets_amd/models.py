@@ -56,6 +56,35 @@ class BasicBlock(nn.Module):
         return self.stem[3]._conv(out, w3, S, residual=sc, add_qparams=(self.add.add.scale, self.add.add.zero_point))
 
 
+def run_identity_chain(blocks, x):
+    """1 or 2 identity BasicBlocks (no shortcut conv) in ONE persistent fused kernel (qbnn_block_chain_i8_mc):
+    activations stay in LDS between stem.0, stem.3 and the residual add.  Same results as calling the blocks."""
+    S = _MC.samples
+    dev = x.data.device
+    descs = (_lib.BlockDesc * len(blocks))()
+    keep = []
+    for d, blk in zip(descs, blocks):
+        assert len(blk.shortcut) == 0
+        ca, cb = blk.stem[0], blk.stem[3]
+        wa, wb = ca.sample_weights(dev), cb.sample_weights(dev)
+        pa, pb = ca._ensure_packed(dev), cb._ensure_packed(dev)
+        keep += [wa, wb]
+        d.w_a, d.w_a_sample_stride, d.bias_a = wa.data_ptr(), wa.shape[1], (pa["bias"].data_ptr() if pa["bias"] is not None else None)
+        d.s_wa, d.z_wa, d.s_a, d.z_a = ca.add_weight.scale, ca.add_weight.zero_point, ca.scale, ca.zero_point
+        d.w_b, d.w_b_sample_stride, d.bias_b = wb.data_ptr(), wb.shape[1], (pb["bias"].data_ptr() if pb["bias"] is not None else None)
+        d.s_wb, d.z_wb, d.s_b, d.z_b = cb.add_weight.scale, cb.add_weight.zero_point, cb.scale, cb.zero_point
+        d.s_o, d.z_o = blk.add.add.scale, blk.add.add.zero_point
+    _, B, H, W, Cc = x.data.shape
+    y = torch.empty((S, B, H, W, Cc), dtype=torch.uint8, device=dev)
+    a_hi = UINT_BOUNDS[blocks[0].args.activation_precision][1]
+    key = "block_chain_i8 x%d %dx%d c%d" % (len(blocks), H, W, Cc)
+    with timed(key, dict(H=H, C=Cc, nblk=len(blocks), nweights=sum(b.stem[0]._packed["cout"] * b.stem[0]._packed["k"] + b.stem[3]._packed["cout"] * b.stem[3]._packed["k"] for b in blocks))):
+        _lib.check(_lib.lib().qbnn_block_chain_i8_mc(_lib.ptr(x.data), x.sample_stride(), x.scale, x.zero_point, B, H, Cc, a_hi,
+                                                     descs, len(blocks), _lib.ptr(y), y[0].numel(), S, _lib.current_stream()))
+    last = blocks[-1].add.add
+    return MCQTensor(y, last.scale, last.zero_point)
+
+
 class QuantStub(nn.Module):
     def __init__(self):
         super().__init__()
@@ -88,6 +117,7 @@ class ConvNetwork_ResNet(nn.Module):
         self.layers.append(Linear(192 * BasicBlock.expansion, output_size, bias_=False, args=args))
         self.quant = QuantStub()
         self.dequant = ident()
+        self.fuse_blocks = True        # False: every conv as its own launch (layer-level C ABI), for A/B checks
         # Philox tensor ids = execution order of the stochastic layers
         for i, m in enumerate(self.stochastic_layers()):
             m.layer_id = i
@@ -166,8 +196,17 @@ class ConvNetwork_ResNet(nn.Module):
         if record is not None:
             record["layers.0.out"] = h.data
         for li in (3, 4, 5, 6):
-            for bi, blk in enumerate(self.layers[li]):
-                h = blk(h)
+            blocks = list(self.layers[li])
+            if self.fuse_blocks and record is None:
+                # identity blocks run as fused persistent chains; a down-sampling block 0 runs layer by layer
+                if len(blocks[0].shortcut) == 0:
+                    h = run_identity_chain(blocks, h)
+                else:
+                    h = blocks[0](h)
+                    h = run_identity_chain(blocks[1:], h)
+                continue
+            for bi, blk in enumerate(blocks):
+                h = blk(h) if not (self.fuse_blocks and len(blk.shortcut) == 0) else run_identity_chain([blk], h)
                 if record is not None:
                     record[f"layers.{li}.{bi}.out"] = h.data
         fc = self.layers[9]

@@ -29,10 +29,11 @@ def _pack(layer, w_logical):
     L = _lib.lib()
     cout = w_logical.shape[0]
     k = int(np.prod(w_logical.shape[1:]))
-    n = L.qbnn_packed_weight_bytes(cout, k, layer.layout)
+    krow = layer._krow(w_logical)
+    n = L.qbnn_packed_weight_bytes(cout, k, krow, layer.layout)
     dst = np.zeros(n, np.int8)
     src = np.ascontiguousarray(w_logical.reshape(cout, k))
-    _lib.check(L.qbnn_pack_weights_host(src.ctypes.data_as(C.c_void_p), cout, k, layer.layout, dst.ctypes.data_as(C.c_void_p)))
+    _lib.check(L.qbnn_pack_weights_host(src.ctypes.data_as(C.c_void_p), cout, k, krow, layer.layout, dst.ctypes.data_as(C.c_void_p)))
     return dst
 
 
@@ -142,6 +143,49 @@ def test_resnet_end_to_end_matches_reference(golden):
     with q.mc_context(1, g["meta"]["philox_seed"], 1):
         p1 = m(x)
     np.testing.assert_allclose(p1.cpu().numpy(), g["probs"][1], rtol=RTOL, atol=1e-8)
+
+
+def test_fused_block_chain_equals_layerwise_and_golden(golden):
+    """qbnn_block_chain_i8_mc (persistent fused BasicBlocks) against the layer-by-layer C ABI path and the golden."""
+    import quantised_bayesian_nets_amd as q
+    from quantised_bayesian_nets_amd.layers import MCQTensor
+    from quantised_bayesian_nets_amd.models import run_identity_chain
+    g = golden
+    m = _model(g)
+    rec, st = g["rec"], g["state"]
+    S, seed = 3, g["meta"]["philox_seed"]
+
+    def act(name, key):
+        s, z = float(np.asarray(st[key + "scale"]).reshape(-1)[0]), int(np.asarray(st[key + "zero_point"]).reshape(-1)[0])
+        return MCQTensor(torch.from_numpy(rec[name]).cuda()[None].contiguous(), s, z, shared=True)
+
+    with q.mc_context(S, seed, 0):
+        # layer 1: two identity blocks in one launch, input = golden layers.0 output (shared by the 3 samples)
+        x = act("layers.0.out", "layers.0.")
+        y2 = run_identity_chain(list(m.layers[3]), x)
+        y1 = run_identity_chain([m.layers[3][0]], x)
+        ref1 = m.layers[3][0](x)
+        ref2 = m.layers[3][1](ref1)
+        assert torch.equal(y1.data, ref1.data) and torch.equal(y2.data, ref2.data)
+        assert np.array_equal(y1.data[0].cpu().numpy(), rec["layers.3.0.out"])
+        assert np.array_equal(y2.data[0].cpu().numpy(), rec["layers.3.1.out"])
+        # second block of the other stages
+        for li in (4, 5, 6):
+            x = act(f"layers.{li}.0.out", f"layers.{li}.0.add.add.")
+            y = run_identity_chain([m.layers[li][1]], x)
+            ref = m.layers[li][1](x)
+            assert torch.equal(y.data, ref.data), li
+            assert np.array_equal(y.data[0].cpu().numpy(), rec[f"layers.{li}.1.out"]), li
+    # whole model: fused == layer-wise, all samples
+    xin = torch.from_numpy(g["x"]).cuda()
+    with q.mc_context(S, seed, 0):
+        m.fuse_blocks = True
+        pf = m.forward_mc(xin)
+        m.fuse_blocks = False
+        pu = m.forward_mc(xin)
+        m.fuse_blocks = True
+    assert torch.equal(pf, pu)
+    np.testing.assert_allclose(pf.cpu().numpy(), g["probs"], rtol=RTOL, atol=1e-8)
 
 
 def test_full_size_against_oracle_and_properties(golden_w8):
