@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "qbnn_kernels.hip")]
 DEPS = SRC + [os.path.join(HERE, "csrc", "qbnn_rng.cuh"), os.path.join(os.path.dirname(HERE), "include", "qbnn.h")]
-LIB = os.path.join(HERE, "libqbnn_hip.so")
+LIB = os.environ.get("QBNN_LIB_OVERRIDE") or os.path.join(HERE, "libqbnn_hip.so")   # override: scratch ablation builds
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden",
                "-Wno-unused-value", "-std=c++17"]

@@ -390,8 +390,13 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
             rsum[mb] = rs_;
           }
 #pragma unroll
-          for (int nb = 0; nb < C::NB; ++nb)
+          for (int nb = 0; nb < C::NB; ++nb) {
+#ifdef QBNN_ABL_NOMFMA
+            acc[mb][nb][0] ^= f.w[u][nb].x ^ f.x[u][mb].y;
+#else
             acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[u][nb], f.x[u][mb], acc[mb][nb], 0, 0, 0);
+#endif
+          }
         }
       }
     };
@@ -439,6 +444,17 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
       }
       const int zwr = p.z_w * R;
       const int m = (mblk * C::MB + mb) * 32 + r;
+#ifdef QBNN_ABL_NOEPI
+      {
+        int keep = zwr;
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) keep ^= acc[mb][nb][i];
+        if (keep == 0x12345678) epi.store(m, 4 * h, 0.f, 0.f, 0.f, 0.f, 0u);
+        continue;
+      }
+#endif
 #pragma unroll
       for (int nb = 0; nb < C::NB; ++nb) {
         uint32_t pre[4];

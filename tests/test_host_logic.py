@@ -1,0 +1,150 @@
+"""CPU-side tests (no GPU): host logic, C-ABI surface, weight packing, sample sharding, and the world_size-2
+gloo path of the MC reduction (the oracle stands in for the per-rank GPU evaluation)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from quantised_bayesian_nets_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "qbnn.h")).read()
+    declared = set(re.findall(r"\b(qbnn_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"qbnn_sample_params", "qbnn_conv_desc", "qbnn_head_desc", "qbnn_block_desc"}
+    L = _lib.lib()
+    for sym in sorted(declared):
+        assert hasattr(L, sym), sym
+    assert set(_lib.EXPORTS) == declared
+    assert L.qbnn_version() >= 1
+
+
+def test_errors_without_gpu_are_loud(golden_w8):
+    import quantised_bayesian_nets_amd as q
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+    m = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args).load_reference_state(golden_w8["state"])
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32))          # CPU tensor: the product has no CPU fallback
+    with pytest.raises(NotImplementedError):
+        q.ModelFactory.get_model("conv_lenet", [1, 1, 28, 28], 10, True, args)
+    bad = types.SimpleNamespace(activation_precision=8, weight_precision=8)
+    with pytest.raises(AssertionError):       # reference quant_utils.py:120: activations are at most 7 bit
+        q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, bad)
+
+
+def test_pack_weights_layout_and_ones_row():
+    """QBNN_LAYOUT_MFMA32: k rows padded to 32 bytes, lane-fragment order, all-ones row for ragged cout."""
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    for cout, kh, krow in [(24, 3, 72), (48, 3, 144), (96, 1, 48), (192, 3, 576), (24, 1, 27)]:
+        k = kh * krow
+        w = rng.integers(-128, 128, (cout, k)).astype(np.int8)
+        n = L.qbnn_packed_weight_bytes(cout, k, krow, 0)
+        rbp = (krow + 31) // 32 * 32
+        KS, NT = kh * rbp // 32, (cout + 31) // 32
+        assert n == NT * KS * 1024
+        dst = np.full(n, 77, np.int8)
+        _lib.check(L.qbnn_pack_weights_host(w.ctypes.data_as(C.c_void_p), cout, k, krow, 0, dst.ctypes.data_as(C.c_void_p)))
+        d = dst.reshape(NT, KS, 64, 16)
+        for (nn, kk) in [(0, 0), (cout - 1, k - 1), (cout // 2, min(krow, k - 1)), (5, krow - 1)]:
+            kp = (kk // krow) * rbp + kk % krow
+            assert d[nn // 32, kp // 32, ((kp // 16) % 2) * 32 + nn % 32, kp % 16] == w[nn, kk]
+        # pads are zero; ragged cout carries the ones row at n == cout
+        total_ones = int((dst == 1).sum()) - int((w == 1).sum())
+        if cout % 32:
+            ones = d[cout // 32, :, :, :].reshape(KS, 2, 32, 16)[:, :, cout % 32, :].reshape(-1)   # [KS*32] in kp order
+            valid = np.array([(kp % rbp) < krow for kp in range(KS * 32)])
+            assert np.array_equal(ones == 1, valid) and total_ones == valid.sum()
+        assert int((dst != 0).sum()) <= cout * k + (k if cout % 32 else 0)
+    # row-major layout is a plain copy
+    w = rng.integers(-128, 128, (10, 192)).astype(np.int8)
+    dst = np.zeros(L.qbnn_packed_weight_bytes(10, 192, 192, 1), np.int8)
+    _lib.check(L.qbnn_pack_weights_host(w.ctypes.data_as(C.c_void_p), 10, 192, 192, 1, dst.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(dst[:1920].reshape(10, 192), w)
+
+
+def test_reference_state_roundtrip(golden_w8):
+    import quantised_bayesian_nets_amd as q
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+    m = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args).load_reference_state(golden_w8["state"])
+    assert m.n_weights() == 1571592 and len(m.stochastic_layers()) == 21
+    for name, layer in zip(m.stochastic_layer_names(), m.stochastic_layers()):
+        st = layer.reference_state(name + ".")
+        for k, v in st.items():
+            assert np.array_equal(np.asarray(v), np.asarray(golden_w8["state"][k])), k
+    assert [l.layer_id for l in m.stochastic_layers()] == list(range(21))
+
+
+def test_shard_samples_partitions_the_range():
+    from quantised_bayesian_nets_amd.mc import shard_samples
+    for S in (1, 7, 100, 1024):
+        for G in (1, 2, 3, 8):
+            parts = [shard_samples(S, r, G) for r in range(G)]
+            assert sum(c for _, c in parts) == S
+            pos = 0
+            for b, c in parts:
+                assert b == pos
+                pos += c
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_finalize_moments_matches_torch():
+    from quantised_bayesian_nets_amd.mc import finalize_moments
+    p = torch.rand(9, 5, 10)
+    mom = torch.stack([p.sum(0), (p * p).sum(0)])
+    mean, var = finalize_moments(mom, 9)
+    torch.testing.assert_close(mean, p.mean(0), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(var, p.var(0), rtol=1e-4, atol=1e-6)     # unbiased, as experiments/utils.py:352
+
+
+_WORKER = r"""
+import os, sys, types, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from conftest import load_golden
+from oracle import oracle as orc
+from quantised_bayesian_nets_amd.mc import shard_samples, all_reduce_moments, finalize_moments
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = load_golden("resnet_bbb_a7w8.npz")
+net = orc.Int8ResNetOracle(g["state"], 7, 8)
+S, seed = 5, 3
+begin, count = shard_samples(S, rank, world)
+x = g["x"][:2]
+mom = torch.zeros(2, 2, 10)
+for s in range(begin, begin + count):          # the oracle stands in for this rank's GPU evaluation
+    p = torch.from_numpy(net.forward(x, seed, s))
+    mom[0] += p; mom[1] += p * p
+all_reduce_moments(mom)
+mean, var = finalize_moments(mom, S)
+if rank == 0:
+    _, ps = net.mc_predict(x, S, seed)
+    ps = torch.from_numpy(ps)
+    torch.testing.assert_close(mean, ps.mean(0), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(var, ps.var(0), rtol=1e-3, atol=1e-7)
+    # samples 0..2 of the global stream are the golden ones recorded from the reference
+    torch.testing.assert_close(ps[:3], torch.from_numpy(g["probs"][:, :2]), rtol=1e-5, atol=1e-8)
+    print("OK")
+dist.destroy_process_group()
+"""
+
+
+def test_world_size_2_gloo_reduce_equals_single_process(tmp_path):
+    """Sharding S over 2 ranks + one sum all-reduce of the [2,B,C] moments == the single-process MC loop."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", OMP_NUM_THREADS="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "OK" in outs[0]
