@@ -74,6 +74,19 @@ int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* sigma_packed, 
                            uint32_t layer_id, uint32_t sample_begin, int32_t n_samples, const float* eps_in,
                            int8_t* w_out, int64_t w_sample_stride, void* stream);
 
+/* The same sampler for up to 24 layers in ONE launch (one launch per MC batch instead of one per layer).
+ * Results are identical to calling qbnn_sample_weights_i8 per entry (Philox path only). */
+typedef struct qbnn_sampler_layer {
+  const int8_t* mu_packed; const int8_t* sigma_packed;
+  int8_t* w_out; int64_t w_sample_stride;
+  int32_t cout, k, krow, layout;
+  uint32_t layer_id;
+  qbnn_sample_params params;
+} qbnn_sampler_layer;
+
+int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* host_layers, int32_t n_layers, uint64_t seed,
+                                 uint32_t sample_begin, int32_t n_samples, void* stream);
+
 /* One int8 stochastic conv layer for S MC samples, including everything the reference model
  * applies between this conv and the next one:
  *   quantized.functional.conv2d / quantized::conv2d_relu      conv_q.py:120-125, :206-209

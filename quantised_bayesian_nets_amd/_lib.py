@@ -30,6 +30,12 @@ class ConvDesc(C.Structure):
                 ("x_is_centered_im2col", C.c_int32)]
 
 
+class SamplerLayer(C.Structure):
+    _fields_ = [("mu_packed", C.c_void_p), ("sigma_packed", C.c_void_p), ("w_out", C.c_void_p), ("w_sample_stride", C.c_int64),
+                ("cout", C.c_int32), ("k", C.c_int32), ("krow", C.c_int32), ("layout", C.c_int32),
+                ("layer_id", C.c_uint32), ("params", SampleParams)]
+
+
 class BlockDesc(C.Structure):
     _fields_ = [("w_a", C.c_void_p), ("w_a_sample_stride", C.c_int64), ("bias_a", C.c_void_p),
                 ("s_wa", C.c_float), ("z_wa", C.c_int32), ("s_a", C.c_float), ("z_a", C.c_int32),
@@ -46,7 +52,7 @@ class HeadDesc(C.Structure):
                 ("a_hi", C.c_int32), ("has_bias", C.c_int32)]
 
 
-EXPORTS = ["qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_conv2d_i8_mc",
+EXPORTS = ["qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_conv2d_i8_mc",
            "qbnn_block_chain_i8_mc",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_head_i8_mc", "qbnn_reduce_moments",
            "qbnn_last_error", "qbnn_version"]
@@ -70,6 +76,7 @@ def lib():
         vp, i32, i64, u32, u64, f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
         L.qbnn_pack_weights_host.argtypes = [vp, i32, i32, i32, i32, vp]
         L.qbnn_sample_weights_i8.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(SampleParams), u64, u32, u32, i32, vp, vp, i64, vp]
+        L.qbnn_sample_weights_i8_multi.argtypes = [C.POINTER(SamplerLayer), i32, u64, u32, i32, vp]
         L.qbnn_conv2d_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, C.POINTER(ConvDesc), vp]
         L.qbnn_block_chain_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(BlockDesc), i32, vp, i64, i32, vp]
         L.qbnn_quantize_input_nchw.argtypes = [vp, i32, i32, i32, i32, f, i32, i32, vp, vp]

@@ -218,6 +218,39 @@ struct QAdd {              // BasicBlock Add + ReLU (models_bbb.py:179-182)
 
 #define QBNN_MAGIC 12582912.0f     // 1.5 * 2^23: (v + MAGIC) has rne(v) in its low mantissa bits for |v| < 2^22
 
+// Diagnostic build only (-DQBNN_STAMP, scratch library): per-phase s_memtime sums of wave 0, written to a debug
+// buffer that nothing else reads.  The shipped library contains none of this.
+#ifdef QBNN_STAMP
+static unsigned long long* g_stamp_buf = nullptr;
+QBNN_EXPORT void qbnn_debug_stamp_buffer(void* p) { g_stamp_buf = (unsigned long long*)p; }
+__device__ unsigned long long g_inner[4];
+QBNN_EXPORT void qbnn_debug_read_inner(unsigned long long* host4) {
+  hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_inner), 32);
+  unsigned long long z[4] = {0, 0, 0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_inner), z, 32);
+}
+#define QBNN_STAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define QBNN_STAMP_START() do { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define QBNN_STAMP_AT(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); st_acc[i] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define QBNN_STAMP_DECL
+#define QBNN_STAMP_START() do {} while (0)
+#define QBNN_STAMP_AT(i) do {} while (0)
+#endif
+
+#ifdef QBNN_STAMP
+#define QBNN_INNER_T0() unsigned long long it_ = 0, ia_[4] = {0, 0, 0, 0}; do { __builtin_amdgcn_sched_barrier(0); it_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define QBNN_INNER_AT(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); ia_[i] += t_ - it_; it_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define QBNN_INNER_FLUSH() do { if (lane == 0 && wave == QBNN_STAMP_WAVE) for (int q_ = 0; q_ < 4; ++q_) atomicAdd(&g_inner[q_], ia_[q_]); } while (0)
+#ifndef QBNN_STAMP_WAVE
+#define QBNN_STAMP_WAVE 7
+#endif
+#else
+#define QBNN_INNER_T0() do {} while (0)
+#define QBNN_INNER_AT(i) do {} while (0)
+#define QBNN_INNER_FLUSH() do {} while (0)
+#endif
+
 template <int CIN_, int COUT_, int KSZ_, int STRIDE_, int HIN_, int HALO_, int G_, int MB_, int NB_>
 struct ConvCfg {
   static constexpr int CIN = CIN_, COUT = COUT_, KSZ = KSZ_, STRIDE = STRIDE_, HIN = HIN_, HALO = HALO_;
@@ -244,6 +277,14 @@ struct ConvCfg {
   static constexpr int MBLKS = MT / MB, NBLKS = NT / NB;
   static constexpr int NPASS = MBLKS * NBLKS;
   static constexpr int OUT_BYTES = (M * COUT + 15) / 16 * 16;
+  // 32-pixel-wide maps, 3x3/s1, one n-tile: an M-tile is one output row, so the input-row fragments of a pass
+  // are shared by the 3 output rows that touch them and all weights fit in registers
+  static constexpr bool ROWREUSE = (HO == 32 && STRIDE == 1 && KSZ == 3 && NT == 1 && NB_ == 1 && KS <= 9 && (32 % MB_) == 0);
+  // weight slab of the LDS ring: SLK k-steps x all NT tiles, <= 36 KB, SLK | KS
+  static constexpr int pick_slab() { int best = 1; for (int d = 1; d <= KS; ++d) if (KS % d == 0 && d * NT <= 36) best = d; return best; }
+  static constexpr int SLK = pick_slab();
+  static constexpr int NSLAB = KS / SLK;
+  static constexpr int SLAB_BYTES = NT * SLK * 1024;
   static constexpr int TILE_SLACK = 32;                   // the last k-step of a row over-reads < 32 bytes
   static_assert(ROWB % 16 == 0, "image rows must be 16-byte multiples");
   static_assert(M % 32 == 0 && MT % MB == 0 && NT % NB == 0, "tile blocking must divide the problem");
@@ -320,6 +361,79 @@ __device__ __forceinline__ void load_bias(float* dst, const float* bias, int tid
   for (int i = tid; i < COUT; i += NTHR) dst[i] = bias ? bias[i] : 0.0f;
 }
 
+// Row-reuse variant for 32-pixel-wide maps (layer 1): one M-tile = one output row.  A pass of MB consecutive output
+// rows needs MB + 2 input rows; each input row's fragments are read from LDS once and feed the (up to) 3 output rows
+// that touch it; all KS weight fragments stay in registers.  No load sits between two MFMAs.
+template <class C, class Epi, int NWAVES>
+__device__ __forceinline__ void conv_passes_rows(const uint8_t* tile, const int8_t* wq, const float* bias_lds, const QConv& p,
+                                                 Epi& epi, int wave, int lane) {
+  static_assert(C::ROWREUSE && C::USE_ONES, "row-reuse path: 32-wide, 3x3/s1, single ragged n-tile");
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int NR = C::MB + C::KSZ - 1;
+  for (int pass = wave; pass < C::NPASS; pass += NWAVES) {
+    const int m0 = pass * C::MB * 32;                         // first pixel of the pass (NBLKS == 1)
+    const int g = m0 / (C::HO * C::HO), oh0 = (m0 % (C::HO * C::HO)) / C::HO;
+    const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::CIN + 16 * h;
+    QBNN_INNER_T0();
+    v4i w[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wq + ((int64_t)ks * 64 + lane) * 16);
+    float4 b4[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      if (8 * g4 < C::COUT) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * h);
+    v4i x[NR][C::SPR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int t = 0; t < C::SPR; ++t) {
+        const v2i lo = *reinterpret_cast<const v2i*>(base + j * C::PITCH + t * 32);
+        const v2i hi = *reinterpret_cast<const v2i*>(base + j * C::PITCH + t * 32 + 8);
+        x[j][t] = v4i{lo.x, lo.y, hi.x, hi.y};
+      }
+    // Software pipeline over the MB output rows of the pass: the 9 MFMAs of row mb are issued, then the epilogue
+    // (VALU + LDS) of row mb-1 -- independent instruction streams inside one basic block, so the matrix pipe works
+    // on row mb while the vector pipe requantises row mb-1.
+    v16i acc[C::MB];
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    QBNN_INNER_AT(0);
+#pragma unroll
+    for (int mb = 0; mb <= C::MB; ++mb) {
+      if (mb < C::MB) {
+#pragma unroll
+        for (int kh = 0; kh < C::KSZ; ++kh)
+#pragma unroll
+          for (int t = 0; t < C::SPR; ++t)
+            acc[mb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * C::SPR + t], x[mb + kh][t], (kh == 0 && t == 0) ? zero16 : acc[mb], 0, 0, 0);
+        QBNN_INNER_AT(1);
+      }
+      if (mb > 0) {
+        const int e = mb - 1;
+        const int rv = acc[e][C::ONES_REG];
+        const int ro = __shfl_xor(rv, 32);
+        const int zwr = p.z_w * (h ? ro : rv);
+        const int po = epi.pixel(m0 + e * 32 + r);
+        uint32_t pre[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          if (8 * g4 < C::COUT) pre[g4] = epi.load(po, 8 * g4 + 4 * h);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          if (8 * g4 >= C::COUT) continue;
+          const float4 bb = b4[g4];
+          const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(acc[e][4 * g4 + 0] - zwr)) * p.mult;
+          const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(acc[e][4 * g4 + 1] - zwr)) * p.mult;
+          const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(acc[e][4 * g4 + 2] - zwr)) * p.mult;
+          const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(acc[e][4 * g4 + 3] - zwr)) * p.mult;
+          epi.store(po, 8 * g4 + 4 * h, v0, v1, v2, v3, pre[g4]);
+        }
+        QBNN_INNER_AT(2);
+      }
+    }
+    QBNN_INNER_FLUSH();
+  }
+}
+
 // All MFMA passes of one conv over LDS-resident tiles.
 // Epilogue functor interface:  pre = epi.load(m, c0)   (residual dword or 0; issued ahead of the arithmetic)
 //                              epi.store(m, c0, v0..v3, pre)
@@ -330,6 +444,10 @@ __device__ __forceinline__ void load_bias(float* dst, const float* bias, int tid
 template <class C, class Epi, int NWAVES = 4>
 __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* wq, const float* bias_lds, const QConv& p,
                                             Epi& epi, int wave, int lane) {
+  if constexpr (C::ROWREUSE) {
+    conv_passes_rows<C, Epi, NWAVES>(tile, wq, bias_lds, p, epi, wave, lane);
+    return;
+  }
   const int r = lane & 31, h = lane >> 5;
   constexpr int U = C::KCHUNK, NCHUNK = C::KS / U;
   struct Frags { v4i w[U][C::NB]; v4i x[U][C::MB]; };
@@ -443,7 +561,7 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
         R = rsum[mb] + __shfl_xor(rsum[mb], 32);
       }
       const int zwr = p.z_w * R;
-      const int m = (mblk * C::MB + mb) * 32 + r;
+      const int m = epi.pixel((mblk * C::MB + mb) * 32 + r);
 #ifdef QBNN_ABL_NOEPI
       {
         int keep = zwr;
@@ -480,17 +598,339 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
   }
 }
 
+// ---- all stochastic layers of a model in ONE launch -------------------------------------------------------------
+#define QBNN_MAX_SAMPLER_LAYERS 24
+struct SamplerLayer {
+  const v4i* mu; const v4i* sigma; int8_t* out; int64_t out_ss;
+  int cout, K, krow, rbp, KS, layout, n_chunks, chunk_begin;     // chunk_begin: first 256-thread block of this layer
+  uint32_t layer_id;
+  qbnn_sample_params p;
+};
+struct SamplerTable { SamplerLayer l[QBNN_MAX_SAMPLER_LAYERS]; int n; };
+
+__global__ __launch_bounds__(256) void sample_weights_multi_kernel(const SamplerTable t, uint32_t seed_lo, uint32_t seed_hi,
+                                                                   uint32_t sample_begin) {
+  int li = 0;
+#pragma unroll 1
+  for (int i = 1; i < t.n; ++i) li = ((int)blockIdx.x >= t.l[i].chunk_begin) ? i : li;
+  const SamplerLayer& L = t.l[li];
+  const int chunk = ((int)blockIdx.x - L.chunk_begin) * 256 + threadIdx.x;
+  if (chunk >= L.n_chunks) return;
+  const int s = blockIdx.y;
+  int n = 0, kh = 0, j0 = 0;
+  if (L.layout == QBNN_LAYOUT_MFMA32) {
+    const int lane = chunk & 63, tile = chunk >> 6;
+    const int nt = tile / L.KS, ks = tile - nt * L.KS;
+    n = nt * 32 + (lane & 31);
+    const int kp0 = ks * 32 + (lane >> 5) * 16;
+    kh = kp0 / L.rbp; j0 = kp0 - kh * L.rbp;
+  }
+  const bool ones_row = (L.layout == QBNN_LAYOUT_MFMA32) && (L.cout & 31) && n == L.cout;
+  const v4i m4 = L.mu[chunk], s4 = L.sigma[chunk];
+  int mw[4] = {m4.x, m4.y, m4.z, m4.w}, sw[4] = {s4.x, s4.y, s4.z, s4.w};
+  uint32_t ow[4] = {0u, 0u, 0u, 0u};
+  const int64_t total = (int64_t)L.cout * L.K;
+  uint32_t cur_blk = 0xffffffffu;
+  float nrm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    int64_t idx;
+    bool valid;
+    if (L.layout == QBNN_LAYOUT_MFMA32) {
+      valid = (n < L.cout) && (j0 + j < L.krow);
+      idx = (int64_t)n * L.K + kh * L.krow + j0 + j;
+      if (ones_row && j0 + j < L.krow) ow[j >> 2] |= 1u << (8 * (j & 3));
+    } else {
+      idx = (int64_t)chunk * 16 + j;
+      valid = idx < total;
+    }
+    if (valid) {
+      const uint32_t blk = (uint32_t)(idx >> 2);
+      if (blk != cur_blk) {
+        cur_blk = blk;
+        qbnn::normal4(qbnn::philox4x32_10(blk, L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi), nrm);
+      }
+      const int l = (int)(idx & 3);
+      const float eps = l == 0 ? nrm[0] : (l == 1 ? nrm[1] : (l == 2 ? nrm[2] : nrm[3]));
+      const int mu_q = (mw[j >> 2] << (24 - 8 * (j & 3))) >> 24;
+      const int sg_q = (sw[j >> 2] << (24 - 8 * (j & 3))) >> 24;
+      ow[j >> 2] |= ((uint32_t)sample_one(mu_q, sg_q, eps, L.p) & 0xffu) << (8 * (j & 3));
+    }
+  }
+  reinterpret_cast<v4i*>(L.out + (int64_t)s * L.out_ss)[chunk] = v4i{(int)ow[0], (int)ow[1], (int)ow[2], (int)ow[3]};
+}
+
+QBNN_EXPORT int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* layers, int32_t n_layers, uint64_t seed,
+                                             uint32_t sample_begin, int32_t n_samples, void* stream) {
+  if (!layers || n_layers <= 0 || n_layers > QBNN_MAX_SAMPLER_LAYERS || n_samples <= 0)
+    return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: bad argument (at most 24 layers per call)%s");
+  SamplerTable t;
+  memset(&t, 0, sizeof(t));
+  t.n = n_layers;
+  int blocks = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    const qbnn_sampler_layer& q = layers[i];
+    if (!q.mu_packed || !q.sigma_packed || !q.w_out || q.cout <= 0 || q.k <= 0)
+      return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: bad layer entry%s");
+    if (q.layout == QBNN_LAYOUT_MFMA32 && (q.krow <= 0 || q.k % q.krow))
+      return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: k must be a multiple of krow%s");
+    const size_t bytes = qbnn_packed_weight_bytes(q.cout, q.k, q.krow, q.layout);
+    if ((size_t)q.w_sample_stride < bytes || (q.w_sample_stride & 15))
+      return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: w_sample_stride too small or unaligned%s");
+    const PackGeom g = pack_geom(q.cout, q.k, q.layout == QBNN_LAYOUT_MFMA32 ? q.krow : q.k);
+    SamplerLayer& L = t.l[i];
+    L.mu = (const v4i*)q.mu_packed; L.sigma = (const v4i*)q.sigma_packed; L.out = q.w_out; L.out_ss = q.w_sample_stride;
+    L.cout = q.cout; L.K = q.k; L.krow = g.krow; L.rbp = g.rbp; L.KS = g.KS; L.layout = q.layout;
+    L.n_chunks = (int)(bytes / 16); L.chunk_begin = blocks; L.layer_id = q.layer_id; L.p = q.params;
+    blocks += ceil_div(L.n_chunks, 256);
+  }
+  hipLaunchKernelGGL(sample_weights_multi_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, t,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), sample_begin);
+  return check_launch("qbnn_sample_weights_i8_multi");
+}
+
+// =====================================================================================
+// conv_lds: the conv core of the fused kernels.  Weights reach the CU ONCE per workgroup: the workgroup's waves DMA
+// them (global_load_lds, 1 KiB fragment tile per wave-instruction, no VGPRs) into a two-slab LDS ring; every wave
+// then reads its fragments with ds_read_b128.  (Fetching them per wave from L2, as the layer-level kernel does,
+// moves 8x the bytes into the CU -- as many cycles as the MFMAs themselves.)
+//   protocol per slab i:   __syncthreads()  [slab i landed (vmcnt(0)), every wave is done with the other buffer,
+//                                            and -- for i == 0 -- the input tile written by the previous phase]
+//                          DMA slab i+1 (or `prefetch_next`: slab 0 of the next conv) into the other buffer
+//                          `after_first_barrier()` once (caller's own prefetch loads)
+//                          MFMAs of slab i
+//   requires NPASS <= NWAVES (one pass per wave, accumulators live across slabs).
+// =====================================================================================
+struct WRing { uint8_t* buf[2]; int cur; };
+
+template <class C, int NWAVES>
+__device__ __forceinline__ void dma_slab(uint8_t* dst, const int8_t* wq, int slab, int wave, int lane) {
+  constexpr int NFRAG = C::NT * C::SLK;
+  for (int f = wave; f < NFRAG; f += NWAVES) {
+    const int nt = f / C::SLK, u = f - nt * C::SLK;
+    __builtin_amdgcn_global_load_lds(wq + ((int64_t)(nt * C::KS + slab * C::SLK + u) * 64 + lane) * 16,
+                                     (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+  }
+}
+
+template <class C, class Epi, int NWAVES, class FNext, class FHook>
+__device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const int8_t* wq, const float* bias_lds, const QConv& p,
+                                         Epi& epi, int wave, int lane, FNext prefetch_next, FHook after_first_barrier) {
+  static_assert(C::NPASS <= NWAVES, "conv_lds: one pass per wave");
+  static_assert(C::SLK % C::KCHUNK == 0, "k-chunks must not straddle weight slabs");
+  const int r = lane & 31, h = lane >> 5;
+  const bool active = wave < C::NPASS;
+  const int pass = active ? wave : 0;
+  const int mblk = pass / C::NBLKS, nblk = pass - mblk * C::NBLKS;
+  // bias of this pass's channels -> registers.  The table is written once at kernel start (a barrier has passed
+  // since); reading it here, BEFORE any LDS-DMA of this conv is in flight, keeps the compiler from guarding the
+  // read with s_waitcnt vmcnt(0).
+  float4 b4[C::NB][4];
+#pragma unroll
+  for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+      b4[nb][g4] = *reinterpret_cast<const float4*>(bias_lds + (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
+    }
+  QBNN_INNER_T0();
+
+  if constexpr (C::ROWREUSE) {
+    // ---- 32-pixel-wide maps (layer 1): one slab = the whole conv; one M-tile = one output row.  All 9 weight
+    // fragments and the MB+2 input-row fragments are loaded once; the 9 MFMAs of row mb are followed in program
+    // order by the epilogue of row mb-1, so the matrix pipe works on row mb while the vector pipe requantises mb-1.
+    static_assert(C::NSLAB == 1 && C::USE_ONES, "row-reuse path");
+    __syncthreads();
+    QBNN_INNER_AT(0);
+    prefetch_next(ring.buf[ring.cur ^ 1]);
+    after_first_barrier();
+    const uint8_t* wl = ring.buf[ring.cur] + lane * 16;
+    ring.cur ^= 1;
+    if (!active) return;
+    constexpr int NR = C::MB + C::KSZ - 1;
+    const int m0 = pass * C::MB * 32;
+    const int g = m0 / (C::HO * C::HO), oh0 = (m0 % (C::HO * C::HO)) / C::HO;
+    const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::CIN + 16 * h;
+    v4i w[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wl + ks * 1024);
+    v4i x[NR][C::SPR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int t = 0; t < C::SPR; ++t) {
+        const v2i lo = *reinterpret_cast<const v2i*>(base + j * C::PITCH + t * 32);
+        const v2i hi = *reinterpret_cast<const v2i*>(base + j * C::PITCH + t * 32 + 8);
+        x[j][t] = v4i{lo.x, lo.y, hi.x, hi.y};
+      }
+    v16i acc[C::MB];
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int mb = 0; mb <= C::MB; ++mb) {
+      if (mb < C::MB) {
+#pragma unroll
+        for (int kh = 0; kh < C::KSZ; ++kh)
+#pragma unroll
+          for (int t = 0; t < C::SPR; ++t)
+            acc[mb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * C::SPR + t], x[mb + kh][t], (kh == 0 && t == 0) ? zero16 : acc[mb], 0, 0, 0);
+      }
+      if (mb > 0) {
+        const int e = mb - 1;
+        const int rv = acc[e][C::ONES_REG];
+        const int ro = __shfl_xor(rv, 32);
+        const int zwr = p.z_w * (h ? ro : rv);
+        const int po = epi.pixel(m0 + e * 32 + r);
+        uint32_t pre[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          if (8 * g4 < C::COUT) pre[g4] = epi.load(po, 8 * g4 + 4 * h);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          if (8 * g4 >= C::COUT) continue;
+          const float4 bb = b4[0][g4];
+          const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(acc[e][4 * g4 + 0] - zwr)) * p.mult;
+          const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(acc[e][4 * g4 + 1] - zwr)) * p.mult;
+          const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(acc[e][4 * g4 + 2] - zwr)) * p.mult;
+          const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(acc[e][4 * g4 + 3] - zwr)) * p.mult;
+          epi.store(po, 8 * g4 + 4 * h, v0, v1, v2, v3, pre[g4]);
+        }
+      }
+    }
+    QBNN_INNER_AT(2);
+    QBNN_INNER_FLUSH();
+    return;
+  } else {
+    const uint8_t* ap[C::MB];
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb) {
+      const int m = (mblk * C::MB + mb) * 32 + r;
+      const int g = m / (C::HO * C::HO), rem = m % (C::HO * C::HO);
+      const int oh = rem / C::HO, ow = rem % C::HO;
+      ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::CIN + 16 * h;
+    }
+    v16i acc[C::MB][C::NB];
+    int rsum[C::MB];
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb) {
+      rsum[mb] = 0;
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0;
+    }
+    constexpr int U = C::KCHUNK, CPS = C::SLK / U;         // chunks per slab
+    struct Frags { v4i w[U][C::NB]; v4i x[U][C::MB]; };
+#pragma unroll
+    for (int slab = 0; slab < C::NSLAB; ++slab) {
+      __syncthreads();
+      QBNN_INNER_AT(0);
+      uint8_t* other = ring.buf[ring.cur ^ 1];
+      if (slab + 1 < C::NSLAB) dma_slab<C, NWAVES>(other, wq, slab + 1, wave, lane);
+      else prefetch_next(other);
+      if (slab == 0) after_first_barrier();
+      const uint8_t* wl = ring.buf[ring.cur] + ((nblk * C::NB) * C::SLK * 64 + lane) * 16;
+      ring.cur ^= 1;
+      if (active) {
+        // fragments of chunk c+1 (LDS -> VGPR) are in flight while the MFMAs of chunk c issue
+        auto load_chunk = [&](Frags& f, int c) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int ks = slab * C::SLK + c * U + u;
+#pragma unroll
+            for (int nb = 0; nb < C::NB; ++nb) f.w[u][nb] = *reinterpret_cast<const v4i*>(wl + (nb * C::SLK + c * U + u) * 1024);
+#pragma unroll
+            for (int mb = 0; mb < C::MB; ++mb) {
+              const v2i lo = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks));
+              const v2i hi = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks) + 8);
+              f.x[u][mb] = v4i{lo.x, lo.y, hi.x, hi.y};
+            }
+          }
+        };
+        auto mfma_chunk = [&](const Frags& f, int c) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int ks = slab * C::SLK + c * U + u;
+#pragma unroll
+            for (int mb = 0; mb < C::MB; ++mb) {
+              if (!C::USE_ONES) {
+                const int m0 = (h ? C::piece_valid(ks, 1, 0) : C::piece_valid(ks, 0, 0)) ? 0x01010101 : 0;
+                const int m1 = (h ? C::piece_valid(ks, 1, 1) : C::piece_valid(ks, 0, 1)) ? 0x01010101 : 0;
+                int rs_ = rsum[mb];
+                rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].x, m0, rs_, false);
+                rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].y, m0, rs_, false);
+                rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].z, m1, rs_, false);
+                rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].w, m1, rs_, false);
+                rsum[mb] = rs_;
+              }
+#pragma unroll
+              for (int nb = 0; nb < C::NB; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[u][nb], f.x[u][mb], acc[mb][nb], 0, 0, 0);
+            }
+          }
+        };
+        Frags f0, f1;
+        load_chunk(f0, 0);
+#pragma unroll
+        for (int c = 0; c < CPS; ++c) {
+          Frags& cur = (c & 1) ? f1 : f0;
+          Frags& nxt = (c & 1) ? f0 : f1;
+          if (c + 1 < CPS) load_chunk(nxt, c + 1);
+          mfma_chunk(cur, c);
+        }
+      }
+      QBNN_INNER_AT(1);
+    }
+    if (!active) return;
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb) {
+      int R;
+      if (C::USE_ONES) {
+        const int rv = acc[mb][C::ONES_TILE % C::NB][C::ONES_REG];
+        const int ro = __shfl_xor(rv, 32);
+        R = h ? ro : rv;
+      } else {
+        R = rsum[mb] + __shfl_xor(rsum[mb], 32);
+      }
+      const int zwr = p.z_w * R;
+      const int po = epi.pixel((mblk * C::MB + mb) * 32 + r);
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb) {
+        uint32_t pre[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+          pre[g4] = epi.load(po, (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+          const int c0 = (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h;
+          const float4 bb = b4[nb][g4];
+          const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(acc[mb][nb][4 * g4 + 0] - zwr)) * p.mult;
+          const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(acc[mb][nb][4 * g4 + 1] - zwr)) * p.mult;
+          const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(acc[mb][nb][4 * g4 + 2] - zwr)) * p.mult;
+          const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(acc[mb][nb][4 * g4 + 3] - zwr)) * p.mult;
+          epi.store(po, c0, v0, v1, v2, v3, pre[g4]);
+        }
+      }
+    }
+    QBNN_INNER_AT(2);
+    QBNN_INNER_FLUSH();
+  }
+}
+
 // ---- epilogue functors -----------------------------------------------------------------------------------------
 // (a) quint8 into a dense [M][COUT] staging buffer; optional quantized::add + ReLU against the quint8 residual that
 //     already sits at the same address (updated in place).
 template <int COUT, bool HAS_RES>
 struct EpiDense {
   uint8_t* outb; QConv p; QAdd a;
-  __device__ __forceinline__ uint32_t load(int m, int c0) const {
-    return HAS_RES ? *reinterpret_cast<const uint32_t*>(outb + m * COUT + c0) : 0u;
+  __device__ __forceinline__ int pixel(int m) const { return m * COUT; }
+  __device__ __forceinline__ uint32_t load(int po, int c0) const {
+    return HAS_RES ? *reinterpret_cast<const uint32_t*>(outb + po + c0) : 0u;
   }
-  __device__ __forceinline__ void store(int m, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
-    uint32_t* o = reinterpret_cast<uint32_t*>(outb + m * COUT + c0);
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
+    uint32_t* o = reinterpret_cast<uint32_t*>(outb + po + c0);
     v0 = med3f(v0, p.vlo, p.vhi); v1 = med3f(v1, p.vlo, p.vhi); v2 = med3f(v2, p.vlo, p.vhi); v3 = med3f(v3, p.vlo, p.vhi);
     const float zy = (float)p.z_y;
     if (!HAS_RES) {
@@ -524,9 +964,10 @@ __device__ __forceinline__ int tile_px_off(int m, int c0) {
 template <int HO, int COUT, int TILE_BYTES>
 struct EpiTile {
   uint8_t* dst; QConv p;
+  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, COUT, TILE_BYTES>(m, 0); }
   __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
-  __device__ __forceinline__ void store(int m, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
-    uint32_t* o = reinterpret_cast<uint32_t*>(dst + tile_px_off<HO, COUT, TILE_BYTES>(m, c0));
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
+    uint32_t* o = reinterpret_cast<uint32_t*>(dst + po + c0);
     const float mg = QBNN_MAGIC;
     *o = pack_low_bytes(med3f(v0, p.vlo, p.vhi) + mg, med3f(v1, p.vlo, p.vhi) + mg, med3f(v2, p.vlo, p.vhi) + mg,
                         med3f(v3, p.vlo, p.vhi) + mg);
@@ -538,11 +979,12 @@ struct EpiTile {
 template <int HO, int COUT, int TILE_BYTES>
 struct EpiTileResInPlace {
   uint8_t* xt; QConv p; QAdd a;
-  __device__ __forceinline__ uint32_t load(int m, int c0) const {
-    return *reinterpret_cast<const uint32_t*>(xt + tile_px_off<HO, COUT, TILE_BYTES>(m, c0));
+  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, COUT, TILE_BYTES>(m, 0); }
+  __device__ __forceinline__ uint32_t load(int po, int c0) const {
+    return *reinterpret_cast<const uint32_t*>(xt + po + c0);
   }
-  __device__ __forceinline__ void store(int m, int c0, float v0, float v1, float v2, float v3, uint32_t rqu) const {
-    uint32_t* o = reinterpret_cast<uint32_t*>(xt + tile_px_off<HO, COUT, TILE_BYTES>(m, c0));
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rqu) const {
+    uint32_t* o = reinterpret_cast<uint32_t*>(xt + po + c0);
     const int rq = (int)rqu;
     const float zy = (float)p.z_y, zr = (float)a.z_r;
     const float vv[4] = {v0, v1, v2, v3};
@@ -627,7 +1069,10 @@ static int launch_conv(const ConvArgs& a, int n_samples, bool has_res, hipStream
 //   fetched into registers while the current one computes (issue-early / write-late), so HBM latency is off the
 //   critical path.
 // =====================================================================================
-constexpr int BLK_THREADS = 512, BLK_WAVES = 8;
+#ifndef QBNN_BLK_THREADS
+#define QBNN_BLK_THREADS 512
+#endif
+constexpr int BLK_THREADS = QBNN_BLK_THREADS, BLK_WAVES = QBNN_BLK_THREADS / 64;
 
 struct BlockParams { QConv a, b; QAdd add; };       // stem.0, stem.3, add
 
@@ -637,6 +1082,7 @@ struct ChainArgs {
   uint8_t* y; int64_t y_ss;           // block-chain output [S][B][H][H][C] quint8
   int B, n_samples;
   int z_in;                           // zero point of x
+  unsigned long long* dbg;            // diagnostic builds only
   BlockParams blk[NBLK];
 };
 
@@ -647,7 +1093,11 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
   constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
   uint8_t* xt = smem;
   uint8_t* tt = smem + TILES;
-  float* bias_lds = reinterpret_cast<float*>(smem + 2 * TILES);        // [NBLK][2][COUT]
+  WRing ring;
+  ring.buf[0] = smem + 2 * TILES;
+  ring.buf[1] = ring.buf[0] + C::SLAB_BYTES;
+  ring.cur = 0;
+  float* bias_lds = reinterpret_cast<float*>(ring.buf[1] + C::SLAB_BYTES);        // [NBLK][2][COUT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
@@ -663,6 +1113,8 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
     load_bias<C::COUT, BLK_THREADS>(bias_lds + (2 * k + 1) * C::COUT, a.blk[k].b.bias, tid);
   }
 
+  // input prefetch registers.  The loads are unconditional (address clamped, value zeroed at use) and are issued
+  // right after a barrier, so the following barrier's vmcnt(0) finds them long landed.
   v4i pre[PER_T];
   auto fetch = [&](int item) {
     const int s = item / groups, img0 = (item - s * groups) * C::G;
@@ -670,17 +1122,24 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
 #pragma unroll
     for (int j = 0; j < PER_T; ++j) {
       const int i = tid + j * BLK_THREADS;
-      pre[j] = v4i{0, 0, 0, 0};
-      if (i < NCH) {
-        const int g = i / CPI, rem = i - g * CPI;
-        if (img0 + g < a.B) pre[j] = *reinterpret_cast<const v4i*>(xs + ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16);
-      }
+      const int g = i / CPI, rem = i - g * CPI;
+      const bool ok = (i < NCH) && (img0 + g < a.B);
+      const int64_t off = ok ? ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16 : 0;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + off);
     }
   };
+  auto sample_of = [&](int item) { return item / groups; };
+
   int item = blockIdx.x;
-  if (item < n_items) fetch(item);
+  if (item < n_items) {
+    fetch(item);
+    dma_slab<C, BLK_WAVES>(ring.buf[ring.cur], a.blk[0].a.w + (int64_t)sample_of(item) * a.blk[0].a.w_ss, 0, wave, lane);
+  }
+  QBNN_STAMP_DECL
   for (; item < n_items; item += gridDim.x) {
     const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const int next = item + (int)gridDim.x;
+    QBNN_STAMP_START();
     // ---- write-late: registers -> centred X tile interior
     {
       const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
@@ -689,30 +1148,38 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
         const int i = tid + j * BLK_THREADS;
         if (i < NCH) {
           const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+          const bool ok = img0 + g < a.B;
           const v4i v = pre[j];
           uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
-          *reinterpret_cast<v2i*>(d) = v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)};
-          *reinterpret_cast<v2i*>(d + 8) = v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)};
+          *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
+          *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
         }
       }
     }
-    // ---- issue-early: next item's input travels while this one computes
-    if (item + (int)gridDim.x < n_items) fetch(item + gridDim.x);
-    __syncthreads();
+    QBNN_STAMP_AT(0);
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) {
       const BlockParams& bp = a.blk[k];
       {
         EpiTile<C::HO, C::COUT, C::TILE_BYTES> epi{tt, bp.a};
-        conv_passes<C, decltype(epi), BLK_WAVES>(xt, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
+        conv_lds<C, decltype(epi), BLK_WAVES>(xt, ring, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane,
+            [&](uint8_t* dst) { dma_slab<C, BLK_WAVES>(dst, bp.b.w + (int64_t)s * bp.b.w_ss, 0, wave, lane); },
+            [&]() { if (k == 0 && next < n_items) fetch(next); });
       }
-      __syncthreads();
+      QBNN_STAMP_AT(2);
       {
         EpiTileResInPlace<C::HO, C::COUT, C::TILE_BYTES> epi{xt, bp.b, bp.add};
-        conv_passes<C, decltype(epi), BLK_WAVES>(tt, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
+        conv_lds<C, decltype(epi), BLK_WAVES>(tt, ring, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane,
+            [&](uint8_t* dst) {
+              if (k + 1 < NBLK) dma_slab<C, BLK_WAVES>(dst, a.blk[k + 1 < NBLK ? k + 1 : 0].a.w + (int64_t)s * a.blk[k + 1 < NBLK ? k + 1 : 0].a.w_ss, 0, wave, lane);
+              else if (next < n_items) dma_slab<C, BLK_WAVES>(dst, a.blk[0].a.w + (int64_t)sample_of(next) * a.blk[0].a.w_ss, 0, wave, lane);
+            },
+            [&]() {});
       }
-      __syncthreads();
+      QBNN_STAMP_AT(4);
     }
+    __syncthreads();
+    QBNN_STAMP_AT(5);
     // ---- X tile interior (centred by the last add's zero point) -> quint8 -> HBM
     {
       const uint32_t z4 = (uint32_t)a.blk[NBLK - 1].add.z_o * 0x01010101u;
@@ -727,13 +1194,19 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
         }
       }
     }
-    __syncthreads();      // X tile free for the next item
+    QBNN_STAMP_AT(6);
+    __syncthreads();      // X tile free for the next item's write-late
+    QBNN_STAMP_AT(7);
   }
+#ifdef QBNN_STAMP
+  if (a.dbg && (tid & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(a.dbg + wave * 8 + i, st_acc[i]);
+#endif
 }
 
 template <class C, int NBLK>
 static int launch_block_chain(const ChainArgs<NBLK>& a, hipStream_t st) {
-  constexpr int LDS = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + NBLK * 2 * C::COUT * 4;
+  constexpr int LDS = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * C::SLAB_BYTES + NBLK * 2 * C::COUT * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)block_chain_i8_kernel<C, NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
@@ -820,7 +1293,7 @@ QBNN_EXPORT int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* 
 using Blk_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;
 using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;
 using Blk_96  = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3>;
-using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3>;
+using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 4, 1, 2>;
 
 template <int NBLK>
 static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
@@ -829,6 +1302,9 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
   ChainArgs<NBLK> a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = B; a.n_samples = n_samples; a.z_in = z_x;
+#ifdef QBNN_STAMP
+  a.dbg = g_stamp_buf;
+#endif
   float s_in = s_x; int z_in = z_x;
   for (int k = 0; k < NBLK; ++k) {
     const qbnn_block_desc& b = blk[k];

@@ -218,6 +218,9 @@ class _BBBInt8(nn.Module):
 
     def sample_weights(self, device, samples=None, seed=None, sample_begin=None, eps=None):
         """W_q for S samples in this layer's packed layout: int8 [S, nbytes]  (conv_q.py:113-119 chain, fused)."""
+        if samples is None and eps is None and _MC.eps is None and getattr(self, "_presampled", None) is not None:
+            w, self._presampled = self._presampled, None      # produced by sample_all_weights() for this MC batch
+            return w
         S = _MC.samples if samples is None else samples
         seed = _MC.seed if seed is None else seed
         sb = _MC.sample_begin if sample_begin is None else sample_begin
@@ -236,6 +239,25 @@ class _BBBInt8(nn.Module):
 
     def _a_hi(self):
         return UINT_BOUNDS[getattr(self.args, "activation_precision", 7)][1]
+
+
+def sample_all_weights(layers, device):
+    """W_q of every layer in `layers` for the current mc_context in ONE kernel launch (qbnn_sample_weights_i8_multi);
+    each layer's next sample_weights() call returns its slab.  Same values as per-layer sampling."""
+    if _MC.eps is not None:
+        return                                    # parity mode (injected eps): per-layer path
+    tab = (_lib.SamplerLayer * len(layers))()
+    outs = []
+    for t, layer in zip(tab, layers):
+        pk = layer._ensure_packed(device)
+        w = torch.empty((_MC.samples, pk["nbytes"]), dtype=torch.int8, device=device)
+        outs.append(w)
+        t.mu_packed, t.sigma_packed, t.w_out, t.w_sample_stride = pk["mu"].data_ptr(), pk["sigma"].data_ptr(), w.data_ptr(), pk["nbytes"]
+        t.cout, t.k, t.krow, t.layout, t.layer_id, t.params = pk["cout"], pk["k"], pk["krow"], layer.layout, layer.layer_id, pk["sp"]
+    with timed("sample_weights_i8_multi"):
+        _lib.check(_lib.lib().qbnn_sample_weights_i8_multi(tab, len(layers), _MC.seed, _MC.sample_begin, _MC.samples, _stream()))
+    for layer, w in zip(layers, outs):
+        layer._presampled = w
 
 
 # ------------------------------------------------------------------ conv

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .layers import Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_context, timed
+from .layers import Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_context, timed, sample_all_weights
 from .quant import UINT_BOUNDS, check_bits
 
 
@@ -191,6 +191,7 @@ class ConvNetwork_ResNet(nn.Module):
         col = torch.empty((B, H * W, 32), dtype=torch.int8, device=dev)
         with timed("im2col3x3_c3"):
             _lib.check(L.qbnn_im2col3x3_c3(_lib.ptr(xq.data), B, H, W, xq.zero_point, _lib.ptr(col), _lib.current_stream()))
+        sample_all_weights(self.stochastic_layers(), dev)      # one launch for the 21 layers of this MC batch
         l0 = self.layers[0]
         h = l0._conv(xq, l0.sample_weights(dev), S, im2col=col)
         if record is not None:
