@@ -129,6 +129,20 @@ int qbnn_block_chain_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x,
                            int32_t C, int32_t a_hi, const qbnn_block_desc* host_blocks, int32_t n_blocks, uint8_t* y,
                            int64_t y_sample_stride, int32_t n_samples, void* stream);
 
+/* A down-sampling BasicBlock (stride 2, Cout = 2 Cin; models_bbb.py:146-183) fused in one persistent kernel:
+ *   shortcut.0 (1x1/s2 Conv2d) -> clamp ;  stem.0 (3x3/s2 ConvReLU2d) -> clamp -> stem.3 (3x3 Conv2d) -> clamp ;
+ *   Add(stem, shortcut) -> clamp -> ReLU -> clamp.     `blk` describes stem.0 / stem.3 / add as in qbnn_block_desc. */
+typedef struct qbnn_down_desc {
+  qbnn_block_desc blk;
+  const int8_t* w_s; int64_t w_s_sample_stride; const float* bias_s;   /* shortcut.0 sampled weights, bias */
+  float s_ws; int32_t z_ws;                                            /* shortcut.0 add_weight qparams    */
+  float s_s; int32_t z_s;                                              /* shortcut.0 output qparams        */
+} qbnn_down_desc;
+
+int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x, int32_t z_x, int32_t B, int32_t H,
+                          int32_t Cin, int32_t a_hi, const qbnn_down_desc* host_desc, uint8_t* y, int64_t y_sample_stride,
+                          int32_t n_samples, void* stream);
+
 /* QuantStub + clamp_activation (models_bbb.py:227-229): fp32 NCHW -> uint8 NHWC. */
 int qbnn_quantize_input_nchw(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, float scale,
                              int32_t zero_point, int32_t a_hi, uint8_t* out, void* stream);

@@ -44,6 +44,11 @@ class BlockDesc(C.Structure):
                 ("s_o", C.c_float), ("z_o", C.c_int32)]
 
 
+class DownDesc(C.Structure):
+    _fields_ = [("blk", BlockDesc), ("w_s", C.c_void_p), ("w_s_sample_stride", C.c_int64), ("bias_s", C.c_void_p),
+                ("s_ws", C.c_float), ("z_ws", C.c_int32), ("s_s", C.c_float), ("z_s", C.c_int32)]
+
+
 class HeadDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("k", C.c_int32), ("C", C.c_int32), ("N", C.c_int32),
                 ("s_x", C.c_float), ("z_x", C.c_int32),
@@ -53,7 +58,7 @@ class HeadDesc(C.Structure):
 
 
 EXPORTS = ["qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_conv2d_i8_mc",
-           "qbnn_block_chain_i8_mc",
+           "qbnn_block_chain_i8_mc", "qbnn_block_down_i8_mc",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_head_i8_mc", "qbnn_reduce_moments",
            "qbnn_last_error", "qbnn_version"]
 
@@ -79,6 +84,7 @@ def lib():
         L.qbnn_sample_weights_i8_multi.argtypes = [C.POINTER(SamplerLayer), i32, u64, u32, i32, vp]
         L.qbnn_conv2d_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, C.POINTER(ConvDesc), vp]
         L.qbnn_block_chain_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(BlockDesc), i32, vp, i64, i32, vp]
+        L.qbnn_block_down_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(DownDesc), vp, i64, i32, vp]
         L.qbnn_quantize_input_nchw.argtypes = [vp, i32, i32, i32, i32, f, i32, i32, vp, vp]
         L.qbnn_im2col3x3_c3.argtypes = [vp, i32, i32, i32, i32, vp, vp]
         L.qbnn_head_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i32, C.POINTER(HeadDesc), vp]

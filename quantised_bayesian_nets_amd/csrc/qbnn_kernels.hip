@@ -1289,6 +1289,172 @@ QBNN_EXPORT int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* 
   return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_mc: unsupported geometry%s Cin=%ld Cout=%ld", "", d->Cin, d->Cout);
 }
 
+// =====================================================================================
+// Fused down-sampling BasicBlock (models_bbb.py:146-183 with stride 2): shortcut 1x1/s2 conv, stem.0 3x3/s2 ConvReLU,
+// stem.3 3x3 conv, Add, ReLU in one persistent kernel.
+//   X tile (Cin, HIN): centred block input      --conv_s-->  SC: dense quint8 [M][COUT] (the residual operand)
+//                                               --conv_a-->  T tile (COUT, HO): centred stem.0 output
+//   T --conv_b--> + SC --> SC in place (block output, quint8) --> HBM
+// =====================================================================================
+struct DownArgs {
+  const uint8_t* x; int64_t x_ss;
+  uint8_t* y; int64_t y_ss;
+  int B, n_samples, z_in;
+  QConv s, a, b; QAdd add;
+};
+
+template <class CA, class CS, class CB>
+__global__ __launch_bounds__(BLK_THREADS) void block_down_i8_kernel(const DownArgs a) {
+  static_assert(CA::M == CS::M && CA::M == CB::M && CA::G == CS::G && CA::G == CB::G, "one work item, three convs");
+  static_assert(CA::COUT == CB::CIN && CA::COUT == CB::COUT && CS::COUT == CB::COUT && CA::HO == CB::HIN, "block geometry");
+  static_assert(CA::TILE_BYTES == CS::TILE_BYTES && CA::CIN == CS::CIN && CA::HIN == CS::HIN, "shared input tile");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int XB = CA::G * CA::TILE_BYTES + CA::TILE_SLACK;
+  constexpr int TB = CB::G * CB::TILE_BYTES + CB::TILE_SLACK;
+  constexpr int SLAB = CA::SLAB_BYTES > CB::SLAB_BYTES ? (CA::SLAB_BYTES > CS::SLAB_BYTES ? CA::SLAB_BYTES : CS::SLAB_BYTES)
+                                                        : (CB::SLAB_BYTES > CS::SLAB_BYTES ? CB::SLAB_BYTES : CS::SLAB_BYTES);
+  constexpr int COUT = CB::COUT;
+  uint8_t* xt = smem;
+  uint8_t* tt = smem + XB;
+  uint8_t* sc = tt + TB;
+  WRing ring;
+  ring.buf[0] = sc + CB::OUT_BYTES;
+  ring.buf[1] = ring.buf[0] + SLAB;
+  ring.cur = 0;
+  float* bias_lds = reinterpret_cast<float*>(ring.buf[1] + SLAB);       // [3][COUT]: s, a, b
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  constexpr int CPR = CA::ROWB / 16, CPI = CA::HIN * CPR, NCH = CA::G * CPI;
+  constexpr int PER_T = (NCH + BLK_THREADS - 1) / BLK_THREADS;
+  const int groups = (a.B + CA::G - 1) / CA::G;
+  const int n_items = a.n_samples * groups;
+
+  zero_halo<CA::TW, CA::CIN, CA::TILE_BYTES, CA::G, BLK_THREADS>(xt, tid);
+  zero_halo<CB::TW, CB::CIN, CB::TILE_BYTES, CB::G, BLK_THREADS>(tt, tid);
+  load_bias<COUT, BLK_THREADS>(bias_lds, a.s.bias, tid);
+  load_bias<COUT, BLK_THREADS>(bias_lds + COUT, a.a.bias, tid);
+  load_bias<COUT, BLK_THREADS>(bias_lds + 2 * COUT, a.b.bias, tid);
+
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * CA::G;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = tid + j * BLK_THREADS;
+      const int g = i / CPI, rem = i - g * CPI;
+      const bool ok = (i < NCH) && (img0 + g < a.B);
+      const int64_t off = ok ? ((int64_t)(img0 + g) * CA::HIN) * CA::ROWB + (int64_t)rem * 16 : 0;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + off);
+    }
+  };
+  int item = blockIdx.x;
+  if (item < n_items) {
+    fetch(item);
+    dma_slab<CS, BLK_WAVES>(ring.buf[ring.cur], a.s.w + (int64_t)(item / groups) * a.s.w_ss, 0, wave, lane);
+  }
+  for (; item < n_items; item += gridDim.x) {
+    const int s = item / groups, img0 = (item - s * groups) * CA::G;
+    const int next = item + (int)gridDim.x;
+    {
+      const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+#pragma unroll
+      for (int j = 0; j < PER_T; ++j) {
+        const int i = tid + j * BLK_THREADS;
+        if (i < NCH) {
+          const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+          const bool ok = img0 + g < a.B;
+          const v4i v = pre[j];
+          uint8_t* d = xt + g * CA::TILE_BYTES + (row + 1) * CA::PITCH + CA::CIN + within * 16;
+          *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
+          *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
+        }
+      }
+    }
+    {
+      EpiDense<COUT, false> epi{sc, a.s, a.add};
+      conv_lds<CS, decltype(epi), BLK_WAVES>(xt, ring, a.s.w + (int64_t)s * a.s.w_ss, bias_lds, a.s, epi, wave, lane,
+          [&](uint8_t* dst) { dma_slab<CA, BLK_WAVES>(dst, a.a.w + (int64_t)s * a.a.w_ss, 0, wave, lane); },
+          [&]() { if (next < n_items) fetch(next); });
+    }
+    {
+      EpiTile<CB::HIN, CB::CIN, CB::TILE_BYTES> epi{tt, a.a};
+      conv_lds<CA, decltype(epi), BLK_WAVES>(xt, ring, a.a.w + (int64_t)s * a.a.w_ss, bias_lds + COUT, a.a, epi, wave, lane,
+          [&](uint8_t* dst) { dma_slab<CB, BLK_WAVES>(dst, a.b.w + (int64_t)s * a.b.w_ss, 0, wave, lane); }, [&]() {});
+    }
+    {
+      EpiDense<COUT, true> epi{sc, a.b, a.add};
+      conv_lds<CB, decltype(epi), BLK_WAVES>(tt, ring, a.b.w + (int64_t)s * a.b.w_ss, bias_lds + 2 * COUT, a.b, epi, wave, lane,
+          [&](uint8_t* dst) { if (next < n_items) dma_slab<CS, BLK_WAVES>(dst, a.s.w + (int64_t)(next / groups) * a.s.w_ss, 0, wave, lane); },
+          [&]() {});
+    }
+    __syncthreads();
+    {
+      constexpr int IMG_OUT = CB::HO * CB::HO * COUT;
+      uint8_t* ys = a.y + (int64_t)s * a.y_ss;
+      for (int i = tid; i < CB::M * COUT / 16; i += BLK_THREADS)
+        if (img0 + (i * 16) / IMG_OUT < a.B)
+          *reinterpret_cast<v4i*>(ys + (int64_t)img0 * IMG_OUT + (int64_t)i * 16) = reinterpret_cast<const v4i*>(sc)[i];
+    }
+    __syncthreads();
+  }
+}
+
+template <class CA, class CS, class CB>
+static int launch_block_down(const DownArgs& a, hipStream_t st) {
+  constexpr int SLAB = CA::SLAB_BYTES > CB::SLAB_BYTES ? (CA::SLAB_BYTES > CS::SLAB_BYTES ? CA::SLAB_BYTES : CS::SLAB_BYTES)
+                                                        : (CB::SLAB_BYTES > CS::SLAB_BYTES ? CB::SLAB_BYTES : CS::SLAB_BYTES);
+  constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + CB::OUT_BYTES + 2 * SLAB + 3 * CB::COUT * 4;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)block_down_i8_kernel<CA, CS, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  const int groups = (a.B + CA::G - 1) / CA::G;
+  const int n_items = a.n_samples * groups;
+  int grid = 256;
+  if (grid > n_items) grid = n_items;
+  hipLaunchKernelGGL((block_down_i8_kernel<CA, CS, CB>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
+  return check_launch("qbnn_block_down_i8_mc");
+}
+
+//                           CIN COUT K  S  HIN HALO G  MB NB
+using D24_a = ConvCfg<24, 48, 3, 2, 32, 1, 1, 1, 2>;
+using D24_s = ConvCfg<24, 48, 1, 2, 32, 1, 1, 1, 2>;
+using D24_b = ConvCfg<48, 48, 3, 1, 16, 1, 1, 1, 2>;
+using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 2, 1, 3>;
+using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 2, 1, 3>;
+using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 2, 1, 3>;
+using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 4, 1, 2>;
+using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 4, 1, 2>;
+using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 4, 1, 2>;
+
+QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cin,
+                                      int32_t a_hi, const qbnn_down_desc* d, uint8_t* y, int64_t y_ss, int32_t n_samples,
+                                      void* stream) {
+  if (!x || !y || !d || n_samples <= 0 || B <= 0 || !d->blk.w_a || !d->blk.w_b || !d->w_s)
+    return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: bad argument%s");
+  DownArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = B; a.n_samples = n_samples; a.z_in = z_x;
+  qbnn_conv_desc c;
+  memset(&c, 0, sizeof(c));
+  c.a_hi = a_hi;
+  int rc;
+  c.s_x = s_x; c.z_x = z_x; c.s_w = d->s_ws; c.z_w = d->z_ws; c.s_y = d->s_s; c.z_y = d->z_s; c.relu = 0; c.has_bias = d->bias_s != nullptr;
+  if ((rc = fill_qconv(a.s, d->w_s, d->w_s_sample_stride, d->bias_s, &c))) return rc;
+  c.s_w = d->blk.s_wa; c.z_w = d->blk.z_wa; c.s_y = d->blk.s_a; c.z_y = d->blk.z_a; c.relu = 1; c.has_bias = d->blk.bias_a != nullptr;
+  if ((rc = fill_qconv(a.a, d->blk.w_a, d->blk.w_a_sample_stride, d->blk.bias_a, &c))) return rc;
+  c.s_x = d->blk.s_a; c.z_x = d->blk.z_a; c.s_w = d->blk.s_wb; c.z_w = d->blk.z_wb; c.s_y = d->blk.s_b; c.z_y = d->blk.z_b; c.relu = 0;
+  c.has_bias = d->blk.bias_b != nullptr;
+  if ((rc = fill_qconv(a.b, d->blk.w_b, d->blk.w_b_sample_stride, d->blk.bias_b, &c))) return rc;
+  c.s_r = d->s_s; c.z_r = d->z_s; c.s_o = d->blk.s_o; c.z_o = d->blk.z_o;
+  if ((rc = fill_qadd(a.add, &c))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 24 && H == 32) return launch_block_down<D24_a, D24_s, D24_b>(a, st);
+  if (Cin == 48 && H == 16) return launch_block_down<D48_a, D48_s, D48_b>(a, st);
+  if (Cin == 96 && H == 8) return launch_block_down<D96_a, D96_s, D96_b>(a, st);
+  return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
+}
+
 //                          CIN COUT K  S  HIN HALO G  MB NB
 using Blk_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;
 using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;

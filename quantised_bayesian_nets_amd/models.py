@@ -56,6 +56,41 @@ class BasicBlock(nn.Module):
         return self.stem[3]._conv(out, w3, S, residual=sc, add_qparams=(self.add.add.scale, self.add.add.zero_point))
 
 
+def _fill_block_desc(d, blk, dev, keep):
+    ca, cb = blk.stem[0], blk.stem[3]
+    wa, wb = ca.sample_weights(dev), cb.sample_weights(dev)
+    pa, pb = ca._ensure_packed(dev), cb._ensure_packed(dev)
+    keep += [wa, wb]
+    d.w_a, d.w_a_sample_stride, d.bias_a = wa.data_ptr(), wa.shape[1], (pa["bias"].data_ptr() if pa["bias"] is not None else None)
+    d.s_wa, d.z_wa, d.s_a, d.z_a = ca.add_weight.scale, ca.add_weight.zero_point, ca.scale, ca.zero_point
+    d.w_b, d.w_b_sample_stride, d.bias_b = wb.data_ptr(), wb.shape[1], (pb["bias"].data_ptr() if pb["bias"] is not None else None)
+    d.s_wb, d.z_wb, d.s_b, d.z_b = cb.add_weight.scale, cb.add_weight.zero_point, cb.scale, cb.zero_point
+    d.s_o, d.z_o = blk.add.add.scale, blk.add.add.zero_point
+
+
+def run_down_block(blk, x):
+    """A down-sampling BasicBlock (shortcut conv + stem + add) in ONE persistent fused kernel (qbnn_block_down_i8_mc)."""
+    S = _MC.samples
+    dev = x.data.device
+    keep = []
+    d = _lib.DownDesc()
+    _fill_block_desc(d.blk, blk, dev, keep)
+    cs = blk.shortcut[0]
+    ws = cs.sample_weights(dev)
+    ps = cs._ensure_packed(dev)
+    keep.append(ws)
+    d.w_s, d.w_s_sample_stride, d.bias_s = ws.data_ptr(), ws.shape[1], (ps["bias"].data_ptr() if ps["bias"] is not None else None)
+    d.s_ws, d.z_ws, d.s_s, d.z_s = cs.add_weight.scale, cs.add_weight.zero_point, cs.scale, cs.zero_point
+    _, B, H, W, Cin = x.data.shape
+    Cout = blk.stem[0].out_channels
+    y = torch.empty((S, B, H // 2, W // 2, Cout), dtype=torch.uint8, device=dev)
+    a_hi = UINT_BOUNDS[blk.args.activation_precision][1]
+    with timed("block_down_i8 %dx%d %d->%d" % (H, W, Cin, Cout)):
+        _lib.check(_lib.lib().qbnn_block_down_i8_mc(_lib.ptr(x.data), x.sample_stride(), x.scale, x.zero_point, B, H, Cin, a_hi,
+                                                    C.byref(d), _lib.ptr(y), y[0].numel(), S, _lib.current_stream()))
+    return MCQTensor(y, blk.add.add.scale, blk.add.add.zero_point)
+
+
 def run_identity_chain(blocks, x):
     """1 or 2 identity BasicBlocks (no shortcut conv) in ONE persistent fused kernel (qbnn_block_chain_i8_mc):
     activations stay in LDS between stem.0, stem.3 and the residual add.  Same results as calling the blocks."""
@@ -203,11 +238,14 @@ class ConvNetwork_ResNet(nn.Module):
                 if len(blocks[0].shortcut) == 0:
                     h = run_identity_chain(blocks, h)
                 else:
-                    h = blocks[0](h)
+                    h = run_down_block(blocks[0], h)
                     h = run_identity_chain(blocks[1:], h)
                 continue
             for bi, blk in enumerate(blocks):
-                h = blk(h) if not (self.fuse_blocks and len(blk.shortcut) == 0) else run_identity_chain([blk], h)
+                if not self.fuse_blocks:
+                    h = blk(h)
+                else:
+                    h = run_identity_chain([blk], h) if len(blk.shortcut) == 0 else run_down_block(blk, h)
                 if record is not None:
                     record[f"layers.{li}.{bi}.out"] = h.data
         fc = self.layers[9]

@@ -149,7 +149,7 @@ def test_fused_block_chain_equals_layerwise_and_golden(golden):
     """qbnn_block_chain_i8_mc (persistent fused BasicBlocks) against the layer-by-layer C ABI path and the golden."""
     import quantised_bayesian_nets_amd as q
     from quantised_bayesian_nets_amd.layers import MCQTensor
-    from quantised_bayesian_nets_amd.models import run_identity_chain
+    from quantised_bayesian_nets_amd.models import run_identity_chain, run_down_block
     g = golden
     m = _model(g)
     rec, st = g["rec"], g["state"]
@@ -169,6 +169,15 @@ def test_fused_block_chain_equals_layerwise_and_golden(golden):
         assert torch.equal(y1.data, ref1.data) and torch.equal(y2.data, ref2.data)
         assert np.array_equal(y1.data[0].cpu().numpy(), rec["layers.3.0.out"])
         assert np.array_equal(y2.data[0].cpu().numpy(), rec["layers.3.1.out"])
+        # down-sampling blocks (shortcut conv + stem + add fused)
+        prev, key = "layers.3.1.out", "layers.3.1.add.add."
+        for li in (4, 5, 6):
+            x = act(prev, key)
+            y = run_down_block(m.layers[li][0], x)
+            ref = m.layers[li][0](x)
+            assert torch.equal(y.data, ref.data), ("down", li)
+            assert np.array_equal(y.data[0].cpu().numpy(), rec[f"layers.{li}.0.out"]), ("down", li)
+            prev, key = f"layers.{li}.1.out", f"layers.{li}.1.add.add."
         # second block of the other stages
         for li in (4, 5, 6):
             x = act(f"layers.{li}.0.out", f"layers.{li}.0.add.add.")
