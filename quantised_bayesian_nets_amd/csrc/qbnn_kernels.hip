@@ -251,8 +251,11 @@ QBNN_EXPORT void qbnn_debug_read_inner(unsigned long long* host4) {
 #define QBNN_INNER_FLUSH() do {} while (0)
 #endif
 
-template <int CIN_, int COUT_, int KSZ_, int STRIDE_, int HIN_, int HALO_, int G_, int MB_, int NB_>
+template <int CIN_, int COUT_, int KSZ_, int STRIDE_, int HIN_, int HALO_, int G_, int MB_, int NB_, bool RING_ = true>
 struct ConvCfg {
+  // RING: fused kernels stage this conv's weights through the LDS slab ring (conv_lds); false = every wave streams
+  // its fragments from L2 (conv_passes) -- better when the conv's weights are far larger than the ring (192 channels)
+  static constexpr bool RING = RING_;
   static constexpr int CIN = CIN_, COUT = COUT_, KSZ = KSZ_, STRIDE = STRIDE_, HIN = HIN_, HALO = HALO_;
   static constexpr int G = G_, MB = MB_, NB = NB_;
   static constexpr int PAD = (KSZ - 1) / 2;
@@ -919,6 +922,25 @@ __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const
   }
 }
 
+// conv core selection for the fused kernels
+template <class C, class Epi, int NWAVES, class FNext, class FHook>
+__device__ __forceinline__ void conv_any(const uint8_t* tile, WRing& ring, const int8_t* wq, const float* bias_lds, const QConv& p,
+                                         Epi& epi, int wave, int lane, FNext prefetch_next, FHook after_first_barrier) {
+  if constexpr (C::RING) {
+    conv_lds<C, Epi, NWAVES>(tile, ring, wq, bias_lds, p, epi, wave, lane, prefetch_next, after_first_barrier);
+  } else {
+    __syncthreads();                 // input tile of this conv complete
+    prefetch_next(ring.buf[ring.cur ^ 1]);
+    ring.cur ^= 1;
+    after_first_barrier();
+    conv_passes<C, Epi, NWAVES>(tile, wq, bias_lds, p, epi, wave, lane);
+  }
+}
+template <class C, int NWAVES>
+__device__ __forceinline__ void dma_slab_if_ring(uint8_t* dst, const int8_t* wq, int wave, int lane) {
+  if constexpr (C::RING) dma_slab<C, NWAVES>(dst, wq, 0, wave, lane);
+}
+
 // ---- epilogue functors -----------------------------------------------------------------------------------------
 // (a) quint8 into a dense [M][COUT] staging buffer; optional quantized::add + ReLU against the quint8 residual that
 //     already sits at the same address (updated in place).
@@ -1094,10 +1116,11 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
   uint8_t* xt = smem;
   uint8_t* tt = smem + TILES;
   WRing ring;
+  constexpr int RSLAB = C::RING ? C::SLAB_BYTES : 16;
   ring.buf[0] = smem + 2 * TILES;
-  ring.buf[1] = ring.buf[0] + C::SLAB_BYTES;
+  ring.buf[1] = ring.buf[0] + RSLAB;
   ring.cur = 0;
-  float* bias_lds = reinterpret_cast<float*>(ring.buf[1] + C::SLAB_BYTES);        // [NBLK][2][COUT]
+  float* bias_lds = reinterpret_cast<float*>(ring.buf[1] + RSLAB);        // [NBLK][2][COUT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
@@ -1133,7 +1156,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
   int item = blockIdx.x;
   if (item < n_items) {
     fetch(item);
-    dma_slab<C, BLK_WAVES>(ring.buf[ring.cur], a.blk[0].a.w + (int64_t)sample_of(item) * a.blk[0].a.w_ss, 0, wave, lane);
+    dma_slab_if_ring<C, BLK_WAVES>(ring.buf[ring.cur], a.blk[0].a.w + (int64_t)sample_of(item) * a.blk[0].a.w_ss, wave, lane);
   }
   QBNN_STAMP_DECL
   for (; item < n_items; item += gridDim.x) {
@@ -1162,17 +1185,17 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
       const BlockParams& bp = a.blk[k];
       {
         EpiTile<C::HO, C::COUT, C::TILE_BYTES> epi{tt, bp.a};
-        conv_lds<C, decltype(epi), BLK_WAVES>(xt, ring, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane,
-            [&](uint8_t* dst) { dma_slab<C, BLK_WAVES>(dst, bp.b.w + (int64_t)s * bp.b.w_ss, 0, wave, lane); },
+        conv_any<C, decltype(epi), BLK_WAVES>(xt, ring, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane,
+            [&](uint8_t* dst) { dma_slab_if_ring<C, BLK_WAVES>(dst, bp.b.w + (int64_t)s * bp.b.w_ss, wave, lane); },
             [&]() { if (k == 0 && next < n_items) fetch(next); });
       }
       QBNN_STAMP_AT(2);
       {
         EpiTileResInPlace<C::HO, C::COUT, C::TILE_BYTES> epi{xt, bp.b, bp.add};
-        conv_lds<C, decltype(epi), BLK_WAVES>(tt, ring, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane,
+        conv_any<C, decltype(epi), BLK_WAVES>(tt, ring, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane,
             [&](uint8_t* dst) {
-              if (k + 1 < NBLK) dma_slab<C, BLK_WAVES>(dst, a.blk[k + 1 < NBLK ? k + 1 : 0].a.w + (int64_t)s * a.blk[k + 1 < NBLK ? k + 1 : 0].a.w_ss, 0, wave, lane);
-              else if (next < n_items) dma_slab<C, BLK_WAVES>(dst, a.blk[0].a.w + (int64_t)sample_of(next) * a.blk[0].a.w_ss, 0, wave, lane);
+              if (k + 1 < NBLK) dma_slab_if_ring<C, BLK_WAVES>(dst, a.blk[k + 1 < NBLK ? k + 1 : 0].a.w + (int64_t)s * a.blk[k + 1 < NBLK ? k + 1 : 0].a.w_ss, wave, lane);
+              else if (next < n_items) dma_slab_if_ring<C, BLK_WAVES>(dst, a.blk[0].a.w + (int64_t)sample_of(next) * a.blk[0].a.w_ss, wave, lane);
             },
             [&]() {});
       }
@@ -1206,7 +1229,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
 
 template <class C, int NBLK>
 static int launch_block_chain(const ChainArgs<NBLK>& a, hipStream_t st) {
-  constexpr int LDS = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * C::SLAB_BYTES + NBLK * 2 * C::COUT * 4;
+  constexpr int LDS = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * (C::RING ? C::SLAB_BYTES : 16) + NBLK * 2 * C::COUT * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)block_chain_i8_kernel<C, NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
@@ -1311,8 +1334,8 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_i8_kernel(const DownAr
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int XB = CA::G * CA::TILE_BYTES + CA::TILE_SLACK;
   constexpr int TB = CB::G * CB::TILE_BYTES + CB::TILE_SLACK;
-  constexpr int SLAB = CA::SLAB_BYTES > CB::SLAB_BYTES ? (CA::SLAB_BYTES > CS::SLAB_BYTES ? CA::SLAB_BYTES : CS::SLAB_BYTES)
-                                                        : (CB::SLAB_BYTES > CS::SLAB_BYTES ? CB::SLAB_BYTES : CS::SLAB_BYTES);
+  constexpr int SA = CA::RING ? CA::SLAB_BYTES : 16, SS = CS::RING ? CS::SLAB_BYTES : 16, SB = CB::RING ? CB::SLAB_BYTES : 16;
+  constexpr int SLAB = SA > SB ? (SA > SS ? SA : SS) : (SB > SS ? SB : SS);
   constexpr int COUT = CB::COUT;
   uint8_t* xt = smem;
   uint8_t* tt = smem + XB;
@@ -1351,7 +1374,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_i8_kernel(const DownAr
   int item = blockIdx.x;
   if (item < n_items) {
     fetch(item);
-    dma_slab<CS, BLK_WAVES>(ring.buf[ring.cur], a.s.w + (int64_t)(item / groups) * a.s.w_ss, 0, wave, lane);
+    dma_slab_if_ring<CS, BLK_WAVES>(ring.buf[ring.cur], a.s.w + (int64_t)(item / groups) * a.s.w_ss, wave, lane);
   }
   for (; item < n_items; item += gridDim.x) {
     const int s = item / groups, img0 = (item - s * groups) * CA::G;
@@ -1373,19 +1396,19 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_i8_kernel(const DownAr
     }
     {
       EpiDense<COUT, false> epi{sc, a.s, a.add};
-      conv_lds<CS, decltype(epi), BLK_WAVES>(xt, ring, a.s.w + (int64_t)s * a.s.w_ss, bias_lds, a.s, epi, wave, lane,
-          [&](uint8_t* dst) { dma_slab<CA, BLK_WAVES>(dst, a.a.w + (int64_t)s * a.a.w_ss, 0, wave, lane); },
+      conv_any<CS, decltype(epi), BLK_WAVES>(xt, ring, a.s.w + (int64_t)s * a.s.w_ss, bias_lds, a.s, epi, wave, lane,
+          [&](uint8_t* dst) { dma_slab_if_ring<CA, BLK_WAVES>(dst, a.a.w + (int64_t)s * a.a.w_ss, wave, lane); },
           [&]() { if (next < n_items) fetch(next); });
     }
     {
       EpiTile<CB::HIN, CB::CIN, CB::TILE_BYTES> epi{tt, a.a};
-      conv_lds<CA, decltype(epi), BLK_WAVES>(xt, ring, a.a.w + (int64_t)s * a.a.w_ss, bias_lds + COUT, a.a, epi, wave, lane,
-          [&](uint8_t* dst) { dma_slab<CB, BLK_WAVES>(dst, a.b.w + (int64_t)s * a.b.w_ss, 0, wave, lane); }, [&]() {});
+      conv_any<CA, decltype(epi), BLK_WAVES>(xt, ring, a.a.w + (int64_t)s * a.a.w_ss, bias_lds + COUT, a.a, epi, wave, lane,
+          [&](uint8_t* dst) { dma_slab_if_ring<CB, BLK_WAVES>(dst, a.b.w + (int64_t)s * a.b.w_ss, wave, lane); }, [&]() {});
     }
     {
       EpiDense<COUT, true> epi{sc, a.b, a.add};
-      conv_lds<CB, decltype(epi), BLK_WAVES>(tt, ring, a.b.w + (int64_t)s * a.b.w_ss, bias_lds + 2 * COUT, a.b, epi, wave, lane,
-          [&](uint8_t* dst) { if (next < n_items) dma_slab<CS, BLK_WAVES>(dst, a.s.w + (int64_t)(next / groups) * a.s.w_ss, 0, wave, lane); },
+      conv_any<CB, decltype(epi), BLK_WAVES>(tt, ring, a.b.w + (int64_t)s * a.b.w_ss, bias_lds + 2 * COUT, a.b, epi, wave, lane,
+          [&](uint8_t* dst) { if (next < n_items) dma_slab_if_ring<CS, BLK_WAVES>(dst, a.s.w + (int64_t)(next / groups) * a.s.w_ss, wave, lane); },
           [&]() {});
     }
     __syncthreads();
@@ -1402,8 +1425,8 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_i8_kernel(const DownAr
 
 template <class CA, class CS, class CB>
 static int launch_block_down(const DownArgs& a, hipStream_t st) {
-  constexpr int SLAB = CA::SLAB_BYTES > CB::SLAB_BYTES ? (CA::SLAB_BYTES > CS::SLAB_BYTES ? CA::SLAB_BYTES : CS::SLAB_BYTES)
-                                                        : (CB::SLAB_BYTES > CS::SLAB_BYTES ? CB::SLAB_BYTES : CS::SLAB_BYTES);
+  constexpr int SA = CA::RING ? CA::SLAB_BYTES : 16, SS = CS::RING ? CS::SLAB_BYTES : 16, SB = CB::RING ? CB::SLAB_BYTES : 16;
+  constexpr int SLAB = SA > SB ? (SA > SS ? SA : SS) : (SB > SS ? SB : SS);
   constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + CB::OUT_BYTES + 2 * SLAB + 3 * CB::COUT * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr = false;
@@ -1423,9 +1446,9 @@ using D24_b = ConvCfg<48, 48, 3, 1, 16, 1, 1, 1, 2>;
 using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 2, 1, 3>;
 using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 2, 1, 3>;
 using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 2, 1, 3>;
-using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 4, 1, 2>;
-using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 4, 1, 2>;
-using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 4, 1, 2>;
+using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
+using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, 1, 3, false>;
+using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
 
 QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cin,
                                       int32_t a_hi, const qbnn_down_desc* d, uint8_t* y, int64_t y_ss, int32_t n_samples,
@@ -1459,7 +1482,7 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
 using Blk_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;
 using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;
 using Blk_96  = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3>;
-using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 4, 1, 2>;
+using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
 
 template <int NBLK>
 static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
