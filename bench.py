@@ -108,20 +108,27 @@ def main():
         d["n"] += 1
     total_ms = sum(d["ms"] for d in agg.values())
     roof = None
-    conv_keys = [k for k in agg if k.startswith("conv")]
+    conv_keys = [k for k in agg if agg[k]["meta"] and "convs" in agg[k]["meta"]]
     if conv_keys:
         dom = max(conv_keys, key=lambda k: agg[k]["ms"])
         d = agg[dom]
         m = d["meta"]
         avg_s = d["ms"] / d["n"] * 1e-3
-        abytes = conv_algorithmic_bytes(S_local, a.batch, m["H"], m["Cin"], m["Cout"], m["ks"], m["stride"], m["nweights"])
-        ops = conv_ops(S_local, a.batch, m["H"], m["Cin"], m["Cout"], m["ks"], m["stride"])
-        gbs = abytes / avg_s / 1e9
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_launch_ms": round(avg_s * 1e3, 4), "launches": d["n"], "share_of_gpu_time": round(d["ms"] / total_ms, 3),
-                "algorithmic_bytes_per_launch": abytes,
-                "mfma_achieved_tops": round(ops / avg_s / 1e12, 1), "mfma_frac_of_i8_peak": round(ops / avg_s / 1e12 / MFMA_I8_PEAK_TOPS, 4)}
+        abytes = sum(conv_algorithmic_bytes(S_local, a.batch, H, ci, co, ks, st, nw) for (H, ci, co, ks, st, nw) in m["convs"])
+        ops = sum(conv_ops(S_local, a.batch, H, ci, co, ks, st) for (H, ci, co, ks, st, nw) in m["convs"])
+        gbs, tops = abytes / avg_s / 1e9, ops / avg_s / 1e12
+        common = {"kernel": dom, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": d["n"],
+                  "share_of_gpu_time": round(d["ms"] / total_ms, 3), "convs_in_launch": len(m["convs"]),
+                  "algorithmic_bytes_per_launch": abytes, "algorithmic_ops_per_launch": ops, "traffic": None}
+        if m["fused"]:
+            # fused block kernels keep activations in LDS: their HBM traffic is a fraction of the layer-granular byte
+            # model, the binding roof is the int8 matrix pipe
+            roof = {"bound": "mfma", "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                    "frac": round(tops / MFMA_I8_PEAK_TOPS, 4), "layer_granular_GBps": round(gbs, 1),
+                    "layer_granular_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), **common}
+        else:
+            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "mfma_achieved_tops": round(tops, 1), "mfma_frac_of_i8_peak": round(tops / MFMA_I8_PEAK_TOPS, 4), **common}
     kernels = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["n"] // a.steps} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
 
     # ---- whole-path roofline view (layer-granular byte model of SURVEY 8(d): 126.66 MB / sample at B=256, int8)

@@ -719,7 +719,7 @@ __device__ __forceinline__ void dma_slab(uint8_t* dst, const int8_t* wq, int sla
 template <class C, class Epi, int NWAVES, class FNext, class FHook>
 __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const int8_t* wq, const float* bias_lds, const QConv& p,
                                          Epi& epi, int wave, int lane, FNext prefetch_next, FHook after_first_barrier) {
-  static_assert(C::NPASS <= NWAVES, "conv_lds: one pass per wave");
+  static_assert(C::NPASS <= NWAVES || C::ROWREUSE, "conv_lds: one pass per wave unless the whole conv is one slab");
   static_assert(C::SLK % C::KCHUNK == 0, "k-chunks must not straddle weight slabs");
   const int r = lane & 31, h = lane >> 5;
   const bool active = wave < C::NPASS;
@@ -751,12 +751,13 @@ __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const
     ring.cur ^= 1;
     if (!active) return;
     constexpr int NR = C::MB + C::KSZ - 1;
-    const int m0 = pass * C::MB * 32;
-    const int g = m0 / (C::HO * C::HO), oh0 = (m0 % (C::HO * C::HO)) / C::HO;
-    const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::CIN + 16 * h;
     v4i w[C::KS];
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wl + ks * 1024);
+    for (int pass_ = wave; pass_ < C::NPASS; pass_ += NWAVES) {
+    const int m0 = pass_ * C::MB * 32;
+    const int g = m0 / (C::HO * C::HO), oh0 = (m0 % (C::HO * C::HO)) / C::HO;
+    const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::CIN + 16 * h;
     v4i x[NR][C::SPR];
 #pragma unroll
     for (int j = 0; j < NR; ++j)
@@ -798,6 +799,7 @@ __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const
           epi.store(po, 8 * g4 + 4 * h, v0, v1, v2, v3, pre[g4]);
         }
       }
+    }
     }
     QBNN_INNER_AT(2);
     QBNN_INNER_FLUSH();
@@ -1108,8 +1110,9 @@ struct ChainArgs {
   BlockParams blk[NBLK];
 };
 
-template <class C, int NBLK>
-__global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const ChainArgs<NBLK> a) {
+template <class C, int NBLK, int NTHR>
+__global__ __launch_bounds__(NTHR, 2) void block_chain_i8_kernel(const ChainArgs<NBLK> a) {
+  constexpr int NWV = NTHR / 64;
   static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
@@ -1124,16 +1127,16 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
-  constexpr int PER_T = (NCH + BLK_THREADS - 1) / BLK_THREADS;
+  constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
 
-  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, BLK_THREADS>(xt, tid);
-  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, BLK_THREADS>(tt, tid);
+  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, NTHR>(xt, tid);
+  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, NTHR>(tt, tid);
 #pragma unroll
   for (int k = 0; k < NBLK; ++k) {
-    load_bias<C::COUT, BLK_THREADS>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
-    load_bias<C::COUT, BLK_THREADS>(bias_lds + (2 * k + 1) * C::COUT, a.blk[k].b.bias, tid);
+    load_bias<C::COUT, NTHR>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
+    load_bias<C::COUT, NTHR>(bias_lds + (2 * k + 1) * C::COUT, a.blk[k].b.bias, tid);
   }
 
   // input prefetch registers.  The loads are unconditional (address clamped, value zeroed at use) and are issued
@@ -1144,7 +1147,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
     const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
 #pragma unroll
     for (int j = 0; j < PER_T; ++j) {
-      const int i = tid + j * BLK_THREADS;
+      const int i = tid + j * NTHR;
       const int g = i / CPI, rem = i - g * CPI;
       const bool ok = (i < NCH) && (img0 + g < a.B);
       const int64_t off = ok ? ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16 : 0;
@@ -1156,7 +1159,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
   int item = blockIdx.x;
   if (item < n_items) {
     fetch(item);
-    dma_slab_if_ring<C, BLK_WAVES>(ring.buf[ring.cur], a.blk[0].a.w + (int64_t)sample_of(item) * a.blk[0].a.w_ss, wave, lane);
+    dma_slab_if_ring<C, NWV>(ring.buf[ring.cur], a.blk[0].a.w + (int64_t)sample_of(item) * a.blk[0].a.w_ss, wave, lane);
   }
   QBNN_STAMP_DECL
   for (; item < n_items; item += gridDim.x) {
@@ -1168,7 +1171,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
       const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
 #pragma unroll
       for (int j = 0; j < PER_T; ++j) {
-        const int i = tid + j * BLK_THREADS;
+        const int i = tid + j * NTHR;
         if (i < NCH) {
           const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
           const bool ok = img0 + g < a.B;
@@ -1185,17 +1188,17 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
       const BlockParams& bp = a.blk[k];
       {
         EpiTile<C::HO, C::COUT, C::TILE_BYTES> epi{tt, bp.a};
-        conv_any<C, decltype(epi), BLK_WAVES>(xt, ring, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane,
-            [&](uint8_t* dst) { dma_slab_if_ring<C, BLK_WAVES>(dst, bp.b.w + (int64_t)s * bp.b.w_ss, wave, lane); },
+        conv_any<C, decltype(epi), NWV>(xt, ring, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane,
+            [&](uint8_t* dst) { dma_slab_if_ring<C, NWV>(dst, bp.b.w + (int64_t)s * bp.b.w_ss, wave, lane); },
             [&]() { if (k == 0 && next < n_items) fetch(next); });
       }
       QBNN_STAMP_AT(2);
       {
         EpiTileResInPlace<C::HO, C::COUT, C::TILE_BYTES> epi{xt, bp.b, bp.add};
-        conv_any<C, decltype(epi), BLK_WAVES>(tt, ring, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane,
+        conv_any<C, decltype(epi), NWV>(tt, ring, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane,
             [&](uint8_t* dst) {
-              if (k + 1 < NBLK) dma_slab_if_ring<C, BLK_WAVES>(dst, a.blk[k + 1 < NBLK ? k + 1 : 0].a.w + (int64_t)s * a.blk[k + 1 < NBLK ? k + 1 : 0].a.w_ss, wave, lane);
-              else if (next < n_items) dma_slab_if_ring<C, BLK_WAVES>(dst, a.blk[0].a.w + (int64_t)sample_of(next) * a.blk[0].a.w_ss, wave, lane);
+              if (k + 1 < NBLK) dma_slab_if_ring<C, NWV>(dst, a.blk[k + 1 < NBLK ? k + 1 : 0].a.w + (int64_t)s * a.blk[k + 1 < NBLK ? k + 1 : 0].a.w_ss, wave, lane);
+              else if (next < n_items) dma_slab_if_ring<C, NWV>(dst, a.blk[0].a.w + (int64_t)sample_of(next) * a.blk[0].a.w_ss, wave, lane);
             },
             [&]() {});
       }
@@ -1207,7 +1210,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
     {
       const uint32_t z4 = (uint32_t)a.blk[NBLK - 1].add.z_o * 0x01010101u;
       uint8_t* ys = a.y + (int64_t)s * a.y_ss;
-      for (int i = tid; i < NCH; i += BLK_THREADS) {
+      for (int i = tid; i < NCH; i += NTHR) {
         const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
         if (img0 + g < a.B) {
           const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
@@ -1227,18 +1230,23 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_i8_kernel(const Chain
 #endif
 }
 
+// workgroup size per geometry: 256 threads (4 waves) where two workgroups fit a CU -- they run out of phase, so one's
+// MFMA phase overlaps the other's epilogue; 512 elsewhere
+template <class C> struct ChainThreads { static constexpr int v = (2 * (2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * (C::RING ? C::SLAB_BYTES : 16)) + 4096 <= 160 * 1024 && C::ROWREUSE) ? 256 : 512; };
+
 template <class C, int NBLK>
 static int launch_block_chain(const ChainArgs<NBLK>& a, hipStream_t st) {
+  constexpr int NTHR = ChainThreads<C>::v;
   constexpr int LDS = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * (C::RING ? C::SLAB_BYTES : 16) + NBLK * 2 * C::COUT * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_chain_i8_kernel<C, NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  if (!attr) { hipFuncSetAttribute((const void*)block_chain_i8_kernel<C, NBLK, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
-  const int per_cu = (160 * 1024) / LDS >= 2 ? 2 : 1;
+  const int per_cu = ((160 * 1024) / LDS >= 2 && NTHR == 256) ? 2 : 1;
   int grid = 256 * per_cu;
   if (grid > n_items) grid = n_items;
-  hipLaunchKernelGGL((block_chain_i8_kernel<C, NBLK>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
+  hipLaunchKernelGGL((block_chain_i8_kernel<C, NBLK, NTHR>), dim3(grid), dim3(NTHR), LDS, st, a);
   return check_launch("qbnn_block_chain_i8_mc");
 }
 

@@ -321,7 +321,7 @@ class Conv2d(_BBBInt8):
             res_ss = residual.sample_stride()
             assert residual.data.shape[1:] == y.shape[1:]
         key = "conv_i8 %dx%d %d->%d k%d s%d%s" % (H, W, Cin, self.out_channels, ks, st, " +res" if residual is not None else "")
-        meta = dict(H=H, Cin=Cin, Cout=self.out_channels, ks=ks, stride=st, nweights=pk["cout"] * pk["k"])
+        meta = dict(fused=False, convs=[(H, 3 if im2col is not None else Cin, self.out_channels, 3 if im2col is not None else ks, st, pk["cout"] * pk["k"])])
         with timed(key, meta):
             _lib.check(_lib.lib().qbnn_conv2d_i8_mc(_lib.ptr(xin), xss, _lib.ptr(w), w.shape[1], _lib.ptr(pk["bias"]),
                                                     _lib.ptr(None if residual is None else residual.data), res_ss,

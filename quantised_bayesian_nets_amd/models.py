@@ -85,7 +85,9 @@ def run_down_block(blk, x):
     Cout = blk.stem[0].out_channels
     y = torch.empty((S, B, H // 2, W // 2, Cout), dtype=torch.uint8, device=dev)
     a_hi = UINT_BOUNDS[blk.args.activation_precision][1]
-    with timed("block_down_i8 %dx%d %d->%d" % (H, W, Cin, Cout)):
+    nw = lambda l: l._packed["cout"] * l._packed["k"]
+    meta = dict(fused=True, convs=[(H, Cin, Cout, 3, 2, nw(blk.stem[0])), (H, Cin, Cout, 1, 2, nw(cs)), (H // 2, Cout, Cout, 3, 1, nw(blk.stem[3]))])
+    with timed("block_down_i8 %dx%d %d->%d" % (H, W, Cin, Cout), meta):
         _lib.check(_lib.lib().qbnn_block_down_i8_mc(_lib.ptr(x.data), x.sample_stride(), x.scale, x.zero_point, B, H, Cin, a_hi,
                                                     C.byref(d), _lib.ptr(y), y[0].numel(), S, _lib.current_stream()))
     return MCQTensor(y, blk.add.add.scale, blk.add.add.zero_point)
@@ -113,7 +115,9 @@ def run_identity_chain(blocks, x):
     y = torch.empty((S, B, H, W, Cc), dtype=torch.uint8, device=dev)
     a_hi = UINT_BOUNDS[blocks[0].args.activation_precision][1]
     key = "block_chain_i8 x%d %dx%d c%d" % (len(blocks), H, W, Cc)
-    with timed(key, dict(H=H, C=Cc, nblk=len(blocks), nweights=sum(b.stem[0]._packed["cout"] * b.stem[0]._packed["k"] + b.stem[3]._packed["cout"] * b.stem[3]._packed["k"] for b in blocks))):
+    nw = lambda l: l._packed["cout"] * l._packed["k"]
+    meta = dict(fused=True, convs=[(H, Cc, Cc, 3, 1, nw(c)) for b in blocks for c in (b.stem[0], b.stem[3])])
+    with timed(key, meta):
         _lib.check(_lib.lib().qbnn_block_chain_i8_mc(_lib.ptr(x.data), x.sample_stride(), x.scale, x.zero_point, B, H, Cc, a_hi,
                                                      descs, len(blocks), _lib.ptr(y), y[0].numel(), S, _lib.current_stream()))
     last = blocks[-1].add.add
