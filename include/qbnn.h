@@ -170,6 +170,34 @@ int qbnn_head_i8_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w_r
  * in sample order (deterministic).  moments[0][n] (+)= sum_s p, moments[1][n] (+)= sum_s p^2. */
 int qbnn_reduce_moments(const float* probs, int32_t n_samples, int64_t n, int32_t accumulate, float* moments, void* stream);
 
+/* ---- MC-Dropout path (BASELINE config 2: LeNet; reference src/models/stochastic/mcdropout/) ----------------------- */
+
+/* Deterministic int8 conv / linear of any geometry (standard torch.nn.quantized Conv2d / Linear(ReLU) as produced by
+ * quant_utils.convert for the MC-Dropout nets, models_mc.py:83-93), for S samples, + clamp_activation.
+ * w_ohwi: int8 [Cout][KH][KW][Cin] row-major; w_sample_stride 0 = shared by all samples.  A linear layer is the 1x1 case
+ * (H = W = 1, Cin = in_features). */
+int qbnn_conv2d_i8_generic_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w_ohwi, int64_t w_sample_stride,
+                              const float* bias, uint8_t* y, int64_t y_sample_stride, int32_t n_samples,
+                              const qbnn_conv_desc* host_desc, void* stream);
+
+/* Quantised BernoulliDropout.forward (mcdropout/dropout.py:15-40) + clamp_activation, x [S][B][HW][C] channels-last:
+ *   mask ~ Bernoulli(keep_prob), one draw per (sample, b, c) -- per channel for 4-D inputs, per element when HW == 1 --
+ *   from the Philox uniform stream  philox4x32_10(ctr = {i >> 2, layer_id, sample_begin + s, 1}, key = seed)[i & 3] >> 8,
+ *   i = b * C + c, keep iff u * 2^-24 < keep_prob;   mask_in != NULL: fp32 [S][B][C] masks are used instead (parity mode);
+ *   mask_q = quantize_per_tensor(mask, s_m, z_m, quint8); y = quantized::mul(x, mask_q) with output (s_m, z_m).
+ * The following mul_scalar(., 1/(1-p)) leaves the integers untouched: the CALLER multiplies the scale. */
+int qbnn_dropout_q_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int32_t HW, int32_t C, float keep_prob, float s_x,
+                      int32_t z_x, float s_m, int32_t z_m, int32_t a_hi, uint64_t seed, uint32_t layer_id, uint32_t sample_begin,
+                      const float* mask_in, uint8_t* y, int64_t y_sample_stride, int32_t n_samples, void* stream);
+
+/* nn.MaxPool2d(2,2) on quint8 (keeps scale / zero point) + clamp_activation; x [S][B][H][W][C]. */
+int qbnn_maxpool2_q_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t a_hi,
+                       uint8_t* y, int64_t y_sample_stride, int32_t n_samples, void* stream);
+
+/* DeQuantStub + F.softmax(dim=-1): x [S][B][N] uint8 -> probs [S][B][N] fp32. */
+int qbnn_dequant_softmax_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int32_t N, float scale, int32_t zero_point,
+                            float* probs, int32_t n_samples, void* stream);
+
 const char* qbnn_last_error(void);
 int qbnn_version(void);
 

@@ -191,6 +191,20 @@ def dequant_softmax(q, s, z):
     return out
 
 
+def dropout_q(x, mask, z_x, s_x, s_m, z_m, a_hi):
+    """x [B,HW,C] or [B,C] uint8; mask [B,C] float 0/1.  Returns ints; the output qparams are (s_m / (1-p), z_m)."""
+    x = np.ascontiguousarray(x, np.uint8)
+    shp = x.shape
+    B, Cc = shp[0], shp[-1]
+    HW = int(np.prod(shp[1:-1])) if x.ndim > 2 else 1
+    mask = np.ascontiguousarray(mask, np.float32)
+    mult = f32(np.float64(s_x) * np.float64(s_m) / np.float64(s_m))
+    out = np.empty(shp, np.uint8)
+    lib().qbo_dropout_q(_p(x), C.c_int64(B), C.c_int64(HW), C.c_int64(Cc), _p(mask), C.c_int32(int(z_x)), C.c_float(f32(s_m)),
+                        C.c_int32(int(z_m)), C.c_float(mult), C.c_int32(int(a_hi)), _p(out))
+    return out
+
+
 # ------------------------------------------------------------- fp32 ops ----
 def softplus(rho):
     rho = np.ascontiguousarray(rho, np.float32)
@@ -337,4 +351,73 @@ class Int8ResNetOracle:
             e = None if eps_fn is None else eps_fn(sample_offset + s)
             ps.append(self.forward(x_nchw, seed, sample_offset + s, e))
         ps = np.stack(ps, 0)
+        return ps.mean(0, dtype=np.float64).astype(np.float32), ps
+
+
+# ------------------------------------------------- MC-Dropout LeNet (config 2) ---
+class Int8LeNetMCOracle:
+    """conv_lenet_mc after prepare_model -> convert: reference mcdropout/models_mc.py:75-111 (graph), dropout.py (masks).
+    State keys (flat): layers.{0,3}.weight (+ .q_scale/.q_zero_point, OIHW), layers.{7,10}.weight ([out,in], `in` in the
+    reference's NCHW flatten order), layers.N.scale/zero_point, layers.{1,4,9}.mul_mask.scale/zero_point, layers.N.p,
+    quant.scale/zero_point."""
+    DROPS = (1, 4, 9)
+
+    def __init__(self, state, a_bits=7):
+        self.st = state
+        self.a_hi = UINT_BOUNDS[a_bits][1]
+        g = lambda k: state[k]
+        self.s_in, self.z_in = float(np.asarray(g("quant.scale")).reshape(-1)[0]), int(np.asarray(g("quant.zero_point")).reshape(-1)[0])
+        self.w = {}
+        for i in (0, 3):
+            self.w[i] = oihw_to_ohwi(np.asarray(g(f"layers.{i}.weight"), np.int8))
+        w7 = np.asarray(g("layers.7.weight"), np.int8)            # [500, 50*7*7] in (c,h,w) order -> (h,w,c)
+        self.w[7] = np.ascontiguousarray(w7.reshape(500, 50, 7, 7).transpose(0, 2, 3, 1).reshape(500, 2450))
+        self.w[10] = np.asarray(g("layers.10.weight"), np.int8)
+
+    def qp(self, i):
+        return float(self.st[f"layers.{i}.scale"]), int(self.st[f"layers.{i}.zero_point"])
+
+    def wqp(self, i):
+        return float(self.st[f"layers.{i}.weight.q_scale"]), int(self.st[f"layers.{i}.weight.q_zero_point"])
+
+    def mask(self, di, shape, seed, sample, masks=None):
+        if masks is not None:
+            return masks[di]
+        p = np.float32(np.asarray(self.st[f"layers.{self.DROPS[di]}.p"]).reshape(-1)[0])
+        keep = np.float32(1.0) - p
+        n = int(np.prod(shape))
+        return (fill_uniform(n, seed, di, sample) < keep).astype(np.float32).reshape(shape)
+
+    def drop(self, di, x, s, z, seed, sample, masks):
+        li = self.DROPS[di]
+        s_m, z_m = float(self.st[f"layers.{li}.mul_mask.scale"]), int(self.st[f"layers.{li}.mul_mask.zero_point"])
+        mult = float(np.float32(np.asarray(self.st[f"layers.{li}.multiplier"]).reshape(-1)[0]))
+        m = self.mask(di, (x.shape[0], x.shape[-1]), seed, sample, masks)
+        y = dropout_q(x, m, z, s, s_m, z_m, self.a_hi)
+        return y, s_m * mult, z_m        # mul_scalar: scale (double) * 1/(1-p)
+
+    def forward(self, x_nchw, seed, sample, masks=None, record=None):
+        a_hi = self.a_hi
+        x = quantize_input_nchw(x_nchw, self.s_in, self.z_in, a_hi)
+        s, z = self.s_in, self.z_in
+        rec = (lambda k, v: record.__setitem__(k, v)) if record is not None else (lambda k, v: None)
+        rec("quant.out", x)
+        sw, zw = self.wqp(0); sy, zy = self.qp(0)
+        x = conv2d_i8(x, self.w[0], None, 1, 2, s, z, sw, zw, sy, zy, False, a_hi); s, z = sy, zy; rec("layers.0.out", x)
+        x, s, z = self.drop(0, x, s, z, seed, sample, masks); rec("layers.1.out", x)
+        x = np.minimum(maxpool2_q(x), a_hi); rec("layers.2.out", x)
+        sw, zw = self.wqp(3); sy, zy = self.qp(3)
+        x = conv2d_i8(x, self.w[3], None, 1, 2, s, z, sw, zw, sy, zy, False, a_hi); s, z = sy, zy; rec("layers.3.out", x)
+        x, s, z = self.drop(1, x, s, z, seed, sample, masks); rec("layers.4.out", x)
+        x = np.minimum(maxpool2_q(x), a_hi); rec("layers.5.out", x)
+        x = x.reshape(x.shape[0], -1)                                            # NHWC flatten; weights were permuted to match
+        sw, zw = self.wqp(7); sy, zy = self.qp(7)
+        x = linear_i8(x, self.w[7], None, s, z, sw, zw, sy, zy, True, a_hi); s, z = sy, zy; rec("layers.7.out", x)
+        x, s, z = self.drop(2, x, s, z, seed, sample, masks); rec("layers.9.out", x)
+        sw, zw = self.wqp(10); sy, zy = self.qp(10)
+        x = linear_i8(x, self.w[10], None, s, z, sw, zw, sy, zy, False, a_hi); s, z = sy, zy; rec("layers.10.out", x)
+        return dequant_softmax(x, s, z)
+
+    def mc_predict(self, x_nchw, samples, seed, sample_offset=0):
+        ps = np.stack([self.forward(x_nchw, seed, sample_offset + s) for s in range(samples)], 0)
         return ps.mean(0, dtype=np.float64).astype(np.float32), ps

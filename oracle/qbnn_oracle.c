@@ -265,8 +265,8 @@ QBO_API void qbo_conv2d_i8(const uint8_t* x, const int8_t* w, const float* bias,
 #pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < p->B; ++b)
     for (int oh = 0; oh < Ho; ++oh) {
-      int32_t accv[512];
-      int16_t xrow[2048];
+      int32_t* accv = (int32_t*)malloc(sizeof(int32_t) * (size_t)Cout);
+      int16_t* xrow = (int16_t*)malloc(sizeof(int16_t) * (size_t)Cin);
       for (int ow = 0; ow < Wo; ++ow) {
         for (int co = 0; co < Cout; ++co) accv[co] = 0;
         for (int kh = 0; kh < p->KH; ++kh) {
@@ -289,6 +289,8 @@ QBO_API void qbo_conv2d_i8(const uint8_t* x, const int8_t* w, const float* bias,
         for (int co = 0; co < Cout; ++co)
           yp[co] = qbo_requant(accv[co], bias ? bias[co] : 0.0f, bias != NULL, rcp, mult, p->z_y, lo, p->a_hi);
       }
+      free(accv);
+      free(xrow);
     }
 }
 
@@ -368,6 +370,28 @@ QBO_API void qbo_maxpool2_q(const uint8_t* x, int32_t B, int32_t H, int32_t W, i
             }
           out[(((int64_t)b * Ho + oh) * Wo + ow) * C + c] = (uint8_t)m;
         }
+}
+
+/* Quantised BernoulliDropout (mcdropout/dropout.py:15-40) on a channels-last tensor [B][HW][C]:
+ *   mask (0/1, one value per (b, c): per-channel for 4-D inputs, per-element for 2-D where HW == 1)
+ *   mask_q = quantize_per_tensor(mask, s_m, z_m, quint8)                               dropout.py:31-34
+ *   y      = mul_mask.mul(x, mask_q)  -> quantized::mul, output qparams (s_m, z_m)      dropout.py:38
+ *   y      = mul_scalar.mul_scalar(y, 1/(1-p)) : integers and zero point unchanged, scale *= 1/(1-p)   :39
+ * then clamp_activation.  `mult` = (float)((double)s_x * (double)s_m / (double)s_m)  (ATen qmul multiplier). */
+QBO_API void qbo_dropout_q(const uint8_t* x, int64_t B, int64_t HW, int64_t C, const float* mask, int32_t z_x,
+                           float s_m, int32_t z_m, float mult, int32_t a_hi, uint8_t* out) {
+  const float inv_sm = 1.0f / s_m;
+  for (int64_t b = 0; b < B; ++b)
+    for (int64_t c = 0; c < C; ++c) {
+      const int32_t mq = qbo_clampi(z_m + qbo_rne_sat(mask[b * C + c] * inv_sm), 0, 255);
+      for (int64_t p = 0; p < HW; ++p) {
+        const int64_t i = (b * HW + p) * C + c;
+        const int32_t prod = ((int32_t)x[i] - z_x) * (mq - z_m);
+        int32_t q = qbo_clampi(z_m + qbo_rne_sat((float)prod * mult), 0, 255);
+        if (q > a_hi) q = a_hi;
+        out[i] = (uint8_t)q;
+      }
+    }
 }
 
 /* DeQuantStub + F.softmax(dim=-1): models_bbb.py:240-243 */

@@ -1678,3 +1678,152 @@ QBNN_EXPORT int qbnn_reduce_moments(const float* probs, int32_t S, int64_t n, in
   hipLaunchKernelGGL(reduce_moments_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, probs, S, n, accumulate, mom);
   return check_launch("qbnn_reduce_moments");
 }
+
+// =====================================================================================
+// MC-Dropout path (BASELINE config 2: LeNet, mcdropout/models_mc.py:75-111).  These nets are tiny and
+// launch/latency-bound at their sizes: plain one-thread-per-output kernels, any geometry.
+// =====================================================================================
+struct GenConvArgs {
+  const uint8_t* x; int64_t x_ss; const int8_t* w; int64_t w_ss; const float* bias; uint8_t* y; int64_t y_ss;
+  int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+  int z_x, z_w, z_y, lo, hi;
+  float rcp, mult;
+};
+
+__global__ __launch_bounds__(256) void conv_generic_i8_kernel(const GenConvArgs a) {
+  const int64_t total = (int64_t)a.B * a.Ho * a.Wo * a.Cout;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int s = blockIdx.y;
+  const int co = (int)(idx % a.Cout);
+  int64_t t = idx / a.Cout;
+  const int ow = (int)(t % a.Wo); t /= a.Wo;
+  const int oh = (int)(t % a.Ho);
+  const int b = (int)(t / a.Ho);
+  const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)b * a.H * a.W * a.Cin;
+  const int8_t* ws = a.w + (int64_t)s * a.w_ss + (int64_t)co * a.KH * a.KW * a.Cin;
+  int acc = 0;
+  for (int kh = 0; kh < a.KH; ++kh) {
+    const int ih = oh * a.stride - a.pad + kh;
+    if (ih < 0 || ih >= a.H) continue;
+    for (int kw = 0; kw < a.KW; ++kw) {
+      const int iw = ow * a.stride - a.pad + kw;
+      if (iw < 0 || iw >= a.W) continue;
+      const uint8_t* xp = xs + ((int64_t)ih * a.W + iw) * a.Cin;
+      const int8_t* wp = ws + (kh * a.KW + kw) * a.Cin;
+      for (int c = 0; c < a.Cin; ++c) acc += ((int)xp[c] - a.z_x) * ((int)wp[c] - a.z_w);
+    }
+  }
+  float xf = (float)acc;
+  if (a.bias) xf = __builtin_fmaf(a.bias[co], a.rcp, xf);
+  int q = a.z_y + rne_sat(xf * a.mult);
+  q = min(max(q, a.lo), a.hi);
+  a.y[(int64_t)s * a.y_ss + idx] = (uint8_t)q;
+}
+
+QBNN_EXPORT int qbnn_conv2d_i8_generic_mc(const uint8_t* x, int64_t x_ss, const int8_t* w_ohwi, int64_t w_ss, const float* bias,
+                                          uint8_t* y, int64_t y_ss, int32_t n_samples, const qbnn_conv_desc* d, void* stream) {
+  if (!x || !w_ohwi || !y || !d || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_generic_mc: bad argument%s");
+  if (d->a_hi > 255 || d->a_hi < 1) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_generic_mc: bad a_hi%s");
+  GenConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.x_ss = x_ss; a.w = w_ohwi; a.w_ss = w_ss; a.bias = d->has_bias ? bias : nullptr; a.y = y; a.y_ss = y_ss;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = a.KW = d->ksize; a.stride = d->stride; a.pad = d->pad;
+  a.Ho = (d->H + 2 * d->pad - d->ksize) / d->stride + 1; a.Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
+  a.z_x = d->z_x; a.z_w = d->z_w; a.z_y = d->z_y; a.lo = d->relu ? d->z_y : 0; a.hi = d->a_hi < 255 ? d->a_hi : 255;
+  const float atw = d->s_x * d->s_w;
+  a.rcp = 1.0f / atw; a.mult = atw / d->s_y;
+  const int64_t total = (int64_t)a.B * a.Ho * a.Wo * a.Cout;
+  hipLaunchKernelGGL(conv_generic_i8_kernel, dim3((unsigned)((total + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("qbnn_conv2d_i8_generic_mc");
+}
+
+// Quantised BernoulliDropout (mcdropout/dropout.py:15-40), x [S][B][HW][C]: one Bernoulli(keep) draw per (sample, b, c)
+// from the Philox uniform stream {ctr = {i >> 2, layer, sample, 1}}[i & 3], i = b * C + c  (or mask_in in parity mode).
+__global__ __launch_bounds__(256) void dropout_q_kernel(const uint8_t* __restrict__ x, int64_t x_ss, int B, int HW, int C,
+                                                         float keep, int z_x, float inv_sm, int z_m, float mult, int hi,
+                                                         uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_id, uint32_t sample_begin,
+                                                         const float* __restrict__ mask_in, uint8_t* __restrict__ y, int64_t y_ss) {
+  const int64_t total = (int64_t)B * HW * C;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int s = blockIdx.y;
+  const int c = (int)(idx % C);
+  const int b = (int)(idx / ((int64_t)HW * C));
+  const int i = b * C + c;
+  float m;
+  if (mask_in) {
+    m = mask_in[(int64_t)s * B * C + i];
+  } else {
+    const qbnn::u32x4 r = qbnn::philox4x32_10((uint32_t)(i >> 2), layer_id, sample_begin + s, 1u, seed_lo, seed_hi);
+    const uint32_t rv = (i & 3) == 0 ? r.x : ((i & 3) == 1 ? r.y : ((i & 3) == 2 ? r.z : r.w));
+    m = ((float)(rv >> 8) * 5.9604644775390625e-8f) < keep ? 1.0f : 0.0f;
+  }
+  const int mq = min(max(z_m + rne_sat(m * inv_sm), 0), 255);
+  const int prod = ((int)x[(int64_t)s * x_ss + idx] - z_x) * (mq - z_m);
+  int q = min(max(z_m + rne_sat((float)prod * mult), 0), 255);
+  y[(int64_t)s * y_ss + idx] = (uint8_t)min(q, hi);
+}
+
+QBNN_EXPORT int qbnn_dropout_q_mc(const uint8_t* x, int64_t x_ss, int32_t B, int32_t HW, int32_t C, float keep_prob, float s_x,
+                                  int32_t z_x, float s_m, int32_t z_m, int32_t a_hi, uint64_t seed, uint32_t layer_id,
+                                  uint32_t sample_begin, const float* mask_in, uint8_t* y, int64_t y_ss, int32_t n_samples,
+                                  void* stream) {
+  if (!x || !y || B <= 0 || HW <= 0 || C <= 0 || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_dropout_q_mc: bad argument%s");
+  const float mult = (float)((double)s_x * (double)s_m / (double)s_m);     // ATen qmul: self_scale * other_scale / out_scale
+  const int64_t total = (int64_t)B * HW * C;
+  hipLaunchKernelGGL(dropout_q_kernel, dim3((unsigned)((total + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
+                     x, x_ss, B, HW, C, keep_prob, z_x, 1.0f / s_m, z_m, mult, a_hi < 255 ? a_hi : 255, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), layer_id, sample_begin, mask_in, y, y_ss);
+  return check_launch("qbnn_dropout_q_mc");
+}
+
+__global__ __launch_bounds__(256) void maxpool2_q_kernel(const uint8_t* __restrict__ x, int64_t x_ss, int B, int H, int W, int C,
+                                                          int hi, uint8_t* __restrict__ y, int64_t y_ss) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * C;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int s = blockIdx.y;
+  const int c = (int)(idx % C);
+  int64_t t = idx / C;
+  const int ow = (int)(t % Wo); t /= Wo;
+  const int oh = (int)(t % Ho);
+  const int64_t b = t / Ho;
+  const uint8_t* xs = x + (int64_t)s * x_ss;
+  int m = 0;
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) m = max(m, (int)xs[((b * H + oh * 2 + i) * W + ow * 2 + j) * C + c]);
+  y[(int64_t)s * y_ss + idx] = (uint8_t)min(m, hi);
+}
+
+QBNN_EXPORT int qbnn_maxpool2_q_mc(const uint8_t* x, int64_t x_ss, int32_t B, int32_t H, int32_t W, int32_t C, int32_t a_hi,
+                                   uint8_t* y, int64_t y_ss, int32_t n_samples, void* stream) {
+  if (!x || !y || B <= 0 || H < 2 || W < 2 || C <= 0 || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_maxpool2_q_mc: bad argument%s");
+  const int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
+  hipLaunchKernelGGL(maxpool2_q_kernel, dim3((unsigned)((total + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
+                     x, x_ss, B, H, W, C, a_hi < 255 ? a_hi : 255, y, y_ss);
+  return check_launch("qbnn_maxpool2_q_mc");
+}
+
+// DeQuantStub + softmax over the last dim (models_mc.py:104-111): x [S][B][N] uint8 -> probs [S][B][N] fp32
+__global__ __launch_bounds__(256) void dequant_softmax_kernel(const uint8_t* __restrict__ x, int64_t x_ss, int B, int N, float sc,
+                                                               int z, float* __restrict__ probs) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const int s = blockIdx.y;
+  const uint8_t* xs = x + (int64_t)s * x_ss + (int64_t)b * N;
+  float mx = -INFINITY;
+  for (int i = 0; i < N; ++i) mx = fmaxf(mx, (float)((int)xs[i] - z) * sc);
+  float sum = 0.f;
+  for (int i = 0; i < N; ++i) sum += expf((float)((int)xs[i] - z) * sc - mx);
+  for (int i = 0; i < N; ++i) probs[((int64_t)s * B + b) * N + i] = expf((float)((int)xs[i] - z) * sc - mx) / sum;
+}
+
+QBNN_EXPORT int qbnn_dequant_softmax_mc(const uint8_t* x, int64_t x_ss, int32_t B, int32_t N, float scale, int32_t zero_point,
+                                        float* probs, int32_t n_samples, void* stream) {
+  if (!x || !probs || B <= 0 || N <= 0 || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_dequant_softmax_mc: bad argument%s");
+  hipLaunchKernelGGL(dequant_softmax_kernel, dim3((B + 255) / 256, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, B, N,
+                     scale, zero_point, probs);
+  return check_launch("qbnn_dequant_softmax_mc");
+}

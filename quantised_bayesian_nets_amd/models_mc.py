@@ -1,0 +1,241 @@
+"""MC-Dropout models behind the reference's API (BASELINE config 2).
+
+Mirror of reference src/models/stochastic/mcdropout/dropout.py (`BernoulliDropout`, :6-46) and
+models_mc.py (`ConvNetwork_LeNet`, :75-111) in their converted int8 form (quant_utils.prepare_model -> convert):
+deterministic torch.nn.quantized Conv2d / Linear(ReLU) layers with an always-on quantised Bernoulli dropout.
+All S MC samples of the active mc_context are evaluated per call; masks come from the Philox uniform stream
+(seed, dropout index, global sample index) instead of torch's global generator.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .layers import MCQTensor, QFunctional, QuantizedParam, _MC, mc_context, timed
+from .quant import UINT_BOUNDS, check_bits
+
+
+def _a_hi(args):
+    return UINT_BOUNDS[getattr(args, "activation_precision", 7)][1]
+
+
+class BernoulliDropout(nn.Module):
+    """reference mcdropout/dropout.py:6-46.  Always stochastic (no `training` check); p <= 0 is the identity;
+    4-D inputs drop whole channels (one draw per (sample, image, channel)); the mask is quantised with mul_mask's own
+    (scale, zero_point) and the 1/(1-p) rescale only changes the scale (quantized::mul_scalar)."""
+
+    def __init__(self, p=0.0):
+        super().__init__()
+        self.p = nn.Parameter(torch.ones((1,)) * p, requires_grad=False)
+        self.multiplier = nn.Parameter(torch.ones((1,)) / (1.0 - self.p), requires_grad=False)
+        self.mul_mask = QFunctional()
+        self.mul_scalar = QFunctional()
+        self.layer_id = 0           # Philox tensor id: index of this dropout among the model's dropouts
+        self.args = None
+
+    def forward(self, x, masks=None):
+        if float(self.p) <= 0.0:
+            return x
+        d = x.data
+        if d.device.type != "cuda":
+            raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
+        S = _MC.samples
+        B, Cc = d.shape[1], d.shape[-1]
+        HW = int(np.prod(d.shape[2:-1])) if d.dim() > 3 else 1
+        y = torch.empty((S,) + tuple(d.shape[1:]), dtype=torch.uint8, device=d.device)
+        keep = float(np.float32(1.0) - np.float32(self.p.item()))
+        if masks is not None:
+            masks = masks.to(device=d.device, dtype=torch.float32).contiguous()
+            assert masks.numel() == S * B * Cc
+        with timed("dropout_q"):
+            _lib.check(_lib.lib().qbnn_dropout_q_mc(_lib.ptr(d), x.sample_stride(), B, HW, Cc, keep, x.scale, x.zero_point,
+                                                    self.mul_mask.scale, self.mul_mask.zero_point, _a_hi(self.args), _MC.seed,
+                                                    self.layer_id, _MC.sample_begin, _lib.ptr(masks), _lib.ptr(y), y[0].numel(), S,
+                                                    _lib.current_stream()))
+        # mul_scalar: integers and zero point unchanged, scale (a double in torch) times 1/(1-p)
+        return MCQTensor(y, self.mul_mask.scale * float(np.float32(self.multiplier.item())), self.mul_mask.zero_point)
+
+    def extra_repr(self):
+        return 'p={}, quant={}'.format(self.p.item(), True)
+
+
+class _QDeterministic(nn.Module):
+    """A converted standard quantised layer (torch.nn.quantized.Conv2d / Linear / LinearReLU): fixed qint8 weight."""
+    relu = False
+
+    def _init(self, w_shape, args):
+        self._weight = QuantizedParam(np.zeros(w_shape, np.int8), 1.0, 0)
+        self.bias_ = None
+        self.scale, self.zero_point = 1.0, 0
+        self.args = args
+        self._dev = None
+
+    def weight(self):
+        return self._weight
+
+    def bias(self):
+        return self.bias_
+
+    def load_reference_state(self, state, prefix):
+        self._weight = QuantizedParam(state[prefix + "weight"], state[prefix + "weight.q_scale"], state[prefix + "weight.q_zero_point"])
+        b = state.get(prefix + "bias", None)
+        self.bias_ = None if b is None or np.asarray(b).size == 0 else torch.from_numpy(np.asarray(b, np.float32).copy())
+        self.scale, self.zero_point = float(state[prefix + "scale"]), int(state[prefix + "zero_point"])
+        self._dev = None
+        return self
+
+    def _device_params(self, device, w_ohwi):
+        if self._dev is None or self._dev["device"] != device:
+            self._dev = dict(device=device, w=torch.from_numpy(np.ascontiguousarray(w_ohwi)).to(device),
+                             bias=None if self.bias_ is None else self.bias_.to(device=device, dtype=torch.float32).contiguous())
+        return self._dev
+
+    def _run(self, x, w_ohwi, H, W, Cin, Cout, ks, stride, pad, out_shape):
+        d = x.data
+        if d.device.type != "cuda":
+            raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
+        S = x.samples if not x.shared else 1
+        dev = self._device_params(d.device, w_ohwi)
+        y = torch.empty((S,) + out_shape, dtype=torch.uint8, device=d.device)
+        c = _lib.ConvDesc()
+        c.B, c.H, c.W, c.Cin, c.Cout, c.ksize, c.stride, c.pad = d.shape[1], H, W, Cin, Cout, ks, stride, pad
+        c.s_x, c.z_x = x.scale, x.zero_point
+        c.s_w, c.z_w = self._weight.q_scale(), self._weight.q_zero_point()
+        c.s_y, c.z_y = self.scale, self.zero_point
+        c.relu, c.a_hi, c.has_bias = int(self.relu), _a_hi(self.args), int(dev["bias"] is not None)
+        with timed("conv_generic_i8 %d->%d k%d" % (Cin, Cout, ks)):
+            _lib.check(_lib.lib().qbnn_conv2d_i8_generic_mc(_lib.ptr(d), x.sample_stride(), _lib.ptr(dev["w"]), 0, _lib.ptr(dev["bias"]),
+                                                            _lib.ptr(y), y[0].numel(), S, C.byref(c), _lib.current_stream()))
+        return MCQTensor(y, self.scale, self.zero_point, shared=x.shared)
+
+
+class QConv2d(_QDeterministic):
+    """torch.nn.quantized.Conv2d as the reference's convert() produces it for models_mc.py:83,86."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False, args=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding = in_channels, out_channels, kernel_size, stride, padding
+        self._init((out_channels, in_channels, kernel_size, kernel_size), args)
+
+    def forward(self, x):
+        _, B, H, W, Cin = x.data.shape
+        ks, st, pd = self.kernel_size, self.stride, self.padding
+        Ho, Wo = (H + 2 * pd - ks) // st + 1, (W + 2 * pd - ks) // st + 1
+        w = self._weight.int_repr().transpose(0, 2, 3, 1)
+        return self._run(x, w, H, W, Cin, self.out_channels, ks, st, pd, (B, Ho, Wo, self.out_channels))
+
+
+class QLinear(_QDeterministic):
+    """torch.nn.quantized.Linear (models_mc.py:93).  `nhwc_from` = (C, H, W) when the input is a flattened conv map: the
+    reference flattens NCHW (src/utils.py:40-47), the build's activations are NHWC, so the weight columns are permuted."""
+
+    def __init__(self, in_features, out_features, bias=False, args=None, nhwc_from=None):
+        super().__init__()
+        self.in_features, self.out_features, self.nhwc_from = in_features, out_features, nhwc_from
+        self._init((out_features, in_features), args)
+
+    def forward(self, x):
+        d = x.data
+        B = d.shape[1]
+        w = self._weight.int_repr()
+        if self.nhwc_from is not None:
+            c, h, wd = self.nhwc_from
+            w = w.reshape(self.out_features, c, h, wd).transpose(0, 2, 3, 1).reshape(self.out_features, -1)
+        flat = MCQTensor(d.reshape(d.shape[0], B, -1), x.scale, x.zero_point, shared=x.shared)
+        return self._run(flat, w, 1, 1, self.in_features, self.out_features, 1, 1, 0, (B, self.out_features))
+
+
+class QLinearReLU(QLinear):
+    relu = True
+
+
+class MaxPool2dQ(nn.Module):
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = args
+
+    def forward(self, x):
+        d = x.data
+        S, B, H, W, Cc = d.shape
+        y = torch.empty((S, B, H // 2, W // 2, Cc), dtype=torch.uint8, device=d.device)
+        with timed("maxpool2_q"):
+            _lib.check(_lib.lib().qbnn_maxpool2_q_mc(_lib.ptr(d), x.sample_stride(), B, H, W, Cc, _a_hi(self.args), _lib.ptr(y),
+                                                     y[0].numel(), S, _lib.current_stream()))
+        return MCQTensor(y, x.scale, x.zero_point, shared=x.shared)
+
+
+class ConvNetwork_LeNet(nn.Module):
+    """reference mcdropout/models_mc.py:75-111 (`conv_lenet_mc`), converted int8 form."""
+
+    def __init__(self, input_size, output_size, q, args):
+        super().__init__()
+        if not q:
+            raise NotImplementedError("only the converted int8 model (q=True) is built so far")
+        check_bits(args)
+        self.args, self.q = args, q
+        self.init_channels = input_size[0]
+        self.output_size = int(output_size)
+        ident = nn.Identity
+        self.layers = nn.ModuleList([QConv2d(self.init_channels, 20, 5, padding=2, args=args), BernoulliDropout(args.p), MaxPool2dQ(args),
+                                     QConv2d(20, 50, 5, padding=2, args=args), BernoulliDropout(args.p), MaxPool2dQ(args),
+                                     ident(),                                  # Flatten
+                                     QLinearReLU(50 * 7 * 7, 500, args=args, nhwc_from=(50, 7, 7)), ident(),
+                                     BernoulliDropout(args.p),
+                                     QLinear(500, output_size, args=args)])
+        for i, m in enumerate(self.dropouts()):
+            m.layer_id, m.args = i, args
+        from .models import QuantStub
+        self.quant = QuantStub()
+
+    def dropouts(self):
+        return [m for m in self.layers if isinstance(m, BernoulliDropout)]
+
+    def load_reference_state(self, state):
+        for i in (0, 3, 7, 10):
+            self.layers[i].load_reference_state(state, f"layers.{i}.")
+        for i in (1, 4, 9):
+            d = self.layers[i]
+            d.mul_mask = QFunctional(state[f"layers.{i}.mul_mask.scale"], state[f"layers.{i}.mul_mask.zero_point"])
+            d.p.data = torch.from_numpy(np.asarray(state[f"layers.{i}.p"], np.float32).reshape(1).copy())
+            d.multiplier.data = torch.from_numpy(np.asarray(state[f"layers.{i}.multiplier"], np.float32).reshape(1).copy())
+        self.quant.scale = float(np.asarray(state["quant.scale"]).reshape(-1)[0])
+        self.quant.zero_point = int(np.asarray(state["quant.zero_point"]).reshape(-1)[0])
+        return self
+
+    def forward_mc(self, x, record=None, masks=None):
+        """All S samples of the current mc_context -> softmax probabilities [S, B, classes].
+        masks: optional {dropout index: fp32 [S, B, C]} (parity mode)."""
+        if x.device.type != "cuda":
+            raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
+        S = _MC.samples
+        x = x.to(torch.float32).contiguous()
+        B, Cc, H, W = x.shape
+        xq = torch.empty((1, B, H, W, Cc), dtype=torch.uint8, device=x.device)
+        a_hi = _a_hi(self.args)
+        _lib.check(_lib.lib().qbnn_quantize_input_nchw(_lib.ptr(x), B, Cc, H, W, self.quant.scale, self.quant.zero_point, a_hi,
+                                                       _lib.ptr(xq), _lib.current_stream()))
+        h = MCQTensor(xq, self.quant.scale, self.quant.zero_point, shared=True)
+        if record is not None:
+            record["quant.out"] = h.data
+        di = 0
+        for i, layer in enumerate(self.layers):
+            if isinstance(layer, nn.Identity):
+                continue
+            if isinstance(layer, BernoulliDropout):
+                h = layer(h, None if masks is None else masks[di])
+                di += 1
+            else:
+                h = layer(h)
+            if record is not None:
+                record[f"layers.{i}.out"] = h.data
+        d = h.data                                   # [S, B, classes]
+        probs = torch.empty((S, B, self.output_size), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().qbnn_dequant_softmax_mc(_lib.ptr(d), h.sample_stride(), B, self.output_size, h.scale, h.zero_point,
+                                                      _lib.ptr(probs), S, _lib.current_stream()))
+        return probs
+
+    def forward(self, x):
+        with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
+            return self.forward_mc(x)[0]

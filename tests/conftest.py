@@ -19,7 +19,7 @@ def load_golden(name):
     d = np.load(os.path.join(GOLDEN, name))
     state = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
     rec = {k[len("rec/"):]: d[k] for k in d.files if k.startswith("rec/")}
-    meta = {k[len("meta."):]: int(d[k]) for k in d.files if k.startswith("meta.")}
+    meta = {k[len("meta."):]: (float(d[k]) if d[k].dtype.kind == "f" else int(d[k])) for k in d.files if k.startswith("meta.")}
     return dict(state=state, rec=rec, meta=meta, x=d["x"], probs=d["probs"], mean_probs=d["mean_probs"])
 
 
@@ -31,3 +31,8 @@ def golden(request):
 @pytest.fixture(scope="session")
 def golden_w8():
     return load_golden("resnet_bbb_a7w8.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_lenet_mc():
+    return load_golden("lenet_mc_a7w8.npz")

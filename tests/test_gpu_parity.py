@@ -246,6 +246,41 @@ def test_full_size_against_oracle_and_properties(golden_w8):
     np.testing.assert_allclose(mean_c.cpu().numpy(), mean.cpu().numpy(), rtol=RTOL, atol=1e-8)
 
 
+def test_lenet_mc_dropout_matches_reference(golden_lenet_mc):
+    """BASELINE config 2 (MNIST-shaped LeNet, MC-Dropout, A7/W8): in-kernel Philox masks, quantised dropout, generic int8
+    conv / linear, max-pool, head -- every layer of sample 0 and all per-sample probabilities against the reference."""
+    import quantised_bayesian_nets_amd as q
+    from oracle import oracle as orc
+    g = golden_lenet_mc
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=float(g["meta"]["p"]) if "p" in g["meta"] else 0.2)
+    m = q.ModelFactory.get_model("conv_lenet_mc", [1, 1, 28, 28], 10, True, args).load_reference_state(g["state"])
+    x = torch.from_numpy(g["x"]).cuda()
+    S, seed = g["probs"].shape[0], g["meta"]["philox_seed"]
+    rec = {}
+    with q.mc_context(S, seed, 0):
+        probs = m.forward_mc(x, record=rec)
+    for k, v in g["rec"].items():
+        got = rec[k][0].cpu().numpy()
+        assert np.array_equal(got.reshape(v.shape), v), k
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=RTOL, atol=1e-8)
+    mean = q.mc_predict(m, x, S, seed)
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean_probs"], rtol=RTOL, atol=1e-8)
+    # injected masks == Philox masks; sample_begin offsets the stream; bigger batch against the oracle
+    net = orc.Int8LeNetMCOracle(g["state"], 7)
+    keep = np.float32(1.0) - np.float32(0.2)
+    B = x.shape[0]
+    masks = {di: torch.from_numpy(np.stack([(orc.fill_uniform(B * c, seed, di, s) < keep).astype(np.float32).reshape(B, c) for s in (1, 2)]))
+             for di, c in enumerate((20, 50, 500))}
+    with q.mc_context(2, 999, 0):
+        pm = m.forward_mc(x, masks=masks)
+    assert torch.equal(pm, probs[1:3])
+    gen = torch.Generator().manual_seed(5)
+    xb = torch.rand(128, 1, 28, 28, generator=gen)
+    with q.mc_context(2, seed, 7):
+        pb = m.forward_mc(xb.cuda())
+    np.testing.assert_allclose(pb[1].cpu().numpy(), net.forward(xb.numpy(), seed, 8), rtol=RTOL, atol=1e-8)
+
+
 def test_errors_are_loud():
     from quantised_bayesian_nets_amd import _lib
     d = _lib.ConvDesc()

@@ -71,3 +71,21 @@ def test_injected_eps_equals_philox_path(golden_w8):
     a = net.forward(g["x"], 3, 1, eps=eps)
     b = net.forward(g["x"], 3, 1)
     assert np.array_equal(a, b)
+
+
+def test_lenet_mc_dropout_bit_exact(golden_lenet_mc):
+    """BASELINE config 2: the quantised BernoulliDropout chain + deterministic int8 LeNet against the reference."""
+    g = golden_lenet_mc
+    net = orc.Int8LeNetMCOracle(g["state"], 7)
+    orec = {}
+    p0 = net.forward(g["x"], g["meta"]["philox_seed"], 0, record=orec)
+    for k, v in g["rec"].items():
+        assert np.array_equal(orec[k].reshape(v.shape), v), k
+    np.testing.assert_allclose(p0, g["probs"][0], rtol=1e-5, atol=1e-8)
+    mean, ps = net.mc_predict(g["x"], g["probs"].shape[0], g["meta"]["philox_seed"])
+    np.testing.assert_allclose(ps, g["probs"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(mean, g["mean_probs"], rtol=1e-5, atol=1e-8)
+    # about p of the channels are dropped (mask -> zero point)
+    z4 = int(g["state"]["layers.4.mul_mask.zero_point"])
+    dropped = (g["rec"]["layers.4.out"].reshape(g["x"].shape[0], -1, 50) == z4).all(axis=1).mean()
+    assert 0.02 < dropped < 0.5
