@@ -198,6 +198,19 @@ int qbnn_maxpool2_q_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int
 int qbnn_dequant_softmax_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int32_t N, float scale, int32_t zero_point,
                             float* probs, int32_t n_samples, void* stream);
 
+/* ---- fp32 Bayes-by-backprop path (BASELINE config 0; reference src/models/stochastic/bbb/linear.py:42-50) ---------- */
+
+/* W[s][i] = mu[i] + eps(s,i) * sigma[i]  (sigma = softplus(rho), computed once by the host), eps from the Philox normal
+ * stream {ctr = {i >> 2, layer_id, sample_begin + s, 0}}[i & 3] or eps_in [S][n] (parity mode). */
+int qbnn_sample_weights_f32(const float* mu, const float* sigma, int64_t n, uint64_t seed, uint32_t layer_id,
+                            uint32_t sample_begin, int32_t n_samples, const float* eps_in, float* w_out, void* stream);
+
+/* y[s][b][n] = act( sum_k x[s][b][k] * w[s][n][k] + bias[n] ),  act: 0 none, 1 ReLU, 2 exp (the log_var head,
+ * models_bbb.py:78).  Sample strides in elements; 0 = shared. */
+int qbnn_linear_f32_mc(const float* x, int64_t x_sample_stride, const float* w, int64_t w_sample_stride, const float* bias,
+                       float* y, int64_t y_sample_stride, int32_t B, int32_t K, int32_t N, int32_t act, int32_t n_samples,
+                       void* stream);
+
 const char* qbnn_last_error(void);
 int qbnn_version(void);
 

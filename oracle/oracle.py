@@ -421,3 +421,35 @@ class Int8LeNetMCOracle:
     def mc_predict(self, x_nchw, samples, seed, sample_offset=0):
         ps = np.stack([self.forward(x_nchw, seed, sample_offset + s) for s in range(samples)], 0)
         return ps.mean(0, dtype=np.float64).astype(np.float32), ps
+
+
+# ------------------------------------------------- float BBB MLP (config 0) ---
+class F32MLPOracle:
+    """`linear_bbb` float, eval branch: reference bbb/linear.py:42-50 per layer (sigma = softplus(rho), W = mu + eps*sigma,
+    y = x @ W^T + b), graph models_bbb.py:61-78: 3 x (Linear(100) + ReLU), heads mu / log_var -> (mu, exp(log_var)).
+    fp32 with fp64 accumulation; tolerance 1e-5 relative against the reference."""
+    NAMES = ("layers.0", "layers.2", "layers.4", "mu", "log_var")
+
+    def __init__(self, state):
+        self.st = state
+
+    def layer(self, name, lid, x, seed, sample, relu):
+        mu, rho, b = (np.asarray(self.st[name + k], np.float32) for k in (".weight", ".std", ".bias"))
+        eps = fill_normal(mu.size, seed, lid, sample).reshape(mu.shape)
+        w = sample_weights_f32(mu, softplus(rho), eps)
+        y = (x.astype(np.float64) @ w.astype(np.float64).T + b.astype(np.float64)).astype(np.float32)
+        return np.maximum(y, 0) if relu else y
+
+    def forward(self, x, seed, sample):
+        h = np.asarray(x, np.float32)
+        for lid, n in enumerate(self.NAMES[:3]):
+            h = self.layer(n, lid, h, seed, sample, True)
+        mu = self.layer("mu", 3, h, seed, sample, False)
+        lv = self.layer("log_var", 4, h, seed, sample, False)
+        return mu, np.exp(lv)
+
+    def mc_predict(self, x, samples, seed):
+        """experiments/utils.py:348-353: (mean_s mu, var_unbiased_s(mu) + mean_s var)."""
+        mus, vs = zip(*[self.forward(x, seed, s) for s in range(samples)])
+        mus, vs = np.stack(mus).astype(np.float64), np.stack(vs).astype(np.float64)
+        return mus.mean(0).astype(np.float32), (mus.var(0, ddof=1) + vs.mean(0)).astype(np.float32)

@@ -5,5 +5,5 @@ Drop-in for the hot path of martinferianc/quantised-bayesian-nets (reference fil
 from .layers import Conv2d, ConvReLU2d, Linear, LinearReLU, MCQTensor, QFunctional, mc_context  # noqa: F401
 from .models import BasicBlock, ConvNetwork_ResNet, ModelFactory  # noqa: F401
 from .models_mc import BernoulliDropout  # noqa: F401
-from .mc import mc_predict, shard_samples, finalize_moments, reduce_moments  # noqa: F401
+from .mc import mc_predict, mc_predict_regression, shard_samples, finalize_moments, reduce_moments  # noqa: F401
 from .quant import UINT_BOUNDS, INT_BOUNDS, NOISE_SCALE, NOISE_ZERO_POINT  # noqa: F401

@@ -1827,3 +1827,62 @@ QBNN_EXPORT int qbnn_dequant_softmax_mc(const uint8_t* x, int64_t x_ss, int32_t 
                      scale, zero_point, probs);
   return check_launch("qbnn_dequant_softmax_mc");
 }
+
+// =====================================================================================
+// fp32 Bayes-by-backprop path (BASELINE config 0: 3x100 MLP; reference bbb/linear.py:42-50).  Tiny, latency-bound:
+// plain VALU kernels.  W = mu + eps * sigma is two fp32 roundings (FloatFunctional mul then add), as in the reference.
+// =====================================================================================
+__global__ __launch_bounds__(256) void sample_weights_f32_kernel(const float* __restrict__ mu, const float* __restrict__ sigma,
+                                                                  int64_t n, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_id,
+                                                                  uint32_t sample_begin, const float* __restrict__ eps_in,
+                                                                  float* __restrict__ w) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;      // group of 4 consecutive weights
+  if (g * 4 >= n) return;
+  const int s = blockIdx.y;
+  float e[4];
+  if (eps_in) {
+    for (int j = 0; j < 4; ++j) e[j] = (g * 4 + j < n) ? eps_in[(int64_t)s * n + g * 4 + j] : 0.f;
+  } else {
+    qbnn::normal4(qbnn::philox4x32_10((uint32_t)g, layer_id, sample_begin + s, 0u, seed_lo, seed_hi), e);
+  }
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = g * 4 + j;
+    if (i < n) { const float t = e[j] * sigma[i]; w[(int64_t)s * n + i] = mu[i] + t; }
+  }
+}
+
+QBNN_EXPORT int qbnn_sample_weights_f32(const float* mu, const float* sigma, int64_t n, uint64_t seed, uint32_t layer_id,
+                                        uint32_t sample_begin, int32_t n_samples, const float* eps_in, float* w_out, void* stream) {
+  if (!mu || !sigma || !w_out || n <= 0 || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_sample_weights_f32: bad argument%s");
+  const int64_t groups = (n + 3) / 4;
+  hipLaunchKernelGGL(sample_weights_f32_kernel, dim3((unsigned)((groups + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
+                     mu, sigma, n, (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out);
+  return check_launch("qbnn_sample_weights_f32");
+}
+
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x, int64_t x_ss, const float* __restrict__ w,
+                                                          int64_t w_ss, const float* __restrict__ bias, float* __restrict__ y,
+                                                          int64_t y_ss, int B, int K, int N, int act) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * N) return;
+  const int s = blockIdx.y;
+  const int n = (int)(idx % N), b = (int)(idx / N);
+  const float* xp = x + (int64_t)s * x_ss + (int64_t)b * K;
+  const float* wp = w + (int64_t)s * w_ss + (int64_t)n * K;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = __builtin_fmaf(xp[k], wp[k], acc);
+  if (bias) acc = acc + bias[n];
+  if (act == 1) acc = fmaxf(acc, 0.f);
+  else if (act == 2) acc = expf(acc);
+  y[(int64_t)s * y_ss + idx] = acc;
+}
+
+QBNN_EXPORT int qbnn_linear_f32_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* bias, float* y,
+                                   int64_t y_ss, int32_t B, int32_t K, int32_t N, int32_t act, int32_t n_samples, void* stream) {
+  if (!x || !w || !y || B <= 0 || K <= 0 || N <= 0 || n_samples <= 0 || act < 0 || act > 2)
+    return fail(QBNN_E_INVALID, "qbnn_linear_f32_mc: bad argument%s");
+  const int64_t total = (int64_t)B * N;
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)((total + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
+                     x, x_ss, w, w_ss, bias, y, y_ss, B, K, N, act);
+  return check_launch("qbnn_linear_f32_mc");
+}

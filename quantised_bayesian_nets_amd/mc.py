@@ -49,6 +49,24 @@ def all_reduce_moments(moments, group=None):
     return moments
 
 
+def mc_predict_regression(model, x, samples, seed, group=None):
+    """Regression branch of the reference loop (experiments/utils.py:348-353):
+    returns (mean_s mu_s, var_unbiased_s(mu_s) + mean_s var_s), each [B, 1]."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    begin, count = shard_samples(samples, rank, world)
+    B = x.shape[0]
+    moments = torch.zeros((2, B, 2), dtype=torch.float32, device=x.device)
+    if count > 0:
+        with mc_context(count, seed, begin):
+            mu, var = model.forward_mc(x)
+        moments = reduce_moments(torch.cat([mu, var], dim=-1).contiguous())      # [2, B, 2]: sums and sums of squares of (mu, var)
+    all_reduce_moments(moments, group)
+    mean_mu = moments[0, :, 0:1] / samples
+    var_mu = (moments[1, :, 0:1] - samples * mean_mu * mean_mu).clamp_min(0) / max(samples - 1, 1)
+    return mean_mu, var_mu + moments[0, :, 1:2] / samples
+
+
 def mc_predict(model, x, samples, seed, return_var=False, chunk=None, group=None, return_probs=False):
     """Predictive mean (and variance) of `samples` stochastic forwards of `x`; equals the reference loop
     (experiments/utils.py:342-355) given identical per-sample weight noise."""

@@ -281,6 +281,9 @@ class ModelFactory:
     def get_model(model, input_size, output_size, q, args, training_mode=True):
         if model == "conv_resnet_bbb":
             return ConvNetwork_ResNet(input_size, output_size, q, args)
+        if model == "linear_bbb":
+            from .models_f32 import LinearNetwork as LinearNetworkBBB
+            return LinearNetworkBBB(input_size, output_size, q, args)
         if model == "conv_lenet_mc":
             from .models_mc import ConvNetwork_LeNet as ConvNetwork_LeNetMC
             return ConvNetwork_LeNetMC(input_size, output_size, q, args)

@@ -36,3 +36,10 @@ def golden_w8():
 @pytest.fixture(scope="session")
 def golden_lenet_mc():
     return load_golden("lenet_mc_a7w8.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_mlp_f32():
+    d = np.load(os.path.join(GOLDEN, "mlp_bbb_f32.npz"))
+    return dict(state={k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}, x=d["x"], mu=d["mu"], var=d["var"],
+                mean=d["mean"], pred_var=d["pred_var"], seed=int(d["meta.philox_seed"]), in_dim=int(d["meta.in_dim"]))

@@ -281,6 +281,27 @@ def test_lenet_mc_dropout_matches_reference(golden_lenet_mc):
     np.testing.assert_allclose(pb[1].cpu().numpy(), net.forward(xb.numpy(), seed, 8), rtol=RTOL, atol=1e-8)
 
 
+def test_float_bbb_mlp_matches_reference(golden_mlp_f32):
+    """BASELINE config 0: fp32 BBB MLP, in-kernel Philox eps, per-sample (mu, var) and the regression MC reduction
+    (experiments/utils.py:348-353) against the reference; tolerance 1e-5 relative (BASELINE north_star)."""
+    import quantised_bayesian_nets_amd as q
+    g = golden_mlp_f32
+    args = types.SimpleNamespace(sigma_prior=-2.0)
+    m = q.ModelFactory.get_model("linear_bbb", [g["in_dim"]], 1, False, args).load_reference_state(g["state"])
+    x = torch.from_numpy(g["x"]).cuda()
+    S = g["mu"].shape[0]
+    with q.mc_context(S, g["seed"], 0):
+        mu, var = m.forward_mc(x)
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(var.cpu().numpy(), g["var"], rtol=1e-5, atol=1e-8)
+    mean, pv = q.mc_predict_regression(m, x, S, g["seed"])
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(pv.cpu().numpy(), g["pred_var"], rtol=1e-4, atol=1e-7)
+    with q.mc_context(1, g["seed"], 4):
+        mu4, var4 = m(x)
+    np.testing.assert_allclose(mu4.cpu().numpy(), g["mu"][4], rtol=1e-5, atol=2e-6)
+
+
 def test_errors_are_loud():
     from quantised_bayesian_nets_amd import _lib
     d = _lib.ConvDesc()

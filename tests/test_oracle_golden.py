@@ -89,3 +89,16 @@ def test_lenet_mc_dropout_bit_exact(golden_lenet_mc):
     z4 = int(g["state"]["layers.4.mul_mask.zero_point"])
     dropped = (g["rec"]["layers.4.out"].reshape(g["x"].shape[0], -1, 50) == z4).all(axis=1).mean()
     assert 0.02 < dropped < 0.5
+
+
+def test_float_bbb_mlp_matches_reference(golden_mlp_f32):
+    """BASELINE config 0 (fp32 Bayes-by-backprop MLP, 10 samples): oracle vs the reference, 1e-5 relative."""
+    g = golden_mlp_f32
+    net = orc.F32MLPOracle(g["state"])
+    for s in (0, 3, 9):
+        mu, var = net.forward(g["x"], g["seed"], s)
+        np.testing.assert_allclose(mu, g["mu"][s], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(var, g["var"][s], rtol=1e-5, atol=1e-8)
+    mean, pv = net.mc_predict(g["x"], g["mu"].shape[0], g["seed"])
+    np.testing.assert_allclose(mean, g["mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pv, g["pred_var"], rtol=1e-4, atol=1e-7)
