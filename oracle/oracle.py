@@ -453,3 +453,49 @@ class F32MLPOracle:
         mus, vs = zip(*[self.forward(x, seed, s) for s in range(samples)])
         mus, vs = np.stack(mus).astype(np.float64), np.stack(vs).astype(np.float64)
         return mus.mean(0).astype(np.float32), (mus.var(0, ddof=1) + vs.mean(0)).astype(np.float32)
+
+
+# ------------------------------------- deterministic int8 ResNet member (config 3) ---
+class Int8ResNetDetOracle:
+    """One ensemble member of `conv_resnet_sgld` after convert: reference sgld/models_sgld.py:109-212 (graph identical to
+    the BBB ResNet, standard torch.nn.quantized Conv2d / ConvReLU2d / Linear, no weight noise); softmax is applied by the
+    wrapper (models_sgld.py:286-287)."""
+
+    def __init__(self, state, a_bits=7):
+        self.st, self.a_hi = state, UINT_BOUNDS[a_bits][1]
+        self.table = resnet_layer_table()
+
+    def conv(self, pfx, x, s_x, z_x, stride, pad, relu):
+        g = lambda k: self.st[pfx + k]
+        w = oihw_to_ohwi(np.asarray(g("weight"), np.int8))
+        b = self.st.get(pfx + "bias", None)
+        sy, zy = float(g("scale")), int(g("zero_point"))
+        if w.ndim == 2:
+            y = linear_i8(x, w, b, s_x, z_x, float(g("weight.q_scale")), int(g("weight.q_zero_point")), sy, zy, relu, self.a_hi)
+        else:
+            y = conv2d_i8(x, w, b, stride, pad, s_x, z_x, float(g("weight.q_scale")), int(g("weight.q_zero_point")), sy, zy, relu, self.a_hi)
+        return y, sy, zy
+
+    def forward(self, x_nchw, record=None):
+        st, a_hi = self.st, self.a_hi
+        rec = (lambda k, v: record.__setitem__(k, v)) if record is not None else (lambda k, v: None)
+        s, z = float(np.asarray(st["quant.scale"]).reshape(-1)[0]), int(np.asarray(st["quant.zero_point"]).reshape(-1)[0])
+        x = quantize_input_nchw(x_nchw, s, z, a_hi)
+        x, s, z = self.conv("layers.0.", x, s, z, 1, 1, True); rec("layers.0.out", x)
+        for li, fs in ((3, 1), (4, 2), (5, 2), (6, 2)):
+            for bi in (0, 1):
+                p = f"layers.{li}.{bi}."
+                stn = fs if bi == 0 else 1
+                o, so, zo = self.conv(p + "stem.0.", x, s, z, stn, 1, True)
+                o, so, zo = self.conv(p + "stem.3.", o, so, zo, 1, 1, False)
+                if (p + "shortcut.0.weight") in st:
+                    sc, ss, zs = self.conv(p + "shortcut.0.", x, s, z, stn, 0, False)
+                else:
+                    sc, ss, zs = x, s, z
+                sa, za = float(st[p + "add.add.scale"]), int(st[p + "add.add.zero_point"])
+                x = qadd_relu(o, so, zo, sc, ss, zs, sa, za, True, a_hi)
+                s, z = sa, za
+                rec(p[:-1] + ".out", x)
+        x = avgpool_q(x, 4, z, a_hi).reshape(x.shape[0], -1)
+        x, s, z = self.conv("layers.9.", x, s, z, 1, 0, False); rec("layers.9.out", x)
+        return dequant_softmax(x, s, z)

@@ -1138,6 +1138,7 @@ __global__ __launch_bounds__(NTHR, 2) void block_chain_i8_kernel(const ChainArgs
     load_bias<C::COUT, NTHR>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
     load_bias<C::COUT, NTHR>(bias_lds + (2 * k + 1) * C::COUT, a.blk[k].b.bias, tid);
   }
+  __syncthreads();      // bias table + halos visible: conv_lds reads the bias BEFORE its first barrier
 
   // input prefetch registers.  The loads are unconditional (address clamped, value zeroed at use) and are issued
   // right after a barrier, so the following barrier's vmcnt(0) finds them long landed.
@@ -1365,6 +1366,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_i8_kernel(const DownAr
   load_bias<COUT, BLK_THREADS>(bias_lds, a.s.bias, tid);
   load_bias<COUT, BLK_THREADS>(bias_lds + COUT, a.a.bias, tid);
   load_bias<COUT, BLK_THREADS>(bias_lds + 2 * COUT, a.b.bias, tid);
+  __syncthreads();      // bias table + halos visible: conv_lds reads the bias BEFORE its first barrier
 
   v4i pre[PER_T];
   auto fetch = [&](int item) {

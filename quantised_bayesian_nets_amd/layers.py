@@ -140,6 +140,9 @@ class _BBBInt8(nn.Module):
         self.args = args
         self.layer_id = 0
         self._packed = None
+        # deterministic = a standard torch.nn.quantized Conv2d / Linear (ensemble members, reference sgld/models_sgld.py):
+        # the fixed qint8 weight is used as the "sampled" weight of the single sample, its qparams as add_weight's
+        self.deterministic = False
 
     def bias(self):
         return self.bias_
@@ -148,6 +151,15 @@ class _BBBInt8(nn.Module):
     def load_reference_state(self, state, prefix):
         g = lambda k: state[prefix + k]
         self.weight = QuantizedParam(g("weight"), g("weight.q_scale"), g("weight.q_zero_point"))
+        if self.deterministic:
+            self.std = QuantizedParam(np.zeros(self.weight.shape, np.int8), 1.0, 0)
+            b = state.get(prefix + "bias", None)
+            self.bias_ = None if b is None or np.asarray(b).size == 0 else torch.from_numpy(np.asarray(b, np.float32).copy())
+            self.scale, self.zero_point = float(g("scale")), int(g("zero_point"))
+            self.add_weight = QFunctional(self.weight.q_scale(), self.weight.q_zero_point())
+            self.mul_noise = QFunctional()
+            self._packed = None
+            return self
         self.std = QuantizedParam(g("std"), g("std.q_scale"), g("std.q_zero_point"))
         b = state.get(prefix + "bias_", None)
         self.bias_ = None if b is None or np.asarray(b).size == 0 else torch.from_numpy(np.asarray(b, np.float32).copy())
@@ -218,6 +230,11 @@ class _BBBInt8(nn.Module):
 
     def sample_weights(self, device, samples=None, seed=None, sample_begin=None, eps=None):
         """W_q for S samples in this layer's packed layout: int8 [S, nbytes]  (conv_q.py:113-119 chain, fused)."""
+        if self.deterministic:
+            pk = self._ensure_packed(device)
+            if (_MC.samples if samples is None else samples) != 1:
+                raise RuntimeError("a deterministic (ensemble member) layer evaluates exactly one sample per call")
+            return pk["mu"].reshape(1, -1)
         if samples is None and eps is None and _MC.eps is None and getattr(self, "_presampled", None) is not None:
             w, self._presampled = self._presampled, None      # produced by sample_all_weights() for this MC batch
             return w

@@ -133,12 +133,13 @@ class QuantStub(nn.Module):
 class ConvNetwork_ResNet(nn.Module):
     """reference models_bbb.py:191-256 (narrow ResNet-18: 24/48/96/192), converted int8 form."""
 
-    def __init__(self, input_size, output_size, q, args):
+    def __init__(self, input_size, output_size, q, args, deterministic=False):
         super().__init__()
         if not q:
             raise NotImplementedError("only the converted int8 model (q=True) is built so far")
         check_bits(args)
         self.args, self.q = args, q
+        self.deterministic = deterministic       # True: an ensemble member (standard quantised layers, no weight noise)
         self.in_planes = 24
         self.init_channels = input_size[1]
         self.output_size = int(output_size)
@@ -160,6 +161,7 @@ class ConvNetwork_ResNet(nn.Module):
         # Philox tensor ids = execution order of the stochastic layers
         for i, m in enumerate(self.stochastic_layers()):
             m.layer_id = i
+            m.deterministic = deterministic
 
     def _make_layer(self, planes, num_blocks, stride):
         strides = [stride] + [1] * (num_blocks - 1)
@@ -230,7 +232,8 @@ class ConvNetwork_ResNet(nn.Module):
         col = torch.empty((B, H * W, 32), dtype=torch.int8, device=dev)
         with timed("im2col3x3_c3"):
             _lib.check(L.qbnn_im2col3x3_c3(_lib.ptr(xq.data), B, H, W, xq.zero_point, _lib.ptr(col), _lib.current_stream()))
-        sample_all_weights(self.stochastic_layers(), dev)      # one launch for the 21 layers of this MC batch
+        if not self.deterministic:
+            sample_all_weights(self.stochastic_layers(), dev)      # one launch for the 21 layers of this MC batch
         l0 = self.layers[0]
         h = l0._conv(xq, l0.sample_weights(dev), S, im2col=col)
         if record is not None:
@@ -274,6 +277,46 @@ class ConvNetwork_ResNet(nn.Module):
             return self.forward_mc(x)[0]
 
 
+class Network(nn.Module):
+    """reference sgld.Network (src/models/stochastic/sgld/models_sgld.py:214-288) in evaluation form
+    (training_mode=False): `args.samples` deterministic int8 members; the "MC samples" are the members.
+    forward() round-robins the members through `self.counter` exactly like the reference; forward_mc() evaluates the
+    members [sample_begin, sample_begin + S) of the active mc_context (so mc_predict shards members over GPUs)."""
+
+    def __init__(self, input_size, output_size, q, args, training_mode=True):
+        super().__init__()
+        if training_mode:
+            raise NotImplementedError("training is out of scope (inference hot path only)")
+        if args.model != "conv_resnet_sgld":
+            raise NotImplementedError("Other templates not implemented!")
+        self.args, self.q, self.training_mode = args, q, training_mode
+        self.output_size = int(output_size)
+        self.ensemble = nn.ModuleList([ConvNetwork_ResNet(input_size, output_size, q, args, deterministic=True) for _ in range(args.samples)])
+        self.counter = 0
+
+    def load_reference_state(self, member_states):
+        assert len(member_states) == len(self.ensemble)
+        for m, st in zip(self.ensemble, member_states):
+            m.load_reference_state(st)
+        return self
+
+    def forward_mc(self, x, record=None):
+        n = len(self.ensemble)
+        outs = []
+        for i in range(_MC.samples):
+            with mc_context(1, _MC.seed, 0):
+                outs.append(self.ensemble[(_MC.sample_begin + i) % n].forward_mc(x, record=record if i == 0 else None))
+        return torch.cat(outs, 0)
+
+    def forward(self, x):
+        with mc_context(1, 0, 0):
+            y = self.ensemble[self.counter].forward_mc(x)[0]
+        self.counter += 1
+        if self.counter >= self.args.samples:
+            self.counter = 0
+        return y
+
+
 class ModelFactory:
     """reference src/models/__init__.py:12-40 (names kept)."""
 
@@ -281,6 +324,8 @@ class ModelFactory:
     def get_model(model, input_size, output_size, q, args, training_mode=True):
         if model == "conv_resnet_bbb":
             return ConvNetwork_ResNet(input_size, output_size, q, args)
+        if "sgld" in model:
+            return Network(input_size, output_size, q, args, training_mode)
         if model == "linear_bbb":
             from .models_f32 import LinearNetwork as LinearNetworkBBB
             return LinearNetworkBBB(input_size, output_size, q, args)

@@ -43,3 +43,12 @@ def golden_mlp_f32():
     d = np.load(os.path.join(GOLDEN, "mlp_bbb_f32.npz"))
     return dict(state={k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}, x=d["x"], mu=d["mu"], var=d["var"],
                 mean=d["mean"], pred_var=d["pred_var"], seed=int(d["meta.philox_seed"]), in_dim=int(d["meta.in_dim"]))
+
+
+@pytest.fixture(scope="session")
+def golden_ensemble():
+    d = np.load(os.path.join(GOLDEN, "ensemble_resnet_a7w8.npz"))
+    n = int(d["meta.members"])
+    members = [{k[len(f"member{i}/"):]: d[k] for k in d.files if k.startswith(f"member{i}/")} for i in range(n)]
+    rec = {k[len("rec/"):]: d[k] for k in d.files if k.startswith("rec/")}
+    return dict(members=members, rec=rec, x=d["x"], probs=d["probs"], mean_probs=d["mean_probs"])

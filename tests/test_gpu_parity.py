@@ -197,6 +197,24 @@ def test_fused_block_chain_equals_layerwise_and_golden(golden):
     np.testing.assert_allclose(pf.cpu().numpy(), g["probs"], rtol=RTOL, atol=1e-8)
 
 
+def test_fused_kernels_first_item_race_regression(golden_w8):
+    """Few work items per workgroup (S = 1, 2 at B = 256 / 37): the first conv of a workgroup's first item reads the bias
+    table and halos written by the kernel prologue.  Repeated fused runs must equal the layer-wise path every time
+    (a missing prologue barrier made this fail about one run in three)."""
+    import quantised_bayesian_nets_amd as q
+    m = _model(golden_w8)
+    gen = torch.Generator().manual_seed(11)
+    for B in (256, 37):
+        x = torch.randn(B, 3, 32, 32, generator=gen).cuda()
+        for S in (1, 2):
+            with q.mc_context(S, 5, 3):
+                m.fuse_blocks = False
+                ref = m.forward_mc(x)
+                m.fuse_blocks = True
+                for _ in range(6):
+                    assert torch.equal(m.forward_mc(x), ref), (B, S)
+
+
 def test_full_size_against_oracle_and_properties(golden_w8):
     """BASELINE config 3 shape (B=256): one sample against the CPU oracle bit-for-bit on the logits path, and
     size-independent properties: chunking / sharding invariance, batch-permutation equivariance, determinism."""
@@ -300,6 +318,31 @@ def test_float_bbb_mlp_matches_reference(golden_mlp_f32):
     with q.mc_context(1, g["seed"], 4):
         mu4, var4 = m(x)
     np.testing.assert_allclose(mu4.cpu().numpy(), g["mu"][4], rtol=1e-5, atol=2e-6)
+
+
+def test_ensemble_matches_reference(golden_ensemble):
+    """BASELINE config 3: SGHMC-style ensemble of deterministic int8 ResNets; members are the MC samples."""
+    import quantised_bayesian_nets_amd as q
+    g = golden_ensemble
+    n = len(g["members"])
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, model="conv_resnet_sgld", samples=n)
+    net = q.ModelFactory.get_model("conv_resnet_sgld", [1, 3, 32, 32], 10, True, args, training_mode=False).load_reference_state(g["members"])
+    x = torch.from_numpy(g["x"]).cuda()
+    rec = {}
+    with q.mc_context(n, 0, 0):
+        probs = net.forward_mc(x, record=rec)
+    for k in ("layers.0.out", "layers.3.1.out", "layers.4.0.out", "layers.6.1.out"):
+        got = rec[k][0].cpu().numpy() if rec[k].dim() == 5 else rec[k].cpu().numpy()
+        assert np.array_equal(got, g["rec"][k]), k
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=RTOL, atol=1e-8)
+    mean = q.mc_predict(net, x, n, 0)
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean_probs"], rtol=RTOL, atol=1e-8)
+    # the reference's round-robin call contract (models_sgld.py:277-288)
+    outs = [net(x).cpu().numpy() for _ in range(n + 1)]
+    np.testing.assert_allclose(np.stack(outs[:n]), g["probs"], rtol=RTOL, atol=1e-8)
+    assert np.array_equal(outs[0], outs[n])
+    with pytest.raises(NotImplementedError):
+        q.ModelFactory.get_model("conv_resnet_sgld", [1, 3, 32, 32], 10, True, args, training_mode=True)
 
 
 def test_errors_are_loud():

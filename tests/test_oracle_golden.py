@@ -102,3 +102,18 @@ def test_float_bbb_mlp_matches_reference(golden_mlp_f32):
     mean, pv = net.mc_predict(g["x"], g["mu"].shape[0], g["seed"])
     np.testing.assert_allclose(mean, g["mean"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(pv, g["pred_var"], rtol=1e-4, atol=1e-7)
+
+
+def test_ensemble_members_match_reference(golden_ensemble):
+    """BASELINE config 3: deterministic int8 ResNet members ("samples" = members), wrapper softmax + mean."""
+    g = golden_ensemble
+    ps = []
+    for i, st in enumerate(g["members"]):
+        o = orc.Int8ResNetDetOracle(st, 7)
+        rec = {}
+        ps.append(o.forward(g["x"], record=rec))
+        if i == 0:
+            for k, v in g["rec"].items():
+                assert np.array_equal(rec[k], v.reshape(rec[k].shape)), k
+    np.testing.assert_allclose(np.stack(ps), g["probs"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(np.stack(ps).mean(0), g["mean_probs"], rtol=1e-5, atol=1e-8)
