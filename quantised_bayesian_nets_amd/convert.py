@@ -1,0 +1,117 @@
+"""QAT -> int8 conversion of Bayes-by-backprop layers, restated natively.
+
+What the reference does at `quant_utils.convert` time for one stochastic layer (conv_q.py:127-177, :214-225,
+linear_q.py:105-145, bbb/conv.py:70-80), expressed on plain tensors:
+
+  1. ConvBn* only -- fold BatchNorm into the distribution parameters:
+        c = gamma * rsqrt(running_var + eps);  mu' = mu * c;  rho' = softplusinv(softplus(rho) * c);
+        bias' = (bias - running_mean) * rsqrt(running_var + eps) * gamma + beta
+  2. one more observer step (MovingAverageMinMax, c = 0.01) of the weight / std FakeQuantize on mu' / softplus(rho'),
+  3. per-tensor-affine qparams from the observers (min/max widened to include 0; zero_point = qmin - round(min/scale)),
+  4. torch.quantize_per_tensor(mu', s_w, z_w, qint8), same for softplus(rho'),
+  5. output (scale, zero_point) from the activation observer; add_weight / mul_noise (scale, zero_point) from theirs.
+
+Host-side only (runs once per model, on CPU tensors); torch is used for the elementwise float ops so that softplus /
+rsqrt / log / exp round exactly as in the reference's own conversion.  Validated bit-for-bit against the reference's
+convert() on real layers: tests/golden/make_golden_convert.py -> tests/test_convert.py.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .layers import QFunctional, QuantizedParam
+
+AVERAGING_CONSTANT = 0.01      # torch MovingAverageMinMaxObserver default, used by the reference's qconfig (quant_utils.py:129-138)
+_EPS = torch.finfo(torch.float32).eps
+
+
+def softplusinv(x):
+    """reference bbb/utils_bbb.py:7-8."""
+    return torch.log(torch.exp(x) - 1.)
+
+
+def fold_bn(mu, rho, bias, bn_rm, bn_rv, bn_eps, bn_w, bn_b):
+    """reference bbb/conv.py:70-80 (fuse_conv_bn_weights)."""
+    if bias is None:
+        bias = torch.zeros_like(bn_rm)
+    rs = torch.rsqrt(bn_rv + bn_eps)
+    c = (bn_w * rs).reshape([-1] + [1] * (mu.dim() - 1))
+    return mu * c, softplusinv(F.softplus(rho) * c), (bias - bn_rm) * rs * bn_w + bn_b
+
+
+class ObserverState:
+    """min/max state of a MovingAverageMinMaxObserver inside a FakeQuantize (per-tensor affine)."""
+
+    def __init__(self, min_val, max_val, quant_min, quant_max):
+        self.min_val = torch.as_tensor(min_val, dtype=torch.float32).reshape(())
+        self.max_val = torch.as_tensor(max_val, dtype=torch.float32).reshape(())
+        self.quant_min, self.quant_max = int(quant_min), int(quant_max)
+
+    @classmethod
+    def from_fake_quant(cls, fq):
+        """Duck-typed read of a torch.quantization.FakeQuantize (or a bare observer) instance."""
+        obs = getattr(fq, "activation_post_process", fq)
+        return cls(obs.min_val.detach().clone(), obs.max_val.detach().clone(), getattr(fq, "quant_min", obs.quant_min),
+                   getattr(fq, "quant_max", obs.quant_max))
+
+    def observe(self, x):
+        mn, mx = torch.aminmax(x.detach().to(torch.float32))
+        if self.min_val == float("inf") and self.max_val == float("-inf"):
+            self.min_val, self.max_val = mn, mx
+        else:
+            self.min_val = self.min_val + AVERAGING_CONSTANT * (mn - self.min_val)
+            self.max_val = self.max_val + AVERAGING_CONSTANT * (mx - self.max_val)
+        return self
+
+    def qparams(self):
+        mn = torch.min(self.min_val, torch.zeros_like(self.min_val))
+        mx = torch.max(self.max_val, torch.zeros_like(self.max_val))
+        scale = (mx - mn) / float(self.quant_max - self.quant_min)
+        scale = torch.max(scale, torch.tensor(_EPS))
+        zp = self.quant_min - torch.round(mn / scale).to(torch.int)
+        zp = torch.clamp(zp, self.quant_min, self.quant_max)
+        return float(scale), int(zp)
+
+
+def quantize_qint8(x, scale, zero_point):
+    """torch.quantize_per_tensor(x, scale, zp, torch.qint8).int_repr(): clamp(rne(x * (1/scale)) + zp, -128, 127)."""
+    return torch.quantize_per_tensor(x.to(torch.float32), float(scale), int(zero_point), torch.qint8).int_repr().numpy()
+
+
+def convert_layer(mu, rho, bias, w_obs, std_obs, act_obs, add_obs, mul_obs, bn=None):
+    """One QAT BBB layer -> the converted int8 layer's state (reference key names, flat numpy).
+    bn: None or dict(running_mean, running_var, eps, weight, bias)."""
+    mu, rho = torch.as_tensor(mu, dtype=torch.float32), torch.as_tensor(rho, dtype=torch.float32)
+    bias = None if bias is None else torch.as_tensor(bias, dtype=torch.float32)
+    if bn is not None:
+        mu, rho, bias = fold_bn(mu, rho, bias, torch.as_tensor(bn["running_mean"]), torch.as_tensor(bn["running_var"]), float(bn["eps"]),
+                                torch.as_tensor(bn["weight"]), torch.as_tensor(bn["bias"]))
+    sigma = F.softplus(rho)
+    s_w, z_w = w_obs.observe(mu).qparams()
+    s_s, z_s = std_obs.observe(sigma).qparams()
+    s_y, z_y = act_obs.qparams()
+    s_a, z_a = add_obs.qparams()
+    s_m, z_m = mul_obs.qparams()
+    out = {"weight": quantize_qint8(mu, s_w, z_w), "weight.q_scale": np.float64(s_w), "weight.q_zero_point": np.int64(z_w),
+           "std": quantize_qint8(sigma, s_s, z_s), "std.q_scale": np.float64(s_s), "std.q_zero_point": np.int64(z_s),
+           "scale": np.float32(s_y), "zero_point": np.int64(z_y),
+           "add_weight.scale": np.float32(s_a), "add_weight.zero_point": np.int64(z_a),
+           "mul_noise.scale": np.float32(s_m), "mul_noise.zero_point": np.int64(z_m)}
+    if bias is not None:
+        out["bias_"] = bias.detach().numpy()
+    return out
+
+
+def convert_qat_module(mod):
+    """Duck-typed entry for a reference QAT module instance (conv_qat.Conv2d / ConvBn2d / ConvReLU2d / ConvBnReLU2d,
+    linear_qat.Linear / LinearReLU): reads its tensors and observer states, returns the converted layer state."""
+    bn = None
+    if hasattr(mod, "bn"):
+        b = mod.bn
+        bn = dict(running_mean=b.running_mean.detach(), running_var=b.running_var.detach(), eps=b.eps, weight=b.weight.detach(), bias=b.bias.detach())
+    bias = None if getattr(mod, "bias", None) is None else mod.bias.detach()
+    return convert_layer(mod.weight.detach(), mod.std.detach(), bias,
+                         ObserverState.from_fake_quant(mod.weight_fake_quant), ObserverState.from_fake_quant(mod.std_fake_quant),
+                         ObserverState.from_fake_quant(mod.activation_post_process),
+                         ObserverState.from_fake_quant(mod.add_weight.activation_post_process),
+                         ObserverState.from_fake_quant(mod.mul_noise.activation_post_process), bn)

@@ -351,8 +351,13 @@ class Conv2d(_BBBInt8):
     def from_float(cls, mod):
         """Accepts an already converted reference module (conv_q.Conv2d / ConvReLU2d instance)."""
         if hasattr(mod, 'weight_fake_quant'):
-            raise NotImplementedError("QAT -> int8 conversion (reference conv_q.py:127-177) is not built yet; "
-                                      "convert with the reference and pass the converted module")
+            # a reference QAT module (conv_qat.Conv2d / ConvBn2d / ConvReLU2d / ConvBnReLU2d): native restatement of
+            # conv_q.py:127-177 (BN folding, observer step, qparams, weight quantisation) in convert.py
+            from .convert import convert_qat_module
+            st = convert_qat_module(mod)
+            q = cls(mod.in_channels, mod.out_channels, mod.kernel_size, mod.stride, mod.padding, mod.dilation, mod.groups,
+                    "bias_" in st, mod.padding_mode, args=getattr(mod, "args", None))
+            return q.load_reference_state(st, "")
         return cls._from_converted(mod, mod.in_channels, mod.out_channels, mod.kernel_size, mod.stride, mod.padding,
                                    mod.dilation, mod.groups, mod.bias() is not None, mod.padding_mode)
 
@@ -382,7 +387,10 @@ class Linear(_BBBInt8):
     @classmethod
     def from_float(cls, mod):
         if hasattr(mod, 'weight_fake_quant'):
-            raise NotImplementedError("QAT -> int8 conversion (reference linear_q.py:105-145) is not built yet")
+            from .convert import convert_qat_module      # reference linear_q.py:105-145, restated in convert.py
+            st = convert_qat_module(mod)
+            q = cls(mod.in_features, mod.out_features, "bias_" in st, args=getattr(mod, "args", None))
+            return q.load_reference_state(st, "")
         return cls._from_converted(mod, mod.in_features, mod.out_features, mod.bias() is not None)
 
 
