@@ -211,6 +211,11 @@ int qbnn_linear_f32_mc(const float* x, int64_t x_sample_stride, const float* w, 
                        float* y, int64_t y_sample_stride, int32_t B, int32_t K, int32_t N, int32_t act, int32_t n_samples,
                        void* stream);
 
+/* Classification metrics of a [B][C] predictive mean against int64 targets (reference src/metrics.py: Error :8-33,
+ * ClassificationNegativeLogLikelihood :36-62, BrierScore :65-91, PredictiveEntropy :94-116, 10-bin L1 calibration error
+ * :381-383).  Writes ceil(B/256) rows of 34 partial sums (layout: csrc/qbnn_kernels.hip); the caller adds the rows. */
+int qbnn_classification_metrics(const float* probs, const int64_t* target, int32_t B, int32_t C, float* partials, void* stream);
+
 const char* qbnn_last_error(void);
 int qbnn_version(void);
 

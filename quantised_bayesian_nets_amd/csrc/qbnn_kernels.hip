@@ -1888,3 +1888,58 @@ QBNN_EXPORT int qbnn_linear_f32_mc(const float* x, int64_t x_ss, const float* w,
                      x, x_ss, w, w_ss, bias, y, y_ss, B, K, N, act);
   return check_launch("qbnn_linear_f32_mc");
 }
+
+// =====================================================================================
+// Classification metrics on the reduced output (reference src/metrics.py:8-116, :355-430), on device so the [B,C]
+// predictive mean need not return to the host per batch.  One thread per image; per-block partial sums
+//   [0] errors  [1] sum -log(p_target + 1e-8)  [2] sum_c (p - onehot)^2  [3] sum_c -p log(p + 1e-8)
+//   [4+b] count, [14+b] confidence sum, [24+b] accuracy sum of calibration bin b (10 uniform bins on max-prob;
+//   bin = index of the first boundary >= confidence, minus 1: torch.bucketize(conf, linspace(0,1,11), right=True) - 1).
+// The host sums the partial rows (deterministic).
+// =====================================================================================
+#define QBNN_METRIC_SLOTS 34
+__global__ __launch_bounds__(256) void classification_metrics_kernel(const float* __restrict__ probs, const int64_t* __restrict__ target,
+                                                                      int B, int C, float* __restrict__ partials) {
+  __shared__ float red[QBNN_METRIC_SLOTS][4];
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  float v[QBNN_METRIC_SLOTS];
+#pragma unroll
+  for (int i = 0; i < QBNN_METRIC_SLOTS; ++i) v[i] = 0.f;
+  if (b < B) {
+    const float* p = probs + (int64_t)b * C;
+    const int t = (int)target[b];
+    int am = 0; float conf = p[0], brier = 0.f, ent = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float pc = p[c];
+      if (pc > conf) { conf = pc; am = c; }
+      const float oh = c == t ? 1.f : 0.f;
+      brier += (pc - oh) * (pc - oh);
+      ent += -pc * logf(pc + 1e-8f);
+    }
+    const float acc = am == t ? 1.f : 0.f;
+    v[0] = 1.f - acc;
+    v[1] = -logf(p[t] + 1e-8f);
+    v[2] = brier;
+    v[3] = ent;
+    int bin = 0;                                   // boundaries k/10: right=True -> first k with k/10 > conf ... minus 1
+    for (int k = 1; k <= 10; ++k) bin = (conf >= (float)k * 0.1f) ? k : bin;
+    bin = min(bin, 9);
+    v[4 + bin] = 1.f; v[14 + bin] = conf; v[24 + bin] = acc;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < QBNN_METRIC_SLOTS; ++i) {
+    float x = v[i];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if (lane == 0) red[i][wave] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < QBNN_METRIC_SLOTS)
+    partials[(int64_t)blockIdx.x * QBNN_METRIC_SLOTS + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+QBNN_EXPORT int qbnn_classification_metrics(const float* probs, const int64_t* target, int32_t B, int32_t C, float* partials, void* stream) {
+  if (!probs || !target || !partials || B <= 0 || C <= 0) return fail(QBNN_E_INVALID, "qbnn_classification_metrics: bad argument%s");
+  hipLaunchKernelGGL(classification_metrics_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, probs, target, B, C, partials);
+  return check_launch("qbnn_classification_metrics");
+}

@@ -345,6 +345,29 @@ def test_ensemble_matches_reference(golden_ensemble):
         q.ModelFactory.get_model("conv_resnet_sgld", [1, 3, 32, 32], 10, True, args, training_mode=True)
 
 
+def test_classification_metrics_match_reference_formulas():
+    """src/metrics.py formulas evaluated with torch on the CPU (the reference's own expressions) vs the device kernel."""
+    import torch.nn.functional as F
+    import quantised_bayesian_nets_amd as q
+    gen = torch.Generator().manual_seed(0)
+    B, Cc = 1000, 10
+    probs = torch.softmax(torch.randn(B, Cc, generator=gen) * 2, -1)
+    target = torch.randint(0, Cc, (B,), generator=gen)
+    m = q.ClassificationMetric(Cc)
+    m.update(probs[:600].cuda(), target[:600].cuda())
+    m.update(probs[600:].cuda(), target[600:].cuda())
+    oh = F.one_hot(target, Cc).float()
+    assert abs(m.error - float((probs.argmax(1) != target).sum()) / B) < 1e-12
+    assert abs(m.nll - float(torch.sum(-oh * torch.log(probs + 1e-8))) / B) < 1e-5
+    assert abs(m.brier - float(torch.sum((probs - oh) ** 2)) / B) < 1e-5
+    assert abs(m.entropy - float(torch.sum(-probs * torch.log(probs + 1e-8))) / B) < 1e-5
+    conf, pred = probs.max(1)
+    acc = (pred == target).float()
+    bins = torch.bucketize(conf, torch.linspace(0, 1, 11), right=True) - 1
+    ece = sum(abs(acc[bins == b].mean() - conf[bins == b].mean()) * (bins == b).float().mean() for b in range(10) if (bins == b).any())
+    assert abs(m.ece - float(ece)) < 1e-5
+
+
 def test_errors_are_loud():
     from quantised_bayesian_nets_amd import _lib
     d = _lib.ConvDesc()
