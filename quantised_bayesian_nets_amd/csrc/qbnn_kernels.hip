@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <math.h>
 #include <string.h>
 #include <type_traits>
 
@@ -214,6 +215,8 @@ struct QAdd {              // BasicBlock Add + ReLU (models_bbb.py:179-182)
   float s_r, nzs_r; int z_r;       // residual operand qparams
   float inv_s_o; int z_o;          // add output qparams
   float vhi;                       // min(255, a_hi) - z_o ; lower bound is 0 (ReLU: q >= z_o)
+  const uint8_t* lut;              // optional 128x128 table of the whole add (qbnn_build_add_lut_host), device memory
+  int z_y;                         // zero point of the conv output that indexes the table rows
 };
 
 #define QBNN_MAGIC 12582912.0f     // 1.5 * 2^23: (v + MAGIC) has rne(v) in its low mantissa bits for |v| < 2^22
@@ -799,6 +802,17 @@ __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const
           epi.store(po, 8 * g4 + 4 * h, v0, v1, v2, v3, pre[g4]);
         }
       }
+#ifndef QBNN_NO_SCHED_HINT
+      if (mb > 0 && mb < C::MB) {
+        // in-order issue: the epilogue VALU of row mb-1 only hides under the (dependent) MFMAs of row mb if it sits
+        // between them in program order -- 1 MFMA : k VALU
+#pragma unroll
+        for (int i = 0; i < C::KS; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, Epi::VALU_PER_MFMA, 0);
+        }
+      }
+#endif
     }
     }
     QBNN_INNER_AT(2);
@@ -948,6 +962,7 @@ __device__ __forceinline__ void dma_slab_if_ring(uint8_t* dst, const int8_t* wq,
 //     already sits at the same address (updated in place).
 template <int COUT, bool HAS_RES>
 struct EpiDense {
+  static constexpr int VALU_PER_MFMA = HAS_RES ? 22 : 11;   // interleave hint: epilogue VALU ops of one 32-pixel row / 9 MFMAs
   uint8_t* outb; QConv p; QAdd a;
   __device__ __forceinline__ int pixel(int m) const { return m * COUT; }
   __device__ __forceinline__ uint32_t load(int po, int c0) const {
@@ -987,6 +1002,7 @@ __device__ __forceinline__ int tile_px_off(int m, int c0) {
 // (b) centred int8 (q - z_y) into the halo'd tile feeding the next conv (geometry HO x HO x COUT, halo 1)
 template <int HO, int COUT, int TILE_BYTES>
 struct EpiTile {
+  static constexpr int VALU_PER_MFMA = 10;
   uint8_t* dst; QConv p;
   __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, COUT, TILE_BYTES>(m, 0); }
   __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
@@ -1002,6 +1018,7 @@ struct EpiTile {
 //     geometry and overwritten in place with the centred block output (q_o - z_o).
 template <int HO, int COUT, int TILE_BYTES>
 struct EpiTileResInPlace {
+  static constexpr int VALU_PER_MFMA = 22;
   uint8_t* xt; QConv p; QAdd a;
   __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, COUT, TILE_BYTES>(m, 0); }
   __device__ __forceinline__ uint32_t load(int po, int c0) const {
@@ -1023,6 +1040,32 @@ struct EpiTileResInPlace {
       t[i] = med3f((da + db) * a.inv_s_o, 0.0f, a.vhi) + QBNN_MAGIC;
     }
     *o = pack_low_bytes(t[0], t[1], t[2], t[3]);
+  }
+};
+
+// (d) as (c), with the whole Add + ReLU looked up in the LDS copy of the block's 128x128 table:
+//     row = conv output q (centred byte q' = q - z_y), column = residual r (centred byte r' = r - z_r).
+template <int HO, int COUT, int TILE_BYTES>
+struct EpiTileResLut {
+  static constexpr int VALU_PER_MFMA = 13;
+  uint8_t* xt; const uint8_t* lut0;      // lut0 = table + (z_y << 7) + z_r : indexable by the centred bytes
+  QConv p;
+  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, COUT, TILE_BYTES>(m, 0); }
+  __device__ __forceinline__ uint32_t load(int po, int c0) const {
+    return *reinterpret_cast<const uint32_t*>(xt + po + c0);
+  }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rqu) const {
+    uint32_t* o = reinterpret_cast<uint32_t*>(xt + po + c0);
+    const int rq = (int)rqu;
+    const int q0 = (__float_as_int(med3f(v0, p.vlo, p.vhi) + QBNN_MAGIC) << 24) >> 24;
+    const int q1 = (__float_as_int(med3f(v1, p.vlo, p.vhi) + QBNN_MAGIC) << 24) >> 24;
+    const int q2 = (__float_as_int(med3f(v2, p.vlo, p.vhi) + QBNN_MAGIC) << 24) >> 24;
+    const int q3 = (__float_as_int(med3f(v3, p.vlo, p.vhi) + QBNN_MAGIC) << 24) >> 24;
+    const uint32_t o0 = lut0[(q0 << 7) + ((rq << 24) >> 24)];
+    const uint32_t o1 = lut0[(q1 << 7) + ((rq << 16) >> 24)];
+    const uint32_t o2 = lut0[(q2 << 7) + ((rq << 8) >> 24)];
+    const uint32_t o3 = lut0[(q3 << 7) + (rq >> 24)];
+    *o = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
   }
 };
 
@@ -1081,6 +1124,29 @@ static int launch_conv(const ConvArgs& a, int n_samples, bool has_res, hipStream
   return check_launch("qbnn_conv2d_i8_mc");
 }
 
+// The quantised residual add of a BasicBlock is a pure function of two 7-bit integers:
+//   out[q][r] = max(min(clamp(z_o + rne((fma(s_y, q, -z_y s_y) + fma(s_r, r, -z_r s_r)) * (1/s_o)), 0, 255), a_hi), z_o) - z_o_centre
+// (quantized::add -> clamp_activation -> ReLU -> clamp_activation, models_bbb.py:179-182).  Tabulating it (16 KiB, built
+// once per block on the host with exactly the arithmetic of the epilogue functors) replaces ~8 VALU operations per
+// output element by one LDS byte read.  centred != 0: entries hold (q_o - z_o) as int8, else q_o.
+QBNN_EXPORT int qbnn_build_add_lut_host(float s_y, int32_t z_y, float s_r, int32_t z_r, float s_o, int32_t z_o, int32_t a_hi,
+                                        int32_t centred, uint8_t* host_out) {
+  if (!host_out || a_hi < 1 || a_hi > 127) return fail(QBNN_E_INVALID, "qbnn_build_add_lut_host: bad argument%s");
+  const float nzs_y = (float)(-z_y) * s_y, nzs_r = (float)(-z_r) * s_r, inv = 1.0f / s_o;
+  for (int q = 0; q < 128; ++q)
+    for (int r = 0; r < 128; ++r) {
+      const float da = fmaf(s_y, (float)q, nzs_y), db = fmaf(s_r, (float)r, nzs_r);
+      float t = (da + db) * inv;
+      t = t < -1.0e9f ? -1.0e9f : (t > 1.0e9f ? 1.0e9f : t);
+      int o = z_o + (int)lrintf(t);
+      o = o < 0 ? 0 : (o > 255 ? 255 : o);
+      o = o > a_hi ? a_hi : o;
+      o = o < z_o ? z_o : o;
+      host_out[q * 128 + r] = (uint8_t)(centred ? (o - z_o) : o);
+    }
+  return QBNN_OK;
+}
+
 // =====================================================================================
 // Fused BasicBlock kernels (models_bbb.py:170-183): persistent workgroups, activations never leave LDS between
 // the block's convs.
@@ -1124,7 +1190,15 @@ __global__ __launch_bounds__(NTHR, 2) void block_chain_i8_kernel(const ChainArgs
   ring.buf[1] = ring.buf[0] + RSLAB;
   ring.cur = 0;
   float* bias_lds = reinterpret_cast<float*>(ring.buf[1] + RSLAB);        // [NBLK][2][COUT]
+  uint8_t* lut_lds = reinterpret_cast<uint8_t*>(bias_lds + NBLK * 2 * C::COUT);   // [NBLK][128*128] when the blocks carry tables
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool use_lut = a.blk[0].add.lut != nullptr;
+  if (use_lut) {
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k)
+      for (int i = tid; i < 1024; i += NTHR)
+        reinterpret_cast<v4i*>(lut_lds + k * 16384)[i] = reinterpret_cast<const v4i*>(a.blk[k].add.lut)[i];
+  }
 
   constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
   constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
@@ -1194,6 +1268,17 @@ __global__ __launch_bounds__(NTHR, 2) void block_chain_i8_kernel(const ChainArgs
             [&]() { if (k == 0 && next < n_items) fetch(next); });
       }
       QBNN_STAMP_AT(2);
+      if (use_lut)
+      {
+        EpiTileResLut<C::HO, C::COUT, C::TILE_BYTES> epi{xt, lut_lds + k * 16384 + (bp.b.z_y << 7) + bp.add.z_r, bp.b};
+        conv_any<C, decltype(epi), NWV>(tt, ring, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane,
+            [&](uint8_t* dst) {
+              if (k + 1 < NBLK) dma_slab_if_ring<C, NWV>(dst, a.blk[k + 1 < NBLK ? k + 1 : 0].a.w + (int64_t)s * a.blk[k + 1 < NBLK ? k + 1 : 0].a.w_ss, wave, lane);
+              else if (next < n_items) dma_slab_if_ring<C, NWV>(dst, a.blk[0].a.w + (int64_t)sample_of(next) * a.blk[0].a.w_ss, wave, lane);
+            },
+            [&]() {});
+      }
+      else
       {
         EpiTileResInPlace<C::HO, C::COUT, C::TILE_BYTES> epi{xt, bp.b, bp.add};
         conv_any<C, decltype(epi), NWV>(tt, ring, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane,
@@ -1233,21 +1318,29 @@ __global__ __launch_bounds__(NTHR, 2) void block_chain_i8_kernel(const ChainArgs
 
 // workgroup size per geometry: 256 threads (4 waves) where two workgroups fit a CU -- they run out of phase, so one's
 // MFMA phase overlaps the other's epilogue; 512 elsewhere
-template <class C> struct ChainThreads { static constexpr int v = (2 * (2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * (C::RING ? C::SLAB_BYTES : 16)) + 4096 <= 160 * 1024 && C::ROWREUSE) ? 256 : 512; };
+template <class C, int NBLK> struct ChainThreads {
+  static constexpr int one = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * (C::RING ? C::SLAB_BYTES : 16) + NBLK * (2 * C::COUT * 4 + 16384);
+  static constexpr int v = (2 * one <= 160 * 1024 && C::ROWREUSE) ? 256 : 512;
+};
 
 template <class C, int NBLK>
 static int launch_block_chain(const ChainArgs<NBLK>& a, hipStream_t st) {
-  constexpr int NTHR = ChainThreads<C>::v;
-  constexpr int LDS = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * (C::RING ? C::SLAB_BYTES : 16) + NBLK * 2 * C::COUT * 4;
-  static_assert(LDS <= 160 * 1024, "LDS budget");
+  constexpr int NTHR = ChainThreads<C, NBLK>::v;
+  constexpr int LDS_BASE = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * (C::RING ? C::SLAB_BYTES : 16) + NBLK * 2 * C::COUT * 4;
+  constexpr bool LUT_FITS = LDS_BASE + NBLK * 16384 <= 160 * 1024;
+  const bool want_lut = LUT_FITS && a.blk[0].add.lut != nullptr;
+  const int LDS = LDS_BASE + (want_lut ? NBLK * 16384 : 0);
+  ChainArgs<NBLK> a2 = a;
+  if (!want_lut) for (int k = 0; k < NBLK; ++k) a2.blk[k].add.lut = nullptr;
+  static_assert(LDS_BASE <= 160 * 1024, "LDS budget");
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_chain_i8_kernel<C, NBLK, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  if (!attr) { hipFuncSetAttribute((const void*)block_chain_i8_kernel<C, NBLK, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_FITS ? LDS_BASE + NBLK * 16384 : LDS_BASE); attr = true; }
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
   const int per_cu = ((160 * 1024) / LDS >= 2 && NTHR == 256) ? 2 : 1;
   int grid = 256 * per_cu;
   if (grid > n_items) grid = n_items;
-  hipLaunchKernelGGL((block_chain_i8_kernel<C, NBLK, NTHR>), dim3(grid), dim3(NTHR), LDS, st, a);
+  hipLaunchKernelGGL((block_chain_i8_kernel<C, NBLK, NTHR>), dim3(grid), dim3(NTHR), LDS, st, a2);
   return check_launch("qbnn_block_chain_i8_mc");
 }
 
@@ -1517,6 +1610,7 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
     if ((rc = fill_qconv(a.blk[k].b, b.w_b, b.w_b_sample_stride, b.bias_b, &d))) return rc;
     d.s_r = s_in; d.z_r = z_in; d.s_o = b.s_o; d.z_o = b.z_o;
     if ((rc = fill_qadd(a.blk[k].add, &d))) return rc;
+    a.blk[k].add.lut = b.add_lut; a.blk[k].add.z_y = b.z_b;
     s_in = b.s_o; z_in = b.z_o;
   }
   if (Cc == 24 && H == 32) return launch_block_chain<Blk_24, NBLK>(a, st);

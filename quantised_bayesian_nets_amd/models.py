@@ -93,6 +93,24 @@ def run_down_block(blk, x):
     return MCQTensor(y, blk.add.add.scale, blk.add.add.zero_point)
 
 
+def _add_lut(blk, s_res, z_res, dev):
+    """Device copy of the block's 128x128 Add+ReLU table (built once per (block, residual qparams))."""
+    key = (float(s_res), int(z_res), str(dev))
+    cache = blk.__dict__.setdefault("_lut_cache", {})
+    if key not in cache:
+        cb = blk.stem[3]
+        host = np.zeros(16384, np.uint8)
+        a_hi = UINT_BOUNDS[blk.args.activation_precision][1]
+        _lib.check(_lib.lib().qbnn_build_add_lut_host(cb.scale, cb.zero_point, s_res, z_res, blk.add.add.scale, blk.add.add.zero_point,
+                                                      a_hi, 1, host.ctypes.data_as(C.c_void_p)))
+        cache[key] = torch.from_numpy(host).to(dev)
+    return cache[key]
+
+
+USE_ADD_LUT = False      # measured on MI355X: the table's random LDS byte reads cost more than the ~8 VALU ops/element they replace
+                         # (layer-1 chain 1.50 -> 1.76 ms); kept selectable for future layouts
+
+
 def run_identity_chain(blocks, x):
     """1 or 2 identity BasicBlocks (no shortcut conv) in ONE persistent fused kernel (qbnn_block_chain_i8_mc):
     activations stay in LDS between stem.0, stem.3 and the residual add.  Same results as calling the blocks."""
@@ -100,8 +118,14 @@ def run_identity_chain(blocks, x):
     dev = x.data.device
     descs = (_lib.BlockDesc * len(blocks))()
     keep = []
+    s_res, z_res = x.scale, x.zero_point
     for d, blk in zip(descs, blocks):
         assert len(blk.shortcut) == 0
+        if USE_ADD_LUT:
+            lut = _add_lut(blk, s_res, z_res, dev)
+            keep.append(lut)
+            d.add_lut = lut.data_ptr()
+        s_res, z_res = blk.add.add.scale, blk.add.add.zero_point
         ca, cb = blk.stem[0], blk.stem[3]
         wa, wb = ca.sample_weights(dev), cb.sample_weights(dev)
         pa, pb = ca._ensure_packed(dev), cb._ensure_packed(dev)
