@@ -117,9 +117,14 @@ def main():
         abytes = sum(conv_algorithmic_bytes(S_local, a.batch, H, ci, co, ks, st, nw) for (H, ci, co, ks, st, nw) in m["convs"])
         ops = sum(conv_ops(S_local, a.batch, H, ci, co, ks, st) for (H, ci, co, ks, st, nw) in m["convs"])
         gbs, tops = abytes / avg_s / 1e9, ops / avg_s / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and S_local == 100 and a.batch == 256:
+            # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE; see that file's note)
+            traffic = json.load(open(tpath))["by_bench_key"].get(dom)
         common = {"kernel": dom, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": d["n"],
                   "share_of_gpu_time": round(d["ms"] / total_ms, 3), "convs_in_launch": len(m["convs"]),
-                  "algorithmic_bytes_per_launch": abytes, "algorithmic_ops_per_launch": ops, "traffic": None}
+                  "algorithmic_bytes_per_launch": abytes, "algorithmic_ops_per_launch": ops, "traffic": traffic}
         if m["fused"]:
             # fused block kernels keep activations in LDS: their HBM traffic is a fraction of the layer-granular byte
             # model, the binding roof is the int8 matrix pipe

@@ -1546,9 +1546,9 @@ static int launch_block_down(const DownArgs& a, hipStream_t st) {
 using D24_a = ConvCfg<24, 48, 3, 2, 32, 1, 1, 1, 2>;
 using D24_s = ConvCfg<24, 48, 1, 2, 32, 1, 1, 1, 2>;
 using D24_b = ConvCfg<48, 48, 3, 1, 16, 1, 1, 1, 2>;
-using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 2, 1, 3>;
-using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 2, 1, 3>;
-using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 2, 1, 3>;
+using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 4, 1, 3, false>;
+using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 4, 1, 3, false>;
+using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, false>;
 using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
 using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, 1, 3, false>;
 using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
