@@ -201,6 +201,11 @@ int qbnn_dropout_q_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int3
 int qbnn_maxpool2_q_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t a_hi,
                        uint8_t* y, int64_t y_sample_stride, int32_t n_samples, void* stream);
 
+/* Flatten (src/utils.py:40-47) of a channels-last map into the reference's NCHW feature order: x [S][B][HW][C] ->
+ * y [S][B][C*HW].  Used in front of a stochastic Linear (its noise stream follows the reference's column order). */
+int qbnn_flatten_nchw_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int32_t HW, int32_t C, uint8_t* y,
+                         int64_t y_sample_stride, int32_t n_samples, void* stream);
+
 /* DeQuantStub + F.softmax(dim=-1): x [S][B][N] uint8 -> probs [S][B][N] fp32. */
 int qbnn_dequant_softmax_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int32_t N, float scale, int32_t zero_point,
                             float* probs, int32_t n_samples, void* stream);

@@ -499,3 +499,68 @@ class Int8ResNetDetOracle:
         x = avgpool_q(x, 4, z, a_hi).reshape(x.shape[0], -1)
         x, s, z = self.conv("layers.9.", x, s, z, 1, 0, False); rec("layers.9.out", x)
         return dequant_softmax(x, s, z)
+
+
+# ------------------------------------------------- small int8 BBB graphs (row a6) ---
+class _Int8BBBBase:
+    def __init__(self, state, a_bits, w_bits, names, relus):
+        self.st, self.a_hi, self.w_bits = state, UINT_BOUNDS[a_bits][1], w_bits
+        self.L = {n: Int8Layer(state, n + ".", i, 1, 0, r, w_bits) for i, (n, r) in enumerate(zip(names, relus))}
+        self.s_in = float(np.asarray(state["quant.scale"]).reshape(-1)[0])
+        self.z_in = int(np.asarray(state["quant.zero_point"]).reshape(-1)[0])
+
+
+class Int8LeNetBBBOracle(_Int8BBBBase):
+    """conv_lenet_bbb int8: reference models_bbb.py:98-143 (no ReLU after the convs; layers.5 fused LinearReLU)."""
+
+    def __init__(self, state, a_bits=7, w_bits=8):
+        super().__init__(state, a_bits, w_bits, ["layers.0", "layers.2", "layers.5", "layers.7"], [False, False, True, False])
+        for n in ("layers.0", "layers.2"):
+            self.L[n].stride, self.L[n].pad = 1, 2
+        # the reference flattens NCHW (src/utils.py:40-47); NHWC here: permute the 2450 input columns of layers.5
+        l5 = self.L["layers.5"]
+        l5.mu_q = np.ascontiguousarray(l5.mu_q.reshape(500, 50, 7, 7).transpose(0, 2, 3, 1).reshape(500, 2450))
+        l5.sigma_q = np.ascontiguousarray(l5.sigma_q.reshape(500, 50, 7, 7).transpose(0, 2, 3, 1).reshape(500, 2450))
+        self.perm5 = np.arange(2450).reshape(50, 7, 7).transpose(1, 2, 0).reshape(-1)     # nhwc position -> reference (c,h,w) index
+
+    def sample(self, n, seed, sample):
+        L = self.L[n]
+        eps = fill_normal(L.mu_q.size, seed, L.layer_id, sample)       # stream defined on the reference-order OHWI tensor
+        if n == "layers.5":
+            eps = eps.reshape(500, 2450)[:, self.perm5]
+        return L.sample(seed, sample, eps.reshape(L.mu_q.shape))
+
+    def forward(self, x_nchw, seed, sample, record=None):
+        a_hi = self.a_hi
+        rec = (lambda k, v: record.__setitem__(k, v)) if record is not None else (lambda k, v: None)
+        x = quantize_input_nchw(x_nchw, self.s_in, self.z_in, a_hi); s, z = self.s_in, self.z_in; rec("quant.out", x)
+        L = self.L["layers.0"]; x = L.forward(x, s, z, self.sample("layers.0", seed, sample), a_hi); s, z = L.s_y, L.z_y; rec("layers.0.out", x)
+        x = np.minimum(maxpool2_q(x), a_hi); rec("layers.1.out", x)
+        L = self.L["layers.2"]; x = L.forward(x, s, z, self.sample("layers.2", seed, sample), a_hi); s, z = L.s_y, L.z_y; rec("layers.2.out", x)
+        x = np.minimum(maxpool2_q(x), a_hi); rec("layers.3.out", x)
+        x = x.reshape(x.shape[0], -1)
+        L = self.L["layers.5"]; x = L.forward(x, s, z, self.sample("layers.5", seed, sample), a_hi); s, z = L.s_y, L.z_y; rec("layers.5.out", x)
+        L = self.L["layers.7"]; x = L.forward(x, s, z, self.sample("layers.7", seed, sample), a_hi); s, z = L.s_y, L.z_y; rec("layers.7.out", x)
+        return dequant_softmax(x, s, z)
+
+
+class Int8MLPBBBOracle(_Int8BBBBase):
+    """linear_bbb with q=True: reference models_bbb.py:32-95 (3 x LinearReLU, heads mu / log_var, DeQuant, exp)."""
+
+    def __init__(self, state, a_bits=7, w_bits=8):
+        super().__init__(state, a_bits, w_bits, ["layers.0", "layers.2", "layers.4", "mu", "log_var"], [True, True, True, False, False])
+
+    def forward(self, x, seed, sample, record=None):
+        a_hi = self.a_hi
+        rec = (lambda k, v: record.__setitem__(k, v)) if record is not None else (lambda k, v: None)
+        x = np.asarray(x, np.float32)
+        q = quantize_input_nchw(x.reshape(x.shape[0], x.shape[1], 1, 1), self.s_in, self.z_in, a_hi).reshape(x.shape)
+        s, z = self.s_in, self.z_in; rec("quant.out", q)
+        for n in ("layers.0", "layers.2", "layers.4"):
+            L = self.L[n]; q = L.forward(q, s, z, L.sample(seed, sample), a_hi); s, z = L.s_y, L.z_y; rec(n + ".out", q)
+        Lm, Lv = self.L["mu"], self.L["log_var"]
+        qm = Lm.forward(q, s, z, Lm.sample(seed, sample), a_hi); rec("mu.out", qm)
+        qv = Lv.forward(q, s, z, Lv.sample(seed, sample), a_hi); rec("log_var.out", qv)
+        mu = (qm.astype(np.float32) - np.float32(Lm.z_y)) * np.float32(Lm.s_y)
+        lv = (qv.astype(np.float32) - np.float32(Lv.z_y)) * np.float32(Lv.s_y)
+        return mu, np.exp(lv)

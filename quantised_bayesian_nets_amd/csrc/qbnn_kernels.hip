@@ -2037,3 +2037,27 @@ QBNN_EXPORT int qbnn_classification_metrics(const float* probs, const int64_t* t
   hipLaunchKernelGGL(classification_metrics_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, probs, target, B, C, partials);
   return check_launch("qbnn_classification_metrics");
 }
+
+// Flatten (reference src/utils.py:40-47) of a channels-last activation into the reference's NCHW feature order:
+// x [S][B][HW][C] -> y [S][B][C*HW], y[c * HW + p] = x[p * C + c].  Needed where a stochastic Linear follows a conv map:
+// its noise stream is indexed by the reference's (c, h, w) column order.
+__global__ __launch_bounds__(256) void flatten_nchw_kernel(const uint8_t* __restrict__ x, int64_t x_ss, int B, int HW, int C,
+                                                            uint8_t* __restrict__ y, int64_t y_ss) {
+  const int64_t total = (int64_t)B * HW * C;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int s = blockIdx.y;
+  const int64_t b = idx / ((int64_t)HW * C);
+  const int r = (int)(idx - b * HW * C);
+  const int c = r / HW, p = r - c * HW;
+  y[(int64_t)s * y_ss + idx] = x[(int64_t)s * x_ss + (b * HW + p) * C + c];
+}
+
+QBNN_EXPORT int qbnn_flatten_nchw_mc(const uint8_t* x, int64_t x_ss, int32_t B, int32_t HW, int32_t C, uint8_t* y, int64_t y_ss,
+                                     int32_t n_samples, void* stream) {
+  if (!x || !y || B <= 0 || HW <= 0 || C <= 0 || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_flatten_nchw_mc: bad argument%s");
+  const int64_t total = (int64_t)B * HW * C;
+  hipLaunchKernelGGL(flatten_nchw_kernel, dim3((unsigned)((total + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
+                     x, x_ss, B, HW, C, y, y_ss);
+  return check_launch("qbnn_flatten_nchw_mc");
+}

@@ -314,7 +314,30 @@ class Conv2d(_BBBInt8):
         w = self.sample_weights(dev)
         return self._conv(x, w, S, residual, add_qparams)
 
+    def _generic(self, x, w, S, H, W, Cin, Cout, ks, st, pd, out_shape):
+        """Any-geometry path (qbnn_conv2d_i8_generic_mc) with per-sample row-major sampled weights: the small nets
+        (LeNet, MLP) whose channel counts do not fit the MFMA tiling."""
+        pk = self._ensure_packed(x.data.device)
+        y = torch.empty((S,) + out_shape, dtype=torch.uint8, device=x.data.device)
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.pad = x.data.shape[1], H, W, Cin, Cout, ks, st, pd
+        d.s_x, d.z_x = x.scale, x.zero_point
+        d.s_w, d.z_w = self.add_weight.scale, self.add_weight.zero_point
+        d.s_y, d.z_y = self.scale, self.zero_point
+        d.relu, d.a_hi, d.has_bias = int(self.relu), self._a_hi(), int(pk["bias"] is not None)
+        with timed("conv_generic_i8 bbb %d->%d k%d" % (Cin, Cout, ks)):
+            _lib.check(_lib.lib().qbnn_conv2d_i8_generic_mc(_lib.ptr(x.data), x.sample_stride(), _lib.ptr(w), w.shape[1], _lib.ptr(pk["bias"]),
+                                                            _lib.ptr(y), y[0].numel(), S, C.byref(d), _stream()))
+        return MCQTensor(y, self.scale, self.zero_point)
+
     def _conv(self, x, w, S, residual=None, add_qparams=None, im2col=None):
+        if self.layout == LAYOUT_ROWMAJOR:
+            if residual is not None or im2col is not None:
+                raise NotImplementedError("the generic conv path has no fused residual / im2col")
+            _, B, H, W, Cin = x.data.shape
+            ks, st, pd = self.kernel_size[0], self.stride[0], self.padding[0]
+            Ho, Wo = (H + 2 * pd - ks) // st + 1, (W + 2 * pd - ks) // st + 1
+            return self._generic(x, w, S, H, W, Cin, self.out_channels, ks, st, pd, (B, Ho, Wo, self.out_channels))
         pk = self._ensure_packed(x.data.device)
         _, B, H, W, Cin = x.data.shape
         ks, st, pd = self.kernel_size[0], self.stride[0], self.padding[0]
@@ -383,6 +406,18 @@ class Linear(_BBBInt8):
 
     def _get_name(self):
         return 'QuantizedLinear'
+
+    def forward(self, x):
+        """reference linear_q.Linear.forward (linear_q.py:80-94) / LinearReLU.forward (:154-173) for S samples:
+        x MCQTensor [S or 1, B, in_features] -> [S, B, out_features]."""
+        d = x.data
+        if d.device.type != "cuda":
+            raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
+        S = _MC.samples
+        w = self.sample_weights(d.device)
+        B = d.shape[1]
+        flat = MCQTensor(d.reshape(d.shape[0], B, -1), x.scale, x.zero_point, shared=x.shared)
+        return Conv2d._generic(self, flat, w, S, 1, 1, self.in_features, self.out_features, 1, 1, 0, (B, self.out_features))
 
     @classmethod
     def from_float(cls, mod):

@@ -351,8 +351,14 @@ class ModelFactory:
         if "sgld" in model:
             return Network(input_size, output_size, q, args, training_mode)
         if model == "linear_bbb":
+            if q:
+                from .models_small import LinearNetwork as LinearNetworkBBBQ
+                return LinearNetworkBBBQ(input_size, output_size, q, args)
             from .models_f32 import LinearNetwork as LinearNetworkBBB
             return LinearNetworkBBB(input_size, output_size, q, args)
+        if model == "conv_lenet_bbb":
+            from .models_small import ConvNetwork_LeNet as ConvNetwork_LeNetBBB
+            return ConvNetwork_LeNetBBB(input_size, output_size, q, args)
         if model == "conv_lenet_mc":
             from .models_mc import ConvNetwork_LeNet as ConvNetwork_LeNetMC
             return ConvNetwork_LeNetMC(input_size, output_size, q, args)

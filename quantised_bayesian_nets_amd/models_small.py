@@ -1,0 +1,141 @@
+"""The small int8 Bayes-by-backprop graphs behind the reference's model API.
+
+Mirror of reference src/models/stochastic/bbb/models_bbb.py: `ConvNetwork_LeNet` (:98-143) and `LinearNetwork` with
+q=True (:32-95) after quant_utils.prepare_model -> convert.  Their channel counts (1/20/50, 13/100) do not fit the MFMA
+tiling of the ResNet kernels; they run on the any-geometry kernels with per-sample row-major sampled weights.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .layers import LAYOUT_ROWMAJOR, Conv2d, Linear, LinearReLU, MCQTensor, _MC, mc_context, sample_all_weights
+from .models import QuantStub
+from .models_mc import MaxPool2dQ
+from .quant import UINT_BOUNDS, check_bits
+
+
+def _quantize(x4, quant, a_hi):
+    B, Cc, H, W = x4.shape
+    out = torch.empty((1, B, H, W, Cc), dtype=torch.uint8, device=x4.device)
+    _lib.check(_lib.lib().qbnn_quantize_input_nchw(_lib.ptr(x4), B, Cc, H, W, quant.scale, quant.zero_point, a_hi, _lib.ptr(out),
+                                                   _lib.current_stream()))
+    return MCQTensor(out, quant.scale, quant.zero_point, shared=True)
+
+
+class _SmallBase(nn.Module):
+    def _finish(self, args):
+        for i, m in enumerate(self.stochastic_layers()):
+            m.layer_id = i
+            m.layout = LAYOUT_ROWMAJOR
+        self.quant = QuantStub()
+        self.a_hi = UINT_BOUNDS[args.activation_precision][1]
+
+    def load_reference_state(self, state):
+        for n, m in zip(self.stochastic_layer_names(), self.stochastic_layers()):
+            m.load_reference_state(state, n + ".")
+        self.quant.scale = float(np.asarray(state["quant.scale"]).reshape(-1)[0])
+        self.quant.zero_point = int(np.asarray(state["quant.zero_point"]).reshape(-1)[0])
+        return self
+
+
+class ConvNetwork_LeNet(_SmallBase):
+    """reference models_bbb.ConvNetwork_LeNet (:98-143), int8: conv5x5 -> maxpool -> conv5x5 -> maxpool -> flatten ->
+    LinearReLU(2450, 500) -> Linear(500, classes) -> dequant -> softmax (no ReLU after the convs)."""
+
+    def __init__(self, input_size, output_size, q, args):
+        super().__init__()
+        if not q:
+            raise NotImplementedError("float conv BBB layers are not built yet")
+        check_bits(args)
+        self.args, self.q, self.output_size = args, q, int(output_size)
+        self.init_channels = input_size[0]
+        ident = nn.Identity
+        self.layers = nn.ModuleList([Conv2d(self.init_channels, 20, (5, 5), stride=1, padding=2, bias=False, args=args), MaxPool2dQ(args),
+                                     Conv2d(20, 50, (5, 5), stride=1, padding=2, bias=False, args=args), MaxPool2dQ(args),
+                                     ident(),                                             # Flatten (NCHW order)
+                                     LinearReLU(50 * 7 * 7, 500, bias_=False, args=args), ident(),
+                                     Linear(500, output_size, bias_=False, args=args)])
+        self._finish(args)
+
+    def stochastic_layers(self):
+        return [self.layers[0], self.layers[2], self.layers[5], self.layers[7]]
+
+    def stochastic_layer_names(self):
+        return ["layers.0", "layers.2", "layers.5", "layers.7"]
+
+    def forward_mc(self, x, record=None):
+        if x.device.type != "cuda":
+            raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
+        S, dev = _MC.samples, x.device
+        rec = (lambda k, v: record.__setitem__(k, v)) if record is not None else (lambda k, v: None)
+        h = _quantize(x.to(torch.float32).contiguous(), self.quant, self.a_hi); rec("quant.out", h.data)
+        sample_all_weights(self.stochastic_layers(), dev)
+        h = self.layers[0]._conv(h, self.layers[0].sample_weights(dev), S); rec("layers.0.out", h.data)
+        h = self.layers[1](h); rec("layers.1.out", h.data)
+        h = self.layers[2]._conv(h, self.layers[2].sample_weights(dev), S); rec("layers.2.out", h.data)
+        h = self.layers[3](h); rec("layers.3.out", h.data)
+        d = h.data
+        _, B, H, W, Cc = d.shape
+        flat = torch.empty((S, B, Cc * H * W), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().qbnn_flatten_nchw_mc(_lib.ptr(d), h.sample_stride(), B, H * W, Cc, _lib.ptr(flat), flat[0].numel(), S,
+                                                   _lib.current_stream()))
+        h = MCQTensor(flat, h.scale, h.zero_point)
+        h = self.layers[5](h); rec("layers.5.out", h.data)
+        h = self.layers[7](h); rec("layers.7.out", h.data)
+        probs = torch.empty((S, B, self.output_size), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().qbnn_dequant_softmax_mc(_lib.ptr(h.data), h.sample_stride(), B, self.output_size, h.scale, h.zero_point,
+                                                      _lib.ptr(probs), S, _lib.current_stream()))
+        return probs
+
+    def forward(self, x):
+        with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
+            return self.forward_mc(x)[0]
+
+
+class LinearNetwork(_SmallBase):
+    """reference models_bbb.LinearNetwork with q=True (:32-95): QuantStub -> 3 x LinearReLU(100) -> heads mu, log_var ->
+    DeQuant -> (mu, exp(log_var))."""
+
+    def __init__(self, input_size, output_size, q, args):
+        super().__init__()
+        check_bits(args)
+        self.args, self.q = args, q
+        self.input_size = 1
+        for i in input_size:
+            self.input_size *= int(i)
+        self.output_size = int(output_size)
+        ident = nn.Identity
+        self.layers = nn.ModuleList([LinearReLU(self.input_size, 100, bias_=True, args=args), ident(),
+                                     LinearReLU(100, 100, bias_=True, args=args), ident(),
+                                     LinearReLU(100, 100, bias_=True, args=args), ident()])
+        self.mu = Linear(100, 1, bias_=True, args=args)
+        self.log_var = Linear(100, 1, bias_=True, args=args)
+        self._finish(args)
+
+    def stochastic_layers(self):
+        return [self.layers[0], self.layers[2], self.layers[4], self.mu, self.log_var]
+
+    def stochastic_layer_names(self):
+        return ["layers.0", "layers.2", "layers.4", "mu", "log_var"]
+
+    def forward_mc(self, x, record=None):
+        """-> (mu [S,B,1], var [S,B,1]) fp32."""
+        if x.device.type != "cuda":
+            raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
+        S, dev = _MC.samples, x.device
+        rec = (lambda k, v: record.__setitem__(k, v)) if record is not None else (lambda k, v: None)
+        x2 = x.to(torch.float32).reshape(x.shape[0], -1)
+        h = _quantize(x2.reshape(x2.shape[0], x2.shape[1], 1, 1).contiguous(), self.quant, self.a_hi)
+        h = MCQTensor(h.data.reshape(1, x2.shape[0], x2.shape[1]), h.scale, h.zero_point, shared=True); rec("quant.out", h.data)
+        sample_all_weights(self.stochastic_layers(), dev)
+        for i in (0, 2, 4):
+            h = self.layers[i](h); rec(f"layers.{i}.out", h.data)
+        qm, qv = self.mu(h), self.log_var(h)
+        rec("mu.out", qm.data); rec("log_var.out", qv.data)
+        return qm.dequantize(), torch.exp(qv.dequantize())
+
+    def forward(self, x):
+        with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
+            mu, var = self.forward_mc(x)
+        return mu[0], var[0]

@@ -52,3 +52,16 @@ def golden_ensemble():
     members = [{k[len(f"member{i}/"):]: d[k] for k in d.files if k.startswith(f"member{i}/")} for i in range(n)]
     rec = {k[len("rec/"):]: d[k] for k in d.files if k.startswith("rec/")}
     return dict(members=members, rec=rec, x=d["x"], probs=d["probs"], mean_probs=d["mean_probs"])
+
+
+@pytest.fixture(scope="session")
+def golden_lenet_bbb():
+    return load_golden("lenet_bbb_a7w8.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_mlp_bbb_q():
+    d = np.load(os.path.join(GOLDEN, "mlp_bbb_a7w8.npz"))
+    return dict(state={k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")},
+                rec={k[len("rec/"):]: d[k] for k in d.files if k.startswith("rec/")}, x=d["x"], mu=d["mu"], var=d["var"],
+                seed=int(d["meta.philox_seed"]))

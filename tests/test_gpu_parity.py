@@ -368,6 +368,33 @@ def test_classification_metrics_match_reference_formulas():
     assert abs(m.ece - float(ece)) < 1e-5
 
 
+def test_small_bbb_int8_graphs_match_reference(golden_lenet_bbb, golden_mlp_bbb_q):
+    """int8 BBB LeNet and MLP (linear_q.Linear / LinearReLU forward for real): every layer of sample 0
+    bit-exact, all samples' outputs to 1e-5 relative."""
+    import quantised_bayesian_nets_amd as q
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+    g = golden_lenet_bbb
+    m = q.ModelFactory.get_model("conv_lenet_bbb", [1, 1, 28, 28], 10, True, args).load_reference_state(g["state"])
+    S, seed = g["probs"].shape[0], g["meta"]["philox_seed"]
+    rec = {}
+    with q.mc_context(S, seed, 0):
+        probs = m.forward_mc(torch.from_numpy(g["x"]).cuda(), record=rec)
+    for k, v in g["rec"].items():
+        assert np.array_equal(rec[k][0].cpu().numpy().reshape(v.shape), v), k
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=RTOL, atol=1e-8)
+    mm = golden_mlp_bbb_q
+    net = q.ModelFactory.get_model("linear_bbb", [13], 1, True, args).load_reference_state(mm["state"])
+    rec = {}
+    with q.mc_context(mm["mu"].shape[0], mm["seed"], 0):
+        mu, var = net.forward_mc(torch.from_numpy(mm["x"]).cuda(), record=rec)
+    for k, v in mm["rec"].items():
+        assert np.array_equal(rec[k][0].cpu().numpy().reshape(v.shape), v), k
+    np.testing.assert_allclose(mu.cpu().numpy(), mm["mu"], rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(var.cpu().numpy(), mm["var"], rtol=RTOL, atol=1e-9)
+    mean, pv = q.mc_predict_regression(net, torch.from_numpy(mm["x"]).cuda(), mm["mu"].shape[0], mm["seed"])
+    np.testing.assert_allclose(mean.cpu().numpy(), mm["mu"].mean(0), rtol=1e-5, atol=1e-6)
+
+
 def test_errors_are_loud():
     from quantised_bayesian_nets_amd import _lib
     d = _lib.ConvDesc()

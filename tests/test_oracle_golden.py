@@ -117,3 +117,23 @@ def test_ensemble_members_match_reference(golden_ensemble):
                 assert np.array_equal(rec[k], v.reshape(rec[k].shape)), k
     np.testing.assert_allclose(np.stack(ps), g["probs"], rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(np.stack(ps).mean(0), g["mean_probs"], rtol=1e-5, atol=1e-8)
+
+
+def test_small_bbb_int8_graphs_bit_exact(golden_lenet_bbb, golden_mlp_bbb_q):
+    """conv_lenet_bbb and linear_bbb (q=True) int8 against the reference."""
+    g = golden_lenet_bbb
+    net = orc.Int8LeNetBBBOracle(g["state"], 7, 8)
+    rec = {}
+    p0 = net.forward(g["x"], g["meta"]["philox_seed"], 0, record=rec)
+    for k, v in g["rec"].items():
+        assert np.array_equal(rec[k].reshape(v.shape), v), k
+    np.testing.assert_allclose(p0, g["probs"][0], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(net.forward(g["x"], g["meta"]["philox_seed"], 2), g["probs"][2], rtol=1e-5, atol=1e-8)
+    m = golden_mlp_bbb_q
+    net = orc.Int8MLPBBBOracle(m["state"], 7, 8)
+    rec = {}
+    mu, var = net.forward(m["x"], m["seed"], 0, record=rec)
+    for k, v in m["rec"].items():
+        assert np.array_equal(rec[k].reshape(v.shape), v), k
+    np.testing.assert_allclose(mu, m["mu"][0], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(var, m["var"][0], rtol=1e-5, atol=1e-9)
