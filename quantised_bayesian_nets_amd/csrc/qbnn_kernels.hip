@@ -254,7 +254,7 @@ QBNN_EXPORT void qbnn_debug_read_inner(unsigned long long* host4) {
 #define QBNN_INNER_FLUSH() do {} while (0)
 #endif
 
-template <int CIN_, int COUT_, int KSZ_, int STRIDE_, int HIN_, int HALO_, int G_, int MB_, int NB_, bool RING_ = true>
+template <int CIN_, int COUT_, int KSZ_, int STRIDE_, int HIN_, int HALO_, int G_, int MB_, int NB_, bool RING_ = true, int SLAB_KB_ = 36>
 struct ConvCfg {
   // RING: fused kernels stage this conv's weights through the LDS slab ring (conv_lds); false = every wave streams
   // its fragments from L2 (conv_passes) -- better when the conv's weights are far larger than the ring (192 channels)
@@ -272,8 +272,9 @@ struct ConvCfg {
   static constexpr int RBP = (RB + 31) / 32 * 32;         // padded to whole 32-byte k-steps (weights are 0 there)
   static constexpr int SPR = RBP / 32;                    // k-steps per kernel row
   static constexpr int KS = KSZ * SPR;
-  // k-steps per unrolled chunk: the largest divisor of a kernel row that keeps <= 12 weight fragments in flight
-  static constexpr int pick_chunk() { int best = 1; for (int d = 1; d <= SPR; ++d) if (SPR % d == 0 && d * NB_ <= 12) best = d; return best; }
+  // k-steps per unrolled chunk: the largest divisor of a kernel row that keeps <= 12 fragments (weights + pixels) per
+  // buffer of the double-buffered K loop (2 x 48 VGPRs) -- more spills the fused kernels
+  static constexpr int pick_chunk() { int best = 1; for (int d = 1; d <= SPR; ++d) if (SPR % d == 0 && d * (NB_ + MB_) <= 12) best = d; return best; }
   static constexpr int KCHUNK = pick_chunk();
   static constexpr int NT = (COUT + 31) / 32;
   static constexpr bool USE_ONES = (COUT % 32) != 0;      // window sum from the packed layout's ones row
@@ -286,8 +287,8 @@ struct ConvCfg {
   // 32-pixel-wide maps, 3x3/s1, one n-tile: an M-tile is one output row, so the input-row fragments of a pass
   // are shared by the 3 output rows that touch them and all weights fit in registers
   static constexpr bool ROWREUSE = (HO == 32 && STRIDE == 1 && KSZ == 3 && NT == 1 && NB_ == 1 && KS <= 9 && (32 % MB_) == 0);
-  // weight slab of the LDS ring: SLK k-steps x all NT tiles, <= 36 KB, SLK | KS
-  static constexpr int pick_slab() { int best = 1; for (int d = 1; d <= KS; ++d) if (KS % d == 0 && d * NT <= 36) best = d; return best; }
+  // weight slab of the LDS ring: SLK k-steps x all NT tiles, <= SLAB_KB KiB, SLK | KS
+  static constexpr int pick_slab() { int best = 1; for (int d = 1; d <= KS; ++d) if (KS % d == 0 && d * NT <= SLAB_KB_) best = d; return best; }
   static constexpr int SLK = pick_slab();
   static constexpr int NSLAB = KS / SLK;
   static constexpr int SLAB_BYTES = NT * SLK * 1024;
@@ -524,15 +525,6 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
         }
       }
     };
-    // bias of this pass's channels -> registers, ahead of the K loop (LDS latency off the epilogue's critical path)
-    float4 b4[C::NB][4];
-#pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
-        b4[nb][g4] = *reinterpret_cast<const float4*>(bias_lds + (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
-      }
     Frags f0, f1;
     load_chunk(f0, 0);
     if (NCHUNK <= 4) {
@@ -556,6 +548,16 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
         if (++kc >= NCHUNK) break;
       }
     }
+    // bias of this pass's channels -> registers only now: held across the K loop they push the fused kernels into
+    // scratch, and a spill reload behind the input prefetch costs a full vmcnt(0) drain
+    float4 b4[C::NB][4];
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+        b4[nb][g4] = *reinterpret_cast<const float4*>(bias_lds + (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
+      }
 #pragma unroll
     for (int mb = 0; mb < C::MB; ++mb) {
       int R;
@@ -882,8 +884,13 @@ __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const
                 rsum[mb] = rs_;
               }
 #pragma unroll
-              for (int nb = 0; nb < C::NB; ++nb)
+              for (int nb = 0; nb < C::NB; ++nb) {
+#ifdef QBNN_ABL_NOMFMA
+                acc[mb][nb][0] ^= f.w[u][nb].x ^ f.x[u][mb].y;
+#else
                 acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[u][nb], f.x[u][mb], acc[mb][nb], 0, 0, 0);
+#endif
+              }
             }
           }
         };
@@ -912,6 +919,17 @@ __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const
       }
       const int zwr = p.z_w * R;
       const int po = epi.pixel((mblk * C::MB + mb) * 32 + r);
+#ifdef QBNN_ABL_NOEPI
+      {
+        int keep = zwr;
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) keep ^= acc[mb][nb][i];
+        if (keep == 0x12345678) epi.store(po, 4 * h, 0.f, 0.f, 0.f, 0.f, 0u);
+        continue;
+      }
+#endif
 #pragma unroll
       for (int nb = 0; nb < C::NB; ++nb) {
         uint32_t pre[4];
@@ -1176,8 +1194,17 @@ struct ChainArgs {
   BlockParams blk[NBLK];
 };
 
+// workgroup size per geometry: 256 threads (4 waves) where two workgroups fit a CU -- they run out of phase, so one's
+// MFMA phase overlaps the other's epilogue; 512 elsewhere
+template <class C, int NBLK> struct ChainThreads {
+  static constexpr int one = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * (C::RING ? C::SLAB_BYTES : 16) + NBLK * (2 * C::COUT * 4 + 16384);
+  static constexpr int base = one - NBLK * 16384;     // without the optional add tables
+  static constexpr int v = (2 * base <= 160 * 1024 && C::NPASS <= 4) ? 256 : ((2 * one <= 160 * 1024 && C::ROWREUSE) ? 256 : 512);
+  static constexpr int per_cu = v == 256 ? ((3 * base <= 160 * 1024) ? 3 : 2) : 1;
+};
+
 template <class C, int NBLK, int NTHR>
-__global__ __launch_bounds__(NTHR, 2) void block_chain_i8_kernel(const ChainArgs<NBLK> a) {
+__global__ __launch_bounds__(NTHR, (NTHR == 256 ? ChainThreads<C, NBLK>::per_cu : 2)) void block_chain_i8_kernel(const ChainArgs<NBLK> a) {
   constexpr int NWV = NTHR / 64;
   static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1316,13 +1343,6 @@ __global__ __launch_bounds__(NTHR, 2) void block_chain_i8_kernel(const ChainArgs
 #endif
 }
 
-// workgroup size per geometry: 256 threads (4 waves) where two workgroups fit a CU -- they run out of phase, so one's
-// MFMA phase overlaps the other's epilogue; 512 elsewhere
-template <class C, int NBLK> struct ChainThreads {
-  static constexpr int one = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * (C::RING ? C::SLAB_BYTES : 16) + NBLK * (2 * C::COUT * 4 + 16384);
-  static constexpr int v = (2 * one <= 160 * 1024 && C::ROWREUSE) ? 256 : 512;
-};
-
 template <class C, int NBLK>
 static int launch_block_chain(const ChainArgs<NBLK>& a, hipStream_t st) {
   constexpr int NTHR = ChainThreads<C, NBLK>::v;
@@ -1337,7 +1357,7 @@ static int launch_block_chain(const ChainArgs<NBLK>& a, hipStream_t st) {
   if (!attr) { hipFuncSetAttribute((const void*)block_chain_i8_kernel<C, NBLK, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_FITS ? LDS_BASE + NBLK * 16384 : LDS_BASE); attr = true; }
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
-  const int per_cu = ((160 * 1024) / LDS >= 2 && NTHR == 256) ? 2 : 1;
+  const int per_cu = NTHR == 256 ? ((160 * 1024) / LDS >= 3 ? 3 : ((160 * 1024) / LDS >= 2 ? 2 : 1)) : 1;
   int grid = 256 * per_cu;
   if (grid > n_items) grid = n_items;
   hipLaunchKernelGGL((block_chain_i8_kernel<C, NBLK, NTHR>), dim3(grid), dim3(NTHR), LDS, st, a2);
