@@ -1562,6 +1562,13 @@ static int launch_block_down(const DownArgs& a, hipStream_t st) {
   return check_launch("qbnn_block_down_i8_mc");
 }
 
+template <class CA, class CS, class CB> static int launch_block_down_ws(const DownArgs& a, hipStream_t st);
+// diagnostic switch (A/B timing): QBNN_FUSED_RING=1 routes every fused block through the ring kernels
+static bool ring_only() {
+  static const bool v = [] { const char* e = getenv("QBNN_FUSED_RING"); return e && e[0] == '1'; }();
+  return v;
+}
+
 //                           CIN COUT K  S  HIN HALO G  MB NB
 using D24_a = ConvCfg<24, 48, 3, 2, 32, 1, 1, 1, 2>;
 using D24_s = ConvCfg<24, 48, 1, 2, 32, 1, 1, 1, 2>;
@@ -1595,10 +1602,493 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
   c.s_r = d->s_s; c.z_r = d->z_s; c.s_o = d->blk.s_o; c.z_o = d->blk.z_o;
   if ((rc = fill_qadd(a.add, &c))) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (Cin == 24 && H == 32) return launch_block_down<D24_a, D24_s, D24_b>(a, st);
+  if (Cin == 24 && H == 32) return ring_only() ? launch_block_down<D24_a, D24_s, D24_b>(a, st) : launch_block_down_ws<D24_a, D24_s, D24_b>(a, st);
   if (Cin == 48 && H == 16) return launch_block_down<D48_a, D48_s, D48_b>(a, st);
   if (Cin == 96 && H == 8) return launch_block_down<D96_a, D96_s, D96_b>(a, st);
   return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
+}
+
+// =====================================================================================
+// Weights-stationary fused kernels (layers whose block weights fit in LDS next to the tiles: 24 and 48 channels).
+// Every workgroup walks a CONTIGUOUS range of work items, so consecutive items belong to the same MC sample and the
+// block's sampled weights are copied into LDS (global_load_lds) once per sample change instead of once per conv.
+// Nothing in the steady state waits on global memory at a barrier: barriers are LDS-only (lds_barrier), the next
+// item's input sits in registers from the moment the current one is written to the tile (a whole item of cover), and
+// the output stores are fire-and-forget.
+// =====================================================================================
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <class C> struct WConv { static constexpr int BYTES = C::NT * C::KS * 1024; };
+
+// whole packed conv (NT x KS fragment tiles of 1 KiB) -> LDS, verbatim
+template <class C, int NWAVES>
+__device__ __forceinline__ void dma_conv(uint8_t* dst, const int8_t* wq, int wave, int lane) {
+  for (int f = wave; f < C::NT * C::KS; f += NWAVES)
+    __builtin_amdgcn_global_load_lds(wq + ((int64_t)f * 64 + lane) * 16, (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+}
+
+// conv over an LDS-resident tile with LDS-resident weights; no barrier inside.  Same arithmetic and epilogue
+// interface as conv_passes / conv_lds.
+template <class C, class Epi, int NWAVES>
+__device__ __forceinline__ void conv_core(const uint8_t* tile, const uint8_t* wconv, const float* bias_lds, const QConv& p,
+                                          Epi& epi, int wave, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  if constexpr (C::ROWREUSE) {
+    static_assert(C::USE_ONES && C::NT == 1, "row-reuse path");
+    float4 b4[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      if (8 * g4 < C::COUT) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * h);
+    constexpr int NR = C::MB + C::KSZ - 1;
+    v4i w[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wconv + lane * 16 + ks * 1024);
+    for (int pass = wave; pass < C::NPASS; pass += NWAVES) {
+      const int m0 = pass * C::MB * 32;
+      const int g = m0 / (C::HO * C::HO), oh0 = (m0 % (C::HO * C::HO)) / C::HO;
+      const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::CIN + 16 * h;
+      v4i x[NR][C::SPR];
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int t = 0; t < C::SPR; ++t) {
+          const v2i lo = *reinterpret_cast<const v2i*>(base + j * C::PITCH + t * 32);
+          const v2i hi = *reinterpret_cast<const v2i*>(base + j * C::PITCH + t * 32 + 8);
+          x[j][t] = v4i{lo.x, lo.y, hi.x, hi.y};
+        }
+      v16i acc[C::MB];
+      const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int mb = 0; mb <= C::MB; ++mb) {
+        if (mb < C::MB) {
+#pragma unroll
+          for (int kh = 0; kh < C::KSZ; ++kh)
+#pragma unroll
+            for (int t = 0; t < C::SPR; ++t)
+              acc[mb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * C::SPR + t], x[mb + kh][t], (kh == 0 && t == 0) ? zero16 : acc[mb], 0, 0, 0);
+        }
+        if (mb > 0) {
+          const int e = mb - 1;
+          const int rv = acc[e][C::ONES_REG];
+          const int ro = __shfl_xor(rv, 32);
+          const int zwr = p.z_w * (h ? ro : rv);
+          const int po = epi.pixel(m0 + e * 32 + r);
+          uint32_t pre[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+            if (8 * g4 < C::COUT) pre[g4] = epi.load(po, 8 * g4 + 4 * h);
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            if (8 * g4 >= C::COUT) continue;
+            const float4 bb = b4[g4];
+            const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(acc[e][4 * g4 + 0] - zwr)) * p.mult;
+            const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(acc[e][4 * g4 + 1] - zwr)) * p.mult;
+            const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(acc[e][4 * g4 + 2] - zwr)) * p.mult;
+            const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(acc[e][4 * g4 + 3] - zwr)) * p.mult;
+            epi.store(po, 8 * g4 + 4 * h, v0, v1, v2, v3, pre[g4]);
+          }
+        }
+        if (mb > 0 && mb < C::MB) {
+          // in-order issue: the epilogue of row mb-1 only hides under the MFMAs of row mb if it sits between them
+#pragma unroll
+          for (int i = 0; i < C::KS; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, Epi::VALU_PER_MFMA, 0);
+          }
+        }
+      }
+    }
+  } else {
+    constexpr int U = C::KCHUNK, NCHUNK = C::KS / U;
+    struct Frags { v4i w[U][C::NB]; v4i x[U][C::MB]; };
+    for (int pass = wave; pass < C::NPASS; pass += NWAVES) {
+      const int mblk = pass / C::NBLKS, nblk = pass - mblk * C::NBLKS;
+      const uint8_t* ap[C::MB];
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) {
+        const int m = (mblk * C::MB + mb) * 32 + r;
+        const int g = m / (C::HO * C::HO), rem = m % (C::HO * C::HO);
+        const int oh = rem / C::HO, ow = rem % C::HO;
+        ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::CIN + 16 * h;
+      }
+      const uint8_t* wl = wconv + ((nblk * C::NB) * C::KS * 64 + lane) * 16;
+      v16i acc[C::MB][C::NB];
+      int rsum[C::MB];
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) {
+        rsum[mb] = 0;
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0;
+      }
+      auto load_chunk = [&](Frags& f, int c) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ks = c * U + u;
+#pragma unroll
+          for (int nb = 0; nb < C::NB; ++nb) f.w[u][nb] = *reinterpret_cast<const v4i*>(wl + (nb * C::KS + ks) * 1024);
+#pragma unroll
+          for (int mb = 0; mb < C::MB; ++mb) {
+            const v2i lo = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks));
+            const v2i hi = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks) + 8);
+            f.x[u][mb] = v4i{lo.x, lo.y, hi.x, hi.y};
+          }
+        }
+      };
+      auto mfma_chunk = [&](const Frags& f, int c) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ks = c * U + u;
+#pragma unroll
+          for (int mb = 0; mb < C::MB; ++mb) {
+            if (!C::USE_ONES) {
+              const int m0 = (h ? C::piece_valid(ks, 1, 0) : C::piece_valid(ks, 0, 0)) ? 0x01010101 : 0;
+              const int m1 = (h ? C::piece_valid(ks, 1, 1) : C::piece_valid(ks, 0, 1)) ? 0x01010101 : 0;
+              int rs_ = rsum[mb];
+              rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].x, m0, rs_, false);
+              rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].y, m0, rs_, false);
+              rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].z, m1, rs_, false);
+              rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].w, m1, rs_, false);
+              rsum[mb] = rs_;
+            }
+#pragma unroll
+            for (int nb = 0; nb < C::NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[u][nb], f.x[u][mb], acc[mb][nb], 0, 0, 0);
+          }
+        }
+      };
+      Frags f0, f1;
+      load_chunk(f0, 0);
+#pragma unroll
+      for (int c = 0; c < NCHUNK; ++c) {
+        Frags& cur = (c & 1) ? f1 : f0;
+        Frags& nxt = (c & 1) ? f0 : f1;
+        if (c + 1 < NCHUNK) load_chunk(nxt, c + 1);
+        mfma_chunk(cur, c);
+      }
+      float4 b4[C::NB][4];
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+          b4[nb][g4] = *reinterpret_cast<const float4*>(bias_lds + (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
+        }
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) {
+        int R;
+        if (C::USE_ONES) {
+          const int rv = acc[mb][C::ONES_TILE % C::NB][C::ONES_REG];
+          const int ro = __shfl_xor(rv, 32);
+          R = h ? ro : rv;
+        } else {
+          R = rsum[mb] + __shfl_xor(rsum[mb], 32);
+        }
+        const int zwr = p.z_w * R;
+        const int po = epi.pixel((mblk * C::MB + mb) * 32 + r);
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb) {
+          uint32_t pre[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+            pre[g4] = epi.load(po, (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
+          }
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+            const int c0 = (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h;
+            const float4 bb = b4[nb][g4];
+            const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(acc[mb][nb][4 * g4 + 0] - zwr)) * p.mult;
+            const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(acc[mb][nb][4 * g4 + 1] - zwr)) * p.mult;
+            const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(acc[mb][nb][4 * g4 + 2] - zwr)) * p.mult;
+            const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(acc[mb][nb][4 * g4 + 3] - zwr)) * p.mult;
+            epi.store(po, c0, v0, v1, v2, v3, pre[g4]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// contiguous item range of workgroup b out of nb
+__device__ __forceinline__ void item_range(int n_items, int b, int nb, int& begin, int& count) {
+  const int q = n_items / nb, rm = n_items - q * nb;
+  begin = b * q + (b < rm ? b : rm);
+  count = q + (b < rm ? 1 : 0);
+}
+
+template <class C, int NBLK>
+__global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const ChainArgs<NBLK> a) {
+  static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int NTHR = BLK_THREADS, NWV = BLK_WAVES;
+  constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
+  constexpr int WB = WConv<C>::BYTES;
+  uint8_t* xt = smem;
+  uint8_t* tt = smem + TILES;
+  uint8_t* wl = smem + 2 * TILES;                                            // [NBLK][2] whole convs
+  float* bias_lds = reinterpret_cast<float*>(wl + 2 * NBLK * WB);            // [NBLK][2][COUT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
+  constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
+  const int groups = (a.B + C::G - 1) / C::G;
+  int begin, count;
+  item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+
+  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, NTHR>(xt, tid);
+  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, NTHR>(tt, tid);
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) {
+    load_bias<C::COUT, NTHR>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
+    load_bias<C::COUT, NTHR>(bias_lds + (2 * k + 1) * C::COUT, a.blk[k].b.bias, tid);
+  }
+
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = tid + j * NTHR;
+      const int g = i / CPI, rem = i - g * CPI;
+      const bool ok = (i < NCH) && (img0 + g < a.B);
+      const int64_t off = ok ? ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16 : 0;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + off);
+    }
+  };
+  // registers -> centred X tile interior.  Runs right after the same thread has read these very chunks out (end of
+  // the previous item), so no barrier separates the two.
+  auto write_tile = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = tid + j * NTHR;
+      if (i < NCH) {
+        const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+        const bool ok = img0 + g < a.B;
+        const v4i v = pre[j];
+        uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+        *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
+        *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
+      }
+    }
+  };
+  if (count <= 0) return;
+  fetch(begin);
+  write_tile(begin);
+  int cur_s = -1;
+  for (int it = 0; it < count; ++it) {
+    const int item = begin + it;
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const bool more = it + 1 < count;
+    // the next item's input: in flight for the whole of this item (unconditional, so the wait counts at its use are
+    // exact: the last iteration re-reads its own item and drops it)
+    fetch(more ? item + 1 : item);
+    if (s != cur_s) {            // workgroup-uniform; at most a few times per launch
+      __syncthreads();           // every wave is done with the previous sample's weights (and the prologue's LDS writes)
+#pragma unroll
+      for (int k = 0; k < NBLK; ++k) {
+        dma_conv<C, NWV>(wl + (2 * k) * WB, a.blk[k].a.w + (int64_t)s * a.blk[k].a.w_ss, wave, lane);
+        dma_conv<C, NWV>(wl + (2 * k + 1) * WB, a.blk[k].b.w + (int64_t)s * a.blk[k].b.w_ss, wave, lane);
+      }
+      __syncthreads();           // vmcnt(0) + barrier: the weights have landed
+      cur_s = s;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+      const BlockParams& bp = a.blk[k];
+      {
+        EpiTile<C::HO, C::COUT, C::TILE_BYTES> epi{tt, bp.a};
+        conv_core<C, decltype(epi), NWV>(xt, wl + (2 * k) * WB, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
+      }
+      lds_barrier();
+      {
+        EpiTileResInPlace<C::HO, C::COUT, C::TILE_BYTES> epi{xt, bp.b, bp.add};
+        conv_core<C, decltype(epi), NWV>(tt, wl + (2 * k + 1) * WB, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
+      }
+      lds_barrier();
+    }
+    // ---- X tile interior (centred by the last add's zero point) -> quint8 registers; next item's input -> X tile;
+    //      registers -> HBM.  The stores are issued last so that nothing ever waits on them: the only vmcnt waits
+    //      of the loop are for the input loads issued a whole item earlier.
+    {
+      const uint32_t z4 = (uint32_t)a.blk[NBLK - 1].add.z_o * 0x01010101u;
+      uint8_t* ys = a.y + (int64_t)s * a.y_ss;
+      v4i outv[PER_T];
+#pragma unroll
+      for (int j = 0; j < PER_T; ++j) {
+        const int i = tid + j * NTHR;
+        if (i < NCH) {
+          const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+          const v2i lo = *reinterpret_cast<const v2i*>(d), hi = *reinterpret_cast<const v2i*>(d + 8);
+          outv[j] = v4i{(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
+        }
+      }
+      if (more) write_tile(item + 1);
+#pragma unroll
+      for (int j = 0; j < PER_T; ++j) {
+        const int i = tid + j * NTHR;
+        if (i < NCH) {
+          const int g = i / CPI, rem = i - g * CPI;
+          if (img0 + g < a.B)
+            *reinterpret_cast<v4i*>(ys + ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16) = outv[j];
+        }
+      }
+    }
+  }
+}
+
+template <class C, int NBLK> constexpr int chain_ws_lds() {
+  return 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * NBLK * WConv<C>::BYTES + NBLK * 2 * C::COUT * 4;
+}
+
+template <class C, int NBLK>
+static int launch_block_chain_ws(const ChainArgs<NBLK>& a, hipStream_t st) {
+  constexpr int LDS = chain_ws_lds<C, NBLK>();
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)block_chain_ws_kernel<C, NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  const int groups = (a.B + C::G - 1) / C::G;
+  const int n_items = a.n_samples * groups;
+  const int grid = n_items < 256 ? n_items : 256;
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
+  return check_launch("qbnn_block_chain_i8_mc");
+}
+
+// weights-stationary when the chain's weights fit next to the tiles, else the slab ring
+template <class C, int NBLK>
+static int launch_chain_auto(const ChainArgs<NBLK>& a, hipStream_t st) {
+  if constexpr (chain_ws_lds<C, NBLK>() <= 160 * 1024) {
+    if (!ring_only()) return launch_block_chain_ws<C, NBLK>(a, st);
+  }
+  return launch_block_chain<C, NBLK>(a, st);
+}
+
+template <class CA, class CS, class CB>
+__global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownArgs a) {
+  static_assert(CA::M == CS::M && CA::M == CB::M && CA::G == CS::G && CA::G == CB::G, "one work item, three convs");
+  static_assert(CA::COUT == CB::CIN && CA::COUT == CB::COUT && CS::COUT == CB::COUT && CA::HO == CB::HIN, "block geometry");
+  static_assert(CA::TILE_BYTES == CS::TILE_BYTES && CA::CIN == CS::CIN && CA::HIN == CS::HIN, "shared input tile");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int XB = CA::G * CA::TILE_BYTES + CA::TILE_SLACK;
+  constexpr int TB = CB::G * CB::TILE_BYTES + CB::TILE_SLACK;
+  constexpr int COUT = CB::COUT;
+  uint8_t* xt = smem;
+  uint8_t* tt = smem + XB;
+  uint8_t* sc = tt + TB;
+  uint8_t* wl_s = sc + CB::OUT_BYTES;
+  uint8_t* wl_a = wl_s + WConv<CS>::BYTES;
+  uint8_t* wl_b = wl_a + WConv<CA>::BYTES;
+  float* bias_lds = reinterpret_cast<float*>(wl_b + WConv<CB>::BYTES);       // [3][COUT]: s, a, b
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  constexpr int CPR = CA::ROWB / 16, CPI = CA::HIN * CPR, NCH = CA::G * CPI;
+  constexpr int PER_T = (NCH + BLK_THREADS - 1) / BLK_THREADS;
+  const int groups = (a.B + CA::G - 1) / CA::G;
+  int begin, count;
+  item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+
+  zero_halo<CA::TW, CA::CIN, CA::TILE_BYTES, CA::G, BLK_THREADS>(xt, tid);
+  zero_halo<CB::TW, CB::CIN, CB::TILE_BYTES, CB::G, BLK_THREADS>(tt, tid);
+  load_bias<COUT, BLK_THREADS>(bias_lds, a.s.bias, tid);
+  load_bias<COUT, BLK_THREADS>(bias_lds + COUT, a.a.bias, tid);
+  load_bias<COUT, BLK_THREADS>(bias_lds + 2 * COUT, a.b.bias, tid);
+
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * CA::G;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = tid + j * BLK_THREADS;
+      const int g = i / CPI, rem = i - g * CPI;
+      const bool ok = (i < NCH) && (img0 + g < a.B);
+      const int64_t off = ok ? ((int64_t)(img0 + g) * CA::HIN) * CA::ROWB + (int64_t)rem * 16 : 0;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + off);
+    }
+  };
+  // the X tile is free from the barrier that follows conv_a on
+  auto write_tile = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * CA::G;
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = tid + j * BLK_THREADS;
+      if (i < NCH) {
+        const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+        const bool ok = img0 + g < a.B;
+        const v4i v = pre[j];
+        uint8_t* d = xt + g * CA::TILE_BYTES + (row + 1) * CA::PITCH + CA::CIN + within * 16;
+        *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
+        *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
+      }
+    }
+  };
+  if (count <= 0) return;
+  fetch(begin);
+  write_tile(begin);
+  int cur_s = -1;
+  for (int it = 0; it < count; ++it) {
+    const int item = begin + it;
+    const int s = item / groups, img0 = (item - s * groups) * CA::G;
+    const bool more = it + 1 < count;
+    fetch(more ? item + 1 : item);       // unconditional: exact wait counts at its use (see block_chain_ws_kernel)
+    if (s != cur_s) {
+      __syncthreads();
+      dma_conv<CS, BLK_WAVES>(wl_s, a.s.w + (int64_t)s * a.s.w_ss, wave, lane);
+      dma_conv<CA, BLK_WAVES>(wl_a, a.a.w + (int64_t)s * a.a.w_ss, wave, lane);
+      dma_conv<CB, BLK_WAVES>(wl_b, a.b.w + (int64_t)s * a.b.w_ss, wave, lane);
+      __syncthreads();
+      cur_s = s;
+    }
+    lds_barrier();       // X complete; the previous item's SC has been read out by every thread
+    {
+      EpiDense<COUT, false> epi{sc, a.s, a.add};
+      conv_core<CS, decltype(epi), BLK_WAVES>(xt, wl_s, bias_lds, a.s, epi, wave, lane);
+    }
+    {
+      EpiTile<CB::HIN, CB::CIN, CB::TILE_BYTES> epi{tt, a.a};
+      conv_core<CA, decltype(epi), BLK_WAVES>(xt, wl_a, bias_lds + COUT, a.a, epi, wave, lane);
+    }
+    lds_barrier();       // T and SC complete
+    {
+      EpiDense<COUT, true> epi{sc, a.b, a.add};
+      conv_core<CB, decltype(epi), BLK_WAVES>(tt, wl_b, bias_lds + 2 * COUT, a.b, epi, wave, lane);
+    }
+    lds_barrier();
+    if (more) write_tile(item + 1);      // before the stores: its vmcnt wait then covers only the (old) input loads
+    {
+      constexpr int IMG_OUT = CB::HO * CB::HO * COUT;
+      uint8_t* ys = a.y + (int64_t)s * a.y_ss;
+      for (int i = tid; i < CB::M * COUT / 16; i += BLK_THREADS)
+        if (img0 + (i * 16) / IMG_OUT < a.B)
+          *reinterpret_cast<v4i*>(ys + (int64_t)img0 * IMG_OUT + (int64_t)i * 16) = reinterpret_cast<const v4i*>(sc)[i];
+    }
+  }
+}
+
+template <class CA, class CS, class CB>
+static int launch_block_down_ws(const DownArgs& a, hipStream_t st) {
+  constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + CB::OUT_BYTES +
+                      WConv<CS>::BYTES + WConv<CA>::BYTES + WConv<CB>::BYTES + 3 * CB::COUT * 4;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)block_down_ws_kernel<CA, CS, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  const int groups = (a.B + CA::G - 1) / CA::G;
+  const int n_items = a.n_samples * groups;
+  const int grid = n_items < 256 ? n_items : 256;
+  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
+  return check_launch("qbnn_block_down_i8_mc");
 }
 
 //                          CIN COUT K  S  HIN HALO G  MB NB
@@ -1633,8 +2123,8 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
     a.blk[k].add.lut = b.add_lut; a.blk[k].add.z_y = b.z_b;
     s_in = b.s_o; z_in = b.z_o;
   }
-  if (Cc == 24 && H == 32) return launch_block_chain<Blk_24, NBLK>(a, st);
-  if (Cc == 48 && H == 16) return launch_block_chain<Blk_48, NBLK>(a, st);
+  if (Cc == 24 && H == 32) return launch_chain_auto<Blk_24, NBLK>(a, st);
+  if (Cc == 48 && H == 16) return launch_chain_auto<Blk_48, NBLK>(a, st);
   if (Cc == 96 && H == 8) return launch_block_chain<Blk_96, NBLK>(a, st);
   if (Cc == 192 && H == 4) return launch_block_chain<Blk_192, NBLK>(a, st);
   return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
