@@ -1562,7 +1562,11 @@ static int launch_block_down(const DownArgs& a, hipStream_t st) {
   return check_launch("qbnn_block_down_i8_mc");
 }
 
-template <class CA, class CS, class CB> static int launch_block_down_ws(const DownArgs& a, hipStream_t st);
+template <class CA, class CS, class CB, bool LDSW> static int launch_block_down_ws(const DownArgs& a, hipStream_t st);
+static bool no_pingpong() {
+  static const bool v = [] { const char* e = getenv("QBNN_NO_PINGPONG"); return e && e[0] == '1'; }();
+  return v;
+}
 // diagnostic switch (A/B timing): QBNN_FUSED_RING=1 routes every fused block through the ring kernels
 static bool ring_only() {
   static const bool v = [] { const char* e = getenv("QBNN_FUSED_RING"); return e && e[0] == '1'; }();
@@ -1602,9 +1606,9 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
   c.s_r = d->s_s; c.z_r = d->z_s; c.s_o = d->blk.s_o; c.z_o = d->blk.z_o;
   if ((rc = fill_qadd(a.add, &c))) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (Cin == 24 && H == 32) return ring_only() ? launch_block_down<D24_a, D24_s, D24_b>(a, st) : launch_block_down_ws<D24_a, D24_s, D24_b>(a, st);
-  if (Cin == 48 && H == 16) return launch_block_down<D48_a, D48_s, D48_b>(a, st);
-  if (Cin == 96 && H == 8) return launch_block_down<D96_a, D96_s, D96_b>(a, st);
+  if (Cin == 24 && H == 32) return ring_only() ? launch_block_down<D24_a, D24_s, D24_b>(a, st) : launch_block_down_ws<D24_a, D24_s, D24_b, true>(a, st);
+  if (Cin == 48 && H == 16) return ring_only() ? launch_block_down<D48_a, D48_s, D48_b>(a, st) : launch_block_down_ws<D48_a, D48_s, D48_b, false>(a, st);
+  if (Cin == 96 && H == 8) return ring_only() ? launch_block_down<D96_a, D96_s, D96_b>(a, st) : launch_block_down_ws<D96_a, D96_s, D96_b, false>(a, st);
   return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
 }
 
@@ -1629,6 +1633,127 @@ template <class C, int NWAVES>
 __device__ __forceinline__ void dma_conv(uint8_t* dst, const int8_t* wq, int wave, int lane) {
   for (int f = wave; f < C::NT * C::KS; f += NWAVES)
     __builtin_amdgcn_global_load_lds(wq + ((int64_t)f * 64 + lane) * 16, (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+}
+
+// The two halves of one MFMA pass (MB x NB output tiles of 32 pixels x 32 channels), separable so that a wave can
+// park its accumulators across a barrier (ping-pong kernels) -- conv_core runs them back to back.
+template <class C> struct ConvAcc { v16i acc[C::MB][C::NB]; int rsum[C::MB]; };
+
+template <class C>
+__device__ __forceinline__ void conv_mfma_phase(const uint8_t* tile, const uint8_t* wconv, ConvAcc<C>& A, int pass, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int U = C::KCHUNK, NCHUNK = C::KS / U;
+  struct Frags { v4i w[U][C::NB]; v4i x[U][C::MB]; };
+  const int mblk = pass / C::NBLKS, nblk = pass - mblk * C::NBLKS;
+  const uint8_t* ap[C::MB];
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb) {
+    const int m = (mblk * C::MB + mb) * 32 + r;
+    const int g = m / (C::HO * C::HO), rem = m % (C::HO * C::HO);
+    const int oh = rem / C::HO, ow = rem % C::HO;
+    ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::CIN + 16 * h;
+  }
+  const uint8_t* wl = wconv + ((nblk * C::NB) * C::KS * 64 + lane) * 16;
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb) {
+    A.rsum[mb] = 0;
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) A.acc[mb][nb][i] = 0;
+  }
+  auto load_chunk = [&](Frags& f, int c) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ks = c * U + u;
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb) f.w[u][nb] = *reinterpret_cast<const v4i*>(wl + (nb * C::KS + ks) * 1024);
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) {
+        const v2i lo = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks));
+        const v2i hi = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks) + 8);
+        f.x[u][mb] = v4i{lo.x, lo.y, hi.x, hi.y};
+      }
+    }
+  };
+  auto mfma_chunk = [&](const Frags& f, int c) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ks = c * U + u;
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) {
+        if (!C::USE_ONES) {
+          const int m0 = (h ? C::piece_valid(ks, 1, 0) : C::piece_valid(ks, 0, 0)) ? 0x01010101 : 0;
+          const int m1 = (h ? C::piece_valid(ks, 1, 1) : C::piece_valid(ks, 0, 1)) ? 0x01010101 : 0;
+          int rs_ = A.rsum[mb];
+          rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].x, m0, rs_, false);
+          rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].y, m0, rs_, false);
+          rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].z, m1, rs_, false);
+          rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].w, m1, rs_, false);
+          A.rsum[mb] = rs_;
+        }
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+          A.acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[u][nb], f.x[u][mb], A.acc[mb][nb], 0, 0, 0);
+      }
+    }
+  };
+  Frags f0, f1;
+  load_chunk(f0, 0);
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c) {
+    Frags& cur = (c & 1) ? f1 : f0;
+    Frags& nxt = (c & 1) ? f0 : f1;
+    if (c + 1 < NCHUNK) load_chunk(nxt, c + 1);
+    mfma_chunk(cur, c);
+  }
+}
+
+template <class C, class Epi>
+__device__ __forceinline__ void conv_epi_phase(const float* bias_lds, const QConv& p, Epi& epi, ConvAcc<C>& A, int pass, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int mblk = pass / C::NBLKS, nblk = pass - mblk * C::NBLKS;
+  float4 b4[C::NB][4];
+#pragma unroll
+  for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+      b4[nb][g4] = *reinterpret_cast<const float4*>(bias_lds + (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
+    }
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb) {
+    int R;
+    if (C::USE_ONES) {
+      const int rv = A.acc[mb][C::ONES_TILE % C::NB][C::ONES_REG];
+      const int ro = __shfl_xor(rv, 32);
+      R = h ? ro : rv;
+    } else {
+      R = A.rsum[mb] + __shfl_xor(A.rsum[mb], 32);
+    }
+    const int zwr = p.z_w * R;
+    const int po = epi.pixel((mblk * C::MB + mb) * 32 + r);
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb) {
+      uint32_t pre[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+        pre[g4] = epi.load(po, (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+        const int c0 = (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h;
+        const float4 bb = b4[nb][g4];
+        const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(A.acc[mb][nb][4 * g4 + 0] - zwr)) * p.mult;
+        const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(A.acc[mb][nb][4 * g4 + 1] - zwr)) * p.mult;
+        const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(A.acc[mb][nb][4 * g4 + 2] - zwr)) * p.mult;
+        const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(A.acc[mb][nb][4 * g4 + 3] - zwr)) * p.mult;
+        epi.store(po, c0, v0, v1, v2, v3, pre[g4]);
+      }
+    }
+  }
 }
 
 // conv over an LDS-resident tile with LDS-resident weights; no barrier inside.  Same arithmetic and epilogue
@@ -1703,115 +1828,10 @@ __device__ __forceinline__ void conv_core(const uint8_t* tile, const uint8_t* wc
       }
     }
   } else {
-    constexpr int U = C::KCHUNK, NCHUNK = C::KS / U;
-    struct Frags { v4i w[U][C::NB]; v4i x[U][C::MB]; };
     for (int pass = wave; pass < C::NPASS; pass += NWAVES) {
-      const int mblk = pass / C::NBLKS, nblk = pass - mblk * C::NBLKS;
-      const uint8_t* ap[C::MB];
-#pragma unroll
-      for (int mb = 0; mb < C::MB; ++mb) {
-        const int m = (mblk * C::MB + mb) * 32 + r;
-        const int g = m / (C::HO * C::HO), rem = m % (C::HO * C::HO);
-        const int oh = rem / C::HO, ow = rem % C::HO;
-        ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::CIN + 16 * h;
-      }
-      const uint8_t* wl = wconv + ((nblk * C::NB) * C::KS * 64 + lane) * 16;
-      v16i acc[C::MB][C::NB];
-      int rsum[C::MB];
-#pragma unroll
-      for (int mb = 0; mb < C::MB; ++mb) {
-        rsum[mb] = 0;
-#pragma unroll
-        for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0;
-      }
-      auto load_chunk = [&](Frags& f, int c) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int ks = c * U + u;
-#pragma unroll
-          for (int nb = 0; nb < C::NB; ++nb) f.w[u][nb] = *reinterpret_cast<const v4i*>(wl + (nb * C::KS + ks) * 1024);
-#pragma unroll
-          for (int mb = 0; mb < C::MB; ++mb) {
-            const v2i lo = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks));
-            const v2i hi = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks) + 8);
-            f.x[u][mb] = v4i{lo.x, lo.y, hi.x, hi.y};
-          }
-        }
-      };
-      auto mfma_chunk = [&](const Frags& f, int c) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int ks = c * U + u;
-#pragma unroll
-          for (int mb = 0; mb < C::MB; ++mb) {
-            if (!C::USE_ONES) {
-              const int m0 = (h ? C::piece_valid(ks, 1, 0) : C::piece_valid(ks, 0, 0)) ? 0x01010101 : 0;
-              const int m1 = (h ? C::piece_valid(ks, 1, 1) : C::piece_valid(ks, 0, 1)) ? 0x01010101 : 0;
-              int rs_ = rsum[mb];
-              rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].x, m0, rs_, false);
-              rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].y, m0, rs_, false);
-              rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].z, m1, rs_, false);
-              rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].w, m1, rs_, false);
-              rsum[mb] = rs_;
-            }
-#pragma unroll
-            for (int nb = 0; nb < C::NB; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[u][nb], f.x[u][mb], acc[mb][nb], 0, 0, 0);
-          }
-        }
-      };
-      Frags f0, f1;
-      load_chunk(f0, 0);
-#pragma unroll
-      for (int c = 0; c < NCHUNK; ++c) {
-        Frags& cur = (c & 1) ? f1 : f0;
-        Frags& nxt = (c & 1) ? f0 : f1;
-        if (c + 1 < NCHUNK) load_chunk(nxt, c + 1);
-        mfma_chunk(cur, c);
-      }
-      float4 b4[C::NB][4];
-#pragma unroll
-      for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
-          b4[nb][g4] = *reinterpret_cast<const float4*>(bias_lds + (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
-        }
-#pragma unroll
-      for (int mb = 0; mb < C::MB; ++mb) {
-        int R;
-        if (C::USE_ONES) {
-          const int rv = acc[mb][C::ONES_TILE % C::NB][C::ONES_REG];
-          const int ro = __shfl_xor(rv, 32);
-          R = h ? ro : rv;
-        } else {
-          R = rsum[mb] + __shfl_xor(rsum[mb], 32);
-        }
-        const int zwr = p.z_w * R;
-        const int po = epi.pixel((mblk * C::MB + mb) * 32 + r);
-#pragma unroll
-        for (int nb = 0; nb < C::NB; ++nb) {
-          uint32_t pre[4];
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
-            pre[g4] = epi.load(po, (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
-          }
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
-            const int c0 = (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h;
-            const float4 bb = b4[nb][g4];
-            const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(acc[mb][nb][4 * g4 + 0] - zwr)) * p.mult;
-            const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(acc[mb][nb][4 * g4 + 1] - zwr)) * p.mult;
-            const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(acc[mb][nb][4 * g4 + 2] - zwr)) * p.mult;
-            const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(acc[mb][nb][4 * g4 + 3] - zwr)) * p.mult;
-            epi.store(po, c0, v0, v1, v2, v3, pre[g4]);
-          }
-        }
-      }
+      ConvAcc<C> A;
+      conv_mfma_phase<C>(tile, wconv, A, pass, lane);
+      conv_epi_phase<C, Epi>(bias_lds, p, epi, A, pass, lane);
     }
   }
 }
@@ -1823,13 +1843,17 @@ __device__ __forceinline__ void item_range(int n_items, int b, int nb, int& begi
   count = q + (b < rm ? 1 : 0);
 }
 
-template <class C, int NBLK>
+// LDSW = true : weights-stationary as described above (contiguous item ranges).
+// LDSW = false: the block's weights are too large for LDS -- every wave streams its fragments from L2 (conv_passes) and
+//               the workgroups walk the items interleaved (item = blockIdx.x + i * gridDim.x), so that all of them
+//               work on the same MC sample at a time and its weights stay hot in L2.  Same barrier / prefetch scheme.
+template <class C, int NBLK, bool LDSW>
 __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const ChainArgs<NBLK> a) {
   static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int NTHR = BLK_THREADS, NWV = BLK_WAVES;
   constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
-  constexpr int WB = WConv<C>::BYTES;
+  constexpr int WB = LDSW ? WConv<C>::BYTES : 0;
   uint8_t* xt = smem;
   uint8_t* tt = smem + TILES;
   uint8_t* wl = smem + 2 * TILES;                                            // [NBLK][2] whole convs
@@ -1839,8 +1863,15 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
   constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
   constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
   const int groups = (a.B + C::G - 1) / C::G;
-  int begin, count;
-  item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+  int begin, count, step;
+  if (LDSW) {
+    item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+    step = 1;
+  } else {
+    const int n_items = a.n_samples * groups;
+    begin = blockIdx.x; step = gridDim.x;
+    count = begin < n_items ? (n_items - begin + step - 1) / step : 0;
+  }
 
   zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, NTHR>(xt, tid);
   zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, NTHR>(tt, tid);
@@ -1886,13 +1917,13 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
   write_tile(begin);
   int cur_s = -1;
   for (int it = 0; it < count; ++it) {
-    const int item = begin + it;
+    const int item = begin + it * step;
     const int s = item / groups, img0 = (item - s * groups) * C::G;
     const bool more = it + 1 < count;
     // the next item's input: in flight for the whole of this item (unconditional, so the wait counts at its use are
     // exact: the last iteration re-reads its own item and drops it)
-    fetch(more ? item + 1 : item);
-    if (s != cur_s) {            // workgroup-uniform; at most a few times per launch
+    fetch(more ? item + step : item);
+    if (LDSW && s != cur_s) {    // workgroup-uniform; at most a few times per launch
       __syncthreads();           // every wave is done with the previous sample's weights (and the prologue's LDS writes)
 #pragma unroll
       for (int k = 0; k < NBLK; ++k) {
@@ -1908,12 +1939,14 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
       const BlockParams& bp = a.blk[k];
       {
         EpiTile<C::HO, C::COUT, C::TILE_BYTES> epi{tt, bp.a};
-        conv_core<C, decltype(epi), NWV>(xt, wl + (2 * k) * WB, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
+        if constexpr (LDSW) conv_core<C, decltype(epi), NWV>(xt, wl + (2 * k) * WB, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
+        else conv_passes<C, decltype(epi), NWV>(xt, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
       }
       lds_barrier();
       {
         EpiTileResInPlace<C::HO, C::COUT, C::TILE_BYTES> epi{xt, bp.b, bp.add};
-        conv_core<C, decltype(epi), NWV>(tt, wl + (2 * k + 1) * WB, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
+        if constexpr (LDSW) conv_core<C, decltype(epi), NWV>(tt, wl + (2 * k + 1) * WB, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
+        else conv_passes<C, decltype(epi), NWV>(tt, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
       }
       lds_barrier();
     }
@@ -1934,7 +1967,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
           outv[j] = v4i{(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
         }
       }
-      if (more) write_tile(item + 1);
+      if (more) write_tile(item + step);
 #pragma unroll
       for (int j = 0; j < PER_T; ++j) {
         const int i = tid + j * NTHR;
@@ -1948,20 +1981,180 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
   }
 }
 
-template <class C, int NBLK> constexpr int chain_ws_lds() {
-  return 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * NBLK * WConv<C>::BYTES + NBLK * 2 * C::COUT * 4;
+// =====================================================================================
+// Ping-pong identity chain (48 channels): the workgroup's 8 waves form two groups of 4 (one wave per SIMD each).
+// Each group owns one work item at a time (its own X0 / X1 / T tiles; the block weights in LDS are shared) and walks
+// the phase sequence   M_a  E_a  M_b  E_b   (M = the conv's MFMA K loop into parked accumulators, E = its
+// requantising epilogue), one phase per barrier interval.  Group 1 runs one interval behind group 0, so in every
+// interval each SIMD holds one wave issuing MFMAs and one wave issuing epilogue VALU -- the matrix and vector pipes
+// overlap instead of alternating.  Input write / output read-out ride along: the finished item k-1 leaves from
+// X[(k-1)&1] during M_a(k); the input of item k+1 enters X[(k+1)&1] during E_a(k).
+// =====================================================================================
+template <class C, int NBLK>
+__global__ __launch_bounds__(512) void block_chain_pp_kernel(const ChainArgs<NBLK> a) {
+  static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
+  static_assert(!C::ROWREUSE && C::NPASS == 4, "one MFMA pass per wave of a 4-wave group");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int GT = 256;                                                   // threads per group
+  constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
+  constexpr int WB = WConv<C>::BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, lw = wave & 3, ltid = tid & (GT - 1);
+  uint8_t* xg = smem + grp * 3 * TILES;                                     // X0, X1, T of this group
+  uint8_t* tt = xg + 2 * TILES;
+  uint8_t* wl = smem + 6 * TILES;                                           // [NBLK][2] whole convs
+  float* bias_lds = reinterpret_cast<float*>(wl + 2 * NBLK * WB);           // [NBLK][2][COUT]
+
+  constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;
+  constexpr int PER_T = (NCH + GT - 1) / GT;
+  const int groups = (a.B + C::G - 1) / C::G;                               // items per sample (host: even)
+  int pbegin, pcount;                                                       // contiguous range of item PAIRS
+  item_range(a.n_samples * groups / 2, blockIdx.x, gridDim.x, pbegin, pcount);
+
+  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, GT>(xg, ltid);
+  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, GT>(xg + TILES, ltid);
+  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, GT>(tt, ltid);
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) {
+    load_bias<C::COUT, 512>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
+    load_bias<C::COUT, 512>(bias_lds + (2 * k + 1) * C::COUT, a.blk[k].b.bias, tid);
+  }
+  if (pcount <= 0) return;
+
+  auto item_of = [&](int k) { return 2 * (pbegin + k) + grp; };
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = ltid + j * GT;
+      const int g = i / CPI, rem = i - g * CPI;
+      const bool ok = (i < NCH) && (img0 + g < a.B);
+      const int64_t off = ok ? ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16 : 0;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + off);
+    }
+  };
+  auto write_tile = [&](uint8_t* xt, int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = ltid + j * GT;
+      if (i < NCH) {
+        const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+        const bool ok = img0 + g < a.B;
+        const v4i v = pre[j];
+        uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+        *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
+        *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
+      }
+    }
+  };
+  auto store_tile = [&](const uint8_t* xt, int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const uint32_t z4 = (uint32_t)a.blk[NBLK - 1].add.z_o * 0x01010101u;
+    uint8_t* ys = a.y + (int64_t)s * a.y_ss;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = ltid + j * GT;
+      if (i < NCH) {
+        const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+        if (img0 + g < a.B) {
+          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+          const v2i lo = *reinterpret_cast<const v2i*>(d), hi = *reinterpret_cast<const v2i*>(d + 8);
+          v4i v = {(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
+          *reinterpret_cast<v4i*>(ys + ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16) = v;
+        }
+      }
+    }
+  };
+
+  fetch(item_of(0));
+  write_tile(xg, item_of(0));
+  fetch(item_of(pcount > 1 ? 1 : 0));
+  constexpr int NPH = 4 * NBLK;
+  const int n_int = NPH * pcount + 1;                  // group 1 finishes one interval after group 0
+  ConvAcc<C> A;
+  int cur_s = -1;
+#pragma unroll 1
+  for (int t = 0; t < n_int; ++t) {
+    // ---- interval boundary.  Group 0 enters a new pair every NPH intervals; if that pair belongs to another MC
+    // sample the block weights are replaced here -- group 1 is in its last epilogue (no weight reads) meanwhile.
+    const int k0 = t / NPH;
+    bool reload = false;
+    int s0 = cur_s;
+    if (t - k0 * NPH == 0 && k0 < pcount) { s0 = (2 * (pbegin + k0)) / groups; reload = s0 != cur_s; }
+    if (reload) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NBLK; ++k) {
+        dma_conv<C, 8>(wl + (2 * k) * WB, a.blk[k].a.w + (int64_t)s0 * a.blk[k].a.w_ss, wave, lane);
+        dma_conv<C, 8>(wl + (2 * k + 1) * WB, a.blk[k].b.w + (int64_t)s0 * a.blk[k].b.w_ss, wave, lane);
+      }
+      __syncthreads();
+      cur_s = s0;
+    } else {
+      lds_barrier();
+    }
+    const int lt = t - grp;
+    if (lt < 0 || lt >= NPH * pcount) continue;
+    const int k = lt / NPH, ph = lt - k * NPH, blk = ph >> 2, q = ph & 3;
+    uint8_t* X = xg + (k & 1) * TILES;
+    uint8_t* Xo = xg + ((k + 1) & 1) * TILES;
+    const BlockParams& bp = a.blk[blk];
+    if (q == 0) {
+      conv_mfma_phase<C>(X, wl + (2 * blk) * WB, A, lw, lane);
+      if (blk == 0 && k > 0) store_tile(Xo, item_of(k - 1));
+    } else if (q == 1) {
+      EpiTile<C::HO, C::COUT, C::TILE_BYTES> epi{tt, bp.a};
+      conv_epi_phase<C, decltype(epi)>(bias_lds + (2 * blk) * C::COUT, bp.a, epi, A, lw, lane);
+      if (blk == 0 && k + 1 < pcount) {
+        write_tile(Xo, item_of(k + 1));
+        fetch(item_of(k + 2 < pcount ? k + 2 : k + 1));
+      }
+    } else if (q == 2) {
+      conv_mfma_phase<C>(tt, wl + (2 * blk + 1) * WB, A, lw, lane);
+    } else {
+      EpiTileResInPlace<C::HO, C::COUT, C::TILE_BYTES> epi{X, bp.b, bp.add};
+      conv_epi_phase<C, decltype(epi)>(bias_lds + (2 * blk + 1) * C::COUT, bp.b, epi, A, lw, lane);
+    }
+  }
+  lds_barrier();
+  store_tile(xg + ((pcount - 1) & 1) * TILES, item_of(pcount - 1));
+}
+
+template <class C, int NBLK> constexpr int chain_pp_lds() {
+  return 6 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * NBLK * WConv<C>::BYTES + NBLK * 2 * C::COUT * 4;
 }
 
 template <class C, int NBLK>
-static int launch_block_chain_ws(const ChainArgs<NBLK>& a, hipStream_t st) {
-  constexpr int LDS = chain_ws_lds<C, NBLK>();
+static int launch_block_chain_pp(const ChainArgs<NBLK>& a, hipStream_t st) {
+  constexpr int LDS = chain_pp_lds<C, NBLK>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_chain_ws_kernel<C, NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  if (!attr) { hipFuncSetAttribute((const void*)block_chain_pp_kernel<C, NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  const int groups = (a.B + C::G - 1) / C::G;
+  const int n_pairs = a.n_samples * groups / 2;
+  const int grid = n_pairs < 256 ? n_pairs : 256;
+  hipLaunchKernelGGL((block_chain_pp_kernel<C, NBLK>), dim3(grid), dim3(512), LDS, st, a);
+  return check_launch("qbnn_block_chain_i8_mc");
+}
+
+template <class C, int NBLK, bool LDSW = true> constexpr int chain_ws_lds() {
+  return 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + (LDSW ? 2 * NBLK * WConv<C>::BYTES : 0) + NBLK * 2 * C::COUT * 4;
+}
+
+template <class C, int NBLK, bool LDSW = true>
+static int launch_block_chain_ws(const ChainArgs<NBLK>& a, hipStream_t st) {
+  constexpr int LDS = chain_ws_lds<C, NBLK, LDSW>();
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)block_chain_ws_kernel<C, NBLK, LDSW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
   const int grid = n_items < 256 ? n_items : 256;
-  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, LDSW>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
   return check_launch("qbnn_block_chain_i8_mc");
 }
 
@@ -1974,7 +2167,7 @@ static int launch_chain_auto(const ChainArgs<NBLK>& a, hipStream_t st) {
   return launch_block_chain<C, NBLK>(a, st);
 }
 
-template <class CA, class CS, class CB>
+template <class CA, class CS, class CB, bool LDSW>
 __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownArgs a) {
   static_assert(CA::M == CS::M && CA::M == CB::M && CA::G == CS::G && CA::G == CB::G, "one work item, three convs");
   static_assert(CA::COUT == CB::CIN && CA::COUT == CB::COUT && CS::COUT == CB::COUT && CA::HO == CB::HIN, "block geometry");
@@ -1987,16 +2180,23 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
   uint8_t* tt = smem + XB;
   uint8_t* sc = tt + TB;
   uint8_t* wl_s = sc + CB::OUT_BYTES;
-  uint8_t* wl_a = wl_s + WConv<CS>::BYTES;
-  uint8_t* wl_b = wl_a + WConv<CA>::BYTES;
-  float* bias_lds = reinterpret_cast<float*>(wl_b + WConv<CB>::BYTES);       // [3][COUT]: s, a, b
+  uint8_t* wl_a = wl_s + (LDSW ? WConv<CS>::BYTES : 0);
+  uint8_t* wl_b = wl_a + (LDSW ? WConv<CA>::BYTES : 0);
+  float* bias_lds = reinterpret_cast<float*>(wl_b + (LDSW ? WConv<CB>::BYTES : 0));       // [3][COUT]: s, a, b
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   constexpr int CPR = CA::ROWB / 16, CPI = CA::HIN * CPR, NCH = CA::G * CPI;
   constexpr int PER_T = (NCH + BLK_THREADS - 1) / BLK_THREADS;
   const int groups = (a.B + CA::G - 1) / CA::G;
-  int begin, count;
-  item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+  int begin, count, step;
+  if (LDSW) {
+    item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+    step = 1;
+  } else {
+    const int n_items = a.n_samples * groups;
+    begin = blockIdx.x; step = gridDim.x;
+    count = begin < n_items ? (n_items - begin + step - 1) / step : 0;
+  }
 
   zero_halo<CA::TW, CA::CIN, CA::TILE_BYTES, CA::G, BLK_THREADS>(xt, tid);
   zero_halo<CB::TW, CB::CIN, CB::TILE_BYTES, CB::G, BLK_THREADS>(tt, tid);
@@ -2039,11 +2239,11 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
   write_tile(begin);
   int cur_s = -1;
   for (int it = 0; it < count; ++it) {
-    const int item = begin + it;
+    const int item = begin + it * step;
     const int s = item / groups, img0 = (item - s * groups) * CA::G;
     const bool more = it + 1 < count;
-    fetch(more ? item + 1 : item);       // unconditional: exact wait counts at its use (see block_chain_ws_kernel)
-    if (s != cur_s) {
+    fetch(more ? item + step : item);    // unconditional: exact wait counts at its use (see block_chain_ws_kernel)
+    if (LDSW && s != cur_s) {
       __syncthreads();
       dma_conv<CS, BLK_WAVES>(wl_s, a.s.w + (int64_t)s * a.s.w_ss, wave, lane);
       dma_conv<CA, BLK_WAVES>(wl_a, a.a.w + (int64_t)s * a.a.w_ss, wave, lane);
@@ -2054,19 +2254,22 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
     lds_barrier();       // X complete; the previous item's SC has been read out by every thread
     {
       EpiDense<COUT, false> epi{sc, a.s, a.add};
-      conv_core<CS, decltype(epi), BLK_WAVES>(xt, wl_s, bias_lds, a.s, epi, wave, lane);
+      if constexpr (LDSW) conv_core<CS, decltype(epi), BLK_WAVES>(xt, wl_s, bias_lds, a.s, epi, wave, lane);
+      else conv_passes<CS, decltype(epi), BLK_WAVES>(xt, a.s.w + (int64_t)s * a.s.w_ss, bias_lds, a.s, epi, wave, lane);
     }
     {
       EpiTile<CB::HIN, CB::CIN, CB::TILE_BYTES> epi{tt, a.a};
-      conv_core<CA, decltype(epi), BLK_WAVES>(xt, wl_a, bias_lds + COUT, a.a, epi, wave, lane);
+      if constexpr (LDSW) conv_core<CA, decltype(epi), BLK_WAVES>(xt, wl_a, bias_lds + COUT, a.a, epi, wave, lane);
+      else conv_passes<CA, decltype(epi), BLK_WAVES>(xt, a.a.w + (int64_t)s * a.a.w_ss, bias_lds + COUT, a.a, epi, wave, lane);
     }
     lds_barrier();       // T and SC complete
     {
       EpiDense<COUT, true> epi{sc, a.b, a.add};
-      conv_core<CB, decltype(epi), BLK_WAVES>(tt, wl_b, bias_lds + 2 * COUT, a.b, epi, wave, lane);
+      if constexpr (LDSW) conv_core<CB, decltype(epi), BLK_WAVES>(tt, wl_b, bias_lds + 2 * COUT, a.b, epi, wave, lane);
+      else conv_passes<CB, decltype(epi), BLK_WAVES>(tt, a.b.w + (int64_t)s * a.b.w_ss, bias_lds + 2 * COUT, a.b, epi, wave, lane);
     }
     lds_barrier();
-    if (more) write_tile(item + 1);      // before the stores: its vmcnt wait then covers only the (old) input loads
+    if (more) write_tile(item + step);      // before the stores: its vmcnt wait then covers only the (old) input loads
     {
       constexpr int IMG_OUT = CB::HO * CB::HO * COUT;
       uint8_t* ys = a.y + (int64_t)s * a.y_ss;
@@ -2077,17 +2280,17 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
   }
 }
 
-template <class CA, class CS, class CB>
+template <class CA, class CS, class CB, bool LDSW>
 static int launch_block_down_ws(const DownArgs& a, hipStream_t st) {
   constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + CB::OUT_BYTES +
-                      WConv<CS>::BYTES + WConv<CA>::BYTES + WConv<CB>::BYTES + 3 * CB::COUT * 4;
+                      (LDSW ? WConv<CS>::BYTES + WConv<CA>::BYTES + WConv<CB>::BYTES : 0) + 3 * CB::COUT * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_down_ws_kernel<CA, CS, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  if (!attr) { hipFuncSetAttribute((const void*)block_down_ws_kernel<CA, CS, CB, LDSW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
   const int groups = (a.B + CA::G - 1) / CA::G;
   const int n_items = a.n_samples * groups;
   const int grid = n_items < 256 ? n_items : 256;
-  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
+  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
   return check_launch("qbnn_block_down_i8_mc");
 }
 
@@ -2095,6 +2298,7 @@ static int launch_block_down_ws(const DownArgs& a, hipStream_t st) {
 using Blk_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;
 using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;
 using Blk_96  = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3>;
+using PP_48   = ConvCfg<48, 48, 3, 1, 16, 1, 1, 2, 2>;          // per wave group of the ping-pong kernel
 using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
 
 template <int NBLK>
@@ -2124,9 +2328,14 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
     s_in = b.s_o; z_in = b.z_o;
   }
   if (Cc == 24 && H == 32) return launch_chain_auto<Blk_24, NBLK>(a, st);
-  if (Cc == 48 && H == 16) return launch_chain_auto<Blk_48, NBLK>(a, st);
+  if (Cc == 48 && H == 16) {
+    if constexpr (chain_pp_lds<PP_48, NBLK>() <= 160 * 1024) {
+      if (!ring_only() && !no_pingpong() && ((B + PP_48::G - 1) / PP_48::G) % 2 == 0) return launch_block_chain_pp<PP_48, NBLK>(a, st);
+    }
+    return launch_chain_auto<Blk_48, NBLK>(a, st);
+  }
   if (Cc == 96 && H == 8) return launch_block_chain<Blk_96, NBLK>(a, st);
-  if (Cc == 192 && H == 4) return launch_block_chain<Blk_192, NBLK>(a, st);
+  if (Cc == 192 && H == 4) return ring_only() ? launch_block_chain<Blk_192, NBLK>(a, st) : launch_block_chain_ws<Blk_192, NBLK, false>(a, st);
   return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
 }
 
