@@ -254,8 +254,12 @@ QBNN_EXPORT void qbnn_debug_read_inner(unsigned long long* host4) {
 #define QBNN_INNER_FLUSH() do {} while (0)
 #endif
 
-template <int CIN_, int COUT_, int KSZ_, int STRIDE_, int HIN_, int HALO_, int G_, int MB_, int NB_, bool RING_ = true, int SLAB_KB_ = 36>
+template <int CIN_, int COUT_, int KSZ_, int STRIDE_, int HIN_, int HALO_, int G_, int MB_, int NB_, bool RING_ = true, int SLAB_KB_ = 36, int PADB_ = 0>
 struct ConvCfg {
+  // PADB: pad bytes after every pixel of the LDS input tile.  With 96 / 192 channels the 32 pixels of a B-operand
+  // fragment sit 96 / 192 bytes apart = 4- / 8-way bank conflicts on every fragment read; +16 bytes makes the
+  // stride 28 / 52 banks (2-way, like the 48-channel tiles).  Taps are then addressed one by one (CIN % 32 == 0).
+  static constexpr int PADB = PADB_;
   // RING: fused kernels stage this conv's weights through the LDS slab ring (conv_lds); false = every wave streams
   // its fragments from L2 (conv_passes) -- better when the conv's weights are far larger than the ring (192 channels)
   static constexpr bool RING = RING_;
@@ -265,8 +269,9 @@ struct ConvCfg {
   static constexpr int OFF0 = HALO - PAD;
   static constexpr int HO = HIN / STRIDE;
   static constexpr int TW = HIN + 2 * HALO;
-  static constexpr int PITCH = TW * CIN;
-  static constexpr int TILE_BYTES = (TW * TW * CIN + 15) / 16 * 16;
+  static constexpr int PIXB = CIN + PADB;                 // bytes from one tile pixel to the next
+  static constexpr int PITCH = TW * PIXB;
+  static constexpr int TILE_BYTES = (TW * TW * PIXB + 15) / 16 * 16;
   static constexpr int ROWB = HIN * CIN;                  // bytes of one image row in HBM
   static constexpr int RB = KSZ * CIN;                    // bytes of one kernel row: (kw, c) contiguous in NHWC
   static constexpr int RBP = (RB + 31) / 32 * 32;         // padded to whole 32-byte k-steps (weights are 0 there)
@@ -300,7 +305,16 @@ struct ConvCfg {
   static_assert(COUT % 32 == 0 || NBLKS == 1, "ragged COUT needs all n-tiles (incl. the ones row) in one pass");
   static_assert(SPR % KCHUNK == 0, "k-chunks must not straddle kernel rows");
   // byte offset (from the lane's base) of k-step ks, and validity of the 8-byte piece `i` of k-half `h`
-  static constexpr int step_off(int ks) { return (ks / SPR) * PITCH + (ks % SPR) * 32; }
+  static constexpr int SPT = CIN / 32;                    // k-steps per tap (padded tiles only)
+  static constexpr int step_off(int ks) {
+    return PADB == 0 ? (ks / SPR) * PITCH + (ks % SPR) * 32
+                     : (ks / SPR) * PITCH + ((ks % SPR) / (SPT > 0 ? SPT : 1)) * PIXB + ((ks % SPR) % (SPT > 0 ? SPT : 1)) * 32;
+  }
+  // offset inside a tile row of the 16-byte chunk `within` of an image row (chunks never straddle pixels when padded)
+  static constexpr int row_chunk_off(int within) {
+    return PADB == 0 ? HALO * CIN + within * 16 : (HALO + (within * 16) / CIN) * PIXB + (within * 16) % CIN;
+  }
+  static_assert(PADB == 0 || (CIN % 32 == 0 && PADB % 8 == 0 && (CIN / 32) % KCHUNK == 0), "padded tiles: whole k-steps per tap, chunks inside a tap");
   static constexpr bool piece_valid(int ks, int h, int i) { return (ks % SPR) * 32 + 16 * h + 8 * i < RB; }
 };
 
@@ -319,6 +333,18 @@ __device__ __forceinline__ uint32_t pack_low_bytes(float t0, float t1, float t2,
   return p01 | p23;
 }
 __device__ __forceinline__ float med3f(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+
+// the 16 bytes a lane contributes to a B-operand (pixel) fragment: one ds_read_b128 where pixels are 16-byte aligned
+template <class C>
+__device__ __forceinline__ v4i load_xfrag(const uint8_t* p) {
+  if constexpr (C::PIXB % 16 == 0) {
+    return *reinterpret_cast<const v4i*>(p);
+  } else {
+    const v2i lo = *reinterpret_cast<const v2i*>(p);
+    const v2i hi = *reinterpret_cast<const v2i*>(p + 8);
+    return v4i{lo.x, lo.y, hi.x, hi.y};
+  }
+}
 
 // zero the halo ring of G tiles of geometry (TW x TW x CH), 8-byte stores
 template <int TW, int CH, int TILE_BYTES, int G, int NTHR = 256>
@@ -356,7 +382,7 @@ __device__ __forceinline__ void load_tiles(uint8_t* tile, const uint8_t* xs, int
       v = *reinterpret_cast<const v4i*>(xs + ((int64_t)(img0 + g) * C::HIN + row) * C::ROWB + within * 16);
       if (!PRESUB) { v.x = sub_bytes(v.x, z4); v.y = sub_bytes(v.y, z4); v.z = sub_bytes(v.z, z4); v.w = sub_bytes(v.w, z4); }
     }
-    uint8_t* d = tile + g * C::TILE_BYTES + (row + C::HALO) * C::PITCH + C::HALO * C::CIN + within * 16;
+    uint8_t* d = tile + g * C::TILE_BYTES + (row + C::HALO) * C::PITCH + C::row_chunk_off(within);
     *reinterpret_cast<v2i*>(d) = v2i{v.x, v.y};
     *reinterpret_cast<v2i*>(d + 8) = v2i{v.z, v.w};
   }
@@ -380,7 +406,7 @@ __device__ __forceinline__ void conv_passes_rows(const uint8_t* tile, const int8
   for (int pass = wave; pass < C::NPASS; pass += NWAVES) {
     const int m0 = pass * C::MB * 32;                         // first pixel of the pass (NBLKS == 1)
     const int g = m0 / (C::HO * C::HO), oh0 = (m0 % (C::HO * C::HO)) / C::HO;
-    const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::CIN + 16 * h;
+    const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::PIXB + 16 * h;
     QBNN_INNER_T0();
     v4i w[C::KS];
 #pragma unroll
@@ -466,13 +492,15 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
       const int m = (mblk * C::MB + mb) * 32 + r;
       const int g = m / (C::HO * C::HO), rem = m % (C::HO * C::HO);
       const int oh = rem / C::HO, ow = rem % C::HO;
-      ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::CIN + 16 * h;
+      ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::PIXB + 16 * h;
     }
     const int8_t* wbase = wq + ((int64_t)(nblk * C::NB) * C::KS * 64 + lane) * 16;
     auto load_chunk = [&](Frags& f, int kc) {
       const int ks0 = kc * U;
       const int kh = ks0 / C::SPR, t0 = ks0 - kh * C::SPR;
-      const int aoff = kh * C::PITCH + t0 * 32;
+      int aoff;
+      if constexpr (C::PADB == 0) aoff = kh * C::PITCH + t0 * 32;
+      else { const int kw = t0 / C::SPT; aoff = kh * C::PITCH + kw * C::PIXB + (t0 - kw * C::SPT) * 32; }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -480,9 +508,7 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
           f.w[u][nb] = *reinterpret_cast<const v4i*>(wbase + ((int64_t)(nb * C::KS + ks0 + u) * 64) * 16);
 #pragma unroll
         for (int mb = 0; mb < C::MB; ++mb) {
-          const v2i lo = *reinterpret_cast<const v2i*>(ap[mb] + aoff + u * 32);
-          const v2i hi = *reinterpret_cast<const v2i*>(ap[mb] + aoff + u * 32 + 8);
-          f.x[u][mb] = v4i{lo.x, lo.y, hi.x, hi.y};
+          f.x[u][mb] = load_xfrag<C>(ap[mb] + aoff + u * 32);
         }
       }
     };
@@ -762,7 +788,7 @@ __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const
     for (int pass_ = wave; pass_ < C::NPASS; pass_ += NWAVES) {
     const int m0 = pass_ * C::MB * 32;
     const int g = m0 / (C::HO * C::HO), oh0 = (m0 % (C::HO * C::HO)) / C::HO;
-    const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::CIN + 16 * h;
+    const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::PIXB + 16 * h;
     v4i x[NR][C::SPR];
 #pragma unroll
     for (int j = 0; j < NR; ++j)
@@ -827,7 +853,7 @@ __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const
       const int m = (mblk * C::MB + mb) * 32 + r;
       const int g = m / (C::HO * C::HO), rem = m % (C::HO * C::HO);
       const int oh = rem / C::HO, ow = rem % C::HO;
-      ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::CIN + 16 * h;
+      ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::PIXB + 16 * h;
     }
     v16i acc[C::MB][C::NB];
     int rsum[C::MB];
@@ -861,9 +887,7 @@ __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const
             for (int nb = 0; nb < C::NB; ++nb) f.w[u][nb] = *reinterpret_cast<const v4i*>(wl + (nb * C::SLK + c * U + u) * 1024);
 #pragma unroll
             for (int mb = 0; mb < C::MB; ++mb) {
-              const v2i lo = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks));
-              const v2i hi = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks) + 8);
-              f.x[u][mb] = v4i{lo.x, lo.y, hi.x, hi.y};
+              f.x[u][mb] = load_xfrag<C>(ap[mb] + C::step_off(ks));
             }
           }
         };
@@ -1011,18 +1035,18 @@ struct EpiDense {
   }
 };
 
-template <int HO, int COUT, int TILE_BYTES>
+template <int HO, int PIXB, int TILE_BYTES>
 __device__ __forceinline__ int tile_px_off(int m, int c0) {
   const int g = m / (HO * HO), rem = m % (HO * HO), oh = rem / HO, ow = rem % HO;
-  return g * TILE_BYTES + ((oh + 1) * (HO + 2) + ow + 1) * COUT + c0;
+  return g * TILE_BYTES + ((oh + 1) * (HO + 2) + ow + 1) * PIXB + c0;
 }
 
-// (b) centred int8 (q - z_y) into the halo'd tile feeding the next conv (geometry HO x HO x COUT, halo 1)
-template <int HO, int COUT, int TILE_BYTES>
+// (b) centred int8 (q - z_y) into the halo'd tile feeding the next conv (geometry HO x HO, PIXB bytes per pixel, halo 1)
+template <int HO, int PIXB, int TILE_BYTES>
 struct EpiTile {
   static constexpr int VALU_PER_MFMA = 10;
   uint8_t* dst; QConv p;
-  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, COUT, TILE_BYTES>(m, 0); }
+  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, PIXB, TILE_BYTES>(m, 0); }
   __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
   __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
     uint32_t* o = reinterpret_cast<uint32_t*>(dst + po + c0);
@@ -1034,11 +1058,11 @@ struct EpiTile {
 
 // (c) conv -> Add(residual) -> ReLU, residual read as centred int8 (x' = q_r - z_r) from a halo'd tile of the same
 //     geometry and overwritten in place with the centred block output (q_o - z_o).
-template <int HO, int COUT, int TILE_BYTES>
+template <int HO, int PIXB, int TILE_BYTES>
 struct EpiTileResInPlace {
   static constexpr int VALU_PER_MFMA = 22;
   uint8_t* xt; QConv p; QAdd a;
-  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, COUT, TILE_BYTES>(m, 0); }
+  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, PIXB, TILE_BYTES>(m, 0); }
   __device__ __forceinline__ uint32_t load(int po, int c0) const {
     return *reinterpret_cast<const uint32_t*>(xt + po + c0);
   }
@@ -1063,12 +1087,12 @@ struct EpiTileResInPlace {
 
 // (d) as (c), with the whole Add + ReLU looked up in the LDS copy of the block's 128x128 table:
 //     row = conv output q (centred byte q' = q - z_y), column = residual r (centred byte r' = r - z_r).
-template <int HO, int COUT, int TILE_BYTES>
+template <int HO, int PIXB, int TILE_BYTES>
 struct EpiTileResLut {
   static constexpr int VALU_PER_MFMA = 13;
   uint8_t* xt; const uint8_t* lut0;      // lut0 = table + (z_y << 7) + z_r : indexable by the centred bytes
   QConv p;
-  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, COUT, TILE_BYTES>(m, 0); }
+  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, PIXB, TILE_BYTES>(m, 0); }
   __device__ __forceinline__ uint32_t load(int po, int c0) const {
     return *reinterpret_cast<const uint32_t*>(xt + po + c0);
   }
@@ -1105,7 +1129,7 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = blockIdx.y, img0 = blockIdx.x * C::G;
 
-  if (C::HALO > 0) zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G>(tile, tid);
+  if (C::HALO > 0) zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G>(tile, tid);
   load_tiles<C, PRESUB>(tile, a.x + (int64_t)s * a.x_ss, img0, a.B, a.p.z_x, tid);
   load_bias<C::COUT>(bias_lds, a.p.bias, tid);
   constexpr int IMG_OUT = C::HO * C::HO * C::COUT;
@@ -1232,8 +1256,8 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? ChainThreads<C, NBLK>::per_cu 
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
 
-  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, NTHR>(xt, tid);
-  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, NTHR>(tt, tid);
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, NTHR>(xt, tid);
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, NTHR>(tt, tid);
 #pragma unroll
   for (int k = 0; k < NBLK; ++k) {
     load_bias<C::COUT, NTHR>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
@@ -1278,7 +1302,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? ChainThreads<C, NBLK>::per_cu 
           const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
           const bool ok = img0 + g < a.B;
           const v4i v = pre[j];
-          uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+          uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
           *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
           *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
         }
@@ -1289,7 +1313,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? ChainThreads<C, NBLK>::per_cu 
     for (int k = 0; k < NBLK; ++k) {
       const BlockParams& bp = a.blk[k];
       {
-        EpiTile<C::HO, C::COUT, C::TILE_BYTES> epi{tt, bp.a};
+        EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{tt, bp.a};
         conv_any<C, decltype(epi), NWV>(xt, ring, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane,
             [&](uint8_t* dst) { dma_slab_if_ring<C, NWV>(dst, bp.b.w + (int64_t)s * bp.b.w_ss, wave, lane); },
             [&]() { if (k == 0 && next < n_items) fetch(next); });
@@ -1297,7 +1321,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? ChainThreads<C, NBLK>::per_cu 
       QBNN_STAMP_AT(2);
       if (use_lut)
       {
-        EpiTileResLut<C::HO, C::COUT, C::TILE_BYTES> epi{xt, lut_lds + k * 16384 + (bp.b.z_y << 7) + bp.add.z_r, bp.b};
+        EpiTileResLut<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, lut_lds + k * 16384 + (bp.b.z_y << 7) + bp.add.z_r, bp.b};
         conv_any<C, decltype(epi), NWV>(tt, ring, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane,
             [&](uint8_t* dst) {
               if (k + 1 < NBLK) dma_slab_if_ring<C, NWV>(dst, a.blk[k + 1 < NBLK ? k + 1 : 0].a.w + (int64_t)s * a.blk[k + 1 < NBLK ? k + 1 : 0].a.w_ss, wave, lane);
@@ -1307,7 +1331,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? ChainThreads<C, NBLK>::per_cu 
       }
       else
       {
-        EpiTileResInPlace<C::HO, C::COUT, C::TILE_BYTES> epi{xt, bp.b, bp.add};
+        EpiTileResInPlace<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, bp.b, bp.add};
         conv_any<C, decltype(epi), NWV>(tt, ring, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane,
             [&](uint8_t* dst) {
               if (k + 1 < NBLK) dma_slab_if_ring<C, NWV>(dst, a.blk[k + 1 < NBLK ? k + 1 : 0].a.w + (int64_t)s * a.blk[k + 1 < NBLK ? k + 1 : 0].a.w_ss, wave, lane);
@@ -1326,7 +1350,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? ChainThreads<C, NBLK>::per_cu 
       for (int i = tid; i < NCH; i += NTHR) {
         const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
         if (img0 + g < a.B) {
-          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
           const v2i lo = *reinterpret_cast<const v2i*>(d), hi = *reinterpret_cast<const v2i*>(d + 8);
           v4i v = {(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
           *reinterpret_cast<v4i*>(ys + ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16) = v;
@@ -1474,8 +1498,8 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_i8_kernel(const DownAr
   const int groups = (a.B + CA::G - 1) / CA::G;
   const int n_items = a.n_samples * groups;
 
-  zero_halo<CA::TW, CA::CIN, CA::TILE_BYTES, CA::G, BLK_THREADS>(xt, tid);
-  zero_halo<CB::TW, CB::CIN, CB::TILE_BYTES, CB::G, BLK_THREADS>(tt, tid);
+  zero_halo<CA::TW, CA::PIXB, CA::TILE_BYTES, CA::G, BLK_THREADS>(xt, tid);
+  zero_halo<CB::TW, CB::PIXB, CB::TILE_BYTES, CB::G, BLK_THREADS>(tt, tid);
   load_bias<COUT, BLK_THREADS>(bias_lds, a.s.bias, tid);
   load_bias<COUT, BLK_THREADS>(bias_lds + COUT, a.a.bias, tid);
   load_bias<COUT, BLK_THREADS>(bias_lds + 2 * COUT, a.b.bias, tid);
@@ -1511,7 +1535,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_i8_kernel(const DownAr
           const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
           const bool ok = img0 + g < a.B;
           const v4i v = pre[j];
-          uint8_t* d = xt + g * CA::TILE_BYTES + (row + 1) * CA::PITCH + CA::CIN + within * 16;
+          uint8_t* d = xt + g * CA::TILE_BYTES + (row + 1) * CA::PITCH + CA::row_chunk_off(within);
           *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
           *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
         }
@@ -1524,7 +1548,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_i8_kernel(const DownAr
           [&]() { if (next < n_items) fetch(next); });
     }
     {
-      EpiTile<CB::HIN, CB::CIN, CB::TILE_BYTES> epi{tt, a.a};
+      EpiTile<CB::HIN, CB::PIXB, CB::TILE_BYTES> epi{tt, a.a};
       conv_any<CA, decltype(epi), BLK_WAVES>(xt, ring, a.a.w + (int64_t)s * a.a.w_ss, bias_lds + COUT, a.a, epi, wave, lane,
           [&](uint8_t* dst) { dma_slab_if_ring<CB, BLK_WAVES>(dst, a.b.w + (int64_t)s * a.b.w_ss, wave, lane); }, [&]() {});
     }
@@ -1579,7 +1603,7 @@ using D24_s = ConvCfg<24, 48, 1, 2, 32, 1, 1, 1, 2>;
 using D24_b = ConvCfg<48, 48, 3, 1, 16, 1, 1, 1, 2>;
 using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 4, 1, 3, false>;
 using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 4, 1, 3, false>;
-using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, false>;
+using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, false, 36, 16>;
 using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
 using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, 1, 3, false>;
 using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
@@ -1651,7 +1675,7 @@ __device__ __forceinline__ void conv_mfma_phase(const uint8_t* tile, const uint8
     const int m = (mblk * C::MB + mb) * 32 + r;
     const int g = m / (C::HO * C::HO), rem = m % (C::HO * C::HO);
     const int oh = rem / C::HO, ow = rem % C::HO;
-    ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::CIN + 16 * h;
+    ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::PIXB + 16 * h;
   }
   const uint8_t* wl = wconv + ((nblk * C::NB) * C::KS * 64 + lane) * 16;
 #pragma unroll
@@ -1670,9 +1694,7 @@ __device__ __forceinline__ void conv_mfma_phase(const uint8_t* tile, const uint8
       for (int nb = 0; nb < C::NB; ++nb) f.w[u][nb] = *reinterpret_cast<const v4i*>(wl + (nb * C::KS + ks) * 1024);
 #pragma unroll
       for (int mb = 0; mb < C::MB; ++mb) {
-        const v2i lo = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks));
-        const v2i hi = *reinterpret_cast<const v2i*>(ap[mb] + C::step_off(ks) + 8);
-        f.x[u][mb] = v4i{lo.x, lo.y, hi.x, hi.y};
+        f.x[u][mb] = load_xfrag<C>(ap[mb] + C::step_off(ks));
       }
     }
   };
@@ -1775,7 +1797,7 @@ __device__ __forceinline__ void conv_core(const uint8_t* tile, const uint8_t* wc
     for (int pass = wave; pass < C::NPASS; pass += NWAVES) {
       const int m0 = pass * C::MB * 32;
       const int g = m0 / (C::HO * C::HO), oh0 = (m0 % (C::HO * C::HO)) / C::HO;
-      const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::CIN + 16 * h;
+      const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::PIXB + 16 * h;
       v4i x[NR][C::SPR];
 #pragma unroll
       for (int j = 0; j < NR; ++j)
@@ -1873,8 +1895,8 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
     count = begin < n_items ? (n_items - begin + step - 1) / step : 0;
   }
 
-  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, NTHR>(xt, tid);
-  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, NTHR>(tt, tid);
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, NTHR>(xt, tid);
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, NTHR>(tt, tid);
 #pragma unroll
   for (int k = 0; k < NBLK; ++k) {
     load_bias<C::COUT, NTHR>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
@@ -1906,7 +1928,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
         const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
         const bool ok = img0 + g < a.B;
         const v4i v = pre[j];
-        uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+        uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
         *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
         *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
       }
@@ -1938,13 +1960,13 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
     for (int k = 0; k < NBLK; ++k) {
       const BlockParams& bp = a.blk[k];
       {
-        EpiTile<C::HO, C::COUT, C::TILE_BYTES> epi{tt, bp.a};
+        EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{tt, bp.a};
         if constexpr (LDSW) conv_core<C, decltype(epi), NWV>(xt, wl + (2 * k) * WB, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
         else conv_passes<C, decltype(epi), NWV>(xt, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
       }
       lds_barrier();
       {
-        EpiTileResInPlace<C::HO, C::COUT, C::TILE_BYTES> epi{xt, bp.b, bp.add};
+        EpiTileResInPlace<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, bp.b, bp.add};
         if constexpr (LDSW) conv_core<C, decltype(epi), NWV>(tt, wl + (2 * k + 1) * WB, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
         else conv_passes<C, decltype(epi), NWV>(tt, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
       }
@@ -1962,7 +1984,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
         const int i = tid + j * NTHR;
         if (i < NCH) {
           const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
-          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
           const v2i lo = *reinterpret_cast<const v2i*>(d), hi = *reinterpret_cast<const v2i*>(d + 8);
           outv[j] = v4i{(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
         }
@@ -2011,9 +2033,9 @@ __global__ __launch_bounds__(512) void block_chain_pp_kernel(const ChainArgs<NBL
   int pbegin, pcount;                                                       // contiguous range of item PAIRS
   item_range(a.n_samples * groups / 2, blockIdx.x, gridDim.x, pbegin, pcount);
 
-  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, GT>(xg, ltid);
-  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, GT>(xg + TILES, ltid);
-  zero_halo<C::TW, C::CIN, C::TILE_BYTES, C::G, GT>(tt, ltid);
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, GT>(xg, ltid);
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, GT>(xg + TILES, ltid);
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, GT>(tt, ltid);
 #pragma unroll
   for (int k = 0; k < NBLK; ++k) {
     load_bias<C::COUT, 512>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
@@ -2045,7 +2067,7 @@ __global__ __launch_bounds__(512) void block_chain_pp_kernel(const ChainArgs<NBL
         const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
         const bool ok = img0 + g < a.B;
         const v4i v = pre[j];
-        uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+        uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
         *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
         *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
       }
@@ -2061,7 +2083,7 @@ __global__ __launch_bounds__(512) void block_chain_pp_kernel(const ChainArgs<NBL
       if (i < NCH) {
         const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
         if (img0 + g < a.B) {
-          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::CIN + within * 16;
+          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
           const v2i lo = *reinterpret_cast<const v2i*>(d), hi = *reinterpret_cast<const v2i*>(d + 8);
           v4i v = {(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
           *reinterpret_cast<v4i*>(ys + ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16) = v;
@@ -2107,7 +2129,7 @@ __global__ __launch_bounds__(512) void block_chain_pp_kernel(const ChainArgs<NBL
       conv_mfma_phase<C>(X, wl + (2 * blk) * WB, A, lw, lane);
       if (blk == 0 && k > 0) store_tile(Xo, item_of(k - 1));
     } else if (q == 1) {
-      EpiTile<C::HO, C::COUT, C::TILE_BYTES> epi{tt, bp.a};
+      EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{tt, bp.a};
       conv_epi_phase<C, decltype(epi)>(bias_lds + (2 * blk) * C::COUT, bp.a, epi, A, lw, lane);
       if (blk == 0 && k + 1 < pcount) {
         write_tile(Xo, item_of(k + 1));
@@ -2116,7 +2138,7 @@ __global__ __launch_bounds__(512) void block_chain_pp_kernel(const ChainArgs<NBL
     } else if (q == 2) {
       conv_mfma_phase<C>(tt, wl + (2 * blk + 1) * WB, A, lw, lane);
     } else {
-      EpiTileResInPlace<C::HO, C::COUT, C::TILE_BYTES> epi{X, bp.b, bp.add};
+      EpiTileResInPlace<C::HO, C::PIXB, C::TILE_BYTES> epi{X, bp.b, bp.add};
       conv_epi_phase<C, decltype(epi)>(bias_lds + (2 * blk + 1) * C::COUT, bp.b, epi, A, lw, lane);
     }
   }
@@ -2198,8 +2220,8 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
     count = begin < n_items ? (n_items - begin + step - 1) / step : 0;
   }
 
-  zero_halo<CA::TW, CA::CIN, CA::TILE_BYTES, CA::G, BLK_THREADS>(xt, tid);
-  zero_halo<CB::TW, CB::CIN, CB::TILE_BYTES, CB::G, BLK_THREADS>(tt, tid);
+  zero_halo<CA::TW, CA::PIXB, CA::TILE_BYTES, CA::G, BLK_THREADS>(xt, tid);
+  zero_halo<CB::TW, CB::PIXB, CB::TILE_BYTES, CB::G, BLK_THREADS>(tt, tid);
   load_bias<COUT, BLK_THREADS>(bias_lds, a.s.bias, tid);
   load_bias<COUT, BLK_THREADS>(bias_lds + COUT, a.a.bias, tid);
   load_bias<COUT, BLK_THREADS>(bias_lds + 2 * COUT, a.b.bias, tid);
@@ -2228,7 +2250,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
         const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
         const bool ok = img0 + g < a.B;
         const v4i v = pre[j];
-        uint8_t* d = xt + g * CA::TILE_BYTES + (row + 1) * CA::PITCH + CA::CIN + within * 16;
+        uint8_t* d = xt + g * CA::TILE_BYTES + (row + 1) * CA::PITCH + CA::row_chunk_off(within);
         *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
         *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
       }
@@ -2258,7 +2280,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
       else conv_passes<CS, decltype(epi), BLK_WAVES>(xt, a.s.w + (int64_t)s * a.s.w_ss, bias_lds, a.s, epi, wave, lane);
     }
     {
-      EpiTile<CB::HIN, CB::CIN, CB::TILE_BYTES> epi{tt, a.a};
+      EpiTile<CB::HIN, CB::PIXB, CB::TILE_BYTES> epi{tt, a.a};
       if constexpr (LDSW) conv_core<CA, decltype(epi), BLK_WAVES>(xt, wl_a, bias_lds + COUT, a.a, epi, wave, lane);
       else conv_passes<CA, decltype(epi), BLK_WAVES>(xt, a.a.w + (int64_t)s * a.a.w_ss, bias_lds + COUT, a.a, epi, wave, lane);
     }
@@ -2297,9 +2319,9 @@ static int launch_block_down_ws(const DownArgs& a, hipStream_t st) {
 //                          CIN COUT K  S  HIN HALO G  MB NB
 using Blk_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;
 using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;
-using Blk_96  = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3>;
+using Blk_96  = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, true, 36, 16>;
 using PP_48   = ConvCfg<48, 48, 3, 1, 16, 1, 1, 2, 2>;          // per wave group of the ping-pong kernel
-using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
+using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false, 36, 16>;
 
 template <int NBLK>
 static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
