@@ -1600,6 +1600,10 @@ static int launch_block_down(const DownArgs& a, hipStream_t st) {
 }
 
 template <class CA, class CS, class CB, bool LDSW> static int launch_block_down_ws(const DownArgs& a, hipStream_t st);
+static bool no_dense() {
+  static const bool v = [] { const char* e = getenv("QBNN_NO_DENSE"); return e && e[0] == '1'; }();
+  return v;
+}
 static bool no_aliased() {
   static const bool v = [] { const char* e = getenv("QBNN_NO_ALIASED"); return e && e[0] == '1'; }();
   return v;
@@ -1755,14 +1759,6 @@ __device__ __forceinline__ void conv_epi_phase_with(const float* bias_lds, const
                                                     ResFn resfn, AheadFn ahead) {
   const int r = lane & 31, h = lane >> 5;
   const int mblk = pass / C::NBLKS, nblk = pass - mblk * C::NBLKS;
-  float4 b4[C::NB][4];
-#pragma unroll
-  for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
-      b4[nb][g4] = *reinterpret_cast<const float4*>(bias_lds + (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
-    }
 #pragma unroll
   for (int mb = 0; mb < C::MB; ++mb) {
     int R;
@@ -1778,6 +1774,12 @@ __device__ __forceinline__ void conv_epi_phase_with(const float* bias_lds, const
     ahead(mb);
 #pragma unroll
     for (int nb = 0; nb < C::NB; ++nb) {
+      float4 b4[4];             // (per n-tile: the whole table in registers costs 16 NB VGPRs through the epilogue)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
+        b4[g4] = *reinterpret_cast<const float4*>(bias_lds + (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
+      }
       uint32_t pre[4];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -1788,7 +1790,7 @@ __device__ __forceinline__ void conv_epi_phase_with(const float* bias_lds, const
       for (int g4 = 0; g4 < 4; ++g4) {
         if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
         const int c0 = (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h;
-        const float4 bb = b4[nb][g4];
+        const float4 bb = b4[g4];
         const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(A.acc[mb][nb][4 * g4 + 0] - zwr)) * p.mult;
         const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(A.acc[mb][nb][4 * g4 + 1] - zwr)) * p.mult;
         const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(A.acc[mb][nb][4 * g4 + 2] - zwr)) * p.mult;
@@ -2433,6 +2435,291 @@ static int launch_block_chain_al(const ChainArgs<1>& a, hipStream_t st) {
   return check_launch("qbnn_block_chain_i8_mc");
 }
 
+// =====================================================================================
+// Dense-tile variant of the aliased wide kernel.  With the 1-pixel halo an 8x8 / 4x4 map costs 1.56x / 2.25x its size
+// in LDS; stored dense ([image][oh][ow][C + 16]) twice as many images fit next to the weight ring (8 at 96 channels,
+// 16 at 192), which doubles the MFMA work per weight slab (the slab's LDS-DMA latency hides behind it) and halves the
+// weight bytes moved per image.  Zero padding is then a per-lane address choice: a tap that falls outside the map
+// reads a line of zeros instead.  The tap's position is a function of the slab / k-step only, so this costs a few
+// VALU operations per slab.
+// =====================================================================================
+template <class C> struct DenseTile {
+  static constexpr int IMG = C::HO * C::HO * C::PIXB;
+  static constexpr int BYTES = C::G * IMG;                  // followed by the zero line (C::PIXB bytes)
+  static constexpr int TPS = C::SLK / C::SPT;               // taps per weight slab
+  static_assert(C::PADB > 0 && C::SLK % C::SPT == 0 && C::STRIDE == 1 && C::KSZ == 3, "slabs are whole taps");
+};
+
+template <class C, int NWV, class FNext>
+__device__ __forceinline__ void conv_ring_mfma_dense(const uint8_t* tile, uint8_t* rbase, int& rcur, const int8_t* wq, ConvAcc<C>& A,
+                                                     int wave, int lane, FNext prefetch_next) {
+  static_assert(C::NPASS == NWV, "one pass per wave");
+  using DT = DenseTile<C>;
+  const int r = lane & 31, h = lane >> 5;
+  const int mblk = wave / C::NBLKS, nblk = wave - mblk * C::NBLKS;
+  int pix0[C::MB], poh[C::MB], pow_[C::MB];               // this lane's pixel per M-tile: byte offset, row, column
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb) {
+    const int m = (mblk * C::MB + mb) * 32 + r;
+    const int rem = m % (C::HO * C::HO);
+    poh[mb] = rem / C::HO; pow_[mb] = rem % C::HO;
+    pix0[mb] = m * C::PIXB + 16 * h;
+  }
+  const uint8_t* zline = tile + DT::BYTES + 16 * h;
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb) {
+    A.rsum[mb] = 0;
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) A.acc[mb][nb][i] = 0;
+  }
+  struct Frags { v4i w[C::NB]; v4i x[C::MB]; };              // one k-step per buffer
+  QBNN_INNER_T0();
+#pragma unroll 1
+  for (int slab = 0; slab < C::NSLAB; ++slab) {
+    dma_barrier();            // slab landed; everyone is done with the other buffer; slab 0: tile complete
+    QBNN_INNER_AT(0);
+    uint8_t* other = rbase + (rcur ^ 1) * C::SLAB_BYTES;
+    if (slab + 1 < C::NSLAB) dma_slab<C, NWV>(other, wq, slab + 1, wave, lane);
+    else prefetch_next(other);
+    const uint8_t* wl = rbase + rcur * C::SLAB_BYTES + ((nblk * C::NB) * C::SLK * 64 + lane) * 16;
+    rcur ^= 1;
+    const uint8_t* tb[C::MB][DT::TPS];
+#pragma unroll
+    for (int tp = 0; tp < DT::TPS; ++tp) {
+      const int tap = slab * DT::TPS + tp, kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) {
+        const bool ok = (unsigned)(poh[mb] + kh - 1) < (unsigned)C::HO && (unsigned)(pow_[mb] + kw - 1) < (unsigned)C::HO;
+        tb[mb][tp] = ok ? tile + pix0[mb] + ((kh - 1) * C::HO + (kw - 1)) * C::PIXB : zline;
+      }
+    }
+    auto load_step = [&](Frags& f, int j) {
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb) f.w[nb] = *reinterpret_cast<const v4i*>(wl + (nb * C::SLK + j) * 1024);
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) f.x[mb] = load_xfrag<C>(tb[mb][j / C::SPT] + (j % C::SPT) * 32);
+    };
+    auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) {
+        int rs_ = A.rsum[mb];
+        rs_ = __builtin_amdgcn_sdot4(f.x[mb].x, 0x01010101, rs_, false);
+        rs_ = __builtin_amdgcn_sdot4(f.x[mb].y, 0x01010101, rs_, false);
+        rs_ = __builtin_amdgcn_sdot4(f.x[mb].z, 0x01010101, rs_, false);
+        rs_ = __builtin_amdgcn_sdot4(f.x[mb].w, 0x01010101, rs_, false);
+        A.rsum[mb] = rs_;
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+          A.acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[nb], f.x[mb], A.acc[mb][nb], 0, 0, 0);
+      }
+    };
+    Frags f0, f1;
+    load_step(f0, 0);
+#pragma unroll
+    for (int j = 0; j < C::SLK; ++j) {
+      Frags& cur = (j & 1) ? f1 : f0;
+      Frags& nxt = (j & 1) ? f0 : f1;
+      if (j + 1 < C::SLK) load_step(nxt, j + 1);
+      mfma_step(cur);
+    }
+    QBNN_INNER_AT(1);
+  }
+  QBNN_INNER_FLUSH();
+}
+
+// dense-tile epilogues: (b') centred stem.0 output, (c') Add(residual from global) + ReLU, centred block output
+template <int PIXB>
+struct EpiDenseTile {
+  uint8_t* dst; QConv p;
+  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
+    const float mg = QBNN_MAGIC;
+    *reinterpret_cast<uint32_t*>(dst + po + c0) =
+        pack_low_bytes(med3f(v0, p.vlo, p.vhi) + mg, med3f(v1, p.vlo, p.vhi) + mg, med3f(v2, p.vlo, p.vhi) + mg, med3f(v3, p.vlo, p.vhi) + mg);
+  }
+};
+template <int PIXB, int CCH>
+struct EpiDenseTileResGlobal {
+  uint8_t* xt; const uint8_t* res; int n_valid_px; QConv p; QAdd a;
+  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
+  __device__ __forceinline__ uint32_t load_px(int m, int c0) const {
+    return m < n_valid_px ? *reinterpret_cast<const uint32_t*>(res + (int64_t)m * CCH + c0) : 0u;
+  }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
+    const float zy = (float)p.z_y;
+    const float vv[4] = {v0, v1, v2, v3};
+    const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float qf = __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)) + zy;
+      const float da = __builtin_fmaf(p.s_y, qf, p.nzs_y);
+      const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
+      t[i] = med3f((da + db) * a.inv_s_o, 0.0f, a.vhi) + QBNN_MAGIC;
+    }
+    *reinterpret_cast<uint32_t*>(xt + po + c0) = pack_low_bytes(t[0], t[1], t[2], t[3]);
+  }
+};
+
+// NWV = 8: two waves per SIMD, 256 VGPRs each (MB x NB = 2 x 3 tiles per wave).  (NWV = 4, one wave per SIMD with
+// 4 x 3 tiles in the 512-register file, was measured 25 % slower: the epilogues then read their accumulators out of
+// AGPRs and a lone wave per SIMD hides neither the LDS nor the VALU latencies.)
+template <class C, int NWV>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 4, NWV / 4)))
+void block_chain_ald_kernel(const ChainArgs<1> a) {
+  static_assert(C::CIN == C::COUT && C::CIN % 32 == 0, "wide identity BasicBlock");
+  using DT = DenseTile<C>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int NTHR = 64 * NWV;
+  uint8_t* xt = smem;                                                        // dense tile + zero line
+  uint8_t* rbase = smem + DT::BYTES + C::PIXB;                               // two weight slabs
+  static_assert((DT::BYTES + C::PIXB) % 16 == 0, "ring alignment");
+  int rcur = 0;
+  float* bias_lds = reinterpret_cast<float*>(rbase + 2 * C::SLAB_BYTES);     // [2][COUT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const BlockParams& bp = a.blk[0];
+
+  constexpr int IMG_PX = C::HO * C::HO;
+  constexpr int CPP = C::CIN / 16;                                           // 16-byte chunks per pixel
+  constexpr int NCH = C::G * IMG_PX * CPP;
+  constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
+  const int groups = (a.B + C::G - 1) / C::G;
+  const int n_items = a.n_samples * groups;
+  const int step = gridDim.x;                       // interleaved walk: all workgroups on the same sample -> weights L2-hot
+  const int count = (int)blockIdx.x < n_items ? (n_items - (int)blockIdx.x + step - 1) / step : 0;
+
+  for (int i = tid; i < C::PIXB / 4; i += NTHR) reinterpret_cast<uint32_t*>(xt + DT::BYTES)[i] = 0u;
+  load_bias<C::COUT, NTHR>(bias_lds, bp.a.bias, tid);
+  load_bias<C::COUT, NTHR>(bias_lds + C::COUT, bp.b.bias, tid);
+  if (count <= 0) return;
+
+  // an item's images are contiguous in HBM: chunk i of the item is byte 16 i of that block
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_PX * C::CIN;
+    const int valid = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX * CPP;
+    int t = tid;
+    asm volatile("" : "+v"(t));         // per-thread addresses are recomputed here, not hoisted out of the item loop (spills)
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = t + j * NTHR;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + (i < valid ? (int64_t)i * 16 : 0));
+    }
+  };
+  auto write_tile = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const int valid = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX * CPP;
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+    int t = tid;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = t + j * NTHR;
+      if (i < NCH) {
+        const int px = i / CPP, within = i - px * CPP;
+        const v4i v = pre[j];
+        *reinterpret_cast<v4i*>(xt + px * C::PIXB + within * 16) =
+            i < valid ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v4i{0, 0, 0, 0};
+      }
+    }
+  };
+  auto wbase = [&](const QConv& q, int item) { return q.w + (int64_t)(item / groups) * q.w_ss; };
+
+  fetch(blockIdx.x);
+  write_tile(blockIdx.x);
+  dma_slab<C, NWV>(rbase, wbase(bp.a, blockIdx.x), 0, wave, lane);
+  ConvAcc<C> A;
+  QBNN_STAMP_DECL
+  for (int it = 0; it < count; ++it) {
+    QBNN_STAMP_START();
+    const int item = blockIdx.x + it * step;
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const bool more = it + 1 < count;
+    const int next = more ? item + step : item;
+    // ---- stem.0: M over the X tile, then T over it
+    conv_ring_mfma_dense<C, NWV>(xt, rbase, rcur, wbase(bp.a, item), A, wave, lane,
+                            [&](uint8_t* dst) { dma_slab<C, NWV>(dst, wbase(bp.b, item), 0, wave, lane); });
+    QBNN_STAMP_AT(0);
+    lds_barrier();                                       // every wave has read its last X fragment
+    QBNN_STAMP_AT(1);
+    {
+      EpiDenseTile<C::PIXB> epi{xt, bp.a};
+      conv_epi_phase<C, decltype(epi)>(bias_lds, bp.a, epi, A, wave, lane);
+    }
+    QBNN_STAMP_AT(2);
+    // ---- stem.3: M over T; residual and next input are requested during the last slab
+    const int valid_px = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX;
+    EpiDenseTileResGlobal<C::PIXB, C::COUT> epi_b{xt, a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_PX * C::COUT, valid_px, bp.b, bp.add};
+    uint32_t resq[2][C::NB][4];
+    auto load_res = [&](int mb) {
+      const int mblk = wave / C::NBLKS, nblk = wave - mblk * C::NBLKS;
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          resq[mb & 1][nb][g4] = epi_b.load_px((mblk * C::MB + mb) * 32 + (lane & 31), (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * (lane >> 5));
+    };
+    conv_ring_mfma_dense<C, NWV>(xt, rbase, rcur, wbase(bp.b, item), A, wave, lane,
+                            [&](uint8_t* dst) { if (more) dma_slab<C, NWV>(dst, wbase(bp.a, next), 0, wave, lane); load_res(0); fetch(next); });
+    QBNN_STAMP_AT(3);
+    lds_barrier();
+    QBNN_STAMP_AT(4);
+    conv_epi_phase_with<C, decltype(epi_b)>(bias_lds + C::COUT, bp.b, epi_b, A, wave, lane,
+                                            [&](int mb, int nb, int g4, int, int) { return resq[mb & 1][nb][g4]; },
+                                            [&](int mb) { if (mb + 1 < C::MB) load_res(mb + 1); });
+    QBNN_STAMP_AT(5);
+    lds_barrier();
+    QBNN_STAMP_AT(6);
+    // ---- per 16-byte chunk: tile -> quint8 register, next item's input -> the same tile bytes, register -> HBM (the
+    //      item's output block is contiguous).  The next input is written unconditionally (the last item rewrites
+    //      itself): a prefetch left unconsumed on one path makes the compiler guard later reuses with vmcnt(0).
+    {
+      const uint32_t z4o = (uint32_t)bp.add.z_o * 0x01010101u, z4i = (uint32_t)a.z_in * 0x01010101u;
+      uint8_t* ys = a.y + (int64_t)s * a.y_ss + (int64_t)img0 * IMG_PX * C::COUT;
+      const int valid = valid_px * CPP;
+      const int nimg0 = (next - (next / groups) * groups) * C::G;
+      const int nvalid = (a.B - nimg0 < C::G ? a.B - nimg0 : C::G) * IMG_PX * CPP;
+      int t = tid;
+      asm volatile("" : "+v"(t));
+#pragma unroll
+      for (int j = 0; j < PER_T; ++j) {
+        const int i = t + j * NTHR;
+        if (i < NCH) {
+          const int px = i / CPP, within = i - px * CPP;
+          v4i* cell = reinterpret_cast<v4i*>(xt + px * C::PIXB + within * 16);
+          const v4i v = *cell, n = pre[j];
+          *cell = i < nvalid ? v4i{(int)sub_bytes(n.x, z4i), (int)sub_bytes(n.y, z4i), (int)sub_bytes(n.z, z4i), (int)sub_bytes(n.w, z4i)} : v4i{0, 0, 0, 0};
+          if (i < valid)
+            *reinterpret_cast<v4i*>(ys + (int64_t)i * 16) = v4i{(int)add_bytes(v.x, z4o), (int)add_bytes(v.y, z4o), (int)add_bytes(v.z, z4o), (int)add_bytes(v.w, z4o)};
+        }
+      }
+    }
+    QBNN_STAMP_AT(7);
+  }
+#ifdef QBNN_STAMP
+  if (a.dbg && (tid & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(a.dbg + wave * 8 + i, st_acc[i]);
+#endif
+}
+
+template <class C, int NWV>
+static int launch_block_chain_ald(const ChainArgs<1>& a, hipStream_t st) {
+  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)block_chain_ald_kernel<C, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  const int groups = (a.B + C::G - 1) / C::G;
+  const int n_items = a.n_samples * groups;
+  const int grid = n_items < 256 ? n_items : 256;
+  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV>), dim3(grid), dim3(64 * NWV), LDS, st, a);
+  return check_launch("qbnn_block_chain_i8_mc");
+}
+
 template <class C, int NBLK, bool LDSW = true> constexpr int chain_ws_lds() {
   return 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + (LDSW ? 2 * NBLK * WConv<C>::BYTES : 0) + NBLK * 2 * C::COUT * 4;
 }
@@ -2592,8 +2879,14 @@ using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;
 using Blk_96  = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, true, 36, 16>;
 using AL_96   = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;     // aliased-tile ring kernel: 8 images / item
 using AL_192  = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, true, 36, 16>;
+using ALD_96  = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;      // dense-tile variant, 8 waves
+using ALD_192 = ConvCfg<192, 192, 3, 1, 4, 1, 16, 2, 3, true, 36, 16>;
 using PP_48   = ConvCfg<48, 48, 3, 1, 16, 1, 1, 2, 2>;          // per wave group of the ping-pong kernel
+#ifdef QBNN_EXP_NSPLIT
+using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 4, 1, false, 36, 16>;
+#else
 using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false, 36, 16>;
+#endif
 
 template <int NBLK>
 static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
@@ -2629,11 +2922,17 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
     return launch_chain_auto<Blk_48, NBLK>(a, st);
   }
   if (Cc == 96 && H == 8) {
-    if constexpr (NBLK == 1) { if (!ring_only() && !no_aliased()) return launch_block_chain_al<AL_96>(a, st); }
+    if constexpr (NBLK == 1) {
+      if (!ring_only() && !no_dense()) return launch_block_chain_ald<ALD_96, 8>(a, st);
+      if (!ring_only() && !no_aliased()) return launch_block_chain_al<AL_96>(a, st);
+    }
     return launch_block_chain<Blk_96, NBLK>(a, st);
   }
   if (Cc == 192 && H == 4) {
-    if constexpr (NBLK == 1) { if (!ring_only() && !no_aliased()) return launch_block_chain_al<AL_192>(a, st); }
+    if constexpr (NBLK == 1) {
+      if (!ring_only() && !no_dense()) return launch_block_chain_ald<ALD_192, 8>(a, st);
+      if (!ring_only() && !no_aliased()) return launch_block_chain_al<AL_192>(a, st);
+    }
     return ring_only() ? launch_block_chain<Blk_192, NBLK>(a, st) : launch_block_chain_ws<Blk_192, NBLK, false>(a, st);
   }
   return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
