@@ -223,6 +223,50 @@ int qbnn_linear_f32_mc(const float* x, int64_t x_sample_stride, const float* w, 
                        float* y, int64_t y_sample_stride, int32_t B, int32_t K, int32_t N, int32_t act, int32_t n_samples,
                        void* stream);
 
+/* ---- fp32 convolutional graphs (row a1: reference bbb/conv.py:33-39 eval branch, models_bbb.py:100-245) -------------- */
+
+/* Z_s = conv2d(X_s, W_s) (+ bias) (ReLU).  x [S|1][B][H][W][Cin] fp32 NHWC, w [S|1][Cout][Cin][k][k] in the REFERENCE's
+ * weight order (so qbnn_sample_weights_f32's noise index is the reference's element index), y [S][B][Ho][Wo][Cout].
+ * Replaces F.conv2d at bbb/conv.py:38 / conv_qat.py:47,158.  Sample strides in elements; 0 = shared. */
+int qbnn_conv2d_f32_mc(const float* x, int64_t x_sample_stride, const float* w, int64_t w_sample_stride, const float* bias, float* y,
+                       int64_t y_sample_stride, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                       int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream);
+
+/* Pointwise on [S][n] with the channel as fastest axis:  v = (mode 0) x * p0[c] + p1[c]  |  (mode 1) x / p0[c] + p1[c]
+ * (p0 / p1 NULL skip that step), v += res (if given), ReLU (if asked).  nn.BatchNorm2d in eval (x * alpha + beta as ATen
+ * computes it), the `Z / scale_factor + bias` of conv_qat.py:159-161, Add (src/utils.py:49-55), nn.ReLU. */
+int qbnn_affine_f32_mc(const float* x, int64_t x_sample_stride, const float* res, int64_t res_sample_stride, const float* p0,
+                       const float* p1, float* y, int64_t y_sample_stride, int64_t n, int32_t C, int32_t mode, int32_t relu,
+                       int32_t n_samples, void* stream);
+
+/* nn.MaxPool2d(k, k) (mode 0) / nn.AvgPool2d(k) (mode 1) on NHWC fp32. */
+int qbnn_pool2d_f32_mc(const float* x, int64_t x_sample_stride, float* y, int64_t y_sample_stride, int32_t B, int32_t H, int32_t W,
+                       int32_t C, int32_t k, int32_t mode, int32_t n_samples, void* stream);
+
+/* Flatten (src/utils.py:40-47) of an NHWC activation in NCHW order: y[s][b][c * HW + p] = x[s][b][p][c]. */
+int qbnn_flatten_nchw_f32_mc(const float* x, int64_t x_sample_stride, int32_t B, int32_t HW, int32_t C, float* y,
+                             int64_t y_sample_stride, int32_t n_samples, void* stream);
+
+/* F.softmax(dim=-1) on fp32 logits [S][B][N] -> probs [S][B][N]. */
+int qbnn_softmax_f32_mc(const float* x, int64_t x_sample_stride, int32_t B, int32_t N, float* probs, int32_t n_samples, void* stream);
+
+/* ---- QAT fake-quant evaluation with live observers (row a2: conv_qat.py:26-49,139-167, linear_qat.py:18-41) ---------- */
+
+#define QBNN_OBSERVER_BLOCKS 512        /* workspace: n_samples * QBNN_OBSERVER_BLOCKS * 2 floats */
+
+/* MovingAverageMinMaxObserver (averaging constant `avg_const`, active in eval) over the S samples IN ORDER, then
+ * calculate_qparams (per-tensor affine, quant range [qmin, qmax]):  state = {min, max, seen?} is read and written
+ * back; scale[s], zero_point[s] are the qparams fake-quant uses for sample s (observer update precedes the
+ * quantisation inside FakeQuantize.forward). */
+int qbnn_observe_f32_mc(const float* x, int64_t x_sample_stride, int64_t n, int32_t n_samples, float* state, float avg_const,
+                        int32_t qmin, int32_t qmax, float* workspace, float* scale, int32_t* zero_point, void* stream);
+
+/* fake_quantize_per_tensor_affine: y = (clamp(rne(x * (1/s)) + z, qmin, qmax) - z) * s with the qparams of sample s at
+ * index s * qparam_stride (stride 0 = one pair for all samples). */
+int qbnn_fake_quant_f32_mc(const float* x, int64_t x_sample_stride, float* y, int64_t y_sample_stride, int64_t n, const float* scale,
+                           const int32_t* zero_point, int32_t qparam_stride, int32_t qmin, int32_t qmax, int32_t n_samples,
+                           void* stream);
+
 /* Classification metrics of a [B][C] predictive mean against int64 targets (reference src/metrics.py: Error :8-33,
  * ClassificationNegativeLogLikelihood :36-62, BrierScore :65-91, PredictiveEntropy :94-116, 10-bin L1 calibration error
  * :381-383).  Writes ceil(B/256) rows of 34 partial sums (layout: csrc/qbnn_kernels.hip); the caller adds the rows. */

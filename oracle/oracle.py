@@ -564,3 +564,108 @@ class Int8MLPBBBOracle(_Int8BBBBase):
         mu = (qm.astype(np.float32) - np.float32(Lm.z_y)) * np.float32(Lm.s_y)
         lv = (qv.astype(np.float32) - np.float32(Lv.z_y)) * np.float32(Lv.s_y)
         return mu, np.exp(lv)
+
+
+# ------------------------------------------- fp32 convolutional BBB graphs (row a1) ---
+def _bn_eval(x, st, name, eps=1e-5):
+    """nn.BatchNorm2d eval as ATen evaluates it: alpha = weight / sqrt(var + eps), beta = bias - mean * alpha,
+    y = x * alpha + beta (fp32, two roundings).  x NHWC."""
+    g, b, rm, rv = (np.asarray(st[f"{name}.{k}"], np.float32) for k in ("weight", "bias", "running_mean", "running_var"))
+    invstd = (np.float32(1.0) / np.sqrt(rv + np.float32(eps))).astype(np.float32)
+    alpha = (g * invstd).astype(np.float32)
+    beta = (b - (rm * alpha).astype(np.float32)).astype(np.float32)
+    return ((x * alpha).astype(np.float32) + beta).astype(np.float32)
+
+
+def _pool_f32(x, k, avg):
+    B, H, W, C = x.shape
+    v = x.reshape(B, H // k, k, W // k, k, C)
+    if not avg:
+        return v.max(axis=(2, 4))
+    acc = np.zeros((B, H // k, W // k, C), np.float32)
+    for dh in range(k):                     # same summation order as the kernel / ATen's avg_pool2d
+        for dw in range(k):
+            acc = (acc + v[:, :, dh, :, dw, :]).astype(np.float32)
+    return (acc / np.float32(k * k)).astype(np.float32)
+
+
+def _softmax_f32(z):
+    z = z.astype(np.float32)
+    e = np.exp(z - z.max(-1, keepdims=True)).astype(np.float32)
+    return (e / e.sum(-1, keepdims=True, dtype=np.float32)).astype(np.float32)
+
+
+class F32ConvOracle:
+    """Float `conv_lenet_bbb` / `conv_resnet_bbb`, eval branch: reference bbb/conv.py:33-39, bbb/linear.py:42-50 per
+    layer, graphs models_bbb.py:100-133 and :191-245.  fp32 with fp64 accumulation inside conv / matmul."""
+
+    def __init__(self, state):
+        self.st = state
+
+    def conv(self, name, lid, x, seed, sample, stride, pad):
+        mu, rho = (np.asarray(self.st[name + k], np.float32) for k in (".weight", ".std"))
+        eps = fill_normal(mu.size, seed, lid, sample).reshape(mu.shape)
+        w = sample_weights_f32(mu, softplus(rho), eps)                        # [Cout, Cin, KH, KW]
+        return conv2d_f32(x, np.ascontiguousarray(w.transpose(0, 2, 3, 1)), None, stride, pad)
+
+    def linear(self, name, lid, x, seed, sample, relu):
+        mu, rho = (np.asarray(self.st[name + k], np.float32) for k in (".weight", ".std"))
+        eps = fill_normal(mu.size, seed, lid, sample).reshape(mu.shape)
+        w = sample_weights_f32(mu, softplus(rho), eps)
+        y = (x.astype(np.float64) @ w.astype(np.float64).T).astype(np.float32)
+        return np.maximum(y, 0) if relu else y
+
+    def lenet(self, x_nchw, seed, sample):
+        h = np.ascontiguousarray(np.asarray(x_nchw, np.float32).transpose(0, 2, 3, 1))
+        h = _pool_f32(self.conv("layers.0", 0, h, seed, sample, 1, 2), 2, False)
+        h = _pool_f32(self.conv("layers.2", 1, h, seed, sample, 1, 2), 2, False)
+        h = np.ascontiguousarray(h.transpose(0, 3, 1, 2)).reshape(h.shape[0], -1)
+        h = self.linear("layers.5", 2, h, seed, sample, True)
+        return _softmax_f32(self.linear("layers.7", 3, h, seed, sample, False))
+
+    def resnet(self, x_nchw, seed, sample):
+        h = np.ascontiguousarray(np.asarray(x_nchw, np.float32).transpose(0, 2, 3, 1))
+        lid = 0
+        h = np.maximum(_bn_eval(self.conv("layers.0", lid, h, seed, sample, 1, 1), self.st, "layers.1"), 0); lid += 1
+        inp = 24
+        for li, planes, stride in ((3, 24, 1), (4, 48, 2), (5, 96, 2), (6, 192, 2)):
+            for bi, st in enumerate((stride, 1)):
+                p = f"layers.{li}.{bi}"
+                out = np.maximum(_bn_eval(self.conv(p + ".stem.0", lid, h, seed, sample, st, 1), self.st, p + ".stem.1"), 0); lid += 1
+                out = _bn_eval(self.conv(p + ".stem.3", lid, out, seed, sample, 1, 1), self.st, p + ".stem.4"); lid += 1
+                sc = h
+                if st != 1 or inp != planes:
+                    sc = _bn_eval(self.conv(p + ".shortcut.0", lid, h, seed, sample, st, 0), self.st, p + ".shortcut.1"); lid += 1
+                h = np.maximum((out + sc).astype(np.float32), 0)
+                inp = planes
+        h = _pool_f32(h, 4, True).reshape(h.shape[0], -1)
+        return _softmax_f32(self.linear("layers.9", lid, h, seed, sample, False))
+
+
+# --------------------------------- QAT fake-quant evaluation with live observers (row a2) ---
+class EmaObserver:
+    """MovingAverageMinMaxObserver (averaging_constant 0.01) + calculate_qparams, per-tensor affine, fp32 arithmetic
+    (torch/ao/quantization/observer.py); `state` = (min, max) or None before the first batch."""
+
+    def __init__(self, qmin, qmax, state=None, c=0.01):
+        self.qmin, self.qmax, self.c = int(qmin), int(qmax), np.float32(c)
+        self.state = None if state is None else (np.float32(state[0]), np.float32(state[1]))
+
+    def update(self, x):
+        mn, mx = np.float32(x.min()), np.float32(x.max())
+        if self.state is None:
+            self.state = (mn, mx)
+        else:
+            a, b = self.state
+            self.state = (np.float32(a + self.c * np.float32(mn - a)), np.float32(b + self.c * np.float32(mx - b)))
+        lo, hi = min(self.state[0], np.float32(0)), max(self.state[1], np.float32(0))
+        scale = max(np.float32(np.float32(hi - lo) / np.float32(self.qmax - self.qmin)), np.float32(1.1920928955078125e-07))
+        zp = int(np.clip(self.qmin - np.rint(np.float32(lo / scale)), self.qmin, self.qmax))
+        return np.float32(scale), zp
+
+    def fake_quant(self, x):
+        """FakeQuantize.forward: observer update, then fake_quantize_per_tensor_affine with the fresh qparams."""
+        s, z = self.update(x)
+        inv = np.float32(1.0) / s
+        q = np.clip(np.rint((np.asarray(x, np.float32) * inv).astype(np.float32)) + np.float32(z), self.qmin, self.qmax)
+        return ((q - np.float32(z)).astype(np.float32) * s).astype(np.float32)

@@ -1,0 +1,7 @@
+// Shared by the translation units of libqbnn_hip.so: error reporting behind qbnn_last_error().
+#ifndef QBNN_COMMON_H_
+#define QBNN_COMMON_H_
+#define QBNN_EXPORT extern "C" __attribute__((visibility("default")))
+int qbnn_fail_msg(int code, const char* msg);       // records msg for qbnn_last_error(), returns code
+int qbnn_check_launch_msg(const char* what);        // hipGetLastError() -> QBNN_OK / QBNN_E_LAUNCH
+#endif

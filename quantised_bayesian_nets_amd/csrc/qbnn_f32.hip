@@ -1,0 +1,330 @@
+// libqbnn_hip.so, second translation unit: the fp32 side of the path.
+//   a1: float Bayes-by-backprop convolution, eval branch (reference bbb/conv.py:33-39): per-MC-sample weights
+//       W_s = mu + eps_s * softplus(rho) (qbnn_sample_weights_f32), Z_s = conv2d(X_s, W_s); BatchNorm (eval), ReLU, Add,
+//       pooling, flatten, softmax of the float graphs (models_bbb.py:100-245).
+//   a2: QAT fake-quant evaluation with LIVE observers (reference quantized/conv_qat.py:26-49,139-167,
+//       linear_qat.py:18-41): MovingAverageMinMax observer update + fake_quantize_per_tensor_affine around every
+//       tensor.  The observers' EMA makes sample s depend on samples < s only through two scalars per observer,
+//       so all S samples are still evaluated layer by layer in one pass: per-sample min/max (parallel), the EMA
+//       recurrence over S scalars on the device (qbnn_observer_scan), fake-quant with per-sample (scale, zero point).
+// fp32 accumulation order differs from the reference's mkldnn kernels; the tolerance is stated in the tests.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/qbnn.h"
+#include "qbnn_common.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// =====================================================================================
+// conv2d, fp32, per-sample weights.  Implicit GEMM on v_mfma_f32_32x32x2f32 (exact fp32 fma chain per output):
+//   workgroup = 4 waves = 64 output pixels x 64 output channels; wave (wm, wn) owns a 32 x 32 sub-tile
+//   (A operand = weights: lane l holds W[n = l & 31][k = l >> 5];  B operand = pixels: lane l holds X[p = l & 31][k]).
+//   K = KH * KW * Cin is walked in chunks of 16 staged through LDS; the gather (im2col on the fly, zero padding,
+//   reference weight order [Cout][Cin][KH][KW]) costs index arithmetic per element -- this kernel serves every
+//   geometry of the float graphs, it is not the tuned int8 path.
+// =====================================================================================
+struct ConvF32Args {
+  const float* x; int64_t x_ss;      // [S|1][B][H][W][Cin] (NHWC)
+  const float* w; int64_t w_ss;      // [S|1][Cout][Cin][KH][KW]
+  const float* bias;                 // [Cout] or null
+  float* y; int64_t y_ss;            // [S][B][Ho][Wo][Cout]
+  int B, H, W, Cin, Cout, KS, stride, pad, Ho, Wo, relu;
+};
+
+constexpr int CF_KC = 16, CF_LD = CF_KC + 1;
+
+__global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvF32Args a) {
+  __shared__ float As[64 * CF_LD];     // weights  [n][k]
+  __shared__ float Bs[64 * CF_LD];     // pixels   [p][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;           // pixel half, channel half
+  const int s = blockIdx.z;
+  const int p0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int npix = a.B * a.Ho * a.Wo;
+  const int K = a.KS * a.KS * a.Cin;
+  const float* xs = a.x + (int64_t)s * a.x_ss;
+  const float* ws = a.w + (int64_t)s * a.w_ss;
+
+  // this thread's 4 gather slots per operand and chunk: element e = tid + 256 j -> (row = e / 16, kk = e % 16)
+  int prow[4], pb[4], poh[4], pow_[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 256 * j, row = e >> 4;
+    const int p = p0 + row;
+    prow[j] = row;
+    if (p < npix) { pb[j] = p / (a.Ho * a.Wo); const int rem = p - pb[j] * a.Ho * a.Wo; poh[j] = rem / a.Wo; pow_[j] = rem - poh[j] * a.Wo; }
+    else { pb[j] = -1; poh[j] = 0; pow_[j] = 0; }
+  }
+  v16f acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += CF_KC) {
+    const int kk = k0 + (tid & 15);                    // same k column for all 4 slots of this thread
+    int kh = 0, kw = 0, c = 0;
+    const bool kok = kk < K;
+    if (kok) { kh = kk / (a.KS * a.Cin); const int r2 = kk - kh * a.KS * a.Cin; kw = r2 / a.Cin; c = r2 - kw * a.Cin; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = prow[j];
+      // pixels
+      float xv = 0.f;
+      if (kok && pb[j] >= 0) {
+        const int ih = poh[j] * a.stride - a.pad + kh, iw = pow_[j] * a.stride - a.pad + kw;
+        if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+          xv = xs[(((int64_t)pb[j] * a.H + ih) * a.W + iw) * a.Cin + c];
+      }
+      Bs[row * CF_LD + (tid & 15)] = xv;
+      // weights
+      float wv = 0.f;
+      const int n = n0 + row;
+      if (kok && n < a.Cout) wv = ws[(((int64_t)n * a.Cin + c) * a.KS + kh) * a.KS + kw];
+      As[row * CF_LD + (tid & 15)] = wv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < CF_KC / 2; ++k2) {
+      const float av = As[(wn * 32 + (lane & 31)) * CF_LD + 2 * k2 + (lane >> 5)];
+      const float bv = Bs[(wm * 32 + (lane & 31)) * CF_LD + 2 * k2 + (lane >> 5)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[i = channel][j = pixel]: lane owns pixel j = lane & 31, register r holds channel 8 (r / 4) + 4 (lane >> 5) + r % 4
+  const int p = p0 + wm * 32 + (lane & 31);
+  if (p >= npix) return;
+  float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)p * a.Cout;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 32 + 8 * g + 4 * (lane >> 5) + i;
+      if (n < a.Cout) {
+        float v = acc[4 * g + i];
+        if (a.bias) v = v + a.bias[n];
+        if (a.relu) v = fmaxf(v, 0.f);
+        yp[n] = v;
+      }
+    }
+}
+
+QBNN_EXPORT int qbnn_conv2d_f32_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* bias, float* y,
+                                   int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                   int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || n_samples <= 0)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: bad argument");
+  ConvF32Args a;
+  a.x = x; a.x_ss = x_ss; a.w = w; a.w_ss = w_ss; a.bias = bias; a.y = y; a.y_ss = y_ss;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = ksize; a.stride = stride; a.pad = pad; a.relu = relu;
+  a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
+  if (a.Ho <= 0 || a.Wo <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: empty output");
+  const int64_t npix = (int64_t)B * a.Ho * a.Wo;
+  dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)n_samples);
+  hipLaunchKernelGGL(conv2d_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return qbnn_check_launch_msg("qbnn_conv2d_f32_mc");
+}
+
+// =====================================================================================
+// Pointwise: per-channel affine (BatchNorm eval as ATen computes it: x * alpha + beta, two roundings;
+// QAT conv-bn:  Z / c + b), optional second operand (Add), optional ReLU.  Channels are the fastest axis (NHWC).
+//   mode 0: v = x * p0[c] + p1[c]     mode 1: v = x / p0[c] + p1[c]     (p0 / p1 null = skip that step)
+//   then v += res (if given), then ReLU (if asked)
+// =====================================================================================
+__global__ __launch_bounds__(256) void affine_f32_kernel(const float* __restrict__ x, int64_t x_ss, const float* __restrict__ res,
+                                                          int64_t res_ss, const float* __restrict__ p0, const float* __restrict__ p1,
+                                                          float* __restrict__ y, int64_t y_ss, int64_t n, int C, int mode, int relu) {
+  const int s = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    float v = x[(int64_t)s * x_ss + i];
+    if (p0) v = mode == 0 ? v * p0[c] : v / p0[c];
+    if (p1) v = v + p1[c];
+    if (res) v = v + res[(int64_t)s * res_ss + i];
+    if (relu) v = fmaxf(v, 0.f);
+    y[(int64_t)s * y_ss + i] = v;
+  }
+}
+
+QBNN_EXPORT int qbnn_affine_f32_mc(const float* x, int64_t x_ss, const float* res, int64_t res_ss, const float* p0, const float* p1,
+                                   float* y, int64_t y_ss, int64_t n, int32_t C, int32_t mode, int32_t relu, int32_t n_samples,
+                                   void* stream) {
+  if (!x || !y || n <= 0 || C <= 0 || n_samples <= 0 || mode < 0 || mode > 1)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_affine_f32_mc: bad argument");
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(affine_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, res, res_ss, p0, p1, y,
+                     y_ss, n, C, mode, relu);
+  return qbnn_check_launch_msg("qbnn_affine_f32_mc");
+}
+
+// ---- pooling (NHWC, kernel = stride = k, no padding): mode 0 max (nn.MaxPool2d), 1 average (nn.AvgPool2d) ----------
+__global__ __launch_bounds__(256) void pool2d_f32_kernel(const float* __restrict__ x, int64_t x_ss, float* __restrict__ y,
+                                                          int64_t y_ss, int B, int H, int W, int C, int k, int mode) {
+  const int Ho = H / k, Wo = W / k;
+  const int64_t n = (int64_t)B * Ho * Wo * C;
+  const int s = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float m = mode == 0 ? -INFINITY : 0.f;
+    for (int dh = 0; dh < k; ++dh)
+      for (int dw = 0; dw < k; ++dw) {
+        const float v = x[(int64_t)s * x_ss + (((int64_t)b * H + oh * k + dh) * W + ow * k + dw) * C + c];
+        m = mode == 0 ? fmaxf(m, v) : m + v;
+      }
+    y[(int64_t)s * y_ss + i] = mode == 0 ? m : m / (float)(k * k);
+  }
+}
+
+QBNN_EXPORT int qbnn_pool2d_f32_mc(const float* x, int64_t x_ss, float* y, int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t C,
+                                   int32_t k, int32_t mode, int32_t n_samples, void* stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || H % k || W % k || n_samples <= 0 || mode < 0 || mode > 1)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_pool2d_f32_mc: bad argument");
+  const int64_t n = (int64_t)B * (H / k) * (W / k) * C;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pool2d_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, y, y_ss, B, H, W, C, k, mode);
+  return qbnn_check_launch_msg("qbnn_pool2d_f32_mc");
+}
+
+// ---- Flatten of an NHWC activation in the reference's NCHW order: y[s][b][c * HW + p] = x[s][b][p][c] ---------------
+__global__ __launch_bounds__(256) void flatten_nchw_f32_kernel(const float* __restrict__ x, int64_t x_ss, float* __restrict__ y,
+                                                                int64_t y_ss, int B, int HW, int C) {
+  const int64_t n = (int64_t)B * HW * C;
+  const int s = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    int64_t t = i / HW;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    y[(int64_t)s * y_ss + i] = x[(int64_t)s * x_ss + ((int64_t)b * HW + p) * C + c];
+  }
+}
+
+QBNN_EXPORT int qbnn_flatten_nchw_f32_mc(const float* x, int64_t x_ss, int32_t B, int32_t HW, int32_t C, float* y, int64_t y_ss,
+                                         int32_t n_samples, void* stream) {
+  if (!x || !y || B <= 0 || HW <= 0 || C <= 0 || n_samples <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_flatten_nchw_f32_mc: bad argument");
+  const int64_t n = (int64_t)B * HW * C;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(flatten_nchw_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, y, y_ss, B, HW, C);
+  return qbnn_check_launch_msg("qbnn_flatten_nchw_f32_mc");
+}
+
+// ---- F.softmax(dim=-1) on [S][B][N] fp32 logits (one thread per row; N is the class count) --------------------------
+__global__ __launch_bounds__(256) void softmax_f32_kernel(const float* __restrict__ x, int64_t x_ss, int B, int N, float* __restrict__ probs) {
+  const int b = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+  if (b >= B) return;
+  const float* xp = x + (int64_t)s * x_ss + (int64_t)b * N;
+  float m = -INFINITY;
+  for (int j = 0; j < N; ++j) m = fmaxf(m, xp[j]);
+  float sum = 0.f;
+  for (int j = 0; j < N; ++j) sum += expf(xp[j] - m);
+  float* pp = probs + ((int64_t)s * B + b) * N;
+  for (int j = 0; j < N; ++j) pp[j] = expf(xp[j] - m) / sum;
+}
+
+QBNN_EXPORT int qbnn_softmax_f32_mc(const float* x, int64_t x_ss, int32_t B, int32_t N, float* probs, int32_t n_samples, void* stream) {
+  if (!x || !probs || B <= 0 || N <= 0 || n_samples <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_softmax_f32_mc: bad argument");
+  hipLaunchKernelGGL(softmax_f32_kernel, dim3((B + 255) / 256, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, B, N, probs);
+  return qbnn_check_launch_msg("qbnn_softmax_f32_mc");
+}
+
+// =====================================================================================
+// QAT evaluation: observers and fake quantisation
+// =====================================================================================
+// per-sample (min, max) of x[s][0..n): partials [S][nblk][2], nblk = gridDim.x
+__global__ __launch_bounds__(256) void minmax_f32_kernel(const float* __restrict__ x, int64_t x_ss, int64_t n, float* __restrict__ partials) {
+  __shared__ float smin[4], smax[4];
+  const int s = blockIdx.y;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[(int64_t)s * x_ss + i];
+    mn = fminf(mn, v); mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mn = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+    mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    float* o = partials + ((int64_t)s * gridDim.x + blockIdx.x) * 2;
+    o[0] = mn; o[1] = mx;
+  }
+}
+
+// MovingAverageMinMaxObserver.forward + calculate_qparams (torch/quantization/observer.py; per-tensor affine), run for
+// the S samples IN ORDER by one workgroup:  first call: (min, max) = (cur_min, cur_max); later:
+// min += c (cur_min - min), max += c (cur_max - max).  qparams: lo = min(min, 0), hi = max(max, 0),
+// scale = max((hi - lo) / float(qmax - qmin), eps_f32), zp = clamp(qmin - round(lo / scale), qmin, qmax).
+// state[0..1] = (min, max), state[2] = 0 until the observer has seen data (all fp32, read and written back).
+__global__ __launch_bounds__(256) void observer_scan_kernel(const float* __restrict__ partials, int nblk, int n_samples, float* __restrict__ state,
+                                                             float avg_const, int qmin, int qmax, float* __restrict__ scale, int* __restrict__ zp) {
+  __shared__ float smin[4], smax[4];
+  float mn_state = state[0], mx_state = state[1];
+  bool init = state[2] != 0.f;
+  for (int s = 0; s < n_samples; ++s) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+      mn = fminf(mn, partials[((int64_t)s * nblk + i) * 2]);
+      mx = fmaxf(mx, partials[((int64_t)s * nblk + i) * 2 + 1]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mn = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+      mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+      if (!init) { mn_state = mn; mx_state = mx; init = true; }
+      else { mn_state = mn_state + avg_const * (mn - mn_state); mx_state = mx_state + avg_const * (mx - mx_state); }
+      const float lo = fminf(mn_state, 0.f), hi = fmaxf(mx_state, 0.f);
+      float sc = (hi - lo) / (float)(qmax - qmin);
+      sc = fmaxf(sc, 1.1920928955078125e-07f);
+      float z = (float)qmin - rintf(lo / sc);
+      z = fminf(fmaxf(z, (float)qmin), (float)qmax);
+      scale[s] = sc; zp[s] = (int)z;
+    }
+  }
+  if (threadIdx.x == 0) { state[0] = mn_state; state[1] = mx_state; state[2] = 1.f; }
+}
+
+QBNN_EXPORT int qbnn_observe_f32_mc(const float* x, int64_t x_ss, int64_t n, int32_t n_samples, float* state, float avg_const,
+                                    int32_t qmin, int32_t qmax, float* workspace, float* scale, int32_t* zero_point, void* stream) {
+  if (!x || !state || !workspace || !scale || !zero_point || n <= 0 || n_samples <= 0 || qmax <= qmin)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_observe_f32_mc: bad argument");
+  const int nblk = (int)((n + 255) / 256 < QBNN_OBSERVER_BLOCKS ? (n + 255) / 256 : QBNN_OBSERVER_BLOCKS);
+  hipLaunchKernelGGL(minmax_f32_kernel, dim3(nblk, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, n, workspace);
+  hipLaunchKernelGGL(observer_scan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, nblk, n_samples, state, avg_const, qmin,
+                     qmax, scale, zero_point);
+  return qbnn_check_launch_msg("qbnn_observe_f32_mc");
+}
+
+// fake_quantize_per_tensor_affine with per-sample qparams: y = (clamp(rne(x * (1 / s)) + z, qmin, qmax) - z) * s
+__global__ __launch_bounds__(256) void fake_quant_f32_kernel(const float* __restrict__ x, int64_t x_ss, float* __restrict__ y, int64_t y_ss,
+                                                              int64_t n, const float* __restrict__ scale, const int* __restrict__ zp,
+                                                              int qp_stride, int qmin, int qmax) {
+  const int s = blockIdx.y;
+  const float sc = scale[s * qp_stride], inv = 1.0f / sc;
+  const float z = (float)zp[s * qp_stride], lo = (float)qmin, hi = (float)qmax;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float q = fminf(fmaxf(rintf(x[(int64_t)s * x_ss + i] * inv) + z, lo), hi);
+    y[(int64_t)s * y_ss + i] = (q - z) * sc;
+  }
+}
+
+QBNN_EXPORT int qbnn_fake_quant_f32_mc(const float* x, int64_t x_ss, float* y, int64_t y_ss, int64_t n, const float* scale,
+                                       const int32_t* zero_point, int32_t qparam_stride, int32_t qmin, int32_t qmax,
+                                       int32_t n_samples, void* stream) {
+  if (!x || !y || !scale || !zero_point || n <= 0 || n_samples <= 0 || qmax <= qmin)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_f32_mc: bad argument");
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(fake_quant_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, y, y_ss, n, scale,
+                     zero_point, qparam_stride, qmin, qmax);
+  return qbnn_check_launch_msg("qbnn_fake_quant_f32_mc");
+}

@@ -11,8 +11,7 @@
 
 #include "../../include/qbnn.h"
 #include "qbnn_rng.cuh"
-
-#define QBNN_EXPORT extern "C" __attribute__((visibility("default")))
+#include "qbnn_common.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -33,6 +32,9 @@ static int check_launch(const char* what) {
   }
   return QBNN_OK;
 }
+
+int qbnn_fail_msg(int code, const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
+int qbnn_check_launch_msg(const char* what) { return check_launch(what); }
 
 QBNN_EXPORT const char* qbnn_last_error(void) { return g_err; }
 QBNN_EXPORT int qbnn_version(void) { return 1; }

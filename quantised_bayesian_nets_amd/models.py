@@ -347,6 +347,9 @@ class ModelFactory:
     @staticmethod
     def get_model(model, input_size, output_size, q, args, training_mode=True):
         if model == "conv_resnet_bbb":
+            if not q:
+                from .models_f32 import ConvNetwork_ResNet as ConvNetwork_ResNetF32
+                return ConvNetwork_ResNetF32(input_size, output_size, q, args)
             return ConvNetwork_ResNet(input_size, output_size, q, args)
         if "sgld" in model:
             return Network(input_size, output_size, q, args, training_mode)
@@ -357,6 +360,9 @@ class ModelFactory:
             from .models_f32 import LinearNetwork as LinearNetworkBBB
             return LinearNetworkBBB(input_size, output_size, q, args)
         if model == "conv_lenet_bbb":
+            if not q:
+                from .models_f32 import ConvNetwork_LeNet as ConvNetwork_LeNetF32
+                return ConvNetwork_LeNetF32(input_size, output_size, q, args)
             from .models_small import ConvNetwork_LeNet as ConvNetwork_LeNetBBB
             return ConvNetwork_LeNetBBB(input_size, output_size, q, args)
         if model == "conv_lenet_mc":

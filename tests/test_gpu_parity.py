@@ -405,3 +405,30 @@ def test_errors_are_loud():
     assert rc < 0 and b"unsupported geometry" in _lib.lib().qbnn_last_error()
     with pytest.raises(RuntimeError):
         _lib.check(rc)
+
+
+@pytest.mark.parametrize("name,model", [("lenet_bbb_f32.npz", "conv_lenet_bbb"), ("resnet_bbb_f32.npz", "conv_resnet_bbb")])
+def test_float_bbb_conv_graphs_match_reference(name, model):
+    """float BBB conv graphs on the GPU (MFMA fp32 implicit-GEMM conv, per-sample weights, in-kernel Philox
+    eps) against the reference's per-sample softmax outputs and their MC mean; fp32 tolerance 1e-5 relative
+    (+2e-6 absolute: summation order differs from mkldnn's)."""
+    import quantised_bayesian_nets_amd as q
+    from conftest import load_golden
+    g = load_golden(name)
+    args = types.SimpleNamespace(sigma_prior=-2.0)
+    shape = [1, 28, 28] if "lenet" in model else [1, 3, 32, 32]
+    m = q.ModelFactory.get_model(model, shape, 10, False, args).load_reference_state(g["state"])
+    x = torch.from_numpy(g["x"]).cuda()
+    S = g["probs"].shape[0]
+    with q.mc_context(S, g["meta"]["philox_seed"], 0):
+        p = m.forward_mc(x)
+    np.testing.assert_allclose(p.cpu().numpy(), g["probs"], rtol=1e-5, atol=2e-6)
+    mean = q.mc_predict(m, x, S, g["meta"]["philox_seed"])
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean_probs"], rtol=1e-5, atol=2e-6)
+    # the oracle on a sample the fixture does not hold
+    from oracle import oracle as orc
+    net = orc.F32ConvOracle(g["state"])
+    fwd = net.lenet if "lenet" in model else net.resnet
+    with q.mc_context(1, 11, 5):
+        p5 = m(x)
+    np.testing.assert_allclose(p5.cpu().numpy(), fwd(g["x"], 11, 5), rtol=1e-5, atol=2e-6)

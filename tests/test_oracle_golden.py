@@ -1,6 +1,7 @@
 """The oracle (oracle/qbnn_oracle.c) against the golden vectors recorded from the real reference
 (tests/golden/make_golden.py).  Integer tensors must match bit-for-bit; fp32 probabilities to 1e-5 rel."""
 import numpy as np
+import pytest
 
 from oracle import oracle as orc
 
@@ -137,3 +138,31 @@ def test_small_bbb_int8_graphs_bit_exact(golden_lenet_bbb, golden_mlp_bbb_q):
         assert np.array_equal(rec[k].reshape(v.shape), v), k
     np.testing.assert_allclose(mu, m["mu"][0], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(var, m["var"][0], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("name,kind", [("lenet_bbb_f32.npz", "lenet"), ("resnet_bbb_f32.npz", "resnet")])
+def test_float_bbb_conv_graphs_match_reference(name, kind):
+    """float BBB conv graphs (eval branch, bbb/conv.py:33-39): oracle vs the reference's per-sample softmax
+    outputs with the same injected eps; fp32 tolerance 1e-5 relative (+1e-6 absolute on probabilities)."""
+    from conftest import load_golden
+    g = load_golden(name)
+    net = orc.F32ConvOracle(g["state"])
+    fwd = net.lenet if kind == "lenet" else net.resnet
+    for s in range(g["probs"].shape[0]):
+        np.testing.assert_allclose(fwd(g["x"], g["meta"]["philox_seed"], s), g["probs"][s], rtol=1e-5, atol=1e-6)
+
+
+def test_ema_observer_matches_torch_fake_quantize():
+    """Row a2 building block: MovingAverageMinMaxObserver + fake_quantize_per_tensor_affine restated (oracle.EmaObserver)
+    against torch's own FakeQuantize module over a sequence of batches (the EMA state matters)."""
+    import torch
+    from torch.ao.quantization import FakeQuantize, MovingAverageMinMaxObserver
+    for (qmin, qmax, dtype) in ((0, 127, torch.quint8), (-128, 127, torch.qint8), (-8, 7, torch.qint8)):
+        fq = FakeQuantize(observer=MovingAverageMinMaxObserver, quant_min=qmin, quant_max=qmax, dtype=dtype, qscheme=torch.per_tensor_affine)
+        ob = orc.EmaObserver(qmin, qmax)
+        rng = np.random.RandomState(qmax)
+        for i in range(6):
+            x = (rng.randn(4, 50).astype(np.float32) * (1 + i)) + np.float32(0.3 * i)
+            want = fq(torch.from_numpy(x)).numpy()
+            got = ob.fake_quant(x)
+            np.testing.assert_array_equal(got, want)
