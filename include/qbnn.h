@@ -227,7 +227,9 @@ int qbnn_linear_f32_mc(const float* x, int64_t x_sample_stride, const float* w, 
 
 /* Z_s = conv2d(X_s, W_s) (+ bias) (ReLU).  x [S|1][B][H][W][Cin] fp32 NHWC, w [S|1][Cout][Cin][k][k] in the REFERENCE's
  * weight order (so qbnn_sample_weights_f32's noise index is the reference's element index), y [S][B][Ho][Wo][Cout].
- * Replaces F.conv2d at bbb/conv.py:38 / conv_qat.py:47,158.  Sample strides in elements; 0 = shared. */
+ * Replaces F.conv2d at bbb/conv.py:38 / conv_qat.py:47,158.  Sample strides in elements; 0 = shared.
+ * `relu` is a flag word: bit 0 = fused ReLU, bit 1 = accumulate in fp64 (one rounding of the exact sum; the QAT path
+ * uses it because a fake-quantiser follows every conv). */
 int qbnn_conv2d_f32_mc(const float* x, int64_t x_sample_stride, const float* w, int64_t w_sample_stride, const float* bias, float* y,
                        int64_t y_sample_stride, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                        int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream);
@@ -253,6 +255,12 @@ int qbnn_softmax_f32_mc(const float* x, int64_t x_sample_stride, int32_t B, int3
 /* ---- QAT fake-quant evaluation with live observers (row a2: conv_qat.py:26-49,139-167, linear_qat.py:18-41) ---------- */
 
 #define QBNN_OBSERVER_BLOCKS 512        /* workspace: n_samples * QBNN_OBSERVER_BLOCKS * 2 floats */
+
+/* W[s][i] = mu[s][i] + eps(s,i) * sigma[s][i] with per-sample operands (strides in elements, 0 = shared); mu NULL gives
+ * the noise term alone (conv_qat.py:45 / linear_qat.py:33: mul_noise.mul(noise, std)).  Noise stream as qbnn_sample_weights_f32. */
+int qbnn_sample_weights_f32_strided(const float* mu, int64_t mu_sample_stride, const float* sigma, int64_t sigma_sample_stride,
+                                    int64_t n, uint64_t seed, uint32_t layer_id, uint32_t sample_begin, int32_t n_samples,
+                                    const float* eps_in, float* w_out, void* stream);
 
 /* MovingAverageMinMaxObserver (averaging constant `avg_const`, active in eval) over the S samples IN ORDER, then
  * calculate_qparams (per-tensor affine, quant range [qmin, qmax]):  state = {min, max, seen?} is read and written

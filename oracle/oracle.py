@@ -669,3 +669,94 @@ class EmaObserver:
         inv = np.float32(1.0) / s
         q = np.clip(np.rint((np.asarray(x, np.float32) * inv).astype(np.float32)) + np.float32(z), self.qmin, self.qmax)
         return ((q - np.float32(z)).astype(np.float32) * s).astype(np.float32)
+
+
+class QATOracle:
+    """Prepared (QAT) BBB models in eval mode with live observers: reference conv_qat.py:26-49,139-167,228-251,
+    linear_qat.py:18-41,78-79 on the graphs of models_bbb.py.  STATEFUL: every forward advances the observers, so the
+    samples must be evaluated in order s = 0, 1, ... exactly like S reference forwards.  `state` uses the reference's
+    state_dict names of the prepared model."""
+
+    def __init__(self, state, a_bits=7, w_bits=8):
+        self.st = state
+        self.ab, self.wb = UINT_BOUNDS[a_bits], INT_BOUNDS[w_bits]
+        self.obs = {}
+
+    def fq(self, prefix, x, weight_like):
+        if prefix not in self.obs:
+            mn = float(np.asarray(self.st[prefix + ".activation_post_process.min_val"]))
+            mx = float(np.asarray(self.st[prefix + ".activation_post_process.max_val"]))
+            lo, hi = self.wb if weight_like else self.ab
+            self.obs[prefix] = EmaObserver(lo, hi, (mn, mx) if np.isfinite(mn) and np.isfinite(mx) else None)
+        return self.obs[prefix].fake_quant(np.asarray(x, np.float32))
+
+    def weights(self, name, lid, seed, sample, c=None):
+        mu, rho = (np.asarray(self.st[name + k], np.float32) for k in (".weight", ".std"))
+        sg = softplus(rho)
+        if c is not None:
+            shape = [-1] + [1] * (mu.ndim - 1)
+            mu, sg = (mu * c.reshape(shape)).astype(np.float32), (sg * c.reshape(shape)).astype(np.float32)
+        w = self.fq(name + ".weight_fake_quant", mu, True)
+        s = self.fq(name + ".std_fake_quant", sg, True)
+        eps = fill_normal(mu.size, seed, lid, sample).reshape(mu.shape)
+        t = self.fq(name + ".mul_noise.activation_post_process", (eps * s).astype(np.float32), True)
+        return self.fq(name + ".add_weight.activation_post_process", (w + t).astype(np.float32), True)
+
+    def conv(self, name, lid, x, seed, sample, stride, pad, bn, relu):
+        c = None
+        if bn:
+            g, rv = np.asarray(self.st[name + ".bn.weight"], np.float32), np.asarray(self.st[name + ".bn.running_var"], np.float32)
+            c = (g / np.sqrt(rv + np.float32(1e-5))).astype(np.float32)
+        W = self.weights(name, lid, seed, sample, c)
+        z = conv2d_f32(x, np.ascontiguousarray(W.transpose(0, 2, 3, 1)), None, stride, pad)
+        if bn:
+            z = (z / c).astype(np.float32)
+            z = _bn_eval(z, self.st, name + ".bn")
+        if relu:
+            z = np.maximum(z, 0)
+        return self.fq(name + ".activation_post_process", z, False)
+
+    def linear(self, name, lid, x, seed, sample, relu, bias):
+        W = self.weights(name, lid, seed, sample)
+        y = (x.astype(np.float64) @ W.astype(np.float64).T).astype(np.float32)
+        if bias:
+            y = (y + np.asarray(self.st[name + ".bias"], np.float32)).astype(np.float32)
+        if relu:
+            y = np.maximum(y, 0)
+        return self.fq(name + ".activation_post_process", y, False)
+
+    def lenet(self, x_nchw, seed, sample):
+        h = np.ascontiguousarray(np.asarray(x_nchw, np.float32).transpose(0, 2, 3, 1))
+        h = self.fq("quant.activation_post_process", h, False)
+        h = _pool_f32(self.conv("layers.0", 0, h, seed, sample, 1, 2, False, False), 2, False)
+        h = _pool_f32(self.conv("layers.2", 1, h, seed, sample, 1, 2, False, False), 2, False)
+        h = np.ascontiguousarray(h.transpose(0, 3, 1, 2)).reshape(h.shape[0], -1)
+        h = self.linear("layers.5", 2, h, seed, sample, True, False)
+        return _softmax_f32(self.linear("layers.7", 3, h, seed, sample, False, False))
+
+    def mlp(self, x, seed, sample):
+        h = self.fq("quant.activation_post_process", np.asarray(x, np.float32), False)
+        for lid, n in enumerate(("layers.0", "layers.2", "layers.4")):
+            h = self.linear(n, lid, h, seed, sample, True, True)
+        mu = self.linear("mu", 3, h, seed, sample, False, True)
+        lv = self.linear("log_var", 4, h, seed, sample, False, True)
+        return mu, np.exp(lv)
+
+    def resnet(self, x_nchw, seed, sample):
+        h = np.ascontiguousarray(np.asarray(x_nchw, np.float32).transpose(0, 2, 3, 1))
+        h = self.fq("quant.activation_post_process", h, False)
+        lid = 0
+        h = self.conv("layers.0", lid, h, seed, sample, 1, 1, True, True); lid += 1
+        inp = 24
+        for li, planes, stride in ((3, 24, 1), (4, 48, 2), (5, 96, 2), (6, 192, 2)):
+            for bi, st in enumerate((stride, 1)):
+                p = f"layers.{li}.{bi}"
+                out = self.conv(p + ".stem.0", lid, h, seed, sample, st, 1, True, True); lid += 1
+                out = self.conv(p + ".stem.3", lid, out, seed, sample, 1, 1, True, False); lid += 1
+                sc = h
+                if st != 1 or inp != planes:
+                    sc = self.conv(p + ".shortcut.0", lid, h, seed, sample, st, 0, True, False); lid += 1
+                h = np.maximum(self.fq(p + ".add.add.activation_post_process", (out + sc).astype(np.float32), False), 0)
+                inp = planes
+        h = _pool_f32(h, 4, True).reshape(h.shape[0], -1)
+        return _softmax_f32(self.linear("layers.9", lid, h, seed, sample, False, False))

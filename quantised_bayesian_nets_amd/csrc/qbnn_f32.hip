@@ -14,6 +14,7 @@
 
 #include "../../include/qbnn.h"
 #include "qbnn_common.h"
+#include "qbnn_rng.cuh"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -111,6 +112,86 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvF32Args a) {
     }
 }
 
+// Same tiling with fp64 accumulation on the vector ALU (each thread a 4 x 4 block of the 64 x 64 tile), selected by
+// flags bit 1.  The QAT path needs it: downstream of every conv sits a fake-quantiser, and a sum whose fp32
+// accumulation error (K up to 1728 terms) moves a value across a rounding boundary changes that activation by a whole
+// grid step.  With one rounding of the exact sum the result agrees with the reference's conv to ~1 ulp.
+__global__ __launch_bounds__(256) void conv2d_f32_acc64_kernel(const ConvF32Args a) {
+  __shared__ float As[64 * CF_LD];
+  __shared__ float Bs[64 * CF_LD];
+  const int tid = threadIdx.x;
+  const int tn = tid & 15, tp = tid >> 4;            // channels 4 tn .. +3, pixels 4 tp .. +3 of the tile
+  const int s = blockIdx.z;
+  const int p0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int npix = a.B * a.Ho * a.Wo;
+  const int K = a.KS * a.KS * a.Cin;
+  const float* xs = a.x + (int64_t)s * a.x_ss;
+  const float* ws = a.w + (int64_t)s * a.w_ss;
+  int prow[4], pb[4], poh[4], pow_[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 256 * j, row = e >> 4;
+    const int p = p0 + row;
+    prow[j] = row;
+    if (p < npix) { pb[j] = p / (a.Ho * a.Wo); const int rem = p - pb[j] * a.Ho * a.Wo; poh[j] = rem / a.Wo; pow_[j] = rem - poh[j] * a.Wo; }
+    else { pb[j] = -1; poh[j] = 0; pow_[j] = 0; }
+  }
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  for (int k0 = 0; k0 < K; k0 += CF_KC) {
+    const int kk = k0 + (tid & 15);
+    int kh = 0, kw = 0, c = 0;
+    const bool kok = kk < K;
+    if (kok) { kh = kk / (a.KS * a.Cin); const int r2 = kk - kh * a.KS * a.Cin; kw = r2 / a.Cin; c = r2 - kw * a.Cin; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = prow[j];
+      float xv = 0.f;
+      if (kok && pb[j] >= 0) {
+        const int ih = poh[j] * a.stride - a.pad + kh, iw = pow_[j] * a.stride - a.pad + kw;
+        if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+          xv = xs[(((int64_t)pb[j] * a.H + ih) * a.W + iw) * a.Cin + c];
+      }
+      Bs[row * CF_LD + (tid & 15)] = xv;
+      float wv = 0.f;
+      const int n = n0 + row;
+      if (kok && n < a.Cout) wv = ws[(((int64_t)n * a.Cin + c) * a.KS + kh) * a.KS + kw];
+      As[row * CF_LD + (tid & 15)] = wv;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < CF_KC; ++k) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = (double)As[(4 * tn + i) * CF_LD + k]; bv[i] = (double)Bs[(4 * tp + i) * CF_LD + k]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(bv[i], av[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = p0 + 4 * tp + i;
+    if (p >= npix) continue;
+    float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)p * a.Cout;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 4 * tn + j;
+      if (n < a.Cout) {
+        float v = (float)acc[i][j];
+        if (a.bias) v = v + a.bias[n];
+        if (a.relu) v = fmaxf(v, 0.f);
+        yp[n] = v;
+      }
+    }
+  }
+}
+
 QBNN_EXPORT int qbnn_conv2d_f32_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* bias, float* y,
                                    int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                                    int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream) {
@@ -118,12 +199,13 @@ QBNN_EXPORT int qbnn_conv2d_f32_mc(const float* x, int64_t x_ss, const float* w,
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: bad argument");
   ConvF32Args a;
   a.x = x; a.x_ss = x_ss; a.w = w; a.w_ss = w_ss; a.bias = bias; a.y = y; a.y_ss = y_ss;
-  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = ksize; a.stride = stride; a.pad = pad; a.relu = relu;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = ksize; a.stride = stride; a.pad = pad; a.relu = relu & 1;
   a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
   if (a.Ho <= 0 || a.Wo <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: empty output");
   const int64_t npix = (int64_t)B * a.Ho * a.Wo;
   dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)n_samples);
-  hipLaunchKernelGGL(conv2d_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (relu & 2) hipLaunchKernelGGL(conv2d_f32_acc64_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv2d_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   return qbnn_check_launch_msg("qbnn_conv2d_f32_mc");
 }
 
@@ -327,4 +409,39 @@ QBNN_EXPORT int qbnn_fake_quant_f32_mc(const float* x, int64_t x_ss, float* y, i
   hipLaunchKernelGGL(fake_quant_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, y, y_ss, n, scale,
                      zero_point, qparam_stride, qmin, qmax);
   return qbnn_check_launch_msg("qbnn_fake_quant_f32_mc");
+}
+
+// W[s][i] = mu[s][i] + eps(s, i) * sigma[s][i] with per-sample mu / sigma (the QAT weight pipeline quantises them with
+// per-sample qparams); mu NULL -> the noise term alone (conv_qat.py:45: mul_noise.mul(noise, std)).  Same Philox stream as
+// qbnn_sample_weights_f32: ctr = {i >> 2, layer_id, sample_begin + s, 0}, element i & 3; eps_in [S][n] overrides it.
+__global__ __launch_bounds__(256) void sample_weights_f32_strided_kernel(const float* __restrict__ mu, int64_t mu_ss, const float* __restrict__ sigma,
+                                                                          int64_t sigma_ss, int64_t n, uint32_t seed_lo, uint32_t seed_hi,
+                                                                          uint32_t layer_id, uint32_t sample_begin,
+                                                                          const float* __restrict__ eps_in, float* __restrict__ w) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g * 4 >= n) return;
+  const int s = blockIdx.y;
+  float e[4];
+  if (eps_in) {
+    for (int j = 0; j < 4; ++j) e[j] = (g * 4 + j < n) ? eps_in[(int64_t)s * n + g * 4 + j] : 0.f;
+  } else {
+    qbnn::normal4(qbnn::philox4x32_10((uint32_t)g, layer_id, sample_begin + s, 0u, seed_lo, seed_hi), e);
+  }
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = g * 4 + j;
+    if (i < n) {
+      const float t = e[j] * sigma[(int64_t)s * sigma_ss + i];
+      w[(int64_t)s * n + i] = mu ? mu[(int64_t)s * mu_ss + i] + t : t;
+    }
+  }
+}
+
+QBNN_EXPORT int qbnn_sample_weights_f32_strided(const float* mu, int64_t mu_ss, const float* sigma, int64_t sigma_ss, int64_t n,
+                                                uint64_t seed, uint32_t layer_id, uint32_t sample_begin, int32_t n_samples,
+                                                const float* eps_in, float* w_out, void* stream) {
+  if (!sigma || !w_out || n <= 0 || n_samples <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_sample_weights_f32_strided: bad argument");
+  const int64_t groups = (n + 3) / 4;
+  hipLaunchKernelGGL(sample_weights_f32_strided_kernel, dim3((unsigned)((groups + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
+                     mu, mu_ss, sigma, sigma_ss, n, (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out);
+  return qbnn_check_launch_msg("qbnn_sample_weights_f32_strided");
 }

@@ -346,6 +346,12 @@ class ModelFactory:
 
     @staticmethod
     def get_model(model, input_size, output_size, q, args, training_mode=True):
+        if q and getattr(args, "qat_eval", False) and model in ("conv_resnet_bbb", "conv_lenet_bbb", "linear_bbb"):
+            # the prepared-but-not-converted model (quant_utils.prepare_model): fake-quant evaluation with live observers
+            from . import models_qat
+            cls = {"conv_resnet_bbb": models_qat.ConvNetwork_ResNet, "conv_lenet_bbb": models_qat.ConvNetwork_LeNet,
+                   "linear_bbb": models_qat.LinearNetwork}[model]
+            return cls(input_size, output_size, q, args)
         if model == "conv_resnet_bbb":
             if not q:
                 from .models_f32 import ConvNetwork_ResNet as ConvNetwork_ResNetF32

@@ -1,0 +1,388 @@
+"""QAT fake-quant evaluation with LIVE observers behind the reference's API.
+
+Mirror of reference src/models/stochastic/bbb/quantized/conv_qat.py (`Conv2d._forward` :26-49, `ConvBn2d._forward`
+:139-167, `ConvBnReLU2d` / `ConvReLU2d` :228-251) and linear_qat.py (`Linear._forward` :18-41, `LinearReLU` :78-79), as
+assembled by quant_utils.prepare_model (:109-147): every tensor of the eval-mode forward passes a FakeQuantize whose
+MovingAverageMinMaxObserver keeps updating.  The S Monte-Carlo samples are still evaluated together, layer by layer:
+the observer recurrence links sample s to the earlier ones only through (min, max), so each FakeQuantize is
+    per-sample min/max (parallel)  ->  EMA + qparams over the S samples in order (one small kernel)  ->
+    fake-quantise every sample with ITS (scale, zero point)                           (qbnn_observe_f32_mc / qbnn_fake_quant_f32_mc)
+and the result equals S sequential reference forwards.  Activations are fp32 NHWC [S, B, H, W, C].
+
+State-dict names follow the reference's prepared model (`<layer>.weight_fake_quant.activation_post_process.min_val`, ...).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .layers import _MC, mc_context, timed
+from .models_f32 import (affine_f32, conv2d_f32, flatten_f32, nchw_to_mc_nhwc, pool2d_f32, softmax_f32)
+from .quant import INT_BOUNDS, UINT_BOUNDS
+
+OBS_BLOCKS = 512            # QBNN_OBSERVER_BLOCKS (include/qbnn.h)
+AVG_CONST = 0.01            # MovingAverageMinMaxObserver default, never overridden by the reference
+
+
+class FakeQuantize(nn.Module):
+    """torch FakeQuantize(observer=MovingAverageMinMaxObserver, per_tensor_affine) with observer and fake-quant both
+    enabled (the reference never disables either, so they run in eval).  `state` = (min, max, seen) lives on the device."""
+
+    def __init__(self, qmin, qmax):
+        super().__init__()
+        self.qmin, self.qmax = int(qmin), int(qmax)
+        self.register_buffer("state", torch.zeros(3, dtype=torch.float32))
+        self.last_scale = None
+        self.last_zero_point = None
+
+    def load(self, st, prefix):
+        mn, mx = float(np.asarray(st[prefix + ".activation_post_process.min_val"])), float(np.asarray(st[prefix + ".activation_post_process.max_val"]))
+        seen = np.isfinite(mn) and np.isfinite(mx)
+        self.state = torch.tensor([mn if seen else 0.0, mx if seen else 0.0, 1.0 if seen else 0.0], dtype=torch.float32)
+
+    def min_max(self):
+        s = self.state.detach().cpu().numpy()
+        return (float(s[0]), float(s[1])) if s[2] else (float("inf"), float("-inf"))
+
+    def forward(self, x):
+        """x [S or 1, ...] fp32 on the GPU -> [S, ...]: sample s is quantised with the qparams the observer holds after
+        having seen samples 0..s (a shared input is observed S times, as S reference forwards would)."""
+        if x.device.type != "cuda":
+            raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
+        S = _MC.samples
+        x = x.contiguous()
+        n = x[0].numel()
+        xs = 0 if x.shape[0] == 1 else n
+        if self.state.device != x.device:
+            self.state = self.state.to(x.device)
+        ws = torch.empty(S * OBS_BLOCKS * 2, dtype=torch.float32, device=x.device)
+        scale = torch.empty(S, dtype=torch.float32, device=x.device)
+        zp = torch.empty(S, dtype=torch.int32, device=x.device)
+        L = _lib.lib()
+        with timed("observe_f32"):
+            _lib.check(L.qbnn_observe_f32_mc(_lib.ptr(x), xs, n, S, _lib.ptr(self.state), AVG_CONST, self.qmin, self.qmax, _lib.ptr(ws),
+                                             _lib.ptr(scale), _lib.ptr(zp), _lib.current_stream()))
+        y = torch.empty((S,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        with timed("fake_quant_f32"):
+            _lib.check(L.qbnn_fake_quant_f32_mc(_lib.ptr(x), xs, _lib.ptr(y), n, n, _lib.ptr(scale), _lib.ptr(zp), 1, self.qmin, self.qmax, S,
+                                                _lib.current_stream()))
+        self.last_scale, self.last_zero_point = scale, zp
+        return y
+
+
+def _bounds(args):
+    return UINT_BOUNDS[args.activation_precision], INT_BOUNDS[args.weight_precision]
+
+
+class _QATBBB(nn.Module):
+    """Shared weight pipeline of conv_qat.Conv2d / linear_qat.Linear in eval:
+       w = FQ_w(mu * c), s = FQ_std(softplus(rho) * c), t = FQ_mul(eps * s), W = FQ_add(w + t)."""
+
+    def _init_fq(self, args):
+        (alo, ahi), (wlo, whi) = _bounds(args)
+        self.weight_fake_quant = FakeQuantize(wlo, whi)
+        self.std_fake_quant = FakeQuantize(wlo, whi)
+        self.mul_noise = FakeQuantize(wlo, whi)          # FloatFunctional.activation_post_process
+        self.add_weight = FakeQuantize(wlo, whi)
+        self.activation_post_process = FakeQuantize(alo, ahi)
+        self.layer_id = 0
+        self._folded = None
+
+    def _folded_params(self, dev):
+        """(mu * c, softplus(rho) * c) flat, computed once with the reference's own torch ops."""
+        if self._folded is None or self._folded[0].device != dev:
+            mu, sg = self.weight.detach().float().cpu(), F.softplus(self.std.detach().float().cpu())
+            c = self.scale_factor()
+            if c is not None:
+                shape = [-1] + [1] * (mu.dim() - 1)
+                mu, sg = mu * c.reshape(shape), sg * c.reshape(shape)
+            self._folded = (mu.reshape(1, -1).contiguous().to(dev), sg.reshape(1, -1).contiguous().to(dev))
+        return self._folded
+
+    def scale_factor(self):
+        return None
+
+    def sampled_weights(self, dev, eps=None):
+        S = _MC.samples
+        mu0, sg0 = self._folded_params(dev)
+        w = self.weight_fake_quant(mu0)                                  # [S, n]
+        s = self.std_fake_quant(sg0)
+        n = w.shape[1]
+        t_pre = torch.empty((S, n), dtype=torch.float32, device=dev)
+        if eps is not None:
+            eps = eps.to(device=dev, dtype=torch.float32).contiguous()
+        with timed("sample_weights_f32"):
+            _lib.check(_lib.lib().qbnn_sample_weights_f32_strided(None, 0, _lib.ptr(s), n, n, _MC.seed, self.layer_id, _MC.sample_begin, S,
+                                                                  _lib.ptr(eps), _lib.ptr(t_pre), _lib.current_stream()))
+        t = self.mul_noise(t_pre)
+        return self.add_weight(affine_f32(w.unsqueeze(-1), res=t.unsqueeze(-1)).squeeze(-1))
+
+    def _load_common(self, st, name):
+        self.weight.data = torch.from_numpy(np.asarray(st[name + ".weight"], np.float32).copy()).reshape(self.weight.shape)
+        self.std.data = torch.from_numpy(np.asarray(st[name + ".std"], np.float32).copy()).reshape(self.std.shape)
+        if self.bias is not None:
+            self.bias.data = torch.from_numpy(np.asarray(st[name + ".bias"], np.float32).copy())
+        self.weight_fake_quant.load(st, name + ".weight_fake_quant")
+        self.std_fake_quant.load(st, name + ".std_fake_quant")
+        self.mul_noise.load(st, name + ".mul_noise.activation_post_process")
+        self.add_weight.load(st, name + ".add_weight.activation_post_process")
+        self.activation_post_process.load(st, name + ".activation_post_process")
+        self._folded = None
+
+
+class Conv2d(_QATBBB):
+    """conv_qat.Conv2d / ConvReLU2d / ConvBn2d / ConvBnReLU2d (`bn`, `relu` flags).  Constructor follows
+    conv_qat.Conv2d(in_channels, out_channels, kernel_size, stride=1, padding=0, ..., bias=False, qconfig=None, args=None)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=False,
+                 padding_mode="zeros", qconfig=None, args=None, bn=False, relu=False, eps=1e-5):
+        super().__init__()
+        k = kernel_size[0] if isinstance(kernel_size, (tuple, list)) else kernel_size
+        self.in_channels, self.out_channels, self.k, self.stride, self.padding = in_channels, out_channels, int(k), int(stride), int(padding)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, self.k, self.k).uniform_(-0.01, 0.01), requires_grad=False)
+        self.std = nn.Parameter(torch.full((out_channels, in_channels, self.k, self.k), -10.0), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels), requires_grad=False) if bias else None
+        self.args, self.relu = args, relu
+        self.bn = None
+        if bn:
+            from .models_f32 import BatchNorm2d
+            self.bn = BatchNorm2d(out_channels, eps)
+        self._init_fq(args)
+
+    def scale_factor(self):
+        if self.bn is None:
+            return None
+        running_std = torch.sqrt(self.bn.running_var.float().cpu() + self.bn.eps)          # conv_qat.py:140-141
+        return self.bn.weight.detach().float().cpu() / running_std
+
+    def forward(self, x, eps=None):
+        dev = x.device
+        W = self.sampled_weights(dev, eps)
+        if self.bn is None:
+            b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
+            z = conv2d_f32(x, W, b, self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True)
+        else:
+            z = conv2d_f32(x, W, None, self.in_channels, self.out_channels, self.k, self.stride, self.padding, False, acc64=True)
+            c = self.scale_factor().to(dev).contiguous()
+            b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
+            z = affine_f32(z, c, b, mode=1)                                                # Z / scale_factor (+ bias), :159-161
+            z = self.bn(z, relu=self.relu)
+        return self.activation_post_process(z)
+
+    def load(self, st, name):
+        self._load_common(st, name)
+        if self.bn is not None:
+            from .models_f32 import _load_bn
+            _load_bn(self.bn, st, name + ".bn")
+        return self
+
+
+class Linear(_QATBBB):
+    """linear_qat.Linear / LinearReLU."""
+
+    def __init__(self, in_features, out_features, bias=False, qconfig=None, args=None, relu=False):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features).uniform_(-0.01, 0.01), requires_grad=False)
+        self.std = nn.Parameter(torch.full((out_features, in_features), -3.0), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_features).uniform_(-0.01, 0.01), requires_grad=False) if bias else None
+        self.args, self.relu = args, relu
+        self._init_fq(args)
+
+    def forward(self, x, eps=None, act=None):
+        dev = x.device
+        W = self.sampled_weights(dev, eps)
+        S, B = _MC.samples, x.shape[1]
+        y = torch.empty((S, B, self.out_features), dtype=torch.float32, device=dev)
+        b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
+        a = (1 if self.relu else 0) if act is None else act
+        x = x.contiguous()
+        with timed("linear_f32"):
+            _lib.check(_lib.lib().qbnn_linear_f32_mc(_lib.ptr(x), 0 if x.shape[0] == 1 else x[0].numel(), _lib.ptr(W), W.shape[1], _lib.ptr(b),
+                                                     _lib.ptr(y), y[0].numel(), B, self.in_features, self.out_features, a, S, _lib.current_stream()))
+        return self.activation_post_process(y)
+
+    def load(self, st, name):
+        self._load_common(st, name)
+        return self
+
+
+class QuantStub(nn.Module):
+    """torch QuantStub of a prepared model: identity + activation FakeQuantize (forward hook)."""
+
+    def __init__(self, args):
+        super().__init__()
+        (alo, ahi), _ = _bounds(args)
+        self.activation_post_process = FakeQuantize(alo, ahi)
+
+    def forward(self, x):
+        return self.activation_post_process(x)
+
+
+class ConvNetwork_LeNet(nn.Module):
+    """Prepared (QAT) `conv_lenet_bbb`, eval: quant - conv - maxpool - conv - maxpool - flatten - fc500+relu - fc - softmax."""
+
+    def __init__(self, input_size, output_size, q, args):
+        super().__init__()
+        self.args, self.q = args, q
+        c0 = input_size[0] if len(input_size) == 3 else input_size[1]
+        self.quant = QuantStub(args)
+        self.layers = nn.ModuleList([Conv2d(c0, 20, 5, 1, 2, args=args), nn.Identity(), Conv2d(20, 50, 5, 1, 2, args=args), nn.Identity(),
+                                     nn.Identity(), Linear(50 * 7 * 7, 500, args=args, relu=True), nn.Identity(), Linear(500, output_size, args=args)])
+        for i, m in enumerate(self.stochastic_layers()):
+            m.layer_id = i
+
+    def stochastic_layer_names(self):
+        return ["layers.0", "layers.2", "layers.5", "layers.7"]
+
+    def stochastic_layers(self):
+        return [self.layers[0], self.layers[2], self.layers[5], self.layers[7]]
+
+    def fake_quantizers(self):
+        out = [("quant.activation_post_process", self.quant.activation_post_process)]
+        for n, m in zip(self.stochastic_layer_names(), self.stochastic_layers()):
+            out += [(n + ".weight_fake_quant", m.weight_fake_quant), (n + ".std_fake_quant", m.std_fake_quant),
+                    (n + ".mul_noise.activation_post_process", m.mul_noise), (n + ".add_weight.activation_post_process", m.add_weight),
+                    (n + ".activation_post_process", m.activation_post_process)]
+        return out
+
+    def load_reference_state(self, st):
+        self.quant.activation_post_process.load(st, "quant.activation_post_process")
+        for n, m in zip(self.stochastic_layer_names(), self.stochastic_layers()):
+            m.load(st, n)
+        return self
+
+    def forward_mc(self, x):
+        h = self.quant(nchw_to_mc_nhwc(x))
+        h = pool2d_f32(self.layers[0](h), 2, avg=False)
+        h = pool2d_f32(self.layers[2](h), 2, avg=False)
+        h = flatten_f32(h)
+        h = self.layers[5](h)
+        return softmax_f32(self.layers[7](h))
+
+    def forward(self, x):
+        with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
+            return self.forward_mc(x)[0]
+
+
+class LinearNetwork(nn.Module):
+    """Prepared (QAT) `linear_bbb`: quant - 3 x (fc100 + relu) - heads mu / log_var -> (mu, exp(log_var))."""
+
+    def __init__(self, input_size, output_size, q, args):
+        super().__init__()
+        self.args, self.q = args, q
+        self.input_size = 1
+        for i in input_size:
+            self.input_size *= int(i)
+        self.quant = QuantStub(args)
+        self.layers = nn.ModuleList([])
+        prev = self.input_size
+        for _ in range(3):
+            self.layers.append(Linear(prev, 100, bias=True, args=args, relu=True))
+            self.layers.append(nn.Identity())
+            prev = 100
+        self.mu = Linear(prev, 1, bias=True, args=args)
+        self.log_var = Linear(prev, 1, bias=True, args=args)
+        for i, m in enumerate(self.stochastic_layers()):
+            m.layer_id = i
+
+    def stochastic_layer_names(self):
+        return ["layers.0", "layers.2", "layers.4", "mu", "log_var"]
+
+    def stochastic_layers(self):
+        return [self.layers[0], self.layers[2], self.layers[4], self.mu, self.log_var]
+
+    def load_reference_state(self, st):
+        self.quant.activation_post_process.load(st, "quant.activation_post_process")
+        for n, m in zip(self.stochastic_layer_names(), self.stochastic_layers()):
+            m.load(st, n)
+        return self
+
+    def forward_mc(self, x):
+        h = self.quant(x.to(torch.float32).reshape(1, x.shape[0], -1))
+        for m in (self.layers[0], self.layers[2], self.layers[4]):
+            h = m(h)
+        mu = self.mu(h)
+        lv = self.log_var(h)
+        return mu, torch.exp(lv)          # DeQuantStub is the identity on fp32; models_bbb.py:78
+
+    def forward(self, x):
+        with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
+            mu, var = self.forward_mc(x)
+        return mu[0], var[0]
+
+
+class BasicBlock(nn.Module):
+    """Prepared BasicBlock: stem.0 ConvBnReLU2d, stem.3 ConvBn2d, shortcut.0 ConvBn2d (where the shape changes), `add.add`
+    FloatFunctional with its own FakeQuantize, `end` ReLU."""
+
+    def __init__(self, in_planes, planes, stride, args):
+        super().__init__()
+        (alo, ahi), _ = _bounds(args)
+        self.stem = nn.ModuleList([Conv2d(in_planes, planes, 3, stride, 1, args=args, bn=True, relu=True), nn.Identity(), nn.Identity(),
+                                   Conv2d(planes, planes, 3, 1, 1, args=args, bn=True), nn.Identity()])
+        self.shortcut = nn.ModuleList([])
+        if stride != 1 or in_planes != planes:
+            self.shortcut.append(Conv2d(in_planes, planes, 1, stride, 0, args=args, bn=True))
+            self.shortcut.append(nn.Identity())
+        self.add = FakeQuantize(alo, ahi)          # add.add.activation_post_process
+
+    def forward(self, x):
+        out = self.stem[3](self.stem[0](x))
+        sc = self.shortcut[0](x) if len(self.shortcut) else x
+        return affine_f32(self.add(affine_f32(out, res=sc)), relu=True)
+
+
+class ConvNetwork_ResNet(nn.Module):
+    """Prepared (QAT) `conv_resnet_bbb`, eval."""
+
+    def __init__(self, input_size, output_size, q, args):
+        super().__init__()
+        self.args, self.q = args, q
+        self.quant = QuantStub(args)
+        self.layers = nn.ModuleList([Conv2d(input_size[1], 24, 3, 1, 1, args=args, bn=True, relu=True), nn.Identity(), nn.Identity()])
+        inp = 24
+        for planes, stride in ((24, 1), (48, 2), (96, 2), (192, 2)):
+            blocks = []
+            for st in (stride, 1):
+                blocks.append(BasicBlock(inp, planes, st, args))
+                inp = planes
+            self.layers.append(nn.ModuleList(blocks))
+        self.layers.append(nn.Identity())
+        self.layers.append(nn.Identity())
+        self.layers.append(Linear(192, output_size, args=args))
+        for i, (_, m) in enumerate(self.stochastic_named()):
+            m.layer_id = i
+
+    def stochastic_named(self):
+        out = [("layers.0", self.layers[0])]
+        for li in (3, 4, 5, 6):
+            for bi, blk in enumerate(self.layers[li]):
+                out.append((f"layers.{li}.{bi}.stem.0", blk.stem[0]))
+                out.append((f"layers.{li}.{bi}.stem.3", blk.stem[3]))
+                if len(blk.shortcut):
+                    out.append((f"layers.{li}.{bi}.shortcut.0", blk.shortcut[0]))
+        out.append(("layers.9", self.layers[9]))
+        return out
+
+    def load_reference_state(self, st):
+        self.quant.activation_post_process.load(st, "quant.activation_post_process")
+        for n, m in self.stochastic_named():
+            m.load(st, n)
+        for li in (3, 4, 5, 6):
+            for bi, blk in enumerate(self.layers[li]):
+                blk.add.load(st, f"layers.{li}.{bi}.add.add.activation_post_process")
+        return self
+
+    def forward_mc(self, x):
+        h = self.layers[0](self.quant(nchw_to_mc_nhwc(x)))
+        for li in (3, 4, 5, 6):
+            for blk in self.layers[li]:
+                h = blk(h)
+        h = flatten_f32(pool2d_f32(h, 4, avg=True))
+        return softmax_f32(self.layers[9](h))
+
+    def forward(self, x):
+        with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
+            return self.forward_mc(x)[0]

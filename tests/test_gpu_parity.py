@@ -432,3 +432,44 @@ def test_float_bbb_conv_graphs_match_reference(name, model):
     with q.mc_context(1, 11, 5):
         p5 = m(x)
     np.testing.assert_allclose(p5.cpu().numpy(), fwd(g["x"], 11, 5), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name,model", [("mlp_bbb_qat.npz", "linear_bbb"), ("lenet_bbb_qat.npz", "conv_lenet_bbb"),
+                                        ("resnet_bbb_qat.npz", "conv_resnet_bbb")])
+def test_qat_eval_with_live_observers_matches_reference(name, model):
+    """the prepared (QAT) model in eval mode on the GPU -- all S samples in one batched pass with the
+    observer recurrence resolved on the device -- against S sequential reference forwards (same injected eps): per-sample
+    outputs, and every observer's final (min, max).  fp32 tolerance 1e-5 relative (+2e-6 absolute)."""
+    import os
+    import quantised_bayesian_nets_amd as q
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    st = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    args = types.SimpleNamespace(sigma_prior=-2.0, activation_precision=7, weight_precision=8, qat_eval=True)
+    shape = {"linear_bbb": [13], "conv_lenet_bbb": [1, 28, 28], "conv_resnet_bbb": [1, 3, 32, 32]}[model]
+    m = q.ModelFactory.get_model(model, shape, 1 if model == "linear_bbb" else 10, True, args).load_reference_state(st)
+    x = torch.from_numpy(d["x"]).cuda()
+    seed = int(d["meta.philox_seed"])
+    if model == "linear_bbb":
+        S = d["mu"].shape[0]
+        with q.mc_context(S, seed, 0):
+            mu, var = m.forward_mc(x)
+        np.testing.assert_allclose(mu.cpu().numpy(), d["mu"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(var.cpu().numpy(), d["var"], rtol=1e-5, atol=1e-8)
+    else:
+        S = d["probs"].shape[0]
+        with q.mc_context(S, seed, 0):
+            p = m.forward_mc(x)
+        np.testing.assert_allclose(p.cpu().numpy(), d["probs"], rtol=1e-5, atol=2e-6)
+    checked = 0
+    for k in d.files:
+        if k.startswith("final/") and k.endswith("min_val"):
+            prefix = k[len("final/"):-len(".activation_post_process.min_val")]
+            mod = m
+            for part in prefix.replace(".add.add.activation_post_process", ".add").replace(".mul_noise.activation_post_process", ".mul_noise") \
+                             .replace(".add_weight.activation_post_process", ".add_weight").split("."):
+                mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+            mn, mx = mod.min_max()
+            np.testing.assert_allclose(mn, float(d[k]), rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(mx, float(d[k.replace("min_val", "max_val")]), rtol=1e-4, atol=1e-5)
+            checked += 1
+    assert checked >= 20

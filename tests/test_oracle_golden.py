@@ -1,5 +1,7 @@
 """The oracle (oracle/qbnn_oracle.c) against the golden vectors recorded from the real reference
 (tests/golden/make_golden.py).  Integer tensors must match bit-for-bit; fp32 probabilities to 1e-5 rel."""
+import os
+
 import numpy as np
 import pytest
 
@@ -166,3 +168,26 @@ def test_ema_observer_matches_torch_fake_quantize():
             want = fq(torch.from_numpy(x)).numpy()
             got = ob.fake_quant(x)
             np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,kind", [("mlp_bbb_qat.npz", "mlp"), ("lenet_bbb_qat.npz", "lenet"), ("resnet_bbb_qat.npz", "resnet")])
+def test_qat_eval_with_live_observers_matches_reference(name, kind):
+    """prepared (QAT) BBB models in eval mode, observers live (conv_qat.py:26-49,139-167; linear_qat.py:18-41):
+    the oracle, run sample after sample, against S reference forwards with the same injected eps, and the observers'
+    final (min, max) against the reference's."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    st = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    net = orc.QATOracle(st)
+    seed = int(d["meta.philox_seed"])
+    if kind == "mlp":
+        for s in range(d["mu"].shape[0]):
+            mu, var = net.mlp(d["x"], seed, s)
+            np.testing.assert_allclose(mu, d["mu"][s], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(var, d["var"][s], rtol=1e-5, atol=1e-8)
+    else:
+        fwd = net.lenet if kind == "lenet" else net.resnet
+        for s in range(d["probs"].shape[0]):
+            np.testing.assert_allclose(fwd(d["x"], seed, s), d["probs"][s], rtol=1e-5, atol=2e-6)
+    for k, ob in net.obs.items():
+        np.testing.assert_allclose(ob.state[0], d["final/" + k + ".activation_post_process.min_val"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ob.state[1], d["final/" + k + ".activation_post_process.max_val"], rtol=1e-4, atol=1e-5)
