@@ -1653,6 +1653,8 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
   c.s_r = d->s_s; c.z_r = d->z_s; c.s_o = d->blk.s_o; c.z_o = d->blk.z_o;
   if ((rc = fill_qadd(a.add, &c))) return rc;
   hipStream_t st = (hipStream_t)stream;
+  // (a ping-pong variant of this block -- phases W / M_a / E_sa / M_b / E_b on two 4-wave groups -- measured 15 % SLOWER
+  //  than the weights-stationary kernel: five barrier intervals per image, each as long as the slower group's phase)
   if (Cin == 24 && H == 32) return ring_only() ? launch_block_down<D24_a, D24_s, D24_b>(a, st) : launch_block_down_ws<D24_a, D24_s, D24_b, true>(a, st);
   if (Cin == 48 && H == 16) return ring_only() ? launch_block_down<D48_a, D48_s, D48_b>(a, st) : launch_block_down_ws<D48_a, D48_s, D48_b, false>(a, st);
   if (Cin == 96 && H == 8) return ring_only() ? launch_block_down<D96_a, D96_s, D96_b>(a, st) : launch_block_down_ws<D96_a, D96_s, D96_b, false>(a, st);
@@ -1684,7 +1686,8 @@ __device__ __forceinline__ void dma_conv(uint8_t* dst, const int8_t* wq, int wav
 
 // The two halves of one MFMA pass (MB x NB output tiles of 32 pixels x 32 channels), separable so that a wave can
 // park its accumulators across a barrier (ping-pong kernels) -- conv_core runs them back to back.
-template <class C> struct ConvAcc { v16i acc[C::MB][C::NB]; int rsum[C::MB]; };
+template <int MB, int NB> struct ConvAccMN { v16i acc[MB][NB]; int rsum[MB]; };
+template <class C> using ConvAcc = ConvAccMN<C::MB, C::NB>;      // convs with equal blocking can share one accumulator set
 
 template <class C>
 __device__ __forceinline__ void conv_mfma_phase(const uint8_t* tile, const uint8_t* wconv, ConvAcc<C>& A, int pass, int lane) {
