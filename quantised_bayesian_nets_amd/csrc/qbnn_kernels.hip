@@ -339,6 +339,16 @@ __device__ __forceinline__ uint32_t pack_low_bytes(float t0, float t1, float t2,
   return p01 | p23;
 }
 __device__ __forceinline__ float med3f(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+// Four non-negative-clamped values -> one dword of bytes: v_cvt_pk_u8_f32 rounds to nearest-even and saturates to
+// [0, 255] (probed on gfx950: 0.5 -> 0, 1.5 -> 2, 2.5 -> 2, -0.6 -> 0, 300 -> 255), so  byte = rne(clamp(v, 0, hi))
+// costs min + cvt per element instead of med3 + magic-add + the v_perm packing.  Only where the lower clamp bound is 0
+// (ReLU-fused outputs stored centred on their zero point).
+__device__ __forceinline__ uint32_t pack_rne_u8(float v0, float v1, float v2, float v3, float hi) {
+  uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(v0, hi), 0u, 0u);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(v1, hi), 1u, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(v2, hi), 2u, r);
+  return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(v3, hi), 3u, r);
+}
 
 // the 16 bytes a lane contributes to a B-operand (pixel) fragment: one ds_read_b128 where pixels are 16-byte aligned
 template <class C>
@@ -1017,16 +1027,20 @@ __device__ __forceinline__ void dma_slab_if_ring(uint8_t* dst, const int8_t* wq,
 // ---- epilogue functors -----------------------------------------------------------------------------------------
 // (a) quint8 into a dense [M][COUT] staging buffer; optional quantized::add + ReLU against the quint8 residual that
 //     already sits at the same address (updated in place).
-template <int COUT, bool HAS_RES>
+template <int COUT, bool HAS_RES, int PITCH = COUT>
 struct EpiDense {
   static constexpr int VALU_PER_MFMA = HAS_RES ? 22 : 11;   // interleave hint: epilogue VALU ops of one 32-pixel row / 9 MFMAs
   uint8_t* outb; QConv p; QAdd a;
-  __device__ __forceinline__ int pixel(int m) const { return m * COUT; }
+  __device__ __forceinline__ int pixel(int m) const { return m * PITCH; }
   __device__ __forceinline__ uint32_t load(int po, int c0) const {
     return HAS_RES ? *reinterpret_cast<const uint32_t*>(outb + po + c0) : 0u;
   }
   __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
     uint32_t* o = reinterpret_cast<uint32_t*>(outb + po + c0);
+    if (!HAS_RES && p.vlo == 0.0f) {      // ReLU-fused conv (workgroup-uniform): non-negative centred bytes, then + z_y bytewise
+      *o = pack_rne_u8(v0, v1, v2, v3, p.vhi) + (uint32_t)p.z_y * 0x01010101u;
+      return;
+    }
     v0 = med3f(v0, p.vlo, p.vhi); v1 = med3f(v1, p.vlo, p.vhi); v2 = med3f(v2, p.vlo, p.vhi); v3 = med3f(v3, p.vlo, p.vhi);
     const float zy = (float)p.z_y;
     if (!HAS_RES) {
@@ -1034,7 +1048,6 @@ struct EpiDense {
       // would flip round-half-even ties
       *o = pack_low_bytes((v0 + QBNN_MAGIC) + zy, (v1 + QBNN_MAGIC) + zy, (v2 + QBNN_MAGIC) + zy, (v3 + QBNN_MAGIC) + zy);
     } else {
-      const float zo = (float)a.z_o;
       float t[4];
       const float vv[4] = {v0, v1, v2, v3};
       const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
@@ -1043,9 +1056,9 @@ struct EpiDense {
         const float qf = __builtin_rintf(vv[i]) + zy;                       // the conv output integer, exactly
         const float da = __builtin_fmaf(p.s_y, qf, p.nzs_y);
         const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
-        t[i] = (med3f((da + db) * a.inv_s_o, 0.0f, a.vhi) + QBNN_MAGIC) + zo;
+        t[i] = (da + db) * a.inv_s_o;
       }
-      *o = pack_low_bytes(t[0], t[1], t[2], t[3]);
+      *o = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi) + (uint32_t)a.z_o * 0x01010101u;      // bytes <= a_hi - z_o: no carry
     }
   }
 };
@@ -1065,9 +1078,7 @@ struct EpiTile {
   __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
   __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
     uint32_t* o = reinterpret_cast<uint32_t*>(dst + po + c0);
-    const float mg = QBNN_MAGIC;
-    *o = pack_low_bytes(med3f(v0, p.vlo, p.vhi) + mg, med3f(v1, p.vlo, p.vhi) + mg, med3f(v2, p.vlo, p.vhi) + mg,
-                        med3f(v3, p.vlo, p.vhi) + mg);
+    *o = pack_rne_u8(v0, v1, v2, v3, p.vhi);        // stem.0 is ConvReLU2d: p.vlo == 0 (set by the library, fill_qconv relu = 1)
   }
 };
 
@@ -1094,9 +1105,9 @@ struct EpiTileResInPlace {
       const float qf = __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)) + zy;
       const float da = __builtin_fmaf(p.s_y, qf, p.nzs_y);
       const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
-      t[i] = med3f((da + db) * a.inv_s_o, 0.0f, a.vhi) + QBNN_MAGIC;
+      t[i] = (da + db) * a.inv_s_o;
     }
-    *o = pack_low_bytes(t[0], t[1], t[2], t[3]);
+    *o = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
   }
 };
 
@@ -1626,7 +1637,7 @@ using D24_s = ConvCfg<24, 48, 1, 2, 32, 1, 1, 1, 2>;
 using D24_b = ConvCfg<48, 48, 3, 1, 16, 1, 1, 1, 2>;
 using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 4, 1, 3, false>;
 using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 4, 1, 3, false>;
-using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, false, 36, 16>;
+using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, false, 36, 8>;
 using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
 using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, 1, 3, false>;
 using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
@@ -1971,7 +1982,9 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
   fetch(begin);
   write_tile(begin);
   int cur_s = -1;
+  QBNN_STAMP_DECL
   for (int it = 0; it < count; ++it) {
+    QBNN_STAMP_START();
     const int item = begin + it * step;
     const int s = item / groups, img0 = (item - s * groups) * C::G;
     const bool more = it + 1 < count;
@@ -1988,7 +2001,9 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
       dma_barrier();             // vmcnt(0) + barrier: the weights have landed
       cur_s = s;
     }
+    QBNN_STAMP_AT(0);
     lds_barrier();
+    QBNN_STAMP_AT(1);
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) {
       const BlockParams& bp = a.blk[k];
@@ -1997,13 +2012,17 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
         if constexpr (LDSW) conv_core<C, decltype(epi), NWV>(xt, wl + (2 * k) * WB, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
         else conv_passes<C, decltype(epi), NWV>(xt, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
       }
+      QBNN_STAMP_AT(2);
       lds_barrier();
+      QBNN_STAMP_AT(3);
       {
         EpiTileResInPlace<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, bp.b, bp.add};
         if constexpr (LDSW) conv_core<C, decltype(epi), NWV>(tt, wl + (2 * k + 1) * WB, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
         else conv_passes<C, decltype(epi), NWV>(tt, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
       }
+      QBNN_STAMP_AT(4);
       lds_barrier();
+      QBNN_STAMP_AT(5);
     }
     // ---- X tile interior (centred by the last add's zero point) -> quint8 registers; next item's input -> X tile;
     //      registers -> HBM.  The stores are issued last so that nothing ever waits on them: the only vmcnt waits
@@ -2033,7 +2052,12 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
         }
       }
     }
+    QBNN_STAMP_AT(6);
   }
+#ifdef QBNN_STAMP
+  if (a.dbg && (tid & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(a.dbg + wave * 8 + i, st_acc[i]);
+#endif
 }
 
 // =====================================================================================
@@ -2298,9 +2322,9 @@ struct EpiTileResGlobal {
       const float qf = __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)) + zy;
       const float da = __builtin_fmaf(p.s_y, qf, p.nzs_y);
       const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
-      t[i] = med3f((da + db) * a.inv_s_o, 0.0f, a.vhi) + QBNN_MAGIC;
+      t[i] = (da + db) * a.inv_s_o;
     }
-    *o = pack_low_bytes(t[0], t[1], t[2], t[3]);
+    *o = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
   }
 };
 
@@ -2541,9 +2565,7 @@ struct EpiDenseTile {
   __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
   __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
   __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
-    const float mg = QBNN_MAGIC;
-    *reinterpret_cast<uint32_t*>(dst + po + c0) =
-        pack_low_bytes(med3f(v0, p.vlo, p.vhi) + mg, med3f(v1, p.vlo, p.vhi) + mg, med3f(v2, p.vlo, p.vhi) + mg, med3f(v3, p.vlo, p.vhi) + mg);
+    *reinterpret_cast<uint32_t*>(dst + po + c0) = pack_rne_u8(v0, v1, v2, v3, p.vhi);      // ConvReLU2d: p.vlo == 0
   }
 };
 template <int PIXB, int CCH>
@@ -2564,9 +2586,9 @@ struct EpiDenseTileResGlobal {
       const float qf = __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)) + zy;
       const float da = __builtin_fmaf(p.s_y, qf, p.nzs_y);
       const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
-      t[i] = med3f((da + db) * a.inv_s_o, 0.0f, a.vhi) + QBNN_MAGIC;
+      t[i] = (da + db) * a.inv_s_o;
     }
-    *reinterpret_cast<uint32_t*>(xt + po + c0) = pack_low_bytes(t[0], t[1], t[2], t[3]);
+    *reinterpret_cast<uint32_t*>(xt + po + c0) = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
   }
 };
 
@@ -2742,6 +2764,11 @@ static int launch_block_chain_ws(const ChainArgs<NBLK>& a, hipStream_t st) {
   return check_launch("qbnn_block_chain_i8_mc");
 }
 
+template <class CB> struct DownSC {
+  static constexpr int PITCH = CB::COUT + 8;
+  static constexpr int BYTES = (CB::M * PITCH + 15) / 16 * 16;
+};
+
 // weights-stationary when the chain's weights fit next to the tiles, else the slab ring
 template <class C, int NBLK>
 static int launch_chain_auto(const ChainArgs<NBLK>& a, hipStream_t st) {
@@ -2760,10 +2787,14 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
   constexpr int XB = CA::G * CA::TILE_BYTES + CA::TILE_SLACK;
   constexpr int TB = CB::G * CB::TILE_BYTES + CB::TILE_SLACK;
   constexpr int COUT = CB::COUT;
+  // SC: the block's shortcut / output staging buffer, quint8 [M][COUT] with the pixel pitch padded by 8 bytes: the
+  // epilogues touch it with one dword per lane at 32 consecutive pixels, and a pitch of 48 / 96 / 192 bytes is a
+  // 4- / 8- / 16-way bank conflict (32 banks for 4-byte accesses); 56 / 104 / 200 are 2-way, which is free.
+  constexpr int SCP = DownSC<CB>::PITCH, SC_BYTES = DownSC<CB>::BYTES;
   uint8_t* xt = smem;
   uint8_t* tt = smem + XB;
   uint8_t* sc = tt + TB;
-  uint8_t* wl_s = sc + CB::OUT_BYTES;
+  uint8_t* wl_s = sc + SC_BYTES;
   uint8_t* wl_a = wl_s + (LDSW ? WConv<CS>::BYTES : 0);
   uint8_t* wl_b = wl_a + (LDSW ? WConv<CA>::BYTES : 0);
   float* bias_lds = reinterpret_cast<float*>(wl_b + (LDSW ? WConv<CB>::BYTES : 0));       // [3][COUT]: s, a, b
@@ -2837,7 +2868,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
     }
     lds_barrier();       // X complete; the previous item's SC has been read out by every thread
     {
-      EpiDense<COUT, false> epi{sc, a.s, a.add};
+      EpiDense<COUT, false, SCP> epi{sc, a.s, a.add};
       if constexpr (LDSW) conv_core<CS, decltype(epi), BLK_WAVES>(xt, wl_s, bias_lds, a.s, epi, wave, lane);
       else conv_passes<CS, decltype(epi), BLK_WAVES>(xt, a.s.w + (int64_t)s * a.s.w_ss, bias_lds, a.s, epi, wave, lane);
     }
@@ -2848,25 +2879,27 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
     }
     lds_barrier();       // T and SC complete
     {
-      EpiDense<COUT, true> epi{sc, a.b, a.add};
+      EpiDense<COUT, true, SCP> epi{sc, a.b, a.add};
       if constexpr (LDSW) conv_core<CB, decltype(epi), BLK_WAVES>(tt, wl_b, bias_lds + 2 * COUT, a.b, epi, wave, lane);
       else conv_passes<CB, decltype(epi), BLK_WAVES>(tt, a.b.w + (int64_t)s * a.b.w_ss, bias_lds + 2 * COUT, a.b, epi, wave, lane);
     }
     lds_barrier();
     if (more) write_tile(item + step);      // before the stores: its vmcnt wait then covers only the (old) input loads
     {
-      constexpr int IMG_OUT = CB::HO * CB::HO * COUT;
+      constexpr int IMG_OUT = CB::HO * CB::HO * COUT, U8 = COUT / 8;          // 8-byte units (the padded pitch is 8-aligned)
       uint8_t* ys = a.y + (int64_t)s * a.y_ss;
-      for (int i = tid; i < CB::M * COUT / 16; i += BLK_THREADS)
-        if (img0 + (i * 16) / IMG_OUT < a.B)
-          *reinterpret_cast<v4i*>(ys + (int64_t)img0 * IMG_OUT + (int64_t)i * 16) = reinterpret_cast<const v4i*>(sc)[i];
+      for (int i = tid; i < CB::M * U8; i += BLK_THREADS)
+        if (img0 + (i * 8) / IMG_OUT < a.B) {
+          const int px = i / U8, within = i - px * U8;
+          *reinterpret_cast<v2i*>(ys + (int64_t)img0 * IMG_OUT + (int64_t)i * 8) = *reinterpret_cast<const v2i*>(sc + px * SCP + within * 8);
+        }
     }
   }
 }
 
 template <class CA, class CS, class CB, bool LDSW>
 static int launch_block_down_ws(const DownArgs& a, hipStream_t st) {
-  constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + CB::OUT_BYTES +
+  constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + DownSC<CB>::BYTES +
                       (LDSW ? WConv<CS>::BYTES + WConv<CA>::BYTES + WConv<CB>::BYTES : 0) + 3 * CB::COUT * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr = false;
