@@ -143,7 +143,16 @@ typedef struct qbnn_down_desc {
   qbnn_block_desc blk;
   const int8_t* w_s; int64_t w_s_sample_stride; const float* bias_s;   /* shortcut.0 sampled weights, bias */
   float s_ws; int32_t z_ws;                                            /* shortcut.0 add_weight qparams    */
-  float s_s; int32_t z_s;                                              /* shortcut.0 output qparams        */
+  float s_s; int32_t z_s;                                              /* layers.0 (ConvReLU2d 3 -> 24 on the centred 27-tap patches of qbnn_im2col3x3_c3, shared by all samples) fused in front
+ * of the 32x32x24 identity chain of qbnn_block_chain_i8_mc: the first conv's output (the network's largest activation)
+ * never reaches HBM.  Same arithmetic as qbnn_conv2d_i8_mc(x_is_centered_im2col) followed by the chain.
+ * Replaces models_bbb.py:226-232 (layers.0 ... layers.3) of the converted model. */
+int qbnn_stem_chain_i8_mc(const int8_t* im2col, int32_t B, const int8_t* w0_packed, int64_t w0_sample_stride, const float* bias0,
+                          float s_x, float s_w0, int32_t z_w0, float s_y0, int32_t z_y0, int32_t a_hi,
+                          const qbnn_block_desc* host_blocks, int32_t n_blocks, uint8_t* y, int64_t y_sample_stride,
+                          int32_t n_samples, void* stream);
+
+/* shortcut.0 output qparams        */
 } qbnn_down_desc;
 
 int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x, int32_t z_x, int32_t B, int32_t H,

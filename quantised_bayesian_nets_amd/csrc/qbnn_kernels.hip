@@ -1242,6 +1242,8 @@ struct ChainArgs {
   int z_in;                           // zero point of x
   unsigned long long* dbg;            // diagnostic builds only
   BlockParams blk[NBLK];
+  const int8_t* stem_x;               // fused layer-0 conv (STEM kernels): centred im2col patches [B][32*32][32], shared by the samples
+  QConv stem;
 };
 
 // workgroup size per geometry: 256 threads (4 waves) where two workgroups fit a CU -- they run out of phase, so one's
@@ -1913,8 +1915,14 @@ __device__ __forceinline__ void item_range(int n_items, int b, int nb, int& begi
 // LDSW = false: the block's weights are too large for LDS -- every wave streams its fragments from L2 (conv_passes) and
 //               the workgroups walk the items interleaved (item = blockIdx.x + i * gridDim.x), so that all of them
 //               work on the same MC sample at a time and its weights stay hot in L2.  Same barrier / prefetch scheme.
-template <class C, int NBLK, bool LDSW>
+// STEM = true (layer 1 only): the network's first conv (3 -> 24 channels, on the pre-gathered 27-tap patches) runs inside
+//               the same kernel -- its output never goes to HBM (that tensor is the largest of the network: 629 MB per
+//               100-sample step written and read back).  The item's input is then its image's patch block (32 KiB,
+//               shared by all samples, L2-resident), staged in a dense LDS tile; conv0's epilogue writes the X tile.
+template <class C, int NBLK, bool LDSW, bool STEM = false>
 __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const ChainArgs<NBLK> a) {
+  using C0 = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;      // layer 0 on the patch tensor: K = 27 -> 32, one k-step
+  static_assert(!STEM || (LDSW && C::CIN == 24 && C::HIN == 32 && C::G == 1), "the fused stem feeds the 32x32x24 chain");
   static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int NTHR = BLK_THREADS, NWV = BLK_WAVES;
@@ -1924,10 +1932,14 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
   uint8_t* tt = smem + TILES;
   uint8_t* wl = smem + 2 * TILES;                                            // [NBLK][2] whole convs
   float* bias_lds = reinterpret_cast<float*>(wl + 2 * NBLK * WB);            // [NBLK][2][COUT]
+  uint8_t* im = reinterpret_cast<uint8_t*>(bias_lds + NBLK * 2 * C::COUT);   // STEM: patch tile [1024][32], stem weights, stem bias
+  uint8_t* wl0 = im + C0::TILE_BYTES;
+  float* bias0 = reinterpret_cast<float*>(wl0 + WConv<C0>::BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
-  constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
+  constexpr int NCH_IN = STEM ? C0::TILE_BYTES / 16 : NCH;                  // ... of its input (the patch block when STEM)
+  constexpr int PER_T = (NCH_IN + NTHR - 1) / NTHR, PER_TO = (NCH + NTHR - 1) / NTHR;
   const int groups = (a.B + C::G - 1) / C::G;
   int begin, count, step;
   if (LDSW) {
@@ -1946,10 +1958,17 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
     load_bias<C::COUT, NTHR>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
     load_bias<C::COUT, NTHR>(bias_lds + (2 * k + 1) * C::COUT, a.blk[k].b.bias, tid);
   }
+  if (STEM) load_bias<C0::COUT, NTHR>(bias0, a.stem.bias, tid);
 
   v4i pre[PER_T];
   auto fetch = [&](int item) {
     const int s = item / groups, img0 = (item - s * groups) * C::G;
+    if constexpr (STEM) {
+      const uint8_t* xs = reinterpret_cast<const uint8_t*>(a.stem_x) + (int64_t)(img0 < a.B ? img0 : 0) * C0::TILE_BYTES;
+#pragma unroll
+      for (int j = 0; j < PER_T; ++j) pre[j] = *reinterpret_cast<const v4i*>(xs + (int64_t)(tid + j * NTHR) * 16);
+      return;
+    }
     const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
 #pragma unroll
     for (int j = 0; j < PER_T; ++j) {
@@ -1964,6 +1983,11 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
   // the previous item), so no barrier separates the two.
   auto write_tile = [&](int item) {
     const int s = item / groups, img0 = (item - s * groups) * C::G;
+    if constexpr (STEM) {          // the patches are already centred; conv0 produces the X tile
+#pragma unroll
+      for (int j = 0; j < PER_T; ++j) *reinterpret_cast<v4i*>(im + (tid + j * NTHR) * 16) = pre[j];
+      return;
+    }
     const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
 #pragma unroll
     for (int j = 0; j < PER_T; ++j) {
@@ -1998,12 +2022,18 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
         dma_conv<C, NWV>(wl + (2 * k) * WB, a.blk[k].a.w + (int64_t)s * a.blk[k].a.w_ss, wave, lane);
         dma_conv<C, NWV>(wl + (2 * k + 1) * WB, a.blk[k].b.w + (int64_t)s * a.blk[k].b.w_ss, wave, lane);
       }
+      if (STEM) dma_conv<C0, NWV>(wl0, a.stem.w + (int64_t)s * a.stem.w_ss, wave, lane);
       dma_barrier();             // vmcnt(0) + barrier: the weights have landed
       cur_s = s;
     }
     QBNN_STAMP_AT(0);
     lds_barrier();
     QBNN_STAMP_AT(1);
+    if constexpr (STEM) {        // layers.0 (ConvReLU2d): patch tile -> X tile, centred on its own zero point (= a.z_in)
+      EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, a.stem};
+      conv_core<C0, decltype(epi), NWV>(im, wl0, bias0, a.stem, epi, wave, lane);
+      lds_barrier();
+    }
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) {
       const BlockParams& bp = a.blk[k];
@@ -2030,9 +2060,9 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
     {
       const uint32_t z4 = (uint32_t)a.blk[NBLK - 1].add.z_o * 0x01010101u;
       uint8_t* ys = a.y + (int64_t)s * a.y_ss;
-      v4i outv[PER_T];
+      v4i outv[PER_TO];
 #pragma unroll
-      for (int j = 0; j < PER_T; ++j) {
+      for (int j = 0; j < PER_TO; ++j) {
         const int i = tid + j * NTHR;
         if (i < NCH) {
           const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
@@ -2043,7 +2073,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
       }
       if (more) write_tile(item + step);
 #pragma unroll
-      for (int j = 0; j < PER_T; ++j) {
+      for (int j = 0; j < PER_TO; ++j) {
         const int i = tid + j * NTHR;
         if (i < NCH) {
           const int g = i / CPI, rem = i - g * CPI;
@@ -2747,20 +2777,21 @@ static int launch_block_chain_ald(const ChainArgs<1>& a, hipStream_t st) {
   return check_launch("qbnn_block_chain_i8_mc");
 }
 
-template <class C, int NBLK, bool LDSW = true> constexpr int chain_ws_lds() {
-  return 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + (LDSW ? 2 * NBLK * WConv<C>::BYTES : 0) + NBLK * 2 * C::COUT * 4;
+template <class C, int NBLK, bool LDSW = true, bool STEM = false> constexpr int chain_ws_lds() {
+  return 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + (LDSW ? 2 * NBLK * WConv<C>::BYTES : 0) + NBLK * 2 * C::COUT * 4 +
+         (STEM ? 32 * 32 * 32 + 1024 + 24 * 4 : 0);
 }
 
-template <class C, int NBLK, bool LDSW = true>
+template <class C, int NBLK, bool LDSW = true, bool STEM = false>
 static int launch_block_chain_ws(const ChainArgs<NBLK>& a, hipStream_t st) {
-  constexpr int LDS = chain_ws_lds<C, NBLK, LDSW>();
+  constexpr int LDS = chain_ws_lds<C, NBLK, LDSW, STEM>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_chain_ws_kernel<C, NBLK, LDSW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  if (!attr) { hipFuncSetAttribute((const void*)block_chain_ws_kernel<C, NBLK, LDSW, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
   const int grid = n_items < 256 ? n_items : 256;
-  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, LDSW>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, LDSW, STEM>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
   return check_launch("qbnn_block_chain_i8_mc");
 }
 
@@ -2929,9 +2960,10 @@ using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false, 36, 16>;
 template <int NBLK>
 static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
                                 int32_t a_hi, const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples,
-                                hipStream_t st) {
+                                hipStream_t st, const int8_t* stem_x = nullptr, const QConv* stem = nullptr) {
   ChainArgs<NBLK> a;
   memset(&a, 0, sizeof(a));
+  if (stem) { a.stem_x = stem_x; a.stem = *stem; }
   a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = B; a.n_samples = n_samples; a.z_in = z_x;
 #ifdef QBNN_STAMP
   a.dbg = g_stamp_buf;
@@ -2951,6 +2983,10 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
     if ((rc = fill_qadd(a.blk[k].add, &d))) return rc;
     a.blk[k].add.lut = b.add_lut; a.blk[k].add.z_y = b.z_b;
     s_in = b.s_o; z_in = b.z_o;
+  }
+  if (stem) {
+    if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
+    return launch_block_chain_ws<Blk_24, NBLK, true, true>(a, st);
   }
   if (Cc == 24 && H == 32) return launch_chain_auto<Blk_24, NBLK>(a, st);
   if (Cc == 48 && H == 16) {
@@ -2986,6 +3022,27 @@ QBNN_EXPORT int qbnn_block_chain_i8_mc(const uint8_t* x, int64_t x_ss, float s_x
   if (n_blocks == 1) return block_chain_dispatch<1>(x, x_ss, s_x, z_x, B, H, Cc, a_hi, host_blocks, y, y_ss, n_samples, st);
   if (n_blocks == 2) return block_chain_dispatch<2>(x, x_ss, s_x, z_x, B, H, Cc, a_hi, host_blocks, y, y_ss, n_samples, st);
   return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: 1 or 2 blocks per launch%s");
+}
+
+QBNN_EXPORT int qbnn_stem_chain_i8_mc(const int8_t* im2col, int32_t B, const int8_t* w0_packed, int64_t w0_ss, const float* bias0,
+                                      float s_x, float s_w0, int32_t z_w0, float s_y0, int32_t z_y0, int32_t a_hi,
+                                      const qbnn_block_desc* host_blocks, int32_t n_blocks, uint8_t* y, int64_t y_ss,
+                                      int32_t n_samples, void* stream) {
+  if (!im2col || !w0_packed || !y || !host_blocks || n_samples <= 0 || B <= 0) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: bad argument%s");
+  for (int k = 0; k < n_blocks; ++k)
+    if (!host_blocks[k].w_a || !host_blocks[k].w_b) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: NULL weights%s");
+  qbnn_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.a_hi = a_hi; d.s_x = s_x; d.z_x = 0; d.s_w = s_w0; d.z_w = z_w0; d.s_y = s_y0; d.z_y = z_y0; d.relu = 1; d.has_bias = bias0 != nullptr;
+  QConv stem;
+  memset(&stem, 0, sizeof(stem));
+  int rc = fill_qconv(stem, w0_packed, w0_ss, bias0, &d);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  // the chain's input is conv0's output: scale s_y0, zero point z_y0
+  if (n_blocks == 1) return block_chain_dispatch<1>(nullptr, 0, s_y0, z_y0, B, 32, 24, a_hi, host_blocks, y, y_ss, n_samples, st, im2col, &stem);
+  if (n_blocks == 2) return block_chain_dispatch<2>(nullptr, 0, s_y0, z_y0, B, 32, 24, a_hi, host_blocks, y, y_ss, n_samples, st, im2col, &stem);
+  return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: 1 or 2 blocks per launch%s");
 }
 
 // =====================================================================================

@@ -6,6 +6,7 @@ Mirror of reference src/models/stochastic/bbb/models_bbb.py: BasicBlock (:146-18
 a converted reference checkpoint loads by key.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -111,11 +112,13 @@ USE_ADD_LUT = False      # measured on MI355X: the table's random LDS byte reads
                          # (layer-1 chain 1.50 -> 1.76 ms); kept selectable for future layouts
 
 
-def run_identity_chain(blocks, x):
+def run_identity_chain(blocks, x, stem=None):
     """1 or 2 identity BasicBlocks (no shortcut conv) in ONE persistent fused kernel (qbnn_block_chain_i8_mc):
-    activations stay in LDS between stem.0, stem.3 and the residual add.  Same results as calling the blocks."""
+    activations stay in LDS between stem.0, stem.3 and the residual add.  Same results as calling the blocks.
+    `stem` = (layers.0 module, its sampled weights, im2col patches [B, 1024, 32], input scale): the network's first conv
+    runs inside the same kernel (qbnn_stem_chain_i8_mc) and `x` only carries conv0's output qparams / shape."""
     S = _MC.samples
-    dev = x.data.device
+    dev = x.data.device if stem is None else stem[2].device
     descs = (_lib.BlockDesc * len(blocks))()
     keep = []
     s_res, z_res = x.scale, x.zero_point
@@ -135,17 +138,37 @@ def run_identity_chain(blocks, x):
         d.w_b, d.w_b_sample_stride, d.bias_b = wb.data_ptr(), wb.shape[1], (pb["bias"].data_ptr() if pb["bias"] is not None else None)
         d.s_wb, d.z_wb, d.s_b, d.z_b = cb.add_weight.scale, cb.add_weight.zero_point, cb.scale, cb.zero_point
         d.s_o, d.z_o = blk.add.add.scale, blk.add.add.zero_point
+    a_hi = UINT_BOUNDS[blocks[0].args.activation_precision][1]
+    nw = lambda l: l._packed["cout"] * l._packed["k"]
+    if stem is not None:
+        l0, w0, col, s_in = stem
+        B, H, W, Cc = col.shape[0], 32, 32, 24
+        pk0 = l0._ensure_packed(dev)
+        y = torch.empty((S, B, H, W, Cc), dtype=torch.uint8, device=dev)
+        key = "stem + block_chain_i8 x%d %dx%d c%d" % (len(blocks), H, W, Cc)
+        meta = dict(fused=True, convs=[(H, 3, Cc, 3, 1, nw(l0))] + [(H, Cc, Cc, 3, 1, nw(c)) for b in blocks for c in (b.stem[0], b.stem[3])])
+        with timed(key, meta):
+            _lib.check(_lib.lib().qbnn_stem_chain_i8_mc(_lib.ptr(col), B, _lib.ptr(w0), w0.shape[1], _lib.ptr(pk0["bias"]), s_in,
+                                                        l0.add_weight.scale, l0.add_weight.zero_point, l0.scale, l0.zero_point, a_hi,
+                                                        descs, len(blocks), _lib.ptr(y), y[0].numel(), S, _lib.current_stream()))
+        last = blocks[-1].add.add
+        return MCQTensor(y, last.scale, last.zero_point)
     _, B, H, W, Cc = x.data.shape
     y = torch.empty((S, B, H, W, Cc), dtype=torch.uint8, device=dev)
-    a_hi = UINT_BOUNDS[blocks[0].args.activation_precision][1]
     key = "block_chain_i8 x%d %dx%d c%d" % (len(blocks), H, W, Cc)
-    nw = lambda l: l._packed["cout"] * l._packed["k"]
     meta = dict(fused=True, convs=[(H, Cc, Cc, 3, 1, nw(c)) for b in blocks for c in (b.stem[0], b.stem[3])])
     with timed(key, meta):
         _lib.check(_lib.lib().qbnn_block_chain_i8_mc(_lib.ptr(x.data), x.sample_stride(), x.scale, x.zero_point, B, H, Cc, a_hi,
                                                      descs, len(blocks), _lib.ptr(y), y[0].numel(), S, _lib.current_stream()))
     last = blocks[-1].add.add
     return MCQTensor(y, last.scale, last.zero_point)
+
+
+class _QParamsOnly:
+    """(scale, zero point) of a tensor that is never materialised (conv0's output inside the fused stem kernel)."""
+
+    def __init__(self, scale, zero_point):
+        self.scale, self.zero_point, self.data = scale, zero_point, None
 
 
 class QuantStub(nn.Module):
@@ -182,6 +205,7 @@ class ConvNetwork_ResNet(nn.Module):
         self.quant = QuantStub()
         self.dequant = ident()
         self.fuse_blocks = True        # False: every conv as its own launch (layer-level C ABI), for A/B checks
+        self.fuse_stem = os.environ.get("QBNN_NO_STEM_FUSION", "0") != "1"    # layers.0 inside the layer-1 chain kernel
         # Philox tensor ids = execution order of the stochastic layers
         for i, m in enumerate(self.stochastic_layers()):
             m.layer_id = i
@@ -259,10 +283,17 @@ class ConvNetwork_ResNet(nn.Module):
         if not self.deterministic:
             sample_all_weights(self.stochastic_layers(), dev)      # one launch for the 21 layers of this MC batch
         l0 = self.layers[0]
-        h = l0._conv(xq, l0.sample_weights(dev), S, im2col=col)
+        fuse_stem = self.fuse_blocks and self.fuse_stem and record is None and len(self.layers[3][0].shortcut) == 0
+        if fuse_stem:
+            # layers.0 runs inside the layer-1 chain kernel: its output (the largest activation of the net) stays on chip
+            h = run_identity_chain(list(self.layers[3]), _QParamsOnly(l0.scale, l0.zero_point), stem=(l0, l0.sample_weights(dev), col, xq.scale))
+        else:
+            h = l0._conv(xq, l0.sample_weights(dev), S, im2col=col)
         if record is not None:
             record["layers.0.out"] = h.data
         for li in (3, 4, 5, 6):
+            if fuse_stem and li == 3:
+                continue
             blocks = list(self.layers[li])
             if self.fuse_blocks and record is None:
                 # identity blocks run as fused persistent chains; a down-sampling block 0 runs layer by layer
