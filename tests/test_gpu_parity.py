@@ -473,3 +473,19 @@ def test_qat_eval_with_live_observers_matches_reference(name, model):
             np.testing.assert_allclose(mx, float(d[k.replace("min_val", "max_val")]), rtol=1e-4, atol=1e-5)
             checked += 1
     assert checked >= 20
+
+
+def test_many_samples_fused_equals_layerwise(golden_w8):
+    """BASELINE config 3 size in the sample dimension too (B = 256, S = 48: every persistent workgroup walks dozens of work
+    items across several MC samples, reloading its LDS-resident weights on the way): the fully fused path (stem + chains +
+    down blocks) must equal the one-launch-per-conv path bit for bit, twice."""
+    import quantised_bayesian_nets_amd as q
+    m = _model(golden_w8)
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(256, 3, 32, 32, generator=gen).cuda()
+    with q.mc_context(48, 9, 100):
+        m.fuse_blocks = False
+        ref = m.forward_mc(x)
+        m.fuse_blocks = True
+        for _ in range(2):
+            assert torch.equal(m.forward_mc(x), ref)
