@@ -232,6 +232,12 @@ int qbnn_linear_f32_mc(const float* x, int64_t x_sample_stride, const float* w, 
                        float* y, int64_t y_sample_stride, int32_t B, int32_t K, int32_t N, int32_t act, int32_t n_samples,
                        void* stream);
 
+/* quantized::add of two quint8 tensors [S|1][n] (+ clamp_activation, ReLU = max(q, z_o), clamp_activation): the `Add` + `end`
+ * of a BasicBlock (src/utils.py:49-55, mcdropout/models_mc.py:156-160) when it cannot be fused into the preceding conv. */
+int qbnn_add_relu_q_mc(const uint8_t* a, int64_t a_sample_stride, float s_a, int32_t z_a, const uint8_t* b, int64_t b_sample_stride,
+                       float s_b, int32_t z_b, uint8_t* y, int64_t y_sample_stride, int64_t n, float s_o, int32_t z_o, int32_t a_hi,
+                       int32_t relu, int32_t n_samples, void* stream);
+
 /* ---- fp32 convolutional graphs (row a1: reference bbb/conv.py:33-39 eval branch, models_bbb.py:100-245) -------------- */
 
 /* Z_s = conv2d(X_s, W_s) (+ bias) (ReLU).  x [S|1][B][H][W][Cin] fp32 NHWC, w [S|1][Cout][Cin][k][k] in the REFERENCE's

@@ -760,3 +760,64 @@ class QATOracle:
                 inp = planes
         h = _pool_f32(h, 4, True).reshape(h.shape[0], -1)
         return _softmax_f32(self.linear("layers.9", lid, h, seed, sample, False, False))
+
+
+# --------------------------------------------- MC-Dropout ResNet, int8 ---
+class Int8ResNetMCOracle:
+    """`conv_resnet_mc` after prepare_model -> convert: reference mcdropout/models_mc.py:116-211 (graph: a channel dropout
+    after every conv), dropout.py:15-40 (quantised masks).  Mask draw order = execution order: layers.3, then per block
+    stem.3, stem.6, shortcut.2."""
+
+    def __init__(self, state, a_bits=7):
+        self.st, self.a_hi = state, UINT_BOUNDS[a_bits][1]
+
+    def conv(self, name, x, s, z, stride, pad, relu):
+        w = oihw_to_ohwi(np.asarray(self.st[name + ".weight"], np.int8))
+        sw, zw = float(self.st[name + ".weight.q_scale"]), int(self.st[name + ".weight.q_zero_point"])
+        sy, zy = float(self.st[name + ".scale"]), int(self.st[name + ".zero_point"])
+        b = self.st.get(name + ".bias", None)
+        return conv2d_i8(x, w, None if b is None else np.asarray(b, np.float32), stride, pad, s, z, sw, zw, sy, zy, relu, self.a_hi), sy, zy
+
+    def drop(self, name, di, x, s, z, seed, sample, masks):
+        s_m, z_m = float(self.st[name + ".mul_mask.scale"]), int(self.st[name + ".mul_mask.zero_point"])
+        mult = float(np.float32(np.asarray(self.st[name + ".multiplier"]).reshape(-1)[0]))
+        if masks is not None:
+            m = masks[di]
+        else:
+            keep = np.float32(1.0) - np.float32(np.asarray(self.st[name + ".p"]).reshape(-1)[0])
+            m = (fill_uniform(x.shape[0] * x.shape[-1], seed, di, sample) < keep).astype(np.float32).reshape(x.shape[0], x.shape[-1])
+        return dropout_q(x, m, z, s, s_m, z_m, self.a_hi), s_m * mult, z_m
+
+    def forward(self, x_nchw, seed, sample, masks=None, record=None):
+        st = self.st
+        s, z = float(np.asarray(st["quant.scale"]).reshape(-1)[0]), int(np.asarray(st["quant.zero_point"]).reshape(-1)[0])
+        h = quantize_input_nchw(x_nchw, s, z, self.a_hi)
+        di = 0
+        h, s, z = self.conv("layers.0", h, s, z, 1, 1, True)
+        h, s, z = self.drop("layers.3", di, h, s, z, seed, sample, masks); di += 1
+        if record is not None:
+            record["layers.3.out"] = h
+        inp = 24
+        for li, planes, stride in ((4, 24, 1), (5, 48, 2), (6, 96, 2), (7, 192, 2)):
+            for bi, stv in enumerate((stride, 1)):
+                p = f"layers.{li}.{bi}"
+                o, so, zo = self.conv(p + ".stem.0", h, s, z, stv, 1, True)
+                o, so, zo = self.drop(p + ".stem.3", di, o, so, zo, seed, sample, masks); di += 1
+                o, so, zo = self.conv(p + ".stem.4", o, so, zo, 1, 1, False)
+                o, so, zo = self.drop(p + ".stem.6", di, o, so, zo, seed, sample, masks); di += 1
+                sc, ss, zs = h, s, z
+                if stv != 1 or inp != planes:
+                    sc, ss, zs = self.conv(p + ".shortcut.0", h, s, z, stv, 0, False)
+                    sc, ss, zs = self.drop(p + ".shortcut.2", di, sc, ss, zs, seed, sample, masks); di += 1
+                s, z = float(st[p + ".add.add.scale"]), int(st[p + ".add.add.zero_point"])
+                h = qadd_relu(o, so, zo, sc, ss, zs, s, z, True, self.a_hi)
+                inp = planes
+                if record is not None:
+                    record[p + ".out"] = h
+        h = avgpool_q(h, 4, z, self.a_hi).reshape(h.shape[0], -1)
+        w = np.asarray(st["layers.10.weight"], np.int8)
+        sw, zw = float(st["layers.10.weight.q_scale"]), int(st["layers.10.weight.q_zero_point"])
+        sy, zy = float(st["layers.10.scale"]), int(st["layers.10.zero_point"])
+        b = st.get("layers.10.bias", None)
+        logits = linear_i8(h, w, None if b is None else np.asarray(b, np.float32), s, z, sw, zw, sy, zy, False, self.a_hi)
+        return dequant_softmax(logits, sy, zy)

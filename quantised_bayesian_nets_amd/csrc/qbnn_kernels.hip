@@ -3045,6 +3045,41 @@ QBNN_EXPORT int qbnn_stem_chain_i8_mc(const int8_t* im2col, int32_t B, const int
   return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: 1 or 2 blocks per launch%s");
 }
 
+// Stand-alone quantized::add (+ clamp_activation, ReLU, clamp_activation) for graphs where something sits between the
+// last conv of a block and its Add (MC-Dropout ResNet: mcdropout/models_mc.py:136-160).  Four elements per thread.
+__global__ __launch_bounds__(256) void add_relu_q_kernel(const uint8_t* __restrict__ a, int64_t a_ss, const uint8_t* __restrict__ b,
+                                                          int64_t b_ss, uint8_t* __restrict__ y, int64_t y_ss, int64_t n4, float s_a,
+                                                          float nzs_a, float s_b, float nzs_b, float inv_s_o, int z_o, int a_hi, int relu) {
+  const int s = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const uint32_t av = reinterpret_cast<const uint32_t*>(a + (int64_t)s * a_ss)[i];
+    const uint32_t bv = reinterpret_cast<const uint32_t*>(b + (int64_t)s * b_ss)[i];
+    uint32_t o = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float da = __builtin_fmaf(s_a, (float)((av >> (8 * j)) & 0xffu), nzs_a);
+      const float db = __builtin_fmaf(s_b, (float)((bv >> (8 * j)) & 0xffu), nzs_b);
+      int q = min(max(z_o + rne_sat((da + db) * inv_s_o), 0), 255);
+      q = min(q, a_hi);
+      if (relu) q = max(q, z_o);
+      o |= (uint32_t)q << (8 * j);
+    }
+    reinterpret_cast<uint32_t*>(y + (int64_t)s * y_ss)[i] = o;
+  }
+}
+
+QBNN_EXPORT int qbnn_add_relu_q_mc(const uint8_t* a, int64_t a_ss, float s_a, int32_t z_a, const uint8_t* b, int64_t b_ss, float s_b,
+                                   int32_t z_b, uint8_t* y, int64_t y_ss, int64_t n, float s_o, int32_t z_o, int32_t a_hi, int32_t relu,
+                                   int32_t n_samples, void* stream) {
+  if (!a || !b || !y || n <= 0 || (n & 3) || n_samples <= 0 || (a_ss & 3) || (b_ss & 3) || (y_ss & 3))
+    return fail(QBNN_E_INVALID, "qbnn_add_relu_q_mc: bad argument (element counts and strides must be multiples of 4)%s");
+  const int64_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(add_relu_q_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, a, a_ss, b, b_ss, y, y_ss, n4, s_a,
+                     (float)(-z_a) * s_a, s_b, (float)(-z_b) * s_b, 1.0f / s_o, z_o, a_hi, relu);
+  return check_launch("qbnn_add_relu_q_mc");
+}
+
 // =====================================================================================
 // Input quantisation, layer-0 im2col, head, MC reduction
 // =====================================================================================

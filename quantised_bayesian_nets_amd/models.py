@@ -402,6 +402,9 @@ class ModelFactory:
                 return ConvNetwork_LeNetF32(input_size, output_size, q, args)
             from .models_small import ConvNetwork_LeNet as ConvNetwork_LeNetBBB
             return ConvNetwork_LeNetBBB(input_size, output_size, q, args)
+        if model == "conv_resnet_mc":
+            from .models_mc import ConvNetwork_ResNet as ConvNetwork_ResNetMC
+            return ConvNetwork_ResNetMC(input_size, output_size, q, args)
         if model == "conv_lenet_mc":
             from .models_mc import ConvNetwork_LeNet as ConvNetwork_LeNetMC
             return ConvNetwork_LeNetMC(input_size, output_size, q, args)

@@ -239,3 +239,152 @@ class ConvNetwork_LeNet(nn.Module):
     def forward(self, x):
         with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
             return self.forward_mc(x)[0]
+
+
+class QConvReLU2d(QConv2d):
+    """torch.nn.intrinsic.quantized.ConvReLU2d (conv + folded BN + ReLU after convert)."""
+    relu = True
+
+
+def _load_dropout(d, state, prefix):
+    d.mul_mask = QFunctional(state[prefix + "mul_mask.scale"], state[prefix + "mul_mask.zero_point"])
+    d.p.data = torch.from_numpy(np.asarray(state[prefix + "p"], np.float32).reshape(1).copy())
+    d.multiplier.data = torch.from_numpy(np.asarray(state[prefix + "multiplier"], np.float32).reshape(1).copy())
+
+
+def add_relu_q(a, b, s_o, z_o, a_hi, relu=True):
+    """quantized::add + clamp + ReLU + clamp on two MCQTensors (either may be shared by the samples)."""
+    S = _MC.samples
+    da, db = a.data, b.data
+    n = da[0].numel()
+    y = torch.empty((S,) + tuple(da.shape[1:]), dtype=torch.uint8, device=da.device)
+    with timed("add_relu_q"):
+        _lib.check(_lib.lib().qbnn_add_relu_q_mc(_lib.ptr(da), a.sample_stride(), a.scale, a.zero_point, _lib.ptr(db), b.sample_stride(),
+                                                 b.scale, b.zero_point, _lib.ptr(y), n, n, s_o, z_o, a_hi, int(relu), S, _lib.current_stream()))
+    return MCQTensor(y, s_o, z_o)
+
+
+class BasicBlock(nn.Module):
+    """reference mcdropout/models_mc.py:116-160 after fuse_model + convert: stem = ConvReLU2d, -, -, Dropout, Conv2d, -, Dropout;
+    shortcut = Conv2d(1x1, stride), -, Dropout where the shape changes; add; end ReLU."""
+    expansion = 1
+
+    def __init__(self, in_planes, planes, stride=1, q=True, args=None):
+        super().__init__()
+        self.args = args
+        ident = nn.Identity
+        self.stem = nn.ModuleList([QConvReLU2d(in_planes, planes, 3, stride, 1, bias=True, args=args), ident(), ident(), BernoulliDropout(args.p),
+                                   QConv2d(planes, planes, 3, 1, 1, bias=True, args=args), ident(), BernoulliDropout(args.p)])
+        self.shortcut = nn.ModuleList([])
+        if stride != 1 or in_planes != planes:
+            self.shortcut.append(QConv2d(in_planes, planes, 1, stride, 0, bias=True, args=args))
+            self.shortcut.append(ident())
+            self.shortcut.append(BernoulliDropout(args.p))
+        self.add = QFunctional()
+
+    def dropouts(self):
+        return [self.stem[3], self.stem[6]] + ([self.shortcut[2]] if len(self.shortcut) else [])
+
+    def load_reference_state(self, state, prefix):
+        self.stem[0].load_reference_state(state, prefix + "stem.0.")
+        self.stem[4].load_reference_state(state, prefix + "stem.4.")
+        _load_dropout(self.stem[3], state, prefix + "stem.3.")
+        _load_dropout(self.stem[6], state, prefix + "stem.6.")
+        if len(self.shortcut):
+            self.shortcut[0].load_reference_state(state, prefix + "shortcut.0.")
+            _load_dropout(self.shortcut[2], state, prefix + "shortcut.2.")
+        self.add = QFunctional(state[prefix + "add.add.scale"], state[prefix + "add.add.zero_point"])
+
+    def forward(self, x, masks):
+        out = self.stem[3](self.stem[0](x), masks.pop(0) if masks is not None else None)
+        out = self.stem[6](self.stem[4](out), masks.pop(0) if masks is not None else None)
+        sc = x
+        if len(self.shortcut):
+            sc = self.shortcut[2](self.shortcut[0](x), masks.pop(0) if masks is not None else None)
+        return add_relu_q(out, sc, self.add.scale, self.add.zero_point, _a_hi(self.args))
+
+
+class ConvNetwork_ResNet(nn.Module):
+    """reference mcdropout/models_mc.py:162-211 (`conv_resnet_mc`), converted int8 form: deterministic quantised convs with a
+    channel dropout after every conv; every conv is its own launch (a dropout sits between each conv and the next)."""
+
+    def __init__(self, input_size, output_size, q, args):
+        super().__init__()
+        if not q:
+            raise NotImplementedError("only the converted int8 model (q=True) is built")
+        check_bits(args)
+        self.args, self.q = args, q
+        self.output_size = int(output_size)
+        ident = nn.Identity
+        self.layers = nn.ModuleList([QConvReLU2d(input_size[1], 24, 3, 1, 1, bias=True, args=args), ident(), ident(), BernoulliDropout(args.p)])
+        inp = 24
+        for planes, stride in ((24, 1), (48, 2), (96, 2), (192, 2)):
+            blocks = []
+            for st in (stride, 1):
+                blocks.append(BasicBlock(inp, planes, st, q, args))
+                inp = planes
+            self.layers.append(nn.ModuleList(blocks))
+        self.layers.append(ident())      # AvgPool2d(4)
+        self.layers.append(ident())      # Flatten
+        self.layers.append(QLinear(192, output_size, args=args))
+        for i, m in enumerate(self.dropouts()):
+            m.layer_id, m.args = i, args
+        from .models import QuantStub
+        self.quant = QuantStub()
+
+    def dropouts(self):
+        out = [self.layers[3]]
+        for li in (4, 5, 6, 7):
+            for blk in self.layers[li]:
+                out += blk.dropouts()
+        return out
+
+    def load_reference_state(self, state):
+        self.layers[0].load_reference_state(state, "layers.0.")
+        _load_dropout(self.layers[3], state, "layers.3.")
+        for li in (4, 5, 6, 7):
+            for bi, blk in enumerate(self.layers[li]):
+                blk.load_reference_state(state, f"layers.{li}.{bi}.")
+        self.layers[10].load_reference_state(state, "layers.10.")
+        self.quant.scale = float(np.asarray(state["quant.scale"]).reshape(-1)[0])
+        self.quant.zero_point = int(np.asarray(state["quant.zero_point"]).reshape(-1)[0])
+        return self
+
+    def forward_mc(self, x, record=None, masks=None):
+        """All S samples -> softmax probabilities [S, B, classes].  masks: optional list of fp32 [S, B, C] in draw order."""
+        if x.device.type != "cuda":
+            raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
+        S = _MC.samples
+        x = x.to(torch.float32).contiguous()
+        B, Cc, H, W = x.shape
+        a_hi = _a_hi(self.args)
+        xq = torch.empty((1, B, H, W, Cc), dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.lib().qbnn_quantize_input_nchw(_lib.ptr(x), B, Cc, H, W, self.quant.scale, self.quant.zero_point, a_hi, _lib.ptr(xq),
+                                                       _lib.current_stream()))
+        masks = list(masks) if masks is not None else None
+        h = MCQTensor(xq, self.quant.scale, self.quant.zero_point, shared=True)
+        h = self.layers[3](self.layers[0](h), masks.pop(0) if masks is not None else None)
+        if record is not None:
+            record["layers.3.out"] = h.data
+        for li in (4, 5, 6, 7):
+            for bi, blk in enumerate(self.layers[li]):
+                h = blk(h, masks)
+                if record is not None:
+                    record[f"layers.{li}.{bi}.out"] = h.data
+        fc = self.layers[10]
+        dev = fc._device_params(x.device, fc._weight.int_repr())
+        probs = torch.empty((S, B, self.output_size), dtype=torch.float32, device=x.device)
+        d = _lib.HeadDesc()
+        d.B, d.k, d.C, d.N = B, h.data.shape[2], h.data.shape[4], self.output_size
+        d.s_x, d.z_x = h.scale, h.zero_point
+        d.s_w, d.z_w = fc._weight.q_scale(), fc._weight.q_zero_point()
+        d.s_y, d.z_y = fc.scale, fc.zero_point
+        d.a_hi, d.has_bias = a_hi, int(dev["bias"] is not None)
+        with timed("head_i8"):
+            _lib.check(_lib.lib().qbnn_head_i8_mc(_lib.ptr(h.data), h.sample_stride(), _lib.ptr(dev["w"]), 0, _lib.ptr(dev["bias"]),
+                                                  _lib.ptr(probs), S, C.byref(d), _lib.current_stream()))
+        return probs
+
+    def forward(self, x):
+        with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
+            return self.forward_mc(x)[0]

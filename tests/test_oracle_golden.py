@@ -191,3 +191,17 @@ def test_qat_eval_with_live_observers_matches_reference(name, kind):
     for k, ob in net.obs.items():
         np.testing.assert_allclose(ob.state[0], d["final/" + k + ".activation_post_process.min_val"], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(ob.state[1], d["final/" + k + ".activation_post_process.max_val"], rtol=1e-4, atol=1e-5)
+
+
+def test_resnet_mc_dropout_matches_reference():
+    """SURVEY row a7 on the ResNet graph (mcdropout/models_mc.py:116-211): oracle vs the reference, bit-exact block outputs
+    for sample 0, 1e-5 on every sample's softmax output."""
+    from conftest import load_golden
+    g = load_golden("resnet_mc_a7w8.npz")
+    net = orc.Int8ResNetMCOracle(g["state"], 7)
+    rec = {}
+    p0 = net.forward(g["x"], g["meta"]["philox_seed"], 0, record=rec)
+    for k, v in g["rec"].items():
+        assert np.array_equal(rec[k[:-len(".out")] + ".out"], v), k
+    np.testing.assert_allclose(p0, g["probs"][0], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(net.forward(g["x"], g["meta"]["philox_seed"], 2), g["probs"][2], rtol=1e-5, atol=1e-8)
