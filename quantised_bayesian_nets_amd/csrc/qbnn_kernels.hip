@@ -227,7 +227,9 @@ struct QAdd {              // BasicBlock Add + ReLU (models_bbb.py:179-182)
 // buffer that nothing else reads.  The shipped library contains none of this.
 #ifdef QBNN_STAMP
 static unsigned long long* g_stamp_buf = nullptr;
-QBNN_EXPORT void qbnn_debug_stamp_buffer(void* p) { g_stamp_buf = (unsigned long long*)p; }
+__device__ unsigned long long* g_stamp_dev_ptr = nullptr;
+#define g_stamp_dev g_stamp_dev_ptr
+QBNN_EXPORT void qbnn_debug_stamp_buffer(void* p) { g_stamp_buf = (unsigned long long*)p; hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_dev_ptr), &p, sizeof(p)); }
 __device__ unsigned long long g_inner[4];
 QBNN_EXPORT void qbnn_debug_read_inner(unsigned long long* host4) {
   hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_inner), 32);
@@ -256,12 +258,17 @@ QBNN_EXPORT void qbnn_debug_read_inner(unsigned long long* host4) {
 #define QBNN_INNER_FLUSH() do {} while (0)
 #endif
 
+#ifndef QBNN_WDEPTH
+#define QBNN_WDEPTH 5
+#endif
 template <int CIN_, int COUT_, int KSZ_, int STRIDE_, int HIN_, int HALO_, int G_, int MB_, int NB_, bool RING_ = true, int SLAB_KB_ = 36, int PADB_ = 0>
 struct ConvCfg {
   // PADB: pad bytes after every pixel of the LDS input tile.  With 96 / 192 channels the 32 pixels of a B-operand
   // fragment sit 96 / 192 bytes apart = 4- / 8-way bank conflicts on every fragment read; +16 bytes makes the
   // stride 28 / 52 banks (2-way, like the 48-channel tiles).  Taps are then addressed one by one (CIN % 32 == 0).
   static constexpr int PADB = PADB_;
+  // depth (k-steps) of the weight register ring of conv_passes_stream; 0 = the chunked double-buffer form
+  static constexpr int WDEPTH = (!RING_ && CIN_ >= 48) ? QBNN_WDEPTH : 0;
   // RING: fused kernels stage this conv's weights through the LDS slab ring (conv_lds); false = every wave streams
   // its fragments from L2 (conv_passes) -- better when the conv's weights are far larger than the ring (192 channels)
   static constexpr bool RING = RING_;
@@ -483,6 +490,10 @@ __device__ __forceinline__ void conv_passes_rows(const uint8_t* tile, const int8
   }
 }
 
+template <class C, class Epi, int NWAVES>
+__device__ __forceinline__ void conv_passes_stream(const uint8_t* tile, const int8_t* wq, const float* bias_lds, const QConv& p,
+                                                   Epi& epi, int wave, int lane);      // defined next to conv_epi_phase
+
 // All MFMA passes of one conv over LDS-resident tiles.
 // Epilogue functor interface:  pre = epi.load(m, c0)   (residual dword or 0; issued ahead of the arithmetic)
 //                              epi.store(m, c0, v0..v3, pre)
@@ -495,6 +506,9 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
                                             Epi& epi, int wave, int lane) {
   if constexpr (C::ROWREUSE) {
     conv_passes_rows<C, Epi, NWAVES>(tile, wq, bias_lds, p, epi, wave, lane);
+    return;
+  } else if constexpr (C::WDEPTH > 0) {
+    conv_passes_stream<C, Epi, NWAVES>(tile, wq, bias_lds, p, epi, wave, lane);
     return;
   }
   const int r = lane & 31, h = lane >> 5;
@@ -1633,16 +1647,24 @@ static bool ring_only() {
   return v;
 }
 
+#ifndef QBNN_D48_MB
+#define QBNN_D48_MB 1
+#define QBNN_D48_NB 3
+#endif
+#ifndef QBNN_D96_MB
+#define QBNN_D96_MB 1
+#define QBNN_D96_NB 3
+#endif
 //                           CIN COUT K  S  HIN HALO G  MB NB
 using D24_a = ConvCfg<24, 48, 3, 2, 32, 1, 1, 1, 2>;
 using D24_s = ConvCfg<24, 48, 1, 2, 32, 1, 1, 1, 2>;
 using D24_b = ConvCfg<48, 48, 3, 1, 16, 1, 1, 1, 2>;
-using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 4, 1, 3, false>;
-using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 4, 1, 3, false>;
-using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, false, 36, 8>;
-using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
-using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, 1, 3, false>;
-using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
+using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 4, QBNN_D48_MB, QBNN_D48_NB, false>;
+using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 4, QBNN_D48_MB, QBNN_D48_NB, false>;
+using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 4, QBNN_D48_MB, QBNN_D48_NB, false, 36, 8>;
+using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 8, QBNN_D96_MB, QBNN_D96_NB, false>;
+using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, QBNN_D96_MB, QBNN_D96_NB, false>;
+using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, QBNN_D96_MB, QBNN_D96_NB, false>;
 
 QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cin,
                                       int32_t a_hi, const qbnn_down_desc* d, uint8_t* y, int64_t y_ss, int32_t n_samples,
@@ -1822,6 +1844,79 @@ __device__ __forceinline__ void conv_epi_phase_with(const float* bias_lds, const
 template <class C, class Epi>
 __device__ __forceinline__ void conv_epi_phase(const float* bias_lds, const QConv& p, Epi& epi, ConvAcc<C>& A, int pass, int lane) {
   conv_epi_phase_with<C, Epi>(bias_lds, p, epi, A, pass, lane, [&](int, int, int, int po, int c0) { return epi.load(po, c0); }, [](int) {});
+}
+
+// Streaming form of conv_passes for weights that come straight from L2 (no LDS staging): the wave's weight fragments
+// (NB tiles x 1 KiB per k-step, consecutive in the packed layout) run through a register ring WD k-steps deep -- an L2
+// round trip is 500-900 cycles, one k-step of MFMAs 32-200 -- while the pixel fragments come from LDS one k-step ahead.
+// Fully unrolled over K; no barrier inside.  (The earlier form double-buffered chunks of <= 3 k-steps and stalled on
+// every chunk: 18 stalls per 192-channel conv.)
+template <class C, class Epi, int NWAVES>
+__device__ __forceinline__ void conv_passes_stream(const uint8_t* tile, const int8_t* wq, const float* bias_lds, const QConv& p,
+                                                   Epi& epi, int wave, int lane) {
+  constexpr int WD = C::KS < C::WDEPTH ? C::KS : C::WDEPTH;
+  const int r = lane & 31, h = lane >> 5;
+  for (int pass = wave; pass < C::NPASS; pass += NWAVES) {
+    const int mblk = pass / C::NBLKS, nblk = pass - mblk * C::NBLKS;
+    const uint8_t* ap[C::MB];
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb) {
+      const int m = (mblk * C::MB + mb) * 32 + r;
+      const int g = m / (C::HO * C::HO), rem = m % (C::HO * C::HO);
+      const int oh = rem / C::HO, ow = rem % C::HO;
+      ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::PIXB + 16 * h;
+    }
+    const int8_t* wbase = wq + ((int64_t)(nblk * C::NB) * C::KS * 64 + lane) * 16;
+    ConvAcc<C> A;
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb) {
+      A.rsum[mb] = 0;
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) A.acc[mb][nb][i] = 0;
+    }
+    v4i wr[WD][C::NB];
+#pragma unroll
+    for (int k = 0; k < WD; ++k)
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb) wr[k][nb] = *reinterpret_cast<const v4i*>(wbase + ((int64_t)(nb * C::KS + k) * 64) * 16);
+    v4i x0[C::MB], x1[C::MB];
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb) x0[mb] = load_xfrag<C>(ap[mb] + C::step_off(0));
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      v4i* xc = (ks & 1) ? x1 : x0;
+      v4i* xn = (ks & 1) ? x0 : x1;
+      if (ks + 1 < C::KS) {
+#pragma unroll
+        for (int mb = 0; mb < C::MB; ++mb) xn[mb] = load_xfrag<C>(ap[mb] + C::step_off(ks + 1));
+      }
+      v4i w[C::NB];
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb) {
+        w[nb] = wr[ks % WD][nb];
+        if (ks + WD < C::KS) wr[ks % WD][nb] = *reinterpret_cast<const v4i*>(wbase + ((int64_t)(nb * C::KS + ks + WD) * 64) * 16);
+      }
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) {
+        if (!C::USE_ONES) {
+          const int m0 = (h ? C::piece_valid(ks, 1, 0) : C::piece_valid(ks, 0, 0)) ? 0x01010101 : 0;
+          const int m1 = (h ? C::piece_valid(ks, 1, 1) : C::piece_valid(ks, 0, 1)) ? 0x01010101 : 0;
+          int rs_ = A.rsum[mb];
+          rs_ = __builtin_amdgcn_sdot4(xc[mb].x, m0, rs_, false);
+          rs_ = __builtin_amdgcn_sdot4(xc[mb].y, m0, rs_, false);
+          rs_ = __builtin_amdgcn_sdot4(xc[mb].z, m1, rs_, false);
+          rs_ = __builtin_amdgcn_sdot4(xc[mb].w, m1, rs_, false);
+          A.rsum[mb] = rs_;
+        }
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+          A.acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb], xc[mb], A.acc[mb][nb], 0, 0, 0);
+      }
+    }
+    conv_epi_phase<C, Epi>(bias_lds, p, epi, A, pass, lane);
+  }
 }
 
 // conv over an LDS-resident tile with LDS-resident weights; no barrier inside.  Same arithmetic and epilogue
@@ -2884,7 +2979,9 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
   fetch(begin);
   write_tile(begin);
   int cur_s = -1;
+  QBNN_STAMP_DECL
   for (int it = 0; it < count; ++it) {
+    QBNN_STAMP_START();
     const int item = begin + it * step;
     const int s = item / groups, img0 = (item - s * groups) * CA::G;
     const bool more = it + 1 < count;
@@ -2897,7 +2994,9 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
       dma_barrier();
       cur_s = s;
     }
+    QBNN_STAMP_AT(0);
     lds_barrier();       // X complete; the previous item's SC has been read out by every thread
+    QBNN_STAMP_AT(1);
     {
       EpiDense<COUT, false, SCP> epi{sc, a.s, a.add};
       if constexpr (LDSW) conv_core<CS, decltype(epi), BLK_WAVES>(xt, wl_s, bias_lds, a.s, epi, wave, lane);
@@ -2908,14 +3007,19 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
       if constexpr (LDSW) conv_core<CA, decltype(epi), BLK_WAVES>(xt, wl_a, bias_lds + COUT, a.a, epi, wave, lane);
       else conv_passes<CA, decltype(epi), BLK_WAVES>(xt, a.a.w + (int64_t)s * a.a.w_ss, bias_lds + COUT, a.a, epi, wave, lane);
     }
+    QBNN_STAMP_AT(2);
     lds_barrier();       // T and SC complete
+    QBNN_STAMP_AT(3);
     {
       EpiDense<COUT, true, SCP> epi{sc, a.b, a.add};
       if constexpr (LDSW) conv_core<CB, decltype(epi), BLK_WAVES>(tt, wl_b, bias_lds + 2 * COUT, a.b, epi, wave, lane);
       else conv_passes<CB, decltype(epi), BLK_WAVES>(tt, a.b.w + (int64_t)s * a.b.w_ss, bias_lds + 2 * COUT, a.b, epi, wave, lane);
     }
+    QBNN_STAMP_AT(4);
     lds_barrier();
+    QBNN_STAMP_AT(5);
     if (more) write_tile(item + step);      // before the stores: its vmcnt wait then covers only the (old) input loads
+    QBNN_STAMP_AT(6);
     {
       constexpr int IMG_OUT = CB::HO * CB::HO * COUT, U8 = COUT / 8;          // 8-byte units (the padded pitch is 8-aligned)
       uint8_t* ys = a.y + (int64_t)s * a.y_ss;
@@ -2925,7 +3029,12 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
           *reinterpret_cast<v2i*>(ys + (int64_t)img0 * IMG_OUT + (int64_t)i * 8) = *reinterpret_cast<const v2i*>(sc + px * SCP + within * 8);
         }
     }
+    QBNN_STAMP_AT(7);
   }
+#ifdef QBNN_STAMP
+  if (g_stamp_dev && (tid & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(g_stamp_dev + wave * 8 + i, st_acc[i]);
+#endif
 }
 
 template <class CA, class CS, class CB, bool LDSW>
