@@ -1633,10 +1633,6 @@ static bool no_dense() {
   static const bool v = [] { const char* e = getenv("QBNN_NO_DENSE"); return e && e[0] == '1'; }();
   return v;
 }
-static bool no_aliased() {
-  static const bool v = [] { const char* e = getenv("QBNN_NO_ALIASED"); return e && e[0] == '1'; }();
-  return v;
-}
 static bool no_pingpong() {
   static const bool v = [] { const char* e = getenv("QBNN_NO_PINGPONG"); return e && e[0] == '1'; }();
   return v;
@@ -1647,24 +1643,16 @@ static bool ring_only() {
   return v;
 }
 
-#ifndef QBNN_D48_MB
-#define QBNN_D48_MB 1
-#define QBNN_D48_NB 3
-#endif
-#ifndef QBNN_D96_MB
-#define QBNN_D96_MB 1
-#define QBNN_D96_NB 3
-#endif
 //                           CIN COUT K  S  HIN HALO G  MB NB
 using D24_a = ConvCfg<24, 48, 3, 2, 32, 1, 1, 1, 2>;
 using D24_s = ConvCfg<24, 48, 1, 2, 32, 1, 1, 1, 2>;
 using D24_b = ConvCfg<48, 48, 3, 1, 16, 1, 1, 1, 2>;
-using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 4, QBNN_D48_MB, QBNN_D48_NB, false>;
-using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 4, QBNN_D48_MB, QBNN_D48_NB, false>;
-using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 4, QBNN_D48_MB, QBNN_D48_NB, false, 36, 8>;
-using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 8, QBNN_D96_MB, QBNN_D96_NB, false>;
-using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, QBNN_D96_MB, QBNN_D96_NB, false>;
-using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, QBNN_D96_MB, QBNN_D96_NB, false>;
+using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 4, 1, 3, false>;
+using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 4, 1, 3, false>;
+using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, false, 36, 8>;
+using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
+using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, 1, 3, false>;
+using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
 
 QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cin,
                                       int32_t a_hi, const qbnn_down_desc* d, uint8_t* y, int64_t y_ss, int32_t n_samples,
@@ -2348,252 +2336,16 @@ static int launch_block_chain_pp(const ChainArgs<NBLK>& a, hipStream_t st) {
 // =====================================================================================
 // Wide identity block (96 / 192 channels): the block's weights (162 / 663 KiB per MC sample) neither fit in LDS nor
 // can every wave afford to stream its own copy from L2, so they pass ONCE per work item through a two-slab LDS ring
-// (global_load_lds) shared by the 8 waves.  To leave room for the ring at G = 8 images per item the stem.0 output T
-// overwrites the input tile X IN PLACE: each conv runs as two workgroup-wide phases,
+// (global_load_lds) shared by the 8 waves.  To leave room for the ring the stem.0 output T overwrites the input tile X
+// IN PLACE: each conv runs as two workgroup-wide phases,
 //     M: every wave accumulates its MB x NB output tiles over all weight slabs (reads the tile),
 //     E: after a barrier, every wave requantises its accumulators and writes them over the tile,
 // and the residual operand of the Add is re-read from global memory (the block input, L2-hot, quint8) instead of
 // being kept in LDS.  One pass per wave: C::NPASS == 8.
-// =====================================================================================
-template <class C, class FNext>
-__device__ __forceinline__ void conv_ring_mfma(const uint8_t* tile, uint8_t* rbase, int& rcur, const int8_t* wq, ConvAcc<C>& A, int wave, int lane,
-                                               FNext prefetch_next) {
-  static_assert(C::NPASS == 8 && C::SLK % C::KCHUNK == 0 && C::SLAB_ALIGNED, "one pass per wave; k-chunks inside a slab; slabs = whole rows / taps");
-  const int r = lane & 31, h = lane >> 5;
-  const int mblk = wave / C::NBLKS, nblk = wave - mblk * C::NBLKS;
-  const uint8_t* ap[C::MB];
-#pragma unroll
-  for (int mb = 0; mb < C::MB; ++mb) {
-    const int m = (mblk * C::MB + mb) * 32 + r;
-    const int g = m / (C::HO * C::HO), rem = m % (C::HO * C::HO);
-    const int oh = rem / C::HO, ow = rem % C::HO;
-    ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::PIXB + 16 * h;
-  }
-#pragma unroll
-  for (int mb = 0; mb < C::MB; ++mb) {
-    A.rsum[mb] = 0;
-#pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) A.acc[mb][nb][i] = 0;
-  }
-  constexpr int U = C::KCHUNK, CPS = C::SLK / U;
-  struct Frags { v4i w[U][C::NB]; v4i x[U][C::MB]; };
-#pragma unroll 1
-  for (int slab = 0; slab < C::NSLAB; ++slab) {
-    dma_barrier();            // slab landed; everyone is done with the other buffer; slab 0: tile complete
-    uint8_t* other = rbase + (rcur ^ 1) * C::SLAB_BYTES;      // (pointer arithmetic: an indexed pointer pair would live in scratch)
-    if (slab + 1 < C::NSLAB) dma_slab<C, 8>(other, wq, slab + 1, wave, lane);
-    else prefetch_next(other);
-    const uint8_t* wl = rbase + rcur * C::SLAB_BYTES + ((nblk * C::NB) * C::SLK * 64 + lane) * 16;
-    rcur ^= 1;
-    const int aoff0 = C::slab_off(slab);
-    auto load_chunk = [&](Frags& f, int c) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int nb = 0; nb < C::NB; ++nb) f.w[u][nb] = *reinterpret_cast<const v4i*>(wl + (nb * C::SLK + c * U + u) * 1024);
-#pragma unroll
-        for (int mb = 0; mb < C::MB; ++mb) f.x[u][mb] = load_xfrag<C>(ap[mb] + aoff0 + C::step_off(c * U + u));
-      }
-    };
-    auto mfma_chunk = [&](const Frags& f, int c) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int mb = 0; mb < C::MB; ++mb) {
-          if (!C::USE_ONES) {        // padded tiles: every byte of a k-step is data
-            int rs_ = A.rsum[mb];
-            rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].x, 0x01010101, rs_, false);
-            rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].y, 0x01010101, rs_, false);
-            rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].z, 0x01010101, rs_, false);
-            rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].w, 0x01010101, rs_, false);
-            A.rsum[mb] = rs_;
-          }
-#pragma unroll
-          for (int nb = 0; nb < C::NB; ++nb)
-            A.acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[u][nb], f.x[u][mb], A.acc[mb][nb], 0, 0, 0);
-        }
-      }
-    };
-    Frags f0, f1;
-    load_chunk(f0, 0);
-#pragma unroll
-    for (int c = 0; c < CPS; ++c) {
-      Frags& cur = (c & 1) ? f1 : f0;
-      Frags& nxt = (c & 1) ? f0 : f1;
-      if (c + 1 < CPS) load_chunk(nxt, c + 1);
-      mfma_chunk(cur, c);
-    }
-  }
-}
-
-// conv -> Add(residual from global, quint8) -> ReLU, centred block output into the tile
-template <int HO, int PIXB, int TILE_BYTES, int CCH>
-struct EpiTileResGlobal {
-  uint8_t* xt; const uint8_t* res; int n_valid_px; QConv p; QAdd a;    // res: this item's block input [G*HO*HO][CCH]
-  __device__ __forceinline__ int pixel(int m) const { return m; }
-  __device__ __forceinline__ uint32_t load(int m, int c0) const {
-    return m < n_valid_px ? *reinterpret_cast<const uint32_t*>(res + (int64_t)m * CCH + c0) : 0u;
-  }
-  __device__ __forceinline__ void store(int m, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
-    uint32_t* o = reinterpret_cast<uint32_t*>(xt + tile_px_off<HO, PIXB, TILE_BYTES>(m, 0) + c0);
-    const float zy = (float)p.z_y;
-    const float vv[4] = {v0, v1, v2, v3};
-    const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
-    float t[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float qf = __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)) + zy;
-      const float da = __builtin_fmaf(p.s_y, qf, p.nzs_y);
-      const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
-      t[i] = (da + db) * a.inv_s_o;
-    }
-    *o = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
-  }
-};
-
-template <class C>
-__global__ __launch_bounds__(512) void block_chain_al_kernel(const ChainArgs<1> a) {
-  static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1 && C::CIN % 32 == 0, "wide identity BasicBlock");
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr int NTHR = 512;
-  constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
-  uint8_t* xt = smem;
-  uint8_t* rbase = smem + TILES;                                             // two weight slabs
-  int rcur = 0;
-  float* bias_lds = reinterpret_cast<float*>(rbase + 2 * C::SLAB_BYTES);     // [2][COUT]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const BlockParams& bp = a.blk[0];
-
-  constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;
-  constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
-  constexpr int IMG_PX = C::HO * C::HO;
-  const int groups = (a.B + C::G - 1) / C::G;
-  const int n_items = a.n_samples * groups;
-  const int step = gridDim.x;                       // interleaved walk: all workgroups on the same sample -> weights L2-hot
-  const int count = (int)blockIdx.x < n_items ? (n_items - (int)blockIdx.x + step - 1) / step : 0;
-
-  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, NTHR>(xt, tid);
-  load_bias<C::COUT, NTHR>(bias_lds, bp.a.bias, tid);
-  load_bias<C::COUT, NTHR>(bias_lds + C::COUT, bp.b.bias, tid);
-  if (count <= 0) return;
-
-  v4i pre[PER_T];
-  auto fetch = [&](int item) {
-    const int s = item / groups, img0 = (item - s * groups) * C::G;
-    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
-#pragma unroll
-    for (int j = 0; j < PER_T; ++j) {
-      const int i = tid + j * NTHR;
-      const int g = i / CPI, rem = i - g * CPI;
-      const bool ok = (i < NCH) && (img0 + g < a.B);
-      const int64_t off = ok ? ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16 : 0;
-      pre[j] = *reinterpret_cast<const v4i*>(xs + off);
-    }
-  };
-  auto write_tile = [&](int item) {
-    const int s = item / groups, img0 = (item - s * groups) * C::G;
-    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
-#pragma unroll
-    for (int j = 0; j < PER_T; ++j) {
-      const int i = tid + j * NTHR;
-      if (i < NCH) {
-        const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
-        const bool ok = img0 + g < a.B;
-        const v4i v = pre[j];
-        uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
-        *reinterpret_cast<v4i*>(d) = ok ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)}
-                                        : v4i{0, 0, 0, 0};
-      }
-    }
-  };
-  auto wbase = [&](const QConv& q, int item) { return q.w + (int64_t)(item / groups) * q.w_ss; };
-
-  fetch(blockIdx.x);
-  write_tile(blockIdx.x);
-  dma_slab<C, 8>(rbase, wbase(bp.a, blockIdx.x), 0, wave, lane);
-  ConvAcc<C> A;
-  for (int it = 0; it < count; ++it) {
-    const int item = blockIdx.x + it * step;
-    const int s = item / groups, img0 = (item - s * groups) * C::G;
-    const bool more = it + 1 < count;
-    const int next = more ? item + step : item;
-    // ---- stem.0: M over the X tile, then T over it
-    conv_ring_mfma<C>(xt, rbase, rcur, wbase(bp.a, item), A, wave, lane,
-                      [&](uint8_t* dst) { dma_slab<C, 8>(dst, wbase(bp.b, item), 0, wave, lane); });
-    lds_barrier();                                       // every wave has read its last X fragment
-    {
-      EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, bp.a};
-      conv_epi_phase<C, decltype(epi)>(bias_lds, bp.a, epi, A, wave, lane);
-    }
-    // ---- stem.3: M over T; the next item's input is requested during the last slab
-    const int valid = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX;
-    EpiTileResGlobal<C::HO, C::PIXB, C::TILE_BYTES, C::COUT> epi_b{xt, a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_PX * C::COUT, valid, bp.b, bp.add};
-    // this wave's residual dwords: M-tile 0 is requested during the last weight slab, M-tile mb + 1 while mb is requantised
-    uint32_t resq[2][C::NB][4];
-    auto load_res = [&](int mb) {
-      const int mblk = wave / C::NBLKS, nblk = wave - mblk * C::NBLKS;
-#pragma unroll
-      for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-          resq[mb & 1][nb][g4] = epi_b.load((mblk * C::MB + mb) * 32 + (lane & 31), (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * (lane >> 5));
-    };
-    conv_ring_mfma<C>(xt, rbase, rcur, wbase(bp.b, item), A, wave, lane,
-                      [&](uint8_t* dst) { if (more) dma_slab<C, 8>(dst, wbase(bp.a, next), 0, wave, lane); load_res(0); fetch(next); });
-    lds_barrier();
-    conv_epi_phase_with<C, decltype(epi_b)>(bias_lds + C::COUT, bp.b, epi_b, A, wave, lane,
-                                            [&](int mb, int nb, int g4, int, int) { return resq[mb & 1][nb][g4]; },
-                                            [&](int mb) { if (mb + 1 < C::MB) load_res(mb + 1); });
-    lds_barrier();
-    // ---- tile interior -> quint8 registers; next input -> tile; registers -> HBM
-    {
-      const uint32_t z4 = (uint32_t)bp.add.z_o * 0x01010101u;
-      uint8_t* ys = a.y + (int64_t)s * a.y_ss;
-      v4i outv[PER_T];
-#pragma unroll
-      for (int j = 0; j < PER_T; ++j) {
-        const int i = tid + j * NTHR;
-        if (i < NCH) {
-          const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
-          const v4i v = *reinterpret_cast<const v4i*>(xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within));
-          outv[j] = v4i{(int)add_bytes(v.x, z4), (int)add_bytes(v.y, z4), (int)add_bytes(v.z, z4), (int)add_bytes(v.w, z4)};
-        }
-      }
-      write_tile(next);       // unconditional (the last item rewrites itself): a prefetch left unconsumed on one path
-                              // makes the compiler guard every later reuse of those registers with vmcnt(0)
-#pragma unroll
-      for (int j = 0; j < PER_T; ++j) {
-        const int i = tid + j * NTHR;
-        if (i < NCH) {
-          const int g = i / CPI, rem = i - g * CPI;
-          if (img0 + g < a.B)
-            *reinterpret_cast<v4i*>(ys + ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16) = outv[j];
-        }
-      }
-    }
-  }
-}
-
-template <class C>
-static int launch_block_chain_al(const ChainArgs<1>& a, hipStream_t st) {
-  constexpr int LDS = C::G * C::TILE_BYTES + C::TILE_SLACK + 2 * C::SLAB_BYTES + 2 * C::COUT * 4;
-  static_assert(LDS <= 160 * 1024, "LDS budget");
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_chain_al_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-  const int groups = (a.B + C::G - 1) / C::G;
-  const int n_items = a.n_samples * groups;
-  const int grid = n_items < 256 ? n_items : 256;
-  hipLaunchKernelGGL((block_chain_al_kernel<C>), dim3(grid), dim3(512), LDS, st, a);
-  return check_launch("qbnn_block_chain_i8_mc");
-}
-
-// =====================================================================================
-// Dense-tile variant of the aliased wide kernel.  With the 1-pixel halo an 8x8 / 4x4 map costs 1.56x / 2.25x its size
+// The tile is DENSE.  With the 1-pixel halo an 8x8 / 4x4 map costs 1.56x / 2.25x its size
 // in LDS; stored dense ([image][oh][ow][C + 16]) twice as many images fit next to the weight ring (8 at 96 channels,
 // 16 at 192), which doubles the MFMA work per weight slab (the slab's LDS-DMA latency hides behind it) and halves the
-// weight bytes moved per image.  Zero padding is then a per-lane address choice: a tap that falls outside the map
+// weight bytes moved per image.  (A halo'd variant with 8 images per item was 15 % slower at 192 channels.)  Zero padding is then a per-lane address choice: a tap that falls outside the map
 // reads a line of zeros instead.  The tap's position is a function of the slab / k-step only, so this costs a few
 // VALU operations per slab.
 // =====================================================================================
@@ -3055,9 +2807,7 @@ static int launch_block_down_ws(const DownArgs& a, hipStream_t st) {
 using Blk_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;
 using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;
 using Blk_96  = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, true, 36, 16>;
-using AL_96   = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;     // aliased-tile ring kernel: 8 images / item
-using AL_192  = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, true, 36, 16>;
-using ALD_96  = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;      // dense-tile variant, 8 waves
+using ALD_96  = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;      // dense aliased-tile ring kernel
 using ALD_192 = ConvCfg<192, 192, 3, 1, 4, 1, 16, 2, 3, true, 36, 16>;
 using PP_48   = ConvCfg<48, 48, 3, 1, 16, 1, 1, 2, 2>;          // per wave group of the ping-pong kernel
 #ifdef QBNN_EXP_NSPLIT
@@ -3107,14 +2857,12 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
   if (Cc == 96 && H == 8) {
     if constexpr (NBLK == 1) {
       if (!ring_only() && !no_dense()) return launch_block_chain_ald<ALD_96, 8>(a, st);
-      if (!ring_only() && !no_aliased()) return launch_block_chain_al<AL_96>(a, st);
     }
     return launch_block_chain<Blk_96, NBLK>(a, st);
   }
   if (Cc == 192 && H == 4) {
     if constexpr (NBLK == 1) {
       if (!ring_only() && !no_dense()) return launch_block_chain_ald<ALD_192, 8>(a, st);
-      if (!ring_only() && !no_aliased()) return launch_block_chain_al<AL_192>(a, st);
     }
     return ring_only() ? launch_block_chain<Blk_192, NBLK>(a, st) : launch_block_chain_ws<Blk_192, NBLK, false>(a, st);
   }
