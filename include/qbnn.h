@@ -169,7 +169,8 @@ int qbnn_im2col3x3_c3(const uint8_t* x, int32_t B, int32_t H, int32_t W, int32_t
 
 /* Network head for S samples: AvgPool2d(k) -> clamp -> Flatten -> int8 Linear -> clamp ->
  * DeQuantStub -> softmax     (models_bbb.py:209-211, :240-243; linear_q.py:80-94).
- *   x [S][B][k][k][C] uint8, w_rowmajor [S][N][C] int8 (QBNN_LAYOUT_ROWMAJOR), probs [S][B][N] fp32. */
+ *   x [S][B][k][k][C] uint8, w_rowmajor [S][N][C] int8 (QBNN_LAYOUT_ROWMAJOR), probs [S][B][N] fp32.
+ *   C <= 256, N <= 16 (one wave per image-sample, four lanes per class); sample strides of 0 share an operand. */
 typedef struct qbnn_head_desc {
   int32_t B, k, C, N;
   float s_x; int32_t z_x;

@@ -2999,7 +2999,7 @@ QBNN_EXPORT int qbnn_im2col3x3_c3(const uint8_t* x, int32_t B, int32_t H, int32_
   return check_launch("qbnn_im2col3x3_c3");
 }
 
-// head: one wave per (sample, image).  C <= 256 channels, N <= 64 classes.
+// head: one wave per (sample, image).  C <= 256 channels, N <= 16 classes (4 lanes per class).
 struct HeadArgs {
   const uint8_t* x; int64_t x_ss;
   const int8_t* w; int64_t w_ss;
@@ -3017,39 +3017,61 @@ __global__ __launch_bounds__(256) void head_i8_kernel(const HeadArgs a) {
   const int s = blockIdx.y;
   if (b >= a.B) return;
   const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)b * a.kk * a.C;
-  // AvgPool2d(k) on quint8, channels-last: q = clamp(rne((sum - kk z) / kk) + z, 0, 255); then clamp_activation
-  for (int c = lane; c < a.C; c += 64) {
-    int sum = 0;
-    for (int p = 0; p < a.kk; ++p) sum += xs[p * a.C + c];
-    int q = min(max(rne_sat((float)(sum - a.kk * a.z_x) * a.inv_kk) + a.z_x, 0), 255);
-    q = min(q, a.a_hi);
-    pooled[wave][c] = q - a.z_x;
+  // AvgPool2d(k) on quint8, channels-last: q = clamp(rne((sum - kk z) / kk) + z, 0, 255); then clamp_activation.
+  // Four channels per lane (one dword per pixel) when C is a multiple of 4.
+  if ((a.C & 3) == 0) {
+    for (int c4 = lane; c4 < a.C / 4; c4 += 64) {
+      int sum[4] = {0, 0, 0, 0};
+      for (int p = 0; p < a.kk; ++p) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(xs + p * a.C + 4 * c4);
+        sum[0] += v & 0xffu; sum[1] += (v >> 8) & 0xffu; sum[2] += (v >> 16) & 0xffu; sum[3] += v >> 24;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int q = min(max(rne_sat((float)(sum[j] - a.kk * a.z_x) * a.inv_kk) + a.z_x, 0), 255);
+        pooled[wave][4 * c4 + j] = min(q, a.a_hi) - a.z_x;
+      }
+    }
+  } else {
+    for (int c = lane; c < a.C; c += 64) {
+      int sum = 0;
+      for (int p = 0; p < a.kk; ++p) sum += xs[p * a.C + c];
+      int q = min(max(rne_sat((float)(sum - a.kk * a.z_x) * a.inv_kk) + a.z_x, 0), 255);
+      pooled[wave][c] = min(q, a.a_hi) - a.z_x;
+    }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same-wave LDS write -> read
   __builtin_amdgcn_wave_barrier();
+  // Linear: lane = (output n, quarter j of the channels); integer partial sums, then a 4-lane butterfly (exact, any order)
   const int8_t* ws = a.w + (int64_t)s * a.w_ss;
+  const int n = lane >> 2, j = lane & 3;
+  int acc = 0;
+  if (n < a.N) {
+    const int c_per = (a.C + 3) / 4, c0 = j * c_per, c1 = min(c0 + c_per, a.C);
+    for (int c = c0; c < c1; ++c) acc += pooled[wave][c] * ((int)ws[n * a.C + c] - a.z_w);
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
   float logit = -INFINITY;
-  if (lane < a.N) {
-    int acc = 0;
-    for (int c = 0; c < a.C; ++c) acc += pooled[wave][c] * ((int)ws[lane * a.C + c] - a.z_w);
+  if (n < a.N && j == 0) {
     float xf = (float)acc;
-    if (a.bias) xf = __builtin_fmaf(a.bias[lane], a.rcp, xf);
+    if (a.bias) xf = __builtin_fmaf(a.bias[n], a.rcp, xf);
     int q = min(max(a.z_y + rne_sat(xf * a.mult), 0), 255);
     q = min(q, a.a_hi);
     logit = (float)(q - a.z_y) * a.s_y;     // DeQuantStub
   }
   float mx = logit;
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  float e = lane < a.N ? expf(logit - mx) : 0.f;
+  float e = (n < a.N && j == 0) ? expf(logit - mx) : 0.f;
   float sum = e;
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-  if (lane < a.N) a.probs[((int64_t)s * a.B + b) * a.N + lane] = e / sum;
+  if (n < a.N && j == 0) a.probs[((int64_t)s * a.B + b) * a.N + n] = e / sum;
 }
 
 QBNN_EXPORT int qbnn_head_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* w, int64_t w_ss, const float* bias,
                                 float* probs, int32_t n_samples, const qbnn_head_desc* d, void* stream) {
   if (!x || !w || !probs || !d || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_head_i8_mc: bad argument%s");
-  if (d->C > 256 || d->N > 64 || d->C <= 0 || d->N <= 0) return fail(QBNN_E_INVALID, "qbnn_head_i8_mc: C <= 256 and N <= 64 required%s");
+  if (d->C > 256 || d->N > 16 || d->C <= 0 || d->N <= 0) return fail(QBNN_E_INVALID, "qbnn_head_i8_mc: C <= 256 and N <= 16 required%s");
   HeadArgs a;
   a.x = x; a.x_ss = x_ss; a.w = w; a.w_ss = w_ss; a.bias = d->has_bias ? bias : nullptr; a.probs = probs;
   a.B = d->B; a.kk = d->k * d->k; a.C = d->C; a.N = d->N;
