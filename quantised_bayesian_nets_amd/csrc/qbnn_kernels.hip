@@ -3088,7 +3088,15 @@ __global__ __launch_bounds__(256) void reduce_moments_kernel(const float* __rest
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float s1 = accumulate ? mom[i] : 0.f, s2 = accumulate ? mom[n + i] : 0.f;
-  for (int s = 0; s < S; ++s) {
+  int s = 0;
+  for (; s + 8 <= S; s += 8) {            // 8 independent loads in flight, summed in sample order
+    float p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = probs[(int64_t)(s + j) * n + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1 += p[j]; s2 += p[j] * p[j]; }
+  }
+  for (; s < S; ++s) {
     const float p = probs[(int64_t)s * n + i];
     s1 += p;
     s2 += p * p;
