@@ -148,3 +148,37 @@ def test_world_size_2_gloo_reduce_equals_single_process(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "OK" in outs[0]
+
+
+def test_model_factory_routes_and_loads_reference_state_without_a_gpu():
+    """Host logic only (no kernel launch): ModelFactory keeps the reference's names / switches (q, args.qat_eval), the
+    float / QAT / MC-Dropout graphs load the reference-format state dicts of the fixtures, and a CPU tensor is refused."""
+    import types
+    import numpy as np
+    import pytest
+    import torch
+    import quantised_bayesian_nets_amd as q
+    from conftest import load_golden
+
+    def st(name):
+        d = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+        return {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+
+    a = types.SimpleNamespace(sigma_prior=-2.0, activation_precision=7, weight_precision=8, p=0.1)
+    f = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, False, a).load_reference_state(st("resnet_bbb_f32.npz"))
+    assert type(f).__module__.endswith("models_f32") and len(f.stochastic_named()) == 21
+    assert [m.layer_id for _, m in f.stochastic_named()] == list(range(21))
+    aq = types.SimpleNamespace(**vars(a), qat_eval=True)
+    m = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, aq).load_reference_state(st("resnet_bbb_qat.npz"))
+    assert type(m).__module__.endswith("models_qat")
+    mn, mx = m.layers[0].weight_fake_quant.min_max()
+    assert np.isfinite(mn) and np.isfinite(mx) and mn < 0 < mx
+    c = m.layers[0].scale_factor()                         # conv_qat.py:140-141
+    assert c.shape == (24,) and bool((c > 0).all())
+    mc = q.ModelFactory.get_model("conv_resnet_mc", [1, 3, 32, 32], 10, True, a).load_reference_state(load_golden("resnet_mc_a7w8.npz")["state"])
+    assert len(mc.dropouts()) == 20 and [d.layer_id for d in mc.dropouts()] == list(range(20))
+    le = q.ModelFactory.get_model("conv_lenet_bbb", [1, 28, 28], 10, False, a).load_reference_state(st("lenet_bbb_f32.npz"))
+    with pytest.raises(RuntimeError):
+        le.forward_mc(torch.zeros(2, 1, 28, 28))           # no CPU fallback
+    with pytest.raises(NotImplementedError):
+        q.ModelFactory.get_model("no_such_model", [1, 3, 32, 32], 10, True, a)
