@@ -696,6 +696,29 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
   const int64_t total = (int64_t)L.cout * L.K;
   uint32_t cur_blk = 0xffffffffu;
   float nrm[4] = {0.f, 0.f, 0.f, 0.f};
+  if (L.layout == QBNN_LAYOUT_MFMA32 && ((L.K | L.krow) & 3) == 0) {
+    // Fast path (every conv but layers.0): the chunk's 16 weights are 4 whole Philox blocks -- element index
+    // n K + kh krow + j0 + j with all terms multiples of 4 -- and a block is valid or padding as a whole.  Straight-line:
+    // 4 x (Philox, Box-Muller, 4 weights), no per-element block tracking or selects.
+    const int64_t idx0 = (int64_t)n * L.K + kh * L.krow + j0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (ones_row && j0 + 4 * g < L.krow) ow[g] = 0x01010101u;
+      if (n < L.cout && j0 + 4 * g < L.krow) {
+        qbnn::normal4(qbnn::philox4x32_10((uint32_t)((idx0 >> 2) + g), L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi), nrm);
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int mu_q = (mw[g] << (24 - 8 * i)) >> 24;
+          const int sg_q = (sw[g] << (24 - 8 * i)) >> 24;
+          o |= ((uint32_t)sample_one(mu_q, sg_q, nrm[i], L.p) & 0xffu) << (8 * i);
+        }
+        ow[g] = o;
+      }
+    }
+    reinterpret_cast<v4i*>(L.out + (int64_t)s * L.out_ss)[chunk] = v4i{(int)ow[0], (int)ow[1], (int)ow[2], (int)ow[3]};
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     int64_t idx;
