@@ -1,0 +1,27 @@
+import sys, os, types, time, ctypes as C, numpy as np, torch
+os.environ["QBNN_LIB_OVERRIDE"] = os.path.abspath("scratch/libqbnn_STAMP0.so")
+sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+from conftest import load_golden
+import quantised_bayesian_nets_amd as q
+from quantised_bayesian_nets_amd import _lib
+from quantised_bayesian_nets_amd.layers import MCQTensor
+from quantised_bayesian_nets_amd.models import run_identity_chain
+g=load_golden('resnet_bbb_a7w8.npz')
+args=types.SimpleNamespace(activation_precision=7, weight_precision=8)
+m=q.ModelFactory.get_model('conv_resnet_bbb',[1,3,32,32],10,True,args).load_reference_state(g['state'])
+S,B=100,256
+def rnd(shape): return torch.randint(0,128,shape,dtype=torch.uint8,device='cuda')
+blocks, xs = list(m.layers[3]), (S,B,32,32,24)
+x = MCQTensor(rnd(xs), 0.05, 60)
+dbg = torch.zeros(64, dtype=torch.int64, device='cuda')
+L=_lib.lib(); L.qbnn_debug_stamp_buffer.argtypes=[C.c_void_p]
+with q.mc_context(S, 3, 0):
+    run_identity_chain(blocks, x); torch.cuda.synchronize()
+    L.qbnn_debug_stamp_buffer(C.c_void_p(dbg.data_ptr()))
+    run_identity_chain(blocks, x); torch.cuda.synchronize()
+d = dbg.cpu().numpy().reshape(8,8).astype(np.float64)
+n_items = S*B
+names=['fetch issue (+weights)','barrier','conv_a (x2)','barrier (x2)','conv_b (x2)','barrier (x2)','copy-out + next tile','-']
+print('c1 NBLK=2: cycles per image, waves 0 / 3 / 4 / 7')
+for i,n in enumerate(names): print('%-24s %8.0f %8.0f %8.0f %8.0f' % (n, d[0,i]/n_items, d[3,i]/n_items, d[4,i]/n_items, d[7,i]/n_items))
+print('total', d[0].sum()/n_items)
