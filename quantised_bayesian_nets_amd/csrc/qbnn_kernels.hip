@@ -2433,12 +2433,8 @@ __device__ __forceinline__ void conv_ring_mfma_dense(const uint8_t* tile, uint8_
     auto mfma_step = [&](const Frags& f) {
 #pragma unroll
       for (int mb = 0; mb < C::MB; ++mb) {
-        int rs_ = A.rsum[mb];
-        rs_ = __builtin_amdgcn_sdot4(f.x[mb].x, 0x01010101, rs_, false);
-        rs_ = __builtin_amdgcn_sdot4(f.x[mb].y, 0x01010101, rs_, false);
-        rs_ = __builtin_amdgcn_sdot4(f.x[mb].z, 0x01010101, rs_, false);
-        rs_ = __builtin_amdgcn_sdot4(f.x[mb].w, 0x01010101, rs_, false);
-        A.rsum[mb] = rs_;
+        // (no window sum here: 4 v_dot4 per fragment cost 11 % of the kernel; the epilogue gathers it from the
+        //  per-pixel channel sums kept beside the tile, see window_sum_from_table)
 #pragma unroll
         for (int nb = 0; nb < C::NB; ++nb)
           A.acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[nb], f.x[mb], A.acc[mb][nb], 0, 0, 0);
@@ -2462,12 +2458,40 @@ __device__ __forceinline__ void conv_ring_mfma_dense(const uint8_t* tile, uint8_
 template <int PIXB>
 struct EpiDenseTile {
   uint8_t* dst; QConv p;
+  mutable int csum;            // sum of the centred bytes this lane has written since the last flush (channel-sum table)
   __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
   __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
   __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
-    *reinterpret_cast<uint32_t*>(dst + po + c0) = pack_rne_u8(v0, v1, v2, v3, p.vhi);      // ConvReLU2d: p.vlo == 0
+    const uint32_t pk = pack_rne_u8(v0, v1, v2, v3, p.vhi);      // ConvReLU2d: p.vlo == 0
+    *reinterpret_cast<uint32_t*>(dst + po + c0) = pk;
+    csum = __builtin_amdgcn_sdot4((int)pk, 0x01010101, csum, false);
   }
 };
+
+// Window sum R(p) = sum over the 3x3 window and all channels of the centred tile bytes, needed because sampled weights
+// have a non-zero zero point (sum x'(W - z_w) = acc - z_w R).  The dense-tile kernel keeps S(p) = channel sum of pixel p in
+// a small LDS table, maintained where the tile is written (one v_dot4 per dword written, LDS atomic add), and gathers
+// the <= 9 neighbours here -- instead of 4 v_dot4 per pixel fragment inside the MFMA loop (x27 / x54 per conv).
+// Leaves R in A.rsum so that conv_epi_phase's (rsum + rsum of lane ^ 32) yields it.
+template <class C>
+__device__ __forceinline__ void window_sum_from_table(const int* tab, ConvAcc<C>& A, int pass, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int mblk = pass / C::NBLKS;
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb) {
+    const int m = (mblk * C::MB + mb) * 32 + r;
+    const int rem = m % (C::HO * C::HO), oh = rem / C::HO, ow = rem % C::HO;
+    int R = 0;
+#pragma unroll
+    for (int kh = -1; kh <= 1; ++kh)
+#pragma unroll
+      for (int kw = -1; kw <= 1; ++kw) {
+        const bool ok = (unsigned)(oh + kh) < (unsigned)C::HO && (unsigned)(ow + kw) < (unsigned)C::HO;
+        R += ok ? tab[m + kh * C::HO + kw] : 0;
+      }
+    A.rsum[mb] = h ? 0 : R;
+  }
+}
 template <int PIXB, int CCH>
 struct EpiDenseTileResGlobal {
   uint8_t* xt; const uint8_t* res; int n_valid_px; QConv p; QAdd a;
@@ -2508,6 +2532,8 @@ void block_chain_ald_kernel(const ChainArgs<1> a) {
   static_assert((DT::BYTES + C::PIXB) % 16 == 0, "ring alignment");
   int rcur = 0;
   float* bias_lds = reinterpret_cast<float*>(rbase + 2 * C::SLAB_BYTES);     // [2][COUT]
+  int* sx = reinterpret_cast<int*>(bias_lds + 2 * C::COUT);                  // channel sums of the X tile  [G * HO * HO]
+  int* stab = sx + C::G * C::HO * C::HO;                                     // ... of the T tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const BlockParams& bp = a.blk[0];
 
@@ -2521,9 +2547,17 @@ void block_chain_ald_kernel(const ChainArgs<1> a) {
   const int count = (int)blockIdx.x < n_items ? (n_items - (int)blockIdx.x + step - 1) / step : 0;
 
   for (int i = tid; i < C::PIXB / 4; i += NTHR) reinterpret_cast<uint32_t*>(xt + DT::BYTES)[i] = 0u;
+  for (int i = tid; i < 2 * C::G * C::HO * C::HO; i += NTHR) sx[i] = 0;
   load_bias<C::COUT, NTHR>(bias_lds, bp.a.bias, tid);
   load_bias<C::COUT, NTHR>(bias_lds + C::COUT, bp.b.bias, tid);
   if (count <= 0) return;
+  __syncthreads();                                   // tables are zero before the first tile write adds into them
+  auto dot16 = [](const v4i& c) {
+    int d = __builtin_amdgcn_sdot4(c.x, 0x01010101, 0, false);
+    d = __builtin_amdgcn_sdot4(c.y, 0x01010101, d, false);
+    d = __builtin_amdgcn_sdot4(c.z, 0x01010101, d, false);
+    return __builtin_amdgcn_sdot4(c.w, 0x01010101, d, false);
+  };
 
   // an item's images are contiguous in HBM: chunk i of the item is byte 16 i of that block
   v4i pre[PER_T];
@@ -2551,8 +2585,9 @@ void block_chain_ald_kernel(const ChainArgs<1> a) {
       if (i < NCH) {
         const int px = i / CPP, within = i - px * CPP;
         const v4i v = pre[j];
-        *reinterpret_cast<v4i*>(xt + px * C::PIXB + within * 16) =
-            i < valid ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v4i{0, 0, 0, 0};
+        const v4i c = i < valid ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v4i{0, 0, 0, 0};
+        *reinterpret_cast<v4i*>(xt + px * C::PIXB + within * 16) = c;
+        __hip_atomic_fetch_add(&sx[px], dot16(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   };
@@ -2576,8 +2611,17 @@ void block_chain_ald_kernel(const ChainArgs<1> a) {
     lds_barrier();                                       // every wave has read its last X fragment
     QBNN_STAMP_AT(1);
     {
-      EpiDenseTile<C::PIXB> epi{xt, bp.a};
-      conv_epi_phase<C, decltype(epi)>(bias_lds, bp.a, epi, A, wave, lane);
+      // stem.0 epilogue: window sums from the X table; the T table collects the channel sums of what is written
+      window_sum_from_table<C>(sx, A, wave, lane);
+      EpiDenseTile<C::PIXB> epi{xt, bp.a, 0};
+      auto flush = [&](int mb) {
+        const int v = epi.csum + __shfl_xor(epi.csum, 32);
+        epi.csum = 0;
+        if (lane < 32) __hip_atomic_fetch_add(&stab[((wave / C::NBLKS) * C::MB + mb) * 32 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      conv_epi_phase_with<C, decltype(epi)>(bias_lds, bp.a, epi, A, wave, lane, [&](int, int, int, int, int) { return 0u; },
+                                            [&](int mb) { if (mb > 0) flush(mb - 1); });
+      flush(C::MB - 1);
     }
     QBNN_STAMP_AT(2);
     // ---- stem.3: M over T; residual and next input are requested during the last slab
@@ -2597,12 +2641,15 @@ void block_chain_ald_kernel(const ChainArgs<1> a) {
     QBNN_STAMP_AT(3);
     lds_barrier();
     QBNN_STAMP_AT(4);
+    for (int i = tid; i < C::G * IMG_PX; i += NTHR) sx[i] = 0;          // X table: last read in the stem.0 epilogue; refilled by the tile write below
+    window_sum_from_table<C>(stab, A, wave, lane);
     conv_epi_phase_with<C, decltype(epi_b)>(bias_lds + C::COUT, bp.b, epi_b, A, wave, lane,
                                             [&](int mb, int nb, int g4, int, int) { return resq[mb & 1][nb][g4]; },
                                             [&](int mb) { if (mb + 1 < C::MB) load_res(mb + 1); });
     QBNN_STAMP_AT(5);
     lds_barrier();
     QBNN_STAMP_AT(6);
+    for (int i = tid; i < C::G * IMG_PX; i += NTHR) stab[i] = 0;        // T table: every wave has gathered from it
     // ---- per 16-byte chunk: tile -> quint8 register, next item's input -> the same tile bytes, register -> HBM (the
     //      item's output block is contiguous).  The next input is written unconditionally (the last item rewrites
     //      itself): a prefetch left unconsumed on one path makes the compiler guard later reuses with vmcnt(0).
@@ -2621,7 +2668,9 @@ void block_chain_ald_kernel(const ChainArgs<1> a) {
           const int px = i / CPP, within = i - px * CPP;
           v4i* cell = reinterpret_cast<v4i*>(xt + px * C::PIXB + within * 16);
           const v4i v = *cell, n = pre[j];
-          *cell = i < nvalid ? v4i{(int)sub_bytes(n.x, z4i), (int)sub_bytes(n.y, z4i), (int)sub_bytes(n.z, z4i), (int)sub_bytes(n.w, z4i)} : v4i{0, 0, 0, 0};
+          const v4i c = i < nvalid ? v4i{(int)sub_bytes(n.x, z4i), (int)sub_bytes(n.y, z4i), (int)sub_bytes(n.z, z4i), (int)sub_bytes(n.w, z4i)} : v4i{0, 0, 0, 0};
+          *cell = c;
+          __hip_atomic_fetch_add(&sx[px], dot16(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (i < valid)
             *reinterpret_cast<v4i*>(ys + (int64_t)i * 16) = v4i{(int)add_bytes(v.x, z4o), (int)add_bytes(v.y, z4o), (int)add_bytes(v.z, z4o), (int)add_bytes(v.w, z4o)};
         }
@@ -2637,7 +2686,7 @@ void block_chain_ald_kernel(const ChainArgs<1> a) {
 
 template <class C, int NWV>
 static int launch_block_chain_ald(const ChainArgs<1>& a, hipStream_t st) {
-  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4;
+  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)block_chain_ald_kernel<C, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
