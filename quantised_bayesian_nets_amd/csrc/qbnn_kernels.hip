@@ -1857,6 +1857,9 @@ __device__ __forceinline__ void conv_epi_phase(const float* bias_lds, const QCon
   conv_epi_phase_with<C, Epi>(bias_lds, p, epi, A, pass, lane, [&](int, int, int, int po, int c0) { return epi.load(po, c0); }, [](int) {});
 }
 
+// (Measured and not adopted here: taking the window sums from a channel-sum table as the dense wide kernel does. Without
+//  the v_dot4 chain in the loop the scheduler sinks every ring refill next to its use -- load, wait, MFMA -- 3x slower; with
+//  the schedule pinned by sched_barrier the table version is 5 % slower than this one.)
 // Streaming form of conv_passes for weights that come straight from L2 (no LDS staging): the wave's weight fragments
 // (NB tiles x 1 KiB per k-step, consecutive in the packed layout) run through a register ring WD k-steps deep -- an L2
 // round trip is 500-900 cycles, one k-step of MFMAs 32-200 -- while the pixel fragments come from LDS one k-step ahead.
