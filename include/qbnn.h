@@ -245,7 +245,7 @@ int qbnn_add_relu_q_mc(const uint8_t* a, int64_t a_sample_stride, float s_a, int
  * weight order (so qbnn_sample_weights_f32's noise index is the reference's element index), y [S][B][Ho][Wo][Cout].
  * Replaces F.conv2d at bbb/conv.py:38 / conv_qat.py:47,158.  Sample strides in elements; 0 = shared.
  * `relu` is a flag word: bit 0 = fused ReLU, bit 1 = accumulate in fp64 (one rounding of the exact sum; the QAT path
- * uses it because a fake-quantiser follows every conv). */
+ * uses it because a fake-quantiser follows every conv), bit 2 = w is stored [Cout][k][k][Cin] (qbnn_sample_weights_f32_ohwi). */
 int qbnn_conv2d_f32_mc(const float* x, int64_t x_sample_stride, const float* w, int64_t w_sample_stride, const float* bias, float* y,
                        int64_t y_sample_stride, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                        int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream);
@@ -277,6 +277,12 @@ int qbnn_softmax_f32_mc(const float* x, int64_t x_sample_stride, int32_t B, int3
 int qbnn_sample_weights_f32_strided(const float* mu, int64_t mu_sample_stride, const float* sigma, int64_t sigma_sample_stride,
                                     int64_t n, uint64_t seed, uint32_t layer_id, uint32_t sample_begin, int32_t n_samples,
                                     const float* eps_in, float* w_out, void* stream);
+
+/* Conv-weight form of the sampler above: same noise stream (indexed by the reference's [Cout][Cin][k][k] element order),
+ * output written [Cout][k][k][Cin] so that the K axis of the implicit GEMM is contiguous for qbnn_conv2d_f32_mc (flags bit 2). */
+int qbnn_sample_weights_f32_ohwi(const float* mu, int64_t mu_sample_stride, const float* sigma, int64_t sigma_sample_stride, int32_t Cout,
+                                 int32_t Cin, int32_t ksize, uint64_t seed, uint32_t layer_id, uint32_t sample_begin, int32_t n_samples,
+                                 const float* eps_in, float* w_out, void* stream);
 
 /* MovingAverageMinMaxObserver (averaging constant `avg_const`, active in eval) over the S samples IN ORDER, then
  * calculate_qparams (per-tensor affine, quant range [qmin, qmax]):  state = {min, max, seen?} is read and written

@@ -33,9 +33,44 @@ struct ConvF32Args {
   const float* bias;                 // [Cout] or null
   float* y; int64_t y_ss;            // [S][B][Ho][Wo][Cout]
   int B, H, W, Cin, Cout, KS, stride, pad, Ho, Wo, relu;
+  int w_ohwi;                        // weights stored [Cout][KH][KW][Cin] (flags bit 2) instead of the reference's [Cout][Cin][KH][KW]
 };
 
 constexpr int CF_KC = 16, CF_LD = CF_KC + 1;
+
+// Gather of one K chunk into registers (4 pixel values + 4 weight values per thread; the 16 threads of a row read 16
+// consecutive k = 64 contiguous bytes of the NHWC input, and of the weights when they are stored [Cout][KH][KW][Cin]).
+struct ConvF32Slots { int prow[4], pb[4], poh[4], pow_[4]; };
+__device__ __forceinline__ void conv_f32_slots(const ConvF32Args& a, int tid, int p0, int npix, ConvF32Slots& t) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 256 * j, row = e >> 4;
+    const int p = p0 + row;
+    t.prow[j] = row;
+    if (p < npix) { t.pb[j] = p / (a.Ho * a.Wo); const int rem = p - t.pb[j] * a.Ho * a.Wo; t.poh[j] = rem / a.Wo; t.pow_[j] = rem - t.poh[j] * a.Wo; }
+    else { t.pb[j] = -1; t.poh[j] = 0; t.pow_[j] = 0; }
+  }
+}
+__device__ __forceinline__ void conv_f32_gather(const ConvF32Args& a, const ConvF32Slots& t, const float* xs, const float* ws, int k0, int K,
+                                                int n0, int tid, float xv[4], float wv[4]) {
+  const int kk = k0 + (tid & 15);                    // same k column for all 4 slots of this thread
+  int kh = 0, kw = 0, c = 0;
+  const bool kok = kk < K;
+  if (kok) { kh = kk / (a.KS * a.Cin); const int r2 = kk - kh * a.KS * a.Cin; kw = r2 / a.Cin; c = r2 - kw * a.Cin; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xv[j] = 0.f;
+    if (kok && t.pb[j] >= 0) {
+      const int ih = t.poh[j] * a.stride - a.pad + kh, iw = t.pow_[j] * a.stride - a.pad + kw;
+      if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+        xv[j] = xs[(((int64_t)t.pb[j] * a.H + ih) * a.W + iw) * a.Cin + c];
+    }
+    wv[j] = 0.f;
+    const int n = n0 + t.prow[j];
+    if (kok && n < a.Cout)
+      wv[j] = a.w_ohwi ? ws[(int64_t)n * K + kk] : ws[(((int64_t)n * a.Cin + c) * a.KS + kh) * a.KS + kw];
+  }
+}
 
 __global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvF32Args a) {
   __shared__ float As[64 * CF_LD];     // weights  [n][k]
@@ -48,44 +83,21 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvF32Args a) {
   const int K = a.KS * a.KS * a.Cin;
   const float* xs = a.x + (int64_t)s * a.x_ss;
   const float* ws = a.w + (int64_t)s * a.w_ss;
-
-  // this thread's 4 gather slots per operand and chunk: element e = tid + 256 j -> (row = e / 16, kk = e % 16)
-  int prow[4], pb[4], poh[4], pow_[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = tid + 256 * j, row = e >> 4;
-    const int p = p0 + row;
-    prow[j] = row;
-    if (p < npix) { pb[j] = p / (a.Ho * a.Wo); const int rem = p - pb[j] * a.Ho * a.Wo; poh[j] = rem / a.Wo; pow_[j] = rem - poh[j] * a.Wo; }
-    else { pb[j] = -1; poh[j] = 0; pow_[j] = 0; }
-  }
+  ConvF32Slots t;
+  conv_f32_slots(a, tid, p0, npix, t);
   v16f acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
+  float xv[4], wv[4];
+  conv_f32_gather(a, t, xs, ws, 0, K, n0, tid, xv, wv);
   for (int k0 = 0; k0 < K; k0 += CF_KC) {
-    const int kk = k0 + (tid & 15);                    // same k column for all 4 slots of this thread
-    int kh = 0, kw = 0, c = 0;
-    const bool kok = kk < K;
-    if (kok) { kh = kk / (a.KS * a.Cin); const int r2 = kk - kh * a.KS * a.Cin; kw = r2 / a.Cin; c = r2 - kw * a.Cin; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = prow[j];
-      // pixels
-      float xv = 0.f;
-      if (kok && pb[j] >= 0) {
-        const int ih = poh[j] * a.stride - a.pad + kh, iw = pow_[j] * a.stride - a.pad + kw;
-        if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-          xv = xs[(((int64_t)pb[j] * a.H + ih) * a.W + iw) * a.Cin + c];
-      }
-      Bs[row * CF_LD + (tid & 15)] = xv;
-      // weights
-      float wv = 0.f;
-      const int n = n0 + row;
-      if (kok && n < a.Cout) wv = ws[(((int64_t)n * a.Cin + c) * a.KS + kh) * a.KS + kw];
-      As[row * CF_LD + (tid & 15)] = wv;
+      Bs[t.prow[j] * CF_LD + (tid & 15)] = xv[j];
+      As[t.prow[j] * CF_LD + (tid & 15)] = wv[j];
     }
     __syncthreads();
+    if (k0 + CF_KC < K) conv_f32_gather(a, t, xs, ws, k0 + CF_KC, K, n0, tid, xv, wv);     // next chunk in flight under the MFMAs
 #pragma unroll
     for (int k2 = 0; k2 < CF_KC / 2; ++k2) {
       const float av = As[(wn * 32 + (lane & 31)) * CF_LD + 2 * k2 + (lane >> 5)];
@@ -127,41 +139,23 @@ __global__ __launch_bounds__(256) void conv2d_f32_acc64_kernel(const ConvF32Args
   const int K = a.KS * a.KS * a.Cin;
   const float* xs = a.x + (int64_t)s * a.x_ss;
   const float* ws = a.w + (int64_t)s * a.w_ss;
-  int prow[4], pb[4], poh[4], pow_[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = tid + 256 * j, row = e >> 4;
-    const int p = p0 + row;
-    prow[j] = row;
-    if (p < npix) { pb[j] = p / (a.Ho * a.Wo); const int rem = p - pb[j] * a.Ho * a.Wo; poh[j] = rem / a.Wo; pow_[j] = rem - poh[j] * a.Wo; }
-    else { pb[j] = -1; poh[j] = 0; pow_[j] = 0; }
-  }
+  ConvF32Slots t;
+  conv_f32_slots(a, tid, p0, npix, t);
   double acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  float xv[4], wv[4];
+  conv_f32_gather(a, t, xs, ws, 0, K, n0, tid, xv, wv);
   for (int k0 = 0; k0 < K; k0 += CF_KC) {
-    const int kk = k0 + (tid & 15);
-    int kh = 0, kw = 0, c = 0;
-    const bool kok = kk < K;
-    if (kok) { kh = kk / (a.KS * a.Cin); const int r2 = kk - kh * a.KS * a.Cin; kw = r2 / a.Cin; c = r2 - kw * a.Cin; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = prow[j];
-      float xv = 0.f;
-      if (kok && pb[j] >= 0) {
-        const int ih = poh[j] * a.stride - a.pad + kh, iw = pow_[j] * a.stride - a.pad + kw;
-        if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-          xv = xs[(((int64_t)pb[j] * a.H + ih) * a.W + iw) * a.Cin + c];
-      }
-      Bs[row * CF_LD + (tid & 15)] = xv;
-      float wv = 0.f;
-      const int n = n0 + row;
-      if (kok && n < a.Cout) wv = ws[(((int64_t)n * a.Cin + c) * a.KS + kh) * a.KS + kw];
-      As[row * CF_LD + (tid & 15)] = wv;
+      Bs[t.prow[j] * CF_LD + (tid & 15)] = xv[j];
+      As[t.prow[j] * CF_LD + (tid & 15)] = wv[j];
     }
     __syncthreads();
+    if (k0 + CF_KC < K) conv_f32_gather(a, t, xs, ws, k0 + CF_KC, K, n0, tid, xv, wv);
 #pragma unroll 4
     for (int k = 0; k < CF_KC; ++k) {
       double av[4], bv[4];
@@ -199,7 +193,7 @@ QBNN_EXPORT int qbnn_conv2d_f32_mc(const float* x, int64_t x_ss, const float* w,
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: bad argument");
   ConvF32Args a;
   a.x = x; a.x_ss = x_ss; a.w = w; a.w_ss = w_ss; a.bias = bias; a.y = y; a.y_ss = y_ss;
-  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = ksize; a.stride = stride; a.pad = pad; a.relu = relu & 1;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = ksize; a.stride = stride; a.pad = pad; a.relu = relu & 1; a.w_ohwi = (relu >> 2) & 1;
   a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
   if (a.Ho <= 0 || a.Wo <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: empty output");
   const int64_t npix = (int64_t)B * a.Ho * a.Wo;
@@ -444,4 +438,45 @@ QBNN_EXPORT int qbnn_sample_weights_f32_strided(const float* mu, int64_t mu_ss, 
   hipLaunchKernelGGL(sample_weights_f32_strided_kernel, dim3((unsigned)((groups + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
                      mu, mu_ss, sigma, sigma_ss, n, (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out);
   return qbnn_check_launch_msg("qbnn_sample_weights_f32_strided");
+}
+
+// As qbnn_sample_weights_f32_strided for a conv weight, but written in [Cout][KH][KW][Cin] order (the K axis of the implicit
+// GEMM contiguous) while the noise index stays the reference's [Cout][Cin][KH][KW] element index.
+__global__ __launch_bounds__(256) void sample_weights_f32_ohwi_kernel(const float* __restrict__ mu, int64_t mu_ss, const float* __restrict__ sigma,
+                                                                       int64_t sigma_ss, int Cout, int Cin, int KS, uint32_t seed_lo,
+                                                                       uint32_t seed_hi, uint32_t layer_id, uint32_t sample_begin,
+                                                                       const float* __restrict__ eps_in, float* __restrict__ w) {
+  const int64_t n = (int64_t)Cout * Cin * KS * KS;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g * 4 >= n) return;
+  const int s = blockIdx.y;
+  float e[4];
+  if (eps_in) {
+    for (int j = 0; j < 4; ++j) e[j] = (g * 4 + j < n) ? eps_in[(int64_t)s * n + g * 4 + j] : 0.f;
+  } else {
+    qbnn::normal4(qbnn::philox4x32_10((uint32_t)g, layer_id, sample_begin + s, 0u, seed_lo, seed_hi), e);
+  }
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = g * 4 + j;
+    if (i < n) {
+      const int kw = (int)(i % KS);
+      int64_t r = i / KS;
+      const int kh = (int)(r % KS); r /= KS;
+      const int c = (int)(r % Cin);
+      const int o = (int)(r / Cin);
+      const float t = e[j] * sigma[(int64_t)s * sigma_ss + i];
+      w[(int64_t)s * n + (((int64_t)o * KS + kh) * KS + kw) * Cin + c] = mu ? mu[(int64_t)s * mu_ss + i] + t : t;
+    }
+  }
+}
+
+QBNN_EXPORT int qbnn_sample_weights_f32_ohwi(const float* mu, int64_t mu_ss, const float* sigma, int64_t sigma_ss, int32_t Cout, int32_t Cin,
+                                             int32_t ksize, uint64_t seed, uint32_t layer_id, uint32_t sample_begin, int32_t n_samples,
+                                             const float* eps_in, float* w_out, void* stream) {
+  if (!sigma || !w_out || Cout <= 0 || Cin <= 0 || ksize <= 0 || n_samples <= 0)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_sample_weights_f32_ohwi: bad argument");
+  const int64_t groups = ((int64_t)Cout * Cin * ksize * ksize + 3) / 4;
+  hipLaunchKernelGGL(sample_weights_f32_ohwi_kernel, dim3((unsigned)((groups + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
+                     mu, mu_ss, sigma, sigma_ss, Cout, Cin, ksize, (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out);
+  return qbnn_check_launch_msg("qbnn_sample_weights_f32_ohwi");
 }

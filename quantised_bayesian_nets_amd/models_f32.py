@@ -121,8 +121,9 @@ def _f32(t, dev):
     return None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
-def conv2d_f32(x, w, bias, cin, cout, k, stride, pad, relu, acc64=False):
-    """x [S|1,B,H,W,Cin], w [S|1, Cout*Cin*k*k] (reference order) -> [S,B,Ho,Wo,Cout] through qbnn_conv2d_f32_mc."""
+def conv2d_f32(x, w, bias, cin, cout, k, stride, pad, relu, acc64=False, ohwi=False):
+    """x [S|1,B,H,W,Cin], w [S|1, Cout*Cin*k*k] (reference order, or [Cout,k,k,Cin] when `ohwi`) -> [S,B,Ho,Wo,Cout]
+    through qbnn_conv2d_f32_mc."""
     S = max(x.shape[0], w.shape[0])
     B, H, W = x.shape[1], x.shape[2], x.shape[3]
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
@@ -130,7 +131,7 @@ def conv2d_f32(x, w, bias, cin, cout, k, stride, pad, relu, acc64=False):
     with timed("conv2d_f32"):
         _lib.check(_lib.lib().qbnn_conv2d_f32_mc(_lib.ptr(x), 0 if x.shape[0] == 1 else x[0].numel(), _lib.ptr(w),
                                                  0 if w.shape[0] == 1 else w[0].numel(), _lib.ptr(bias), _lib.ptr(y), y[0].numel(),
-                                                 B, H, W, cin, cout, k, stride, pad, int(relu) | (2 if acc64 else 0), S, _lib.current_stream()))
+                                                 B, H, W, cin, cout, k, stride, pad, int(relu) | (2 if acc64 else 0) | (4 if ohwi else 0), S, _lib.current_stream()))
     return y
 
 
@@ -180,6 +181,19 @@ def sample_weights_f32(mu, sigma, layer_id, eps=None):
     return w
 
 
+def sample_conv_weights_f32(mu, sigma, cout, cin, k, layer_id, eps=None, mu_ss=0, sigma_ss=0):
+    """As sample_weights_f32 for a conv weight (noise indexed in the reference's [Cout][Cin][k][k] order), written
+    [Cout][k][k][Cin]; mu / sigma may be per-sample ([S, n], stride n) or shared (stride 0); mu None = noise term only."""
+    S, n = _MC.samples, cout * cin * k * k
+    w = torch.empty((S, n), dtype=torch.float32, device=sigma.device)
+    if eps is not None:
+        eps = eps.to(device=sigma.device, dtype=torch.float32).contiguous()
+    with timed("sample_weights_f32"):
+        _lib.check(_lib.lib().qbnn_sample_weights_f32_ohwi(_lib.ptr(mu), mu_ss, _lib.ptr(sigma), sigma_ss, cout, cin, k, _MC.seed, layer_id,
+                                                           _MC.sample_begin, S, _lib.ptr(eps), _lib.ptr(w), _lib.current_stream()))
+    return w
+
+
 def nchw_to_mc_nhwc(x):
     """[B,C,H,W] fp32 input -> [1,B,H,W,C] (shared by all samples)."""
     return x.to(torch.float32).permute(0, 2, 3, 1).contiguous().unsqueeze(0)
@@ -213,8 +227,10 @@ class Conv2d(nn.Module):
             raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
         if self._sigma is None or self._sigma.device != x.device:
             self._sigma = F.softplus(self.std.detach().cpu().float()).to(x.device).contiguous().reshape(-1)
-        w = sample_weights_f32(_f32(self.weight, x.device).reshape(-1), self._sigma, self.layer_id, eps)
-        return conv2d_f32(x, w, _f32(self.bias, x.device), self.in_channels, self.out_channels, self.k, self.stride, self.padding, relu)
+        w = sample_conv_weights_f32(_f32(self.weight, x.device).reshape(-1), self._sigma, self.out_channels, self.in_channels, self.k,
+                                    self.layer_id, eps)
+        return conv2d_f32(x, w, _f32(self.bias, x.device), self.in_channels, self.out_channels, self.k, self.stride, self.padding, relu,
+                          ohwi=True)
 
 
 class BatchNorm2d(nn.Module):

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .layers import _MC, mc_context, timed
-from .models_f32 import (affine_f32, conv2d_f32, flatten_f32, nchw_to_mc_nhwc, pool2d_f32, softmax_f32)
+from .models_f32 import (affine_f32, conv2d_f32, flatten_f32, nchw_to_mc_nhwc, pool2d_f32, sample_conv_weights_f32, softmax_f32)
 from .quant import INT_BOUNDS, UINT_BOUNDS
 
 OBS_BLOCKS = 512            # QBNN_OBSERVER_BLOCKS (include/qbnn.h)
@@ -97,6 +97,8 @@ class _QATBBB(nn.Module):
             if c is not None:
                 shape = [-1] + [1] * (mu.dim() - 1)
                 mu, sg = mu * c.reshape(shape), sg * c.reshape(shape)
+            if mu.dim() == 4:      # conv: the mean also in [Cout][k][k][Cin] order (the layout the conv kernel streams)
+                mu = mu.permute(0, 2, 3, 1)
             self._folded = (mu.reshape(1, -1).contiguous().to(dev), sg.reshape(1, -1).contiguous().to(dev))
         return self._folded
 
@@ -109,12 +111,17 @@ class _QATBBB(nn.Module):
         w = self.weight_fake_quant(mu0)                                  # [S, n]
         s = self.std_fake_quant(sg0)
         n = w.shape[1]
-        t_pre = torch.empty((S, n), dtype=torch.float32, device=dev)
-        if eps is not None:
-            eps = eps.to(device=dev, dtype=torch.float32).contiguous()
-        with timed("sample_weights_f32"):
-            _lib.check(_lib.lib().qbnn_sample_weights_f32_strided(None, 0, _lib.ptr(s), n, n, _MC.seed, self.layer_id, _MC.sample_begin, S,
-                                                                  _lib.ptr(eps), _lib.ptr(t_pre), _lib.current_stream()))
+        if self.weight.dim() == 4:
+            # conv: w (fake-quantised mean) is already [Cout][k][k][Cin]; the noise term is drawn on the reference's element
+            # order and written in that layout too, so everything downstream is elementwise
+            t_pre = sample_conv_weights_f32(None, s, self.out_channels, self.in_channels, self.k, self.layer_id, eps, sigma_ss=n)
+        else:
+            t_pre = torch.empty((S, n), dtype=torch.float32, device=dev)
+            if eps is not None:
+                eps = eps.to(device=dev, dtype=torch.float32).contiguous()
+            with timed("sample_weights_f32"):
+                _lib.check(_lib.lib().qbnn_sample_weights_f32_strided(None, 0, _lib.ptr(s), n, n, _MC.seed, self.layer_id, _MC.sample_begin, S,
+                                                                      _lib.ptr(eps), _lib.ptr(t_pre), _lib.current_stream()))
         t = self.mul_noise(t_pre)
         return self.add_weight(affine_f32(w.unsqueeze(-1), res=t.unsqueeze(-1)).squeeze(-1))
 
@@ -161,9 +168,9 @@ class Conv2d(_QATBBB):
         W = self.sampled_weights(dev, eps)
         if self.bn is None:
             b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
-            z = conv2d_f32(x, W, b, self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True)
+            z = conv2d_f32(x, W, b, self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True, ohwi=True)
         else:
-            z = conv2d_f32(x, W, None, self.in_channels, self.out_channels, self.k, self.stride, self.padding, False, acc64=True)
+            z = conv2d_f32(x, W, None, self.in_channels, self.out_channels, self.k, self.stride, self.padding, False, acc64=True, ohwi=True)
             c = self.scale_factor().to(dev).contiguous()
             b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
             z = affine_f32(z, c, b, mode=1)                                                # Z / scale_factor (+ bias), :159-161
