@@ -34,7 +34,19 @@ struct ConvF32Args {
   float* y; int64_t y_ss;            // [S][B][Ho][Wo][Cout]
   int B, H, W, Cin, Cout, KS, stride, pad, Ho, Wo, relu;
   int w_ohwi;                        // weights stored [Cout][KH][KW][Cin] (flags bit 2) instead of the reference's [Cout][Cin][KH][KW]
+  // fused tail (qbnn_conv2d_f32_fused_mc): v = conv (+ bias); v = v * alpha[n]; v = v + beta[n]; v = v + res; ReLU -- each step
+  // rounded to fp32 exactly as the separate BatchNorm / Add / ReLU kernels would
+  const float* alpha; const float* beta; const float* res; int64_t res_ss;
 };
+
+__device__ __forceinline__ float conv_f32_tail(const ConvF32Args& a, float v, int n, int s, int64_t off) {
+  if (a.bias) v = v + a.bias[n];
+  if (a.alpha) v = v * a.alpha[n];
+  if (a.beta) v = v + a.beta[n];
+  if (a.res) v = v + a.res[(int64_t)s * a.res_ss + off];
+  if (a.relu) v = fmaxf(v, 0.f);
+  return v;
+}
 
 constexpr int CF_KC = 16, CF_LD = CF_KC + 1;
 
@@ -70,6 +82,67 @@ __device__ __forceinline__ void conv_f32_gather(const ConvF32Args& a, const Conv
     if (kok && n < a.Cout)
       wv[j] = a.w_ohwi ? ws[(int64_t)n * K + kk] : ws[(((int64_t)n * a.Cin + c) * a.KS + kh) * a.KS + kw];
   }
+}
+
+// Fast path of the MFMA kernel: Cin % 16 == 0 and K-contiguous weights.  A 16-wide K chunk then lies inside one tap, so the
+// tap is wavefront-uniform and every thread moves ONE float4 per operand and chunk (thread -> row tid / 4, channels
+// 4 (tid % 4) .. +3) instead of 8 scalars with per-element index arithmetic (which made the generic form VALU-bound).
+constexpr int CF_LD4 = 20;           // row pitch in floats: 16-byte aligned rows for the float4 stores
+__global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a) {
+  __shared__ __attribute__((aligned(16))) float As[64 * CF_LD4];
+  __shared__ __attribute__((aligned(16))) float Bs[64 * CF_LD4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int s = blockIdx.z;
+  const int p0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int npix = a.B * a.Ho * a.Wo;
+  const int K = a.KS * a.KS * a.Cin;
+  const float* xs = a.x + (int64_t)s * a.x_ss;
+  const float* ws = a.w + (int64_t)s * a.w_ss;
+  const int row = tid >> 2, kq = (tid & 3) * 4;
+  const int p = p0 + row, n = n0 + row;
+  int pb = -1, ih0 = 0, iw0 = 0;
+  if (p < npix) { pb = p / (a.Ho * a.Wo); const int rem = p - pb * a.Ho * a.Wo; ih0 = (rem / a.Wo) * a.stride - a.pad; iw0 = (rem % a.Wo) * a.stride - a.pad; }
+  const float* wrow = ws + (int64_t)(n < a.Cout ? n : 0) * K + kq;
+  const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto gather = [&](int k0, v4f& xv, v4f& wv) {
+    const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;       // uniform: Cin % 16 == 0
+    const int kh = tap / a.KS, kw = tap - kh * a.KS;
+    const int ih = ih0 + kh, iw = iw0 + kw;
+    const bool ok = pb >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+    xv = ok ? *reinterpret_cast<const v4f*>(xs + (((int64_t)pb * a.H + ih) * a.W + iw) * a.Cin + c0 + kq) : zero4;
+    wv = n < a.Cout ? *reinterpret_cast<const v4f*>(wrow + k0) : zero4;
+  };
+  v16f acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  v4f xv, wv;
+  gather(0, xv, wv);
+  for (int k0 = 0; k0 < K; k0 += CF_KC) {
+    *reinterpret_cast<v4f*>(&Bs[row * CF_LD4 + kq]) = xv;
+    *reinterpret_cast<v4f*>(&As[row * CF_LD4 + kq]) = wv;
+    __syncthreads();
+    if (k0 + CF_KC < K) gather(k0 + CF_KC, xv, wv);
+#pragma unroll
+    for (int k2 = 0; k2 < CF_KC / 2; ++k2) {
+      const float av = As[(wn * 32 + (lane & 31)) * CF_LD4 + 2 * k2 + (lane >> 5)];
+      const float bv = Bs[(wm * 32 + (lane & 31)) * CF_LD4 + 2 * k2 + (lane >> 5)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int po = p0 + wm * 32 + (lane & 31);
+  if (po >= npix) return;
+  float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int no = n0 + wn * 32 + 8 * g + 4 * (lane >> 5) + i;
+      if (no < a.Cout) {
+        yp[no] = conv_f32_tail(a, acc[4 * g + i], no, s, (int64_t)po * a.Cout + no);
+      }
+    }
 }
 
 __global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvF32Args a) {
@@ -116,10 +189,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvF32Args a) {
     for (int i = 0; i < 4; ++i) {
       const int n = n0 + wn * 32 + 8 * g + 4 * (lane >> 5) + i;
       if (n < a.Cout) {
-        float v = acc[4 * g + i];
-        if (a.bias) v = v + a.bias[n];
-        if (a.relu) v = fmaxf(v, 0.f);
-        yp[n] = v;
+        yp[n] = conv_f32_tail(a, acc[4 * g + i], n, s, (int64_t)p * a.Cout + n);
       }
     }
 }
@@ -177,28 +247,30 @@ __global__ __launch_bounds__(256) void conv2d_f32_acc64_kernel(const ConvF32Args
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + 4 * tn + j;
       if (n < a.Cout) {
-        float v = (float)acc[i][j];
-        if (a.bias) v = v + a.bias[n];
-        if (a.relu) v = fmaxf(v, 0.f);
-        yp[n] = v;
+        yp[n] = conv_f32_tail(a, (float)acc[i][j], n, s, (int64_t)p * a.Cout + n);
       }
     }
   }
 }
 
-QBNN_EXPORT int qbnn_conv2d_f32_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* bias, float* y,
-                                   int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                                   int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream) {
+QBNN_EXPORT int qbnn_conv2d_f32_fused_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* bias, const float* alpha,
+                                         const float* beta, const float* res, int64_t res_ss, float* y, int64_t y_ss, int32_t B, int32_t H,
+                                         int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu,
+                                         int32_t n_samples, void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || n_samples <= 0)
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: bad argument");
   ConvF32Args a;
+  a.alpha = alpha; a.beta = beta; a.res = res; a.res_ss = res_ss;
   a.x = x; a.x_ss = x_ss; a.w = w; a.w_ss = w_ss; a.bias = bias; a.y = y; a.y_ss = y_ss;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = ksize; a.stride = stride; a.pad = pad; a.relu = relu & 1; a.w_ohwi = (relu >> 2) & 1;
   a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
   if (a.Ho <= 0 || a.Wo <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: empty output");
   const int64_t npix = (int64_t)B * a.Ho * a.Wo;
   dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)n_samples);
+  const bool vec = a.w_ohwi && (Cin % 16) == 0 && (x_ss % 4) == 0 && (w_ss % 4) == 0 &&
+                   (reinterpret_cast<uintptr_t>(x) % 16) == 0 && (reinterpret_cast<uintptr_t>(w) % 16) == 0;
   if (relu & 2) hipLaunchKernelGGL(conv2d_f32_acc64_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (vec) hipLaunchKernelGGL(conv2d_f32_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(conv2d_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   return qbnn_check_launch_msg("qbnn_conv2d_f32_mc");
 }
@@ -479,4 +551,11 @@ QBNN_EXPORT int qbnn_sample_weights_f32_ohwi(const float* mu, int64_t mu_ss, con
   hipLaunchKernelGGL(sample_weights_f32_ohwi_kernel, dim3((unsigned)((groups + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
                      mu, mu_ss, sigma, sigma_ss, Cout, Cin, ksize, (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out);
   return qbnn_check_launch_msg("qbnn_sample_weights_f32_ohwi");
+}
+
+QBNN_EXPORT int qbnn_conv2d_f32_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* bias, float* y,
+                                   int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                   int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream) {
+  return qbnn_conv2d_f32_fused_mc(x, x_ss, w, w_ss, bias, nullptr, nullptr, nullptr, 0, y, y_ss, B, H, W, Cin, Cout, ksize, stride, pad, relu,
+                                  n_samples, stream);
 }

@@ -121,17 +121,20 @@ def _f32(t, dev):
     return None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
-def conv2d_f32(x, w, bias, cin, cout, k, stride, pad, relu, acc64=False, ohwi=False):
+def conv2d_f32(x, w, bias, cin, cout, k, stride, pad, relu, acc64=False, ohwi=False, bn=None, res=None):
     """x [S|1,B,H,W,Cin], w [S|1, Cout*Cin*k*k] (reference order, or [Cout,k,k,Cin] when `ohwi`) -> [S,B,Ho,Wo,Cout]
     through qbnn_conv2d_f32_mc."""
     S = max(x.shape[0], w.shape[0])
     B, H, W = x.shape[1], x.shape[2], x.shape[3]
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     y = torch.empty((S, B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    alpha, beta = bn if bn is not None else (None, None)      # BatchNorm eval coefficients: fused tail of the conv kernel
     with timed("conv2d_f32"):
-        _lib.check(_lib.lib().qbnn_conv2d_f32_mc(_lib.ptr(x), 0 if x.shape[0] == 1 else x[0].numel(), _lib.ptr(w),
-                                                 0 if w.shape[0] == 1 else w[0].numel(), _lib.ptr(bias), _lib.ptr(y), y[0].numel(),
-                                                 B, H, W, cin, cout, k, stride, pad, int(relu) | (2 if acc64 else 0) | (4 if ohwi else 0), S, _lib.current_stream()))
+        _lib.check(_lib.lib().qbnn_conv2d_f32_fused_mc(_lib.ptr(x), 0 if x.shape[0] == 1 else x[0].numel(), _lib.ptr(w),
+                                                       0 if w.shape[0] == 1 else w[0].numel(), _lib.ptr(bias), _lib.ptr(alpha), _lib.ptr(beta),
+                                                       _lib.ptr(res), 0 if res is None or res.shape[0] == 1 else res[0].numel(), _lib.ptr(y),
+                                                       y[0].numel(), B, H, W, cin, cout, k, stride, pad,
+                                                       int(relu) | (2 if acc64 else 0) | (4 if ohwi else 0), S, _lib.current_stream()))
     return y
 
 
@@ -222,7 +225,9 @@ class Conv2d(nn.Module):
         sigma, mu, sp = F.softplus(self.std), self.weight, self.std_prior
         return 0.5 * (2 * torch.log(sp / sigma) - 1 + (sigma / sp).pow(2) + ((0 - mu) / sp).pow(2)).sum()
 
-    def forward(self, x, relu=False, eps=None):
+    def forward(self, x, relu=False, eps=None, bn=None, res=None):
+        """bn: a BatchNorm2d (eval) applied to the conv output, res: a tensor added after it, relu: final ReLU -- all in the
+        conv kernel's epilogue, rounded step by step like the separate modules of the reference graph."""
         if x.device.type != "cuda":
             raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
         if self._sigma is None or self._sigma.device != x.device:
@@ -230,7 +235,7 @@ class Conv2d(nn.Module):
         w = sample_conv_weights_f32(_f32(self.weight, x.device).reshape(-1), self._sigma, self.out_channels, self.in_channels, self.k,
                                     self.layer_id, eps)
         return conv2d_f32(x, w, _f32(self.bias, x.device), self.in_channels, self.out_channels, self.k, self.stride, self.padding, relu,
-                          ohwi=True)
+                          ohwi=True, bn=None if bn is None else bn.coefficients(x.device), res=res)
 
 
 class BatchNorm2d(nn.Module):
@@ -333,10 +338,9 @@ class BasicBlock(nn.Module):
             self.shortcut.append(BatchNorm2d(planes))
 
     def forward(self, x):
-        out = self.stem[1](self.stem[0](x), relu=True)
-        out = self.stem[3](out)
-        sc = self.shortcut[1](self.shortcut[0](x)) if len(self.shortcut) else x
-        return self.stem[4](out, relu=True, res=sc)        # bn, + shortcut (Add), ReLU
+        out = self.stem[0](x, relu=True, bn=self.stem[1])                              # conv - bn - relu
+        sc = self.shortcut[0](x, bn=self.shortcut[1]) if len(self.shortcut) else x       # conv - bn
+        return self.stem[3](out, relu=True, bn=self.stem[4], res=sc)                     # conv - bn - Add - ReLU
 
 
 class ConvNetwork_ResNet(nn.Module):
@@ -389,7 +393,7 @@ class ConvNetwork_ResNet(nn.Module):
 
     def forward_mc(self, x):
         h = nchw_to_mc_nhwc(x)
-        h = self.layers[1](self.layers[0](h), relu=True)
+        h = self.layers[0](h, relu=True, bn=self.layers[1])
         for li in (3, 4, 5, 6):
             for blk in self.layers[li]:
                 h = blk(h)
