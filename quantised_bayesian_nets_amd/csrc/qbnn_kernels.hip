@@ -572,11 +572,7 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
           }
 #pragma unroll
           for (int nb = 0; nb < C::NB; ++nb) {
-#ifdef QBNN_ABL_NOMFMA
-            acc[mb][nb][0] ^= f.w[u][nb].x ^ f.x[u][mb].y;
-#else
             acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[u][nb], f.x[u][mb], acc[mb][nb], 0, 0, 0);
-#endif
           }
         }
       }
@@ -626,17 +622,6 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
       }
       const int zwr = p.z_w * R;
       const int m = epi.pixel((mblk * C::MB + mb) * 32 + r);
-#ifdef QBNN_ABL_NOEPI
-      {
-        int keep = zwr;
-#pragma unroll
-        for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) keep ^= acc[mb][nb][i];
-        if (keep == 0x12345678) epi.store(m, 4 * h, 0.f, 0.f, 0.f, 0.f, 0u);
-        continue;
-      }
-#endif
 #pragma unroll
       for (int nb = 0; nb < C::NB; ++nb) {
         uint32_t pre[4];
@@ -971,11 +956,7 @@ __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const
               }
 #pragma unroll
               for (int nb = 0; nb < C::NB; ++nb) {
-#ifdef QBNN_ABL_NOMFMA
-                acc[mb][nb][0] ^= f.w[u][nb].x ^ f.x[u][mb].y;
-#else
                 acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[u][nb], f.x[u][mb], acc[mb][nb], 0, 0, 0);
-#endif
               }
             }
           }
@@ -1005,17 +986,6 @@ __device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const
       }
       const int zwr = p.z_w * R;
       const int po = epi.pixel((mblk * C::MB + mb) * 32 + r);
-#ifdef QBNN_ABL_NOEPI
-      {
-        int keep = zwr;
-#pragma unroll
-        for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) keep ^= acc[mb][nb][i];
-        if (keep == 0x12345678) epi.store(po, 4 * h, 0.f, 0.f, 0.f, 0.f, 0u);
-        continue;
-      }
-#endif
 #pragma unroll
       for (int nb = 0; nb < C::NB; ++nb) {
         uint32_t pre[4];
@@ -1189,7 +1159,7 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvArgs a) {
   uint8_t* tile = smem;
   uint8_t* outb = smem + C::G * C::TILE_BYTES + C::TILE_SLACK;
   float* bias_lds = reinterpret_cast<float*>(outb + C::OUT_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
   const int s = blockIdx.y, img0 = blockIdx.x * C::G;
 
   if (C::HALO > 0) zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G>(tile, tid);
@@ -1307,7 +1277,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? ChainThreads<C, NBLK>::per_cu 
   ring.cur = 0;
   float* bias_lds = reinterpret_cast<float*>(ring.buf[1] + RSLAB);        // [NBLK][2][COUT]
   uint8_t* lut_lds = reinterpret_cast<uint8_t*>(bias_lds + NBLK * 2 * C::COUT);   // [NBLK][128*128] when the blocks carry tables
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
   const bool use_lut = a.blk[0].add.lut != nullptr;
   if (use_lut) {
 #pragma unroll
@@ -1556,7 +1526,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_i8_kernel(const DownAr
   ring.buf[1] = ring.buf[0] + SLAB;
   ring.cur = 0;
   float* bias_lds = reinterpret_cast<float*>(ring.buf[1] + SLAB);       // [3][COUT]: s, a, b
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
 
   constexpr int CPR = CA::ROWB / 16, CPI = CA::HIN * CPR, NCH = CA::G * CPI;
   constexpr int PER_T = (NCH + BLK_THREADS - 1) / BLK_THREADS;
@@ -2020,10 +1990,37 @@ __device__ __forceinline__ void item_range(int n_items, int b, int nb, int& begi
   count = q + (b < rm ? 1 : 0);
 }
 
+// Interleaved, XCD-aware walk for the kernels that stream their weights per item (no weights-stationary LDS copy).
+// Workgroup b runs on XCD b % 8 (round-robin dispatch, one workgroup per CU), and every XCD has its own 4 MiB L2.  XCD x
+// takes the x-th eighth of the sample-major item list, and its 32 workgroups walk that range interleaved: at any time
+// they sit on the same one or two MC samples, so a sample's weights (130 - 660 KiB) are filled into one L2 (two where a
+// range boundary cuts a sample) once and every later read is an L2 hit.  (Plain `item = b + i * gridDim` spreads each
+// sample over all eight L2s: 8x the fill traffic, and each L2 churns through the weights of 8 samples at a time.)
+#ifndef QBNN_XCDS
+#define QBNN_XCDS 8
+#endif
+struct ItemWalk {
+  int first, per, count;
+  __device__ __forceinline__ ItemWalk(int n_items, int b, int nb) {
+    if (QBNN_XCDS > 1 && (nb % QBNN_XCDS) == 0) {
+      int xb, xn;
+      item_range(n_items, b % QBNN_XCDS, QBNN_XCDS, xb, xn);
+      const int j = b / QBNN_XCDS;
+      per = nb / QBNN_XCDS;
+      first = xb + j;
+      count = j < xn ? (xn - j + per - 1) / per : 0;
+    } else {
+      first = b; per = nb;
+      count = b < n_items ? (n_items - b + nb - 1) / nb : 0;
+    }
+  }
+  __device__ __forceinline__ int item(int it) const { return first + it * per; }
+};
+
 // LDSW = true : weights-stationary as described above (contiguous item ranges).
 // LDSW = false: the block's weights are too large for LDS -- every wave streams its fragments from L2 (conv_passes) and
-//               the workgroups walk the items interleaved (item = blockIdx.x + i * gridDim.x), so that all of them
-//               work on the same MC sample at a time and its weights stay hot in L2.  Same barrier / prefetch scheme.
+//               the workgroups walk the items interleaved per XCD (ItemWalk), so that the workgroups sharing an L2
+//               work on the same MC sample at a time and its weights stay hot there.  Same barrier / prefetch scheme.
 // STEM = true (layer 1 only): the network's first conv (3 -> 24 channels, on the pre-gathered 27-tap patches) runs inside
 //               the same kernel -- its output never goes to HBM (that tensor is the largest of the network: 629 MB per
 //               100-sample step written and read back).  The item's input is then its image's patch block (32 KiB,
@@ -2044,21 +2041,17 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
   uint8_t* im = reinterpret_cast<uint8_t*>(bias_lds + NBLK * 2 * C::COUT);   // STEM: patch tile [1024][32], stem weights, stem bias
   uint8_t* wl0 = im + C0::TILE_BYTES;
   float* bias0 = reinterpret_cast<float*>(wl0 + WConv<C0>::BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
 
   constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
   constexpr int NCH_IN = STEM ? C0::TILE_BYTES / 16 : NCH;                  // ... of its input (the patch block when STEM)
   constexpr int PER_T = (NCH_IN + NTHR - 1) / NTHR, PER_TO = (NCH + NTHR - 1) / NTHR;
   const int groups = (a.B + C::G - 1) / C::G;
-  int begin, count, step;
-  if (LDSW) {
-    item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
-    step = 1;
-  } else {
-    const int n_items = a.n_samples * groups;
-    begin = blockIdx.x; step = gridDim.x;
-    count = begin < n_items ? (n_items - begin + step - 1) / step : 0;
-  }
+  int begin = 0, count;
+  const ItemWalk walk(a.n_samples * groups, blockIdx.x, gridDim.x);
+  if (LDSW) item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+  else count = walk.count;
+  auto item_at = [&](int it) { return LDSW ? begin + it : walk.item(it); };
 
   zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, NTHR>(xt, tid);
   zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, NTHR>(tt, tid);
@@ -2112,18 +2105,18 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
     }
   };
   if (count <= 0) return;
-  fetch(begin);
-  write_tile(begin);
+  fetch(item_at(0));
+  write_tile(item_at(0));
   int cur_s = -1;
   QBNN_STAMP_DECL
   for (int it = 0; it < count; ++it) {
     QBNN_STAMP_START();
-    const int item = begin + it * step;
+    const int item = item_at(it);
     const int s = item / groups, img0 = (item - s * groups) * C::G;
     const bool more = it + 1 < count;
     // the next item's input: in flight for the whole of this item (unconditional, so the wait counts at its use are
     // exact: the last iteration re-reads its own item and drops it)
-    fetch(more ? item + step : item);
+    fetch(more ? item_at(it + 1) : item);
     if (LDSW && s != cur_s) {    // workgroup-uniform; at most a few times per launch
       __syncthreads();           // every wave is done with the previous sample's weights (and the prologue's LDS writes)
 #pragma unroll
@@ -2180,7 +2173,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const Chain
           outv[j] = v4i{(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
         }
       }
-      if (more) write_tile(item + step);
+      if (more) write_tile(item_at(it + 1));
 #pragma unroll
       for (int j = 0; j < PER_TO; ++j) {
         const int i = tid + j * NTHR;
@@ -2216,7 +2209,7 @@ __global__ __launch_bounds__(512) void block_chain_pp_kernel(const ChainArgs<NBL
   constexpr int GT = 256;                                                   // threads per group
   constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
   constexpr int WB = WConv<C>::BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
   const int grp = wave >> 2, lw = wave & 3, ltid = tid & (GT - 1);
   uint8_t* xg = smem + grp * 3 * TILES;                                     // X0, X1, T of this group
   uint8_t* tt = xg + 2 * TILES;
@@ -2539,7 +2532,7 @@ void block_chain_ald_kernel(const ChainArgs<1> a) {
   float* bias_lds = reinterpret_cast<float*>(rbase + 2 * C::SLAB_BYTES);     // [2][COUT]
   int* sx = reinterpret_cast<int*>(bias_lds + 2 * C::COUT);                  // channel sums of the X tile  [G * HO * HO]
   int* stab = sx + C::G * C::HO * C::HO;                                     // ... of the T tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
   const BlockParams& bp = a.blk[0];
 
   constexpr int IMG_PX = C::HO * C::HO;
@@ -2547,9 +2540,8 @@ void block_chain_ald_kernel(const ChainArgs<1> a) {
   constexpr int NCH = C::G * IMG_PX * CPP;
   constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
   const int groups = (a.B + C::G - 1) / C::G;
-  const int n_items = a.n_samples * groups;
-  const int step = gridDim.x;                       // interleaved walk: all workgroups on the same sample -> weights L2-hot
-  const int count = (int)blockIdx.x < n_items ? (n_items - (int)blockIdx.x + step - 1) / step : 0;
+  const ItemWalk walk(a.n_samples * groups, blockIdx.x, gridDim.x);     // interleaved per XCD: a sample's weights stay in ONE L2
+  const int count = walk.count;
 
   for (int i = tid; i < C::PIXB / 4; i += NTHR) reinterpret_cast<uint32_t*>(xt + DT::BYTES)[i] = 0u;
   for (int i = tid; i < 2 * C::G * C::HO * C::HO; i += NTHR) sx[i] = 0;
@@ -2598,17 +2590,17 @@ void block_chain_ald_kernel(const ChainArgs<1> a) {
   };
   auto wbase = [&](const QConv& q, int item) { return q.w + (int64_t)(item / groups) * q.w_ss; };
 
-  fetch(blockIdx.x);
-  write_tile(blockIdx.x);
-  dma_slab<C, NWV>(rbase, wbase(bp.a, blockIdx.x), 0, wave, lane);
+  fetch(walk.item(0));
+  write_tile(walk.item(0));
+  dma_slab<C, NWV>(rbase, wbase(bp.a, walk.item(0)), 0, wave, lane);
   ConvAcc<C> A;
   QBNN_STAMP_DECL
   for (int it = 0; it < count; ++it) {
     QBNN_STAMP_START();
-    const int item = blockIdx.x + it * step;
+    const int item = walk.item(it);
     const int s = item / groups, img0 = (item - s * groups) * C::G;
     const bool more = it + 1 < count;
-    const int next = more ? item + step : item;
+    const int next = more ? walk.item(it + 1) : item;
     // ---- stem.0: M over the X tile, then T over it
     conv_ring_mfma_dense<C, NWV>(xt, rbase, rcur, wbase(bp.a, item), A, wave, lane,
                             [&](uint8_t* dst) { dma_slab<C, NWV>(dst, wbase(bp.b, item), 0, wave, lane); });
@@ -2754,20 +2746,16 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
   uint8_t* wl_a = wl_s + (LDSW ? WConv<CS>::BYTES : 0);
   uint8_t* wl_b = wl_a + (LDSW ? WConv<CA>::BYTES : 0);
   float* bias_lds = reinterpret_cast<float*>(wl_b + (LDSW ? WConv<CB>::BYTES : 0));       // [3][COUT]: s, a, b
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
 
   constexpr int CPR = CA::ROWB / 16, CPI = CA::HIN * CPR, NCH = CA::G * CPI;
   constexpr int PER_T = (NCH + BLK_THREADS - 1) / BLK_THREADS;
   const int groups = (a.B + CA::G - 1) / CA::G;
-  int begin, count, step;
-  if (LDSW) {
-    item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
-    step = 1;
-  } else {
-    const int n_items = a.n_samples * groups;
-    begin = blockIdx.x; step = gridDim.x;
-    count = begin < n_items ? (n_items - begin + step - 1) / step : 0;
-  }
+  int begin = 0, count;
+  const ItemWalk walk(a.n_samples * groups, blockIdx.x, gridDim.x);
+  if (LDSW) item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+  else count = walk.count;
+  auto item_at = [&](int it) { return LDSW ? begin + it : walk.item(it); };
 
   zero_halo<CA::TW, CA::PIXB, CA::TILE_BYTES, CA::G, BLK_THREADS>(xt, tid);
   zero_halo<CB::TW, CB::PIXB, CB::TILE_BYTES, CB::G, BLK_THREADS>(tt, tid);
@@ -2806,16 +2794,16 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
     }
   };
   if (count <= 0) return;
-  fetch(begin);
-  write_tile(begin);
+  fetch(item_at(0));
+  write_tile(item_at(0));
   int cur_s = -1;
   QBNN_STAMP_DECL
   for (int it = 0; it < count; ++it) {
     QBNN_STAMP_START();
-    const int item = begin + it * step;
+    const int item = item_at(it);
     const int s = item / groups, img0 = (item - s * groups) * CA::G;
     const bool more = it + 1 < count;
-    fetch(more ? item + step : item);    // unconditional: exact wait counts at its use (see block_chain_ws_kernel)
+    fetch(more ? item_at(it + 1) : item);    // unconditional: exact wait counts at its use (see block_chain_ws_kernel)
     if (LDSW && s != cur_s) {
       __syncthreads();
       dma_conv<CS, BLK_WAVES>(wl_s, a.s.w + (int64_t)s * a.s.w_ss, wave, lane);
@@ -2848,7 +2836,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
     QBNN_STAMP_AT(4);
     lds_barrier();
     QBNN_STAMP_AT(5);
-    if (more) write_tile(item + step);      // before the stores: its vmcnt wait then covers only the (old) input loads
+    if (more) write_tile(item_at(it + 1));      // before the stores: its vmcnt wait then covers only the (old) input loads
     QBNN_STAMP_AT(6);
     {
       constexpr int IMG_OUT = CB::HO * CB::HO * COUT, U8 = COUT / 8;          // 8-byte units (the padded pitch is 8-aligned)
@@ -3090,7 +3078,7 @@ struct HeadArgs {
 
 __global__ __launch_bounds__(256) void head_i8_kernel(const HeadArgs a) {
   __shared__ int pooled[4][256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * 4 + wave;
   const int s = blockIdx.y;
   if (b >= a.B) return;
@@ -3433,7 +3421,7 @@ __global__ __launch_bounds__(256) void classification_metrics_kernel(const float
     bin = min(bin, 9);
     v[4 + bin] = 1.f; v[14 + bin] = conf; v[24 + bin] = acc;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
   for (int i = 0; i < QBNN_METRIC_SLOTS; ++i) {
     float x = v[i];
