@@ -250,12 +250,15 @@ int qbnn_conv2d_f32_mc(const float* x, int64_t x_sample_stride, const float* w, 
                        int64_t y_sample_stride, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                        int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream);
 
-/* qbnn_conv2d_f32_mc with the float graphs' tail fused: v = conv (+ bias); v *= alpha[n]; v += beta[n] (nn.BatchNorm2d in eval,
- * alpha = weight / sqrt(var + eps), beta = bias - mean alpha); v += res (Add, res [S|1][B][Ho][Wo][Cout]); ReLU (flags bit 0).
+/* qbnn_conv2d_f32_mc with the float graphs' tail fused: v = conv; v /= div[n] (conv_qat.py:159, Z / scale_factor); v += bias[n];
+ * v *= alpha[n]; v += beta[n] (nn.BatchNorm2d in eval, alpha = weight / sqrt(var + eps), beta = bias - mean alpha);
+ * v += res (Add, res [S|1][B][Ho][Wo][Cout]); ReLU (flags bit 0).
  * Every step is rounded to fp32 as the stand-alone kernels round it; NULL pointers skip a step.
- * Replaces conv -> bn -> (add) -> relu of models_bbb.py:154-183 for the un-prepared float model. */
-int qbnn_conv2d_f32_fused_mc(const float* x, int64_t x_sample_stride, const float* w, int64_t w_sample_stride, const float* bias,
-                             const float* alpha, const float* beta, const float* res, int64_t res_sample_stride, float* y,
+ * Replaces conv -> bn -> (add) -> relu of models_bbb.py:154-183 for the un-prepared float model, and conv -> / c + b -> bn -> relu
+ * of conv_qat.py:150-165 for the prepared one.  With flags bit 1 (fp64 accumulation) and Cin % 4 == 0, OHWI weights, the sum
+ * runs on v_mfma_f64_16x16x4_f64. */
+int qbnn_conv2d_f32_fused_mc(const float* x, int64_t x_sample_stride, const float* w, int64_t w_sample_stride, const float* div,
+                             const float* bias, const float* alpha, const float* beta, const float* res, int64_t res_sample_stride, float* y,
                              int64_t y_sample_stride, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                              int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream);
 

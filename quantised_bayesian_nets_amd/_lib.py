@@ -102,7 +102,7 @@ def lib():
         L.qbnn_im2col3x3_c3.argtypes = [vp, i32, i32, i32, i32, vp, vp]
         L.qbnn_head_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i32, C.POINTER(HeadDesc), vp]
         L.qbnn_reduce_moments.argtypes = [vp, i32, i64, i32, vp, vp]
-        L.qbnn_conv2d_f32_fused_mc.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.qbnn_conv2d_f32_fused_mc.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         L.qbnn_conv2d_f32_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         L.qbnn_affine_f32_mc.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp]
         L.qbnn_pool2d_f32_mc.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]

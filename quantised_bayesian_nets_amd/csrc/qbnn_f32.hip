@@ -34,12 +34,13 @@ struct ConvF32Args {
   float* y; int64_t y_ss;            // [S][B][Ho][Wo][Cout]
   int B, H, W, Cin, Cout, KS, stride, pad, Ho, Wo, relu;
   int w_ohwi;                        // weights stored [Cout][KH][KW][Cin] (flags bit 2) instead of the reference's [Cout][Cin][KH][KW]
-  // fused tail (qbnn_conv2d_f32_fused_mc): v = conv (+ bias); v = v * alpha[n]; v = v + beta[n]; v = v + res; ReLU -- each step
-  // rounded to fp32 exactly as the separate BatchNorm / Add / ReLU kernels would
-  const float* alpha; const float* beta; const float* res; int64_t res_ss;
+  // fused tail (qbnn_conv2d_f32_fused_mc): v = conv; v = v / div[n]; v = v + bias[n]; v = v * alpha[n]; v = v + beta[n];
+  // v = v + res; ReLU -- each step rounded to fp32 exactly as the separate pointwise kernels would
+  const float* div; const float* alpha; const float* beta; const float* res; int64_t res_ss;
 };
 
 __device__ __forceinline__ float conv_f32_tail(const ConvF32Args& a, float v, int n, int s, int64_t off) {
+  if (a.div) v = v / a.div[n];
   if (a.bias) v = v + a.bias[n];
   if (a.alpha) v = v * a.alpha[n];
   if (a.beta) v = v + a.beta[n];
@@ -84,65 +85,132 @@ __device__ __forceinline__ void conv_f32_gather(const ConvF32Args& a, const Conv
   }
 }
 
-// Fast path of the MFMA kernel: Cin % 16 == 0 and K-contiguous weights.  A 16-wide K chunk then lies inside one tap, so the
-// tap is wavefront-uniform and every thread moves ONE float4 per operand and chunk (thread -> row tid / 4, channels
-// 4 (tid % 4) .. +3) instead of 8 scalars with per-element index arithmetic (which made the generic form VALU-bound).
+// Fast path of the MFMA kernels: Cin % 4 == 0 and K-contiguous weights.  Every thread moves one float4 per operand row and
+// 16-wide K chunk (thread -> row tid / 4, k = 4 (tid % 4) .. +3 of the chunk; a float4 never straddles a tap) instead of 8
+// scalars with per-element index arithmetic (which made the generic form VALU-bound: 21 vs 80-100 TFLOP/s).
+// Workgroup tile = PT pixels x NT channels (PT NT = 4096), 4 waves of 32 x 32: 64 x 64, or 128 x 32 where that wastes
+// fewer padded channels (Cout = 24: 75 % instead of 37 % useful MFMA work; Cout = 96: 100 % instead of 75 %).
+//   ACC64 = false: v_mfma_f32_32x32x2f32, the fp32 fma chain of the float graphs.
+//   ACC64 = true : v_mfma_f64_16x16x4_f64 (products of two fp32 values are exact in fp64), 2 x 2 tiles per wave.  A operand =
+//                  pixels, B = weights: lane l supplies row / column (l & 15) and holds D[pixel 4 r + (l >> 4)][channel l & 15]
+//                  in register r (layout probed on the hardware), so a quarter-wave writes 16 consecutive channels of a pixel.
+// The contraction only needs A and B to agree on which k a (step, lane group) pair means: lane half h takes k = 8 h .. 8 h + 7
+// of the chunk (fp64: quarter q takes 4 q .. 4 q + 3), so every operand read is a conflict-free ds_read_b128.
 constexpr int CF_LD4 = 20;           // row pitch in floats: 16-byte aligned rows for the float4 stores
+typedef double v4d __attribute__((ext_vector_type(4)));
+template <int PT, int NT, bool ACC64>
 __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a) {
-  __shared__ __attribute__((aligned(16))) float As[64 * CF_LD4];
-  __shared__ __attribute__((aligned(16))) float Bs[64 * CF_LD4];
+  static_assert(PT * NT == 4096 && PT % 64 == 0 && NT % 32 == 0, "4 waves of 32 x 32");
+  __shared__ __attribute__((aligned(16))) float As[NT * CF_LD4];     // weights [n][k]
+  __shared__ __attribute__((aligned(16))) float Bs[PT * CF_LD4];     // pixels  [p][k]
+  constexpr int WN = NT / 32, XP = PT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int s = blockIdx.z;
-  const int p0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int p0 = blockIdx.x * PT, n0 = blockIdx.y * NT;
   const int npix = a.B * a.Ho * a.Wo;
   const int K = a.KS * a.KS * a.Cin;
   const float* xs = a.x + (int64_t)s * a.x_ss;
   const float* ws = a.w + (int64_t)s * a.w_ss;
   const int row = tid >> 2, kq = (tid & 3) * 4;
-  const int p = p0 + row, n = n0 + row;
-  int pb = -1, ih0 = 0, iw0 = 0;
-  if (p < npix) { pb = p / (a.Ho * a.Wo); const int rem = p - pb * a.Ho * a.Wo; ih0 = (rem / a.Wo) * a.stride - a.pad; iw0 = (rem % a.Wo) * a.stride - a.pad; }
-  const float* wrow = ws + (int64_t)(n < a.Cout ? n : 0) * K + kq;
+  int pb[XP], ih0[XP], iw0[XP];
+#pragma unroll
+  for (int j = 0; j < XP; ++j) {
+    const int p = p0 + row + 64 * j;
+    pb[j] = -1; ih0[j] = 0; iw0[j] = 0;
+    if (p < npix) { pb[j] = p / (a.Ho * a.Wo); const int rem = p - pb[j] * a.Ho * a.Wo; ih0[j] = (rem / a.Wo) * a.stride - a.pad; iw0[j] = (rem % a.Wo) * a.stride - a.pad; }
+  }
+  const bool wrow_ok = row < NT && n0 + row < a.Cout;
+  const float* wrow = ws + (int64_t)(wrow_ok ? n0 + row : 0) * K + kq;
   const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
-  auto gather = [&](int k0, v4f& xv, v4f& wv) {
-    const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;       // uniform: Cin % 16 == 0
-    const int kh = tap / a.KS, kw = tap - kh * a.KS;
-    const int ih = ih0 + kh, iw = iw0 + kw;
-    const bool ok = pb >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-    xv = ok ? *reinterpret_cast<const v4f*>(xs + (((int64_t)pb * a.H + ih) * a.W + iw) * a.Cin + c0 + kq) : zero4;
-    wv = n < a.Cout ? *reinterpret_cast<const v4f*>(wrow + k0) : zero4;
+  // this thread's float4 of the chunk: k = k0 + kq lies in tap (gkh, gkw) at channel gc (Cin % 4 == 0: never straddles a
+  // tap); advanced by 16 per chunk without divisions
+  int gkh, gkw, gc;
+  { const int tap = kq / a.Cin; gc = kq - tap * a.Cin; gkh = tap / a.KS; gkw = tap - gkh * a.KS; }
+  auto gather = [&](int k0, v4f (&xv)[XP], v4f& wv) {
+    const bool kok = k0 + kq < K;
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int ih = ih0[j] + gkh, iw = iw0[j] + gkw;
+      const bool ok = kok && pb[j] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      xv[j] = ok ? *reinterpret_cast<const v4f*>(xs + (((int64_t)pb[j] * a.H + ih) * a.W + iw) * a.Cin + gc) : zero4;
+    }
+    wv = (kok && wrow_ok) ? *reinterpret_cast<const v4f*>(wrow + k0) : zero4;
+    gc += CF_KC;
+    while (gc >= a.Cin) { gc -= a.Cin; if (++gkw == a.KS) { gkw = 0; ++gkh; } }
   };
   v16f acc;
+  v4d acc64[2][2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  v4f xv, wv;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc64[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int l15 = lane & 15, q = lane >> 4;
+  v4f xv[XP], wv;
   gather(0, xv, wv);
   for (int k0 = 0; k0 < K; k0 += CF_KC) {
-    *reinterpret_cast<v4f*>(&Bs[row * CF_LD4 + kq]) = xv;
-    *reinterpret_cast<v4f*>(&As[row * CF_LD4 + kq]) = wv;
-    __syncthreads();
-    if (k0 + CF_KC < K) gather(k0 + CF_KC, xv, wv);
 #pragma unroll
-    for (int k2 = 0; k2 < CF_KC / 2; ++k2) {
-      const float av = As[(wn * 32 + (lane & 31)) * CF_LD4 + 2 * k2 + (lane >> 5)];
-      const float bv = Bs[(wm * 32 + (lane & 31)) * CF_LD4 + 2 * k2 + (lane >> 5)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    for (int j = 0; j < XP; ++j) *reinterpret_cast<v4f*>(&Bs[(row + 64 * j) * CF_LD4 + kq]) = xv[j];
+    if (row < NT) *reinterpret_cast<v4f*>(&As[row * CF_LD4 + kq]) = wv;
+    __syncthreads();
+    if (k0 + CF_KC < K) gather(k0 + CF_KC, xv, wv);           // next chunk in flight under the MFMAs
+    if constexpr (!ACC64) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const v4f a4 = *reinterpret_cast<const v4f*>(&As[(wn * 32 + (lane & 31)) * CF_LD4 + 8 * (lane >> 5) + 4 * t]);
+        const v4f b4 = *reinterpret_cast<const v4f*>(&Bs[(wm * 32 + (lane & 31)) * CF_LD4 + 8 * (lane >> 5) + 4 * t]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { av[4 * t + i] = a4[i]; bv[4 * t + i] = b4[i]; }
+      }
+#pragma unroll
+      for (int t = 0; t < CF_KC / 2; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+    } else {
+      v4f p4[2], c4[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        p4[t] = *reinterpret_cast<const v4f*>(&Bs[(wm * 32 + t * 16 + l15) * CF_LD4 + 4 * q]);
+        c4[t] = *reinterpret_cast<const v4f*>(&As[(wn * 32 + t * 16 + l15) * CF_LD4 + 4 * q]);
+      }
+#pragma unroll
+      for (int k4 = 0; k4 < CF_KC / 4; ++k4)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc64[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)p4[i][k4], (double)c4[j][k4], acc64[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
-  const int po = p0 + wm * 32 + (lane & 31);
-  if (po >= npix) return;
-  float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
+  if constexpr (!ACC64) {
+    // D[i = channel][j = pixel]: lane owns pixel j = lane & 31, register r holds channel 8 (r / 4) + 4 (lane >> 5) + r % 4
+    const int po = p0 + wm * 32 + (lane & 31);
+    if (po >= npix) return;
+    float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int no = n0 + wn * 32 + 8 * g + 4 * (lane >> 5) + i;
-      if (no < a.Cout) {
-        yp[no] = conv_f32_tail(a, acc[4 * g + i], no, s, (int64_t)po * a.Cout + no);
+      for (int i = 0; i < 4; ++i) {
+        const int no = n0 + wn * 32 + 8 * g + 4 * (lane >> 5) + i;
+        if (no < a.Cout) yp[no] = conv_f32_tail(a, acc[4 * g + i], no, s, (int64_t)po * a.Cout + no);
       }
-    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int po = p0 + wm * 32 + i * 16 + 4 * r + q;
+        if (po >= npix) continue;
+        float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int no = n0 + wn * 32 + j * 16 + l15;
+          if (no < a.Cout) yp[no] = conv_f32_tail(a, (float)acc64[i][j][r], no, s, (int64_t)po * a.Cout + no);
+        }
+      }
+  }
 }
 
 __global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvF32Args a) {
@@ -253,25 +321,37 @@ __global__ __launch_bounds__(256) void conv2d_f32_acc64_kernel(const ConvF32Args
   }
 }
 
-QBNN_EXPORT int qbnn_conv2d_f32_fused_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* bias, const float* alpha,
-                                         const float* beta, const float* res, int64_t res_ss, float* y, int64_t y_ss, int32_t B, int32_t H,
+QBNN_EXPORT int qbnn_conv2d_f32_fused_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* div, const float* bias,
+                                         const float* alpha, const float* beta, const float* res, int64_t res_ss, float* y, int64_t y_ss, int32_t B, int32_t H,
                                          int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu,
                                          int32_t n_samples, void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || n_samples <= 0)
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: bad argument");
   ConvF32Args a;
-  a.alpha = alpha; a.beta = beta; a.res = res; a.res_ss = res_ss;
+  a.div = div; a.alpha = alpha; a.beta = beta; a.res = res; a.res_ss = res_ss;
   a.x = x; a.x_ss = x_ss; a.w = w; a.w_ss = w_ss; a.bias = bias; a.y = y; a.y_ss = y_ss;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = ksize; a.stride = stride; a.pad = pad; a.relu = relu & 1; a.w_ohwi = (relu >> 2) & 1;
   a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
   if (a.Ho <= 0 || a.Wo <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: empty output");
   const int64_t npix = (int64_t)B * a.Ho * a.Wo;
   dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)n_samples);
-  const bool vec = a.w_ohwi && (Cin % 16) == 0 && (x_ss % 4) == 0 && (w_ss % 4) == 0 &&
+  const bool vec = a.w_ohwi && (Cin % 4) == 0 && (x_ss % 4) == 0 && (w_ss % 4) == 0 &&
                    (reinterpret_cast<uintptr_t>(x) % 16) == 0 && (reinterpret_cast<uintptr_t>(w) % 16) == 0;
-  if (relu & 2) hipLaunchKernelGGL(conv2d_f32_acc64_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else if (vec) hipLaunchKernelGGL(conv2d_f32_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(conv2d_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  const bool acc64 = (relu & 2) != 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (vec) {
+    // 128 pixels x 32 channels per workgroup where 32-wide channel tiles pad less than 64-wide ones (Cout = 24, 96, ...)
+    const bool narrow = (Cout + 31) / 32 * 32 < (Cout + 63) / 64 * 64;
+    if (narrow) {
+      dim3 g2((unsigned)((npix + 127) / 128), (unsigned)((Cout + 31) / 32), (unsigned)n_samples);
+      if (acc64) hipLaunchKernelGGL((conv2d_f32_vec_kernel<128, 32, true>), g2, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv2d_f32_vec_kernel<128, 32, false>), g2, dim3(256), 0, st, a);
+    } else {
+      if (acc64) hipLaunchKernelGGL((conv2d_f32_vec_kernel<64, 64, true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv2d_f32_vec_kernel<64, 64, false>), grid, dim3(256), 0, st, a);
+    }
+  } else if (acc64) hipLaunchKernelGGL(conv2d_f32_acc64_kernel, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(conv2d_f32_kernel, grid, dim3(256), 0, st, a);
   return qbnn_check_launch_msg("qbnn_conv2d_f32_mc");
 }
 
@@ -556,6 +636,6 @@ QBNN_EXPORT int qbnn_sample_weights_f32_ohwi(const float* mu, int64_t mu_ss, con
 QBNN_EXPORT int qbnn_conv2d_f32_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* bias, float* y,
                                    int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                                    int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream) {
-  return qbnn_conv2d_f32_fused_mc(x, x_ss, w, w_ss, bias, nullptr, nullptr, nullptr, 0, y, y_ss, B, H, W, Cin, Cout, ksize, stride, pad, relu,
+  return qbnn_conv2d_f32_fused_mc(x, x_ss, w, w_ss, nullptr, bias, nullptr, nullptr, nullptr, 0, y, y_ss, B, H, W, Cin, Cout, ksize, stride, pad, relu,
                                   n_samples, stream);
 }

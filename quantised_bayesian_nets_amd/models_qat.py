@@ -155,6 +155,7 @@ class Conv2d(_QATBBB):
         if bn:
             from .models_f32 import BatchNorm2d
             self.bn = BatchNorm2d(out_channels, eps)
+        self._cb = None
         self._init_fq(args)
 
     def scale_factor(self):
@@ -170,11 +171,11 @@ class Conv2d(_QATBBB):
             b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
             z = conv2d_f32(x, W, b, self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True, ohwi=True)
         else:
-            z = conv2d_f32(x, W, None, self.in_channels, self.out_channels, self.k, self.stride, self.padding, False, acc64=True, ohwi=True)
-            c = self.scale_factor().to(dev).contiguous()
-            b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
-            z = affine_f32(z, c, b, mode=1)                                                # Z / scale_factor (+ bias), :159-161
-            z = self.bn(z, relu=self.relu)
+            # conv, Z / scale_factor (+ bias) (:159-161), bn, ReLU: one kernel, each step rounded as the reference rounds it
+            if self._cb is None or self._cb[0].device != dev:
+                self._cb = (self.scale_factor().to(dev).contiguous(), None if self.bias is None else self.bias.detach().to(dev).contiguous())
+            z = conv2d_f32(x, W, self._cb[1], self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True,
+                           ohwi=True, div=self._cb[0], bn=self.bn.coefficients(dev))
         return self.activation_post_process(z)
 
     def load(self, st, name):
@@ -182,6 +183,7 @@ class Conv2d(_QATBBB):
         if self.bn is not None:
             from .models_f32 import _load_bn
             _load_bn(self.bn, st, name + ".bn")
+        self._cb = None
         return self
 
 
