@@ -30,6 +30,8 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_I8_PEAK_TOPS = 5000.0   # int8 dense = 2x bf16 (2.5 PF)
+MFMA_I8_SUSTAINED_TOPS = 3260.0   # measured: pure v_mfma_i32_32x32x32_i8 loop on random int8 operands, whole chip
+                                  # (tools/mfma_sustained.hip, profiles/r01_mfma_sustained.txt; 4700 on all-zero operands)
 
 
 def conv_algorithmic_bytes(S, B, H, Cin, Cout, ks, stride, nweights):
@@ -135,7 +137,8 @@ def main():
             # fused block kernels keep activations in LDS: their HBM traffic is a fraction of the layer-granular byte
             # model, the binding roof is the int8 matrix pipe
             roof = {"bound": "mfma", "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
-                    "frac": round(tops / MFMA_I8_PEAK_TOPS, 4), "layer_granular_GBps": round(gbs, 1),
+                    "frac": round(tops / MFMA_I8_PEAK_TOPS, 4), "sustained_peak_measured": MFMA_I8_SUSTAINED_TOPS,
+                    "frac_of_sustained": round(tops / MFMA_I8_SUSTAINED_TOPS, 4), "layer_granular_GBps": round(gbs, 1),
                     "layer_granular_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), **common}
         else:
             roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
