@@ -509,3 +509,47 @@ def test_resnet_mc_dropout_matches_reference():
     np.testing.assert_allclose(p.cpu().numpy(), g["probs"], rtol=1e-5, atol=1e-8)
     mean = q.mc_predict(m, x, S, g["meta"]["philox_seed"])
     np.testing.assert_allclose(mean.cpu().numpy(), g["mean_probs"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("acc64", [False, True])
+def test_fp32_conv_kernels_every_path_against_torch(acc64):
+    """qbnn_conv2d_f32_fused_mc through the C ABI against torch's fp32 conv2d + the same pointwise tail, on geometries that
+    reach every kernel variant: float4 path with 64x64 and 128x32 tiles, K not a multiple of the 16-wide chunk (Cin = 20, 24),
+    ragged pixel / channel tiles, stride 2, 1x1, shared input (sample stride 0), the gather kernel (Cin = 3, reference
+    weight order) and the fused tail (/ div, + bias, * alpha, + beta, + res, ReLU).  fp32 tolerance: 1e-5 of the output scale
+    (summation order differs); the fp64-accumulating variant must agree with a float64 torch conv to one fp32 rounding."""
+    from quantised_bayesian_nets_amd.models_f32 import conv2d_f32
+    gen = torch.Generator().manual_seed(5)
+    cases = [  # S, B, H, Cin, Cout, k, stride, pad, ohwi, shared_x, tail
+        (3, 5, 12, 24, 24, 3, 1, 1, True, False, True),     # 128x32 tiles, K = 216 (13.5 chunks), ragged pixel tile
+        (2, 3, 9, 20, 40, 3, 2, 1, True, False, False),     # Cin % 4 == 0 only, 64x64 tiles, ragged Cout, stride 2
+        (2, 4, 8, 48, 96, 1, 2, 0, True, True, True),       # 1x1 stride 2, Cout = 96 -> narrow tiles, input shared by the samples
+        (2, 2, 6, 192, 192, 3, 1, 1, True, False, True),    # 64x64 tiles, K = 1728
+        (2, 3, 10, 3, 24, 3, 1, 1, False, True, True),      # gather kernel, reference weight order
+        (1, 2, 7, 6, 10, 5, 1, 2, True, False, False),      # Cin % 4 != 0 -> gather kernel with K-contiguous weights
+    ]
+    for (S, B, H, ci, co, k, st, pad, ohwi, shared, tail) in cases:
+        x = torch.randn(1 if shared else S, B, ci, H, H, generator=gen)
+        w = torch.randn(S, co, ci, k, k, generator=gen) * 0.1
+        bias, div, alpha, beta = (torch.randn(co, generator=gen) for _ in range(4))
+        div = div.abs() + 0.5
+        Ho = (H + 2 * pad - k) // st + 1
+        res = torch.randn(S, B, co, Ho, Ho, generator=gen)
+        dt = torch.float64 if acc64 else torch.float32
+        ref = torch.stack([torch.nn.functional.conv2d(x[0 if shared else s].to(dt), w[s].to(dt), None, st, pad) for s in range(S)]).float()
+        if tail:
+            ref = ref / div.view(1, 1, -1, 1, 1)
+            ref = ref + bias.view(1, 1, -1, 1, 1)
+            ref = ref * alpha.view(1, 1, -1, 1, 1)
+            ref = ref + beta.view(1, 1, -1, 1, 1)
+            ref = torch.relu(ref + res)
+        xg = x.permute(0, 1, 3, 4, 2).contiguous().cuda()                       # NHWC
+        wg = (w.permute(0, 1, 3, 4, 2) if ohwi else w).reshape(S, -1).contiguous().cuda()
+        kw = dict(acc64=acc64, ohwi=ohwi)
+        if tail:
+            kw.update(div=div.cuda(), bn=(alpha.cuda(), beta.cuda()), res=res.permute(0, 1, 3, 4, 2).contiguous().cuda())
+        y = conv2d_f32(xg, wg, bias.cuda() if tail else None, ci, co, k, st, pad, tail, **kw)
+        got = y.permute(0, 1, 4, 2, 3).cpu()
+        scale = float(ref.abs().max())
+        tol = (2e-7 if acc64 else 1e-5) * scale * (8 if tail else 1)      # the tail's roundings amplify a 1-ulp conv difference
+        assert float((got - ref).abs().max()) <= tol, ((S, B, H, ci, co, k, st), float((got - ref).abs().max()), tol)
