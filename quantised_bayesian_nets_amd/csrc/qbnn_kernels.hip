@@ -2836,15 +2836,34 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownAr
     QBNN_STAMP_AT(4);
     lds_barrier();
     QBNN_STAMP_AT(5);
-    if (more) write_tile(item_at(it + 1));      // before the stores: its vmcnt wait then covers only the (old) input loads
-    QBNN_STAMP_AT(6);
-    {
-      constexpr int IMG_OUT = CB::HO * CB::HO * COUT, U8 = COUT / 8;          // 8-byte units (the padded pitch is 8-aligned)
-      uint8_t* ys = a.y + (int64_t)s * a.y_ss;
+    // read-out of the finished block output.  Weights-stationary form (registers to spare): all LDS reads first (a rolled
+    // read -> wait -> store loop pays the LDS latency per trip), then the next X tile, then the stores -- nothing in the
+    // next item waits on them.  The streaming forms sit at the register limit and keep the rolled loop.
+    constexpr int IMG_OUT = CB::HO * CB::HO * COUT, U8 = COUT / 8;          // 8-byte units (the padded pitch is 8-aligned)
+    constexpr int NOUT = (CB::M * U8 + BLK_THREADS - 1) / BLK_THREADS;
+    uint8_t* ys = a.y + (int64_t)s * a.y_ss + (int64_t)img0 * IMG_OUT;
+    if constexpr (LDSW) {
+      v2i outv[NOUT];
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const int i = tid + j * BLK_THREADS;
+        const int px = i / U8, within = i - px * U8;
+        if (i < CB::M * U8) outv[j] = *reinterpret_cast<const v2i*>(sc + px * SCP + within * 8);
+      }
+      if (more) write_tile(item_at(it + 1));      // before the stores: its vmcnt wait then covers only the (old) input loads
+      QBNN_STAMP_AT(6);
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const int i = tid + j * BLK_THREADS;
+        if (i < CB::M * U8 && img0 + (i * 8) / IMG_OUT < a.B) *reinterpret_cast<v2i*>(ys + (int64_t)i * 8) = outv[j];
+      }
+    } else {
+      if (more) write_tile(item_at(it + 1));
+      QBNN_STAMP_AT(6);
       for (int i = tid; i < CB::M * U8; i += BLK_THREADS)
         if (img0 + (i * 8) / IMG_OUT < a.B) {
           const int px = i / U8, within = i - px * U8;
-          *reinterpret_cast<v2i*>(ys + (int64_t)img0 * IMG_OUT + (int64_t)i * 8) = *reinterpret_cast<const v2i*>(sc + px * SCP + within * 8);
+          *reinterpret_cast<v2i*>(ys + (int64_t)i * 8) = *reinterpret_cast<const v2i*>(sc + px * SCP + within * 8);
         }
     }
     QBNN_STAMP_AT(7);
