@@ -96,6 +96,9 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
+    # HIP events around the fused conv-block launches only (the candidates for `roofline`; the small kernels are in the
+    # rocprofv3 summary under profiles/): every event costs a few microseconds of drained queue inside the timed region
+    qlayers.PROFILE_FILTER = lambda meta: bool(meta) and "convs" in meta
     qlayers.PROFILE = prof = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -131,7 +134,7 @@ def main():
             # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE; see that file's note)
             traffic = json.load(open(tpath))["by_bench_key"].get(dom)
         common = {"kernel": dom, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": d["n"],
-                  "share_of_gpu_time": round(d["ms"] / total_ms, 3), "convs_in_launch": len(m["convs"]),
+                  "share_of_step_time": round(d["ms"] / (dt * 1e3), 3), "convs_in_launch": len(m["convs"]),
                   "algorithmic_bytes_per_launch": abytes, "algorithmic_ops_per_launch": ops, "traffic": traffic}
         if m["fused"]:
             # fused block kernels keep activations in LDS: their HBM traffic is a fraction of the layer-granular byte

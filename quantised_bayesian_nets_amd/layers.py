@@ -21,20 +21,30 @@ from .quant import INT_BOUNDS, UINT_BOUNDS, make_sample_params
 
 LAYOUT_MFMA32, LAYOUT_ROWMAJOR = 0, 1
 
-# bench.py sets this to a list: every kernel launch then appends (key, meta, start_event, end_event), HIP events
-# recorded on the launch stream (torch's current stream).
+# bench.py sets this to a list: kernel launches then append (key, meta, start_event, end_event), HIP events recorded on the
+# launch stream (torch's current stream).  PROFILE_FILTER (a predicate on meta) limits the events to the launches of
+# interest, and back-to-back profiled launches share one event (end of one = start of the next): every event is a marker
+# packet that drains the queue, ~4 us each, which at 24 events per 4 ms step was 2.5 % of the measured step.
 PROFILE = None
+PROFILE_FILTER = None
+_prev_end = None
 
 
 @contextlib.contextmanager
 def timed(key, meta=None):
-    if PROFILE is None:
+    global _prev_end
+    if PROFILE is None or (PROFILE_FILTER is not None and not PROFILE_FILTER(meta)):
+        _prev_end = None                 # another launch goes between: the next profiled one needs its own start event
         yield
         return
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    e0 = _prev_end
+    if e0 is None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     yield
+    e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
+    _prev_end = e1
     PROFILE.append((key, meta, e0, e1))
 
 
