@@ -348,24 +348,77 @@ class Network(nn.Module):
         self.output_size = int(output_size)
         self.ensemble = nn.ModuleList([ConvNetwork_ResNet(input_size, output_size, q, args, deterministic=True) for _ in range(args.samples)])
         self.counter = 0
+        # A member's forward is ~12 launches on one sample's worth of work: launch-bound.  Members are deterministic (no
+        # seed, no sample offset), so each member's launch chain is captured once per input shape into a HIP graph and
+        # replayed (QBNN_NO_GRAPHS=1: always launch eagerly).
+        self.use_graphs = os.environ.get("QBNN_NO_GRAPHS", "0") != "1"
+        self._graphs = {}
+        self._streams = []
 
     def load_reference_state(self, member_states):
         assert len(member_states) == len(self.ensemble)
         for m, st in zip(self.ensemble, member_states):
             m.load_reference_state(st)
+        self._graphs = {}
         return self
+
+    def _member_forward(self, idx, x, record=None):
+        """[1, B, C] probabilities of member `idx`; replays the member's captured launch chain when there is one."""
+        from . import layers as _layers
+        member = self.ensemble[idx]
+        if record is not None or not self.use_graphs or _layers.PROFILE is not None or x.device.type != "cuda":
+            with mc_context(1, 0, 0):
+                return member.forward_mc(x, record=record)
+        key = (idx, tuple(x.shape), x.dtype, x.device.index)
+        ent = self._graphs.get(key)
+        if ent is None:
+            with mc_context(1, 0, 0):
+                member.forward_mc(x)                        # eager once: packs the weights, fills every cache the chain reads
+                try:
+                    static_x = x.clone()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        static_y = member.forward_mc(static_x)
+                    ent = (graph, static_x, static_y)
+                except Exception:                           # capture refused: keep launching eagerly (same kernels)
+                    torch.cuda.synchronize()
+                    ent = False
+            self._graphs[key] = ent
+        if ent is False:
+            with mc_context(1, 0, 0):
+                return member.forward_mc(x)
+        graph, static_x, static_y = ent
+        static_x.copy_(x)
+        graph.replay()
+        return static_y.clone()
 
     def forward_mc(self, x, record=None):
         n = len(self.ensemble)
-        outs = []
-        for i in range(_MC.samples):
-            with mc_context(1, _MC.seed, 0):
-                outs.append(self.ensemble[(_MC.sample_begin + i) % n].forward_mc(x, record=record if i == 0 else None))
+        idx = [(_MC.sample_begin + i) % n for i in range(_MC.samples)]
+        graphed = (record is None and self.use_graphs and x.device.type == "cuda" and len(idx) > 1 and
+                   all(self._graphs.get((j, tuple(x.shape), x.dtype, x.device.index)) for j in idx))
+        if not graphed:
+            return torch.cat([self._member_forward(j, x, record=record if i == 0 else None) for i, j in enumerate(idx)], 0)
+        # every member has a captured chain: replay them round-robin on a few side streams -- one member's late layers
+        # fill 16-64 of the 256 CUs, so independent members overlap
+        main = torch.cuda.current_stream()
+        if not self._streams:
+            self._streams = [torch.cuda.Stream() for _ in range(4)]
+        outs = [None] * len(idx)
+        for st in self._streams:
+            st.wait_stream(main)
+        for i, j in enumerate(idx):
+            st = self._streams[i % len(self._streams)]
+            with torch.cuda.stream(st):
+                outs[i] = self._member_forward(j, x)
+                outs[i].record_stream(main)
+        for st in self._streams:
+            main.wait_stream(st)
         return torch.cat(outs, 0)
 
     def forward(self, x):
         with mc_context(1, 0, 0):
-            y = self.ensemble[self.counter].forward_mc(x)[0]
+            y = self._member_forward(self.counter, x)[0]
         self.counter += 1
         if self.counter >= self.args.samples:
             self.counter = 0

@@ -337,6 +337,13 @@ def test_ensemble_matches_reference(golden_ensemble):
     np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=RTOL, atol=1e-8)
     mean = q.mc_predict(net, x, n, 0)
     np.testing.assert_allclose(mean.cpu().numpy(), g["mean_probs"], rtol=RTOL, atol=1e-8)
+    # the members' launch chains are now captured as HIP graphs: later passes replay them on side streams, on new inputs too
+    for _ in range(3):
+        with q.mc_context(n, 0, 0):
+            assert torch.equal(net.forward_mc(x), probs)
+    x2 = torch.flip(x, dims=[0])
+    with q.mc_context(n, 0, 0):
+        assert torch.equal(net.forward_mc(x2), torch.flip(probs, dims=[1]))
     # the reference's round-robin call contract (models_sgld.py:277-288)
     outs = [net(x).cpu().numpy() for _ in range(n + 1)]
     np.testing.assert_allclose(np.stack(outs[:n]), g["probs"], rtol=RTOL, atol=1e-8)
