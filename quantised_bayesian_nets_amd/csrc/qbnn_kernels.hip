@@ -3245,6 +3245,9 @@ __global__ __launch_bounds__(256) void conv_generic_i8_kernel(const GenConvArgs 
 //   sum_k (x_k - z_x)(w_k - z_w) = acc - z_w R + a Wsum[co] - K a z_w,   a = 128 - z_x, R = sum_k x'_k, Wsum = sum_k w_k
 // -- all int32-exact; R and Wsum are v_dot4 sums over the fragments the MFMA consumes.  Bit-identical to
 // conv_generic_i8_kernel (tests compare the two), 50-200x faster on the LeNet / MLP layers.
+// VEC4: Cin % 4 == 0 and 4-byte aligned operands -- a dword never straddles a tap, so the gather moves 4 channels per load
+// with one index decomposition per dword instead of per byte (the gather's vector-ALU work is what bounds this kernel).
+template <bool VEC4>
 __global__ __launch_bounds__(256) void conv_generic_mfma_i8_kernel(const GenConvArgs a) {
   constexpr int LD = 48;
   __shared__ __attribute__((aligned(16))) uint8_t As[64 * LD];      // weights [n][k]
@@ -3270,6 +3273,22 @@ __global__ __launch_bounds__(256) void conv_generic_mfma_i8_kernel(const GenConv
     int tap = kk / a.Cin, c = kk - tap * a.Cin;
     int kh = tap / a.KW, kw = tap - kh * a.KW;
     xv[0] = xv[1] = wv[0] = wv[1] = 0u;
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j, kk += 4) {
+        if (kk < K) {
+          if (pb >= 0) {
+            const int ih = ih0 + kh, iw = iw0 + kw;
+            const bool in = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            xv[j] = in ? (*reinterpret_cast<const uint32_t*>(xs + xbase + ((int64_t)ih * a.W + iw) * a.Cin + c) ^ 0x80808080u) : xpad * 0x01010101u;
+          }
+          if (n < a.Cout) wv[j] = *reinterpret_cast<const uint32_t*>(wrow + kk);
+        }
+        c += 4;
+        if (c == a.Cin) { c = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j, ++kk) {
       uint32_t xb = 0u, wb = 0u;
@@ -3350,9 +3369,13 @@ QBNN_EXPORT int qbnn_conv2d_i8_generic_mc(const uint8_t* x, int64_t x_ss, const 
   const int64_t total = npix * a.Cout;
   if (generic_naive() || (int64_t)a.KH * a.KW * a.Cin > (1 << 16))      // (int32 head-room of the correction terms)
     hipLaunchKernelGGL(conv_generic_i8_kernel, dim3((unsigned)((total + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(conv_generic_mfma_i8_kernel, dim3((unsigned)((npix + 63) / 64), (unsigned)((a.Cout + 63) / 64), n_samples), dim3(256), 0,
-                       (hipStream_t)stream, a);
+  else {
+    const dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((a.Cout + 63) / 64), n_samples);
+    const bool vec4 = (a.Cin % 4) == 0 && (x_ss % 4) == 0 && (w_ss % 4) == 0 && (reinterpret_cast<uintptr_t>(x) % 4) == 0 &&
+                      (reinterpret_cast<uintptr_t>(w_ohwi) % 4) == 0;
+    if (vec4) hipLaunchKernelGGL(conv_generic_mfma_i8_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_generic_mfma_i8_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   return check_launch("qbnn_conv2d_i8_generic_mc");
 }
 
