@@ -3552,6 +3552,11 @@ QBNN_EXPORT int qbnn_linear_f32_mc(const float* x, int64_t x_ss, const float* w,
                                    int64_t y_ss, int32_t B, int32_t K, int32_t N, int32_t act, int32_t n_samples, void* stream) {
   if (!x || !w || !y || B <= 0 || K <= 0 || N <= 0 || n_samples <= 0 || act < 0 || act > 2)
     return fail(QBNN_E_INVALID, "qbnn_linear_f32_mc: bad argument%s");
+  // a Linear is a 1x1 conv over a 1x1 map with [out][in] = OHWI weights: the MFMA implicit-GEMM kernels of qbnn_f32.hip
+  // (float4 path when in_features % 4 == 0); only the exp head (N = 1) stays on the one-thread-per-output kernel
+  if (act != 2)
+    return qbnn_conv2d_f32_fused_mc(x, x_ss, w, w_ss, nullptr, bias, nullptr, nullptr, nullptr, 0, y, y_ss, B, 1, 1, K, N, 1, 1, 0,
+                                    (act == 1 ? 1 : 0) | 4, n_samples, stream);
   const int64_t total = (int64_t)B * N;
   hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)((total + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
                      x, x_ss, w, w_ss, bias, y, y_ss, B, K, N, act);
