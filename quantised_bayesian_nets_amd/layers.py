@@ -340,7 +340,7 @@ class Conv2d(_BBBInt8):
                                                             _lib.ptr(y), y[0].numel(), S, C.byref(d), _stream()))
         return MCQTensor(y, self.scale, self.zero_point)
 
-    def _conv(self, x, w, S, residual=None, add_qparams=None, im2col=None):
+    def _conv(self, x, w, S, residual=None, add_qparams=None, im2col=None, w_shared=False):
         if self.layout == LAYOUT_ROWMAJOR:
             if residual is not None or im2col is not None:
                 raise NotImplementedError("the generic conv path has no fused residual / im2col")
@@ -373,7 +373,7 @@ class Conv2d(_BBBInt8):
         key = "conv_i8 %dx%d %d->%d k%d s%d%s" % (H, W, Cin, self.out_channels, ks, st, " +res" if residual is not None else "")
         meta = dict(fused=False, convs=[(H, 3 if im2col is not None else Cin, self.out_channels, 3 if im2col is not None else ks, st, pk["cout"] * pk["k"])])
         with timed(key, meta):
-            _lib.check(_lib.lib().qbnn_conv2d_i8_mc(_lib.ptr(xin), xss, _lib.ptr(w), w.shape[1], _lib.ptr(pk["bias"]),
+            _lib.check(_lib.lib().qbnn_conv2d_i8_mc(_lib.ptr(xin), xss, _lib.ptr(w), 0 if w_shared else w.shape[1], _lib.ptr(pk["bias"]),
                                                     _lib.ptr(None if residual is None else residual.data), res_ss,
                                                     _lib.ptr(y), y[0].numel(), S, C.byref(d), _stream()))
         if residual is not None:

@@ -119,10 +119,37 @@ class QConv2d(_QDeterministic):
         self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding = in_channels, out_channels, kernel_size, stride, padding
         self._init((out_channels, in_channels, kernel_size, kernel_size), args)
 
+    # geometries of the tuned LDS-tiled layer kernel (qbnn_conv2d_i8_mc): (H, Cin, Cout, k, stride), pad = (k - 1) / 2
+    _TUNED = {(32, 24, 24, 3, 1), (32, 24, 48, 3, 2), (32, 24, 48, 1, 2), (16, 48, 48, 3, 1), (16, 48, 96, 3, 2), (16, 48, 96, 1, 2),
+              (8, 96, 96, 3, 1), (8, 96, 192, 3, 2), (8, 96, 192, 1, 2), (4, 192, 192, 3, 1)}
+
+    def _tuned(self):
+        """This conv as a deterministic layers.Conv2d: the fixed qint8 weight is the one 'sample', shared by all MC samples."""
+        if getattr(self, "_fast", None) is None:
+            from .layers import Conv2d as _Conv, ConvReLU2d as _ConvReLU
+            m = (_ConvReLU if self.relu else _Conv)(self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
+                                                    bias=self.bias_ is not None, args=self.args)
+            m.deterministic = True
+            st = {"weight": self._weight.int_repr(), "weight.q_scale": self._weight.q_scale(), "weight.q_zero_point": self._weight.q_zero_point(),
+                  "scale": self.scale, "zero_point": self.zero_point}
+            if self.bias_ is not None:
+                st["bias"] = self.bias_.cpu().numpy()
+            self._fast = m.load_reference_state(st, "")
+        return self._fast
+
+    def load_reference_state(self, state, prefix):
+        self._fast = None
+        return super().load_reference_state(state, prefix)
+
     def forward(self, x):
         _, B, H, W, Cin = x.data.shape
         ks, st, pd = self.kernel_size, self.stride, self.padding
         Ho, Wo = (H + 2 * pd - ks) // st + 1, (W + 2 * pd - ks) // st + 1
+        if H == W and pd == (ks - 1) // 2 and (H, Cin, self.out_channels, ks, st) in self._TUNED:
+            m = self._tuned()
+            pk = m._ensure_packed(x.data.device)
+            y = m._conv(x, pk["mu"].reshape(1, -1), 1 if x.shared else x.samples, w_shared=True)
+            return MCQTensor(y.data, self.scale, self.zero_point, shared=x.shared)
         w = self._weight.int_repr().transpose(0, 2, 3, 1)
         return self._run(x, w, H, W, Cin, self.out_channels, ks, st, pd, (B, Ho, Wo, self.out_channels))
 
