@@ -197,6 +197,13 @@ int qbnn_conv2d_i8_generic_mc(const uint8_t* x, int64_t x_sample_stride, const i
                               const float* bias, uint8_t* y, int64_t y_sample_stride, int32_t n_samples,
                               const qbnn_conv_desc* host_desc, void* stream);
 
+/* The same contract on the one-thread-per-output scalar kernel (the first implementation): kept as the on-device
+ * cross-check of the MFMA form -- tests require bit-identical outputs -- and selected for every call by
+ * QBNN_GENERIC_NAIVE=1. */
+int qbnn_conv2d_i8_generic_scalar_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w_ohwi, int64_t w_sample_stride,
+                              const float* bias, uint8_t* y, int64_t y_sample_stride, int32_t n_samples,
+                              const qbnn_conv_desc* host_desc, void* stream);
+
 /* Quantised BernoulliDropout.forward (mcdropout/dropout.py:15-40) + clamp_activation, x [S][B][HW][C] channels-last:
  *   mask ~ Bernoulli(keep_prob), one draw per (sample, b, c) -- per channel for 4-D inputs, per element when HW == 1 --
  *   from the Philox uniform stream  philox4x32_10(ctr = {i >> 2, layer_id, sample_begin + s, 1}, key = seed)[i & 3] >> 8,

@@ -3352,8 +3352,21 @@ __global__ __launch_bounds__(256) void conv_generic_mfma_i8_kernel(const GenConv
 
 static bool generic_naive() { static const bool v = [] { const char* e = getenv("QBNN_GENERIC_NAIVE"); return e && e[0] == '1'; }(); return v; }
 
+static int conv2d_i8_generic(const uint8_t* x, int64_t x_ss, const int8_t* w_ohwi, int64_t w_ss, const float* bias, uint8_t* y,
+                             int64_t y_ss, int32_t n_samples, const qbnn_conv_desc* d, void* stream, bool scalar_form);
+
 QBNN_EXPORT int qbnn_conv2d_i8_generic_mc(const uint8_t* x, int64_t x_ss, const int8_t* w_ohwi, int64_t w_ss, const float* bias,
                                           uint8_t* y, int64_t y_ss, int32_t n_samples, const qbnn_conv_desc* d, void* stream) {
+  return conv2d_i8_generic(x, x_ss, w_ohwi, w_ss, bias, y, y_ss, n_samples, d, stream, generic_naive());
+}
+
+QBNN_EXPORT int qbnn_conv2d_i8_generic_scalar_mc(const uint8_t* x, int64_t x_ss, const int8_t* w_ohwi, int64_t w_ss, const float* bias,
+                                                 uint8_t* y, int64_t y_ss, int32_t n_samples, const qbnn_conv_desc* d, void* stream) {
+  return conv2d_i8_generic(x, x_ss, w_ohwi, w_ss, bias, y, y_ss, n_samples, d, stream, true);
+}
+
+static int conv2d_i8_generic(const uint8_t* x, int64_t x_ss, const int8_t* w_ohwi, int64_t w_ss, const float* bias, uint8_t* y,
+                             int64_t y_ss, int32_t n_samples, const qbnn_conv_desc* d, void* stream, bool scalar_form) {
   if (!x || !w_ohwi || !y || !d || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_generic_mc: bad argument%s");
   if (d->a_hi > 255 || d->a_hi < 1) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_generic_mc: bad a_hi%s");
   GenConvArgs a;
@@ -3367,7 +3380,7 @@ QBNN_EXPORT int qbnn_conv2d_i8_generic_mc(const uint8_t* x, int64_t x_ss, const 
   if (a.Ho <= 0 || a.Wo <= 0 || a.Cin <= 0 || a.Cout <= 0) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_generic_mc: empty geometry%s");
   const int64_t npix = (int64_t)a.B * a.Ho * a.Wo;
   const int64_t total = npix * a.Cout;
-  if (generic_naive() || (int64_t)a.KH * a.KW * a.Cin > (1 << 16))      // (int32 head-room of the correction terms)
+  if (scalar_form || (int64_t)a.KH * a.KW * a.Cin > (1 << 16))      // (int32 head-room of the correction terms)
     hipLaunchKernelGGL(conv_generic_i8_kernel, dim3((unsigned)((total + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream, a);
   else {
     const dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((a.Cout + 63) / 64), n_samples);

@@ -560,3 +560,60 @@ def test_fp32_conv_kernels_every_path_against_torch(acc64):
         scale = float(ref.abs().max())
         tol = (2e-7 if acc64 else 1e-5) * scale * (8 if tail else 1)      # the tail's roundings amplify a 1-ulp conv difference
         assert float((got - ref).abs().max()) <= tol, ((S, B, H, ci, co, k, st), float((got - ref).abs().max()), tol)
+
+
+def test_generic_int8_conv_mfma_equals_scalar_form_and_integer_reference():
+    """qbnn_conv2d_i8_generic_mc (byte / dword gathered MFMA implicit GEMM with zero-point corrections) against the scalar
+    one-thread-per-output kernel bit for bit, and both against an int64 numpy restatement of sum (x - z_x)(w - z_w), on
+    adversarial geometries and zero points: odd Cin, K not a multiple of 32, ragged pixel / channel tiles, padding + stride,
+    1x1 linear shapes, extreme zero points, shared input and shared weights.  The bias centres the outputs so that no case
+    saturates (a saturated output would hide the arithmetic)."""
+    import ctypes as C
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+    cases = [  # S, B, H, Cin, Cout, k, stride, pad, z_x, z_w, shared_x, shared_w, relu
+        (3, 5, 9, 20, 50, 5, 1, 2, 60, 3, True, False, True),
+        (2, 3, 12, 1, 20, 5, 1, 2, 0, -128, False, False, False),
+        (2, 130, 1, 2450, 70, 1, 1, 0, 255, 127, False, True, True),
+        (4, 7, 10, 7, 9, 3, 2, 1, 128, -5, False, False, False),
+        (2, 2, 8, 24, 130, 3, 1, 1, 64, 11, True, True, True),
+        (1, 66, 1, 13, 100, 1, 1, 0, 17, -77, False, False, True),
+    ]
+    for (S, B, H, ci, co, k, st, pad, zx, zw, sx, sw, relu) in cases:
+        Ho = (H + 2 * pad - k) // st + 1
+        xh = rng.integers(0, 256, size=(1 if sx else S, B, H, H, ci), dtype=np.uint8)
+        wh = rng.integers(-128, 128, size=(1 if sw else S, co, k, k, ci), dtype=np.int8)
+        # int64 restatement; padded taps contribute (x - z_x) = 0
+        xp = np.pad(xh.astype(np.int64) - zx, ((0, 0), (0, 0), (pad, pad), (pad, pad), (0, 0)))
+        wn = wh.astype(np.int64) - zw
+        acc = np.zeros((S, B, Ho, Ho, co), np.int64)
+        for s in range(S):
+            for kh in range(k):
+                for kw in range(k):
+                    patch = xp[0 if sx else s, :, kh:kh + st * Ho:st, kw:kw + st * Ho:st, :]
+                    acc[s] += np.einsum("bhwc,oc->bhwo", patch, wn[0 if sw else s, :, kh, kw, :])
+        s_x, s_w = np.float32(0.02), np.float32(0.003)
+        atw = s_x * s_w
+        s_y = np.float32(atw * acc.std() / 25.0)
+        bias_h = (-acc.mean(axis=(0, 1, 2, 3)) * np.float64(atw)).astype(np.float32)      # centres every channel on z_y
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.pad = B, H, H, ci, co, k, st, pad
+        d.s_x, d.z_x, d.s_w, d.z_w, d.s_y, d.z_y = float(s_x), zx, float(s_w), zw, float(s_y), 60
+        d.relu, d.a_hi, d.has_bias = int(relu), 127, 1
+        x, w, bias = torch.from_numpy(xh).cuda(), torch.from_numpy(wh).cuda(), torch.from_numpy(bias_h).cuda()
+        outs = []
+        for fn in (L.qbnn_conv2d_i8_generic_mc, L.qbnn_conv2d_i8_generic_scalar_mc):
+            y = torch.zeros((S, B, Ho, Ho, co), dtype=torch.uint8, device="cuda")
+            _lib.check(fn(_lib.ptr(x), 0 if sx else x[0].numel(), _lib.ptr(w), 0 if sw else w[0].numel(), _lib.ptr(bias),
+                          _lib.ptr(y), y[0].numel(), S, C.byref(d), _lib.current_stream()))
+            outs.append(y.cpu().numpy())
+        case = (S, B, H, ci, co, k, st, pad, zx, zw)
+        assert np.array_equal(outs[0], outs[1]), case
+        assert outs[0].std() > 5.0, case
+        # requantisation as the kernels do it: fma(bias, 1 / (s_x s_w), acc) * (s_x s_w / s_y), rne, + z_y, clamp
+        rcp, mult = np.float32(1.0) / atw, atw / s_y
+        # (float)acc rounds first (|acc| may exceed 2^24); the fma's product is exact in float64, one rounding to fp32
+        xf = (bias_h.astype(np.float64) * np.float64(rcp) + acc.astype(np.float32).astype(np.float64)).astype(np.float32)
+        q = np.clip(60 + np.rint(xf * mult).astype(np.int64), 60 if relu else 0, 127).astype(np.uint8)
+        assert np.array_equal(q, outs[0]), case
