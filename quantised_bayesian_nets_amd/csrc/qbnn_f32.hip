@@ -573,6 +573,18 @@ __global__ __launch_bounds__(256) void sample_weights_f32_strided_kernel(const f
   } else {
     qbnn::normal4(qbnn::philox4x32_10((uint32_t)g, layer_id, sample_begin + s, 0u, seed_lo, seed_hi), e);
   }
+  if ((n & 3) == 0 && ((mu_ss | sigma_ss) & 3) == 0 &&
+      ((reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(sigma) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+    const float4 s4 = reinterpret_cast<const float4*>(sigma + (int64_t)s * sigma_ss)[g];
+    const float4 m4 = mu ? reinterpret_cast<const float4*>(mu + (int64_t)s * mu_ss)[g] : float4{0.f, 0.f, 0.f, 0.f};
+    float4 o;
+    { const float t = e[0] * s4.x; o.x = mu ? m4.x + t : t; }
+    { const float t = e[1] * s4.y; o.y = mu ? m4.y + t : t; }
+    { const float t = e[2] * s4.z; o.z = mu ? m4.z + t : t; }
+    { const float t = e[3] * s4.w; o.w = mu ? m4.w + t : t; }
+    reinterpret_cast<float4*>(w + (int64_t)s * n)[g] = o;
+    return;
+  }
   for (int j = 0; j < 4; ++j) {
     const int64_t i = g * 4 + j;
     if (i < n) {

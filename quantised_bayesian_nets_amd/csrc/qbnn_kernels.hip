@@ -3529,6 +3529,17 @@ __global__ __launch_bounds__(256) void sample_weights_f32_kernel(const float* __
   } else {
     qbnn::normal4(qbnn::philox4x32_10((uint32_t)g, layer_id, sample_begin + s, 0u, seed_lo, seed_hi), e);
   }
+  if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(sigma) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+    // whole group in range and 16-byte aligned: one vector load per operand, one vector store (same arithmetic per element)
+    const float4 m4 = reinterpret_cast<const float4*>(mu)[g], s4 = reinterpret_cast<const float4*>(sigma)[g];
+    float4 o;
+    { const float t = e[0] * s4.x; o.x = m4.x + t; }
+    { const float t = e[1] * s4.y; o.y = m4.y + t; }
+    { const float t = e[2] * s4.z; o.z = m4.z + t; }
+    { const float t = e[3] * s4.w; o.w = m4.w + t; }
+    reinterpret_cast<float4*>(w + (int64_t)s * n)[g] = o;
+    return;
+  }
   for (int j = 0; j < 4; ++j) {
     const int64_t i = g * 4 + j;
     if (i < n) { const float t = e[j] * sigma[i]; w[(int64_t)s * n + i] = mu[i] + t; }
