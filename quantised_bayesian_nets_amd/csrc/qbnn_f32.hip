@@ -20,16 +20,14 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // =====================================================================================
-// conv2d, fp32, per-sample weights.  Implicit GEMM on v_mfma_f32_32x32x2f32 (exact fp32 fma chain per output):
-//   workgroup = 4 waves = 64 output pixels x 64 output channels; wave (wm, wn) owns a 32 x 32 sub-tile
-//   (A operand = weights: lane l holds W[n = l & 31][k = l >> 5];  B operand = pixels: lane l holds X[p = l & 31][k]).
-//   K = KH * KW * Cin is walked in chunks of 16 staged through LDS; the gather (im2col on the fly, zero padding,
-//   reference weight order [Cout][Cin][KH][KW]) costs index arithmetic per element -- this kernel serves every
-//   geometry of the float graphs, it is not the tuned int8 path.
+// conv2d, fp32, per-sample weights, any geometry: one implicit-GEMM kernel template (conv2d_f32_vec_kernel) on
+// v_mfma_f32_32x32x2f32 (fp32 fma chain per output) or v_mfma_f64_16x16x4_f64 (fp64 accumulation), K = KH KW Cin walked in
+// 16-wide chunks staged through LDS with the next chunk prefetched into registers; im2col on the fly with zero padding.
+// The gather is a float4 per row (VEC) or four scalars with per-element index arithmetic (any Cin, either weight order).
 // =====================================================================================
 struct ConvF32Args {
   const float* x; int64_t x_ss;      // [S|1][B][H][W][Cin] (NHWC)
-  const float* w; int64_t w_ss;      // [S|1][Cout][Cin][KH][KW]
+  const float* w; int64_t w_ss;      // [S|1][Cout][Cin][KH][KW], or [Cout][KH][KW][Cin] with w_ohwi
   const float* bias;                 // [Cout] or null
   float* y; int64_t y_ss;            // [S][B][Ho][Wo][Cout]
   int B, H, W, Cin, Cout, KS, stride, pad, Ho, Wo, relu;
@@ -49,43 +47,9 @@ __device__ __forceinline__ float conv_f32_tail(const ConvF32Args& a, float v, in
   return v;
 }
 
-constexpr int CF_KC = 16, CF_LD = CF_KC + 1;
+constexpr int CF_KC = 16;
 
-// Gather of one K chunk into registers (4 pixel values + 4 weight values per thread; the 16 threads of a row read 16
-// consecutive k = 64 contiguous bytes of the NHWC input, and of the weights when they are stored [Cout][KH][KW][Cin]).
-struct ConvF32Slots { int prow[4], pb[4], poh[4], pow_[4]; };
-__device__ __forceinline__ void conv_f32_slots(const ConvF32Args& a, int tid, int p0, int npix, ConvF32Slots& t) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = tid + 256 * j, row = e >> 4;
-    const int p = p0 + row;
-    t.prow[j] = row;
-    if (p < npix) { t.pb[j] = p / (a.Ho * a.Wo); const int rem = p - t.pb[j] * a.Ho * a.Wo; t.poh[j] = rem / a.Wo; t.pow_[j] = rem - t.poh[j] * a.Wo; }
-    else { t.pb[j] = -1; t.poh[j] = 0; t.pow_[j] = 0; }
-  }
-}
-__device__ __forceinline__ void conv_f32_gather(const ConvF32Args& a, const ConvF32Slots& t, const float* xs, const float* ws, int k0, int K,
-                                                int n0, int tid, float xv[4], float wv[4]) {
-  const int kk = k0 + (tid & 15);                    // same k column for all 4 slots of this thread
-  int kh = 0, kw = 0, c = 0;
-  const bool kok = kk < K;
-  if (kok) { kh = kk / (a.KS * a.Cin); const int r2 = kk - kh * a.KS * a.Cin; kw = r2 / a.Cin; c = r2 - kw * a.Cin; }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    xv[j] = 0.f;
-    if (kok && t.pb[j] >= 0) {
-      const int ih = t.poh[j] * a.stride - a.pad + kh, iw = t.pow_[j] * a.stride - a.pad + kw;
-      if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-        xv[j] = xs[(((int64_t)t.pb[j] * a.H + ih) * a.W + iw) * a.Cin + c];
-    }
-    wv[j] = 0.f;
-    const int n = n0 + t.prow[j];
-    if (kok && n < a.Cout)
-      wv[j] = a.w_ohwi ? ws[(int64_t)n * K + kk] : ws[(((int64_t)n * a.Cin + c) * a.KS + kh) * a.KS + kw];
-  }
-}
-
-// Fast path of the MFMA kernels: Cin % 4 == 0 and K-contiguous weights.  Every thread moves one float4 per operand row and
+// VEC (Cin % 4 == 0 and K-contiguous weights): every thread moves one float4 per operand row and
 // 16-wide K chunk (thread -> row tid / 4, k = 4 (tid % 4) .. +3 of the chunk; a float4 never straddles a tap) instead of 8
 // scalars with per-element index arithmetic (which made the generic form VALU-bound: 21 vs 80-100 TFLOP/s).
 // Workgroup tile = PT pixels x NT channels (PT NT = 4096), 4 waves of 32 x 32: 64 x 64, or 128 x 32 where that wastes
@@ -98,7 +62,7 @@ __device__ __forceinline__ void conv_f32_gather(const ConvF32Args& a, const Conv
 // of the chunk (fp64: quarter q takes 4 q .. 4 q + 3), so every operand read is a conflict-free ds_read_b128.
 constexpr int CF_LD4 = 20;           // row pitch in floats: 16-byte aligned rows for the float4 stores
 typedef double v4d __attribute__((ext_vector_type(4)));
-template <int PT, int NT, bool ACC64>
+template <int PT, int NT, bool ACC64, bool VEC>
 __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a) {
   static_assert(PT * NT == 4096 && PT % 64 == 0 && NT % 32 == 0, "4 waves of 32 x 32");
   __shared__ __attribute__((aligned(16))) float As[NT * CF_LD4];     // weights [n][k]
@@ -128,6 +92,25 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
   int gkh, gkw, gc;
   { const int tap = kq / a.Cin; gc = kq - tap * a.Cin; gkh = tap / a.KS; gkw = tap - gkh * a.KS; }
   auto gather = [&](int k0, v4f (&xv)[XP], v4f& wv) {
+    if constexpr (!VEC) {
+      // any Cin, either weight order: the same four k of the chunk, element by element (index arithmetic per element)
+      int kk = k0 + kq;
+      int tap = kk / a.Cin, c = kk - tap * a.Cin;
+      int kh = tap / a.KS, kw = tap - kh * a.KS;
+#pragma unroll
+      for (int i = 0; i < 4; ++i, ++kk) {
+        const bool kok = kk < K;
+#pragma unroll
+        for (int j = 0; j < XP; ++j) {
+          const int ih = ih0[j] + kh, iw = iw0[j] + kw;
+          const bool ok = kok && pb[j] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+          xv[j][i] = ok ? xs[(((int64_t)pb[j] * a.H + ih) * a.W + iw) * a.Cin + c] : 0.f;
+        }
+        wv[i] = (kok && wrow_ok) ? (a.w_ohwi ? wrow[k0 + i] : ws[(((int64_t)(n0 + row) * a.Cin + c) * a.KS + kh) * a.KS + kw]) : 0.f;
+        if (++c == a.Cin) { c = 0; if (++kw == a.KS) { kw = 0; ++kh; } }
+      }
+      return;
+    }
     const bool kok = k0 + kq < K;
 #pragma unroll
     for (int j = 0; j < XP; ++j) {
@@ -213,114 +196,6 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
   }
 }
 
-__global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvF32Args a) {
-  __shared__ float As[64 * CF_LD];     // weights  [n][k]
-  __shared__ float Bs[64 * CF_LD];     // pixels   [p][k]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;           // pixel half, channel half
-  const int s = blockIdx.z;
-  const int p0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-  const int npix = a.B * a.Ho * a.Wo;
-  const int K = a.KS * a.KS * a.Cin;
-  const float* xs = a.x + (int64_t)s * a.x_ss;
-  const float* ws = a.w + (int64_t)s * a.w_ss;
-  ConvF32Slots t;
-  conv_f32_slots(a, tid, p0, npix, t);
-  v16f acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  float xv[4], wv[4];
-  conv_f32_gather(a, t, xs, ws, 0, K, n0, tid, xv, wv);
-  for (int k0 = 0; k0 < K; k0 += CF_KC) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      Bs[t.prow[j] * CF_LD + (tid & 15)] = xv[j];
-      As[t.prow[j] * CF_LD + (tid & 15)] = wv[j];
-    }
-    __syncthreads();
-    if (k0 + CF_KC < K) conv_f32_gather(a, t, xs, ws, k0 + CF_KC, K, n0, tid, xv, wv);     // next chunk in flight under the MFMAs
-#pragma unroll
-    for (int k2 = 0; k2 < CF_KC / 2; ++k2) {
-      const float av = As[(wn * 32 + (lane & 31)) * CF_LD + 2 * k2 + (lane >> 5)];
-      const float bv = Bs[(wm * 32 + (lane & 31)) * CF_LD + 2 * k2 + (lane >> 5)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  // D[i = channel][j = pixel]: lane owns pixel j = lane & 31, register r holds channel 8 (r / 4) + 4 (lane >> 5) + r % 4
-  const int p = p0 + wm * 32 + (lane & 31);
-  if (p >= npix) return;
-  float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)p * a.Cout;
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = n0 + wn * 32 + 8 * g + 4 * (lane >> 5) + i;
-      if (n < a.Cout) {
-        yp[n] = conv_f32_tail(a, acc[4 * g + i], n, s, (int64_t)p * a.Cout + n);
-      }
-    }
-}
-
-// Same tiling with fp64 accumulation on the vector ALU (each thread a 4 x 4 block of the 64 x 64 tile), selected by
-// flags bit 1.  The QAT path needs it: downstream of every conv sits a fake-quantiser, and a sum whose fp32
-// accumulation error (K up to 1728 terms) moves a value across a rounding boundary changes that activation by a whole
-// grid step.  With one rounding of the exact sum the result agrees with the reference's conv to ~1 ulp.
-__global__ __launch_bounds__(256) void conv2d_f32_acc64_kernel(const ConvF32Args a) {
-  __shared__ float As[64 * CF_LD];
-  __shared__ float Bs[64 * CF_LD];
-  const int tid = threadIdx.x;
-  const int tn = tid & 15, tp = tid >> 4;            // channels 4 tn .. +3, pixels 4 tp .. +3 of the tile
-  const int s = blockIdx.z;
-  const int p0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-  const int npix = a.B * a.Ho * a.Wo;
-  const int K = a.KS * a.KS * a.Cin;
-  const float* xs = a.x + (int64_t)s * a.x_ss;
-  const float* ws = a.w + (int64_t)s * a.w_ss;
-  ConvF32Slots t;
-  conv_f32_slots(a, tid, p0, npix, t);
-  double acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-  float xv[4], wv[4];
-  conv_f32_gather(a, t, xs, ws, 0, K, n0, tid, xv, wv);
-  for (int k0 = 0; k0 < K; k0 += CF_KC) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      Bs[t.prow[j] * CF_LD + (tid & 15)] = xv[j];
-      As[t.prow[j] * CF_LD + (tid & 15)] = wv[j];
-    }
-    __syncthreads();
-    if (k0 + CF_KC < K) conv_f32_gather(a, t, xs, ws, k0 + CF_KC, K, n0, tid, xv, wv);
-#pragma unroll 4
-    for (int k = 0; k < CF_KC; ++k) {
-      double av[4], bv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { av[i] = (double)As[(4 * tn + i) * CF_LD + k]; bv[i] = (double)Bs[(4 * tp + i) * CF_LD + k]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(bv[i], av[j], acc[i][j]);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = p0 + 4 * tp + i;
-    if (p >= npix) continue;
-    float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)p * a.Cout;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 4 * tn + j;
-      if (n < a.Cout) {
-        yp[n] = conv_f32_tail(a, (float)acc[i][j], n, s, (int64_t)p * a.Cout + n);
-      }
-    }
-  }
-}
-
 QBNN_EXPORT int qbnn_conv2d_f32_fused_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* div, const float* bias,
                                          const float* alpha, const float* beta, const float* res, int64_t res_ss, float* y, int64_t y_ss, int32_t B, int32_t H,
                                          int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu,
@@ -339,19 +214,19 @@ QBNN_EXPORT int qbnn_conv2d_f32_fused_mc(const float* x, int64_t x_ss, const flo
                    (reinterpret_cast<uintptr_t>(x) % 16) == 0 && (reinterpret_cast<uintptr_t>(w) % 16) == 0;
   const bool acc64 = (relu & 2) != 0;
   hipStream_t st = (hipStream_t)stream;
-  if (vec) {
-    // 128 pixels x 32 channels per workgroup where 32-wide channel tiles pad less than 64-wide ones (Cout = 24, 96, ...)
-    const bool narrow = (Cout + 31) / 32 * 32 < (Cout + 63) / 64 * 64;
-    if (narrow) {
-      dim3 g2((unsigned)((npix + 127) / 128), (unsigned)((Cout + 31) / 32), (unsigned)n_samples);
-      if (acc64) hipLaunchKernelGGL((conv2d_f32_vec_kernel<128, 32, true>), g2, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((conv2d_f32_vec_kernel<128, 32, false>), g2, dim3(256), 0, st, a);
-    } else {
-      if (acc64) hipLaunchKernelGGL((conv2d_f32_vec_kernel<64, 64, true>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((conv2d_f32_vec_kernel<64, 64, false>), grid, dim3(256), 0, st, a);
-    }
-  } else if (acc64) hipLaunchKernelGGL(conv2d_f32_acc64_kernel, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(conv2d_f32_kernel, grid, dim3(256), 0, st, a);
+  // 128 pixels x 32 channels per workgroup where 32-wide channel tiles pad less than 64-wide ones (Cout = 24, 96, ...)
+  const bool narrow = (Cout + 31) / 32 * 32 < (Cout + 63) / 64 * 64;
+  const dim3 g2((unsigned)((npix + 127) / 128), (unsigned)((Cout + 31) / 32), (unsigned)n_samples);
+#define QBNN_F32_LAUNCH(A64, V)                                                                                             \
+  do {                                                                                                                      \
+    if (narrow) hipLaunchKernelGGL((conv2d_f32_vec_kernel<128, 32, A64, V>), g2, dim3(256), 0, st, a);                       \
+    else hipLaunchKernelGGL((conv2d_f32_vec_kernel<64, 64, A64, V>), grid, dim3(256), 0, st, a);                             \
+  } while (0)
+  if (acc64 && vec) QBNN_F32_LAUNCH(true, true);
+  else if (acc64) QBNN_F32_LAUNCH(true, false);
+  else if (vec) QBNN_F32_LAUNCH(false, true);
+  else QBNN_F32_LAUNCH(false, false);
+#undef QBNN_F32_LAUNCH
   return qbnn_check_launch_msg("qbnn_conv2d_f32_mc");
 }
 
