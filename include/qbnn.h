@@ -267,7 +267,14 @@ int qbnn_conv2d_f32_mc(const float* x, int64_t x_sample_stride, const float* w, 
 int qbnn_conv2d_f32_fused_mc(const float* x, int64_t x_sample_stride, const float* w, int64_t w_sample_stride, const float* div,
                              const float* bias, const float* alpha, const float* beta, const float* res, int64_t res_sample_stride, float* y,
                              int64_t y_sample_stride, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                             int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream);
+                             int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, float* minmax_partials, void* stream);
+
+/* Observer fusion for the QAT path: with `minmax_partials` ([S][qbnn_conv2d_f32_blocks(...)][2] floats) non-NULL every workgroup
+ * of the conv writes the (min, max) of the outputs it produced, and qbnn_observe_partials_f32_mc runs the
+ * MovingAverageMinMaxObserver recurrence of qbnn_observe_f32_mc on them -- the conv output is not read a second time. */
+int32_t qbnn_conv2d_f32_blocks(int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad);
+int qbnn_observe_partials_f32_mc(const float* partials, int32_t n_blocks, int32_t n_samples, float* state, float avg_const,
+                                 int32_t qmin, int32_t qmax, float* scale, int32_t* zero_point, void* stream);
 
 /* Pointwise on [S][n] with the channel as fastest axis:  v = (mode 0) x * p0[c] + p1[c]  |  (mode 1) x / p0[c] + p1[c]
  * (p0 / p1 NULL skip that step), v += res (if given), ReLU (if asked).  nn.BatchNorm2d in eval (x * alpha + beta as ATen

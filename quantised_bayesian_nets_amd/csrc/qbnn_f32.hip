@@ -35,6 +35,7 @@ struct ConvF32Args {
   // fused tail (qbnn_conv2d_f32_fused_mc): v = conv; v = v / div[n]; v = v + bias[n]; v = v * alpha[n]; v = v + beta[n];
   // v = v + res; ReLU -- each step rounded to fp32 exactly as the separate pointwise kernels would
   const float* div; const float* alpha; const float* beta; const float* res; int64_t res_ss;
+  float* mm_partials;                // optional [S][workgroups per sample][2]: (min, max) of each workgroup's outputs (QAT observers)
 };
 
 __device__ __forceinline__ float conv_f32_tail(const ConvF32Args& a, float v, int n, int s, int64_t off) {
@@ -167,18 +168,23 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
     }
     __syncthreads();
   }
+  float vmin = INFINITY, vmax = -INFINITY;       // of the outputs this thread writes (observer fusion)
   if constexpr (!ACC64) {
     // D[i = channel][j = pixel]: lane owns pixel j = lane & 31, register r holds channel 8 (r / 4) + 4 (lane >> 5) + r % 4
     const int po = p0 + wm * 32 + (lane & 31);
-    if (po >= npix) return;
-    float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
+    if (po < npix) {
+      float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int no = n0 + wn * 32 + 8 * g + 4 * (lane >> 5) + i;
-        if (no < a.Cout) yp[no] = conv_f32_tail(a, acc[4 * g + i], no, s, (int64_t)po * a.Cout + no);
-      }
+        for (int i = 0; i < 4; ++i) {
+          const int no = n0 + wn * 32 + 8 * g + 4 * (lane >> 5) + i;
+          if (no < a.Cout) {
+            const float v = conv_f32_tail(a, acc[4 * g + i], no, s, (int64_t)po * a.Cout + no);
+            yp[no] = v; vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+          }
+        }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -190,20 +196,46 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int no = n0 + wn * 32 + j * 16 + l15;
-          if (no < a.Cout) yp[no] = conv_f32_tail(a, (float)acc64[i][j][r], no, s, (int64_t)po * a.Cout + no);
+          if (no < a.Cout) {
+            const float v = conv_f32_tail(a, (float)acc64[i][j][r], no, s, (int64_t)po * a.Cout + no);
+            yp[no] = v; vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+          }
         }
       }
   }
+  if (a.mm_partials) {
+    // (min, max) of this workgroup's outputs -> its slot of the observer's partials (no second pass over the tensor)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o)); }
+    float* red = As;                        // the K loop's last barrier has passed: the staging tiles are free
+    if (lane == 0) { red[2 * wave] = vmin; red[2 * wave + 1] = vmax; }
+    __syncthreads();
+    if (tid == 0) {
+      const int64_t slot = ((int64_t)s * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      a.mm_partials[2 * slot] = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
+      a.mm_partials[2 * slot + 1] = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+    }
+  }
+}
+
+static bool conv_f32_narrow(int Cout) { return (Cout + 31) / 32 * 32 < (Cout + 63) / 64 * 64; }
+
+// workgroups per sample of the conv launch = length of one sample's row of `minmax_partials`
+QBNN_EXPORT int32_t qbnn_conv2d_f32_blocks(int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad) {
+  const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return 0;
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  return conv_f32_narrow(Cout) ? (int32_t)(((npix + 127) / 128) * ((Cout + 31) / 32)) : (int32_t)(((npix + 63) / 64) * ((Cout + 63) / 64));
 }
 
 QBNN_EXPORT int qbnn_conv2d_f32_fused_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* div, const float* bias,
                                          const float* alpha, const float* beta, const float* res, int64_t res_ss, float* y, int64_t y_ss, int32_t B, int32_t H,
                                          int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu,
-                                         int32_t n_samples, void* stream) {
+                                         int32_t n_samples, float* minmax_partials, void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || n_samples <= 0)
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: bad argument");
   ConvF32Args a;
-  a.div = div; a.alpha = alpha; a.beta = beta; a.res = res; a.res_ss = res_ss;
+  a.div = div; a.alpha = alpha; a.beta = beta; a.res = res; a.res_ss = res_ss; a.mm_partials = minmax_partials;
   a.x = x; a.x_ss = x_ss; a.w = w; a.w_ss = w_ss; a.bias = bias; a.y = y; a.y_ss = y_ss;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = ksize; a.stride = stride; a.pad = pad; a.relu = relu & 1; a.w_ohwi = (relu >> 2) & 1;
   a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
@@ -215,7 +247,7 @@ QBNN_EXPORT int qbnn_conv2d_f32_fused_mc(const float* x, int64_t x_ss, const flo
   const bool acc64 = (relu & 2) != 0;
   hipStream_t st = (hipStream_t)stream;
   // 128 pixels x 32 channels per workgroup where 32-wide channel tiles pad less than 64-wide ones (Cout = 24, 96, ...)
-  const bool narrow = (Cout + 31) / 32 * 32 < (Cout + 63) / 64 * 64;
+  const bool narrow = conv_f32_narrow(Cout);
   const dim3 g2((unsigned)((npix + 127) / 128), (unsigned)((Cout + 31) / 32), (unsigned)n_samples);
 #define QBNN_F32_LAUNCH(A64, V)                                                                                             \
   do {                                                                                                                      \
@@ -397,6 +429,17 @@ __global__ __launch_bounds__(256) void observer_scan_kernel(const float* __restr
   if (threadIdx.x == 0) { state[0] = mn_state; state[1] = mx_state; state[2] = 1.f; }
 }
 
+// The observer recurrence alone, on per-workgroup (min, max) partials a producer already wrote (qbnn_conv2d_f32_fused_mc's
+// minmax_partials): [S][n_blocks][2].
+QBNN_EXPORT int qbnn_observe_partials_f32_mc(const float* partials, int32_t n_blocks, int32_t n_samples, float* state, float avg_const,
+                                             int32_t qmin, int32_t qmax, float* scale, int32_t* zero_point, void* stream) {
+  if (!partials || !state || !scale || !zero_point || n_blocks <= 0 || n_samples <= 0 || qmax <= qmin)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_observe_partials_f32_mc: bad argument");
+  hipLaunchKernelGGL(observer_scan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_blocks, n_samples, state, avg_const, qmin,
+                     qmax, scale, zero_point);
+  return qbnn_check_launch_msg("qbnn_observe_partials_f32_mc");
+}
+
 QBNN_EXPORT int qbnn_observe_f32_mc(const float* x, int64_t x_ss, int64_t n, int32_t n_samples, float* state, float avg_const,
                                     int32_t qmin, int32_t qmax, float* workspace, float* scale, int32_t* zero_point, void* stream) {
   if (!x || !state || !workspace || !scale || !zero_point || n <= 0 || n_samples <= 0 || qmax <= qmin)
@@ -524,5 +567,5 @@ QBNN_EXPORT int qbnn_conv2d_f32_mc(const float* x, int64_t x_ss, const float* w,
                                    int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                                    int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream) {
   return qbnn_conv2d_f32_fused_mc(x, x_ss, w, w_ss, nullptr, bias, nullptr, nullptr, nullptr, 0, y, y_ss, B, H, W, Cin, Cout, ksize, stride, pad, relu,
-                                  n_samples, stream);
+                                  n_samples, nullptr, stream);
 }

@@ -3580,7 +3580,7 @@ QBNN_EXPORT int qbnn_linear_f32_mc(const float* x, int64_t x_ss, const float* w,
   // (float4 path when in_features % 4 == 0); only the exp head (N = 1) stays on the one-thread-per-output kernel
   if (act != 2)
     return qbnn_conv2d_f32_fused_mc(x, x_ss, w, w_ss, nullptr, bias, nullptr, nullptr, nullptr, 0, y, y_ss, B, 1, 1, K, N, 1, 1, 0,
-                                    (act == 1 ? 1 : 0) | 4, n_samples, stream);
+                                    (act == 1 ? 1 : 0) | 4, n_samples, nullptr, stream);
   const int64_t total = (int64_t)B * N;
   hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)((total + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
                      x, x_ss, w, w_ss, bias, y, y_ss, B, K, N, act);

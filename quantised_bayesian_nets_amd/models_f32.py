@@ -121,7 +121,7 @@ def _f32(t, dev):
     return None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
-def conv2d_f32(x, w, bias, cin, cout, k, stride, pad, relu, acc64=False, ohwi=False, bn=None, res=None, div=None):
+def conv2d_f32(x, w, bias, cin, cout, k, stride, pad, relu, acc64=False, ohwi=False, bn=None, res=None, div=None, minmax=False):
     """x [S|1,B,H,W,Cin], w [S|1, Cout*Cin*k*k] (reference order, or [Cout,k,k,Cin] when `ohwi`) -> [S,B,Ho,Wo,Cout]
     through qbnn_conv2d_f32_mc."""
     S = max(x.shape[0], w.shape[0])
@@ -129,12 +129,19 @@ def conv2d_f32(x, w, bias, cin, cout, k, stride, pad, relu, acc64=False, ohwi=Fa
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     y = torch.empty((S, B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
     alpha, beta = bn if bn is not None else (None, None)      # BatchNorm eval coefficients: fused tail of the conv kernel
+    partials, nblk = None, 0
+    if minmax:       # QAT: every workgroup leaves the (min, max) of its outputs for the observer that follows the conv
+        nblk = int(_lib.lib().qbnn_conv2d_f32_blocks(B, H, W, cout, k, stride, pad))
+        partials = torch.empty(S * nblk * 2, dtype=torch.float32, device=x.device)
     with timed("conv2d_f32"):
         _lib.check(_lib.lib().qbnn_conv2d_f32_fused_mc(_lib.ptr(x), 0 if x.shape[0] == 1 else x[0].numel(), _lib.ptr(w),
                                                        0 if w.shape[0] == 1 else w[0].numel(), _lib.ptr(div), _lib.ptr(bias), _lib.ptr(alpha), _lib.ptr(beta),
                                                        _lib.ptr(res), 0 if res is None or res.shape[0] == 1 else res[0].numel(), _lib.ptr(y),
                                                        y[0].numel(), B, H, W, cin, cout, k, stride, pad,
-                                                       int(relu) | (2 if acc64 else 0) | (4 if ohwi else 0), S, _lib.current_stream()))
+                                                       int(relu) | (2 if acc64 else 0) | (4 if ohwi else 0), S, _lib.ptr(partials),
+                                                       _lib.current_stream()))
+    if minmax:
+        return y, (partials, nblk)
     return y
 
 

@@ -45,9 +45,10 @@ class FakeQuantize(nn.Module):
         s = self.state.detach().cpu().numpy()
         return (float(s[0]), float(s[1])) if s[2] else (float("inf"), float("-inf"))
 
-    def forward(self, x):
+    def forward(self, x, partials=None):
         """x [S or 1, ...] fp32 on the GPU -> [S, ...]: sample s is quantised with the qparams the observer holds after
-        having seen samples 0..s (a shared input is observed S times, as S reference forwards would)."""
+        having seen samples 0..s (a shared input is observed S times, as S reference forwards would).
+        partials = (buffer, n_blocks): per-workgroup (min, max) the producing conv already wrote -- the min/max pass is skipped."""
         if x.device.type != "cuda":
             raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
         S = _MC.samples
@@ -56,13 +57,17 @@ class FakeQuantize(nn.Module):
         xs = 0 if x.shape[0] == 1 else n
         if self.state.device != x.device:
             self.state = self.state.to(x.device)
-        ws = torch.empty(S * OBS_BLOCKS * 2, dtype=torch.float32, device=x.device)
         scale = torch.empty(S, dtype=torch.float32, device=x.device)
         zp = torch.empty(S, dtype=torch.int32, device=x.device)
         L = _lib.lib()
         with timed("observe_f32"):
-            _lib.check(L.qbnn_observe_f32_mc(_lib.ptr(x), xs, n, S, _lib.ptr(self.state), AVG_CONST, self.qmin, self.qmax, _lib.ptr(ws),
-                                             _lib.ptr(scale), _lib.ptr(zp), _lib.current_stream()))
+            if partials is not None and x.shape[0] == S:
+                _lib.check(L.qbnn_observe_partials_f32_mc(_lib.ptr(partials[0]), partials[1], S, _lib.ptr(self.state), AVG_CONST, self.qmin,
+                                                          self.qmax, _lib.ptr(scale), _lib.ptr(zp), _lib.current_stream()))
+            else:
+                ws = torch.empty(S * OBS_BLOCKS * 2, dtype=torch.float32, device=x.device)
+                _lib.check(L.qbnn_observe_f32_mc(_lib.ptr(x), xs, n, S, _lib.ptr(self.state), AVG_CONST, self.qmin, self.qmax, _lib.ptr(ws),
+                                                 _lib.ptr(scale), _lib.ptr(zp), _lib.current_stream()))
         y = torch.empty((S,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
         with timed("fake_quant_f32"):
             _lib.check(L.qbnn_fake_quant_f32_mc(_lib.ptr(x), xs, _lib.ptr(y), n, n, _lib.ptr(scale), _lib.ptr(zp), 1, self.qmin, self.qmax, S,
@@ -169,14 +174,15 @@ class Conv2d(_QATBBB):
         W = self.sampled_weights(dev, eps)
         if self.bn is None:
             b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
-            z = conv2d_f32(x, W, b, self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True, ohwi=True)
+            z, mm = conv2d_f32(x, W, b, self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True,
+                               ohwi=True, minmax=True)
         else:
             # conv, Z / scale_factor (+ bias) (:159-161), bn, ReLU: one kernel, each step rounded as the reference rounds it
             if self._cb is None or self._cb[0].device != dev:
                 self._cb = (self.scale_factor().to(dev).contiguous(), None if self.bias is None else self.bias.detach().to(dev).contiguous())
-            z = conv2d_f32(x, W, self._cb[1], self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True,
-                           ohwi=True, div=self._cb[0], bn=self.bn.coefficients(dev))
-        return self.activation_post_process(z)
+            z, mm = conv2d_f32(x, W, self._cb[1], self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True,
+                               ohwi=True, div=self._cb[0], bn=self.bn.coefficients(dev), minmax=True)
+        return self.activation_post_process(z, partials=mm)
 
     def load(self, st, name):
         self._load_common(st, name)
@@ -207,6 +213,10 @@ class Linear(_QATBBB):
         b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
         a = (1 if self.relu else 0) if act is None else act
         x = x.contiguous()
+        if a in (0, 1):      # the 1x1 case of the conv kernel: its workgroups leave the output's (min, max) for the observer
+            y5, mm = conv2d_f32(x.reshape(x.shape[0], B, 1, 1, self.in_features), W, b, self.in_features, self.out_features, 1, 1, 0, bool(a),
+                                ohwi=True, minmax=True)
+            return self.activation_post_process(y5.reshape(S, B, self.out_features), partials=mm)
         with timed("linear_f32"):
             _lib.check(_lib.lib().qbnn_linear_f32_mc(_lib.ptr(x), 0 if x.shape[0] == 1 else x[0].numel(), _lib.ptr(W), W.shape[1], _lib.ptr(b),
                                                      _lib.ptr(y), y[0].numel(), B, self.in_features, self.out_features, a, S, _lib.current_stream()))
