@@ -247,12 +247,22 @@ class ConvNetwork_LeNet(nn.Module):
         if record is not None:
             record["quant.out"] = h.data
         di = 0
+        skip = -1
         for i, layer in enumerate(self.layers):
-            if isinstance(layer, nn.Identity):
+            if isinstance(layer, nn.Identity) or i == skip:
                 continue
             if isinstance(layer, BernoulliDropout):
-                h = layer(h, None if masks is None else masks[di])
+                m = None if masks is None else masks[di]
                 di += 1
+                nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None
+                if record is None and isinstance(nxt, MaxPool2dQ):
+                    # dropout -> max-pool == max-pool -> dropout, bit for bit: the mask is constant over a pooling window (one
+                    # draw per image and channel) and the quantised multiply is monotone in x for a factor >= 0, so it commutes
+                    # with max.  Pooling first quarters the dropout's traffic, and pools a sample-shared tensor once.
+                    h = layer(nxt(h), m)
+                    skip = i + 1
+                    continue
+                h = layer(h, m)
             else:
                 h = layer(h)
             if record is not None:

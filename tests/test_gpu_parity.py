@@ -283,6 +283,9 @@ def test_lenet_mc_dropout_matches_reference(golden_lenet_mc):
     np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=RTOL, atol=1e-8)
     mean = q.mc_predict(m, x, S, seed)
     np.testing.assert_allclose(mean.cpu().numpy(), g["mean_probs"], rtol=RTOL, atol=1e-8)
+    # without `record` the model pools before it drops (the two commute exactly): same bits as the layer-by-layer order above
+    with q.mc_context(S, seed, 0):
+        assert torch.equal(m.forward_mc(x), probs)
     # injected masks == Philox masks; sample_begin offsets the stream; bigger batch against the oracle
     net = orc.Int8LeNetMCOracle(g["state"], 7)
     keep = np.float32(1.0) - np.float32(0.2)
