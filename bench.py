@@ -65,7 +65,9 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # QBNN_BENCH_FORCE_DIST=1 (under torch.distributed.run with one rank): take the RCCL init / barrier / all-reduce path on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("QBNN_BENCH_FORCE_DIST", "0") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import quantised_bayesian_nets_amd as q
@@ -84,7 +86,7 @@ def main():
         return q.mc_predict(model, x, S_global, seed, return_var=True)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -107,7 +109,7 @@ def main():
     dt = time.perf_counter() - t0
     qlayers.PROFILE = None
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -186,7 +188,7 @@ def main():
                           "image_samples_per_s": round(value * a.batch, 1), "parallelism": f"mc-sample-shard x{world}"},
                "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "kernels": kernels}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -8,6 +8,8 @@ Multi-GPU: MC samples are independent given (parameters, input, seed).  Rank r o
 global sample indices [r*S/G, (r+1)*S/G); the Philox subsequence is the GLOBAL sample index, so per-sample results do
 not depend on G.  One sum all-reduce of the [2, B, C] fp32 partial moments (20 KB at B=256, C=10) over RCCL/xGMI.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -44,7 +46,7 @@ def finalize_moments(moments, samples):
 
 
 def all_reduce_moments(moments, group=None):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("QBNN_BENCH_FORCE_DIST", "0") == "1"):
         dist.all_reduce(moments, op=dist.ReduceOp.SUM, group=group)
     return moments
 
