@@ -3245,9 +3245,9 @@ __global__ __launch_bounds__(256) void conv_generic_i8_kernel(const GenConvArgs 
 //   sum_k (x_k - z_x)(w_k - z_w) = acc - z_w R + a Wsum[co] - K a z_w,   a = 128 - z_x, R = sum_k x'_k, Wsum = sum_k w_k
 // -- all int32-exact; R and Wsum are v_dot4 sums over the fragments the MFMA consumes.  Bit-identical to
 // conv_generic_i8_kernel (tests compare the two), 50-200x faster on the LeNet / MLP layers.
-// VEC4: Cin % 4 == 0 and 4-byte aligned operands -- a dword never straddles a tap, so the gather moves 4 channels per load
-// with one index decomposition per dword instead of per byte (the gather's vector-ALU work is what bounds this kernel).
-template <bool VEC4>
+// GB = 4 / 2: Cin % GB == 0 and GB-byte aligned operands -- a unit never straddles a tap, so the gather moves GB channels per
+// load with one index step per unit instead of per byte (the gather's vector-ALU work is what bounds this kernel).
+template <int GB>
 __global__ __launch_bounds__(256) void conv_generic_mfma_i8_kernel(const GenConvArgs a) {
   constexpr int LD = 48;
   __shared__ __attribute__((aligned(16))) uint8_t As[64 * LD];      // weights [n][k]
@@ -3268,41 +3268,38 @@ __global__ __launch_bounds__(256) void conv_generic_mfma_i8_kernel(const GenConv
   const int64_t xbase = (int64_t)(pb < 0 ? 0 : pb) * a.H * a.W * a.Cin;
   const int8_t* wrow = ws + (int64_t)(n < a.Cout ? n : 0) * K;
   const uint32_t xpad = (uint32_t)(a.z_x ^ 0x80) & 0xffu;
+  // the thread's 8 bytes of the chunk in units of GB = 1, 2 or 4 bytes (Cin % GB == 0: a unit never straddles a tap)
   auto gather = [&](int k0, uint32_t (&xv)[2], uint32_t (&wv)[2]) {
     int kk = k0 + kb;
     int tap = kk / a.Cin, c = kk - tap * a.Cin;
     int kh = tap / a.KW, kw = tap - kh * a.KW;
     xv[0] = xv[1] = wv[0] = wv[1] = 0u;
-    if constexpr (VEC4) {
+    constexpr uint32_t UMASK = GB == 4 ? 0xffffffffu : (GB == 2 ? 0xffffu : 0xffu);
 #pragma unroll
-      for (int j = 0; j < 2; ++j, kk += 4) {
-        if (kk < K) {
-          if (pb >= 0) {
-            const int ih = ih0 + kh, iw = iw0 + kw;
-            const bool in = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            xv[j] = in ? (*reinterpret_cast<const uint32_t*>(xs + xbase + ((int64_t)ih * a.W + iw) * a.Cin + c) ^ 0x80808080u) : xpad * 0x01010101u;
-          }
-          if (n < a.Cout) wv[j] = *reinterpret_cast<const uint32_t*>(wrow + kk);
-        }
-        c += 4;
-        if (c == a.Cin) { c = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
-      }
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j, ++kk) {
+    for (int j = 0; j < 8 / GB; ++j, kk += GB) {
       uint32_t xb = 0u, wb = 0u;
       if (kk < K) {
         if (pb >= 0) {
           const int ih = ih0 + kh, iw = iw0 + kw;
           const bool in = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-          xb = in ? ((uint32_t)xs[xbase + ((int64_t)ih * a.W + iw) * a.Cin + c] ^ 0x80u) : xpad;
+          const uint8_t* src = xs + xbase + ((int64_t)ih * a.W + iw) * a.Cin + c;
+          uint32_t v;
+          if constexpr (GB == 4) v = *reinterpret_cast<const uint32_t*>(src);
+          else if constexpr (GB == 2) v = *reinterpret_cast<const uint16_t*>(src);
+          else v = *src;
+          xb = in ? (v ^ (0x80808080u & UMASK)) : (xpad * 0x01010101u) & UMASK;
         }
-        if (n < a.Cout) wb = (uint32_t)(uint8_t)wrow[kk];
+        if (n < a.Cout) {
+          if constexpr (GB == 4) wb = *reinterpret_cast<const uint32_t*>(wrow + kk);
+          else if constexpr (GB == 2) wb = *reinterpret_cast<const uint16_t*>(wrow + kk);
+          else wb = (uint32_t)(uint8_t)wrow[kk];
+        }
       }
-      xv[j >> 2] |= xb << (8 * (j & 3));
-      wv[j >> 2] |= wb << (8 * (j & 3));
-      if (++c == a.Cin) { c = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
+      constexpr int PER = 4 / GB;                       // units per dword
+      xv[j / PER] |= xb << (8 * GB * (j % PER));
+      wv[j / PER] |= wb << (8 * GB * (j % PER));
+      c += GB;
+      if (c == a.Cin) { c = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
     }
   };
   v16i acc;
@@ -3384,10 +3381,13 @@ static int conv2d_i8_generic(const uint8_t* x, int64_t x_ss, const int8_t* w_ohw
     hipLaunchKernelGGL(conv_generic_i8_kernel, dim3((unsigned)((total + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream, a);
   else {
     const dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((a.Cout + 63) / 64), n_samples);
-    const bool vec4 = (a.Cin % 4) == 0 && (x_ss % 4) == 0 && (w_ss % 4) == 0 && (reinterpret_cast<uintptr_t>(x) % 4) == 0 &&
-                      (reinterpret_cast<uintptr_t>(w_ohwi) % 4) == 0;
-    if (vec4) hipLaunchKernelGGL(conv_generic_mfma_i8_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv_generic_mfma_i8_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    auto unit_ok = [&](int gb) {
+      return (a.Cin % gb) == 0 && (x_ss % gb) == 0 && (w_ss % gb) == 0 && (reinterpret_cast<uintptr_t>(x) % gb) == 0 &&
+             (reinterpret_cast<uintptr_t>(w_ohwi) % gb) == 0;
+    };
+    if (unit_ok(4)) hipLaunchKernelGGL(conv_generic_mfma_i8_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (unit_ok(2)) hipLaunchKernelGGL(conv_generic_mfma_i8_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_generic_mfma_i8_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
   }
   return check_launch("qbnn_conv2d_i8_generic_mc");
 }
