@@ -399,11 +399,11 @@ class Network(nn.Module):
                    all(self._graphs.get((j, tuple(x.shape), x.dtype, x.device.index)) for j in idx))
         if not graphed:
             return torch.cat([self._member_forward(j, x, record=record if i == 0 else None) for i, j in enumerate(idx)], 0)
-        # every member has a captured chain: replay them round-robin on a few side streams -- one member's late layers
+        # every member has a captured chain: replay them round-robin on side streams (8; QBNN_ENSEMBLE_STREAMS) -- one member's late layers
         # fill 16-64 of the 256 CUs, so independent members overlap
         main = torch.cuda.current_stream()
         if not self._streams:
-            self._streams = [torch.cuda.Stream() for _ in range(4)]
+            self._streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("QBNN_ENSEMBLE_STREAMS", "8")))]
         outs = [None] * len(idx)
         for st in self._streams:
             st.wait_stream(main)
