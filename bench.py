@@ -7,7 +7,9 @@ evaluates `--samples` samples (weak scaling: global S = N * samples, Philox subs
 [2,B,C] partial moments are summed with one RCCL all-reduce per step.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--samples S] [--batch B]
-  (N > 1: launched by torch.distributed.run, one rank per GPU)
+  N > 1: either launched by torch.distributed.run (one rank per GPU: RANK / LOCAL_RANK / WORLD_SIZE in the environment), or
+  started plainly -- then this process touches no GPU, spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+  as a child and relays rank 0's JSON line and the child's exit code.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the one with the largest share of GPU time in
 the timed region), measured with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (a port of the
@@ -46,6 +48,59 @@ def conv_ops(S, B, H, Cin, Cout, ks, stride):
     return 2 * S * B * Ho * Ho * Cout * Cin * ks * ks
 
 
+def cpu_baseline(a, g, x_host, seed):
+    """The reference's CPU path timed on this host, on a bounded sample of the same workload (same batch, a few MC samples).
+    Primary leg, kind "torch-fbgemm": the op sequence of the reference's int8 layers through PyTorch's own quantised CPU
+    operators (ATen + FBGEMM) -- oracle/fbgemm_baseline.py, which reproduces the golden vectors recorded from the reference.
+    Second leg, kind "port": the plain-C restatement oracle/qbnn_oracle.c (OpenMP), the parity checker."""
+    from oracle import oracle as orc
+    from oracle.fbgemm_baseline import FbgemmResNetBBB
+    xn = x_host.numpy()
+    fb = FbgemmResNetBBB(g["state"], 7, a.w_bits)
+    fb.forward(xn)                                         # warm-up (thread pool, allocator)
+    n_fb = a.cpu_samples or 5
+    ts = []
+    for _ in range(n_fb):
+        t = time.perf_counter()
+        fb.forward(xn)
+        ts.append(time.perf_counter() - t)
+    med = sorted(ts)[len(ts) // 2]
+    net = orc.Int8ResNetOracle(g["state"], 7, a.w_bits)
+    t = time.perf_counter()
+    p_or = net.forward(xn, seed, 0)
+    one = time.perf_counter() - t
+    n_cpu = a.cpu_samples or max(1, min(8, int(10.0 / max(one, 1e-3))))
+    t = time.perf_counter()
+    for s in range(1, 1 + n_cpu):
+        net.forward(xn, seed, s)
+    el = time.perf_counter() - t
+    return {"value": round(1.0 / med, 4), "unit": "MC samples/s", "cores": torch.get_num_threads(), "kind": "torch-fbgemm",
+            "sample": f"median of {n_fb} single MC samples of the same batch ({a.batch} images) through torch's quantised CPU ops "
+                      f"(fbgemm engine; per layer normal_ -> quantize_per_tensor -> quantized.mul/add -> clamp -> conv2d_prepack -> "
+                      f"quantized.conv2d(_relu) -> clamp), after 1 warm-up sample",
+            "seconds_per_sample_min_med_max": [round(min(ts), 4), round(med, 4), round(max(ts), 4)],
+            "host_cpus": os.cpu_count(),
+            "port": {"value": round(n_cpu / el, 4), "unit": "MC samples/s", "cores": orc.lib().qbo_num_threads(), "kind": "port",
+                     "sample": f"{n_cpu} MC samples of the same batch through oracle/qbnn_oracle.c (OpenMP), after 1 warm-up sample"},
+            "_p_oracle_sample0": p_or}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N fresh ranks under torch.distributed.run as a CHILD process (this
+    process has made no HIP call and makes none: never exec from, or fork, a process that initialised the GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,13 +112,26 @@ def main():
     ap.add_argument("--prime", type=int, default=12, help="setup steps before the W warm-up steps (clock ramp, allocator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=0, help="oracle samples to time (0 = auto, about 10-30 s)")
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="launcher test (no GPU, gloo): ranks rendezvous, all-reduce their rank, rank 0 prints one JSON line")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if a.plumbing_check:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"plumbing_check": True, "ranks": dist.get_world_size(), "rank_sum": float(t.item())}))
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     # QBNN_BENCH_FORCE_DIST=1 (under torch.distributed.run with one rank): take the RCCL init / barrier / all-reduce path on a 1-GPU box
     use_dist = world > 1 or os.environ.get("QBNN_BENCH_FORCE_DIST", "0") == "1"
@@ -159,24 +227,25 @@ def main():
 
     cpu = None
     if rank == 0 and not a.no_cpu_baseline:
-        from oracle import oracle as orc
-        net = orc.Int8ResNetOracle(g["state"], 7, a.w_bits)
-        xn = x_host.numpy()
-        t = time.perf_counter()
-        p_or = net.forward(xn, seed, 0)
-        one = time.perf_counter() - t
-        n_cpu = a.cpu_samples or max(1, min(8, int(15.0 / max(one, 1e-3))))
-        t = time.perf_counter()
-        for s in range(1, 1 + n_cpu):
-            net.forward(xn, seed, s)
-        el = time.perf_counter() - t
-        cpu = {"value": round(n_cpu / el, 4), "unit": "MC samples/s", "cores": orc.lib().qbo_num_threads(), "kind": "port",
-               "sample": f"{n_cpu} MC samples of the same batch ({a.batch} images) through oracle/qbnn_oracle.c (OpenMP), after 1 warm-up sample",
-               "host_cpus": os.cpu_count()}
+        cpu = cpu_baseline(a, g, x_host, seed)
         # the oracle's sample 0 doubles as an in-run parity check of the GPU result
         with q.mc_context(1, seed, 0):
             p_gpu = model.forward_mc(x)[0].cpu().numpy()
-        cpu["gpu_matches_oracle_sample0"] = bool(np.allclose(p_gpu, p_or, rtol=1e-5, atol=1e-8))
+        cpu["gpu_matches_oracle_sample0"] = bool(np.allclose(p_gpu, cpu.pop("_p_oracle_sample0"), rtol=1e-5, atol=1e-8))
+
+    rccl = None
+    if use_dist:
+        # the path's one collective in isolation: sum all-reduce of the [2, B, C] fp32 moments (20 KB), RCCL over xGMI
+        mom = torch.zeros((2, a.batch, 10), dtype=torch.float32, device="cuda")
+        for _ in range(5):
+            dist.all_reduce(mom)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(mom)
+        torch.cuda.synchronize()
+        rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_bytes": mom.numel() * 4,
+                "allreduce_us": round((time.perf_counter() - t) / 50 * 1e6, 1), "collectives_per_step": 1}
 
     if rank == 0:
         out = {"metric": "MC forward samples/sec, ResNet-18 BBB int8 batch=256", "value": round(value, 2), "unit": "MC samples/s",
@@ -186,7 +255,8 @@ def main():
                                       "%d MC samples per GPU per step, batch=%d" % (a.w_bits, S_local, a.batch),
                           "samples_per_gpu": S_local, "global_samples": S_global, "batch": a.batch,
                           "image_samples_per_s": round(value * a.batch, 1), "parallelism": f"mc-sample-shard x{world}"},
-               "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "kernels": kernels}
+               "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "rccl": rccl, "rccl_ranks": world if use_dist else 0,
+               "kernels": kernels}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

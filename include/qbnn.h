@@ -143,7 +143,10 @@ typedef struct qbnn_down_desc {
   qbnn_block_desc blk;
   const int8_t* w_s; int64_t w_s_sample_stride; const float* bias_s;   /* shortcut.0 sampled weights, bias */
   float s_ws; int32_t z_ws;                                            /* shortcut.0 add_weight qparams    */
-  float s_s; int32_t z_s;                                              /* layers.0 (ConvReLU2d 3 -> 24 on the centred 27-tap patches of qbnn_im2col3x3_c3, shared by all samples) fused in front
+  float s_s; int32_t z_s;                                              /* shortcut.0 output qparams        */
+} qbnn_down_desc;
+
+/* layers.0 (ConvReLU2d 3 -> 24 on the centred 27-tap patches of qbnn_im2col3x3_c3, shared by all samples) fused in front
  * of the 32x32x24 identity chain of qbnn_block_chain_i8_mc: the first conv's output (the network's largest activation)
  * never reaches HBM.  Same arithmetic as qbnn_conv2d_i8_mc(x_is_centered_im2col) followed by the chain.
  * Replaces models_bbb.py:226-232 (layers.0 ... layers.3) of the converted model. */
@@ -151,9 +154,6 @@ int qbnn_stem_chain_i8_mc(const int8_t* im2col, int32_t B, const int8_t* w0_pack
                           float s_x, float s_w0, int32_t z_w0, float s_y0, int32_t z_y0, int32_t a_hi,
                           const qbnn_block_desc* host_blocks, int32_t n_blocks, uint8_t* y, int64_t y_sample_stride,
                           int32_t n_samples, void* stream);
-
-/* shortcut.0 output qparams        */
-} qbnn_down_desc;
 
 int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x, int32_t z_x, int32_t B, int32_t H,
                           int32_t Cin, int32_t a_hi, const qbnn_down_desc* host_desc, uint8_t* y, int64_t y_sample_stride,
@@ -183,9 +183,15 @@ typedef struct qbnn_head_desc {
 int qbnn_head_i8_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w_rowmajor, int64_t w_sample_stride,
                     const float* bias, float* probs, int32_t n_samples, const qbnn_head_desc* host_desc, void* stream);
 
-/* MC reduction (experiments/utils.py:342-355): sum over the S per-sample outputs of p and p*p,
- * in sample order (deterministic).  moments[0][n] (+)= sum_s p, moments[1][n] (+)= sum_s p^2. */
-int qbnn_reduce_moments(const float* probs, int32_t n_samples, int64_t n, int32_t accumulate, float* moments, void* stream);
+/* MC reduction (experiments/utils.py:342-355): sum over the S per-sample outputs of p and p*p, in sample order
+ * (deterministic), kept in fp64 (the variance below cancels in fp32):  moments[0][n] (+)= sum_s p, moments[1][n] (+)= sum_s p^2.
+ * finalize_total > 0 (single rank, last chunk): the same launch also writes mean = sum / total and, if var_out != NULL,
+ * the unbiased variance (sum2 - sum^2 / total) / (total - 1) of experiments/utils.py:352 as fp32. */
+int qbnn_reduce_moments(const float* probs, int32_t n_samples, int64_t n, int32_t accumulate, double* moments,
+                        int32_t finalize_total, float* mean_out, float* var_out, void* stream);
+
+/* After the cross-GPU sum of the fp64 moments: mean / unbiased variance as above. */
+int qbnn_finalize_moments(const double* moments, int64_t n, int32_t total_samples, float* mean_out, float* var_out, void* stream);
 
 /* ---- MC-Dropout path (BASELINE config 2: LeNet; reference src/models/stochastic/mcdropout/) ----------------------- */
 

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <math.h>
 #include <string.h>
+#include <atomic>
 #include <type_traits>
 
 #include "../../include/qbnn.h"
@@ -30,6 +31,23 @@ static int check_launch(const char* what) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return QBNN_E_LAUNCH;
   }
+  return QBNN_OK;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: `done` keeps one bit per device ordinal
+// (set after a successful call), so a process that runs models on several GPUs, or from several threads, sets it on each.
+static int ensure_dyn_lds(const void* fn, std::atomic<uint64_t>& done, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipGetDevice: %s", hipGetErrorString(e)); return QBNN_E_LAUNCH; }
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return QBNN_OK;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d): %s", bytes, hipGetErrorString(e));
+    return QBNN_E_LAUNCH;
+  }
+  done.fetch_or(bit, std::memory_order_release);
   return QBNN_OK;
 }
 
@@ -1188,12 +1206,12 @@ static int launch_conv(const ConvArgs& a, int n_samples, bool has_res, hipStream
   static_assert(LDS <= 160 * 1024, "LDS budget");
   dim3 grid(ceil_div(a.B, C::G), n_samples);
   if (has_res) {
-    static bool attr_r = false;
-    if (!attr_r) { hipFuncSetAttribute((const void*)conv_i8_kernel<C, true, PRESUB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_r = true; }
+    static std::atomic<uint64_t> attr_r{0};
+    if (int rc_attr = ensure_dyn_lds((const void*)conv_i8_kernel<C, true, PRESUB>, attr_r, LDS)) return rc_attr;
     hipLaunchKernelGGL((conv_i8_kernel<C, true, PRESUB>), grid, dim3(256), LDS, st, a);
   } else {
-    static bool attr_n = false;
-    if (!attr_n) { hipFuncSetAttribute((const void*)conv_i8_kernel<C, false, PRESUB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_n = true; }
+    static std::atomic<uint64_t> attr_n{0};
+    if (int rc_attr = ensure_dyn_lds((const void*)conv_i8_kernel<C, false, PRESUB>, attr_n, LDS)) return rc_attr;
     hipLaunchKernelGGL((conv_i8_kernel<C, false, PRESUB>), grid, dim3(256), LDS, st, a);
   }
   return check_launch("qbnn_conv2d_i8_mc");
@@ -1412,8 +1430,8 @@ static int launch_block_chain(const ChainArgs<NBLK>& a, hipStream_t st) {
   ChainArgs<NBLK> a2 = a;
   if (!want_lut) for (int k = 0; k < NBLK; ++k) a2.blk[k].add.lut = nullptr;
   static_assert(LDS_BASE <= 160 * 1024, "LDS budget");
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_chain_i8_kernel<C, NBLK, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_FITS ? LDS_BASE + NBLK * 16384 : LDS_BASE); attr = true; }
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_i8_kernel<C, NBLK, NTHR>, attr, LUT_FITS ? LDS_BASE + NBLK * 16384 : LDS_BASE)) return rc_attr;
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
   const int per_cu = NTHR == 256 ? ((160 * 1024) / LDS >= 3 ? 3 : ((160 * 1024) / LDS >= 2 ? 2 : 1)) : 1;
@@ -1611,8 +1629,8 @@ static int launch_block_down(const DownArgs& a, hipStream_t st) {
   constexpr int SLAB = SA > SB ? (SA > SS ? SA : SS) : (SB > SS ? SB : SS);
   constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + CB::OUT_BYTES + 2 * SLAB + 3 * CB::COUT * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_down_i8_kernel<CA, CS, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_down_i8_kernel<CA, CS, CB>, attr, LDS)) return rc_attr;
   const int groups = (a.B + CA::G - 1) / CA::G;
   const int n_items = a.n_samples * groups;
   int grid = 256;
@@ -2343,8 +2361,8 @@ template <class C, int NBLK>
 static int launch_block_chain_pp(const ChainArgs<NBLK>& a, hipStream_t st) {
   constexpr int LDS = chain_pp_lds<C, NBLK>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_chain_pp_kernel<C, NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_pp_kernel<C, NBLK>, attr, LDS)) return rc_attr;
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_pairs = a.n_samples * groups / 2;
   const int grid = n_pairs < 256 ? n_pairs : 256;
@@ -2685,8 +2703,8 @@ template <class C, int NWV>
 static int launch_block_chain_ald(const ChainArgs<1>& a, hipStream_t st) {
   constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_chain_ald_kernel<C, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV>, attr, LDS)) return rc_attr;
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
   const int grid = n_items < 256 ? n_items : 256;
@@ -2703,8 +2721,8 @@ template <class C, int NBLK, bool LDSW = true, bool STEM = false>
 static int launch_block_chain_ws(const ChainArgs<NBLK>& a, hipStream_t st) {
   constexpr int LDS = chain_ws_lds<C, NBLK, LDSW, STEM>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_chain_ws_kernel<C, NBLK, LDSW, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, LDSW, STEM>, attr, LDS)) return rc_attr;
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
   const int grid = n_items < 256 ? n_items : 256;
@@ -2879,8 +2897,8 @@ static int launch_block_down_ws(const DownArgs& a, hipStream_t st) {
   constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + DownSC<CB>::BYTES +
                       (LDSW ? WConv<CS>::BYTES + WConv<CA>::BYTES + WConv<CB>::BYTES : 0) + 3 * CB::COUT * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)block_down_ws_kernel<CA, CS, CB, LDSW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_down_ws_kernel<CA, CS, CB, LDSW>, attr, LDS)) return rc_attr;
   const int groups = (a.B + CA::G - 1) / CA::G;
   const int n_items = a.n_samples * groups;
   const int grid = n_items < 256 ? n_items : 256;
@@ -3168,31 +3186,62 @@ QBNN_EXPORT int qbnn_head_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* w,
   return check_launch("qbnn_head_i8_mc");
 }
 
-__global__ __launch_bounds__(256) void reduce_moments_kernel(const float* __restrict__ probs, int S, int64_t n,
-                                                             int accumulate, float* __restrict__ mom) {
+// MC reduction.  The sums are kept in fp64: var = (sum p^2 - (sum p)^2 / S) / (S - 1) cancels catastrophically in fp32 when the
+// spread of a class probability is small against its mean (the regression head's predictive variance feeds the reference's NLL).
+// FINAL: this launch also finalises (single rank, last chunk): mean / unbiased variance as fp32, no further launches.
+template <bool FINAL>
+__global__ __launch_bounds__(256) void reduce_moments_kernel(const float* __restrict__ probs, int S, int64_t n, int accumulate,
+                                                             double* __restrict__ mom, int total, float* __restrict__ mean_out,
+                                                             float* __restrict__ var_out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float s1 = accumulate ? mom[i] : 0.f, s2 = accumulate ? mom[n + i] : 0.f;
+  double s1 = accumulate ? mom[i] : 0.0, s2 = accumulate ? mom[n + i] : 0.0;
   int s = 0;
   for (; s + 8 <= S; s += 8) {            // 8 independent loads in flight, summed in sample order
     float p[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) p[j] = probs[(int64_t)(s + j) * n + i];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1 += p[j]; s2 += p[j] * p[j]; }
+    for (int j = 0; j < 8; ++j) { s1 += (double)p[j]; s2 += (double)p[j] * (double)p[j]; }
   }
   for (; s < S; ++s) {
-    const float p = probs[(int64_t)s * n + i];
+    const double p = (double)probs[(int64_t)s * n + i];
     s1 += p;
     s2 += p * p;
   }
   mom[i] = s1; mom[n + i] = s2;
+  if (FINAL) {
+    const double m = s1 / (double)total;
+    mean_out[i] = (float)m;
+    if (var_out) var_out[i] = total > 1 ? (float)(fmax(s2 - s1 * m, 0.0) / (double)(total - 1)) : 0.f;
+  }
 }
 
-QBNN_EXPORT int qbnn_reduce_moments(const float* probs, int32_t S, int64_t n, int32_t accumulate, float* mom, void* stream) {
+__global__ __launch_bounds__(256) void finalize_moments_kernel(const double* __restrict__ mom, int64_t n, int total,
+                                                               float* __restrict__ mean_out, float* __restrict__ var_out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double s1 = mom[i], s2 = mom[n + i], m = s1 / (double)total;
+  mean_out[i] = (float)m;
+  if (var_out) var_out[i] = total > 1 ? (float)(fmax(s2 - s1 * m, 0.0) / (double)(total - 1)) : 0.f;
+}
+
+QBNN_EXPORT int qbnn_reduce_moments(const float* probs, int32_t S, int64_t n, int32_t accumulate, double* mom,
+                                    int32_t finalize_total, float* mean_out, float* var_out, void* stream) {
   if (!probs || !mom || S <= 0 || n <= 0) return fail(QBNN_E_INVALID, "qbnn_reduce_moments: bad argument%s");
-  hipLaunchKernelGGL(reduce_moments_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, probs, S, n, accumulate, mom);
+  if (finalize_total > 0 && !mean_out) return fail(QBNN_E_INVALID, "qbnn_reduce_moments: finalize_total > 0 needs mean_out%s");
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (finalize_total > 0)
+    hipLaunchKernelGGL(reduce_moments_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, probs, S, n, accumulate, mom, finalize_total, mean_out, var_out);
+  else
+    hipLaunchKernelGGL(reduce_moments_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, probs, S, n, accumulate, mom, 0, nullptr, nullptr);
   return check_launch("qbnn_reduce_moments");
+}
+
+QBNN_EXPORT int qbnn_finalize_moments(const double* mom, int64_t n, int32_t total_samples, float* mean_out, float* var_out, void* stream) {
+  if (!mom || !mean_out || n <= 0 || total_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_finalize_moments: bad argument%s");
+  hipLaunchKernelGGL(finalize_moments_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mom, n, total_samples, mean_out, var_out);
+  return check_launch("qbnn_finalize_moments");
 }
 
 // =====================================================================================

@@ -6,7 +6,7 @@ keeps sum p^2, so the per-class predictive variance is available (a superset of 
 
 Multi-GPU: MC samples are independent given (parameters, input, seed).  Rank r of G evaluates the contiguous block of
 global sample indices [r*S/G, (r+1)*S/G); the Philox subsequence is the GLOBAL sample index, so per-sample results do
-not depend on G.  One sum all-reduce of the [2, B, C] fp32 partial moments (20 KB at B=256, C=10) over RCCL/xGMI.
+not depend on G.  One sum all-reduce of the [2, B, C] fp64 partial moments (40 KB at B=256, C=10) over RCCL/xGMI.
 """
 import os
 
@@ -24,73 +24,112 @@ def shard_samples(samples, rank, world_size):
     return begin, base + (1 if rank < rem else 0)
 
 
-def reduce_moments(probs, accumulate_into=None):
-    """sum_s p and sum_s p^2 over the leading (sample) dim on the device, in sample order: returns [2, B, C]."""
+def reduce_moments(probs, accumulate_into=None, finalize_total=0, want_var=True):
+    """sum_s p and sum_s p^2 over the leading (sample) dim on the device, in sample order, in fp64: returns [2, B, C].
+    finalize_total > 0: the same launch also finalises (single rank, last chunk) -> returns (moments, mean, var)."""
     S = probs.shape[0]
     n = probs[0].numel()
-    mom = accumulate_into if accumulate_into is not None else torch.empty((2,) + tuple(probs.shape[1:]), dtype=torch.float32, device=probs.device)
+    shape = tuple(probs.shape[1:])
+    mom = accumulate_into if accumulate_into is not None else torch.empty((2,) + shape, dtype=torch.float64, device=probs.device)
+    assert mom.dtype == torch.float64
+    mean = var = None
+    if finalize_total > 0:
+        mean = torch.empty(shape, dtype=torch.float32, device=probs.device)
+        var = torch.empty(shape, dtype=torch.float32, device=probs.device) if want_var else None
     with timed("reduce_moments"):
         _lib.check(_lib.lib().qbnn_reduce_moments(_lib.ptr(probs.contiguous()), S, n, int(accumulate_into is not None), _lib.ptr(mom),
-                                                  _lib.current_stream()))
-    return mom
+                                                  int(finalize_total), _lib.ptr(mean), _lib.ptr(var), _lib.current_stream()))
+    return (mom, mean, var) if finalize_total > 0 else mom
 
 
-def finalize_moments(moments, samples):
-    """mean = sum/S ; var = (sum2 - S mean^2)/(S-1) (unbiased, as torch.var in experiments/utils.py:352)."""
-    mean = moments[0] / samples
+def finalize_moments(moments, samples, want_var=True):
+    """mean = sum/S ; var = (sum2 - sum^2/S)/(S-1) (unbiased, as torch.var in experiments/utils.py:352), from fp64 sums.
+    Device moments: one small kernel (qbnn_finalize_moments).  Host moments (the gloo tests' stand-in ranks): torch fp64."""
+    if moments.device.type == "cuda" and moments.dtype == torch.float64:
+        shape = tuple(moments.shape[1:])
+        mean = torch.empty(shape, dtype=torch.float32, device=moments.device)
+        var = torch.empty(shape, dtype=torch.float32, device=moments.device) if want_var else None
+        with timed("finalize_moments"):
+            _lib.check(_lib.lib().qbnn_finalize_moments(_lib.ptr(moments.contiguous()), mean.numel(), int(samples), _lib.ptr(mean), _lib.ptr(var),
+                                                        _lib.current_stream()))
+        return mean, var
+    m64 = moments.to(torch.float64)
+    mean = m64[0] / samples
     if samples > 1:
-        var = (moments[1] - samples * mean * mean).clamp_min(0) / (samples - 1)
+        var = (m64[1] - m64[0] * mean).clamp_min(0) / (samples - 1)
     else:
         var = torch.zeros_like(mean)
-    return mean, var
+    return mean.to(torch.float32), var.to(torch.float32)
+
+
+def _force_dist():
+    return os.environ.get("QBNN_BENCH_FORCE_DIST", "0") == "1"
+
+
+def _dist_active(group=None):
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _force_dist())
 
 
 def all_reduce_moments(moments, group=None):
-    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("QBNN_BENCH_FORCE_DIST", "0") == "1"):
+    """The path's one collective: sum all-reduce of the [2, B, C] fp64 partial moments (40 KB at B=256, C=10) over RCCL / xGMI."""
+    if _dist_active(group):
         dist.all_reduce(moments, op=dist.ReduceOp.SUM, group=group)
     return moments
+
+
+def _rank_world(model, group):
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world > 1 and getattr(model, "sequential_samples", False):
+        # QAT evaluation with live observers (models_qat.py): sample s depends on samples < s through the EMA min/max of
+        # every FakeQuantize, so a rank that starts at sample_begin > 0 would run with the wrong observer state
+        raise RuntimeError("qat_eval models evaluate their MC samples in order (live observers) and cannot be sharded over ranks; "
+                           "evaluate them on one rank")
+    return rank, world
 
 
 def mc_predict_regression(model, x, samples, seed, group=None):
     """Regression branch of the reference loop (experiments/utils.py:348-353):
     returns (mean_s mu_s, var_unbiased_s(mu_s) + mean_s var_s), each [B, 1]."""
-    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank, world = _rank_world(model, group)
     begin, count = shard_samples(samples, rank, world)
     B = x.shape[0]
-    moments = torch.zeros((2, B, 2), dtype=torch.float32, device=x.device)
+    moments = torch.zeros((2, B, 2), dtype=torch.float64, device=x.device)
     if count > 0:
         with mc_context(count, seed, begin):
             mu, var = model.forward_mc(x)
         moments = reduce_moments(torch.cat([mu, var], dim=-1).contiguous())      # [2, B, 2]: sums and sums of squares of (mu, var)
     all_reduce_moments(moments, group)
-    mean_mu = moments[0, :, 0:1] / samples
-    var_mu = (moments[1, :, 0:1] - samples * mean_mu * mean_mu).clamp_min(0) / max(samples - 1, 1)
-    return mean_mu, var_mu + moments[0, :, 1:2] / samples
+    mean, uvar = finalize_moments(moments, samples)                               # [B, 2] each: columns (mu, var)
+    return mean[:, 0:1], uvar[:, 0:1] + mean[:, 1:2]
 
 
 def mc_predict(model, x, samples, seed, return_var=False, chunk=None, group=None, return_probs=False):
     """Predictive mean (and variance) of `samples` stochastic forwards of `x`; equals the reference loop
     (experiments/utils.py:342-355) given identical per-sample weight noise."""
-    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank, world = _rank_world(model, group)
     begin, count = shard_samples(samples, rank, world)
     chunk = count if chunk is None else chunk
-    moments, all_probs = None, []
+    single = not _dist_active(group)                 # one rank: the last chunk's reduction launch also finalises
+    moments, all_probs, mean, var = None, [], None, None
     done = 0
     while done < count:
         n = min(chunk, count - done)
         with mc_context(n, seed, begin + done):
             probs = model.forward_mc(x)
-        moments = reduce_moments(probs, moments)
+        if single and done + n == count:
+            moments, mean, var = reduce_moments(probs, moments, finalize_total=samples, want_var=return_var)
+        else:
+            moments = reduce_moments(probs, moments)
         if return_probs:
             all_probs.append(probs)
         done += n
-    if moments is None:
-        B = x.shape[0]
-        moments = torch.zeros((2, B, model.output_size), dtype=torch.float32, device=x.device)
-    all_reduce_moments(moments, group)
-    mean, var = finalize_moments(moments, samples)
+    if mean is None:
+        if moments is None:
+            B = x.shape[0]
+            moments = torch.zeros((2, B, model.output_size), dtype=torch.float64, device=x.device)
+        all_reduce_moments(moments, group)
+        mean, var = finalize_moments(moments, samples, want_var=return_var)
     out = (mean, var) if return_var else mean
     if return_probs:
         return out, (torch.cat(all_probs, 0) if all_probs else None)

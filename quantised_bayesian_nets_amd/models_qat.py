@@ -241,6 +241,7 @@ class QuantStub(nn.Module):
 
 class ConvNetwork_LeNet(nn.Module):
     """Prepared (QAT) `conv_lenet_bbb`, eval: quant - conv - maxpool - conv - maxpool - flatten - fc500+relu - fc - softmax."""
+    sequential_samples = True      # live EMA observers: sample s depends on samples < s (mc.py refuses to shard these over ranks)
 
     def __init__(self, input_size, output_size, q, args):
         super().__init__()
@@ -287,6 +288,7 @@ class ConvNetwork_LeNet(nn.Module):
 
 class LinearNetwork(nn.Module):
     """Prepared (QAT) `linear_bbb`: quant - 3 x (fc100 + relu) - heads mu / log_var -> (mu, exp(log_var))."""
+    sequential_samples = True      # live EMA observers: sample s depends on samples < s (mc.py refuses to shard these over ranks)
 
     def __init__(self, input_size, output_size, q, args):
         super().__init__()
@@ -355,6 +357,7 @@ class BasicBlock(nn.Module):
 
 class ConvNetwork_ResNet(nn.Module):
     """Prepared (QAT) `conv_resnet_bbb`, eval."""
+    sequential_samples = True      # live EMA observers: sample s depends on samples < s (mc.py refuses to shard these over ranks)
 
     def __init__(self, input_size, output_size, q, args):
         super().__init__()

@@ -65,3 +65,28 @@ def golden_mlp_bbb_q():
     return dict(state={k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")},
                 rec={k[len("rec/"):]: d[k] for k in d.files if k.startswith("rec/")}, x=d["x"], mu=d["mu"], var=d["var"],
                 seed=int(d["meta.philox_seed"]))
+
+
+def synth_ensemble_members(g, n):
+    """`n` distinct member state dicts for size tests / benches of the SGHMC ensemble (BASELINE config 4: 16 members):
+    the members recorded from the reference (fixture: 2) first, then deterministic perturbations of their int8 weights and
+    biases (same qparams, so every member stays a valid converted network).  Data only; nothing is read at run time
+    besides the committed fixture."""
+    out = []
+    for i in range(n):
+        base = g["members"][i % len(g["members"])]
+        if i < len(g["members"]):
+            out.append(base)
+            continue
+        rng = np.random.default_rng(7000 + i)
+        st = {}
+        for k, v in base.items():
+            v = np.asarray(v)
+            if k.endswith(".weight") and v.dtype == np.int8:
+                st[k] = np.clip(v.astype(np.int32) + rng.integers(-6, 7, v.shape), -128, 127).astype(np.int8)
+            elif k.endswith(".bias") and v.size:
+                st[k] = (v * (1.0 + 0.1 * rng.standard_normal(v.shape))).astype(np.float32)
+            else:
+                st[k] = v
+        out.append(st)
+    return out

@@ -137,8 +137,9 @@ def test_resnet_end_to_end_matches_reference(golden):
     np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=RTOL, atol=1e-8)
     mean, var = q.mc_predict(m, x, S, g["meta"]["philox_seed"], return_var=True)
     np.testing.assert_allclose(mean.cpu().numpy(), g["mean_probs"], rtol=RTOL, atol=1e-8)
-    ref_var = torch.from_numpy(g["probs"]).var(dim=0).numpy()
-    np.testing.assert_allclose(var.cpu().numpy(), ref_var, rtol=1e-3, atol=1e-7)
+    ref_var = torch.from_numpy(g["probs"]).double().var(dim=0).numpy()
+    np.testing.assert_allclose(var.cpu().numpy(), ref_var, rtol=1e-3, atol=1e-7)           # vs the reference's fp32 probabilities
+    np.testing.assert_allclose(var.cpu().numpy(), probs.double().var(dim=0).cpu().numpy(), rtol=1e-5, atol=1e-12)   # fp64 sums: no cancellation
     # reference single-forward call contract
     with q.mc_context(1, g["meta"]["philox_seed"], 1):
         p1 = m(x)
@@ -318,6 +319,8 @@ def test_float_bbb_mlp_matches_reference(golden_mlp_f32):
     mean, pv = q.mc_predict_regression(m, x, S, g["seed"])
     np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(pv.cpu().numpy(), g["pred_var"], rtol=1e-4, atol=1e-7)
+    own = mu.double().var(dim=0) + var.double().mean(dim=0)                # experiments/utils.py:352-353 on the device's own samples
+    np.testing.assert_allclose(pv.cpu().numpy(), own.cpu().numpy(), rtol=1e-5, atol=1e-12)
     with q.mc_context(1, g["seed"], 4):
         mu4, var4 = m(x)
     np.testing.assert_allclose(mu4.cpu().numpy(), g["mu"][4], rtol=1e-5, atol=2e-6)
@@ -620,3 +623,128 @@ def test_generic_int8_conv_mfma_equals_scalar_form_and_integer_reference():
         xf = (bias_h.astype(np.float64) * np.float64(rcp) + acc.astype(np.float32).astype(np.float64)).astype(np.float32)
         q = np.clip(60 + np.rint(xf * mult).astype(np.int64), 60 if relu else 0, 127).astype(np.uint8)
         assert np.array_equal(q, outs[0]), case
+
+
+# ------------------------------------------------------------------------------------------ full-size parity (round 2)
+def test_w4_full_size_fused_against_oracle_sample_by_sample():
+    """BASELINE config 5 arithmetic (A7/W4: sampled weights clamped to [-8, 7]) at the full batch (B = 256), S = 6 samples
+    of the fused path against the CPU oracle sample by sample: integer block outputs bit-exact, probabilities 1e-5."""
+    import quantised_bayesian_nets_amd as q
+    from conftest import load_golden
+    from oracle import oracle as orc
+    g = load_golden("resnet_bbb_a7w4.npz")
+    m = _model(g)
+    x = torch.randn(256, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+    xc = x.cuda()
+    S, seed, begin = 6, 3, 0
+    with q.mc_context(S, seed, begin):
+        probs = m.forward_mc(xc)                      # fully fused path (stem + chains + down blocks)
+        rec = {}
+        m.forward_mc(xc, record=rec)                  # per-block launches, recording the block outputs
+    net = orc.Int8ResNetOracle(g["state"], 7, 4)
+    for s in range(S):
+        orec = {}
+        p_or = net.forward(x.numpy(), seed, begin + s, record=orec)
+        for k in ("layers.0.out", "layers.3.1.out", "layers.4.1.out", "layers.5.0.out", "layers.6.1.out"):
+            assert np.array_equal(rec[k][s].cpu().numpy(), orec["layers.0.out" if k == "layers.0.out" else k]), (k, s)
+        np.testing.assert_allclose(probs[s].cpu().numpy(), p_or, rtol=RTOL, atol=1e-8)
+        w = orec["layers.5.1.stem.0.w_q"]
+        assert w.min() >= -8 and w.max() <= 7
+
+
+@pytest.mark.parametrize("w_bits", [8, 4])
+def test_high_sample_indices_against_oracle(w_bits):
+    """Config 5 draws S = 1024 samples: Philox subsequences >= 256 (a second byte of the sample counter) must match the
+    oracle too.  Sampler for every layer at sample_begin in {255, 256, 1023}, and the fused path end to end at B = 256."""
+    import quantised_bayesian_nets_amd as q
+    from conftest import load_golden
+    from oracle import oracle as orc
+    g = load_golden(f"resnet_bbb_a7w{w_bits}.npz")
+    m = _model(g)
+    net = orc.Int8ResNetOracle(g["state"], 7, w_bits)
+    seed = 3
+    for begin in (255, 256, 1023):
+        for name, layer, (pfx, *_r) in zip(m.stochastic_layer_names(), m.stochastic_layers(), net.table):
+            w = layer.sample_weights("cuda", samples=2, seed=seed, sample_begin=begin).cpu().numpy()
+            for i in range(2):
+                assert np.array_equal(w[i], _pack(layer, net.layers[pfx].sample(seed, begin + i))), (name, begin + i)
+    x = torch.randn(256, 3, 32, 32, generator=torch.Generator().manual_seed(5))
+    xc = x.cuda()
+    with q.mc_context(2, seed, 255):
+        p = m.forward_mc(xc)                          # samples 255, 256
+    with q.mc_context(1, seed, 1023):
+        p1023 = m.forward_mc(xc)
+    for s, got in ((255, p[0]), (256, p[1]), (1023, p1023[0])):
+        np.testing.assert_allclose(got.cpu().numpy(), net.forward(x.numpy(), seed, s), rtol=RTOL, atol=1e-8)
+    # a 1024-sample evaluation sharded as 8 ranks would shard it: rank 7 owns [896, 1024)
+    from quantised_bayesian_nets_amd.mc import shard_samples
+    assert shard_samples(1024, 7, 8) == (896, 128)
+    with q.mc_context(128, seed, 896):
+        tail = m.forward_mc(xc)
+    assert torch.equal(tail[127], p1023[0])
+
+
+def test_ensemble_16_members_full_batch_against_oracle(golden_ensemble):
+    """BASELINE config 4 size: 16 members at B = 256.  Every member's probabilities against the deterministic-member oracle
+    (integer logits path bit-exact -> 1e-5 on probabilities), through forward_mc (all members of the mc_context) -- first
+    call and replays -- and through the reference's round-robin forward()."""
+    import quantised_bayesian_nets_amd as q
+    from conftest import synth_ensemble_members
+    from oracle import oracle as orc
+    n = 16
+    members = synth_ensemble_members(golden_ensemble, n)
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, model="conv_resnet_sgld", samples=n)
+    net = q.ModelFactory.get_model("conv_resnet_sgld", [1, 3, 32, 32], 10, True, args, training_mode=False).load_reference_state(members)
+    x = torch.randn(256, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+    xc = x.cuda()
+    ref = np.stack([orc.Int8ResNetDetOracle(st, 7).forward(x.numpy()) for st in members])
+    assert np.abs(ref[0] - ref[5]).max() > 1e-3                    # the synthetic members really differ
+    for _ in range(3):                                              # eager / captured / replayed
+        with q.mc_context(n, 0, 0):
+            probs = net.forward_mc(xc)
+        np.testing.assert_allclose(probs.cpu().numpy(), ref, rtol=RTOL, atol=1e-8)
+    with q.mc_context(5, 0, 9):                                     # a rank's shard: members 9..13
+        part = net.forward_mc(xc)
+    assert torch.equal(part, probs[9:14])
+    mean = q.mc_predict(net, xc, n, 0)
+    np.testing.assert_allclose(mean.cpu().numpy(), ref.mean(0), rtol=RTOL, atol=1e-7)
+    net.counter = 0
+    for i in range(n):
+        np.testing.assert_allclose(net(xc).cpu().numpy(), ref[i], rtol=RTOL, atol=1e-8)
+
+
+_DIST_WORKER = r"""
+import os, sys, types, numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from conftest import load_golden
+import quantised_bayesian_nets_amd as q
+torch.cuda.set_device(0)
+g = load_golden("resnet_bbb_a7w8.npz")
+args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+m = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args).load_reference_state(g["state"])
+x = torch.randn(64, 3, 32, 32, generator=torch.Generator().manual_seed(2)).cuda()
+mean0, var0 = q.mc_predict(m, x, 7, 3, return_var=True)            # no process group
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+os.environ["QBNN_BENCH_FORCE_DIST"] = "1"                          # take the all-reduce with one rank too
+mean1, var1 = q.mc_predict(m, x, 7, 3, return_var=True)
+torch.cuda.synchronize()
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+assert torch.equal(mean0, mean1) and torch.equal(var0, var1)
+dist.destroy_process_group()
+print("DIST-OK")
+"""
+
+
+def test_rccl_path_one_rank_equals_no_dist(tmp_path):
+    """The RCCL leg of mc_predict (init_process_group('nccl') + the sum all-reduce of the moments) with one rank, in a child
+    process: bit-identical to the evaluation without a process group."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dist_worker.py"
+    script.write_text(_DIST_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIST-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -99,10 +99,16 @@ def test_shard_samples_partitions_the_range():
 def test_finalize_moments_matches_torch():
     from quantised_bayesian_nets_amd.mc import finalize_moments
     p = torch.rand(9, 5, 10)
-    mom = torch.stack([p.sum(0), (p * p).sum(0)])
+    p64 = p.double()
+    mom = torch.stack([p64.sum(0), (p64 * p64).sum(0)])                  # the device kernel keeps the sums in fp64
     mean, var = finalize_moments(mom, 9)
     torch.testing.assert_close(mean, p.mean(0), rtol=1e-6, atol=1e-7)
-    torch.testing.assert_close(var, p.var(0), rtol=1e-4, atol=1e-6)     # unbiased, as experiments/utils.py:352
+    torch.testing.assert_close(var, p.var(0), rtol=1e-5, atol=1e-8)     # unbiased, as experiments/utils.py:352
+    # small spread against the mean (what made fp32 sums cancel): still 1e-5 from fp64 sums
+    q_ = 0.9 + 1e-4 * torch.rand(100, 7, 3)
+    q64 = q_.double()
+    mean, var = finalize_moments(torch.stack([q64.sum(0), (q64 * q64).sum(0)]), 100)
+    torch.testing.assert_close(var, q64.var(0).float(), rtol=1e-5, atol=0)
 
 
 _WORKER = r"""
@@ -118,9 +124,9 @@ net = orc.Int8ResNetOracle(g["state"], 7, 8)
 S, seed = 5, 3
 begin, count = shard_samples(S, rank, world)
 x = g["x"][:2]
-mom = torch.zeros(2, 2, 10)
+mom = torch.zeros(2, 2, 10, dtype=torch.float64)
 for s in range(begin, begin + count):          # the oracle stands in for this rank's GPU evaluation
-    p = torch.from_numpy(net.forward(x, seed, s))
+    p = torch.from_numpy(net.forward(x, seed, s)).double()
     mom[0] += p; mom[1] += p * p
 all_reduce_moments(mom)
 mean, var = finalize_moments(mom, S)
@@ -128,10 +134,19 @@ if rank == 0:
     _, ps = net.mc_predict(x, S, seed)
     ps = torch.from_numpy(ps)
     torch.testing.assert_close(mean, ps.mean(0), rtol=1e-5, atol=1e-7)
-    torch.testing.assert_close(var, ps.var(0), rtol=1e-3, atol=1e-7)
+    torch.testing.assert_close(var, ps.double().var(0).float(), rtol=1e-5, atol=1e-9)
     # samples 0..2 of the global stream are the golden ones recorded from the reference
     torch.testing.assert_close(ps[:3], torch.from_numpy(g["probs"][:, :2]), rtol=1e-5, atol=1e-8)
     print("OK")
+# a QAT model with live observers is sequential in the sample index: mc_predict must refuse to shard it
+from quantised_bayesian_nets_amd.mc import mc_predict
+class _Seq:
+    sequential_samples = True
+try:
+    mc_predict(_Seq(), torch.zeros(1), 4, 0)
+    raise SystemExit("sharded a sequential model")
+except RuntimeError as e:
+    assert "cannot be sharded" in str(e)
 dist.destroy_process_group()
 """
 
@@ -182,3 +197,32 @@ def test_model_factory_routes_and_loads_reference_state_without_a_gpu():
         le.forward_mc(torch.zeros(2, 1, 28, 28))           # no CPU fallback
     with pytest.raises(NotImplementedError):
         q.ModelFactory.get_model("no_such_model", [1, 3, 32, 32], 10, True, a)
+
+
+def test_public_header_is_valid_c99():
+    """include/qbnn.h is the C ABI: it must compile as plain C (a maintainer binds it from C / cgo / ctypes generators)."""
+    hdr = os.path.join(ROOT, "include", "qbnn.h")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # every struct the Python binding mirrors has the same size as the C one
+    from quantised_bayesian_nets_amd import _lib
+    prog = '#include <stdio.h>\n#include "qbnn.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(qbnn_sample_params), sizeof(qbnn_conv_desc), sizeof(qbnn_block_desc), sizeof(qbnn_down_desc), sizeof(qbnn_head_desc));return 0;}\n'
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "s.c")
+        open(src, "w").write(prog)
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(td, "s")])
+        sizes = [int(v) for v in subprocess.check_output([os.path.join(td, "s")]).split()]
+    assert sizes == [C.sizeof(_lib.SampleParams), C.sizeof(_lib.ConvDesc), C.sizeof(_lib.BlockDesc), C.sizeof(_lib.DownDesc), C.sizeof(_lib.HeadDesc)]
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` with no launcher spawns 2 fresh ranks under torch.distributed.run as a child and relays
+    rank 0's JSON line (here: the no-GPU plumbing mode over gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-check"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1 and json.loads(line[0]) == {"plumbing_check": True, "ranks": 2, "rank_sum": 1.0}

@@ -205,3 +205,22 @@ def test_resnet_mc_dropout_matches_reference():
         assert np.array_equal(rec[k[:-len(".out")] + ".out"], v), k
     np.testing.assert_allclose(p0, g["probs"][0], rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(net.forward(g["x"], g["meta"]["philox_seed"], 2), g["probs"][2], rtol=1e-5, atol=1e-8)
+
+
+def test_fbgemm_harness_matches_golden(golden):
+    """bench.py's `cpu_baseline` of kind "torch-fbgemm" (oracle/fbgemm_baseline.py: the reference's op sequence through
+    torch's own quantised CPU operators) reproduces the probabilities recorded from the reference, given the same eps."""
+    from oracle.fbgemm_baseline import FbgemmResNetBBB
+    wb, seed = golden["meta"]["w_bits"], golden["meta"]["philox_seed"]
+    net = orc.Int8ResNetOracle(golden["state"], golden["meta"]["a_bits"], wb)
+    fb = FbgemmResNetBBB(golden["state"], golden["meta"]["a_bits"], wb)
+    for s in range(golden["probs"].shape[0]):
+        eps = {pfx: orc.fill_normal(net.layers[pfx].mu_q.size, seed, i, s).reshape(net.layers[pfx].mu_q.shape)
+               for i, (pfx, *_) in enumerate(net.table)}
+        rec = {}
+        p = fb.forward(golden["x"], eps, record=rec)
+        np.testing.assert_allclose(p, golden["probs"][s], rtol=1e-6, atol=1e-9)
+        if s == 0:
+            for k in ("layers.3.0.out", "layers.4.0.out", "layers.6.1.out"):
+                if k in golden["rec"]:
+                    assert np.array_equal(rec[k], golden["rec"][k]), k
