@@ -42,8 +42,8 @@ class ConvParams(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libqbnn_oracle.so")
-    src = os.path.join(_HERE, "qbnn_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "qbnn_oracle.c"), os.path.join(_HERE, "qbnn_eps_table.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return so
 
@@ -75,6 +75,24 @@ def fill_normal(n, seed, layer, sample):
     eps = np.empty(n, np.float32)
     lib().qbo_fill_normal(_p(eps), C.c_int64(n), C.c_uint64(seed), C.c_uint32(layer), C.c_uint32(sample))
     return eps
+
+
+def fill_eps_q(n, seed, layer, sample):
+    """The int8 mode's weight noise: eps_q in [-128, 127] drawn directly from Philox words through the alias table of
+    clamp(rne(N(0,1) / s_n)) (qbnn_oracle.c: qbo_fill_eps_q)."""
+    e = np.empty(n, np.int8)
+    lib().qbo_fill_eps_q(_p(e), C.c_int64(n), C.c_uint64(seed), C.c_uint32(layer), C.c_uint32(sample))
+    return e
+
+
+def eps_from_eps_q(eps_q):
+    """The fp32 eps to inject into the reference so that ITS quantize_per_tensor(eps, s_n, 0, qint8) returns eps_q."""
+    return eps_q.astype(np.float32) * f32(NOISE_SCALE)
+
+
+def fill_eps_i8(n, seed, layer, sample):
+    """fp32 eps of the int8 noise stream (what the fixture generators inject into the reference's normal_)."""
+    return eps_from_eps_q(fill_eps_q(n, seed, layer, sample))
 
 
 def fill_uniform(n, seed, layer, sample):
@@ -525,7 +543,7 @@ class Int8LeNetBBBOracle(_Int8BBBBase):
 
     def sample(self, n, seed, sample):
         L = self.L[n]
-        eps = fill_normal(L.mu_q.size, seed, L.layer_id, sample)       # stream defined on the reference-order OHWI tensor
+        eps = fill_eps_i8(L.mu_q.size, seed, L.layer_id, sample)       # stream defined on the reference-order OHWI tensor
         if n == "layers.5":
             eps = eps.reshape(500, 2450)[:, self.perm5]
         return L.sample(seed, sample, eps.reshape(L.mu_q.shape))

@@ -211,6 +211,30 @@ QBO_API void qbo_sample_weights_i8(const int8_t* mu_q, const int8_t* sigma_q, co
   }
 }
 
+/* The int8 noise stream.  The reference quantises its N(0,1) draw one instruction after drawing it
+ * (conv_q.py:113-115, linear_q.py:86-88): eps_q = clamp(rne(eps * (1/s_n)), -128, 127) is a discrete random variable
+ * with P(k) = Phi((k + 1/2) s_n') - Phi((k - 1/2) s_n') (tails folded into -128 / 127).  The int8 mode therefore draws
+ * eps_q DIRECTLY: one 32-bit Philox word per weight through Walker's alias table of that distribution
+ * (qbnn_eps_table.h, generated by tools/make_eps_table.py; |P_table - P| < 2^-31), integer compare only:
+ *   block = philox(ctr = {i >> 2, layer, sample, 0}, key = seed);  u = block[i & 3];
+ *   c = u >> 24;  eps_q = ((u & 0xffffff) < thr[c] ? c : alias[c]) - 128.
+ * Parity with the reference is by injection: eps = (float)eps_q * s_n quantises back to eps_q exactly (checked for all 256
+ * values by the fixture generators and by tests/test_oracle_golden.py). */
+#include "qbnn_eps_table.h"
+static inline int32_t qbo_eps_q_from_u32(uint32_t u) {
+  const uint32_t e = QBNN_EPS_ALIAS[u >> 24];
+  return (int32_t)(((u & 0xffffffu) < (e >> 8)) ? (u >> 24) : (e & 0xffu)) - 128;
+}
+
+QBO_API void qbo_fill_eps_q(int8_t* eps_q, int64_t n, uint64_t seed, uint32_t layer, uint32_t sample) {
+  uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+  for (int64_t i = 0; i < n; i += 4) {
+    uint32_t ctr[4] = { (uint32_t)(i >> 2), layer, sample, 0u }, r[4];
+    qbo_philox4x32_10(ctr, key, r);
+    for (int j = 0; j < 4 && i + j < n; ++j) eps_q[i + j] = (int8_t)qbo_eps_q_from_u32(r[j]);
+  }
+}
+
 /* Philox-driven variant (what the GPU sampler does in-kernel) */
 QBO_API void qbo_sample_weights_i8_philox(const int8_t* mu_q, const int8_t* sigma_q, int64_t n,
                                           const qbo_sample_params* p, uint64_t seed, uint32_t layer,
@@ -218,11 +242,9 @@ QBO_API void qbo_sample_weights_i8_philox(const int8_t* mu_q, const int8_t* sigm
   uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
   for (int64_t i = 0; i < n; i += 4) {
     uint32_t ctr[4] = { (uint32_t)(i >> 2), layer, sample, 0u }, r[4];
-    float v[4];
     qbo_philox4x32_10(ctr, key, r);
-    qbo_normal4(r, v);
     for (int j = 0; j < 4 && i + j < n; ++j) {
-      int32_t e = qbo_quant_eps(v[j], p->inv_noise_scale);
+      int32_t e = qbo_eps_q_from_u32(r[j]);
       w_q_out[i + j] = (int8_t)qbo_sample_one(mu_q[i + j], sigma_q[i + j], e, p);
     }
   }

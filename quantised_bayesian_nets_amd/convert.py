@@ -115,3 +115,69 @@ def convert_qat_module(mod):
                          ObserverState.from_fake_quant(mod.activation_post_process),
                          ObserverState.from_fake_quant(mod.add_weight.activation_post_process),
                          ObserverState.from_fake_quant(mod.mul_noise.activation_post_process), bn)
+
+
+# ---------------------------------------------------------------------------------------------- model level
+_OBS = ".activation_post_process."
+
+
+def _obs(state, key, bounds):
+    """ObserverState of the FakeQuantize stored under `key` (…activation_post_process.{min_val,max_val}) in a prepared state dict."""
+    return ObserverState(np.asarray(state[key + "min_val"]).reshape(()), np.asarray(state[key + "max_val"]).reshape(()), bounds[0], bounds[1])
+
+
+def convert_model_state(prepared, args, bn_eps=1e-5):
+    """The reference's model-level `quant_utils.convert` (src/quant_utils.py:62-99) on a flat state dict.
+
+    `prepared`: flat {key: numpy} state of a PREPARED (QAT) BBB model -- the keys of the reference model's state_dict after
+    `prepare_model` (quant_utils.py:112-147) and calibration: per stochastic layer `<p>.weight` (mu), `<p>.std` (rho),
+    optional `<p>.bias`, `<p>.bn.{weight,bias,running_mean,running_var}` for ConvBn*, and the min / max of its five
+    FakeQuantize observers; `quant.activation_post_process...`; one `...add.add.activation_post_process...` per BasicBlock.
+    (models_qat.py holds the same dict, with the observers as they stand after its live-observer evaluations.)
+    The walk is what `convert` does: every swappable module is replaced through its class's `from_float`
+    (conv_q.py:127-177, linear_q.py:105-145), QuantStub -> Quantize and FloatFunctional -> QFunctional take their observer's
+    qparams.  The quantisation ranges come from `args` exactly as in prepare_model (:122-123): weight-like observers (weight,
+    std, add_weight, mul_noise) use INT_BOUNDS[weight_precision], activations UINT_BOUNDS[activation_precision].
+    Returns the converted model's flat state (reference key names), i.e. what `load_reference_state` ingests and what the
+    reference would have saved with `utils.save_model` after `postprocess_model` (quant_utils.py:100-109)."""
+    from .quant import INT_BOUNDS, UINT_BOUNDS
+    wb, ab = INT_BOUNDS[args.weight_precision], UINT_BOUNDS[args.activation_precision]
+    out = {}
+    tag = ".weight_fake_quant" + _OBS + "min_val"
+    layers = [k[:-len(tag)] for k in prepared if k.endswith(tag)]
+    for p in layers:
+        bn = None
+        if (p + ".bn.running_mean") in prepared:
+            bn = dict(running_mean=prepared[p + ".bn.running_mean"], running_var=prepared[p + ".bn.running_var"], eps=bn_eps,
+                      weight=prepared[p + ".bn.weight"], bias=prepared[p + ".bn.bias"])
+        st = convert_layer(prepared[p + ".weight"], prepared[p + ".std"], prepared.get(p + ".bias"),
+                           _obs(prepared, p + ".weight_fake_quant" + _OBS, wb), _obs(prepared, p + ".std_fake_quant" + _OBS, wb),
+                           _obs(prepared, p + _OBS + "activation_post_process.", ab),
+                           _obs(prepared, p + ".add_weight" + _OBS + "activation_post_process.", wb),
+                           _obs(prepared, p + ".mul_noise" + _OBS + "activation_post_process.", wb), bn)
+        out.update({p + "." + k: v for k, v in st.items()})
+        if (p + ".std_prior") in prepared:
+            out[p + ".std_prior"] = np.asarray(prepared[p + ".std_prior"])
+    # QuantStub -> Quantize, Add's FloatFunctional -> QFunctional: (scale, zero_point) of their activation observer
+    for k in prepared:
+        if k.endswith(_OBS + "activation_post_process.min_val") and not any(k.startswith(p + ".") for p in layers):
+            base = k[:-len(_OBS + "activation_post_process.min_val")]
+            s, z = _obs(prepared, base + _OBS + "activation_post_process.", ab).qparams()
+            if base == "quant":
+                out["quant.scale"], out["quant.zero_point"] = np.asarray([s], np.float32), np.asarray([z], np.int64)
+            else:
+                out[base + ".scale"], out[base + ".zero_point"] = np.float32(s), np.int64(z)
+    return out
+
+
+def convert_model(prepared, model_name, input_size, output_size, args):
+    """prepared state (or a models_qat model holding one) -> the converted int8 model of this package, ready for the HIP path:
+    `ModelFactory.get_model(model_name, ..., q=True, args)` loaded with `convert_model_state(prepared, args)`."""
+    from .models import ModelFactory
+    import types
+    if hasattr(prepared, "prepared_state"):
+        prepared = prepared.prepared_state()
+    a = types.SimpleNamespace(**{k: v for k, v in vars(args).items() if k != "qat_eval"})
+    model = ModelFactory.get_model(model_name, input_size, output_size, True, a, training_mode=False) if "sgld" in model_name else \
+        ModelFactory.get_model(model_name, input_size, output_size, True, a)
+    return model.load_reference_state(convert_model_state(prepared, a))

@@ -13,6 +13,8 @@
 #include "../../include/qbnn.h"
 #include "qbnn_rng.cuh"
 #include "qbnn_common.h"
+#define QBNN_EPS_TABLE_QUALIFIER __device__ static const
+#include "qbnn_eps_table.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -118,8 +120,22 @@ __device__ __forceinline__ int rne_sat(float v) {
   return __float2int_rn(v);
 }
 
+// eps_q drawn directly: one 32-bit Philox word through the alias table of clamp(rne(N(0,1) / s_n), -128, 127)
+// (qbnn_eps_table.h; `tab` = the workgroup's LDS copy).  Integer compare only: the same bits as oracle/qbnn_oracle.c.
+__device__ __forceinline__ int eps_q_from_u32(uint32_t u, const uint32_t* tab) {
+  const uint32_t e = tab[u >> 24];
+  return (int)(((u & 0xffffffu) < (e >> 8)) ? (u >> 24) : (e & 0xffu)) - 128;
+}
+__device__ __forceinline__ void load_eps_table(uint32_t* tab, int tid) {       // 256 threads: one entry each
+  tab[tid & 255] = QBNN_EPS_ALIAS[tid & 255];
+}
+
+__device__ __forceinline__ int sample_one_q(int mu_q, int sigma_q, int eps_q, const qbnn_sample_params& p);
+// injected fp32 eps (parity mode): quantise it as the reference does, then the common chain
 __device__ __forceinline__ int sample_one(int mu_q, int sigma_q, float eps, const qbnn_sample_params& p) {
-  const int eps_q = clampi(rne_sat(eps * p.inv_noise_scale), -128, 127);
+  return sample_one_q(mu_q, sigma_q, clampi(rne_sat(eps * p.inv_noise_scale), -128, 127), p);
+}
+__device__ __forceinline__ int sample_one_q(int mu_q, int sigma_q, int eps_q, const qbnn_sample_params& p) {
   const int prod = (sigma_q - p.z_sigma) * eps_q;
   const int t_q = clampi(p.z_mul + rne_sat((float)prod * p.mul_multiplier), -128, 127);
   const float dw = __builtin_fmaf(p.s_w, (float)mu_q, p.nzs_w);
@@ -132,6 +148,9 @@ __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
     const v4i* __restrict__ mu, const v4i* __restrict__ sigma, int cout, int K, int krow, int rbp, int KS, int layout,
     int n_chunks, qbnn_sample_params p, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_id, uint32_t sample_begin,
     const float* __restrict__ eps_in, int8_t* __restrict__ w_out, int64_t w_sample_stride) {
+  __shared__ uint32_t eps_tab[256];
+  load_eps_table(eps_tab, threadIdx.x);
+  __syncthreads();
   const int chunk = blockIdx.x * 256 + threadIdx.x;
   if (chunk >= n_chunks) return;
   const int s = blockIdx.y;
@@ -149,7 +168,7 @@ __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
   uint32_t ow[4] = {0u, 0u, 0u, 0u};
   const int64_t total = (int64_t)cout * K;
   uint32_t cur_blk = 0xffffffffu;
-  float nrm[4] = {0.f, 0.f, 0.f, 0.f};
+  qbnn::u32x4 rb = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     int64_t idx;
@@ -163,21 +182,21 @@ __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
       valid = idx < total;
     }
     if (valid) {
-      float eps;
+      const int mu_q = (mw[j >> 2] << (24 - 8 * (j & 3))) >> 24;       // sign-extended byte j
+      const int sg_q = (sw[j >> 2] << (24 - 8 * (j & 3))) >> 24;
+      int wq;
       if (eps_in) {
-        eps = eps_in[(int64_t)s * total + idx];
+        wq = sample_one(mu_q, sg_q, eps_in[(int64_t)s * total + idx], p);
       } else {
         const uint32_t blk = (uint32_t)(idx >> 2);
         if (blk != cur_blk) {
           cur_blk = blk;
-          qbnn::normal4(qbnn::philox4x32_10(blk, layer_id, sample_begin + s, 0u, seed_lo, seed_hi), nrm);
+          rb = qbnn::philox4x32_10(blk, layer_id, sample_begin + s, 0u, seed_lo, seed_hi);
         }
         const int l = (int)(idx & 3);
-        eps = l == 0 ? nrm[0] : (l == 1 ? nrm[1] : (l == 2 ? nrm[2] : nrm[3]));
+        const uint32_t u = l == 0 ? rb.x : (l == 1 ? rb.y : (l == 2 ? rb.z : rb.w));
+        wq = sample_one_q(mu_q, sg_q, eps_q_from_u32(u, eps_tab), p);
       }
-      const int mu_q = (mw[j >> 2] << (24 - 8 * (j & 3))) >> 24;       // sign-extended byte j
-      const int sg_q = (sw[j >> 2] << (24 - 8 * (j & 3))) >> 24;
-      const int wq = sample_one(mu_q, sg_q, eps, p);
       ow[j >> 2] |= ((uint32_t)wq & 0xffu) << (8 * (j & 3));
     }
   }
@@ -230,9 +249,14 @@ struct QConv {             // one conv layer's scalars (by value in kernel argum
   float rcp, mult;                 // FBGEMM act_times_w_rcp, output multiplier
   float vlo, vhi;                  // clamp of v = xf*mult before rounding: lo - z_y, min(255, a_hi) - z_y
   float s_y, nzs_y;                // output qparams as a quantized::add operand
+  // ATen dequantises an add operand as fma(s, (float)q, nzs), nzs = rn(-z * s).  With q = q' + z (q' the centred integer the
+  // epilogue holds):  s q + nzs = s q' + (s z + nzs), and dl = s z + nzs is the (negated) rounding error of the product z * s,
+  // which is exactly representable: fma(s, q', dl) rounds the same real number once -> the same bits, one add fewer.
+  float dl_y;
 };
 struct QAdd {              // BasicBlock Add + ReLU (models_bbb.py:179-182)
   float s_r, nzs_r; int z_r;       // residual operand qparams
+  float dl_r;                      // s_r z_r + nzs_r exactly (see QConv::dl_y): dequantises the CENTRED residual byte directly
   float inv_s_o; int z_o;          // add output qparams
   float vhi;                       // min(255, a_hi) - z_o ; lower bound is 0 (ReLU: q >= z_o)
   const uint8_t* lut;              // optional 128x128 table of the whole add (qbnn_build_add_lut_host), device memory
@@ -681,6 +705,9 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
 #pragma unroll 1
   for (int i = 1; i < t.n; ++i) li = ((int)blockIdx.x >= t.l[i].chunk_begin) ? i : li;
   const SamplerLayer& L = t.l[li];
+  __shared__ uint32_t eps_tab[256];
+  load_eps_table(eps_tab, threadIdx.x);
+  __syncthreads();
   const int chunk = ((int)blockIdx.x - L.chunk_begin) * 256 + threadIdx.x;
   if (chunk >= L.n_chunks) return;
   const int s = blockIdx.y;
@@ -698,23 +725,24 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
   uint32_t ow[4] = {0u, 0u, 0u, 0u};
   const int64_t total = (int64_t)L.cout * L.K;
   uint32_t cur_blk = 0xffffffffu;
-  float nrm[4] = {0.f, 0.f, 0.f, 0.f};
+  qbnn::u32x4 rb = {0u, 0u, 0u, 0u};
   if (L.layout == QBNN_LAYOUT_MFMA32 && ((L.K | L.krow) & 3) == 0) {
     // Fast path (every conv but layers.0): the chunk's 16 weights are 4 whole Philox blocks -- element index
     // n K + kh krow + j0 + j with all terms multiples of 4 -- and a block is valid or padding as a whole.  Straight-line:
-    // 4 x (Philox, Box-Muller, 4 weights), no per-element block tracking or selects.
+    // 4 x (Philox, 4 alias draws, 4 weights), no per-element block tracking or selects.
     const int64_t idx0 = (int64_t)n * L.K + kh * L.krow + j0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (ones_row && j0 + 4 * g < L.krow) ow[g] = 0x01010101u;
       if (n < L.cout && j0 + 4 * g < L.krow) {
-        qbnn::normal4(qbnn::philox4x32_10((uint32_t)((idx0 >> 2) + g), L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi), nrm);
+        const qbnn::u32x4 r4 = qbnn::philox4x32_10((uint32_t)((idx0 >> 2) + g), L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi);
+        const uint32_t uu[4] = {r4.x, r4.y, r4.z, r4.w};
         uint32_t o = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int mu_q = (mw[g] << (24 - 8 * i)) >> 24;
           const int sg_q = (sw[g] << (24 - 8 * i)) >> 24;
-          o |= ((uint32_t)sample_one(mu_q, sg_q, nrm[i], L.p) & 0xffu) << (8 * i);
+          o |= ((uint32_t)sample_one_q(mu_q, sg_q, eps_q_from_u32(uu[i], eps_tab), L.p) & 0xffu) << (8 * i);
         }
         ow[g] = o;
       }
@@ -738,13 +766,13 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
       const uint32_t blk = (uint32_t)(idx >> 2);
       if (blk != cur_blk) {
         cur_blk = blk;
-        qbnn::normal4(qbnn::philox4x32_10(blk, L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi), nrm);
+        rb = qbnn::philox4x32_10(blk, L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi);
       }
       const int l = (int)(idx & 3);
-      const float eps = l == 0 ? nrm[0] : (l == 1 ? nrm[1] : (l == 2 ? nrm[2] : nrm[3]));
+      const uint32_t u = l == 0 ? rb.x : (l == 1 ? rb.y : (l == 2 ? rb.z : rb.w));
       const int mu_q = (mw[j >> 2] << (24 - 8 * (j & 3))) >> 24;
       const int sg_q = (sw[j >> 2] << (24 - 8 * (j & 3))) >> 24;
-      ow[j >> 2] |= ((uint32_t)sample_one(mu_q, sg_q, eps, L.p) & 0xffu) << (8 * (j & 3));
+      ow[j >> 2] |= ((uint32_t)sample_one_q(mu_q, sg_q, eps_q_from_u32(u, eps_tab), L.p) & 0xffu) << (8 * (j & 3));
     }
   }
   reinterpret_cast<v4i*>(L.out + (int64_t)s * L.out_ss)[chunk] = v4i{(int)ow[0], (int)ow[1], (int)ow[2], (int)ow[3]};
@@ -1067,8 +1095,8 @@ struct EpiDense {
       return;
     }
     v0 = med3f(v0, p.vlo, p.vhi); v1 = med3f(v1, p.vlo, p.vhi); v2 = med3f(v2, p.vlo, p.vhi); v3 = med3f(v3, p.vlo, p.vhi);
-    const float zy = (float)p.z_y;
     if (!HAS_RES) {
+      const float zy = (float)p.z_y;
       // round with the (even) magic constant first, then add z_y exactly: folding an odd z_y into the constant
       // would flip round-half-even ties
       *o = pack_low_bytes((v0 + QBNN_MAGIC) + zy, (v1 + QBNN_MAGIC) + zy, (v2 + QBNN_MAGIC) + zy, (v3 + QBNN_MAGIC) + zy);
@@ -1078,8 +1106,7 @@ struct EpiDense {
       const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float qf = __builtin_rintf(vv[i]) + zy;                       // the conv output integer, exactly
-        const float da = __builtin_fmaf(p.s_y, qf, p.nzs_y);
+        const float da = __builtin_fmaf(p.s_y, __builtin_rintf(vv[i]), p.dl_y);      // centred conv output integer, exactly
         const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
         t[i] = (da + db) * a.inv_s_o;
       }
@@ -1120,16 +1147,13 @@ struct EpiTileResInPlace {
   __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rqu) const {
     uint32_t* o = reinterpret_cast<uint32_t*>(xt + po + c0);
     const int rq = (int)rqu;
-    const float zy = (float)p.z_y, zr = (float)a.z_r;
     const float vv[4] = {v0, v1, v2, v3};
-    const float rf[4] = {(float)((rq << 24) >> 24) + zr, (float)((rq << 16) >> 24) + zr, (float)((rq << 8) >> 24) + zr,
-                         (float)(rq >> 24) + zr};
+    const float rf[4] = {(float)((rq << 24) >> 24), (float)((rq << 16) >> 24), (float)((rq << 8) >> 24), (float)(rq >> 24)};   // centred r'
     float t[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float qf = __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)) + zy;
-      const float da = __builtin_fmaf(p.s_y, qf, p.nzs_y);
-      const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
+      const float da = __builtin_fmaf(p.s_y, __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)), p.dl_y);
+      const float db = __builtin_fmaf(a.s_r, rf[i], a.dl_r);
       t[i] = (da + db) * a.inv_s_o;
     }
     *o = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
@@ -1465,6 +1489,7 @@ static int fill_qconv(QConv& p, const int8_t* w, int64_t w_ss, const float* bias
   const int lo = d->relu ? d->z_y : 0, hi = d->a_hi < 255 ? d->a_hi : 255;
   p.vlo = (float)(lo - d->z_y); p.vhi = (float)(hi - d->z_y);
   p.s_y = d->s_y; p.nzs_y = (float)(-d->z_y) * d->s_y;
+  p.dl_y = fmaf(d->s_y, (float)d->z_y, p.nzs_y);
   return QBNN_OK;
 }
 
@@ -1472,6 +1497,7 @@ static int fill_qadd(QAdd& a, const qbnn_conv_desc* d) {
   if (d->z_o < 0 || d->z_o > 127 || d->z_r < 0 || d->z_r > 127)
     return fail(QBNN_E_INVALID, "qbnn conv: add zero points must be in [0,127]%s");
   a.s_r = d->s_r; a.nzs_r = (float)(-d->z_r) * d->s_r; a.z_r = d->z_r;
+  a.dl_r = fmaf(d->s_r, (float)d->z_r, a.nzs_r);
   a.inv_s_o = 1.0f / d->s_o; a.z_o = d->z_o;
   a.vhi = (float)((d->a_hi < 255 ? d->a_hi : 255) - d->z_o);
   return QBNN_OK;
@@ -2515,14 +2541,12 @@ struct EpiDenseTileResGlobal {
   }
   __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
   __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
-    const float zy = (float)p.z_y;
     const float vv[4] = {v0, v1, v2, v3};
     const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
     float t[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float qf = __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)) + zy;
-      const float da = __builtin_fmaf(p.s_y, qf, p.nzs_y);
+      const float da = __builtin_fmaf(p.s_y, __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)), p.dl_y);
       const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
       t[i] = (da + db) * a.inv_s_o;
     }
@@ -2536,6 +2560,12 @@ struct EpiDenseTileResGlobal {
 // -5 %), both of which spill the next item's input prefetch and so put its HBM latency back on the critical path; and two
 // independent 4-wave workgroups per CU (4 images each, 9 KiB slabs) whose M and E phases drift apart on their own: equal
 // time at 96 channels -- overlapping the phases is not what this kernel lacks.
+// Round 2 re-tested that with a full ping-pong kernel (two 4-wave groups in anti-phase sharing ONE weight ring, the E group
+// taking its epilogue in slices between the M group's slab barriers; bit-exact, no spills): 0.399 ms at 96 channels and
+// 0.454 ms at 192 against 0.341 / 0.298 ms here.  The wall is accumulator capacity: the 8 waves' 48 accumulator tiles ARE the
+// item (8 / 16 images); a group that drains its accumulators while the other multiplies halves the images per pass of the
+// block's weights (162 / 663 KiB), and the L2 -> LDS weight stream (3.5 TB/s chip-wide here, 4.7 TB/s there) is what the M
+// phase waits for.  More images per weight pass needs more accumulator registers, not more LDS.
 template <class C, int NWV>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 4, NWV / 4)))
 void block_chain_ald_kernel(const ChainArgs<1> a) {
@@ -2711,6 +2741,7 @@ static int launch_block_chain_ald(const ChainArgs<1>& a, hipStream_t st) {
   hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV>), dim3(grid), dim3(64 * NWV), LDS, st, a);
   return check_launch("qbnn_block_chain_i8_mc");
 }
+
 
 template <class C, int NBLK, bool LDSW = true, bool STEM = false> constexpr int chain_ws_lds() {
   return 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + (LDSW ? 2 * NBLK * WConv<C>::BYTES : 0) + NBLK * 2 * C::COUT * 4 +

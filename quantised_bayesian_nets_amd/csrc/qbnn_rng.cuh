@@ -23,8 +23,9 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    const uint32_t n0 = hi1 ^ c1 ^ k0;
-    const uint32_t n2 = hi0 ^ c3 ^ k1;
+    // three-input xor in one instruction (v_bitop3_b32, truth table 0x96); the compiler emits two v_xor_b32 otherwise
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }

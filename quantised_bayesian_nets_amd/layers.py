@@ -176,6 +176,8 @@ class _BBBInt8(nn.Module):
         self.scale, self.zero_point = float(g("scale")), int(g("zero_point"))
         self.add_weight = QFunctional(g("add_weight.scale"), g("add_weight.zero_point"))
         self.mul_noise = QFunctional(g("mul_noise.scale"), g("mul_noise.zero_point"))
+        if (prefix + "std_prior") in state:          # carried through conversion untouched (conv_q.py:160, linear_q.py:131)
+            self.std_prior.data = torch.from_numpy(np.asarray(state[prefix + "std_prior"], np.float32).reshape(-1).copy())
         self._packed = None
         return self
 

@@ -362,6 +362,16 @@ class Network(nn.Module):
         self._graphs = {}
         return self
 
+    def load_ensemble(self, args, path=None, special_info=""):
+        """reference models_sgld.py:245-261: one checkpoint file per member (`weights_<special><n>.pt` under `path`, natural
+        order, the last `args.samples`), each read like `utils.load_model` (prefixes `module.` / `main_net.` stripped)."""
+        from .checkpoint import ensemble_files, load_state
+        path = args.save if path is None else path
+        self.sample_names = ensemble_files(path, args.samples, special_info)
+        if len(self.sample_names) < len(self.ensemble):
+            raise RuntimeError(f"found {len(self.sample_names)} member checkpoints under {path}, need {len(self.ensemble)}")
+        return self.load_reference_state([load_state(os.path.join(path, n)) for n in self.sample_names])
+
     def _member_forward(self, idx, x, record=None):
         """[1, B, C] probabilities of member `idx`; replays the member's captured launch chain when there is one."""
         from . import layers as _layers

@@ -37,6 +37,7 @@ class FakeQuantize(nn.Module):
         self.last_zero_point = None
 
     def load(self, st, prefix):
+        self._key = prefix                      # where this observer lives in the reference's prepared state dict
         mn, mx = float(np.asarray(st[prefix + ".activation_post_process.min_val"])), float(np.asarray(st[prefix + ".activation_post_process.max_val"]))
         seen = np.isfinite(mn) and np.isfinite(mx)
         self.state = torch.tensor([mn if seen else 0.0, mx if seen else 0.0, 1.0 if seen else 0.0], dtype=torch.float32)
@@ -78,6 +79,19 @@ class FakeQuantize(nn.Module):
 
 def _bounds(args):
     return UINT_BOUNDS[args.activation_precision], INT_BOUNDS[args.weight_precision]
+
+
+def prepared_state(model):
+    """The model's state in the reference's prepared-model vocabulary (the dict it was loaded from), with every observer's
+    (min, max) as it stands NOW -- after the live-observer evaluations run so far.  This is what `convert.convert_model_state`
+    (the reference's quant_utils.convert, :62-99) turns into the int8 model."""
+    st = dict(model._prepared)
+    for m in model.modules():
+        if isinstance(m, FakeQuantize) and getattr(m, "_key", None) is not None:
+            mn, mx = m.min_max()
+            st[m._key + ".activation_post_process.min_val"] = np.float32(mn)
+            st[m._key + ".activation_post_process.max_val"] = np.float32(mx)
+    return st
 
 
 class _QATBBB(nn.Module):
@@ -267,7 +281,11 @@ class ConvNetwork_LeNet(nn.Module):
                     (n + ".activation_post_process", m.activation_post_process)]
         return out
 
+    def prepared_state(self):
+        return prepared_state(self)
+
     def load_reference_state(self, st):
+        self._prepared = st
         self.quant.activation_post_process.load(st, "quant.activation_post_process")
         for n, m in zip(self.stochastic_layer_names(), self.stochastic_layers()):
             m.load(st, n)
@@ -314,7 +332,11 @@ class LinearNetwork(nn.Module):
     def stochastic_layers(self):
         return [self.layers[0], self.layers[2], self.layers[4], self.mu, self.log_var]
 
+    def prepared_state(self):
+        return prepared_state(self)
+
     def load_reference_state(self, st):
+        self._prepared = st
         self.quant.activation_post_process.load(st, "quant.activation_post_process")
         for n, m in zip(self.stochastic_layer_names(), self.stochastic_layers()):
             m.load(st, n)
@@ -388,7 +410,11 @@ class ConvNetwork_ResNet(nn.Module):
         out.append(("layers.9", self.layers[9]))
         return out
 
+    def prepared_state(self):
+        return prepared_state(self)
+
     def load_reference_state(self, st):
+        self._prepared = st
         self.quant.activation_post_process.load(st, "quant.activation_post_process")
         for n, m in self.stochastic_named():
             m.load(st, n)

@@ -6,7 +6,7 @@ ref_shim.py, builds `conv_resnet_bbb`, calibrates it exactly the way the
 reference's training script would (prepare_model -> 1 train-mode + 3 eval-mode
 forwards -> convert, quant_utils.py:62-147), then runs the reference's own int8
 stochastic forward with the weight noise INJECTED from the build's Philox stream
-(oracle.fill_normal), and records:
+(oracle.fill_eps_i8: the int8 mode draws eps_q directly; the injected fp32 eps = eps_q * s_n quantises back to it), and records:
 
   * the converted model's state_dict in flat numpy form (reference key names),
   * the input batch,
@@ -41,7 +41,7 @@ from oracle import oracle as orc  # noqa: E402
 PARAM_SEED, INPUT_SEED, PHILOX_SEED = 1, 2, 3
 
 
-def build_reference_model(a_bits, w_bits, batch):
+def build_reference_model(a_bits, w_bits, batch, before_convert=None):
     from src.models import ModelFactory
     import src.quant_utils as qu
     from src.models.stochastic.bbb.conv import Conv2d as Conv2dBBB
@@ -72,6 +72,8 @@ def build_reference_model(a_bits, w_bits, batch):
     with torch.no_grad():
         for _ in range(3):
             model(x_cal)
+    if before_convert is not None:
+        before_convert(model)          # the prepared (QAT) model, calibrated, right before the reference converts it
     qu.convert(model)
     model.eval()
     return model, args
@@ -98,6 +100,10 @@ class Injector:
     a forward pass (draw order = execution order) returns the build's eps."""
 
     def __init__(self, table_shapes):
+        # the injected eps = (float)eps_q * s_n must come back as eps_q from the reference's own quantize_per_tensor
+        k = np.arange(-128, 128).astype(np.int8)
+        back = torch.quantize_per_tensor(torch.from_numpy(orc.eps_from_eps_q(k)), orc.NOISE_SCALE, 0, torch.qint8).int_repr().numpy()
+        assert np.array_equal(back, k), "eps_q -> eps -> quantize_per_tensor is not the identity"
         self.shapes = table_shapes
         self.queue = None
         self.orig = torch.Tensor.normal_
@@ -106,7 +112,7 @@ class Injector:
         self.queue = []
         for lid, shp in enumerate(self.shapes):
             n = int(np.prod(shp))
-            e = orc.fill_normal(n, seed, lid, sample)
+            e = orc.fill_eps_i8(n, seed, lid, sample)        # int8 noise stream: (float)eps_q * s_n, eps_q from the alias sampler
             if len(shp) == 4:   # our stream is defined on the OHWI flattening
                 o, i, kh, kw = shp
                 e = e.reshape(o, kh, kw, i).transpose(0, 3, 1, 2)

@@ -114,6 +114,13 @@ def main():
     path = os.path.join(HERE, "ensemble_resnet_a7w8.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) / 1e6, "MB")
+    # one checkpoint file per member, as an SGHMC run leaves them (src/utils.py:84-93 saves the converted copy of the training
+    # wrapper, whose single net is `main_net`; models_sgld.py:245-261 finds `weights_<n>.pt` and src/utils.py:112-123 strips the prefix)
+    ck = os.path.join(HERE, "ensemble_ckpt")
+    os.makedirs(ck, exist_ok=True)
+    for i, mem in enumerate(net.ensemble):
+        torch.save({"main_net." + k: v for k, v in mem.state_dict().items()}, os.path.join(ck, f"weights_{i + 1}.pt"))
+    print("wrote", ck, [round(os.path.getsize(os.path.join(ck, f)) / 1e6, 2) for f in sorted(os.listdir(ck))], "MB")
 
 
 if __name__ == "__main__":

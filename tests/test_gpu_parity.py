@@ -67,7 +67,7 @@ def test_sampler_injected_eps_equals_philox(golden_w8):
     m = _model(golden_w8)
     for layer in (m.layers[0], m.layers[4][0].shortcut[0], m.layers[6][1].stem[3], m.layers[9]):
         n = int(np.prod(layer.weight.shape))
-        eps = np.stack([orc.fill_normal(n, 11, layer.layer_id, s) for s in (5, 6)])
+        eps = np.stack([orc.fill_eps_i8(n, 11, layer.layer_id, s) for s in (5, 6)])
         a = layer.sample_weights("cuda", samples=2, seed=11, sample_begin=5)
         b = layer.sample_weights("cuda", samples=2, seed=0, sample_begin=0, eps=torch.from_numpy(eps))
         assert torch.equal(a, b)

@@ -69,7 +69,7 @@ def test_mc_reduction_matches_reference(golden):
 def test_injected_eps_equals_philox_path(golden_w8):
     g = golden_w8
     net = orc.Int8ResNetOracle(g["state"], 7, 8)
-    eps = {pfx: orc.fill_normal(net.layers[pfx].mu_q.size, 3, i, 1).reshape(net.layers[pfx].mu_q.shape)
+    eps = {pfx: orc.fill_eps_i8(net.layers[pfx].mu_q.size, 3, i, 1).reshape(net.layers[pfx].mu_q.shape)
            for i, (pfx, *_) in enumerate(net.table)}
     a = net.forward(g["x"], 3, 1, eps=eps)
     b = net.forward(g["x"], 3, 1)
@@ -215,7 +215,7 @@ def test_fbgemm_harness_matches_golden(golden):
     net = orc.Int8ResNetOracle(golden["state"], golden["meta"]["a_bits"], wb)
     fb = FbgemmResNetBBB(golden["state"], golden["meta"]["a_bits"], wb)
     for s in range(golden["probs"].shape[0]):
-        eps = {pfx: orc.fill_normal(net.layers[pfx].mu_q.size, seed, i, s).reshape(net.layers[pfx].mu_q.shape)
+        eps = {pfx: orc.fill_eps_i8(net.layers[pfx].mu_q.size, seed, i, s).reshape(net.layers[pfx].mu_q.shape)
                for i, (pfx, *_) in enumerate(net.table)}
         rec = {}
         p = fb.forward(golden["x"], eps, record=rec)
@@ -224,3 +224,46 @@ def test_fbgemm_harness_matches_golden(golden):
             for k in ("layers.3.0.out", "layers.4.0.out", "layers.6.1.out"):
                 if k in golden["rec"]:
                     assert np.array_equal(rec[k], golden["rec"][k]), k
+
+
+def test_int8_noise_stream_alias_sampler():
+    """The int8 mode draws eps_q directly (oracle: qbo_fill_eps_q; GPU: eps_q_from_u32) through the alias table of
+    clamp(rne(N(0,1) / s_n), -128, 127) -- the distribution of the reference's quantised noise (conv_q.py:113-115)."""
+    import math
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = open(os.path.join(root, "oracle", "qbnn_eps_table.h")).read()
+    b = open(os.path.join(root, "quantised_bayesian_nets_amd", "csrc", "qbnn_eps_table.h")).read()
+    assert a == b                                                   # oracle and kernels read the same committed data
+    words = [int(w, 16) for w in re.findall(r"0x([0-9a-f]{8})u", a)]
+    assert len(words) == 256
+    # implied probabilities of the table vs the analytic ones (independent of the generator's alias construction)
+    s = np.float32(orc.NOISE_SCALE)
+    inv = float(np.float32(1.0) / s)
+    phi = lambda x: 0.5 * math.erfc(-x / math.sqrt(2.0))
+    p = np.array([(1.0 if k == 127 else phi((k + 0.5) / inv)) - (0.0 if k == -128 else phi((k - 0.5) / inv)) for k in range(-128, 128)])
+    num = np.zeros(256, np.int64)
+    for c, w in enumerate(words):
+        num[c] += w >> 8
+        num[w & 0xff] += (1 << 24) - (w >> 8)
+    assert num.sum() == 1 << 32
+    assert np.abs(num / float(1 << 32) - p).max() < 2.0 ** -30
+    # the stream: empirical moments of 4M draws match the discrete distribution; keyed by (seed, layer, sample); ragged prefix
+    e = orc.fill_eps_q(1 << 22, 3, 5, 7)
+    k = np.arange(-128, 128)
+    mean, var = (p * k).sum(), (p * k * k).sum() - (p * k).sum() ** 2
+    assert abs(e.astype(np.float64).mean() - mean) < 5 * math.sqrt(var / e.size)
+    assert abs(e.astype(np.float64).var() - var) < 0.01 * var
+    hist = np.bincount(e.astype(np.int64) + 128, minlength=256) / e.size
+    assert np.abs(hist - p).max() < 5 * math.sqrt(p.max() / e.size)
+    assert hist[0] > 0 and hist[255] > 0                           # the folded tails occur (|eps| > 3)
+    assert np.array_equal(orc.fill_eps_q(1003, 3, 5, 7), e[:1003])
+    assert not np.array_equal(orc.fill_eps_q(64, 3, 5, 8), e[:64]) and not np.array_equal(orc.fill_eps_q(64, 3, 6, 7), e[:64])
+    assert not np.array_equal(orc.fill_eps_q(64, 4, 5, 7), e[:64])
+    # injection contract: (float)eps_q * s_n comes back as eps_q from the reference's quantisation formula and from torch's op
+    kk = np.arange(-128, 128).astype(np.int8)
+    assert np.array_equal(orc.quantize_eps(orc.eps_from_eps_q(kk)), kk)
+    import torch
+    back = torch.quantize_per_tensor(torch.from_numpy(orc.eps_from_eps_q(kk)), orc.NOISE_SCALE, 0, torch.qint8).int_repr().numpy()
+    assert np.array_equal(back, kk)

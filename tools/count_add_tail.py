@@ -46,7 +46,7 @@ def main():
     worst_p = 0.0
     n_prob_diff = 0
     for s in range(a.samples):
-        eps = {pfx: orc.fill_normal(net.layers[pfx].mu_q.size, seed, i, s).reshape(net.layers[pfx].mu_q.shape)
+        eps = {pfx: orc.fill_eps_i8(net.layers[pfx].mu_q.size, seed, i, s).reshape(net.layers[pfx].mu_q.shape)
                for i, (pfx, *_) in enumerate(net.table)}
         rec = {}
         p_at = fb.forward(x, eps, record=rec)

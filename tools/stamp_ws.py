@@ -1,5 +1,5 @@
 import sys, os, types, time, ctypes as C, numpy as np, torch
-os.environ["QBNN_LIB_OVERRIDE"] = os.path.abspath("scratch/libqbnn_STAMP0.so")
+os.environ["QBNN_LIB_OVERRIDE"] = os.path.abspath(os.environ.get("QBNN_STAMP_LIB", "tools/_build/libqbnn_STAMP0.so"))
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 from conftest import load_golden
 import quantised_bayesian_nets_amd as q
