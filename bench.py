@@ -32,6 +32,8 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_I8_PEAK_TOPS = 5000.0   # int8 dense = 2x bf16 (2.5 PF)
+VALU_PEAK_LANE_OPS = 1024 * 16 * 2.4e9   # 256 CUs x 4 SIMDs, 16 lanes per cycle, 2.4 GHz
+VALU_OPS_PLAIN, VALU_OPS_RES = 6, 13     # epilogue lane-ops per output element in the shipped ISA (profiles/r02_isa_epilogue.txt)
 MFMA_I8_SUSTAINED_TOPS = 3260.0   # measured: pure v_mfma_i32_32x32x32_i8 loop on random int8 operands, whole chip
                                   # (tools/mfma_sustained.hip, profiles/r01_mfma_sustained.txt; 4700 on all-zero operands)
 
@@ -46,6 +48,80 @@ def conv_algorithmic_bytes(S, B, H, Cin, Cout, ks, stride, nweights):
 def conv_ops(S, B, H, Cin, Cout, ks, stride):
     Ho = H // stride
     return 2 * S * B * Ho * Ho * Cout * Cin * ks * ks
+
+
+def kernel_source_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("qbnn_kernels.hip", "qbnn_rng.cuh", "qbnn_eps_table.h"):
+        h.update(open(os.path.join(ROOT, "quantised_bayesian_nets_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _wl_resnet(w_bits, samples_default, tag):
+    def build(a, world, q, load_golden):
+        wb = w_bits or a.w_bits
+        g = load_golden(f"resnet_bbb_a7w{wb}.npz")   # random-init, calibrated, converted int8 conv_resnet_bbb (recorded from the reference)
+        args = types.SimpleNamespace(activation_precision=7, weight_precision=wb)
+        a.w_bits = wb
+        model = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args).load_reference_state(g["state"])
+        S = a.samples if a.samples > 0 else samples_default
+        x_host = torch.randn(a.batch, 3, 32, 32, generator=torch.Generator().manual_seed(2))     # synthetic CIFAR-shaped, normalised
+        return dict(golden=g, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=True, cpu_baseline=True,
+                    step=lambda m, x, S_, seed: q.mc_predict(m, x, S_, seed, return_var=True), scaling="weak", dtype="int8",
+                    metric="MC forward samples/sec, ResNet-18 BBB int8 batch=256", unit="MC samples/s",
+                    describe="%s: CIFAR-10-shaped ResNet-18 (24/48/96/192) Bayes-by-backprop, A7/W%d int8, %d MC samples per GPU per step, "
+                             "batch=%d" % (tag, wb, S, a.batch))
+    return build
+
+
+def _wl_ensemble16(a, world, q, load_golden):
+    """BASELINE configs[3]: 16 SGHMC members (deterministic int8 ResNets), members = the MC samples, sharded over the ranks (strong scaling)."""
+    from conftest import synth_ensemble_members
+    d = np.load(os.path.join(ROOT, "tests", "golden", "ensemble_resnet_a7w8.npz"))
+    n0 = int(d["meta.members"])
+    ge = dict(members=[{k[len(f"member{i}/"):]: d[k] for k in d.files if k.startswith(f"member{i}/")} for i in range(n0)])
+    n = 16
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, model="conv_resnet_sgld", samples=n)
+    model = q.ModelFactory.get_model("conv_resnet_sgld", [1, 3, 32, 32], 10, True, args, training_mode=False).load_reference_state(synth_ensemble_members(ge, n))
+    x_host = torch.randn(a.batch, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+    return dict(golden=None, model=model, x_host=x_host, units_per_gpu=n // world, units_global=n, resnet=False, cpu_baseline=False,
+                step=lambda m, x, S_, seed: q.mc_predict(m, x, S_, 0), scaling="strong", dtype="int8",
+                metric="ensemble member forwards/sec, ResNet-18 SGHMC 16-member int8 batch=256", unit="member forwards/s",
+                describe="configs[3]: CIFAR-10-shaped ResNet-18 SGHMC ensemble, 16 deterministic int8 members (2 recorded from the reference + 14 "
+                         "deterministic perturbations), batch=%d, members sharded over the ranks" % a.batch)
+
+
+def _wl_lenet_mc(a, world, q, load_golden):
+    """BASELINE configs[1]: MNIST-shaped LeNet MC-Dropout A7/W8, 100 MC samples, batch 128."""
+    g = load_golden("lenet_mc_a7w8.npz")
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=0.2)
+    model = q.ModelFactory.get_model("conv_lenet_mc", [1, 1, 28, 28], 10, True, args).load_reference_state(g["state"])
+    S = a.samples if a.samples > 0 else 100
+    B = 128 if a.batch == 256 else a.batch
+    x_host = torch.rand(B, 1, 28, 28, generator=torch.Generator().manual_seed(2))
+    return dict(golden=g, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=False, cpu_baseline=False,
+                step=lambda m, x, S_, seed: q.mc_predict(m, x, S_, seed), scaling="weak", dtype="int8",
+                metric="MC forward samples/sec, LeNet MC-Dropout int8 batch=128", unit="MC samples/s",
+                describe="configs[1]: MNIST-shaped LeNet MC-Dropout (p=0.2), A7/W8 int8, %d MC samples per GPU per step, batch=%d" % (S, B))
+
+
+def _wl_mlp_f32(a, world, q, load_golden):
+    """BASELINE configs[0]: UCI-regression-shaped 4x100 MLP, Bayes-by-backprop fp32, 10 MC samples, 1000 rows."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "mlp_bbb_f32.npz"))
+    st = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    in_dim = int(d["meta.in_dim"])
+    model = q.ModelFactory.get_model("linear_bbb", [in_dim], 1, False, types.SimpleNamespace(sigma_prior=-2.0)).load_reference_state(st)
+    S = a.samples if a.samples > 0 else 10
+    x_host = torch.randn(1000, in_dim, generator=torch.Generator().manual_seed(2))
+    return dict(golden=None, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=False, cpu_baseline=False,
+                step=lambda m, x, S_, seed: q.mc_predict_regression(m, x, S_, seed), scaling="weak", dtype="f32",
+                metric="MC forward samples/sec, 4x100 MLP BBB fp32, 1000 rows", unit="MC samples/s",
+                describe="configs[0]: UCI-regression-shaped (in_dim %d) 4x100 MLP Bayes-by-backprop fp32, %d MC samples per GPU per step, 1000 rows" % (in_dim, S))
+
+
+WORKLOADS = {"resnet_bbb": _wl_resnet(0, 100, "configs[2]"), "resnet_bbb_w4": _wl_resnet(4, 128, "configs[4] (A7/W4, 1024 samples over 8 GPUs = 128 per GPU)"),
+             "ensemble16": _wl_ensemble16, "lenet_mc": _wl_lenet_mc, "mlp_f32": _wl_mlp_f32}
 
 
 def cpu_baseline(a, g, x_host, seed):
@@ -106,9 +182,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--samples", type=int, default=100, help="MC samples per GPU per step (BASELINE config 3: 100)")
+    ap.add_argument("--samples", type=int, default=0, help="MC samples per GPU per step (0 = the workload's own: 100 for resnet_bbb, BASELINE configs[2])")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--w-bits", type=int, default=8)
+    ap.add_argument("--workload", default="resnet_bbb", choices=sorted(WORKLOADS),
+                    help="resnet_bbb = BASELINE.json's metric (default); the others are BASELINE.json's remaining configs")
     ap.add_argument("--prime", type=int, default=12, help="setup steps before the W warm-up steps (clock ramp, allocator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=0, help="oracle samples to time (0 = auto, about 10-30 s)")
@@ -142,16 +220,13 @@ def main():
     from quantised_bayesian_nets_amd import layers as qlayers
     from conftest import load_golden
 
-    g = load_golden(f"resnet_bbb_a7w{a.w_bits}.npz")   # random-init, calibrated, converted int8 conv_resnet_bbb
-    args = types.SimpleNamespace(activation_precision=7, weight_precision=a.w_bits)
-    model = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args).load_reference_state(g["state"])
-    gen = torch.Generator().manual_seed(2)
-    x_host = torch.randn(a.batch, 3, 32, 32, generator=gen)     # synthetic CIFAR-shaped, normalised
+    wl = WORKLOADS[a.workload](a, world, q, load_golden)
+    g, model, x_host, step_fn = wl["golden"], wl["model"], wl["x_host"], wl["step"]
     x = x_host.cuda()
-    S_local, S_global, seed = a.samples, a.samples * world, 3
+    S_local, S_global, seed = wl["units_per_gpu"], wl["units_global"], 3
 
     def step():
-        return q.mc_predict(model, x, S_global, seed, return_var=True)
+        return step_fn(model, x, S_global, seed)
 
     def fence():
         if use_dist:
@@ -172,7 +247,7 @@ def main():
     qlayers.PROFILE = prof = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        mean, var = step()
+        step()
     fence()
     dt = time.perf_counter() - t0
     qlayers.PROFILE = None
@@ -195,17 +270,36 @@ def main():
         d = agg[dom]
         m = d["meta"]
         avg_s = d["ms"] / d["n"] * 1e-3
-        abytes = sum(conv_algorithmic_bytes(S_local, a.batch, H, ci, co, ks, st, nw) for (H, ci, co, ks, st, nw) in m["convs"])
-        ops = sum(conv_ops(S_local, a.batch, H, ci, co, ks, st) for (H, ci, co, ks, st, nw) in m["convs"])
+        Bx = x_host.shape[0]
+        abytes = sum(conv_algorithmic_bytes(S_local, Bx, H, ci, co, ks, st, nw) for (H, ci, co, ks, st, nw) in m["convs"])
+        ops = sum(conv_ops(S_local, Bx, H, ci, co, ks, st) for (H, ci, co, ks, st, nw) in m["convs"])
         gbs, tops = abytes / avg_s / 1e9, ops / avg_s / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and S_local == 100 and a.batch == 256:
-            # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE; see that file's note)
-            traffic = json.load(open(tpath))["by_bench_key"].get(dom)
+        # HBM bytes per launch: PMC counters need rocprofv3, so they come from the committed passes of tools/profile_round.sh
+        # (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs) -- but ONLY while that file was measured on this very kernel source
+        # and workload shape; otherwise null (never a stale number)
+        traffic, traffic_note = None, "no PMC summary for this kernel source: run tools/profile_round.sh"
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("kernel_source_sha16") != kernel_source_sha16():
+                traffic_note = "profiles/r02_pmc_traffic.json was measured on an older kernel source"
+            elif (tj.get("samples"), tj.get("batch"), tj.get("workload")) != (S_local, x_host.shape[0], a.workload):
+                traffic_note = "profiles/r02_pmc_traffic.json was measured on another workload shape"
+            else:
+                traffic, traffic_note = tj["by_bench_key"].get(dom), "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this source)"
+        # vector-ALU roof of the exact-arithmetic epilogue: lane-operations per output element counted in the shipped ISA
+        # (profiles/r02_isa_epilogue.txt): 6 for a plain requantisation (sub, cvt, fma, mul, min, cvt_pk), 13 for stem.3 +
+        # quantized::add + ReLU; 1024 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s
+        outs = [S_local * Bx * (H // st) ** 2 * co for (H, ci, co, ks, st, nw) in m["convs"]]
+        n_res = sum(1 for i, c in enumerate(m["convs"]) if m.get("res_convs") and i in m["res_convs"])
+        lane_ops = sum(o * (VALU_OPS_RES if (m.get("res_convs") and i in m["res_convs"]) else VALU_OPS_PLAIN) for i, o in enumerate(outs))
+        valu = {"epilogue_lane_ops_per_launch": lane_ops, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "floor_ms": round(lane_ops / VALU_PEAK_LANE_OPS * 1e3, 4),
+                "frac": round(lane_ops / VALU_PEAK_LANE_OPS / avg_s, 4), "ops_per_output": {"requant": VALU_OPS_PLAIN, "requant+add+relu": VALU_OPS_RES},
+                "residual_convs": n_res}
         common = {"kernel": dom, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": d["n"],
                   "share_of_step_time": round(d["ms"] / (dt * 1e3), 3), "convs_in_launch": len(m["convs"]),
-                  "algorithmic_bytes_per_launch": abytes, "algorithmic_ops_per_launch": ops, "traffic": traffic}
+                  "algorithmic_bytes_per_launch": abytes, "algorithmic_ops_per_launch": ops, "traffic": traffic, "traffic_source": traffic_note,
+                  "valu": valu}
         if m["fused"]:
             # fused block kernels keep activations in LDS: their HBM traffic is a fraction of the layer-granular byte
             # model, the binding roof is the int8 matrix pipe
@@ -220,23 +314,25 @@ def main():
 
     # ---- whole-path roofline view (layer-granular byte model of SURVEY 8(d): 126.66 MB / sample at B=256, int8)
     value = S_global * a.steps / dt
-    bytes_per_sample = 126.66e6 * a.batch / 256
-    path = {"algorithmic_GBps_per_gpu": round(value / world * bytes_per_sample / 1e9, 1),
-            "frac_of_hbm_peak": round(value / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4),
-            "int8_TOPS_per_gpu": round(value / world * 40.203e9 * a.batch / 256 / 1e12, 1)}
+    path = None
+    if wl["resnet"]:
+        bytes_per_sample = 126.66e6 * a.batch / 256
+        path = {"algorithmic_GBps_per_gpu": round(value / world * bytes_per_sample / 1e9, 1),
+                "frac_of_hbm_peak": round(value / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4),
+                "int8_TOPS_per_gpu": round(value / world * 40.203e9 * a.batch / 256 / 1e12, 1)}
 
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and not a.no_cpu_baseline and wl["cpu_baseline"]:
         cpu = cpu_baseline(a, g, x_host, seed)
         # the oracle's sample 0 doubles as an in-run parity check of the GPU result
         with q.mc_context(1, seed, 0):
-            p_gpu = model.forward_mc(x)[0].cpu().numpy()
+            p_gpu = model.forward_mc(x)[0].cpu().numpy()         # (resnet workloads only)
         cpu["gpu_matches_oracle_sample0"] = bool(np.allclose(p_gpu, cpu.pop("_p_oracle_sample0"), rtol=1e-5, atol=1e-8))
 
     rccl = None
     if use_dist:
-        # the path's one collective in isolation: sum all-reduce of the [2, B, C] fp32 moments (20 KB), RCCL over xGMI
-        mom = torch.zeros((2, a.batch, 10), dtype=torch.float32, device="cuda")
+        # the path's one collective in isolation: sum all-reduce of the [2, B, C] fp64 moments (40 KB), RCCL over xGMI
+        mom = torch.zeros((2, a.batch, 10), dtype=torch.float64, device="cuda")
         for _ in range(5):
             dist.all_reduce(mom)
         torch.cuda.synchronize()
@@ -244,17 +340,15 @@ def main():
         for _ in range(50):
             dist.all_reduce(mom)
         torch.cuda.synchronize()
-        rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_bytes": mom.numel() * 4,
+        rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_bytes": mom.numel() * 8,
                 "allreduce_us": round((time.perf_counter() - t) / 50 * 1e6, 1), "collectives_per_step": 1}
 
     if rank == 0:
-        out = {"metric": "MC forward samples/sec, ResNet-18 BBB int8 batch=256", "value": round(value, 2), "unit": "MC samples/s",
+        out = {"metric": wl["metric"], "value": round(value, 2), "unit": wl["unit"],
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-               "config": {"workload": "configs[2]: CIFAR-10-shaped ResNet-18 (24/48/96/192) Bayes-by-backprop, A7/W%d int8, "
-                                      "%d MC samples per GPU per step, batch=%d" % (a.w_bits, S_local, a.batch),
-                          "samples_per_gpu": S_local, "global_samples": S_global, "batch": a.batch,
-                          "image_samples_per_s": round(value * a.batch, 1), "parallelism": f"mc-sample-shard x{world}"},
+               "higher_is_better": True, "scaling": wl["scaling"], "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
+               "config": {"workload": wl["describe"], "samples_per_gpu": S_local, "global_samples": S_global, "batch": x_host.shape[0],
+                          "image_samples_per_s": round(value * x_host.shape[0], 1), "parallelism": f"mc-sample-shard x{world}"},
                "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "rccl": rccl, "rccl_ranks": world if use_dist else 0,
                "kernels": kernels}
         print(json.dumps(out))

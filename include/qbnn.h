@@ -334,6 +334,11 @@ int qbnn_fake_quant_f32_mc(const float* x, int64_t x_sample_stride, float* y, in
  * :381-383).  Writes ceil(B/256) rows of 34 partial sums (layout: csrc/qbnn_kernels.hip); the caller adds the rows. */
 int qbnn_classification_metrics(const float* probs, const int64_t* target, int32_t B, int32_t C, float* partials, void* stream);
 
+/* Regression metrics on the reduced MC output (reference src/metrics.py:119-230, RegressionMetric.update :468-500):
+ * per block of 256 rows, partials[blk][0..2] = sum of the Gaussian NLL 0.5 log(2 pi var + 1e-8) + (t - mean)^2 / (2 var + 1e-8),
+ * of the squared error and of the absolute error.  var == NULL: variance 1 (a mean-only model, :154). */
+int qbnn_regression_metrics(const float* mean, const float* var, const float* target, int32_t B, float* partials, void* stream);
+
 const char* qbnn_last_error(void);
 int qbnn_version(void);
 

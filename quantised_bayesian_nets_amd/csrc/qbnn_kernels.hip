@@ -3722,6 +3722,38 @@ QBNN_EXPORT int qbnn_classification_metrics(const float* probs, const int64_t* t
   return check_launch("qbnn_classification_metrics");
 }
 
+// Regression metrics on the reduced MC output (reference src/metrics.py:119-230 fed by RegressionMetric.update :468-500):
+//   partial sums per 256-row block of   nll = 0.5 log(2 pi var + 1e-8) + (t - mean)^2 / (2 var + 1e-8)   (:143),
+//   squared error (:186), absolute error (:224).  Accumulated in fp64 by the caller.
+__global__ __launch_bounds__(256) void regression_metrics_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                                                  const float* __restrict__ target, int B, float* __restrict__ partials) {
+  __shared__ float red[3][4];
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  float v[3] = {0.f, 0.f, 0.f};
+  if (b < B) {
+    const float m = mean[b], vr = var ? var[b] : 1.0f, t = target[b];
+    const float d = t - m;
+    v[0] = 0.5f * logf(2.0f * 3.14159265358979323846f * vr + 1e-8f) + d * d / (2.0f * vr + 1e-8f);
+    v[1] = d * d;
+    v[2] = fabsf(d);
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float x = v[i];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if (lane == 0) red[i][wave] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) partials[(int64_t)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+QBNN_EXPORT int qbnn_regression_metrics(const float* mean, const float* var, const float* target, int32_t B, float* partials, void* stream) {
+  if (!mean || !target || !partials || B <= 0) return fail(QBNN_E_INVALID, "qbnn_regression_metrics: bad argument%s");
+  hipLaunchKernelGGL(regression_metrics_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, var, target, B, partials);
+  return check_launch("qbnn_regression_metrics");
+}
+
 // Flatten (reference src/utils.py:40-47) of a channels-last activation into the reference's NCHW feature order:
 // x [S][B][HW][C] -> y [S][B][C*HW], y[c * HW + p] = x[p * C + c].  Needed where a stochastic Linear follows a conv map:
 // its noise stream is indexed by the reference's (c, h, w) column order.

@@ -96,6 +96,39 @@ class MCQTensor:
         return (self.data.to(torch.float32) - float(self.zero_point)) * np.float32(self.scale)
 
 
+# ---- the reference's own tensor type at the layer seam ---------------------------------------------------------------
+def is_torch_quantized(x):
+    return isinstance(x, torch.Tensor) and x.is_quantized
+
+
+def mcq_from_torch(x):
+    """torch quint8 tensor as the reference's layers pass it (NCHW-logical `(N, C, H, W)`, or `(N, F)`; conv_q.py:107-125,
+    linear_q.py:80-94) -> MCQTensor of ONE sample on the GPU ([1, N, H, W, C] / [1, N, F] uint8, channels-last).
+    A CPU tensor (where the reference keeps its int8 model) is uploaded: the arithmetic itself only exists on the MI355X."""
+    if x.dtype != torch.quint8:
+        raise TypeError("expected a quint8 activation tensor")
+    if x.qscheme() not in (torch.per_tensor_affine, torch.per_tensor_symmetric):
+        raise RuntimeError("Unsupported qscheme: activations are quantised per tensor")
+    if not torch.cuda.is_available():
+        raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
+    q = x.int_repr().to("cuda")
+    if q.dim() == 4:
+        q = q.permute(0, 2, 3, 1)
+    elif q.dim() != 2:
+        raise ValueError("Input shape must be `(N, C, H, W)` or `(N, F)`!")
+    return MCQTensor(q.contiguous().unsqueeze(0), x.q_scale(), x.q_zero_point())
+
+
+def torch_from_mcq(y, device):
+    """MCQTensor holding one sample -> torch quint8 tensor in the reference's layout, on `device` (where the input lived)."""
+    if y.data.shape[0] != 1:
+        raise RuntimeError("a torch quantised tensor carries one MC sample: call the layer under mc_context(samples=1)")
+    q = y.data[0]
+    if q.dim() == 4:
+        q = q.permute(0, 3, 1, 2)
+    return torch._make_per_tensor_quantized_tensor(q.contiguous().to(device), y.scale, y.zero_point)
+
+
 class QFunctional:
     """Stand-in for torch.nn.quantized.QFunctional: only the (scale, zero_point) the reference reads."""
 
@@ -316,7 +349,17 @@ class Conv2d(_BBBInt8):
         return 'QuantizedConv2d'
 
     def forward(self, x, residual=None, add_qparams=None):
-        """x: MCQTensor.  residual/add_qparams: fuse `Add` + ReLU of BasicBlock (models_bbb.py:179-182)."""
+        """x: MCQTensor (S samples at once), or -- the reference's own call contract, conv_q.py:107-125 -- a torch quint8
+        `(N, C, H, W)` tensor: then ONE stochastic forward (the mc_context's first sample) and a torch quint8 tensor back, so
+        the layer can sit inside the reference's own graph (`clamp_activation(layer(x))`, models_bbb.py:229-238).
+        residual/add_qparams: fuse `Add` + ReLU of BasicBlock (models_bbb.py:179-182)."""
+        if is_torch_quantized(x):
+            if len(x.shape) != 4:
+                raise ValueError("Input shape must be `(N, C, H, W)`!")
+            if residual is not None:
+                raise NotImplementedError("the fused residual takes MCQTensor operands")
+            with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
+                return torch_from_mcq(self.forward(mcq_from_torch(x)), x.device)
         if x.data.dim() != 5:
             raise ValueError("Input shape must be `(S, N, H, W, C)`!")
         dev = x.data.device
@@ -324,7 +367,17 @@ class Conv2d(_BBBInt8):
             raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
         S = _MC.samples
         w = self.sample_weights(dev)
-        return self._conv(x, w, S, residual, add_qparams)
+        im2col = None
+        if self.layout == LAYOUT_MFMA32 and self.in_channels == 3 and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1):
+            # the network's first conv runs on the pre-gathered 27-tap patches (K = 27 -> 32), as in ConvNetwork_ResNet.forward_mc
+            _, B, H, W, _c = x.data.shape
+            im2col = torch.empty((B, H * W, 32), dtype=torch.int8, device=dev)
+            src = x.data if x.data.shape[0] == 1 else None
+            if src is None:
+                raise NotImplementedError("a 3-channel first conv takes an input shared by the samples")
+            with timed("im2col3x3_c3"):
+                _lib.check(_lib.lib().qbnn_im2col3x3_c3(_lib.ptr(src), B, H, W, x.zero_point, _lib.ptr(im2col), _stream()))
+        return self._conv(x, w, S, residual, add_qparams, im2col=im2col)
 
     def _generic(self, x, w, S, H, W, Cin, Cout, ks, st, pd, out_shape):
         """Any-geometry path (qbnn_conv2d_i8_generic_mc) with per-sample row-major sampled weights: the small nets
@@ -421,7 +474,11 @@ class Linear(_BBBInt8):
 
     def forward(self, x):
         """reference linear_q.Linear.forward (linear_q.py:80-94) / LinearReLU.forward (:154-173) for S samples:
-        x MCQTensor [S or 1, B, in_features] -> [S, B, out_features]."""
+        x MCQTensor [S or 1, B, in_features] -> [S, B, out_features]; or a torch quint8 `(N, in_features)` tensor -> one
+        stochastic forward, torch quint8 `(N, out_features)` back (the reference's call contract)."""
+        if is_torch_quantized(x):
+            with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
+                return torch_from_mcq(self.forward(mcq_from_torch(x)), x.device)
         d = x.data
         if d.device.type != "cuda":
             raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")

@@ -87,7 +87,8 @@ def run_down_block(blk, x):
     y = torch.empty((S, B, H // 2, W // 2, Cout), dtype=torch.uint8, device=dev)
     a_hi = UINT_BOUNDS[blk.args.activation_precision][1]
     nw = lambda l: l._packed["cout"] * l._packed["k"]
-    meta = dict(fused=True, convs=[(H, Cin, Cout, 3, 2, nw(blk.stem[0])), (H, Cin, Cout, 1, 2, nw(cs)), (H // 2, Cout, Cout, 3, 1, nw(blk.stem[3]))])
+    meta = dict(fused=True, convs=[(H, Cin, Cout, 3, 2, nw(blk.stem[0])), (H, Cin, Cout, 1, 2, nw(cs)), (H // 2, Cout, Cout, 3, 1, nw(blk.stem[3]))],
+                res_convs=[2])          # stem.3 carries the Add + ReLU epilogue
     with timed("block_down_i8 %dx%d %d->%d" % (H, W, Cin, Cout), meta):
         _lib.check(_lib.lib().qbnn_block_down_i8_mc(_lib.ptr(x.data), x.sample_stride(), x.scale, x.zero_point, B, H, Cin, a_hi,
                                                     C.byref(d), _lib.ptr(y), y[0].numel(), S, _lib.current_stream()))
@@ -146,7 +147,8 @@ def run_identity_chain(blocks, x, stem=None):
         pk0 = l0._ensure_packed(dev)
         y = torch.empty((S, B, H, W, Cc), dtype=torch.uint8, device=dev)
         key = "stem + block_chain_i8 x%d %dx%d c%d" % (len(blocks), H, W, Cc)
-        meta = dict(fused=True, convs=[(H, 3, Cc, 3, 1, nw(l0))] + [(H, Cc, Cc, 3, 1, nw(c)) for b in blocks for c in (b.stem[0], b.stem[3])])
+        meta = dict(fused=True, convs=[(H, 3, Cc, 3, 1, nw(l0))] + [(H, Cc, Cc, 3, 1, nw(c)) for b in blocks for c in (b.stem[0], b.stem[3])],
+                    res_convs=[2 + 2 * i for i in range(len(blocks))])
         with timed(key, meta):
             _lib.check(_lib.lib().qbnn_stem_chain_i8_mc(_lib.ptr(col), B, _lib.ptr(w0), w0.shape[1], _lib.ptr(pk0["bias"]), s_in,
                                                         l0.add_weight.scale, l0.add_weight.zero_point, l0.scale, l0.zero_point, a_hi,
@@ -156,7 +158,8 @@ def run_identity_chain(blocks, x, stem=None):
     _, B, H, W, Cc = x.data.shape
     y = torch.empty((S, B, H, W, Cc), dtype=torch.uint8, device=dev)
     key = "block_chain_i8 x%d %dx%d c%d" % (len(blocks), H, W, Cc)
-    meta = dict(fused=True, convs=[(H, Cc, Cc, 3, 1, nw(c)) for b in blocks for c in (b.stem[0], b.stem[3])])
+    meta = dict(fused=True, convs=[(H, Cc, Cc, 3, 1, nw(c)) for b in blocks for c in (b.stem[0], b.stem[3])],
+                res_convs=[1 + 2 * i for i in range(len(blocks))])
     with timed(key, meta):
         _lib.check(_lib.lib().qbnn_block_chain_i8_mc(_lib.ptr(x.data), x.sample_stride(), x.scale, x.zero_point, B, H, Cc, a_hi,
                                                      descs, len(blocks), _lib.ptr(y), y[0].numel(), S, _lib.current_stream()))

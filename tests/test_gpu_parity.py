@@ -381,6 +381,35 @@ def test_classification_metrics_match_reference_formulas():
     assert abs(m.ece - float(ece)) < 1e-5
 
 
+def test_regression_metrics_match_reference_formulas(golden_mlp_f32):
+    """src/metrics.py:119-230 (Gaussian NLL with its 1e-8 guards, MSE / RMSE, MAE) evaluated with torch on the CPU -- the
+    reference's literal expressions -- vs the device kernel, on the MC-reduced (mean, variance) of the fp32 BBB MLP."""
+    import math
+    import torch.nn.functional as F
+    import quantised_bayesian_nets_amd as q
+    g = golden_mlp_f32
+    m = q.ModelFactory.get_model("linear_bbb", [g["in_dim"]], 1, False, types.SimpleNamespace(sigma_prior=-2.0)).load_reference_state(g["state"])
+    x = torch.from_numpy(g["x"]).cuda()
+    mean, var = q.mc_predict_regression(m, x, g["mu"].shape[0], g["seed"])
+    target = torch.randn(x.shape[0], generator=torch.Generator().manual_seed(4))
+    met = q.RegressionMetric(1)
+    half = x.shape[0] // 2
+    met.update((mean[:half], var[:half]), target[:half])             # accumulates over batches like the reference's metric objects
+    met.update((mean[half:], var[half:]), target[half:])
+    mu_c, var_c, B = mean.cpu().squeeze(), var.cpu().squeeze(), x.shape[0]
+    nll = torch.sum(0.5 * torch.log(2 * math.pi * var_c + 1e-8) + (target - mu_c) ** 2 / (2 * var_c + 1e-8)) / B
+    mse = F.mse_loss(mu_c, target, reduction="sum") / B
+    mae = F.l1_loss(mu_c, target, reduction="sum") / B
+    assert abs(met.nll - float(nll)) < 1e-5 * max(1.0, abs(float(nll)))
+    assert abs(met.mse - float(mse)) < 1e-5 * float(mse) and abs(met.rmse - float(torch.sqrt(mse))) < 1e-5 * float(torch.sqrt(mse))
+    assert abs(met.mae - float(mae)) < 1e-5 * float(mae)
+    assert met.get_key_metric() == met.rmse and sorted(met.compute()) == ["mae", "mse", "nll", "rmse"]
+    only_mean = q.RegressionMetric(1)
+    only_mean.update((mean, None), target)                            # metrics.py:154: a mean-only model is scored with unit variance
+    nll1 = torch.sum(0.5 * torch.log(torch.tensor(2 * math.pi) + 1e-8) + (target - mu_c) ** 2 / (2 + 1e-8)) / B
+    assert abs(only_mean.nll - float(nll1)) < 1e-5 * abs(float(nll1))
+
+
 def test_small_bbb_int8_graphs_match_reference(golden_lenet_bbb, golden_mlp_bbb_q):
     """int8 BBB LeNet and MLP (linear_q.Linear / LinearReLU forward for real): every layer of sample 0
     bit-exact, all samples' outputs to 1e-5 relative."""
@@ -748,3 +777,39 @@ def test_rccl_path_one_rank_equals_no_dist(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DIST-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_layers_take_and_return_torch_quantized_tensors(golden):
+    """The layer-level drop-in seam (reference conv_q.py:107-125, linear_q.py:80-94): `layer(x)` with x a torch quint8 NCHW
+    tensor -- what the reference's graph passes between modules, followed by its own `clamp_activation` (src/utils.py:25-30,
+    which tests `x.dtype == torch.quint8`) -- runs ONE stochastic forward on the GPU and hands a torch quint8 tensor back.
+    Checked on the recorded layer inputs / outputs of the reference (sample 0 of the golden noise stream)."""
+    import quantised_bayesian_nets_amd as q
+    g = golden
+    m = _model(g)
+    st, rec, seed = g["state"], g["rec"], g["meta"]["philox_seed"]
+    a_hi = 2 ** g["meta"]["a_bits"] - 1
+
+    def qt(nhwc, scale, zp):
+        t = torch.from_numpy(np.ascontiguousarray(nhwc.transpose(0, 3, 1, 2)) if nhwc.ndim == 4 else nhwc.copy())
+        return torch._make_per_tensor_quantized_tensor(t, float(scale), int(zp))
+
+    def clamp_activation(x):                      # the reference's helper, applied by its graph after every module
+        assert x.dtype == torch.quint8
+        return torch.clamp(x, (0 - x.q_zero_point()) * x.q_scale(), (a_hi - x.q_zero_point()) * x.q_scale())
+
+    cases = [("layers.0", m.layers[0], rec["quant.out"], st["quant.scale"].reshape(-1)[0], st["quant.zero_point"].reshape(-1)[0]),
+             ("layers.3.0.stem.0", m.layers[3][0].stem[0], rec["layers.0.out"], st["layers.0.scale"], st["layers.0.zero_point"]),
+             ("layers.4.0.shortcut.0", m.layers[4][0].shortcut[0], rec["layers.3.1.out"], st["layers.3.1.add.add.scale"], st["layers.3.1.add.add.zero_point"]),
+             ("layers.9", m.layers[9], rec["layers.7.out"].reshape(rec["layers.7.out"].shape[0], -1), st["layers.6.1.add.add.scale"], st["layers.6.1.add.add.zero_point"])]
+    for name, layer, x_in, s_in, z_in in cases:
+        x = qt(x_in, s_in, z_in)                                      # a CPU quint8 tensor, as in the reference's int8 graph
+        with q.mc_context(1, seed, 0):
+            y = clamp_activation(layer(x))
+        assert y.dtype == torch.quint8 and y.device == x.device and y.shape[0] == x.shape[0]
+        assert y.q_scale() == pytest.approx(float(st[name + ".scale"]), rel=0, abs=0) and y.q_zero_point() == int(st[name + ".zero_point"])
+        got = y.int_repr().numpy()
+        got = got.transpose(0, 2, 3, 1) if got.ndim == 4 else got
+        assert np.array_equal(got, rec[name + ".out"]), name
+    with pytest.raises(ValueError):
+        m.layers[3][0].stem[0](qt(rec["layers.7.out"].reshape(4, -1), 0.1, 3))        # conv_q.py:190-191: "Input shape must be `(N, C, H, W)`!"
