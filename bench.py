@@ -244,7 +244,9 @@ def main():
     # HIP events around the fused conv-block launches only (the candidates for `roofline`; the small kernels are in the
     # rocprofv3 summary under profiles/): every event costs a few microseconds of drained queue inside the timed region
     qlayers.PROFILE_FILTER = lambda meta: bool(meta) and "convs" in meta
-    qlayers.PROFILE = prof = []
+    prof = []
+    if wl["resnet"]:
+        qlayers.PROFILE = prof        # (the launch-bound workloads run as captured graphs: no per-launch events there)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
