@@ -159,6 +159,35 @@ int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x, 
                           int32_t Cin, int32_t a_hi, const qbnn_down_desc* host_desc, uint8_t* y, int64_t y_sample_stride,
                           int32_t n_samples, void* stream);
 
+/* ---- several independent calls in ONE launch (ensemble members) -------------------------------------------------------
+ * reference sgld/models_sgld.py:214-288: `Network` holds args.samples deterministic members, each a converted network of its own
+ * (own weights, biases AND quantisation parameters), evaluated one after the other.  Members cannot ride the MC-sample
+ * dimension of the calls above (qparams are per call), so these entry points take an ARRAY of calls and run them side by
+ * side in one grid (any n_calls; the library splits them into launches of up to 8 -- 4 with the fused stem).  Every call
+ * means exactly what the single-call entry point means; all calls of one array share the geometry arguments. */
+typedef struct qbnn_chain_call {
+  const uint8_t* x; int64_t x_sample_stride; float s_x; int32_t z_x;      /* as qbnn_block_chain_i8_mc (unused behind the stem) */
+  const qbnn_block_desc* blocks;                                          /* n_blocks descriptors                                */
+  uint8_t* y; int64_t y_sample_stride; int32_t n_samples;
+  /* with_stem != 0: the arguments of qbnn_stem_chain_i8_mc */
+  const int8_t* im2col; const int8_t* w0_packed; int64_t w0_sample_stride; const float* bias0;
+  float s_in; float s_w0; int32_t z_w0; float s_y0; int32_t z_y0;
+} qbnn_chain_call;
+int qbnn_block_chain_i8_multi(const qbnn_chain_call* calls, int32_t n_calls, int32_t with_stem, int32_t B, int32_t H, int32_t C,
+                              int32_t a_hi, int32_t n_blocks, void* stream);
+
+typedef struct qbnn_down_call {
+  const uint8_t* x; int64_t x_sample_stride; float s_x; int32_t z_x;
+  const qbnn_down_desc* desc;
+  uint8_t* y; int64_t y_sample_stride; int32_t n_samples;
+} qbnn_down_call;
+int qbnn_block_down_i8_multi(const qbnn_down_call* calls, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t a_hi, void* stream);
+
+/* QuantStub + clamp_activation + layer-0 patch gather (qbnn_quantize_input_nchw followed by qbnn_im2col3x3_c3) for n input
+ * quantisations at once: x fp32 NCHW [B][3][H][W] -> out[m][B][H*W][32] centred int8 patches, m < n (host arrays scales / zero_points). */
+int qbnn_quantize_im2col3x3_c3_multi(const float* x, int32_t B, int32_t H, int32_t W, const float* scales, const int32_t* zero_points,
+                                     int32_t n, int32_t a_hi, int8_t* out, int64_t out_stride, void* stream);
+
 /* QuantStub + clamp_activation (models_bbb.py:227-229): fp32 NCHW -> uint8 NHWC. */
 int qbnn_quantize_input_nchw(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, float scale,
                              int32_t zero_point, int32_t a_hi, uint8_t* out, void* stream);
@@ -182,6 +211,13 @@ typedef struct qbnn_head_desc {
 
 int qbnn_head_i8_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w_rowmajor, int64_t w_sample_stride,
                     const float* bias, float* probs, int32_t n_samples, const qbnn_head_desc* host_desc, void* stream);
+
+typedef struct qbnn_head_call {
+  const uint8_t* x; int64_t x_sample_stride; const int8_t* w; int64_t w_sample_stride; const float* bias; float* probs;
+  int32_t n_samples; const qbnn_head_desc* desc;
+} qbnn_head_call;
+/* n_calls heads side by side (see qbnn_block_chain_i8_multi); the calls of one array evaluate the same number of samples. */
+int qbnn_head_i8_multi(const qbnn_head_call* calls, int32_t n_calls, void* stream);
 
 /* MC reduction (experiments/utils.py:342-355): sum over the S per-sample outputs of p and p*p, in sample order
  * (deterministic), kept in fp64 (the variance below cancels in fp32):  moments[0][n] (+)= sum_s p, moments[1][n] (+)= sum_s p^2.

@@ -57,8 +57,25 @@ class HeadDesc(C.Structure):
                 ("a_hi", C.c_int32), ("has_bias", C.c_int32)]
 
 
+class ChainCall(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_sample_stride", C.c_int64), ("s_x", C.c_float), ("z_x", C.c_int32),
+                ("blocks", C.POINTER(BlockDesc)), ("y", C.c_void_p), ("y_sample_stride", C.c_int64), ("n_samples", C.c_int32),
+                ("im2col", C.c_void_p), ("w0_packed", C.c_void_p), ("w0_sample_stride", C.c_int64), ("bias0", C.c_void_p),
+                ("s_in", C.c_float), ("s_w0", C.c_float), ("z_w0", C.c_int32), ("s_y0", C.c_float), ("z_y0", C.c_int32)]
+
+
+class DownCall(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_sample_stride", C.c_int64), ("s_x", C.c_float), ("z_x", C.c_int32),
+                ("desc", C.POINTER(DownDesc)), ("y", C.c_void_p), ("y_sample_stride", C.c_int64), ("n_samples", C.c_int32)]
+
+
+class HeadCall(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_sample_stride", C.c_int64), ("w", C.c_void_p), ("w_sample_stride", C.c_int64), ("bias", C.c_void_p),
+                ("probs", C.c_void_p), ("n_samples", C.c_int32), ("desc", C.POINTER(HeadDesc))]
+
+
 EXPORTS = ["qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_conv2d_i8_mc",
-           "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_build_add_lut_host",
+           "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi", "qbnn_build_add_lut_host",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_conv2d_i8_generic_mc", "qbnn_conv2d_i8_generic_scalar_mc", "qbnn_dropout_q_mc", "qbnn_maxpool2_q_mc",
            "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
            "qbnn_conv2d_f32_mc", "qbnn_conv2d_f32_fused_mc", "qbnn_conv2d_f32_blocks", "qbnn_observe_partials_f32_mc", "qbnn_affine_f32_mc", "qbnn_pool2d_f32_mc", "qbnn_flatten_nchw_f32_mc", "qbnn_softmax_f32_mc", "qbnn_observe_f32_mc", "qbnn_fake_quant_f32_mc", "qbnn_sample_weights_f32_strided", "qbnn_sample_weights_f32_ohwi",
@@ -88,6 +105,10 @@ def lib():
         L.qbnn_block_chain_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(BlockDesc), i32, vp, i64, i32, vp]
         L.qbnn_stem_chain_i8_mc.argtypes = [vp, i32, vp, i64, vp, f, f, i32, f, i32, i32, C.POINTER(BlockDesc), i32, vp, i64, i32, vp]
         L.qbnn_block_down_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(DownDesc), vp, i64, i32, vp]
+        L.qbnn_block_chain_i8_multi.argtypes = [C.POINTER(ChainCall), i32, i32, i32, i32, i32, i32, i32, vp]
+        L.qbnn_block_down_i8_multi.argtypes = [C.POINTER(DownCall), i32, i32, i32, i32, i32, vp]
+        L.qbnn_head_i8_multi.argtypes = [C.POINTER(HeadCall), i32, vp]
+        L.qbnn_quantize_im2col3x3_c3_multi.argtypes = [vp, i32, i32, i32, C.POINTER(f), C.POINTER(i32), i32, i32, vp, i64, vp]
         L.qbnn_conv2d_i8_generic_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, C.POINTER(ConvDesc), vp]
         L.qbnn_conv2d_i8_generic_scalar_mc.argtypes = L.qbnn_conv2d_i8_generic_mc.argtypes
         L.qbnn_dropout_q_mc.argtypes = [vp, i64, i32, i32, i32, f, f, i32, f, i32, i32, u64, u32, u32, vp, vp, i64, i32, vp]

@@ -1295,6 +1295,13 @@ struct ChainArgs {
   QConv stem;
 };
 
+// Several independent launches of one fused kernel in ONE grid: gridDim.y (head: gridDim.z) picks the argument block.  Used for
+// ensemble members (reference sgld/models_sgld.py:277-288): every member has its own tensors, weights AND quantisation
+// parameters, so it cannot ride the MC-sample dimension of a launch -- but member m's workgroups can sit next to member
+// m+1's.  NM = 1 is the ordinary launch (same code, argument block 0).
+#define QBNN_FUSED_CALLS 8            // argument blocks per launch (kernel arguments are limited to 4 KiB)
+template <class A, int NM> struct ArgsArr { A m[NM]; };
+
 // workgroup size per geometry: 256 threads (4 waves) where two workgroups fit a CU -- they run out of phase, so one's
 // MFMA phase overlaps the other's epilogue; 512 elsewhere
 template <class C, int NBLK> struct ChainThreads {
@@ -1691,12 +1698,8 @@ using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
 using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, 1, 3, false>;
 using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
 
-QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cin,
-                                      int32_t a_hi, const qbnn_down_desc* d, uint8_t* y, int64_t y_ss, int32_t n_samples,
-                                      void* stream) {
-  if (!x || !y || !d || n_samples <= 0 || B <= 0 || !d->blk.w_a || !d->blk.w_b || !d->w_s)
-    return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: bad argument%s");
-  DownArgs a;
+static int build_down_args(DownArgs& a, const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t a_hi, const qbnn_down_desc* d,
+                           uint8_t* y, int64_t y_ss, int32_t n_samples) {
   memset(&a, 0, sizeof(a));
   a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = B; a.n_samples = n_samples; a.z_in = z_x;
   qbnn_conv_desc c;
@@ -1711,7 +1714,41 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
   c.has_bias = d->blk.bias_b != nullptr;
   if ((rc = fill_qconv(a.b, d->blk.w_b, d->blk.w_b_sample_stride, d->blk.bias_b, &c))) return rc;
   c.s_r = d->s_s; c.z_r = d->z_s; c.s_o = d->blk.s_o; c.z_o = d->blk.z_o;
-  if ((rc = fill_qadd(a.add, &c))) return rc;
+  return fill_qadd(a.add, &c);
+}
+
+template <class CA, class CS, class CB, bool LDSW> static int launch_block_down_ws_multi(const DownArgs* arr, int n, hipStream_t st);
+
+QBNN_EXPORT int qbnn_block_down_i8_multi(const qbnn_down_call* calls, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t a_hi, void* stream) {
+  if (!calls || n_calls <= 0 || B <= 0) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: bad argument%s");
+  hipStream_t st = (hipStream_t)stream;
+  for (int c0 = 0; c0 < n_calls;) {
+    const int n = n_calls - c0 < QBNN_FUSED_CALLS ? n_calls - c0 : QBNN_FUSED_CALLS;
+    DownArgs arr[QBNN_FUSED_CALLS];
+    int rc;
+    for (int i = 0; i < n; ++i) {
+      const qbnn_down_call& k = calls[c0 + i];
+      if (!k.x || !k.y || !k.desc || k.n_samples <= 0 || !k.desc->blk.w_a || !k.desc->blk.w_b || !k.desc->w_s)
+        return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: bad call entry%s");
+      if ((rc = build_down_args(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.desc, k.y, k.y_sample_stride, k.n_samples))) return rc;
+    }
+    if (Cin == 24 && H == 32) rc = launch_block_down_ws_multi<D24_a, D24_s, D24_b, true>(arr, n, st);
+    else if (Cin == 48 && H == 16) rc = launch_block_down_ws_multi<D48_a, D48_s, D48_b, false>(arr, n, st);
+    else if (Cin == 96 && H == 8) rc = launch_block_down_ws_multi<D96_a, D96_s, D96_b, false>(arr, n, st);
+    else return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
+    if (rc) return rc;
+    c0 += n;
+  }
+  return QBNN_OK;
+}
+
+QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cin,
+                                      int32_t a_hi, const qbnn_down_desc* d, uint8_t* y, int64_t y_ss, int32_t n_samples,
+                                      void* stream) {
+  if (!x || !y || !d || n_samples <= 0 || B <= 0 || !d->blk.w_a || !d->blk.w_b || !d->w_s)
+    return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: bad argument%s");
+  DownArgs a;
+  if (int rc = build_down_args(a, x, x_ss, s_x, z_x, B, a_hi, d, y, y_ss, n_samples)) return rc;
   hipStream_t st = (hipStream_t)stream;
   // (a ping-pong variant of this block -- phases W / M_a / E_sa / M_b / E_b on two 4-wave groups -- measured 15 % SLOWER
   //  than the weights-stationary kernel: five barrier intervals per image, each as long as the slower group's phase)
@@ -2069,8 +2106,9 @@ struct ItemWalk {
 //               the same kernel -- its output never goes to HBM (that tensor is the largest of the network: 629 MB per
 //               100-sample step written and read back).  The item's input is then its image's patch block (32 KiB,
 //               shared by all samples, L2-resident), staged in a dense LDS tile; conv0's epilogue writes the X tile.
-template <class C, int NBLK, bool LDSW, bool STEM = false>
-__global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const ChainArgs<NBLK> a) {
+template <class C, int NBLK, bool LDSW, bool STEM = false, int NM = 1>
+__global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all) {
+  const ChainArgs<NBLK>& a = all.m[NM == 1 ? 0 : blockIdx.y];
   using C0 = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;      // layer 0 on the patch tensor: K = 27 -> 32, one k-step
   static_assert(!STEM || (LDSW && C::CIN == 24 && C::HIN == 32 && C::G == 1), "the fused stem feeds the 32x32x24 chain");
   static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
@@ -2566,9 +2604,10 @@ struct EpiDenseTileResGlobal {
 // item (8 / 16 images); a group that drains its accumulators while the other multiplies halves the images per pass of the
 // block's weights (162 / 663 KiB), and the L2 -> LDS weight stream (3.5 TB/s chip-wide here, 4.7 TB/s there) is what the M
 // phase waits for.  More images per weight pass needs more accumulator registers, not more LDS.
-template <class C, int NWV>
+template <class C, int NWV, int NM = 1>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 4, NWV / 4)))
-void block_chain_ald_kernel(const ChainArgs<1> a) {
+void block_chain_ald_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
+  const ChainArgs<1>& a = all.m[NM == 1 ? 0 : blockIdx.y];
   static_assert(C::CIN == C::COUT && C::CIN % 32 == 0, "wide identity BasicBlock");
   using DT = DenseTile<C>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -2734,12 +2773,33 @@ static int launch_block_chain_ald(const ChainArgs<1>& a, hipStream_t st) {
   constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV>, attr, LDS)) return rc_attr;
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV, 1>, attr, LDS)) return rc_attr;
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
   const int grid = n_items < 256 ? n_items : 256;
-  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV>), dim3(grid), dim3(64 * NWV), LDS, st, a);
+  ArgsArr<ChainArgs<1>, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, 1>), dim3(grid), dim3(64 * NWV), LDS, st, one);
   return check_launch("qbnn_block_chain_i8_mc");
+}
+
+// grid of a fused multi-call launch: every call gets the same number of workgroups (<= its item count), 256 in total
+static int fused_grid_x(int max_items, int n_calls) {
+  const int per = 256 / n_calls > 0 ? 256 / n_calls : 1;
+  return max_items < per ? (max_items > 0 ? max_items : 1) : per;
+}
+
+template <class C, int NWV>
+static int launch_block_chain_ald_multi(const ChainArgs<1>* arr, int n, hipStream_t st) {
+  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4;
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV, QBNN_FUSED_CALLS>, attr, LDS)) return rc_attr;
+  ArgsArr<ChainArgs<1>, QBNN_FUSED_CALLS> all;
+  memset(&all, 0, sizeof(all));                   // unused blocks: n_samples = 0 -> their workgroups (none launched) would exit at once
+  int items = 0;
+  for (int i = 0; i < n; ++i) { all.m[i] = arr[i]; const int it = arr[i].n_samples * ((arr[i].B + C::G - 1) / C::G); items = it > items ? it : items; }
+  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, QBNN_FUSED_CALLS>), dim3(fused_grid_x(items, n), n), dim3(64 * NWV), LDS, st, all);
+  return check_launch("qbnn_block_chain_i8_multi");
 }
 
 
@@ -2753,12 +2813,29 @@ static int launch_block_chain_ws(const ChainArgs<NBLK>& a, hipStream_t st) {
   constexpr int LDS = chain_ws_lds<C, NBLK, LDSW, STEM>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, LDSW, STEM>, attr, LDS)) return rc_attr;
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, LDSW, STEM, 1>, attr, LDS)) return rc_attr;
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
   const int grid = n_items < 256 ? n_items : 256;
-  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, LDSW, STEM>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
+  ArgsArr<ChainArgs<NBLK>, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, LDSW, STEM, 1>), dim3(grid), dim3(BLK_THREADS), LDS, st, one);
   return check_launch("qbnn_block_chain_i8_mc");
+}
+
+template <class C, int NBLK, bool STEM, int NM>
+static int launch_block_chain_ws_multi(const ChainArgs<NBLK>* arr, int n, hipStream_t st) {
+  constexpr int LDS = chain_ws_lds<C, NBLK, true, STEM>();
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static_assert(sizeof(ArgsArr<ChainArgs<NBLK>, NM>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, true, STEM, NM>, attr, LDS)) return rc_attr;
+  ArgsArr<ChainArgs<NBLK>, NM> all;
+  memset(&all, 0, sizeof(all));
+  int items = 0;
+  for (int i = 0; i < n; ++i) { all.m[i] = arr[i]; const int it = arr[i].n_samples * ((arr[i].B + C::G - 1) / C::G); items = it > items ? it : items; }
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, true, STEM, NM>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, all);
+  return check_launch("qbnn_block_chain_i8_multi");
 }
 
 template <class CB> struct DownSC {
@@ -2775,8 +2852,9 @@ static int launch_chain_auto(const ChainArgs<NBLK>& a, hipStream_t st) {
   return launch_block_chain<C, NBLK>(a, st);
 }
 
-template <class CA, class CS, class CB, bool LDSW>
-__global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const DownArgs a) {
+template <class CA, class CS, class CB, bool LDSW, int NM = 1>
+__global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const ArgsArr<DownArgs, NM> all) {
+  const DownArgs& a = all.m[NM == 1 ? 0 : blockIdx.y];
   static_assert(CA::M == CS::M && CA::M == CB::M && CA::G == CS::G && CA::G == CB::G, "one work item, three convs");
   static_assert(CA::COUT == CB::CIN && CA::COUT == CB::COUT && CS::COUT == CB::COUT && CA::HO == CB::HIN, "block geometry");
   static_assert(CA::TILE_BYTES == CS::TILE_BYTES && CA::CIN == CS::CIN && CA::HIN == CS::HIN, "shared input tile");
@@ -2929,12 +3007,29 @@ static int launch_block_down_ws(const DownArgs& a, hipStream_t st) {
                       (LDSW ? WConv<CS>::BYTES + WConv<CA>::BYTES + WConv<CB>::BYTES : 0) + 3 * CB::COUT * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)block_down_ws_kernel<CA, CS, CB, LDSW>, attr, LDS)) return rc_attr;
+  if (int rc_attr = ensure_dyn_lds((const void*)block_down_ws_kernel<CA, CS, CB, LDSW, 1>, attr, LDS)) return rc_attr;
   const int groups = (a.B + CA::G - 1) / CA::G;
   const int n_items = a.n_samples * groups;
   const int grid = n_items < 256 ? n_items : 256;
-  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
+  ArgsArr<DownArgs, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW, 1>), dim3(grid), dim3(BLK_THREADS), LDS, st, one);
   return check_launch("qbnn_block_down_i8_mc");
+}
+
+template <class CA, class CS, class CB, bool LDSW>
+static int launch_block_down_ws_multi(const DownArgs* arr, int n, hipStream_t st) {
+  constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + DownSC<CB>::BYTES +
+                      (LDSW ? WConv<CS>::BYTES + WConv<CA>::BYTES + WConv<CB>::BYTES : 0) + 3 * CB::COUT * 4;
+  static_assert(sizeof(ArgsArr<DownArgs, QBNN_FUSED_CALLS>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_down_ws_kernel<CA, CS, CB, LDSW, QBNN_FUSED_CALLS>, attr, LDS)) return rc_attr;
+  ArgsArr<DownArgs, QBNN_FUSED_CALLS> all;
+  memset(&all, 0, sizeof(all));
+  int items = 0;
+  for (int i = 0; i < n; ++i) { all.m[i] = arr[i]; const int it = arr[i].n_samples * ((arr[i].B + CA::G - 1) / CA::G); items = it > items ? it : items; }
+  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW, QBNN_FUSED_CALLS>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, all);
+  return check_launch("qbnn_block_down_i8_multi");
 }
 
 //                          CIN COUT K  S  HIN HALO G  MB NB
@@ -2951,10 +3046,8 @@ using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false, 36, 16>;
 #endif
 
 template <int NBLK>
-static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
-                                int32_t a_hi, const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples,
-                                hipStream_t st, const int8_t* stem_x = nullptr, const QConv* stem = nullptr) {
-  ChainArgs<NBLK> a;
+static int build_chain_args(ChainArgs<NBLK>& a, const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t a_hi,
+                            const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples, const int8_t* stem_x, const QConv* stem) {
   memset(&a, 0, sizeof(a));
   if (stem) { a.stem_x = stem_x; a.stem = *stem; }
   a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = B; a.n_samples = n_samples; a.z_in = z_x;
@@ -2977,6 +3070,24 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
     a.blk[k].add.lut = b.add_lut; a.blk[k].add.z_y = b.z_b;
     s_in = b.s_o; z_in = b.z_o;
   }
+  return QBNN_OK;
+}
+
+static int build_stem_qconv(QConv& stem, const int8_t* w0_packed, int64_t w0_ss, const float* bias0, float s_x, float s_w0, int32_t z_w0,
+                            float s_y0, int32_t z_y0, int32_t a_hi) {
+  qbnn_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.a_hi = a_hi; d.s_x = s_x; d.z_x = 0; d.s_w = s_w0; d.z_w = z_w0; d.s_y = s_y0; d.z_y = z_y0; d.relu = 1; d.has_bias = bias0 != nullptr;
+  memset(&stem, 0, sizeof(stem));
+  return fill_qconv(stem, w0_packed, w0_ss, bias0, &d);
+}
+
+template <int NBLK>
+static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
+                                int32_t a_hi, const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples,
+                                hipStream_t st, const int8_t* stem_x = nullptr, const QConv* stem = nullptr) {
+  ChainArgs<NBLK> a;
+  if (int rc = build_chain_args<NBLK>(a, x, x_ss, s_x, z_x, B, a_hi, blk, y, y_ss, n_samples, stem_x, stem)) return rc;
   if (stem) {
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
     return launch_block_chain_ws<Blk_24, NBLK, true, true>(a, st);
@@ -3022,18 +3133,53 @@ QBNN_EXPORT int qbnn_stem_chain_i8_mc(const int8_t* im2col, int32_t B, const int
   if (!im2col || !w0_packed || !y || !host_blocks || n_samples <= 0 || B <= 0) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: bad argument%s");
   for (int k = 0; k < n_blocks; ++k)
     if (!host_blocks[k].w_a || !host_blocks[k].w_b) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: NULL weights%s");
-  qbnn_conv_desc d;
-  memset(&d, 0, sizeof(d));
-  d.a_hi = a_hi; d.s_x = s_x; d.z_x = 0; d.s_w = s_w0; d.z_w = z_w0; d.s_y = s_y0; d.z_y = z_y0; d.relu = 1; d.has_bias = bias0 != nullptr;
   QConv stem;
-  memset(&stem, 0, sizeof(stem));
-  int rc = fill_qconv(stem, w0_packed, w0_ss, bias0, &d);
-  if (rc) return rc;
+  if (int rc = build_stem_qconv(stem, w0_packed, w0_ss, bias0, s_x, s_w0, z_w0, s_y0, z_y0, a_hi)) return rc;
   hipStream_t st = (hipStream_t)stream;
   // the chain's input is conv0's output: scale s_y0, zero point z_y0
   if (n_blocks == 1) return block_chain_dispatch<1>(nullptr, 0, s_y0, z_y0, B, 32, 24, a_hi, host_blocks, y, y_ss, n_samples, st, im2col, &stem);
   if (n_blocks == 2) return block_chain_dispatch<2>(nullptr, 0, s_y0, z_y0, B, 32, 24, a_hi, host_blocks, y, y_ss, n_samples, st, im2col, &stem);
   return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: 1 or 2 blocks per launch%s");
+}
+
+// ---- fused multi-call launches (ensemble members): see ArgsArr ------------------------------------------------------------
+QBNN_EXPORT int qbnn_block_chain_i8_multi(const qbnn_chain_call* calls, int32_t n_calls, int32_t with_stem, int32_t B, int32_t H,
+                                          int32_t Cc, int32_t a_hi, int32_t n_blocks, void* stream) {
+  if (!calls || n_calls <= 0 || B <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: bad argument%s");
+  hipStream_t st = (hipStream_t)stream;
+  constexpr int NM2 = 4;                              // ChainArgs<2> with the stem: 4 argument blocks fit the 4 KiB of kernel arguments
+  for (int c0 = 0; c0 < n_calls;) {
+    const int lim = (with_stem || n_blocks == 2) ? NM2 : QBNN_FUSED_CALLS;
+    const int n = n_calls - c0 < lim ? n_calls - c0 : lim;
+    int rc = QBNN_OK;
+    if (with_stem) {
+      if (n_blocks != 2 || Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: the fused stem feeds the two 32x32x24 blocks only%s");
+      ChainArgs<2> arr[NM2];
+      for (int i = 0; i < n; ++i) {
+        const qbnn_chain_call& k = calls[c0 + i];
+        if (!k.im2col || !k.w0_packed || !k.blocks || !k.y || k.n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: bad call entry%s");
+        QConv stem;
+        if ((rc = build_stem_qconv(stem, k.w0_packed, k.w0_sample_stride, k.bias0, k.s_in, k.s_w0, k.z_w0, k.s_y0, k.z_y0, a_hi))) return rc;
+        if ((rc = build_chain_args<2>(arr[i], nullptr, 0, k.s_y0, k.z_y0, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, k.im2col, &stem))) return rc;
+      }
+      rc = launch_block_chain_ws_multi<Blk_24, 2, true, NM2>(arr, n, st);
+    } else {
+      if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: one block per call (two only behind the fused stem)%s");
+      ChainArgs<1> arr[QBNN_FUSED_CALLS];
+      for (int i = 0; i < n; ++i) {
+        const qbnn_chain_call& k = calls[c0 + i];
+        if (!k.x || !k.blocks || !k.y || k.n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: bad call entry%s");
+        if ((rc = build_chain_args<1>(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, nullptr, nullptr))) return rc;
+      }
+      if (Cc == 48 && H == 16) rc = launch_block_chain_ws_multi<Blk_48, 1, false, QBNN_FUSED_CALLS>(arr, n, st);
+      else if (Cc == 96 && H == 8) rc = launch_block_chain_ald_multi<ALD_96, 8>(arr, n, st);
+      else if (Cc == 192 && H == 4) rc = launch_block_chain_ald_multi<ALD_192, 8>(arr, n, st);
+      else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
+    }
+    if (rc) return rc;
+    c0 += n;
+  }
+  return QBNN_OK;
 }
 
 // Stand-alone quantized::add (+ clamp_activation, ReLU, clamp_activation) for graphs where something sits between the
@@ -3133,6 +3279,63 @@ QBNN_EXPORT int qbnn_im2col3x3_c3(const uint8_t* x, int32_t B, int32_t H, int32_
   return check_launch("qbnn_im2col3x3_c3");
 }
 
+// QuantStub + clamp_activation + the layer-0 patch gather for SEVERAL input quantisations at once (ensemble members each own
+// a `quant.scale / zero_point`): fp32 NCHW [B][3][H][W] -> centred int8 patches out[m][B][H*W][32], member m = blockIdx.y.
+struct QuantIm2colArgs { float inv[16]; int z[16]; };
+__global__ __launch_bounds__(256) void quantize_im2col3x3_c3_kernel(const float* __restrict__ x, int B, int H, int W, const QuantIm2colArgs q,
+                                                                     int a_hi, int8_t* __restrict__ out, int64_t out_stride) {
+  const int m = blockIdx.y;
+  const float inv = q.inv[m];
+  const int z = q.z[m];
+  const int64_t npix = (int64_t)B * H * W, plane = (int64_t)H * W;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const int ow = (int)(p % W);
+    const int oh = (int)((p / W) % H);
+    const int64_t b = p / plane;
+    uint32_t wds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int8_t* by = reinterpret_cast<int8_t*>(wds);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = oh + kh - 1, iw = ow + kw - 1;
+        const bool in = ih >= 0 && ih < H && iw >= 0 && iw < W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          int v = 0;
+          if (in) {
+            const float f = x[((b * 3 + c) * H + ih) * W + iw];
+            v = min(min(max(z + rne_sat(f * inv), 0), 255), a_hi) - z;          // quantize_input_kernel, then im2col3x3_c3_kernel's centring
+          }
+          by[(kh * 3 + kw) * 3 + c] = (int8_t)v;
+        }
+      }
+    v4i* o = reinterpret_cast<v4i*>(out + (int64_t)m * out_stride + p * 32);
+    o[0] = v4i{(int)wds[0], (int)wds[1], (int)wds[2], (int)wds[3]};
+    o[1] = v4i{(int)wds[4], (int)wds[5], (int)wds[6], (int)wds[7]};
+  }
+}
+
+QBNN_EXPORT int qbnn_quantize_im2col3x3_c3_multi(const float* x, int32_t B, int32_t H, int32_t W, const float* scales, const int32_t* zero_points,
+                                                 int32_t n, int32_t a_hi, int8_t* out, int64_t out_stride, void* stream) {
+  if (!x || !scales || !zero_points || !out || B <= 0 || n <= 0) return fail(QBNN_E_INVALID, "qbnn_quantize_im2col3x3_c3_multi: bad argument%s");
+  const int64_t npix = (int64_t)B * H * W;
+  const int blocks = (int)((npix + 255) / 256 < 1024 ? (npix + 255) / 256 : 1024);
+  for (int c0 = 0; c0 < n; c0 += 16) {
+    const int k = n - c0 < 16 ? n - c0 : 16;
+    QuantIm2colArgs q;
+    memset(&q, 0, sizeof(q));
+    for (int i = 0; i < k; ++i) {
+      if (zero_points[c0 + i] < 0 || zero_points[c0 + i] > 127) return fail(QBNN_E_INVALID, "qbnn_quantize_im2col3x3_c3_multi: zero points must be in [0,127]%s");
+      q.inv[i] = 1.0f / scales[c0 + i]; q.z[i] = zero_points[c0 + i];
+    }
+    hipLaunchKernelGGL(quantize_im2col3x3_c3_kernel, dim3(blocks, k), dim3(256), 0, (hipStream_t)stream, x, B, H, W, q, a_hi,
+                       out + (int64_t)c0 * out_stride, out_stride);
+    if (int rc = check_launch("qbnn_quantize_im2col3x3_c3_multi")) return rc;
+  }
+  return QBNN_OK;
+}
+
 // head: one wave per (sample, image).  C <= 256 channels, N <= 16 classes (4 lanes per class).
 struct HeadArgs {
   const uint8_t* x; int64_t x_ss;
@@ -3144,7 +3347,9 @@ struct HeadArgs {
   float inv_kk, rcp, mult, s_y;
 };
 
-__global__ __launch_bounds__(256) void head_i8_kernel(const HeadArgs a) {
+template <int NM = 1>
+__global__ __launch_bounds__(256) void head_i8_kernel(const ArgsArr<HeadArgs, NM> all) {
+  const HeadArgs& a = all.m[NM == 1 ? 0 : blockIdx.z];
   __shared__ int pooled[4][256];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * 4 + wave;
@@ -3202,19 +3407,46 @@ __global__ __launch_bounds__(256) void head_i8_kernel(const HeadArgs a) {
   if (n < a.N && j == 0) a.probs[((int64_t)s * a.B + b) * a.N + n] = e / sum;
 }
 
-QBNN_EXPORT int qbnn_head_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* w, int64_t w_ss, const float* bias,
-                                float* probs, int32_t n_samples, const qbnn_head_desc* d, void* stream) {
-  if (!x || !w || !probs || !d || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_head_i8_mc: bad argument%s");
-  if (d->C > 256 || d->N > 16 || d->C <= 0 || d->N <= 0) return fail(QBNN_E_INVALID, "qbnn_head_i8_mc: C <= 256 and N <= 16 required%s");
-  HeadArgs a;
+static int build_head_args(HeadArgs& a, const uint8_t* x, int64_t x_ss, const int8_t* w, int64_t w_ss, const float* bias, float* probs,
+                           const qbnn_head_desc* d) {
+  if (d->C > 256 || d->N > 16 || d->C <= 0 || d->N <= 0) return fail(QBNN_E_INVALID, "qbnn_head_i8: C <= 256 and N <= 16 required%s");
   a.x = x; a.x_ss = x_ss; a.w = w; a.w_ss = w_ss; a.bias = d->has_bias ? bias : nullptr; a.probs = probs;
   a.B = d->B; a.kk = d->k * d->k; a.C = d->C; a.N = d->N;
   a.z_x = d->z_x; a.z_w = d->z_w; a.z_y = d->z_y; a.a_hi = d->a_hi;
   a.inv_kk = 1.0f / (float)(d->k * d->k);
   const float atw = d->s_x * d->s_w;
   a.rcp = 1.0f / atw; a.mult = atw / d->s_y; a.s_y = d->s_y;
-  hipLaunchKernelGGL(head_i8_kernel, dim3(ceil_div(d->B, 4), n_samples), dim3(256), 0, (hipStream_t)stream, a);
+  return QBNN_OK;
+}
+
+QBNN_EXPORT int qbnn_head_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* w, int64_t w_ss, const float* bias,
+                                float* probs, int32_t n_samples, const qbnn_head_desc* d, void* stream) {
+  if (!x || !w || !probs || !d || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_head_i8_mc: bad argument%s");
+  ArgsArr<HeadArgs, 1> one;
+  if (int rc = build_head_args(one.m[0], x, x_ss, w, w_ss, bias, probs, d)) return rc;
+  hipLaunchKernelGGL(head_i8_kernel<1>, dim3(ceil_div(d->B, 4), n_samples), dim3(256), 0, (hipStream_t)stream, one);
   return check_launch("qbnn_head_i8_mc");
+}
+
+QBNN_EXPORT int qbnn_head_i8_multi(const qbnn_head_call* calls, int32_t n_calls, void* stream) {
+  if (!calls || n_calls <= 0) return fail(QBNN_E_INVALID, "qbnn_head_i8_multi: bad argument%s");
+  for (int c0 = 0; c0 < n_calls;) {
+    const int n = n_calls - c0 < QBNN_FUSED_CALLS ? n_calls - c0 : QBNN_FUSED_CALLS;
+    ArgsArr<HeadArgs, QBNN_FUSED_CALLS> all;
+    memset(&all, 0, sizeof(all));
+    int maxB = 0, maxS = 0;
+    for (int i = 0; i < n; ++i) {
+      const qbnn_head_call& k = calls[c0 + i];
+      if (!k.x || !k.w || !k.probs || !k.desc || k.n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_head_i8_multi: bad call entry%s");
+      if (int rc = build_head_args(all.m[i], k.x, k.x_sample_stride, k.w, k.w_sample_stride, k.bias, k.probs, k.desc)) return rc;
+      if (k.n_samples != calls[c0].n_samples) return fail(QBNN_E_INVALID, "qbnn_head_i8_multi: the calls of one launch evaluate the same number of samples%s");
+      maxB = k.desc->B > maxB ? k.desc->B : maxB; maxS = k.n_samples;
+    }
+    hipLaunchKernelGGL(head_i8_kernel<QBNN_FUSED_CALLS>, dim3(ceil_div(maxB, 4), maxS, n), dim3(256), 0, (hipStream_t)stream, all);
+    if (int rc = check_launch("qbnn_head_i8_multi")) return rc;
+    c0 += n;
+  }
+  return QBNN_OK;
 }
 
 // MC reduction.  The sums are kept in fp64: var = (sum p^2 - (sum p)^2 / S) / (S - 1) cancels catastrophically in fp32 when the

@@ -357,12 +357,16 @@ class Network(nn.Module):
         self.use_graphs = os.environ.get("QBNN_NO_GRAPHS", "0") != "1"
         self._graphs = {}
         self._streams = []
+        # members side by side in fused multi-call launches (the default); False: one launch chain per member (graphs / streams)
+        self.fused_members = True
+        self._plans = {}
 
     def load_reference_state(self, member_states):
         assert len(member_states) == len(self.ensemble)
         for m, st in zip(self.ensemble, member_states):
             m.load_reference_state(st)
         self._graphs = {}
+        self._plans = {}
         return self
 
     def load_ensemble(self, args, path=None, special_info=""):
@@ -393,7 +397,9 @@ class Network(nn.Module):
                     with torch.cuda.graph(graph):
                         static_y = member.forward_mc(static_x)
                     ent = (graph, static_x, static_y)
-                except Exception:                           # capture refused: keep launching eagerly (same kernels)
+                except Exception as e:                      # capture refused: keep launching eagerly (same kernels), but say so
+                    import warnings
+                    warnings.warn(f"qbnn ensemble: HIP graph capture of member {idx} failed ({e!r}); launching eagerly")
                     torch.cuda.synchronize()
                     ent = False
             self._graphs[key] = ent
@@ -405,9 +411,113 @@ class Network(nn.Module):
         graph.replay()
         return static_y.clone()
 
+    # ---- members side by side: one fused multi-call launch per layer group (qbnn_*_multi) instead of ~12 launches per member
+    def _member_plan(self, idx, B, dev):
+        """Static buffers + the call arrays of the fused launches for members `idx` at batch B (built once, replayed)."""
+        key = (tuple(idx), B, dev.index)
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        M, L = len(idx), _lib.lib()
+        mem = [self.ensemble[j] for j in idx]
+        a_hi = UINT_BOUNDS[self.args.activation_precision][1]
+        keep = []
+        u8 = lambda *shape: torch.empty(shape, dtype=torch.uint8, device=dev)
+        col = torch.empty((M, B, 1024, 32), dtype=torch.int8, device=dev)
+        acts = {3: u8(M, B, 32, 32, 24), "4d": u8(M, B, 16, 16, 48), 4: u8(M, B, 16, 16, 48), "5d": u8(M, B, 8, 8, 96), 5: u8(M, B, 8, 8, 96),
+                "6d": u8(M, B, 4, 4, 192), 6: u8(M, B, 4, 4, 192)}
+        probs = torch.empty((M, B, self.output_size), dtype=torch.float32, device=dev)
+        scales = (C.c_float * M)(*[m.quant.scale for m in mem])
+        zps = (C.c_int32 * M)(*[m.quant.zero_point for m in mem])
+        with mc_context(1, 0, 0):
+            # layers.0 + layers.3 (two identity blocks) behind the fused stem
+            stem_calls = (_lib.ChainCall * M)()
+            for i, m in enumerate(mem):
+                l0 = m.layers[0]
+                pk0 = l0._ensure_packed(dev)
+                descs = (_lib.BlockDesc * 2)()
+                for d, blk in zip(descs, m.layers[3]):
+                    _fill_block_desc(d, blk, dev, keep)
+                keep.append(descs)
+                c = stem_calls[i]
+                c.blocks, c.y, c.y_sample_stride, c.n_samples = descs, acts[3][i].data_ptr(), acts[3][i].numel(), 1
+                c.im2col, c.w0_packed, c.w0_sample_stride = col[i].data_ptr(), pk0["mu"].data_ptr(), 0
+                c.bias0 = pk0["bias"].data_ptr() if pk0["bias"] is not None else None
+                c.s_in, c.s_w0, c.z_w0, c.s_y0, c.z_y0 = m.quant.scale, l0.add_weight.scale, l0.add_weight.zero_point, l0.scale, l0.zero_point
+            steps = [("stem", stem_calls)]
+            prev = 3
+            for li, (H, Cin) in ((4, (32, 24)), (5, (16, 48)), (6, (8, 96))):
+                dcalls, ccalls = (_lib.DownCall * M)(), (_lib.ChainCall * M)()
+                for i, m in enumerate(mem):
+                    b0, b1 = m.layers[li][0], m.layers[li][1]
+                    prev_add = m.layers[prev][-1].add.add
+                    dd = _lib.DownDesc()
+                    _fill_block_desc(dd.blk, b0, dev, keep)
+                    cs = b0.shortcut[0]
+                    ps = cs._ensure_packed(dev)
+                    dd.w_s, dd.w_s_sample_stride, dd.bias_s = ps["mu"].data_ptr(), 0, (ps["bias"].data_ptr() if ps["bias"] is not None else None)
+                    dd.s_ws, dd.z_ws, dd.s_s, dd.z_s = cs.add_weight.scale, cs.add_weight.zero_point, cs.scale, cs.zero_point
+                    keep.append(dd)
+                    k = dcalls[i]
+                    xin = acts[prev][i]
+                    k.x, k.x_sample_stride, k.s_x, k.z_x = xin.data_ptr(), xin.numel(), prev_add.scale, prev_add.zero_point
+                    k.desc, k.y, k.y_sample_stride, k.n_samples = C.pointer(dd), acts[f"{li}d"][i].data_ptr(), acts[f"{li}d"][i].numel(), 1
+                    d1 = (_lib.BlockDesc * 1)()
+                    _fill_block_desc(d1[0], b1, dev, keep)
+                    keep.append(d1)
+                    q = ccalls[i]
+                    q.x, q.x_sample_stride, q.s_x, q.z_x = acts[f"{li}d"][i].data_ptr(), acts[f"{li}d"][i].numel(), b0.add.add.scale, b0.add.add.zero_point
+                    q.blocks, q.y, q.y_sample_stride, q.n_samples = d1, acts[li][i].data_ptr(), acts[li][i].numel(), 1
+                steps += [("down", dcalls, H, Cin), ("chain", ccalls, H // 2, 2 * Cin)]
+                prev = li
+            hcalls = (_lib.HeadCall * M)()
+            for i, m in enumerate(mem):
+                fc, last = m.layers[9], m.layers[6][-1].add.add
+                pk = fc._ensure_packed(dev)
+                hd = _lib.HeadDesc()
+                hd.B, hd.k, hd.C, hd.N = B, 4, 192, self.output_size
+                hd.s_x, hd.z_x, hd.s_w, hd.z_w = last.scale, last.zero_point, fc.add_weight.scale, fc.add_weight.zero_point
+                hd.s_y, hd.z_y, hd.a_hi, hd.has_bias = fc.scale, fc.zero_point, a_hi, int(pk["bias"] is not None)
+                keep.append(hd)
+                h = hcalls[i]
+                h.x, h.x_sample_stride, h.w, h.w_sample_stride = acts[6][i].data_ptr(), acts[6][i].numel(), pk["mu"].data_ptr(), 0
+                h.bias, h.probs, h.n_samples, h.desc = (pk["bias"].data_ptr() if pk["bias"] is not None else None), probs[i].data_ptr(), 1, C.pointer(hd)
+        plan = dict(M=M, col=col, acts=acts, probs=probs, scales=scales, zps=zps, steps=steps, head=hcalls, keep=keep, a_hi=a_hi)
+        self._plans[key] = plan
+        return plan
+
+    def _forward_members_fused(self, idx, x):
+        """[len(idx), B, C] probabilities of members `idx`: 10 launches for ALL of them (input quantisation + patches, stem + layer 1,
+        three down blocks, three identity blocks, head), each member with its own weights and quantisation parameters."""
+        if x.device.type != "cuda":
+            raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
+        x = x.to(torch.float32).contiguous()
+        B, Cc, H, W = x.shape
+        if Cc != 3 or H != 32 or W != 32:
+            raise NotImplementedError("conv_resnet_sgld expects 3x32x32 inputs")
+        p = self._member_plan(idx, B, x.device)
+        L, st, M = _lib.lib(), _lib.current_stream(), p["M"]
+        with timed("ensemble quantize + im2col"):
+            _lib.check(L.qbnn_quantize_im2col3x3_c3_multi(_lib.ptr(x), B, H, W, p["scales"], p["zps"], M, p["a_hi"], _lib.ptr(p["col"]), p["col"][0].numel(), st))
+        for step in p["steps"]:
+            if step[0] == "stem":
+                with timed("ensemble stem + layer 1"):
+                    _lib.check(L.qbnn_block_chain_i8_multi(step[1], M, 1, B, 32, 24, p["a_hi"], 2, st))
+            elif step[0] == "down":
+                with timed("ensemble down %d" % step[3]):
+                    _lib.check(L.qbnn_block_down_i8_multi(step[1], M, B, step[2], step[3], p["a_hi"], st))
+            else:
+                with timed("ensemble chain %d" % step[3]):
+                    _lib.check(L.qbnn_block_chain_i8_multi(step[1], M, 0, B, step[2], step[3], p["a_hi"], 1, st))
+        with timed("ensemble head"):
+            _lib.check(L.qbnn_head_i8_multi(p["head"], M, st))
+        return p["probs"].clone()
+
     def forward_mc(self, x, record=None):
         n = len(self.ensemble)
         idx = [(_MC.sample_begin + i) % n for i in range(_MC.samples)]
+        if record is None and self.fused_members and x.device.type == "cuda" and len(set(idx)) == len(idx):
+            return self._forward_members_fused(idx, x)
         graphed = (record is None and self.use_graphs and x.device.type == "cuda" and len(idx) > 1 and
                    all(self._graphs.get((j, tuple(x.shape), x.dtype, x.device.index)) for j in idx))
         if not graphed:
@@ -421,7 +531,8 @@ class Network(nn.Module):
         for st in self._streams:
             st.wait_stream(main)
         for i, j in enumerate(idx):
-            st = self._streams[i % len(self._streams)]
+            st = self._streams[j % len(self._streams)]      # by MEMBER: two replays of one member's graph (samples > members) share its
+                                                            # static buffers and must not run concurrently
             with torch.cuda.stream(st):
                 outs[i] = self._member_forward(j, x)
                 outs[i].record_stream(main)

@@ -737,6 +737,24 @@ def test_ensemble_16_members_full_batch_against_oracle(golden_ensemble):
     assert torch.equal(part, probs[9:14])
     mean = q.mc_predict(net, xc, n, 0)
     np.testing.assert_allclose(mean.cpu().numpy(), ref.mean(0), rtol=RTOL, atol=1e-7)
+    # the per-member launch chains (captured graphs on side streams) give the same bits as the fused multi-call launches
+    net.fused_members = False
+    for _ in range(2):
+        with q.mc_context(n, 0, 0):
+            assert torch.equal(net.forward_mc(xc), probs)
+    with q.mc_context(n + 3, 0, 0):                                 # more samples than members: the round-robin wraps
+        wrap = net.forward_mc(xc)
+    assert torch.equal(wrap[:n], probs) and torch.equal(wrap[n:], probs[:3])
+    net.fused_members = True
+    with q.mc_context(3, 0, 14):                                    # wraps inside a fused call: members 14, 15, 0
+        assert torch.equal(net.forward_mc(xc), torch.cat([probs[14:], probs[:1]]))
+    xr = torch.randn(37, 3, 32, 32, generator=torch.Generator().manual_seed(9)).cuda()      # ragged batch through the fused launches
+    with q.mc_context(n, 0, 0):
+        pr = net.forward_mc(xr)
+    net.fused_members = False
+    with q.mc_context(n, 0, 0):
+        assert torch.equal(net.forward_mc(xr), pr)
+    net.fused_members = True
     net.counter = 0
     for i in range(n):
         np.testing.assert_allclose(net(xc).cpu().numpy(), ref[i], rtol=RTOL, atol=1e-8)
