@@ -324,7 +324,7 @@ def main():
                 "int8_TOPS_per_gpu": round(value / world * 40.203e9 * a.batch / 256 / 1e12, 1)}
 
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline and wl["cpu_baseline"]:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and wl["cpu_baseline"]:      # the CPU leg runs at N = 1 only
         cpu = cpu_baseline(a, g, x_host, seed)
         # the oracle's sample 0 doubles as an in-run parity check of the GPU result
         with q.mc_context(1, seed, 0):

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Round-end evidence: bench line, rocprofv3 kernel stats of the same command, HBM-traffic and utilisation counters.
+# usage (GPU box, repo root): tools/profile_round.sh [round tag, default r02]
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 timeout 300 python3 bench.py --steps 20 --warmup 5 > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
@@ -8,8 +10,14 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/fina
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/final/pmc_w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d gpurun_out/final/pmc_a -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/final/pmc_b -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-python3 - <<'PY'
-import csv, glob, collections, json, shutil
+QBNN_ROUND=$R python3 - <<'PY'
+import csv, glob, collections, json, shutil, hashlib, os
+R = os.environ.get('QBNN_ROUND', 'r02')
+def src_sha():
+    h = hashlib.sha256()
+    for f in ('qbnn_kernels.hip', 'qbnn_rng.cuh', 'qbnn_eps_table.h'):
+        h.update(open(os.path.join('quantised_bayesian_nets_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:16]
 def bench_key(k):
     rules = [("block_chain_ws_kernel<ConvCfg<24, 24", "stem + block_chain_i8 x2 32x32 c24"), ("block_chain_pp_kernel<ConvCfg<48", "block_chain_i8 x1 16x16 c48"),
              ("block_chain_ws_kernel<ConvCfg<48", "block_chain_i8 x1 16x16 c48"), ("block_chain_ald_kernel<ConvCfg<96", "block_chain_i8 x1 8x8 c96"),
@@ -39,7 +47,8 @@ for k, v in raw.items():
     if bk:
         by_key[bk] = v["hbm_bytes_per_launch_corrected"]
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1` (S=100, B=256); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section)",
-           "by_bench_key": by_key, "raw": raw}, open("gpurun_out/final/r01_pmc_traffic.json", "w"), indent=1)
+           "kernel_source_sha16": src_sha(), "workload": "resnet_bbb", "samples": 100, "batch": 256,
+           "by_bench_key": by_key, "raw": raw}, open("gpurun_out/final/%s_pmc_traffic.json" % R, "w"), indent=1)
 print("HBM bytes per step:", sum(by_key.values()) / 1e9, "GB")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for part in "ab":
@@ -57,10 +66,10 @@ for k, c in acc.items():
         v["lds_active_frac"] = v.get("SQ_LDS_IDX_ACTIVE", 0) / (cyc * 256)
         v["lds_conflict_share"] = v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1), 1)
     util[bench_key(k) or k[:60]] = v
-json.dump(util, open("gpurun_out/final/r01_pmc_util.json", "w"), indent=1)
+json.dump(util, open("gpurun_out/final/%s_pmc_util.json" % R, "w"), indent=1)
 for k, v in sorted(util.items(), key=lambda kv: -kv[1].get("shader_cycles", 0))[:10]:
     print("%-40s cyc %8.0f VALU %5.1f%% MFMA %5.1f%% LDS %5.1f%%" % (k, v.get("shader_cycles", 0), 100 * v.get("valu_issue_frac(4cyc/instr)", 0), 100 * v.get("mfma_busy_frac", 0), 100 * v.get("lds_active_frac", 0)))
 for f in glob.glob("gpurun_out/final/stats/*/*kernel_stats.csv"):
-    shutil.copy(f, "gpurun_out/final/r01_kernel_stats.csv")
+    shutil.copy(f, "gpurun_out/final/%s_kernel_stats.csv" % R)
 PY
 cat gpurun_out/final/bench.json
