@@ -111,7 +111,8 @@ int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w
                       const float* bias, const uint8_t* res, int64_t res_sample_stride, uint8_t* y,
                       int64_t y_sample_stride, int32_t n_samples, const qbnn_conv_desc* host_desc, void* stream);
 
-/* A chain of 1 or 2 identity BasicBlocks (models_bbb.py:170-183, no shortcut conv) fused in one persistent kernel:
+/* A chain of identity BasicBlocks (models_bbb.py:170-183, no shortcut conv) fused in one persistent kernel -- 1 or 2 blocks at
+ * 24 / 48 channels (the blocks' weights stay in LDS), 1 block per call at 96 / 192 channels (its weights stream through LDS):
  *   per block: stem.0 ConvReLU2d -> clamp -> stem.3 Conv2d -> clamp -> Add(block input) -> clamp -> ReLU -> clamp.
  * Activations stay in LDS between the convs; HBM traffic is one read of x and one write of y per image.
  * Same results as the corresponding sequence of qbnn_conv2d_i8_mc calls. */
@@ -123,14 +124,7 @@ typedef struct qbnn_block_desc {
   float s_wb; int32_t z_wb;
   float s_b; int32_t z_b;
   float s_o; int32_t z_o;                                              /* add.add.scale / zero_point                  */
-  const uint8_t* add_lut;   /* optional: device copy of qbnn_build_add_lut_host(s_b, z_b, s_res, z_res, s_o, z_o, a_hi, 1);
-                               NULL = compute the add arithmetically.  All blocks of a call must agree. */
 } qbnn_block_desc;
-
-/* Host helper: tabulate Add -> clamp -> ReLU -> clamp of a BasicBlock (models_bbb.py:179-182) for every pair
- * (conv output q, residual r) in [0,127]^2: host_out[q * 128 + r] = q_out - z_o (centred != 0) or q_out. */
-int qbnn_build_add_lut_host(float s_y, int32_t z_y, float s_r, int32_t z_r, float s_o, int32_t z_o, int32_t a_hi,
-                            int32_t centred, uint8_t* host_out);
 
 int qbnn_block_chain_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x, int32_t z_x, int32_t B, int32_t H,
                            int32_t C, int32_t a_hi, const qbnn_block_desc* host_blocks, int32_t n_blocks, uint8_t* y,

@@ -41,7 +41,7 @@ class BlockDesc(C.Structure):
                 ("s_wa", C.c_float), ("z_wa", C.c_int32), ("s_a", C.c_float), ("z_a", C.c_int32),
                 ("w_b", C.c_void_p), ("w_b_sample_stride", C.c_int64), ("bias_b", C.c_void_p),
                 ("s_wb", C.c_float), ("z_wb", C.c_int32), ("s_b", C.c_float), ("z_b", C.c_int32),
-                ("s_o", C.c_float), ("z_o", C.c_int32), ("add_lut", C.c_void_p)]
+                ("s_o", C.c_float), ("z_o", C.c_int32)]
 
 
 class DownDesc(C.Structure):
@@ -75,7 +75,7 @@ class HeadCall(C.Structure):
 
 
 EXPORTS = ["qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_conv2d_i8_mc",
-           "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi", "qbnn_build_add_lut_host",
+           "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_conv2d_i8_generic_mc", "qbnn_conv2d_i8_generic_scalar_mc", "qbnn_dropout_q_mc", "qbnn_maxpool2_q_mc",
            "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
            "qbnn_conv2d_f32_mc", "qbnn_conv2d_f32_fused_mc", "qbnn_conv2d_f32_blocks", "qbnn_observe_partials_f32_mc", "qbnn_affine_f32_mc", "qbnn_pool2d_f32_mc", "qbnn_flatten_nchw_f32_mc", "qbnn_softmax_f32_mc", "qbnn_observe_f32_mc", "qbnn_fake_quant_f32_mc", "qbnn_sample_weights_f32_strided", "qbnn_sample_weights_f32_ohwi",
@@ -119,7 +119,6 @@ def lib():
         L.qbnn_linear_f32_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp]
         L.qbnn_classification_metrics.argtypes = [vp, vp, i32, i32, vp, vp]
         L.qbnn_regression_metrics.argtypes = [vp, vp, vp, i32, vp, vp]
-        L.qbnn_build_add_lut_host.argtypes = [f, i32, f, i32, f, i32, i32, i32, vp]
         L.qbnn_flatten_nchw_mc.argtypes = [vp, i64, i32, i32, i32, vp, i64, i32, vp]
         L.qbnn_quantize_input_nchw.argtypes = [vp, i32, i32, i32, i32, f, i32, i32, vp, vp]
         L.qbnn_im2col3x3_c3.argtypes = [vp, i32, i32, i32, i32, vp, vp]

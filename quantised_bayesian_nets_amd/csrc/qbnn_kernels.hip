@@ -259,8 +259,6 @@ struct QAdd {              // BasicBlock Add + ReLU (models_bbb.py:179-182)
   float dl_r;                      // s_r z_r + nzs_r exactly (see QConv::dl_y): dequantises the CENTRED residual byte directly
   float inv_s_o; int z_o;          // add output qparams
   float vhi;                       // min(255, a_hi) - z_o ; lower bound is 0 (ReLU: q >= z_o)
-  const uint8_t* lut;              // optional 128x128 table of the whole add (qbnn_build_add_lut_host), device memory
-  int z_y;                         // zero point of the conv output that indexes the table rows
 };
 
 #define QBNN_MAGIC 12582912.0f     // 1.5 * 2^23: (v + MAGIC) has rne(v) in its low mantissa bits for |v| < 2^22
@@ -808,19 +806,9 @@ QBNN_EXPORT int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* layers, i
 }
 
 // =====================================================================================
-// conv_lds: the conv core of the fused kernels.  Weights reach the CU ONCE per workgroup: the workgroup's waves DMA
-// them (global_load_lds, 1 KiB fragment tile per wave-instruction, no VGPRs) into a two-slab LDS ring; every wave
-// then reads its fragments with ds_read_b128.  (Fetching them per wave from L2, as the layer-level kernel does,
-// moves 8x the bytes into the CU -- as many cycles as the MFMAs themselves.)
-//   protocol per slab i:   __syncthreads()  [slab i landed (vmcnt(0)), every wave is done with the other buffer,
-//                                            and -- for i == 0 -- the input tile written by the previous phase]
-//                          DMA slab i+1 (or `prefetch_next`: slab 0 of the next conv) into the other buffer
-//                          `after_first_barrier()` once (caller's own prefetch loads)
-//                          MFMAs of slab i
-//   requires NPASS <= NWAVES (one pass per wave, accumulators live across slabs).
+// LDS-DMA helpers of the fused kernels: weights reach a CU ONCE per workgroup -- its waves DMA them (global_load_lds, 1 KiB
+// fragment tile per wave-instruction, no VGPRs) into LDS; every wave then reads its fragments with ds_read_b128.
 // =====================================================================================
-struct WRing { uint8_t* buf[2]; int cur; };
-
 // Barrier that publishes LDS-DMA data.  __syncthreads() alone is NOT enough: at workgroup scope the compiler's release
 // fence waits for LDS traffic only (lgkmcnt), and global_load_lds completes on the vector-memory counter -- without
 // the explicit vmcnt(0) a wave could pass the barrier while its own share of the slab is still in flight.
@@ -838,243 +826,6 @@ __device__ __forceinline__ void dma_slab(uint8_t* dst, const int8_t* wq, int sla
     __builtin_amdgcn_global_load_lds(wq + ((int64_t)(nt * C::KS + slab * C::SLK + u) * 64 + lane) * 16,
                                      (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
   }
-}
-
-template <class C, class Epi, int NWAVES, class FNext, class FHook>
-__device__ __forceinline__ void conv_lds(const uint8_t* tile, WRing& ring, const int8_t* wq, const float* bias_lds, const QConv& p,
-                                         Epi& epi, int wave, int lane, FNext prefetch_next, FHook after_first_barrier) {
-  static_assert(C::NPASS <= NWAVES || C::ROWREUSE, "conv_lds: one pass per wave unless the whole conv is one slab");
-  static_assert(C::SLK % C::KCHUNK == 0, "k-chunks must not straddle weight slabs");
-  const int r = lane & 31, h = lane >> 5;
-  const bool active = wave < C::NPASS;
-  const int pass = active ? wave : 0;
-  const int mblk = pass / C::NBLKS, nblk = pass - mblk * C::NBLKS;
-  // bias of this pass's channels -> registers.  The table is written once at kernel start (a barrier has passed
-  // since); reading it here, BEFORE any LDS-DMA of this conv is in flight, keeps the compiler from guarding the
-  // read with s_waitcnt vmcnt(0).
-  float4 b4[C::NB][4];
-#pragma unroll
-  for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
-      b4[nb][g4] = *reinterpret_cast<const float4*>(bias_lds + (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
-    }
-  QBNN_INNER_T0();
-
-  if constexpr (C::ROWREUSE) {
-    // ---- 32-pixel-wide maps (layer 1): one slab = the whole conv; one M-tile = one output row.  All 9 weight
-    // fragments and the MB+2 input-row fragments are loaded once; the 9 MFMAs of row mb are followed in program
-    // order by the epilogue of row mb-1, so the matrix pipe works on row mb while the vector pipe requantises mb-1.
-    static_assert(C::NSLAB == 1 && C::USE_ONES, "row-reuse path");
-    dma_barrier();
-    QBNN_INNER_AT(0);
-    prefetch_next(ring.buf[ring.cur ^ 1]);
-    after_first_barrier();
-    const uint8_t* wl = ring.buf[ring.cur] + lane * 16;
-    ring.cur ^= 1;
-    if (!active) return;
-    constexpr int NR = C::MB + C::KSZ - 1;
-    v4i w[C::KS];
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wl + ks * 1024);
-    for (int pass_ = wave; pass_ < C::NPASS; pass_ += NWAVES) {
-    const int m0 = pass_ * C::MB * 32;
-    const int g = m0 / (C::HO * C::HO), oh0 = (m0 % (C::HO * C::HO)) / C::HO;
-    const uint8_t* base = tile + g * C::TILE_BYTES + ((oh0 + C::OFF0) * C::TW + r + C::OFF0) * C::PIXB + 16 * h;
-    v4i x[NR][C::SPR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j)
-#pragma unroll
-      for (int t = 0; t < C::SPR; ++t) {
-        const v2i lo = *reinterpret_cast<const v2i*>(base + j * C::PITCH + t * 32);
-        const v2i hi = *reinterpret_cast<const v2i*>(base + j * C::PITCH + t * 32 + 8);
-        x[j][t] = v4i{lo.x, lo.y, hi.x, hi.y};
-      }
-    v16i acc[C::MB];
-    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int mb = 0; mb <= C::MB; ++mb) {
-      if (mb < C::MB) {
-#pragma unroll
-        for (int kh = 0; kh < C::KSZ; ++kh)
-#pragma unroll
-          for (int t = 0; t < C::SPR; ++t)
-            acc[mb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * C::SPR + t], x[mb + kh][t], (kh == 0 && t == 0) ? zero16 : acc[mb], 0, 0, 0);
-      }
-      if (mb > 0) {
-        const int e = mb - 1;
-        const int rv = acc[e][C::ONES_REG];
-        const int ro = __shfl_xor(rv, 32);
-        const int zwr = p.z_w * (h ? ro : rv);
-        const int po = epi.pixel(m0 + e * 32 + r);
-        uint32_t pre[4];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-          if (8 * g4 < C::COUT) pre[g4] = epi.load(po, 8 * g4 + 4 * h);
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          if (8 * g4 >= C::COUT) continue;
-          const float4 bb = b4[0][g4];
-          const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(acc[e][4 * g4 + 0] - zwr)) * p.mult;
-          const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(acc[e][4 * g4 + 1] - zwr)) * p.mult;
-          const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(acc[e][4 * g4 + 2] - zwr)) * p.mult;
-          const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(acc[e][4 * g4 + 3] - zwr)) * p.mult;
-          epi.store(po, 8 * g4 + 4 * h, v0, v1, v2, v3, pre[g4]);
-        }
-      }
-#ifndef QBNN_NO_SCHED_HINT
-      if (mb > 0 && mb < C::MB) {
-        // in-order issue: the epilogue VALU of row mb-1 only hides under the (dependent) MFMAs of row mb if it sits
-        // between them in program order -- 1 MFMA : k VALU
-#pragma unroll
-        for (int i = 0; i < C::KS; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, Epi::VALU_PER_MFMA, 0);
-        }
-      }
-#endif
-    }
-    }
-    QBNN_INNER_AT(2);
-    QBNN_INNER_FLUSH();
-    return;
-  } else {
-    const uint8_t* ap[C::MB];
-#pragma unroll
-    for (int mb = 0; mb < C::MB; ++mb) {
-      const int m = (mblk * C::MB + mb) * 32 + r;
-      const int g = m / (C::HO * C::HO), rem = m % (C::HO * C::HO);
-      const int oh = rem / C::HO, ow = rem % C::HO;
-      ap[mb] = tile + g * C::TILE_BYTES + ((oh * C::STRIDE + C::OFF0) * C::TW + ow * C::STRIDE + C::OFF0) * C::PIXB + 16 * h;
-    }
-    v16i acc[C::MB][C::NB];
-    int rsum[C::MB];
-#pragma unroll
-    for (int mb = 0; mb < C::MB; ++mb) {
-      rsum[mb] = 0;
-#pragma unroll
-      for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0;
-    }
-    constexpr int U = C::KCHUNK, CPS = C::SLK / U;         // chunks per slab
-    struct Frags { v4i w[U][C::NB]; v4i x[U][C::MB]; };
-#pragma unroll
-    for (int slab = 0; slab < C::NSLAB; ++slab) {
-      dma_barrier();
-      QBNN_INNER_AT(0);
-      uint8_t* other = ring.buf[ring.cur ^ 1];
-      if (slab + 1 < C::NSLAB) dma_slab<C, NWAVES>(other, wq, slab + 1, wave, lane);
-      else prefetch_next(other);
-      if (slab == 0) after_first_barrier();
-      const uint8_t* wl = ring.buf[ring.cur] + ((nblk * C::NB) * C::SLK * 64 + lane) * 16;
-      ring.cur ^= 1;
-      if (active) {
-        // fragments of chunk c+1 (LDS -> VGPR) are in flight while the MFMAs of chunk c issue
-        auto load_chunk = [&](Frags& f, int c) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int ks = slab * C::SLK + c * U + u;
-#pragma unroll
-            for (int nb = 0; nb < C::NB; ++nb) f.w[u][nb] = *reinterpret_cast<const v4i*>(wl + (nb * C::SLK + c * U + u) * 1024);
-#pragma unroll
-            for (int mb = 0; mb < C::MB; ++mb) {
-              f.x[u][mb] = load_xfrag<C>(ap[mb] + C::step_off(ks));
-            }
-          }
-        };
-        auto mfma_chunk = [&](const Frags& f, int c) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int ks = slab * C::SLK + c * U + u;
-#pragma unroll
-            for (int mb = 0; mb < C::MB; ++mb) {
-              if (!C::USE_ONES) {
-                const int m0 = (h ? C::piece_valid(ks, 1, 0) : C::piece_valid(ks, 0, 0)) ? 0x01010101 : 0;
-                const int m1 = (h ? C::piece_valid(ks, 1, 1) : C::piece_valid(ks, 0, 1)) ? 0x01010101 : 0;
-                int rs_ = rsum[mb];
-                rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].x, m0, rs_, false);
-                rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].y, m0, rs_, false);
-                rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].z, m1, rs_, false);
-                rs_ = __builtin_amdgcn_sdot4(f.x[u][mb].w, m1, rs_, false);
-                rsum[mb] = rs_;
-              }
-#pragma unroll
-              for (int nb = 0; nb < C::NB; ++nb) {
-                acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[u][nb], f.x[u][mb], acc[mb][nb], 0, 0, 0);
-              }
-            }
-          }
-        };
-        Frags f0, f1;
-        load_chunk(f0, 0);
-#pragma unroll
-        for (int c = 0; c < CPS; ++c) {
-          Frags& cur = (c & 1) ? f1 : f0;
-          Frags& nxt = (c & 1) ? f0 : f1;
-          if (c + 1 < CPS) load_chunk(nxt, c + 1);
-          mfma_chunk(cur, c);
-        }
-      }
-      QBNN_INNER_AT(1);
-    }
-    if (!active) return;
-#pragma unroll
-    for (int mb = 0; mb < C::MB; ++mb) {
-      int R;
-      if (C::USE_ONES) {
-        const int rv = acc[mb][C::ONES_TILE % C::NB][C::ONES_REG];
-        const int ro = __shfl_xor(rv, 32);
-        R = h ? ro : rv;
-      } else {
-        R = rsum[mb] + __shfl_xor(rsum[mb], 32);
-      }
-      const int zwr = p.z_w * R;
-      const int po = epi.pixel((mblk * C::MB + mb) * 32 + r);
-#pragma unroll
-      for (int nb = 0; nb < C::NB; ++nb) {
-        uint32_t pre[4];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
-          pre[g4] = epi.load(po, (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h);
-        }
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          if (C::COUT % 32 != 0 && nb * 32 + 8 * g4 >= C::COUT) continue;
-          const int c0 = (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * h;
-          const float4 bb = b4[nb][g4];
-          const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(acc[mb][nb][4 * g4 + 0] - zwr)) * p.mult;
-          const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(acc[mb][nb][4 * g4 + 1] - zwr)) * p.mult;
-          const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(acc[mb][nb][4 * g4 + 2] - zwr)) * p.mult;
-          const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(acc[mb][nb][4 * g4 + 3] - zwr)) * p.mult;
-          epi.store(po, c0, v0, v1, v2, v3, pre[g4]);
-        }
-      }
-    }
-    QBNN_INNER_AT(2);
-    QBNN_INNER_FLUSH();
-  }
-}
-
-// conv core selection for the fused kernels
-template <class C, class Epi, int NWAVES, class FNext, class FHook>
-__device__ __forceinline__ void conv_any(const uint8_t* tile, WRing& ring, const int8_t* wq, const float* bias_lds, const QConv& p,
-                                         Epi& epi, int wave, int lane, FNext prefetch_next, FHook after_first_barrier) {
-  if constexpr (C::RING) {
-    conv_lds<C, Epi, NWAVES>(tile, ring, wq, bias_lds, p, epi, wave, lane, prefetch_next, after_first_barrier);
-  } else {
-    __syncthreads();                 // input tile of this conv complete
-    prefetch_next(ring.buf[ring.cur ^ 1]);
-    ring.cur ^= 1;
-    after_first_barrier();
-    conv_passes<C, Epi, NWAVES>(tile, wq, bias_lds, p, epi, wave, lane);
-  }
-}
-template <class C, int NWAVES>
-__device__ __forceinline__ void dma_slab_if_ring(uint8_t* dst, const int8_t* wq, int wave, int lane) {
-  if constexpr (C::RING) dma_slab<C, NWAVES>(dst, wq, 0, wave, lane);
 }
 
 // ---- epilogue functors -----------------------------------------------------------------------------------------
@@ -1160,32 +911,6 @@ struct EpiTileResInPlace {
   }
 };
 
-// (d) as (c), with the whole Add + ReLU looked up in the LDS copy of the block's 128x128 table:
-//     row = conv output q (centred byte q' = q - z_y), column = residual r (centred byte r' = r - z_r).
-template <int HO, int PIXB, int TILE_BYTES>
-struct EpiTileResLut {
-  static constexpr int VALU_PER_MFMA = 13;
-  uint8_t* xt; const uint8_t* lut0;      // lut0 = table + (z_y << 7) + z_r : indexable by the centred bytes
-  QConv p;
-  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, PIXB, TILE_BYTES>(m, 0); }
-  __device__ __forceinline__ uint32_t load(int po, int c0) const {
-    return *reinterpret_cast<const uint32_t*>(xt + po + c0);
-  }
-  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rqu) const {
-    uint32_t* o = reinterpret_cast<uint32_t*>(xt + po + c0);
-    const int rq = (int)rqu;
-    const int q0 = (__float_as_int(med3f(v0, p.vlo, p.vhi) + QBNN_MAGIC) << 24) >> 24;
-    const int q1 = (__float_as_int(med3f(v1, p.vlo, p.vhi) + QBNN_MAGIC) << 24) >> 24;
-    const int q2 = (__float_as_int(med3f(v2, p.vlo, p.vhi) + QBNN_MAGIC) << 24) >> 24;
-    const int q3 = (__float_as_int(med3f(v3, p.vlo, p.vhi) + QBNN_MAGIC) << 24) >> 24;
-    const uint32_t o0 = lut0[(q0 << 7) + ((rq << 24) >> 24)];
-    const uint32_t o1 = lut0[(q1 << 7) + ((rq << 16) >> 24)];
-    const uint32_t o2 = lut0[(q2 << 7) + ((rq << 8) >> 24)];
-    const uint32_t o3 = lut0[(q3 << 7) + (rq >> 24)];
-    *o = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
-  }
-};
-
 // ---- single-conv kernel (layer-level C ABI entry) ---------------------------------------------------------------
 struct ConvArgs {
   const uint8_t* x; int64_t x_ss;
@@ -1241,29 +966,6 @@ static int launch_conv(const ConvArgs& a, int n_samples, bool has_res, hipStream
   return check_launch("qbnn_conv2d_i8_mc");
 }
 
-// The quantised residual add of a BasicBlock is a pure function of two 7-bit integers:
-//   out[q][r] = max(min(clamp(z_o + rne((fma(s_y, q, -z_y s_y) + fma(s_r, r, -z_r s_r)) * (1/s_o)), 0, 255), a_hi), z_o) - z_o_centre
-// (quantized::add -> clamp_activation -> ReLU -> clamp_activation, models_bbb.py:179-182).  Tabulating it (16 KiB, built
-// once per block on the host with exactly the arithmetic of the epilogue functors) replaces ~8 VALU operations per
-// output element by one LDS byte read.  centred != 0: entries hold (q_o - z_o) as int8, else q_o.
-QBNN_EXPORT int qbnn_build_add_lut_host(float s_y, int32_t z_y, float s_r, int32_t z_r, float s_o, int32_t z_o, int32_t a_hi,
-                                        int32_t centred, uint8_t* host_out) {
-  if (!host_out || a_hi < 1 || a_hi > 127) return fail(QBNN_E_INVALID, "qbnn_build_add_lut_host: bad argument%s");
-  const float nzs_y = (float)(-z_y) * s_y, nzs_r = (float)(-z_r) * s_r, inv = 1.0f / s_o;
-  for (int q = 0; q < 128; ++q)
-    for (int r = 0; r < 128; ++r) {
-      const float da = fmaf(s_y, (float)q, nzs_y), db = fmaf(s_r, (float)r, nzs_r);
-      float t = (da + db) * inv;
-      t = t < -1.0e9f ? -1.0e9f : (t > 1.0e9f ? 1.0e9f : t);
-      int o = z_o + (int)lrintf(t);
-      o = o < 0 ? 0 : (o > 255 ? 255 : o);
-      o = o > a_hi ? a_hi : o;
-      o = o < z_o ? z_o : o;
-      host_out[q * 128 + r] = (uint8_t)(centred ? (o - z_o) : o);
-    }
-  return QBNN_OK;
-}
-
 // =====================================================================================
 // Fused BasicBlock kernels (models_bbb.py:170-183): persistent workgroups, activations never leave LDS between
 // the block's convs.
@@ -1301,176 +1003,6 @@ struct ChainArgs {
 // m+1's.  NM = 1 is the ordinary launch (same code, argument block 0).
 #define QBNN_FUSED_CALLS 8            // argument blocks per launch (kernel arguments are limited to 4 KiB)
 template <class A, int NM> struct ArgsArr { A m[NM]; };
-
-// workgroup size per geometry: 256 threads (4 waves) where two workgroups fit a CU -- they run out of phase, so one's
-// MFMA phase overlaps the other's epilogue; 512 elsewhere
-template <class C, int NBLK> struct ChainThreads {
-  static constexpr int one = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * (C::RING ? C::SLAB_BYTES : 16) + NBLK * (2 * C::COUT * 4 + 16384);
-  static constexpr int base = one - NBLK * 16384;     // without the optional add tables
-  static constexpr int v = (2 * base <= 160 * 1024 && C::NPASS <= 4) ? 256 : ((2 * one <= 160 * 1024 && C::ROWREUSE) ? 256 : 512);
-  static constexpr int per_cu = v == 256 ? ((3 * base <= 160 * 1024) ? 3 : 2) : 1;
-};
-
-template <class C, int NBLK, int NTHR>
-__global__ __launch_bounds__(NTHR, (NTHR == 256 ? ChainThreads<C, NBLK>::per_cu : 2)) void block_chain_i8_kernel(const ChainArgs<NBLK> a) {
-  constexpr int NWV = NTHR / 64;
-  static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
-  uint8_t* xt = smem;
-  uint8_t* tt = smem + TILES;
-  WRing ring;
-  constexpr int RSLAB = C::RING ? C::SLAB_BYTES : 16;
-  ring.buf[0] = smem + 2 * TILES;
-  ring.buf[1] = ring.buf[0] + RSLAB;
-  ring.cur = 0;
-  float* bias_lds = reinterpret_cast<float*>(ring.buf[1] + RSLAB);        // [NBLK][2][COUT]
-  uint8_t* lut_lds = reinterpret_cast<uint8_t*>(bias_lds + NBLK * 2 * C::COUT);   // [NBLK][128*128] when the blocks carry tables
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
-  const bool use_lut = a.blk[0].add.lut != nullptr;
-  if (use_lut) {
-#pragma unroll
-    for (int k = 0; k < NBLK; ++k)
-      for (int i = tid; i < 1024; i += NTHR)
-        reinterpret_cast<v4i*>(lut_lds + k * 16384)[i] = reinterpret_cast<const v4i*>(a.blk[k].add.lut)[i];
-  }
-
-  constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
-  constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
-  const int groups = (a.B + C::G - 1) / C::G;
-  const int n_items = a.n_samples * groups;
-
-  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, NTHR>(xt, tid);
-  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, NTHR>(tt, tid);
-#pragma unroll
-  for (int k = 0; k < NBLK; ++k) {
-    load_bias<C::COUT, NTHR>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
-    load_bias<C::COUT, NTHR>(bias_lds + (2 * k + 1) * C::COUT, a.blk[k].b.bias, tid);
-  }
-  __syncthreads();      // bias table + halos visible: conv_lds reads the bias BEFORE its first barrier
-
-  // input prefetch registers.  The loads are unconditional (address clamped, value zeroed at use) and are issued
-  // right after a barrier, so the following barrier's vmcnt(0) finds them long landed.
-  v4i pre[PER_T];
-  auto fetch = [&](int item) {
-    const int s = item / groups, img0 = (item - s * groups) * C::G;
-    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
-#pragma unroll
-    for (int j = 0; j < PER_T; ++j) {
-      const int i = tid + j * NTHR;
-      const int g = i / CPI, rem = i - g * CPI;
-      const bool ok = (i < NCH) && (img0 + g < a.B);
-      const int64_t off = ok ? ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16 : 0;
-      pre[j] = *reinterpret_cast<const v4i*>(xs + off);
-    }
-  };
-  auto sample_of = [&](int item) { return item / groups; };
-
-  int item = blockIdx.x;
-  if (item < n_items) {
-    fetch(item);
-    dma_slab_if_ring<C, NWV>(ring.buf[ring.cur], a.blk[0].a.w + (int64_t)sample_of(item) * a.blk[0].a.w_ss, wave, lane);
-  }
-  QBNN_STAMP_DECL
-  for (; item < n_items; item += gridDim.x) {
-    const int s = item / groups, img0 = (item - s * groups) * C::G;
-    const int next = item + (int)gridDim.x;
-    QBNN_STAMP_START();
-    // ---- write-late: registers -> centred X tile interior
-    {
-      const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
-#pragma unroll
-      for (int j = 0; j < PER_T; ++j) {
-        const int i = tid + j * NTHR;
-        if (i < NCH) {
-          const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
-          const bool ok = img0 + g < a.B;
-          const v4i v = pre[j];
-          uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
-          *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
-          *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
-        }
-      }
-    }
-    QBNN_STAMP_AT(0);
-#pragma unroll
-    for (int k = 0; k < NBLK; ++k) {
-      const BlockParams& bp = a.blk[k];
-      {
-        EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{tt, bp.a};
-        conv_any<C, decltype(epi), NWV>(xt, ring, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane,
-            [&](uint8_t* dst) { dma_slab_if_ring<C, NWV>(dst, bp.b.w + (int64_t)s * bp.b.w_ss, wave, lane); },
-            [&]() { if (k == 0 && next < n_items) fetch(next); });
-      }
-      QBNN_STAMP_AT(2);
-      if (use_lut)
-      {
-        EpiTileResLut<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, lut_lds + k * 16384 + (bp.b.z_y << 7) + bp.add.z_r, bp.b};
-        conv_any<C, decltype(epi), NWV>(tt, ring, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane,
-            [&](uint8_t* dst) {
-              if (k + 1 < NBLK) dma_slab_if_ring<C, NWV>(dst, a.blk[k + 1 < NBLK ? k + 1 : 0].a.w + (int64_t)s * a.blk[k + 1 < NBLK ? k + 1 : 0].a.w_ss, wave, lane);
-              else if (next < n_items) dma_slab_if_ring<C, NWV>(dst, a.blk[0].a.w + (int64_t)sample_of(next) * a.blk[0].a.w_ss, wave, lane);
-            },
-            [&]() {});
-      }
-      else
-      {
-        EpiTileResInPlace<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, bp.b, bp.add};
-        conv_any<C, decltype(epi), NWV>(tt, ring, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane,
-            [&](uint8_t* dst) {
-              if (k + 1 < NBLK) dma_slab_if_ring<C, NWV>(dst, a.blk[k + 1 < NBLK ? k + 1 : 0].a.w + (int64_t)s * a.blk[k + 1 < NBLK ? k + 1 : 0].a.w_ss, wave, lane);
-              else if (next < n_items) dma_slab_if_ring<C, NWV>(dst, a.blk[0].a.w + (int64_t)sample_of(next) * a.blk[0].a.w_ss, wave, lane);
-            },
-            [&]() {});
-      }
-      QBNN_STAMP_AT(4);
-    }
-    __syncthreads();
-    QBNN_STAMP_AT(5);
-    // ---- X tile interior (centred by the last add's zero point) -> quint8 -> HBM
-    {
-      const uint32_t z4 = (uint32_t)a.blk[NBLK - 1].add.z_o * 0x01010101u;
-      uint8_t* ys = a.y + (int64_t)s * a.y_ss;
-      for (int i = tid; i < NCH; i += NTHR) {
-        const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
-        if (img0 + g < a.B) {
-          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
-          const v2i lo = *reinterpret_cast<const v2i*>(d), hi = *reinterpret_cast<const v2i*>(d + 8);
-          v4i v = {(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
-          *reinterpret_cast<v4i*>(ys + ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16) = v;
-        }
-      }
-    }
-    QBNN_STAMP_AT(6);
-    __syncthreads();      // X tile free for the next item's write-late
-    QBNN_STAMP_AT(7);
-  }
-#ifdef QBNN_STAMP
-  if (a.dbg && (tid & 63) == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(a.dbg + wave * 8 + i, st_acc[i]);
-#endif
-}
-
-template <class C, int NBLK>
-static int launch_block_chain(const ChainArgs<NBLK>& a, hipStream_t st) {
-  constexpr int NTHR = ChainThreads<C, NBLK>::v;
-  constexpr int LDS_BASE = 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * (C::RING ? C::SLAB_BYTES : 16) + NBLK * 2 * C::COUT * 4;
-  constexpr bool LUT_FITS = LDS_BASE + NBLK * 16384 <= 160 * 1024;
-  const bool want_lut = LUT_FITS && a.blk[0].add.lut != nullptr;
-  const int LDS = LDS_BASE + (want_lut ? NBLK * 16384 : 0);
-  ChainArgs<NBLK> a2 = a;
-  if (!want_lut) for (int k = 0; k < NBLK; ++k) a2.blk[k].add.lut = nullptr;
-  static_assert(LDS_BASE <= 160 * 1024, "LDS budget");
-  static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_i8_kernel<C, NBLK, NTHR>, attr, LUT_FITS ? LDS_BASE + NBLK * 16384 : LDS_BASE)) return rc_attr;
-  const int groups = (a.B + C::G - 1) / C::G;
-  const int n_items = a.n_samples * groups;
-  const int per_cu = NTHR == 256 ? ((160 * 1024) / LDS >= 3 ? 3 : ((160 * 1024) / LDS >= 2 ? 2 : 1)) : 1;
-  int grid = 256 * per_cu;
-  if (grid > n_items) grid = n_items;
-  hipLaunchKernelGGL((block_chain_i8_kernel<C, NBLK, NTHR>), dim3(grid), dim3(NTHR), LDS, st, a2);
-  return check_launch("qbnn_block_chain_i8_mc");
-}
 
 //                        CIN COUT K  S  HIN HALO G  MB NB
 using Cfg_c0      = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;    // layers.0 on the im2col tensor (K = 27 -> 32)
@@ -1558,132 +1090,9 @@ struct DownArgs {
   QConv s, a, b; QAdd add;
 };
 
-template <class CA, class CS, class CB>
-__global__ __launch_bounds__(BLK_THREADS) void block_down_i8_kernel(const DownArgs a) {
-  static_assert(CA::M == CS::M && CA::M == CB::M && CA::G == CS::G && CA::G == CB::G, "one work item, three convs");
-  static_assert(CA::COUT == CB::CIN && CA::COUT == CB::COUT && CS::COUT == CB::COUT && CA::HO == CB::HIN, "block geometry");
-  static_assert(CA::TILE_BYTES == CS::TILE_BYTES && CA::CIN == CS::CIN && CA::HIN == CS::HIN, "shared input tile");
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr int XB = CA::G * CA::TILE_BYTES + CA::TILE_SLACK;
-  constexpr int TB = CB::G * CB::TILE_BYTES + CB::TILE_SLACK;
-  constexpr int SA = CA::RING ? CA::SLAB_BYTES : 16, SS = CS::RING ? CS::SLAB_BYTES : 16, SB = CB::RING ? CB::SLAB_BYTES : 16;
-  constexpr int SLAB = SA > SB ? (SA > SS ? SA : SS) : (SB > SS ? SB : SS);
-  constexpr int COUT = CB::COUT;
-  uint8_t* xt = smem;
-  uint8_t* tt = smem + XB;
-  uint8_t* sc = tt + TB;
-  WRing ring;
-  ring.buf[0] = sc + CB::OUT_BYTES;
-  ring.buf[1] = ring.buf[0] + SLAB;
-  ring.cur = 0;
-  float* bias_lds = reinterpret_cast<float*>(ring.buf[1] + SLAB);       // [3][COUT]: s, a, b
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
-
-  constexpr int CPR = CA::ROWB / 16, CPI = CA::HIN * CPR, NCH = CA::G * CPI;
-  constexpr int PER_T = (NCH + BLK_THREADS - 1) / BLK_THREADS;
-  const int groups = (a.B + CA::G - 1) / CA::G;
-  const int n_items = a.n_samples * groups;
-
-  zero_halo<CA::TW, CA::PIXB, CA::TILE_BYTES, CA::G, BLK_THREADS>(xt, tid);
-  zero_halo<CB::TW, CB::PIXB, CB::TILE_BYTES, CB::G, BLK_THREADS>(tt, tid);
-  load_bias<COUT, BLK_THREADS>(bias_lds, a.s.bias, tid);
-  load_bias<COUT, BLK_THREADS>(bias_lds + COUT, a.a.bias, tid);
-  load_bias<COUT, BLK_THREADS>(bias_lds + 2 * COUT, a.b.bias, tid);
-  __syncthreads();      // bias table + halos visible: conv_lds reads the bias BEFORE its first barrier
-
-  v4i pre[PER_T];
-  auto fetch = [&](int item) {
-    const int s = item / groups, img0 = (item - s * groups) * CA::G;
-    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
-#pragma unroll
-    for (int j = 0; j < PER_T; ++j) {
-      const int i = tid + j * BLK_THREADS;
-      const int g = i / CPI, rem = i - g * CPI;
-      const bool ok = (i < NCH) && (img0 + g < a.B);
-      const int64_t off = ok ? ((int64_t)(img0 + g) * CA::HIN) * CA::ROWB + (int64_t)rem * 16 : 0;
-      pre[j] = *reinterpret_cast<const v4i*>(xs + off);
-    }
-  };
-  int item = blockIdx.x;
-  if (item < n_items) {
-    fetch(item);
-    dma_slab_if_ring<CS, BLK_WAVES>(ring.buf[ring.cur], a.s.w + (int64_t)(item / groups) * a.s.w_ss, wave, lane);
-  }
-  for (; item < n_items; item += gridDim.x) {
-    const int s = item / groups, img0 = (item - s * groups) * CA::G;
-    const int next = item + (int)gridDim.x;
-    {
-      const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
-#pragma unroll
-      for (int j = 0; j < PER_T; ++j) {
-        const int i = tid + j * BLK_THREADS;
-        if (i < NCH) {
-          const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
-          const bool ok = img0 + g < a.B;
-          const v4i v = pre[j];
-          uint8_t* d = xt + g * CA::TILE_BYTES + (row + 1) * CA::PITCH + CA::row_chunk_off(within);
-          *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
-          *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
-        }
-      }
-    }
-    {
-      EpiDense<COUT, false> epi{sc, a.s, a.add};
-      conv_any<CS, decltype(epi), BLK_WAVES>(xt, ring, a.s.w + (int64_t)s * a.s.w_ss, bias_lds, a.s, epi, wave, lane,
-          [&](uint8_t* dst) { dma_slab_if_ring<CA, BLK_WAVES>(dst, a.a.w + (int64_t)s * a.a.w_ss, wave, lane); },
-          [&]() { if (next < n_items) fetch(next); });
-    }
-    {
-      EpiTile<CB::HIN, CB::PIXB, CB::TILE_BYTES> epi{tt, a.a};
-      conv_any<CA, decltype(epi), BLK_WAVES>(xt, ring, a.a.w + (int64_t)s * a.a.w_ss, bias_lds + COUT, a.a, epi, wave, lane,
-          [&](uint8_t* dst) { dma_slab_if_ring<CB, BLK_WAVES>(dst, a.b.w + (int64_t)s * a.b.w_ss, wave, lane); }, [&]() {});
-    }
-    {
-      EpiDense<COUT, true> epi{sc, a.b, a.add};
-      conv_any<CB, decltype(epi), BLK_WAVES>(tt, ring, a.b.w + (int64_t)s * a.b.w_ss, bias_lds + 2 * COUT, a.b, epi, wave, lane,
-          [&](uint8_t* dst) { if (next < n_items) dma_slab_if_ring<CS, BLK_WAVES>(dst, a.s.w + (int64_t)(next / groups) * a.s.w_ss, wave, lane); },
-          [&]() {});
-    }
-    __syncthreads();
-    {
-      constexpr int IMG_OUT = CB::HO * CB::HO * COUT;
-      uint8_t* ys = a.y + (int64_t)s * a.y_ss;
-      for (int i = tid; i < CB::M * COUT / 16; i += BLK_THREADS)
-        if (img0 + (i * 16) / IMG_OUT < a.B)
-          *reinterpret_cast<v4i*>(ys + (int64_t)img0 * IMG_OUT + (int64_t)i * 16) = reinterpret_cast<const v4i*>(sc)[i];
-    }
-    __syncthreads();
-  }
-}
-
-template <class CA, class CS, class CB>
-static int launch_block_down(const DownArgs& a, hipStream_t st) {
-  constexpr int SA = CA::RING ? CA::SLAB_BYTES : 16, SS = CS::RING ? CS::SLAB_BYTES : 16, SB = CB::RING ? CB::SLAB_BYTES : 16;
-  constexpr int SLAB = SA > SB ? (SA > SS ? SA : SS) : (SB > SS ? SB : SS);
-  constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + CB::OUT_BYTES + 2 * SLAB + 3 * CB::COUT * 4;
-  static_assert(LDS <= 160 * 1024, "LDS budget");
-  static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)block_down_i8_kernel<CA, CS, CB>, attr, LDS)) return rc_attr;
-  const int groups = (a.B + CA::G - 1) / CA::G;
-  const int n_items = a.n_samples * groups;
-  int grid = 256;
-  if (grid > n_items) grid = n_items;
-  hipLaunchKernelGGL((block_down_i8_kernel<CA, CS, CB>), dim3(grid), dim3(BLK_THREADS), LDS, st, a);
-  return check_launch("qbnn_block_down_i8_mc");
-}
-
 template <class CA, class CS, class CB, bool LDSW> static int launch_block_down_ws(const DownArgs& a, hipStream_t st);
-static bool no_dense() {
-  static const bool v = [] { const char* e = getenv("QBNN_NO_DENSE"); return e && e[0] == '1'; }();
-  return v;
-}
 static bool no_pingpong() {
   static const bool v = [] { const char* e = getenv("QBNN_NO_PINGPONG"); return e && e[0] == '1'; }();
-  return v;
-}
-// diagnostic switch (A/B timing): QBNN_FUSED_RING=1 routes every fused block through the ring kernels
-static bool ring_only() {
-  static const bool v = [] { const char* e = getenv("QBNN_FUSED_RING"); return e && e[0] == '1'; }();
   return v;
 }
 
@@ -1752,9 +1161,9 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
   hipStream_t st = (hipStream_t)stream;
   // (a ping-pong variant of this block -- phases W / M_a / E_sa / M_b / E_b on two 4-wave groups -- measured 15 % SLOWER
   //  than the weights-stationary kernel: five barrier intervals per image, each as long as the slower group's phase)
-  if (Cin == 24 && H == 32) return ring_only() ? launch_block_down<D24_a, D24_s, D24_b>(a, st) : launch_block_down_ws<D24_a, D24_s, D24_b, true>(a, st);
-  if (Cin == 48 && H == 16) return ring_only() ? launch_block_down<D48_a, D48_s, D48_b>(a, st) : launch_block_down_ws<D48_a, D48_s, D48_b, false>(a, st);
-  if (Cin == 96 && H == 8) return ring_only() ? launch_block_down<D96_a, D96_s, D96_b>(a, st) : launch_block_down_ws<D96_a, D96_s, D96_b, false>(a, st);
+  if (Cin == 24 && H == 32) return launch_block_down_ws<D24_a, D24_s, D24_b, true>(a, st);
+  if (Cin == 48 && H == 16) return launch_block_down_ws<D48_a, D48_s, D48_b, false>(a, st);
+  if (Cin == 96 && H == 8) return launch_block_down_ws<D96_a, D96_s, D96_b, false>(a, st);
   return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
 }
 
@@ -2843,15 +2252,6 @@ template <class CB> struct DownSC {
   static constexpr int BYTES = (CB::M * PITCH + 15) / 16 * 16;
 };
 
-// weights-stationary when the chain's weights fit next to the tiles, else the slab ring
-template <class C, int NBLK>
-static int launch_chain_auto(const ChainArgs<NBLK>& a, hipStream_t st) {
-  if constexpr (chain_ws_lds<C, NBLK>() <= 160 * 1024) {
-    if (!ring_only()) return launch_block_chain_ws<C, NBLK>(a, st);
-  }
-  return launch_block_chain<C, NBLK>(a, st);
-}
-
 template <class CA, class CS, class CB, bool LDSW, int NM = 1>
 __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const ArgsArr<DownArgs, NM> all) {
   const DownArgs& a = all.m[NM == 1 ? 0 : blockIdx.y];
@@ -3035,15 +2435,9 @@ static int launch_block_down_ws_multi(const DownArgs* arr, int n, hipStream_t st
 //                          CIN COUT K  S  HIN HALO G  MB NB
 using Blk_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;
 using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;
-using Blk_96  = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, true, 36, 16>;
 using ALD_96  = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;      // dense aliased-tile ring kernel
 using ALD_192 = ConvCfg<192, 192, 3, 1, 4, 1, 16, 2, 3, true, 36, 16>;
 using PP_48   = ConvCfg<48, 48, 3, 1, 16, 1, 1, 2, 2>;          // per wave group of the ping-pong kernel
-#ifdef QBNN_EXP_NSPLIT
-using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 4, 1, false, 36, 16>;
-#else
-using Blk_192 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false, 36, 16>;
-#endif
 
 template <int NBLK>
 static int build_chain_args(ChainArgs<NBLK>& a, const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t a_hi,
@@ -3067,7 +2461,6 @@ static int build_chain_args(ChainArgs<NBLK>& a, const uint8_t* x, int64_t x_ss, 
     if ((rc = fill_qconv(a.blk[k].b, b.w_b, b.w_b_sample_stride, b.bias_b, &d))) return rc;
     d.s_r = s_in; d.z_r = z_in; d.s_o = b.s_o; d.z_o = b.z_o;
     if ((rc = fill_qadd(a.blk[k].add, &d))) return rc;
-    a.blk[k].add.lut = b.add_lut; a.blk[k].add.z_y = b.z_b;
     s_in = b.s_o; z_in = b.z_o;
   }
   return QBNN_OK;
@@ -3092,24 +2485,21 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
     return launch_block_chain_ws<Blk_24, NBLK, true, true>(a, st);
   }
-  if (Cc == 24 && H == 32) return launch_chain_auto<Blk_24, NBLK>(a, st);
+  if (Cc == 24 && H == 32) return launch_block_chain_ws<Blk_24, NBLK>(a, st);
   if (Cc == 48 && H == 16) {
     if constexpr (chain_pp_lds<PP_48, NBLK>() <= 160 * 1024) {
-      if (!ring_only() && !no_pingpong() && ((B + PP_48::G - 1) / PP_48::G) % 2 == 0) return launch_block_chain_pp<PP_48, NBLK>(a, st);
+      if (!no_pingpong() && ((B + PP_48::G - 1) / PP_48::G) % 2 == 0) return launch_block_chain_pp<PP_48, NBLK>(a, st);
     }
-    return launch_chain_auto<Blk_48, NBLK>(a, st);
+    if constexpr (chain_ws_lds<Blk_48, NBLK>() <= 160 * 1024) return launch_block_chain_ws<Blk_48, NBLK>(a, st);
+    else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one 48-channel block per launch for this batch size%s");
   }
   if (Cc == 96 && H == 8) {
-    if constexpr (NBLK == 1) {
-      if (!ring_only() && !no_dense()) return launch_block_chain_ald<ALD_96, 8>(a, st);
-    }
-    return launch_block_chain<Blk_96, NBLK>(a, st);
+    if constexpr (NBLK == 1) return launch_block_chain_ald<ALD_96, 8>(a, st);
+    else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one block per launch at 96 channels (its weights stream through the LDS ring)%s");
   }
   if (Cc == 192 && H == 4) {
-    if constexpr (NBLK == 1) {
-      if (!ring_only() && !no_dense()) return launch_block_chain_ald<ALD_192, 8>(a, st);
-    }
-    return ring_only() ? launch_block_chain<Blk_192, NBLK>(a, st) : launch_block_chain_ws<Blk_192, NBLK, false>(a, st);
+    if constexpr (NBLK == 1) return launch_block_chain_ald<ALD_192, 8>(a, st);
+    else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one block per launch at 192 channels (its weights stream through the LDS ring)%s");
   }
   return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
 }

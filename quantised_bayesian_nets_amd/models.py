@@ -95,41 +95,24 @@ def run_down_block(blk, x):
     return MCQTensor(y, blk.add.add.scale, blk.add.add.zero_point)
 
 
-def _add_lut(blk, s_res, z_res, dev):
-    """Device copy of the block's 128x128 Add+ReLU table (built once per (block, residual qparams))."""
-    key = (float(s_res), int(z_res), str(dev))
-    cache = blk.__dict__.setdefault("_lut_cache", {})
-    if key not in cache:
-        cb = blk.stem[3]
-        host = np.zeros(16384, np.uint8)
-        a_hi = UINT_BOUNDS[blk.args.activation_precision][1]
-        _lib.check(_lib.lib().qbnn_build_add_lut_host(cb.scale, cb.zero_point, s_res, z_res, blk.add.add.scale, blk.add.add.zero_point,
-                                                      a_hi, 1, host.ctypes.data_as(C.c_void_p)))
-        cache[key] = torch.from_numpy(host).to(dev)
-    return cache[key]
-
-
-USE_ADD_LUT = False      # measured on MI355X: the table's random LDS byte reads cost more than the ~8 VALU ops/element they replace
-                         # (layer-1 chain 1.50 -> 1.76 ms); kept selectable for future layouts
-
-
 def run_identity_chain(blocks, x, stem=None):
-    """1 or 2 identity BasicBlocks (no shortcut conv) in ONE persistent fused kernel (qbnn_block_chain_i8_mc):
+    """Identity BasicBlocks (no shortcut conv) in ONE persistent fused kernel per call (qbnn_block_chain_i8_mc; 1 or 2 blocks at
+    24 / 48 channels, one block per launch at 96 / 192 -- longer lists are walked here):
     activations stay in LDS between stem.0, stem.3 and the residual add.  Same results as calling the blocks.
     `stem` = (layers.0 module, its sampled weights, im2col patches [B, 1024, 32], input scale): the network's first conv
     runs inside the same kernel (qbnn_stem_chain_i8_mc) and `x` only carries conv0's output qparams / shape."""
     S = _MC.samples
+    if stem is None and (len(blocks) > 2 or (len(blocks) == 2 and x.data.shape[4] >= 96)):
+        h = x
+        step = 1 if x.data.shape[4] >= 96 else 2
+        for i in range(0, len(blocks), step):
+            h = run_identity_chain(blocks[i:i + step], h)
+        return h
     dev = x.data.device if stem is None else stem[2].device
     descs = (_lib.BlockDesc * len(blocks))()
     keep = []
-    s_res, z_res = x.scale, x.zero_point
     for d, blk in zip(descs, blocks):
         assert len(blk.shortcut) == 0
-        if USE_ADD_LUT:
-            lut = _add_lut(blk, s_res, z_res, dev)
-            keep.append(lut)
-            d.add_lut = lut.data_ptr()
-        s_res, z_res = blk.add.add.scale, blk.add.add.zero_point
         ca, cb = blk.stem[0], blk.stem[3]
         wa, wb = ca.sample_weights(dev), cb.sample_weights(dev)
         pa, pb = ca._ensure_packed(dev), cb._ensure_packed(dev)
