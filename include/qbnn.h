@@ -65,9 +65,11 @@ int qbnn_pack_weights_host(const int8_t* host_src, int32_t cout, int32_t k, int3
  * normal_() -> quantize_per_tensor -> quantized::mul -> quantized::add -> clamp_weight
  * (conv_q.py:113-119, :198-205; linear_q.py:86-92, :160-167).
  *   mu_packed / sigma_packed : the layer's qint8 `weight` / `std` in `layout`
- *   eps for element i (OHWI flat index) of sample s comes from the Philox stream
- *     philox4x32_10(ctr = {i >> 2, layer_id, sample_begin + s, 0}, key = seed)[i & 3]
- *   unless eps_in != NULL: then eps_in[s * cout * k + i] (fp32) is used (parity mode).
+ *   the QUANTISED noise eps_q of element i (OHWI flat index) of sample s is drawn directly from its discrete distribution
+ *     (P(k) of clamp(rne(N(0,1) / NOISE_SCALE), -128, 127)) with one Philox word and Walker's alias table (csrc/qbnn_eps_table.h):
+ *     u = philox4x32_10(ctr = {i >> 2, layer_id, sample_begin + s, 0}, key = seed)[i & 3];  c = u >> 24;
+ *     eps_q = ((u & 0xffffff) < thr[c] ? c : alias[c]) - 128
+ *   unless eps_in != NULL: then the fp32 eps_in[s * cout * k + i] is quantised as the reference does (parity mode).
  *   w_out + s * w_sample_stride receives sample s in `layout`. */
 int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* sigma_packed, int32_t cout, int32_t k, int32_t krow,
                            int32_t layout, const qbnn_sample_params* host_params, uint64_t seed,
