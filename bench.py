@@ -115,7 +115,7 @@ def _wl_mlp_f32(a, world, q, load_golden):
     S = a.samples if a.samples > 0 else 10
     x_host = torch.randn(1000, in_dim, generator=torch.Generator().manual_seed(2))
     return dict(golden=None, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=False, cpu_baseline=False,
-                step=lambda m, x, S_, seed: q.mc_predict_regression(m, x, S_, seed), scaling="weak", dtype="f32",
+                step=lambda m, x, S_, seed: q.mc_predict_regression(m, x, S_, seed), scaling="weak", dtype="f32", graph=dict(regression=True),
                 metric="MC forward samples/sec, 4x100 MLP BBB fp32, 1000 rows", unit="MC samples/s",
                 describe="configs[0]: UCI-regression-shaped (in_dim %d) 4x100 MLP Bayes-by-backprop fp32, %d MC samples per GPU per step, 1000 rows" % (in_dim, S))
 
@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--prime", type=int, default=12, help="setup steps before the W warm-up steps (clock ramp, allocator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=0, help="oracle samples to time (0 = auto, about 10-30 s)")
+    ap.add_argument("--no-graph", action="store_true", help="mlp_f32 (the launch-bound workload: ~25 launches of microseconds): launch eagerly instead of replaying its captured HIP graph")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launcher test (no GPU, gloo): ranks rendezvous, all-reduce their rank, rank 0 prints one JSON line")
     a = ap.parse_args()
@@ -225,8 +226,12 @@ def main():
     x = x_host.cuda()
     S_local, S_global, seed = wl["units_per_gpu"], wl["units_global"], 3
 
+    graphed = None
+    if "graph" in wl and not a.no_graph:
+        graphed = q.GraphedPredictor(model, S_global, **wl["graph"])
+
     def step():
-        return step_fn(model, x, S_global, seed)
+        return graphed(x, seed) if graphed is not None else step_fn(model, x, S_global, seed)
 
     def fence():
         if use_dist:
@@ -351,7 +356,7 @@ def main():
                "higher_is_better": True, "scaling": wl["scaling"], "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
                "config": {"workload": wl["describe"], "samples_per_gpu": S_local, "global_samples": S_global, "batch": x_host.shape[0],
                           "image_samples_per_s": round(value * x_host.shape[0], 1), "parallelism": f"mc-sample-shard x{world}"},
-               "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "rccl": rccl, "rccl_ranks": world if use_dist else 0,
+               "graph_replay": graphed is not None, "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "rccl": rccl, "rccl_ranks": world if use_dist else 0,
                "kernels": kernels}
         print(json.dumps(out))
     if use_dist:

@@ -76,6 +76,15 @@ int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* sigma_packed, 
                            uint32_t layer_id, uint32_t sample_begin, int32_t n_samples, const float* eps_in,
                            int8_t* w_out, int64_t w_sample_stride, void* stream);
 
+/* Captured-graph mode.  Kernel arguments are frozen when a launch is captured into a HIP graph, but every MC evaluation wants new
+ * noise.  While a device address is set on the CALLING THREAD (dev_seed3 != NULL), every sampler / dropout launch made from it
+ * (qbnn_sample_weights_i8(_multi), qbnn_dropout_q_mc, qbnn_sample_weights_f32(_strided,_ohwi)) reads
+ *   dev_seed3[0..2] = { (uint32)seed, (uint32)(seed >> 32), sample_begin }
+ * from device memory at run time instead of using its `seed` / `sample_begin` arguments; NULL restores the arguments.  The host
+ * updates the three words (an ordinary stream-ordered copy) before each replay.  This is the library's only mutable state besides
+ * the last-error string: thread-local, set and cleared explicitly around a capture. */
+int qbnn_set_device_noise_source(const uint32_t* dev_seed3);
+
 /* The same sampler for up to 24 layers in ONE launch (one launch per MC batch instead of one per layer).
  * Results are identical to calling qbnn_sample_weights_i8 per entry (Philox path only). */
 typedef struct qbnn_sampler_layer {

@@ -74,7 +74,7 @@ class HeadCall(C.Structure):
                 ("probs", C.c_void_p), ("n_samples", C.c_int32), ("desc", C.POINTER(HeadDesc))]
 
 
-EXPORTS = ["qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_conv2d_i8_mc",
+EXPORTS = ["qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_set_device_noise_source", "qbnn_conv2d_i8_mc",
            "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_conv2d_i8_generic_mc", "qbnn_conv2d_i8_generic_scalar_mc", "qbnn_dropout_q_mc", "qbnn_maxpool2_q_mc",
            "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
@@ -100,6 +100,7 @@ def lib():
         vp, i32, i64, u32, u64, f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
         L.qbnn_pack_weights_host.argtypes = [vp, i32, i32, i32, i32, vp]
         L.qbnn_sample_weights_i8.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(SampleParams), u64, u32, u32, i32, vp, vp, i64, vp]
+        L.qbnn_set_device_noise_source.argtypes = [vp]
         L.qbnn_sample_weights_i8_multi.argtypes = [C.POINTER(SamplerLayer), i32, u64, u32, i32, vp]
         L.qbnn_conv2d_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, C.POINTER(ConvDesc), vp]
         L.qbnn_block_chain_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(BlockDesc), i32, vp, i64, i32, vp]

@@ -4,4 +4,5 @@
 #define QBNN_EXPORT extern "C" __attribute__((visibility("default")))
 int qbnn_fail_msg(int code, const char* msg);       // records msg for qbnn_last_error(), returns code
 int qbnn_check_launch_msg(const char* what);        // hipGetLastError() -> QBNN_OK / QBNN_E_LAUNCH
+const unsigned int* qbnn_noise_dev();               // this thread's device noise source (qbnn_set_device_noise_source) or nullptr
 #endif

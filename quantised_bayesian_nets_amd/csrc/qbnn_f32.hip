@@ -481,7 +481,9 @@ QBNN_EXPORT int qbnn_fake_quant_f32_mc(const float* x, int64_t x_ss, float* y, i
 __global__ __launch_bounds__(256) void sample_weights_f32_strided_kernel(const float* __restrict__ mu, int64_t mu_ss, const float* __restrict__ sigma,
                                                                           int64_t sigma_ss, int64_t n, uint32_t seed_lo, uint32_t seed_hi,
                                                                           uint32_t layer_id, uint32_t sample_begin,
-                                                                          const float* __restrict__ eps_in, float* __restrict__ w) {
+                                                                          const float* __restrict__ eps_in, float* __restrict__ w,
+                                                                          const uint32_t* __restrict__ nd) {
+  if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }      // captured-graph mode: the seed lives in device memory
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g * 4 >= n) return;
   const int s = blockIdx.y;
@@ -518,7 +520,7 @@ QBNN_EXPORT int qbnn_sample_weights_f32_strided(const float* mu, int64_t mu_ss, 
   if (!sigma || !w_out || n <= 0 || n_samples <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_sample_weights_f32_strided: bad argument");
   const int64_t groups = (n + 3) / 4;
   hipLaunchKernelGGL(sample_weights_f32_strided_kernel, dim3((unsigned)((groups + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
-                     mu, mu_ss, sigma, sigma_ss, n, (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out);
+                     mu, mu_ss, sigma, sigma_ss, n, (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out, qbnn_noise_dev());
   return qbnn_check_launch_msg("qbnn_sample_weights_f32_strided");
 }
 
@@ -527,7 +529,9 @@ QBNN_EXPORT int qbnn_sample_weights_f32_strided(const float* mu, int64_t mu_ss, 
 __global__ __launch_bounds__(256) void sample_weights_f32_ohwi_kernel(const float* __restrict__ mu, int64_t mu_ss, const float* __restrict__ sigma,
                                                                        int64_t sigma_ss, int Cout, int Cin, int KS, uint32_t seed_lo,
                                                                        uint32_t seed_hi, uint32_t layer_id, uint32_t sample_begin,
-                                                                       const float* __restrict__ eps_in, float* __restrict__ w) {
+                                                                       const float* __restrict__ eps_in, float* __restrict__ w,
+                                                                       const uint32_t* __restrict__ nd) {
+  if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }      // captured-graph mode: the seed lives in device memory
   const int64_t n = (int64_t)Cout * Cin * KS * KS;
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g * 4 >= n) return;
@@ -559,7 +563,7 @@ QBNN_EXPORT int qbnn_sample_weights_f32_ohwi(const float* mu, int64_t mu_ss, con
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_sample_weights_f32_ohwi: bad argument");
   const int64_t groups = ((int64_t)Cout * Cin * ksize * ksize + 3) / 4;
   hipLaunchKernelGGL(sample_weights_f32_ohwi_kernel, dim3((unsigned)((groups + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
-                     mu, mu_ss, sigma, sigma_ss, Cout, Cin, ksize, (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out);
+                     mu, mu_ss, sigma, sigma_ss, Cout, Cin, ksize, (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out, qbnn_noise_dev());
   return qbnn_check_launch_msg("qbnn_sample_weights_f32_ohwi");
 }
 

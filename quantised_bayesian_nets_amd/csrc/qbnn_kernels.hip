@@ -53,6 +53,12 @@ static int ensure_dyn_lds(const void* fn, std::atomic<uint64_t>& done, int bytes
   return QBNN_OK;
 }
 
+// Device noise source (see include/qbnn.h: qbnn_set_device_noise_source): while non-null on the calling thread, every sampler /
+// dropout launch reads (seed_lo, seed_hi, sample_begin) from this device address instead of from its kernel arguments.
+static thread_local const unsigned int* g_noise_dev = nullptr;
+const unsigned int* qbnn_noise_dev() { return g_noise_dev; }
+QBNN_EXPORT int qbnn_set_device_noise_source(const uint32_t* dev_seed3) { g_noise_dev = dev_seed3; return QBNN_OK; }
+
 int qbnn_fail_msg(int code, const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
 int qbnn_check_launch_msg(const char* what) { return check_launch(what); }
 
@@ -147,7 +153,8 @@ __device__ __forceinline__ int sample_one_q(int mu_q, int sigma_q, int eps_q, co
 __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
     const v4i* __restrict__ mu, const v4i* __restrict__ sigma, int cout, int K, int krow, int rbp, int KS, int layout,
     int n_chunks, qbnn_sample_params p, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_id, uint32_t sample_begin,
-    const float* __restrict__ eps_in, int8_t* __restrict__ w_out, int64_t w_sample_stride) {
+    const float* __restrict__ eps_in, int8_t* __restrict__ w_out, int64_t w_sample_stride, const uint32_t* __restrict__ nd) {
+  if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }      // captured-graph mode: the seed lives in device memory
   __shared__ uint32_t eps_tab[256];
   load_eps_table(eps_tab, threadIdx.x);
   __syncthreads();
@@ -222,7 +229,7 @@ QBNN_EXPORT int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* si
   dim3 grid(ceil_div(n_chunks, 256), n_samples);
   hipLaunchKernelGGL(sample_weights_i8_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                      (const v4i*)mu_packed, (const v4i*)sigma_packed, cout, k, g.krow, g.rbp, g.KS, layout, n_chunks, *hp,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out, w_sample_stride);
+                     (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out, w_sample_stride, g_noise_dev);
   return check_launch("qbnn_sample_weights_i8");
 }
 
@@ -698,7 +705,8 @@ struct SamplerLayer {
 struct SamplerTable { SamplerLayer l[QBNN_MAX_SAMPLER_LAYERS]; int n; };
 
 __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const SamplerTable t, uint32_t seed_lo, uint32_t seed_hi,
-                                                                   uint32_t sample_begin) {
+                                                                   uint32_t sample_begin, const uint32_t* __restrict__ nd) {
+  if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }      // captured-graph mode: the seed lives in device memory
   int li = 0;
 #pragma unroll 1
   for (int i = 1; i < t.n; ++i) li = ((int)blockIdx.x >= t.l[i].chunk_begin) ? i : li;
@@ -801,7 +809,7 @@ QBNN_EXPORT int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* layers, i
     blocks += ceil_div(L.n_chunks, 256);
   }
   hipLaunchKernelGGL(sample_weights_multi_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, t,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), sample_begin);
+                     (uint32_t)seed, (uint32_t)(seed >> 32), sample_begin, g_noise_dev);
   return check_launch("qbnn_sample_weights_i8_multi");
 }
 
@@ -3103,7 +3111,9 @@ template <bool VEC4>
 __global__ __launch_bounds__(256) void dropout_q_kernel(const uint8_t* __restrict__ x, int64_t x_ss, int B, int HW, int C,
                                                          float keep, int z_x, float inv_sm, int z_m, float mult, int hi,
                                                          uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_id, uint32_t sample_begin,
-                                                         const float* __restrict__ mask_in, uint8_t* __restrict__ y, int64_t y_ss) {
+                                                         const float* __restrict__ mask_in, uint8_t* __restrict__ y, int64_t y_ss,
+                                                         const uint32_t* __restrict__ nd) {
+  if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }      // captured-graph mode: the seed lives in device memory
   const int b = blockIdx.x, s = blockIdx.y;
   const int CS = VEC4 ? C / 4 : C;
   const int per_pass = 256 / CS > 0 ? 256 / CS : 1;          // pixels covered by the workgroup per trip (CS <= 256), else slots loop
@@ -3156,11 +3166,11 @@ QBNN_EXPORT int qbnn_dropout_q_mc(const uint8_t* x, int64_t x_ss, int32_t B, int
   if (vec4)
     hipLaunchKernelGGL(dropout_q_kernel<true>, dim3((unsigned)B, n_samples), dim3(256), 0, (hipStream_t)stream,
                        x, x_ss, B, HW, C, keep_prob, z_x, 1.0f / s_m, z_m, mult, a_hi < 255 ? a_hi : 255, (uint32_t)seed,
-                       (uint32_t)(seed >> 32), layer_id, sample_begin, mask_in, y, y_ss);
+                       (uint32_t)(seed >> 32), layer_id, sample_begin, mask_in, y, y_ss, g_noise_dev);
   else
     hipLaunchKernelGGL(dropout_q_kernel<false>, dim3((unsigned)B, n_samples), dim3(256), 0, (hipStream_t)stream,
                        x, x_ss, B, HW, C, keep_prob, z_x, 1.0f / s_m, z_m, mult, a_hi < 255 ? a_hi : 255, (uint32_t)seed,
-                       (uint32_t)(seed >> 32), layer_id, sample_begin, mask_in, y, y_ss);
+                       (uint32_t)(seed >> 32), layer_id, sample_begin, mask_in, y, y_ss, g_noise_dev);
   return check_launch("qbnn_dropout_q_mc");
 }
 
@@ -3221,7 +3231,8 @@ QBNN_EXPORT int qbnn_dequant_softmax_mc(const uint8_t* x, int64_t x_ss, int32_t 
 __global__ __launch_bounds__(256) void sample_weights_f32_kernel(const float* __restrict__ mu, const float* __restrict__ sigma,
                                                                   int64_t n, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_id,
                                                                   uint32_t sample_begin, const float* __restrict__ eps_in,
-                                                                  float* __restrict__ w) {
+                                                                  float* __restrict__ w, const uint32_t* __restrict__ nd) {
+  if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }      // captured-graph mode: the seed lives in device memory
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;      // group of 4 consecutive weights
   if (g * 4 >= n) return;
   const int s = blockIdx.y;
@@ -3253,7 +3264,7 @@ QBNN_EXPORT int qbnn_sample_weights_f32(const float* mu, const float* sigma, int
   if (!mu || !sigma || !w_out || n <= 0 || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_sample_weights_f32: bad argument%s");
   const int64_t groups = (n + 3) / 4;
   hipLaunchKernelGGL(sample_weights_f32_kernel, dim3((unsigned)((groups + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
-                     mu, sigma, n, (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out);
+                     mu, sigma, n, (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out, g_noise_dev);
   return check_launch("qbnn_sample_weights_f32");
 }
 

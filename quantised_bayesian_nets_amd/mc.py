@@ -134,3 +134,75 @@ def mc_predict(model, x, samples, seed, return_var=False, chunk=None, group=None
     if return_probs:
         return out, (torch.cat(all_probs, 0) if all_probs else None)
     return out
+
+
+class GraphedPredictor:
+    """`mc_predict` / `mc_predict_regression` captured ONCE per input shape into a HIP graph and replayed.
+
+    A Monte-Carlo evaluation of a small network is 15-25 launches of a few microseconds each (LeNet, MLP; an ensemble: 13): the
+    launches, not the kernels, set its time.  Kernel arguments are frozen at capture, so the Philox seed and the first global
+    sample index are read from three words of device memory instead (`qbnn_set_device_noise_source`); a call copies the input
+    into the graph's static buffer, writes the three words, and replays.  Same results as the eager path for the same
+    (x, seed): the kernels and their order are identical.  One rank only evaluates the whole graph; with a process group the
+    local moments come from the graph and the all-reduce + finalisation run after it.
+    (The ResNet BBB step gains nothing from this -- its launch gaps are 0.02 ms of 3.7 -- but it works there too.)"""
+
+    def __init__(self, model, samples, return_var=False, regression=False, group=None):
+        self.model, self.samples, self.return_var, self.regression, self.group = model, int(samples), return_var, regression, group
+        self._graphs = {}
+
+    def _local(self, x, begin, count):
+        """The rank-local part: forward of `count` samples + their fp64 moments (and mean / var when this rank is all there is)."""
+        with mc_context(count, 0, begin):
+            out = self.model.forward_mc(x)
+        if self.regression:
+            mu, var = out
+            return reduce_moments(torch.cat([mu, var], dim=-1).contiguous())
+        if not _dist_active(self.group):
+            return reduce_moments(out, None, finalize_total=self.samples, want_var=self.return_var)
+        return reduce_moments(out)
+
+    def _capture(self, x, begin, count):
+        import numpy as np
+        L = _lib.lib()
+        static_x = x.clone()
+        noise = torch.zeros(4, dtype=torch.int32, device=x.device)
+        host = torch.from_numpy(np.zeros(4, np.int32)).pin_memory()
+        self._local(static_x, begin, count)                     # eager once: packs weights, builds every cache the launches read
+        torch.cuda.synchronize()
+        _lib.check(L.qbnn_set_device_noise_source(_lib.ptr(noise)))
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                res = self._local(static_x, begin, count)
+        finally:
+            _lib.check(L.qbnn_set_device_noise_source(None))
+        return static_x, noise, host, graph, res
+
+    def __call__(self, x, seed, sample_begin=0):
+        import numpy as np
+        if x.device.type != "cuda":
+            raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
+        rank, world = _rank_world(self.model, self.group)
+        begin, count = shard_samples(self.samples, rank, world)
+        key = (tuple(x.shape), x.dtype, x.device.index, begin, count)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = self._capture(x, begin, count)
+        static_x, noise, host, graph, res = ent
+        static_x.copy_(x)
+        host.numpy()[:] = np.array([seed & 0xffffffff, (seed >> 32) & 0xffffffff, (begin + sample_begin) & 0xffffffff, 0], np.uint32).view(np.int32)
+        noise.copy_(host, non_blocking=True)
+        graph.replay()
+        if self.regression:
+            moments = res.clone()
+            all_reduce_moments(moments, self.group)
+            mean, uvar = finalize_moments(moments, self.samples)
+            return mean[:, 0:1], uvar[:, 0:1] + mean[:, 1:2]
+        if not _dist_active(self.group):
+            _mom, mean, var = res
+            return (mean.clone(), var.clone()) if self.return_var else mean.clone()
+        moments = res.clone()
+        all_reduce_moments(moments, self.group)
+        mean, var = finalize_moments(moments, self.samples, want_var=self.return_var)
+        return (mean, var) if self.return_var else mean

@@ -39,7 +39,9 @@ class Linear(nn.Module):
         S = _MC.samples
         if self._sigma is None or self._sigma.device != x.device:
             self._sigma = F.softplus(self.std.detach().cpu().float()).to(x.device).contiguous()   # one-time, same op as the reference
-        mu = self.weight.detach().to(x.device).contiguous()
+            self._mu_dev = self.weight.detach().to(x.device).contiguous()                        # device copies made once (they were
+            self._bias_dev = None if self.bias is None else self.bias.detach().to(x.device).contiguous()   # re-uploaded on every call)
+        mu = self._mu_dev
         n = mu.numel()
         w = torch.empty((S, n), dtype=torch.float32, device=x.device)
         if eps is not None:
@@ -50,7 +52,7 @@ class Linear(nn.Module):
         B = x.shape[1]
         y = torch.empty((S, B, self.out_features), dtype=torch.float32, device=x.device)
         xs = 0 if x.shape[0] == 1 else x[0].numel()
-        b = None if self.bias is None else self.bias.detach().to(x.device).contiguous()
+        b = self._bias_dev
         with timed("linear_f32"):
             _lib.check(_lib.lib().qbnn_linear_f32_mc(_lib.ptr(x.contiguous()), xs, _lib.ptr(w), n, _lib.ptr(b), _lib.ptr(y), y[0].numel(),
                                                      B, self.in_features, self.out_features, act, S, _lib.current_stream()))

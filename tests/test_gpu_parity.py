@@ -876,3 +876,49 @@ def test_environment_switches_give_the_same_results(switch, tmp_path):
     script.write_text(_SWITCH_WORKER)
     r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, **{switch: "1"}), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SWITCH-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_graphed_predictor_equals_eager(golden_w8, golden_lenet_mc, golden_mlp_f32, golden_ensemble):
+    """One captured HIP graph per (model, input shape), replayed with new inputs and new seeds (read from device memory):
+    bit-identical to the eager `mc_predict` for the int8 BBB ResNet, the MC-Dropout LeNet (dropout masks), the fp32 BBB MLP
+    (regression reduction) and the 16-member ensemble."""
+    import quantised_bayesian_nets_amd as q
+    from conftest import synth_ensemble_members
+    gen = torch.Generator().manual_seed(31)
+    # int8 BBB ResNet
+    m = _model(golden_w8)
+    gp = q.GraphedPredictor(m, 7, return_var=True)
+    for seed, sb in ((3, 0), (2 ** 40 + 17, 5), (3, 0)):
+        x = torch.randn(64, 3, 32, 32, generator=gen).cuda()
+        mean, var = gp(x, seed, sample_begin=sb)
+        with q.mc_context(7, seed, sb):
+            probs = m.forward_mc(x)
+        assert torch.equal(mean, q.mc_predict(m, x, 7, seed, return_var=True)[0]) if sb == 0 else True
+        np.testing.assert_allclose(mean.cpu().numpy(), probs.double().mean(0).cpu().numpy(), rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(var.cpu().numpy(), probs.double().var(0).cpu().numpy(), rtol=1e-5, atol=1e-12)
+    # MC-Dropout LeNet: the masks follow the device seed too
+    g = golden_lenet_mc
+    la = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=0.2)
+    lm = q.ModelFactory.get_model("conv_lenet_mc", [1, 1, 28, 28], 10, True, la).load_reference_state(g["state"])
+    gl = q.GraphedPredictor(lm, 9)
+    for seed in (g["meta"]["philox_seed"], 12345):
+        x = torch.rand(128, 1, 28, 28, generator=gen).cuda()
+        assert torch.equal(gl(x, seed), q.mc_predict(lm, x, 9, seed))
+    # fp32 BBB MLP, regression reduction
+    gm = golden_mlp_f32
+    mm = q.ModelFactory.get_model("linear_bbb", [gm["in_dim"]], 1, False, types.SimpleNamespace(sigma_prior=-2.0)).load_reference_state(gm["state"])
+    gr = q.GraphedPredictor(mm, 10, regression=True)
+    for seed in (gm["seed"], 99):
+        x = torch.randn(1000, gm["in_dim"], generator=gen).cuda()
+        a, b = gr(x, seed)
+        c, d = q.mc_predict_regression(mm, x, 10, seed)
+        assert torch.equal(a, c) and torch.equal(b, d)
+    # ensemble (no noise at all: the graph only saves the launches)
+    n = 16
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, model="conv_resnet_sgld", samples=n)
+    net = q.ModelFactory.get_model("conv_resnet_sgld", [1, 3, 32, 32], 10, True, args, training_mode=False).load_reference_state(
+        synth_ensemble_members(golden_ensemble, n))
+    ge = q.GraphedPredictor(net, n)
+    for _ in range(2):
+        x = torch.randn(64, 3, 32, 32, generator=gen).cuda()
+        assert torch.equal(ge(x, 0), q.mc_predict(net, x, n, 0))
