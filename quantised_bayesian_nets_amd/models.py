@@ -328,11 +328,18 @@ class Network(nn.Module):
         super().__init__()
         if training_mode:
             raise NotImplementedError("training is out of scope (inference hot path only)")
-        if args.model != "conv_resnet_sgld":
+        if args.model == "conv_resnet_sgld":
+            template = ConvNetwork_ResNet
+        elif args.model == "conv_lenet_sgld":
+            from .models_small import ConvNetwork_LeNet as template
+        elif args.model == "linear_sgld":
+            from .models_small import LinearNetwork as template
+        else:
             raise NotImplementedError("Other templates not implemented!")
         self.args, self.q, self.training_mode = args, q, training_mode
         self.output_size = int(output_size)
-        self.ensemble = nn.ModuleList([ConvNetwork_ResNet(input_size, output_size, q, args, deterministic=True) for _ in range(args.samples)])
+        self.ensemble = nn.ModuleList([template(input_size, output_size, q, args, deterministic=True) for _ in range(args.samples)])
+        self.regression = args.model == "linear_sgld"        # members return (mu, var); no softmax (models_sgld.py:286-287)
         self.counter = 0
         # A member's forward is ~12 launches on one sample's worth of work: launch-bound.  Members are deterministic (no
         # seed, no sample offset), so each member's launch chain is captured once per input shape into a HIP graph and
@@ -340,8 +347,8 @@ class Network(nn.Module):
         self.use_graphs = os.environ.get("QBNN_NO_GRAPHS", "0") != "1"
         self._graphs = {}
         self._streams = []
-        # members side by side in fused multi-call launches (the default); False: one launch chain per member (graphs / streams)
-        self.fused_members = True
+        # members side by side in fused multi-call launches (the ResNet template's default); False: one launch chain per member
+        self.fused_members = args.model == "conv_resnet_sgld"
         self._plans = {}
 
     def load_reference_state(self, member_states):
@@ -366,7 +373,7 @@ class Network(nn.Module):
         """[1, B, C] probabilities of member `idx`; replays the member's captured launch chain when there is one."""
         from . import layers as _layers
         member = self.ensemble[idx]
-        if record is not None or not self.use_graphs or _layers.PROFILE is not None or x.device.type != "cuda":
+        if record is not None or not self.use_graphs or self.regression or _layers.PROFILE is not None or x.device.type != "cuda":
             with mc_context(1, 0, 0):
                 return member.forward_mc(x, record=record)
         key = (idx, tuple(x.shape), x.dtype, x.device.index)
@@ -501,10 +508,13 @@ class Network(nn.Module):
         idx = [(_MC.sample_begin + i) % n for i in range(_MC.samples)]
         if record is None and self.fused_members and x.device.type == "cuda" and len(set(idx)) == len(idx):
             return self._forward_members_fused(idx, x)
-        graphed = (record is None and self.use_graphs and x.device.type == "cuda" and len(idx) > 1 and
+        graphed = (record is None and self.use_graphs and not self.regression and x.device.type == "cuda" and len(idx) > 1 and
                    all(self._graphs.get((j, tuple(x.shape), x.dtype, x.device.index)) for j in idx))
         if not graphed:
-            return torch.cat([self._member_forward(j, x, record=record if i == 0 else None) for i, j in enumerate(idx)], 0)
+            outs = [self._member_forward(j, x, record=record if i == 0 else None) for i, j in enumerate(idx)]
+            if self.regression:
+                return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
+            return torch.cat(outs, 0)
         # every member has a captured chain: replay them round-robin on side streams (8; QBNN_ENSEMBLE_STREAMS) -- one member's late layers
         # fill 16-64 of the 256 CUs, so independent members overlap
         main = torch.cuda.current_stream()
@@ -525,7 +535,8 @@ class Network(nn.Module):
 
     def forward(self, x):
         with mc_context(1, 0, 0):
-            y = self._member_forward(self.counter, x)[0]
+            y = self._member_forward(self.counter, x)
+        y = (y[0][0], y[1][0]) if self.regression else y[0]
         self.counter += 1
         if self.counter >= self.args.samples:
             self.counter = 0

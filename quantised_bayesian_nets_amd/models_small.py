@@ -24,10 +24,13 @@ def _quantize(x4, quant, a_hi):
 
 
 class _SmallBase(nn.Module):
+    deterministic = False        # True: an SGHMC ensemble member (standard quantised layers, fixed weights; sgld/models_sgld.py:13-97)
+
     def _finish(self, args):
         for i, m in enumerate(self.stochastic_layers()):
             m.layer_id = i
             m.layout = LAYOUT_ROWMAJOR
+            m.deterministic = self.deterministic
         self.quant = QuantStub()
         self.a_hi = UINT_BOUNDS[args.activation_precision][1]
 
@@ -43,13 +46,13 @@ class ConvNetwork_LeNet(_SmallBase):
     """reference models_bbb.ConvNetwork_LeNet (:98-143), int8: conv5x5 -> maxpool -> conv5x5 -> maxpool -> flatten ->
     LinearReLU(2450, 500) -> Linear(500, classes) -> dequant -> softmax (no ReLU after the convs)."""
 
-    def __init__(self, input_size, output_size, q, args):
+    def __init__(self, input_size, output_size, q, args, deterministic=False):
         super().__init__()
         if not q:
             raise NotImplementedError("float conv BBB layers are not built yet")
         check_bits(args)
-        self.args, self.q, self.output_size = args, q, int(output_size)
-        self.init_channels = input_size[0]
+        self.args, self.q, self.output_size, self.deterministic = args, q, int(output_size), deterministic
+        self.init_channels = input_size[0] if len(input_size) == 3 else input_size[1]       # [C,H,W] (bbb) or [1,C,H,W] (sgld)
         ident = nn.Identity
         self.layers = nn.ModuleList([Conv2d(self.init_channels, 20, (5, 5), stride=1, padding=2, bias=False, args=args), MaxPool2dQ(args),
                                      Conv2d(20, 50, (5, 5), stride=1, padding=2, bias=False, args=args), MaxPool2dQ(args),
@@ -70,7 +73,8 @@ class ConvNetwork_LeNet(_SmallBase):
         S, dev = _MC.samples, x.device
         rec = (lambda k, v: record.__setitem__(k, v)) if record is not None else (lambda k, v: None)
         h = _quantize(x.to(torch.float32).contiguous(), self.quant, self.a_hi); rec("quant.out", h.data)
-        sample_all_weights(self.stochastic_layers(), dev)
+        if not self.deterministic:
+            sample_all_weights(self.stochastic_layers(), dev)
         h = self.layers[0]._conv(h, self.layers[0].sample_weights(dev), S); rec("layers.0.out", h.data)
         h = self.layers[1](h); rec("layers.1.out", h.data)
         h = self.layers[2]._conv(h, self.layers[2].sample_weights(dev), S); rec("layers.2.out", h.data)
@@ -97,10 +101,10 @@ class LinearNetwork(_SmallBase):
     """reference models_bbb.LinearNetwork with q=True (:32-95): QuantStub -> 3 x LinearReLU(100) -> heads mu, log_var ->
     DeQuant -> (mu, exp(log_var))."""
 
-    def __init__(self, input_size, output_size, q, args):
+    def __init__(self, input_size, output_size, q, args, deterministic=False):
         super().__init__()
         check_bits(args)
-        self.args, self.q = args, q
+        self.args, self.q, self.deterministic = args, q, deterministic
         self.input_size = 1
         for i in input_size:
             self.input_size *= int(i)
@@ -128,7 +132,8 @@ class LinearNetwork(_SmallBase):
         x2 = x.to(torch.float32).reshape(x.shape[0], -1)
         h = _quantize(x2.reshape(x2.shape[0], x2.shape[1], 1, 1).contiguous(), self.quant, self.a_hi)
         h = MCQTensor(h.data.reshape(1, x2.shape[0], x2.shape[1]), h.scale, h.zero_point, shared=True); rec("quant.out", h.data)
-        sample_all_weights(self.stochastic_layers(), dev)
+        if not self.deterministic:
+            sample_all_weights(self.stochastic_layers(), dev)
         for i in (0, 2, 4):
             h = self.layers[i](h); rec(f"layers.{i}.out", h.data)
         qm, qv = self.mu(h), self.log_var(h)

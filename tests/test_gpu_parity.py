@@ -922,3 +922,49 @@ def test_graphed_predictor_equals_eager(golden_w8, golden_lenet_mc, golden_mlp_f
     for _ in range(2):
         x = torch.randn(64, 3, 32, 32, generator=gen).cuda()
         assert torch.equal(ge(x, 0), q.mc_predict(net, x, n, 0))
+
+
+def test_small_sghmc_templates_match_reference():
+    """reference sgld.Network's other two templates (models_sgld.py:13-97, :219-226): `conv_lenet_sgld` (deterministic int8 LeNet
+    members, softmax in the wrapper) and `linear_sgld` (MLP members returning (mu, exp(log_var))), members = the MC samples."""
+    import os
+    import quantised_bayesian_nets_amd as q
+    from conftest import GOLDEN
+
+    def members(d):
+        n = int(d["meta.members"])
+        return [{k[len(f"member{i}/"):]: d[k] for k in d.files if k.startswith(f"member{i}/")} for i in range(n)]
+
+    d = np.load(os.path.join(GOLDEN, "ensemble_lenet_a7w8.npz"))
+    n = int(d["meta.members"])
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, model="conv_lenet_sgld", samples=n, task="classification")
+    net = q.ModelFactory.get_model("conv_lenet_sgld", [1, 1, 28, 28], 10, True, args, training_mode=False).load_reference_state(members(d))
+    x = torch.from_numpy(d["x"]).cuda()
+    rec = {}
+    with q.mc_context(n, 0, 0):
+        probs = net.forward_mc(x, record=rec)
+    for k in ("quant.out", "layers.0.out", "layers.1.out", "layers.2.out", "layers.3.out", "layers.5.out", "layers.7.out"):
+        got = rec[k][0].cpu().numpy()
+        assert np.array_equal(got.reshape(d["rec/" + k].shape), d["rec/" + k]), k
+    np.testing.assert_allclose(probs.cpu().numpy(), d["probs"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(q.mc_predict(net, x, n, 0).cpu().numpy(), d["probs"].mean(0), rtol=RTOL, atol=1e-8)
+    outs = [net(x).cpu().numpy() for _ in range(n + 1)]                     # the wrapper's round-robin call contract
+    np.testing.assert_allclose(np.stack(outs[:n]), d["probs"], rtol=RTOL, atol=1e-8)
+    assert np.array_equal(outs[0], outs[n])
+
+    d = np.load(os.path.join(GOLDEN, "ensemble_mlp_a7w8.npz"))
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, model="linear_sgld", samples=n, task="regression")
+    net = q.ModelFactory.get_model("linear_sgld", [13], 1, True, args, training_mode=False).load_reference_state(members(d))
+    x = torch.from_numpy(d["x"]).cuda()
+    rec = {}
+    with q.mc_context(n, 0, 0):
+        mu, var = net.forward_mc(x, record=rec)
+    for k in ("quant.out", "layers.0.out", "layers.2.out", "layers.4.out", "mu.out", "log_var.out"):
+        assert np.array_equal(rec[k][0].cpu().numpy().reshape(d["rec/" + k].shape), d["rec/" + k]), k
+    np.testing.assert_allclose(mu.cpu().numpy(), d["mu"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(var.cpu().numpy(), d["var"], rtol=1e-5, atol=1e-8)
+    mean, pv = q.mc_predict_regression(net, x, n, 0)
+    np.testing.assert_allclose(mean.cpu().numpy(), d["mu"].mean(0), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pv.cpu().numpy(), d["mu"].astype(np.float64).var(0, ddof=1) + d["var"].mean(0), rtol=1e-4, atol=1e-8)
+    m0, v0 = net(x)
+    np.testing.assert_allclose(m0.cpu().numpy(), d["mu"][0], rtol=1e-5, atol=1e-6)
