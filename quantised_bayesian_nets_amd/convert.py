@@ -181,3 +181,70 @@ def convert_model(prepared, model_name, input_size, output_size, args):
     model = ModelFactory.get_model(model_name, input_size, output_size, True, a, training_mode=False) if "sgld" in model_name else \
         ModelFactory.get_model(model_name, input_size, output_size, True, a)
     return model.load_reference_state(convert_model_state(prepared, a))
+
+
+# ---------------------------------------------------------------------------------------------- prepare
+def prepare_model_state(float_state):
+    """The state-dict side of the reference's `quant_utils.prepare_model` (src/quant_utils.py:112-147) for a BBB model:
+
+      * fusion (`model.fuse_model()` -> `fuse_bbb_modules`, models_bbb.py:10-29, :186-188, :249): a stochastic conv followed by its
+        BatchNorm becomes one ConvBn(ReLU)2d module at the conv's index -- the BatchNorm's tensors move from `<seq>.<i+1>.*` to
+        `<seq>.<i>.bn.*` (the later indices become Identity);
+      * observer insertion (`prepare` x2 + `convert(model, QAT_MODULE_MAPPINGS)`): every stochastic layer gets the five FakeQuantize
+        of conv_qat.py:21-23, :75-77 (weight, std, mul_noise, add_weight, output), the QuantStub and every BasicBlock's `Add` one
+        activation FakeQuantize each -- all fresh (min = +inf, max = -inf, scale 1, zero point 0).
+
+    `float_state`: flat {key: numpy} state of the float model (`weight` = mu, `std` = rho, BatchNorm parameters / statistics).
+    Returns the prepared model's flat state: what `models_qat` loads (live-observer evaluation = calibration) and what
+    `convert_model_state` converts."""
+    out = {}
+    inf = np.float32(np.inf)
+    eps = np.asarray([np.finfo(np.float32).eps], np.float32)
+
+    def observer(prefix):           # a FakeQuantize holding a fresh MovingAverageMinMaxObserver
+        out[prefix + ".scale"] = np.asarray([1.0], np.float32)
+        out[prefix + ".zero_point"] = np.asarray([0], np.int32)
+        out[prefix + ".activation_post_process.eps"] = eps
+        out[prefix + ".activation_post_process.min_val"] = inf
+        out[prefix + ".activation_post_process.max_val"] = -inf
+
+    layers = [k[:-len(".std")] for k in float_state if k.endswith(".std")]
+    bn_of = {}
+    for p in layers:
+        head, _, idx = p.rpartition(".")
+        if idx.isdigit():
+            cand = f"{head}.{int(idx) + 1}"
+            if (cand + ".running_mean") in float_state:
+                bn_of[cand] = p
+    for k, v in float_state.items():
+        moved = False
+        for bn, conv in bn_of.items():
+            if k.startswith(bn + "."):
+                if not k.endswith("num_batches_tracked"):
+                    out[conv + ".bn." + k[len(bn) + 1:]] = np.asarray(v)
+                moved = True
+                break
+        if not moved:
+            out[k] = np.asarray(v)
+    for p in layers:
+        for fq in ("weight_fake_quant", "std_fake_quant", "activation_post_process", "add_weight.activation_post_process",
+                   "mul_noise.activation_post_process"):
+            observer(p + "." + fq)
+    observer("quant.activation_post_process")
+    for p in layers:                                        # one Add per BasicBlock: the blocks are the parents of `<blk>.stem.0`
+        if p.endswith(".stem.0"):
+            observer(p[:-len(".stem.0")] + ".add.add.activation_post_process")
+    return out
+
+
+def calibrate(qat_model, batches, seed=0):
+    """Calibration as the reference's evaluation-mode forwards do it: every forward of the prepared model updates every
+    observer (they are never disabled: SURVEY 3.3).  Runs one stochastic forward per batch on the GPU (`models_qat`, live
+    observers); afterwards `convert_model_state(qat_model.prepared_state(), args)` / `convert_model(qat_model, ...)` gives the
+    int8 model.  (The reference's TRAIN-mode forwards -- local reparametrisation, BatchNorm batch statistics -- are training and
+    out of scope; a model calibrated there arrives as a prepared state dict instead.)"""
+    from .layers import mc_context
+    for i, x in enumerate(batches):
+        with mc_context(1, seed, i):
+            qat_model.forward_mc(x)
+    return qat_model

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Fixture for the native prepare -> calibrate -> convert pipeline.  RUNS ONLY IN THE BUILD CONTAINER.
+
+Takes the FLOAT conv_resnet_bbb already committed as a fixture (state of tests/golden/resnet_bbb_f32.npz), loads it into the real
+reference's float model, lets the REFERENCE prepare it (quant_utils.prepare_model, :112-147: fusion, qconfig, observers), calibrates
+it with S eval-mode forwards of the fixture's input (the live observers update in eval; the build's fp32 Philox eps injected), and
+converts it (quant_utils.convert).  Records the fresh prepared state's key set, the observers after calibration and the converted
+model's quantisation parameters + a hash of every int8 tensor.
+Output: tests/golden/resnet_bbb_prepare_calibrate.npz (data only)."""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+import torch  # noqa: E402
+
+from oracle import oracle as orc  # noqa: E402
+
+SEED, S = 3, 3
+
+
+def main():
+    from src.models import ModelFactory
+    import src.quant_utils as qu
+    d = np.load(os.path.join(HERE, "resnet_bbb_f32.npz"))
+    fstate = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    x = torch.from_numpy(d["x"])
+    args = types.SimpleNamespace(sigma_prior=-2.0, model="conv_resnet_bbb", q=True, at=True, samples=S, task="classification",
+                                 activation_precision=7, weight_precision=8)
+    torch.manual_seed(1)
+    model = ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args)
+    sd = model.state_dict()
+    for k, v in fstate.items():
+        assert k in sd, k
+        sd[k] = torch.from_numpy(np.asarray(v))
+    model.load_state_dict(sd)
+    qu.prepare_model(model, args)
+    fresh = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()
+             if "fake_quant_enabled" not in k and "observer_enabled" not in k and not k.endswith("num_batches_tracked")}
+    model.eval()
+    shapes = []
+    hooks = [m.register_forward_pre_hook(lambda m, i: shapes.append(tuple(m.weight.shape))) for m in model.modules() if hasattr(m, "weight_fake_quant")]
+    snap = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        model(x)
+    for h in hooks:
+        h.remove()
+    model.load_state_dict(snap)
+    queue, orig = [], torch.Tensor.normal_
+
+    def normal_(t, mean=0, std=1, *, generator=None):
+        e = queue.pop(0)
+        assert tuple(t.shape) == e.shape
+        t.copy_(torch.from_numpy(e))
+        return t
+
+    torch.Tensor.normal_ = normal_
+    try:
+        with torch.no_grad():
+            for s in range(S):
+                queue[:] = [orc.fill_normal(int(np.prod(sh)), SEED, lid, s).reshape(sh) for lid, sh in enumerate(shapes)]
+                model(x)
+    finally:
+        torch.Tensor.normal_ = orig
+    out = {"meta.samples": np.int64(S), "meta.philox_seed": np.int64(SEED)}
+    out["fresh_keys"] = np.array(sorted(fresh), dtype=object).astype(str)
+    for k, v in fresh.items():
+        if k.endswith("min_val") or k.endswith("max_val"):
+            out["fresh/" + k] = v
+    for k, v in model.state_dict().items():
+        if k.endswith("min_val") or k.endswith("max_val"):
+            out["calibrated/" + k] = v.detach().numpy().copy()
+    qu.convert(model)
+    for k, v in model.state_dict().items():
+        if v is None:
+            continue
+        if isinstance(v, torch.Tensor) and v.is_quantized:
+            out["converted/" + k + ".q_scale"] = np.float64(v.q_scale())
+            out["converted/" + k + ".q_zero_point"] = np.int64(v.q_zero_point())
+            out["converted/" + k + ".sha1"] = np.array(hashlib.sha1(v.int_repr().numpy().tobytes()).hexdigest())
+            if k in ("layers.0.weight", "layers.4.0.shortcut.0.weight", "layers.9.weight", "layers.0.std"):
+                out["converted/" + k] = v.int_repr().numpy()
+        elif isinstance(v, torch.Tensor):
+            out["converted/" + k] = v.detach().numpy()
+        else:
+            out["converted/" + k] = np.asarray(v)
+    path = os.path.join(HERE, "resnet_bbb_prepare_calibrate.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, round(os.path.getsize(path) / 1e6, 3), "MB;", len(fresh), "prepared keys")
+
+
+if __name__ == "__main__":
+    main()

@@ -188,3 +188,26 @@ def test_load_ensemble_reads_one_file_per_member(golden_ensemble, tmp_path):
             else:
                 assert layer.bias_ is None
         assert mem.quant.scale == float(np.asarray(g["quant.scale"]).reshape(-1)[0])
+
+
+def test_prepare_model_state_builds_the_reference_prepared_keys():
+    """SURVEY 8f row 4, prepare side: `prepare_model_state` (fusion + observer insertion of quant_utils.prepare_model,
+    src/quant_utils.py:112-147) turns the float conv_resnet_bbb fixture into exactly the key set the reference's prepared model
+    has (713 entries), BatchNorm tensors under `<conv>.bn.*`, every observer fresh."""
+    from quantised_bayesian_nets_amd.convert import prepare_model_state
+    d = np.load(os.path.join(GOLDEN_DIR, "resnet_bbb_f32.npz"))
+    fstate = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    ref = np.load(os.path.join(GOLDEN_DIR, "resnet_bbb_prepare_calibrate.npz"))
+    prep = prepare_model_state(fstate)
+    assert sorted(prep) == sorted(str(k) for k in ref["fresh_keys"])
+    for k in ref.files:
+        if k.startswith("fresh/"):
+            assert np.array_equal(np.asarray(prep[k[len("fresh/"):]]), ref[k]), k          # +inf / -inf
+    assert np.array_equal(prep["layers.4.0.stem.0.bn.running_var"], fstate["layers.4.0.stem.1.running_var"])
+    assert np.array_equal(prep["layers.0.weight"], fstate["layers.0.weight"])
+    # the package's QAT model loads it (observers unseen)
+    import types
+    import quantised_bayesian_nets_amd as q
+    aq = types.SimpleNamespace(sigma_prior=-2.0, activation_precision=7, weight_precision=8, qat_eval=True)
+    m = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, aq).load_reference_state(prep)
+    assert m.layers[0].weight_fake_quant.min_max() == (float("inf"), float("-inf"))
