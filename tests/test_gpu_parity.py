@@ -1037,3 +1037,28 @@ def test_native_prepare_calibrate_convert_pipeline():
     model = convert_model(m, "conv_resnet_bbb", [1, 3, 32, 32], 10, args)
     p = q.mc_predict(model, x, 4, 1)
     np.testing.assert_allclose(p.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
+
+
+def test_edge_shapes_single_image_single_sample_odd_counts(golden_w8):
+    """Edge cases of the fused path: one image, one sample; three images with 101 samples (an odd count above 100, items that do not
+    fill the persistent grid evenly); 255 images (one short of the tile-group multiples).  Fused == layer-wise bit for bit, and the
+    single-image case against the CPU oracle."""
+    import quantised_bayesian_nets_amd as q
+    from oracle import oracle as orc
+    m = _model(golden_w8)
+    gen = torch.Generator().manual_seed(77)
+    net = orc.Int8ResNetOracle(golden_w8["state"], 7, 8)
+    x1 = torch.randn(1, 3, 32, 32, generator=gen)
+    with q.mc_context(1, 5, 0):
+        p = m.forward_mc(x1.cuda())
+    np.testing.assert_allclose(p[0].cpu().numpy(), net.forward(x1.numpy(), 5, 0), rtol=RTOL, atol=1e-8)
+    assert torch.equal(q.mc_predict(m, x1.cuda(), 1, 5), p[0])
+    for B, S in ((3, 101), (255, 2), (1, 7)):
+        x = torch.randn(B, 3, 32, 32, generator=gen).cuda()
+        with q.mc_context(S, 9, 1000):
+            m.fuse_blocks = False
+            ref = m.forward_mc(x)
+            m.fuse_blocks = True
+            assert torch.equal(m.forward_mc(x), ref), (B, S)
+        mean, var = q.mc_predict(m, x, S, 9, return_var=True)
+        assert mean.shape == (B, 10) and bool(torch.isfinite(var).all())
