@@ -34,6 +34,11 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_I8_PEAK_TOPS = 5000.0   # int8 dense = 2x bf16 (2.5 PF)
 VALU_PEAK_LANE_OPS = 1024 * 16 * 2.4e9   # 256 CUs x 4 SIMDs, 16 lanes per cycle, 2.4 GHz
 VALU_OPS_PLAIN, VALU_OPS_RES = 6, 13     # epilogue lane-ops per output element in the shipped ISA (profiles/r02_isa_epilogue.txt)
+# the same instructions weighted by their measured issue cost (tools/valu_rate_bench.hip, profiles/r02_valu_rates.txt: SIMD cycles per
+# wave64 instruction at 2.4 GHz with every SIMD busy -- add / sub / mul / fma / and / or ~3.1, min / max / med3 / cvt* / rndne / bfe ~6.8):
+#   requant            = sub 3.05 + cvt_f32_i32 6.84 + fmac 3.34 + mul 3.27 + min 6.78 + cvt_pk_u8 6.85          = 30.1
+#   requant + add/relu = ... + med3 6.86 + rndne 6.78 + fma 3.34 + cvt_sdwa 6.72 + fma 3.34 + add 3.11 + mul 3.27 = 63.5
+VALU_CYC_PLAIN, VALU_CYC_RES = 30.1, 63.5
 MFMA_I8_SUSTAINED_TOPS = 3260.0   # measured: pure v_mfma_i32_32x32x32_i8 loop on random int8 operands, whole chip
                                   # (tools/mfma_sustained.hip, profiles/r01_mfma_sustained.txt; 4700 on all-zero operands)
 
@@ -300,9 +305,14 @@ def main():
         outs = [S_local * Bx * (H // st) ** 2 * co for (H, ci, co, ks, st, nw) in m["convs"]]
         n_res = sum(1 for i, c in enumerate(m["convs"]) if m.get("res_convs") and i in m["res_convs"])
         lane_ops = sum(o * (VALU_OPS_RES if (m.get("res_convs") and i in m["res_convs"]) else VALU_OPS_PLAIN) for i, o in enumerate(outs))
+        simd_cycles = sum(o / 64.0 * (VALU_CYC_RES if (m.get("res_convs") and i in m["res_convs"]) else VALU_CYC_PLAIN) for i, o in enumerate(outs))
+        floor_w = simd_cycles / 1024 / 2.4e9
         valu = {"epilogue_lane_ops_per_launch": lane_ops, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "floor_ms": round(lane_ops / VALU_PEAK_LANE_OPS * 1e3, 4),
                 "frac": round(lane_ops / VALU_PEAK_LANE_OPS / avg_s, 4), "ops_per_output": {"requant": VALU_OPS_PLAIN, "requant+add+relu": VALU_OPS_RES},
-                "residual_convs": n_res}
+                "residual_convs": n_res,
+                "cost_weighted": {"simd_cycles_per_output": {"requant": VALU_CYC_PLAIN, "requant+add+relu": VALU_CYC_RES},
+                                  "floor_ms": round(floor_w * 1e3, 4), "frac": round(floor_w / avg_s, 4),
+                                  "note": "instructions weighted by their measured issue cost (profiles/r02_valu_rates.txt)"}}
         common = {"kernel": dom, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": d["n"],
                   "share_of_step_time": round(d["ms"] / (dt * 1e3), 3), "convs_in_launch": len(m["convs"]),
                   "algorithmic_bytes_per_launch": abytes, "algorithmic_ops_per_launch": ops, "traffic": traffic, "traffic_source": traffic_note,
