@@ -216,11 +216,19 @@ def main():
             print(json.dumps({"plumbing_check": True, "ranks": dist.get_world_size(), "rank_sum": float(t.item())}))
         dist.destroy_process_group()
         return
-    torch.cuda.set_device(local_rank)
+    # rehearsal on a one-GPU box: QBNN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and QBNN_BENCH_BACKEND=gloo replaces RCCL (which
+    # refuses two ranks on one device) -- the N > 1 code path (sharding, barriers, reduce, rank-0 JSON) on the real kernels
+    share_gpu = os.environ.get("QBNN_BENCH_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("QBNN_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
     # QBNN_BENCH_FORCE_DIST=1 (under torch.distributed.run with one rank): take the RCCL init / barrier / all-reduce path on a 1-GPU box
     use_dist = world > 1 or os.environ.get("QBNN_BENCH_FORCE_DIST", "0") == "1"
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     import quantised_bayesian_nets_amd as q
     from quantised_bayesian_nets_amd import layers as qlayers

@@ -1062,3 +1062,47 @@ def test_edge_shapes_single_image_single_sample_odd_counts(golden_w8):
             assert torch.equal(m.forward_mc(x), ref), (B, S)
         mean, var = q.mc_predict(m, x, S, 9, return_var=True)
         assert mean.shape == (B, 10) and bool(torch.isfinite(var).all())
+
+
+_TWO_RANK_WORKER = r"""
+import os, sys, types, numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from conftest import load_golden
+import quantised_bayesian_nets_amd as q
+torch.cuda.set_device(0)                                   # both ranks share the one GPU of the test box
+dist.init_process_group("gloo")                            # RCCL refuses two ranks on one device; the sharding logic is the same
+rank = dist.get_rank()
+g = load_golden("resnet_bbb_a7w8.npz")
+args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+m = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args).load_reference_state(g["state"])
+x = torch.randn(64, 3, 32, 32, generator=torch.Generator().manual_seed(2)).cuda()
+S, seed = 7, 3                                             # odd: the ranks evaluate 4 and 3 samples
+mean, var = q.mc_predict(m, x, S, seed, return_var=True)
+gp_mean = q.GraphedPredictor(m, S)(x, seed)                # the captured-graph form shards the same way
+if rank == 0:
+    with q.mc_context(S, seed, 0):
+        probs = m.forward_mc(x)                            # all 7 samples on this rank
+    np.testing.assert_allclose(mean.cpu().numpy(), probs.double().mean(0).cpu().numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(var.cpu().numpy(), probs.double().var(0).cpu().numpy(), rtol=1e-5, atol=1e-12)
+    assert torch.equal(gp_mean, mean)
+    print("TWO-RANK-OK")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_sharing_the_gpu_equal_one_rank(tmp_path):
+    """The N > 1 path on the real kernels: two ranks (gloo, both on cuda:0) shard 7 samples 4 + 3 by GLOBAL sample index, sum their fp64
+    moments and finalise -- equal to one rank evaluating all 7 (1e-6: the fp64 sums are added in another order)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two_rank_worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", str(script), root]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "TWO-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
