@@ -122,6 +122,24 @@ int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w
                       const float* bias, const uint8_t* res, int64_t res_sample_stride, uint8_t* y,
                       int64_t y_sample_stride, int32_t n_samples, const qbnn_conv_desc* host_desc, void* stream);
 
+/* The same conv with the ops an MC-Dropout graph puts behind it (mcdropout/models_mc.py:116-160) in its epilogue:
+ *   BernoulliDropout.forward (mcdropout/dropout.py:15-40) on the conv output -- qbnn_dropout_q_mc's arithmetic and mask stream
+ *       (index b * Cout + c, tensor id drop_layer_id, MC sample sample_begin + s; mask_in fp32 [S][B][Cout] = parity mode);
+ *   add != 0: then quantized::add(., other) -> clamp -> ReLU -> clamp (qbnn_add_relu_q_mc's arithmetic with relu = 1); (s_a, z_m)
+ *       are the qparams of the first operand, the dropped conv output after mul_scalar: s_a = s_m / (1 - p);
+ *       other [S|1][B][Ho][Wo][Cout] quint8 with (s_b, z_b).
+ * d->has_res and d->x_is_centered_im2col must be 0; z_m in [0,127].  Output qparams are the caller's bookkeeping: (s_o, z_o) with
+ * add, else (s_m / (1 - p), z_m).  Same bits as qbnn_conv2d_i8_mc -> qbnn_dropout_q_mc (-> qbnn_add_relu_q_mc). */
+typedef struct qbnn_post_desc {
+  float keep_prob; float s_m; int32_t z_m; uint32_t drop_layer_id;
+  int32_t add; float s_a; float s_b; int32_t z_b; float s_o; int32_t z_o;
+} qbnn_post_desc;
+
+int qbnn_conv2d_i8_post_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w_packed, int64_t w_sample_stride,
+                           const float* bias, uint8_t* y, int64_t y_sample_stride, int32_t n_samples,
+                           const qbnn_conv_desc* host_desc, const qbnn_post_desc* host_post, const float* mask_in,
+                           const uint8_t* other, int64_t other_sample_stride, uint64_t seed, uint32_t sample_begin, void* stream);
+
 /* A chain of identity BasicBlocks (models_bbb.py:170-183, no shortcut conv) fused in one persistent kernel -- 1 or 2 blocks at
  * 24 / 48 channels (the blocks' weights stay in LDS), 1 block per call at 96 / 192 channels (its weights stream through LDS):
  *   per block: stem.0 ConvReLU2d -> clamp -> stem.3 Conv2d -> clamp -> Add(block input) -> clamp -> ReLU -> clamp.

@@ -836,6 +836,47 @@ __device__ __forceinline__ void dma_slab(uint8_t* dst, const int8_t* wq, int sla
   }
 }
 
+// Post-ops of the layer kernel for graphs with a dropout behind every conv (mcdropout/models_mc.py:116-160): quantised
+// BernoulliDropout on the conv output, then optionally quantized::add with the block's other branch + ReLU -- in the conv's
+// epilogue (EpiDenseDrop), on the centred integer it already holds.  Same bits as the stand-alone kernels
+// (dropout_q_kernel, add_relu_q_kernel), whose element functions follow.
+struct PostArgs {
+  float keep, inv_sm, dmult; int z_m;
+  float dlo, dhi;                  // clamp of the dropped value before rounding: -z_m, min(255, a_hi) - z_m
+  uint32_t seed_lo, seed_hi, layer_id, sample_begin;
+  const float* mask_in; const uint32_t* nd;
+  float s_a, dl_a;                 // add: first operand = the dropped conv output (s_m / (1 - p), z_m); dl_a = s_a z_m + nzs_a exactly
+};
+
+// quantised mask value minus its zero point for slot i = b * C + c of MC sample s (mcdropout/dropout.py:24-33)
+__device__ __forceinline__ int drop_mask_q(int i, int s, int64_t n_slots, float keep, float inv_sm, int z_m, uint32_t seed_lo,
+                                           uint32_t seed_hi, uint32_t layer_id, uint32_t sample_begin, const float* mask_in) {
+  float m;
+  if (mask_in) {
+    m = mask_in[(int64_t)s * n_slots + i];
+  } else {
+    const qbnn::u32x4 r = qbnn::philox4x32_10((uint32_t)(i >> 2), layer_id, sample_begin + s, 1u, seed_lo, seed_hi);
+    const uint32_t rv = (i & 3) == 0 ? r.x : ((i & 3) == 1 ? r.y : ((i & 3) == 2 ? r.z : r.w));
+    m = ((float)(rv >> 8) * 5.9604644775390625e-8f) < keep ? 1.0f : 0.0f;
+  }
+  return min(max(z_m + rne_sat(m * inv_sm), 0), 255) - z_m;
+}
+// quantized::mul(x, mask_q) with the mask's qparams as output qparams, then clamp_activation
+__device__ __forceinline__ uint32_t drop_one(int xb, int mq, int z_x, int z_m, float mult, int hi) {
+  const int q = min(max(z_m + rne_sat((float)((xb - z_x) * mq) * mult), 0), 255);
+  return (uint32_t)min(q, hi);
+}
+// quantized::add + clamp_activation (+ ReLU)
+__device__ __forceinline__ uint32_t add_relu_one(uint32_t qa, uint32_t qb, float s_a, float nzs_a, float s_b, float nzs_b, float inv_s_o,
+                                                 int z_o, int a_hi, int relu) {
+  const float da = __builtin_fmaf(s_a, (float)qa, nzs_a);
+  const float db = __builtin_fmaf(s_b, (float)qb, nzs_b);
+  int q = min(max(z_o + rne_sat((da + db) * inv_s_o), 0), 255);
+  q = min(q, a_hi);
+  if (relu) q = max(q, z_o);
+  return (uint32_t)q;
+}
+
 // ---- epilogue functors -----------------------------------------------------------------------------------------
 // (a) quint8 into a dense [M][COUT] staging buffer; optional quantized::add + ReLU against the quint8 residual that
 //     already sits at the same address (updated in place).
@@ -870,6 +911,48 @@ struct EpiDense {
         t[i] = (da + db) * a.inv_s_o;
       }
       *o = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi) + (uint32_t)a.z_o * 0x01010101u;      // bytes <= a_hi - z_o: no carry
+    }
+  }
+};
+
+// (a') EpiDense with a quantised channel dropout between the requantisation and the store / the Add:
+//   q' = rne(clamp(v))                       centred conv output (q - z_y), as EpiDense
+//   r' = rne(clamp((q' * mq) * dmult))       quantized::mul(x, mask_q): (x - z_x)(mask_q - z_m) is exact in fp32; centred on z_m
+//   no Add: byte r' + z_m;   Add: fma(s_a, r', dl_a) dequantises it (QConv::dl_y's argument), the rest is EpiDense's Add + ReLU.
+// mq: fp32 [G][COUT] in LDS, the mask value (minus its zero point) of (image, channel) for this MC sample.
+template <int COUT, int IMG_PIX, bool HAS_RES>
+struct EpiDenseDrop {
+  static constexpr int VALU_PER_MFMA = HAS_RES ? 26 : 16;
+  uint8_t* outb; QConv p; QAdd a; PostArgs q; const float* mq;
+  __device__ __forceinline__ int pixel(int m) const { return m * COUT; }
+  __device__ __forceinline__ uint32_t load(int po, int c0) const {
+    return HAS_RES ? *reinterpret_cast<const uint32_t*>(outb + po + c0) : 0u;
+  }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
+    uint32_t* o = reinterpret_cast<uint32_t*>(outb + po + c0);
+    const int g = po / (IMG_PIX * COUT);
+    const float4 m4 = *reinterpret_cast<const float4*>(mq + g * COUT + c0);
+    const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+    const float vv[4] = {v0, v1, v2, v3};
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float qc = __builtin_rintf(med3f(vv[i], p.vlo, p.vhi));
+      r[i] = med3f((qc * mm[i]) * q.dmult, q.dlo, q.dhi);
+    }
+    if (!HAS_RES) {
+      const float zm = (float)q.z_m;
+      *o = pack_low_bytes((r[0] + QBNN_MAGIC) + zm, (r[1] + QBNN_MAGIC) + zm, (r[2] + QBNN_MAGIC) + zm, (r[3] + QBNN_MAGIC) + zm);
+    } else {
+      const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
+      float t[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float da = __builtin_fmaf(q.s_a, __builtin_rintf(r[i]), q.dl_a);
+        const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
+        t[i] = (da + db) * a.inv_s_o;
+      }
+      *o = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi) + (uint32_t)a.z_o * 0x01010101u;
     }
   }
 };
@@ -926,14 +1009,16 @@ struct ConvArgs {
   uint8_t* y; int64_t y_ss;
   int B;
   QConv p; QAdd a;
+  PostArgs post;                   // POST kernels only
 };
 
-template <class C, bool HAS_RES, bool PRESUB>
+template <class C, bool HAS_RES, bool PRESUB, bool POST = false>
 __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* tile = smem;
   uint8_t* outb = smem + C::G * C::TILE_BYTES + C::TILE_SLACK;
   float* bias_lds = reinterpret_cast<float*>(outb + C::OUT_BYTES);
+  float* mq_lds = bias_lds + C::COUT;                                     // POST: [G][COUT] mask values of this workgroup's images
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
   const int s = blockIdx.y, img0 = blockIdx.x * C::G;
 
@@ -941,6 +1026,15 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvArgs a) {
   load_tiles<C, PRESUB>(tile, a.x + (int64_t)s * a.x_ss, img0, a.B, a.p.z_x, tid);
   load_bias<C::COUT>(bias_lds, a.p.bias, tid);
   constexpr int IMG_OUT = C::HO * C::HO * C::COUT;
+  if constexpr (POST) {
+    uint32_t seed_lo = a.post.seed_lo, seed_hi = a.post.seed_hi, sample_begin = a.post.sample_begin;
+    if (a.post.nd) { seed_lo = a.post.nd[0]; seed_hi = a.post.nd[1]; sample_begin = a.post.nd[2]; }
+    for (int i = tid; i < C::G * C::COUT; i += 256) {
+      const int b = img0 + i / C::COUT;
+      mq_lds[i] = b < a.B ? (float)drop_mask_q(b * C::COUT + i % C::COUT, s, (int64_t)a.B * C::COUT, a.post.keep, a.post.inv_sm,
+                                               a.post.z_m, seed_lo, seed_hi, a.post.layer_id, sample_begin, a.post.mask_in) : 0.f;
+    }
+  }
   if (HAS_RES) {
     const uint8_t* rs = a.res + (int64_t)s * a.res_ss;
     for (int i = tid; i < C::M * C::COUT / 16; i += 256)
@@ -948,8 +1042,13 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvArgs a) {
         reinterpret_cast<v4i*>(outb)[i] = *reinterpret_cast<const v4i*>(rs + (int64_t)img0 * IMG_OUT + (int64_t)i * 16);
   }
   __syncthreads();
-  EpiDense<C::COUT, HAS_RES> epi{outb, a.p, a.a};
-  conv_passes<C>(tile, a.p.w + (int64_t)s * a.p.w_ss, bias_lds, a.p, epi, wave, lane);
+  if constexpr (POST) {
+    EpiDenseDrop<C::COUT, C::HO * C::HO, HAS_RES> epi{outb, a.p, a.a, a.post, mq_lds};
+    conv_passes<C>(tile, a.p.w + (int64_t)s * a.p.w_ss, bias_lds, a.p, epi, wave, lane);
+  } else {
+    EpiDense<C::COUT, HAS_RES> epi{outb, a.p, a.a};
+    conv_passes<C>(tile, a.p.w + (int64_t)s * a.p.w_ss, bias_lds, a.p, epi, wave, lane);
+  }
   __syncthreads();
   uint8_t* ys = a.y + (int64_t)s * a.y_ss;
   for (int i = tid; i < C::M * C::COUT / 16; i += 256)
@@ -958,10 +1057,28 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvArgs a) {
 }
 
 template <class C, bool PRESUB>
-static int launch_conv(const ConvArgs& a, int n_samples, bool has_res, hipStream_t st) {
+static int launch_conv(const ConvArgs& a, int n_samples, bool has_res, hipStream_t st, bool post = false) {
   constexpr int LDS = C::G * C::TILE_BYTES + C::TILE_SLACK + C::OUT_BYTES + C::COUT * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   dim3 grid(ceil_div(a.B, C::G), n_samples);
+  if (post) {
+    if constexpr (!PRESUB) {
+      constexpr int LDSP = LDS + C::G * C::COUT * 4;
+      static_assert(LDSP <= 160 * 1024, "LDS budget");
+      if (has_res) {
+        static std::atomic<uint64_t> attr_pr{0};
+        if (int rc_attr = ensure_dyn_lds((const void*)conv_i8_kernel<C, true, false, true>, attr_pr, LDSP)) return rc_attr;
+        hipLaunchKernelGGL((conv_i8_kernel<C, true, false, true>), grid, dim3(256), LDSP, st, a);
+      } else {
+        static std::atomic<uint64_t> attr_p{0};
+        if (int rc_attr = ensure_dyn_lds((const void*)conv_i8_kernel<C, false, false, true>, attr_p, LDSP)) return rc_attr;
+        hipLaunchKernelGGL((conv_i8_kernel<C, false, false, true>), grid, dim3(256), LDSP, st, a);
+      }
+      return check_launch("qbnn_conv2d_i8_post_mc");
+    } else {
+      return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_post_mc: not for the im2col layer%s");
+    }
+  }
   if (has_res) {
     static std::atomic<uint64_t> attr_r{0};
     if (int rc_attr = ensure_dyn_lds((const void*)conv_i8_kernel<C, true, PRESUB>, attr_r, LDS)) return rc_attr;
@@ -1050,6 +1167,8 @@ static int fill_qadd(QAdd& a, const qbnn_conv_desc* d) {
   return QBNN_OK;
 }
 
+static int dispatch_conv(const ConvArgs& a, const qbnn_conv_desc* d, int n_samples, bool hr, bool post, hipStream_t st);
+
 QBNN_EXPORT int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* w_packed, int64_t w_ss, const float* bias,
                                   const uint8_t* res, int64_t res_ss, uint8_t* y, int64_t y_ss, int32_t n_samples,
                                   const qbnn_conv_desc* d, void* stream) {
@@ -1063,12 +1182,14 @@ QBNN_EXPORT int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* 
   int rc = fill_qconv(a.p, w_packed, w_ss, bias, d);
   if (rc) return rc;
   if (d->has_res && (rc = fill_qadd(a.a, d))) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  const bool hr = d->has_res != 0;
+  return dispatch_conv(a, d, n_samples, d->has_res != 0, false, (hipStream_t)stream);
+}
+
+static int dispatch_conv(const ConvArgs& a, const qbnn_conv_desc* d, int n_samples, bool hr, bool post, hipStream_t st) {
 #define QBNN_CASE(CFG, cin, cout, ks, sd, hin, im2c)                                                      \
   if (d->Cin == (cin) && d->Cout == (cout) && d->ksize == (ks) && d->stride == (sd) && d->H == (hin) &&   \
       d->pad == ((ks) - 1) / 2 && (d->x_is_centered_im2col != 0) == (im2c))                                \
-    return launch_conv<CFG, im2c>(a, n_samples, hr, st);
+    return launch_conv<CFG, im2c>(a, n_samples, hr, st, post);
   QBNN_CASE(Cfg_c0, 32, 24, 1, 1, 32, true)
   QBNN_CASE(Cfg_24_24, 24, 24, 3, 1, 32, false)
   QBNN_CASE(Cfg_24_48s, 24, 48, 3, 2, 32, false)
@@ -1082,6 +1203,41 @@ QBNN_EXPORT int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* 
   QBNN_CASE(Cfg_192_192, 192, 192, 3, 1, 4, false)
 #undef QBNN_CASE
   return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_mc: unsupported geometry%s Cin=%ld Cout=%ld", "", d->Cin, d->Cout);
+}
+
+QBNN_EXPORT int qbnn_conv2d_i8_post_mc(const uint8_t* x, int64_t x_ss, const int8_t* w_packed, int64_t w_ss, const float* bias,
+                                       uint8_t* y, int64_t y_ss, int32_t n_samples, const qbnn_conv_desc* d,
+                                       const qbnn_post_desc* q, const float* mask_in, const uint8_t* other, int64_t other_ss,
+                                       uint64_t seed, uint32_t sample_begin, void* stream) {
+  if (!x || !w_packed || !y || !d || !q || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_post_mc: bad argument%s");
+  if (d->has_res || d->x_is_centered_im2col) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_post_mc: has_res / im2col are not combined with post-ops%s");
+  if (d->has_bias && !bias) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_post_mc: has_bias set but bias is NULL%s");
+  if (d->H != d->W) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_post_mc: only square inputs are supported%s");
+  if (q->add && (!other || (other_ss & 15) || (reinterpret_cast<uintptr_t>(other) & 15)))
+    return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_post_mc: add operand missing or not 16-byte aligned%s");
+  if (q->z_m < 0 || q->z_m > 127 || !(q->s_m > 0.f)) return fail(QBNN_E_INVALID, "qbnn_conv2d_i8_post_mc: mask zero point must be in [0,127]%s");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = d->B;
+  int rc = fill_qconv(a.p, w_packed, w_ss, bias, d);
+  if (rc) return rc;
+  PostArgs& o = a.post;
+  const int hi = d->a_hi < 255 ? d->a_hi : 255;
+  o.keep = q->keep_prob; o.inv_sm = 1.0f / q->s_m; o.z_m = q->z_m;
+  o.dmult = (float)((double)d->s_y * (double)q->s_m / (double)q->s_m);     // ATen qmul: self_scale * other_scale / out_scale
+  o.dlo = (float)(-q->z_m); o.dhi = (float)(hi - q->z_m);
+  o.seed_lo = (uint32_t)seed; o.seed_hi = (uint32_t)(seed >> 32); o.layer_id = q->drop_layer_id; o.sample_begin = sample_begin;
+  o.mask_in = mask_in; o.nd = g_noise_dev;
+  if (q->add) {
+    // the Add's operands: a = the dropped conv output with (s_a, z_m), b = `other` -- the epilogue's residual slot
+    qbnn_conv_desc dd = *d;
+    dd.s_r = q->s_b; dd.z_r = q->z_b; dd.s_o = q->s_o; dd.z_o = q->z_o;
+    if ((rc = fill_qadd(a.a, &dd))) return rc;
+    a.res = other; a.res_ss = other_ss;
+    o.s_a = q->s_a;
+    o.dl_a = fmaf(q->s_a, (float)q->z_m, (float)(-q->z_m) * q->s_a);
+  }
+  return dispatch_conv(a, d, n_samples, q->add != 0, true, (hipStream_t)stream);
 }
 
 // =====================================================================================
@@ -2592,12 +2748,7 @@ __global__ __launch_bounds__(256) void add_relu_q_kernel(const uint8_t* __restri
     uint32_t o = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float da = __builtin_fmaf(s_a, (float)((av >> (8 * j)) & 0xffu), nzs_a);
-      const float db = __builtin_fmaf(s_b, (float)((bv >> (8 * j)) & 0xffu), nzs_b);
-      int q = min(max(z_o + rne_sat((da + db) * inv_s_o), 0), 255);
-      q = min(q, a_hi);
-      if (relu) q = max(q, z_o);
-      o |= (uint32_t)q << (8 * j);
+      o |= add_relu_one((av >> (8 * j)) & 0xffu, (bv >> (8 * j)) & 0xffu, s_a, nzs_a, s_b, nzs_b, inv_s_o, z_o, a_hi, relu) << (8 * j);
     }
     reinterpret_cast<uint32_t*>(y + (int64_t)s * y_ss)[i] = o;
   }
@@ -3120,21 +3271,9 @@ __global__ __launch_bounds__(256) void dropout_q_kernel(const uint8_t* __restric
   const uint8_t* xs = x + (int64_t)s * x_ss + (int64_t)b * HW * C;
   uint8_t* ys = y + (int64_t)s * y_ss + (int64_t)b * HW * C;
   auto mask_q = [&](int c) {                                   // quantised mask value minus its zero point, channel c of image b
-    const int i = b * C + c;
-    float m;
-    if (mask_in) {
-      m = mask_in[(int64_t)s * B * C + i];
-    } else {
-      const qbnn::u32x4 r = qbnn::philox4x32_10((uint32_t)(i >> 2), layer_id, sample_begin + s, 1u, seed_lo, seed_hi);
-      const uint32_t rv = (i & 3) == 0 ? r.x : ((i & 3) == 1 ? r.y : ((i & 3) == 2 ? r.z : r.w));
-      m = ((float)(rv >> 8) * 5.9604644775390625e-8f) < keep ? 1.0f : 0.0f;
-    }
-    return min(max(z_m + rne_sat(m * inv_sm), 0), 255) - z_m;
+    return drop_mask_q(b * C + c, s, (int64_t)B * C, keep, inv_sm, z_m, seed_lo, seed_hi, layer_id, sample_begin, mask_in);
   };
-  auto one = [&](int xb, int mq) {
-    const int q = min(max(z_m + rne_sat((float)((xb - z_x) * mq) * mult), 0), 255);
-    return (uint32_t)min(q, hi);
-  };
+  auto one = [&](int xb, int mq) { return drop_one(xb, mq, z_x, z_m, mult, hi); };
   for (int slot = threadIdx.x % (CS < 256 ? CS : 256); slot < CS; slot += 256) {       // one trip unless C > 256 (VEC4: C > 1024)
     const int first = CS < 256 ? threadIdx.x / CS : 0;
     if (CS < 256 && first >= per_pass) break;                                       // threads beyond a whole number of pixels idle

@@ -395,9 +395,11 @@ class Conv2d(_BBBInt8):
                                                             _lib.ptr(y), y[0].numel(), S, C.byref(d), _stream()))
         return MCQTensor(y, self.scale, self.zero_point)
 
-    def _conv(self, x, w, S, residual=None, add_qparams=None, im2col=None, w_shared=False):
+    def _conv(self, x, w, S, residual=None, add_qparams=None, im2col=None, w_shared=False, post=None):
+        """post: optional dict(desc=_lib.PostDesc, masks=fp32 [S, B, Cout] or None, other=MCQTensor or None, out_qparams=(scale, zp)) --
+        the MC-Dropout graphs' dropout (+ Add + ReLU) in the conv's store pass (qbnn_conv2d_i8_post_mc)."""
         if self.layout == LAYOUT_ROWMAJOR:
-            if residual is not None or im2col is not None:
+            if residual is not None or im2col is not None or post is not None:
                 raise NotImplementedError("the generic conv path has no fused residual / im2col")
             _, B, H, W, Cin = x.data.shape
             ks, st, pd = self.kernel_size[0], self.stride[0], self.padding[0]
@@ -427,6 +429,21 @@ class Conv2d(_BBBInt8):
             assert residual.data.shape[1:] == y.shape[1:]
         key = "conv_i8 %dx%d %d->%d k%d s%d%s" % (H, W, Cin, self.out_channels, ks, st, " +res" if residual is not None else "")
         meta = dict(fused=False, convs=[(H, 3 if im2col is not None else Cin, self.out_channels, 3 if im2col is not None else ks, st, pk["cout"] * pk["k"])])
+        if post is not None:
+            assert residual is None and im2col is None
+            other = post.get("other")
+            masks = post.get("masks")
+            if masks is not None:
+                masks = masks.to(device=y.device, dtype=torch.float32).contiguous()
+                assert masks.numel() == S * B * self.out_channels
+            if other is not None:
+                assert other.data.shape[1:] == y.shape[1:]
+            with timed(key + " +post", meta):
+                _lib.check(_lib.lib().qbnn_conv2d_i8_post_mc(_lib.ptr(xin), xss, _lib.ptr(w), 0 if w_shared else w.shape[1], _lib.ptr(pk["bias"]),
+                                                             _lib.ptr(y), y[0].numel(), S, C.byref(d), C.byref(post["desc"]), _lib.ptr(masks),
+                                                             _lib.ptr(None if other is None else other.data),
+                                                             0 if other is None else other.sample_stride(), _MC.seed, _MC.sample_begin, _stream()))
+            return MCQTensor(y, post["out_qparams"][0], post["out_qparams"][1])
         with timed(key, meta):
             _lib.check(_lib.lib().qbnn_conv2d_i8_mc(_lib.ptr(xin), xss, _lib.ptr(w), 0 if w_shared else w.shape[1], _lib.ptr(pk["bias"]),
                                                     _lib.ptr(None if residual is None else residual.data), res_ss,

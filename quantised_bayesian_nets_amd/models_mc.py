@@ -141,11 +141,34 @@ class QConv2d(_QDeterministic):
         self._fast = None
         return super().load_reference_state(state, prefix)
 
+    def is_tuned(self, x):
+        _, B, H, W, Cin = x.data.shape
+        ks = self.kernel_size
+        return H == W and self.padding == (ks - 1) // 2 and (H, Cin, self.out_channels, ks, self.stride) in self._TUNED
+
+    def forward_post(self, x, drop, masks=None, add=None):
+        """conv -> BernoulliDropout `drop` (-> quantized::add with the MCQTensor `other` -> ReLU; add = (other, s_o, z_o)) in ONE launch:
+        the dropout and the Add run in the conv kernel's epilogue (qbnn_conv2d_i8_post_mc).  x must not be sample-shared."""
+        assert self.is_tuned(x) and not x.shared and float(drop.p) > 0.0
+        m = self._tuned()
+        pk = m._ensure_packed(x.data.device)
+        q = _lib.PostDesc()
+        q.keep_prob = float(np.float32(1.0) - np.float32(drop.p.item()))
+        q.s_m, q.z_m, q.drop_layer_id = drop.mul_mask.scale, drop.mul_mask.zero_point, drop.layer_id
+        s_d = drop.mul_mask.scale * float(np.float32(drop.multiplier.item()))      # mul_scalar: only the scale changes
+        out_q = (s_d, drop.mul_mask.zero_point)
+        other = None
+        if add is not None:
+            other, s_o, z_o = add
+            q.add, q.s_a, q.s_b, q.z_b, q.s_o, q.z_o = 1, s_d, other.scale, other.zero_point, s_o, z_o
+            out_q = (s_o, z_o)
+        return m._conv(x, pk["mu"].reshape(1, -1), x.samples, w_shared=True, post=dict(desc=q, masks=masks, other=other, out_qparams=out_q))
+
     def forward(self, x):
         _, B, H, W, Cin = x.data.shape
         ks, st, pd = self.kernel_size, self.stride, self.padding
         Ho, Wo = (H + 2 * pd - ks) // st + 1, (W + 2 * pd - ks) // st + 1
-        if H == W and pd == (ks - 1) // 2 and (H, Cin, self.out_channels, ks, st) in self._TUNED:
+        if self.is_tuned(x):
             m = self._tuned()
             pk = m._ensure_packed(x.data.device)
             y = m._conv(x, pk["mu"].reshape(1, -1), 1 if x.shared else x.samples, w_shared=True)
@@ -332,7 +355,20 @@ class BasicBlock(nn.Module):
             _load_dropout(self.shortcut[2], state, prefix + "shortcut.2.")
         self.add = QFunctional(state[prefix + "add.add.scale"], state[prefix + "add.add.zero_point"])
 
+    fuse_post = True       # dropouts and the Add in the convs' epilogues (False: one launch per op, the A/B and recording path)
+
     def forward(self, x, masks):
+        convs = [self.stem[0], self.stem[4]] + ([self.shortcut[0]] if len(self.shortcut) else [])
+        if (self.fuse_post and not x.shared and float(self.stem[3].p) > 0.0 and self.stem[0].is_tuned(x)
+                and all(0 <= d.mul_mask.zero_point <= 127 for d in self.dropouts())
+                and (not len(self.shortcut) or self.shortcut[0].is_tuned(x))):
+            m_a = masks.pop(0) if masks is not None else None            # draw order of the reference: stem.3, stem.6, shortcut.2
+            m_b = masks.pop(0) if masks is not None else None
+            sc = x
+            if len(self.shortcut):
+                sc = self.shortcut[0].forward_post(x, self.shortcut[2], masks.pop(0) if masks is not None else None)
+            out = self.stem[0].forward_post(x, self.stem[3], m_a)
+            return self.stem[4].forward_post(out, self.stem[6], m_b, add=(sc, self.add.scale, self.add.zero_point))
         out = self.stem[3](self.stem[0](x), masks.pop(0) if masks is not None else None)
         out = self.stem[6](self.stem[4](out), masks.pop(0) if masks is not None else None)
         sc = x

@@ -1106,3 +1106,36 @@ def test_two_ranks_sharing_the_gpu_equal_one_rank(tmp_path):
            "--master-port", "29653", str(script), root]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "TWO-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_resnet_mc_fused_post_ops_equal_separate_launches():
+    """`conv_resnet_mc`: dropout (+ Add + ReLU) in the convs' store passes (qbnn_conv2d_i8_post_mc) against one launch per op --
+    bit-identical with Philox masks and with injected masks, on a batch that leaves ragged image groups in every layer."""
+    import quantised_bayesian_nets_amd as q
+    from quantised_bayesian_nets_amd import models_mc
+    from conftest import load_golden
+    g = load_golden("resnet_mc_a7w8.npz")
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=g["meta"]["p"])
+    m = q.ModelFactory.get_model("conv_resnet_mc", [1, 3, 32, 32], 10, True, args).load_reference_state(g["state"])
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(7, 3, 32, 32, generator=gen).cuda()
+    S = 3
+    widths = [24] + [24] * 4 + [48] * 5 + [96] * 5 + [192] * 5          # dropouts in draw order (a down block has three)
+    assert len(widths) == len(m.dropouts())
+    masks = [(torch.rand(S, 7, c, generator=gen) < 0.8).float() for c in widths]
+    out = {}
+    for fused in (False, True):
+        models_mc.BasicBlock.fuse_post = fused
+        try:
+            rec_p, rec_m = {}, {}
+            with q.mc_context(S, 99, 5):
+                p_philox = m.forward_mc(x, record=rec_p)
+                p_masks = m.forward_mc(x, record=rec_m, masks=masks)
+            out[fused] = (p_philox, p_masks, rec_p, rec_m)
+        finally:
+            models_mc.BasicBlock.fuse_post = True
+    for k in out[False][2]:
+        assert torch.equal(out[False][2][k], out[True][2][k]), k
+        assert torch.equal(out[False][3][k], out[True][3][k]), k
+    assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][1], out[True][1])
+    assert not torch.equal(out[True][0], out[True][1])
