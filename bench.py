@@ -106,7 +106,7 @@ def _wl_lenet_mc(a, world, q, load_golden):
     B = 128 if a.batch == 256 else a.batch
     x_host = torch.rand(B, 1, 28, 28, generator=torch.Generator().manual_seed(2))
     return dict(golden=g, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=False, cpu_baseline=False,
-                step=lambda m, x, S_, seed: q.mc_predict(m, x, S_, seed), scaling="weak", dtype="int8",
+                step=lambda m, x, S_, seed: q.mc_predict(m, x, S_, seed), scaling="weak", dtype="int8", graph={},
                 metric="MC forward samples/sec, LeNet MC-Dropout int8 batch=128", unit="MC samples/s",
                 describe="configs[1]: MNIST-shaped LeNet MC-Dropout (p=0.2), A7/W8 int8, %d MC samples per GPU per step, batch=%d" % (S, B))
 

@@ -279,6 +279,33 @@ int qbnn_dropout_q_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int3
                       int32_t z_x, float s_m, int32_t z_m, int32_t a_hi, uint64_t seed, uint32_t layer_id, uint32_t sample_begin,
                       const float* mask_in, uint8_t* y, int64_t y_sample_stride, int32_t n_samples, void* stream);
 
+/* The small networks' layers on the matrix pipe (LeNet / MLP graphs: mcdropout/models_mc.py:75-111, bbb/models_bbb.py), weights in
+ * the QBNN_LAYOUT_MFMA32 fragment layout (fixed: sample stride 0; sampled: the sampler's output).  Same arithmetic contract -- and the
+ * same bits -- as qbnn_conv2d_i8_generic_mc -> qbnn_maxpool2_q_mc -> qbnn_dropout_q_mc.  Activations <= 7 bit, zero points in [0,127]. */
+typedef struct qbnn_dropout_desc {
+  float keep_prob; float s_m; int32_t z_m;   /* 1 - p; mul_mask.scale / .zero_point                       */
+  uint32_t layer_id;                         /* Philox tensor id of the dropout (mask index b * C + c)     */
+} qbnn_dropout_desc;
+
+/* conv (k x k, stride 1, pad (k-1)/2, weights packed with krow = k * Cin) -> clamp [-> MaxPool2d(2,2)] [-> BernoulliDropout, one draw per
+ * (sample, image, channel)] -> Flatten in NHWC order: y [S][B][ldy], ldy % 16 == 0, bytes beyond the map written 0.  drop == NULL: no
+ * dropout; mask_in fp32 [S][B][Cout]: parity mode.  drop_in != NULL: a BernoulliDropout (one draw per (sample, image, INPUT channel);
+ * mask_in_in fp32 [S][B][Cin]) is applied to x -- qparams (s_in, z_in), typically shared by the samples -- while it enters LDS; the
+ * desc's (s_x, z_x) are then that dropout's output qparams (s_m / (1 - p), z_m).  Built geometry: 14 x 14, 20 -> 50, 5 x 5 (LeNet layers.3). */
+int qbnn_conv_pool_drop_i8_mc(const uint8_t* x, int64_t x_sample_stride, const int8_t* w_packed, int64_t w_sample_stride,
+                              const float* bias, uint8_t* y, int64_t y_sample_stride, int32_t ldy, int32_t n_samples,
+                              const qbnn_conv_desc* host_desc, int32_t pool, const qbnn_dropout_desc* drop, const float* mask_in,
+                              const qbnn_dropout_desc* drop_in, const float* mask_in_in, float s_in, int32_t z_in,
+                              uint64_t seed, uint32_t sample_begin, void* stream);
+
+/* Linear / LinearReLU (desc: B rows, Cin = K, Cout = N, H = W = ksize = stride = 1; weights packed with krow = k = K) -> clamp
+ * [-> BernoulliDropout on the 2-D activation: one draw per element, index b * N + n]: x [S|1][B][ldx] (ldx % 16 == 0, bytes K..ldx-1
+ * ignored), y [S][B][ldy] (ldy % 4 == 0, bytes N..ldy-1 written 0; or ldy == N: dense rows).  mask_in fp32 [S][B][N]: parity mode. */
+int qbnn_linear_i8_mc(const uint8_t* x, int64_t x_sample_stride, int32_t ldx, const int8_t* w_packed, int64_t w_sample_stride,
+                      const float* bias, uint8_t* y, int64_t y_sample_stride, int32_t ldy, int32_t n_samples,
+                      const qbnn_conv_desc* host_desc, const qbnn_dropout_desc* drop, const float* mask_in, uint64_t seed,
+                      uint32_t sample_begin, void* stream);
+
 /* nn.MaxPool2d(2,2) on quint8 (keeps scale / zero point) + clamp_activation; x [S][B][H][W][C]. */
 int qbnn_maxpool2_q_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t a_hi,
                        uint8_t* y, int64_t y_sample_stride, int32_t n_samples, void* stream);

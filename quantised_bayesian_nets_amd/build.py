@@ -3,7 +3,8 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", "qbnn_kernels.hip"), os.path.join(HERE, "csrc", "qbnn_f32.hip")]
+SRC = [os.path.join(HERE, "csrc", "qbnn_kernels.hip"), os.path.join(HERE, "csrc", "qbnn_f32.hip"),
+       os.path.join(HERE, "csrc", "qbnn_small.hip")]
 DEPS = SRC + [os.path.join(HERE, "csrc", "qbnn_rng.cuh"), os.path.join(HERE, "csrc", "qbnn_common.h"), os.path.join(os.path.dirname(HERE), "include", "qbnn.h")]
 LIB = os.environ.get("QBNN_LIB_OVERRIDE") or os.path.join(HERE, "libqbnn_hip.so")   # override: scratch ablation builds
 

@@ -59,6 +59,7 @@ static thread_local const unsigned int* g_noise_dev = nullptr;
 const unsigned int* qbnn_noise_dev() { return g_noise_dev; }
 QBNN_EXPORT int qbnn_set_device_noise_source(const uint32_t* dev_seed3) { g_noise_dev = dev_seed3; return QBNN_OK; }
 
+int qbnn_ensure_dyn_lds(const void* fn, std::atomic<uint64_t>* done, int bytes) { return ensure_dyn_lds(fn, *done, bytes); }
 int qbnn_fail_msg(int code, const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
 int qbnn_check_launch_msg(const char* what) { return check_launch(what); }
 

@@ -92,6 +92,29 @@ class _QDeterministic(nn.Module):
                              bias=None if self.bias_ is None else self.bias_.to(device=device, dtype=torch.float32).contiguous())
         return self._dev
 
+    def _packed_mfma(self, device, w_rows, krow):
+        """The fixed weight as QBNN_LAYOUT_MFMA32 fragments (w_rows: int8 [Cout, K] in the kernel's K order)."""
+        key = ("mfma", krow)
+        if getattr(self, "_pk", None) is None or self._pk["key"] != key or self._pk["device"] != device:
+            L = _lib.lib()
+            cout, k = w_rows.shape
+            nbytes = L.qbnn_packed_weight_bytes(cout, k, krow, 0)        # QBNN_LAYOUT_MFMA32
+            dst = np.zeros(nbytes, np.int8)
+            src = np.ascontiguousarray(w_rows, dtype=np.int8)
+            _lib.check(L.qbnn_pack_weights_host(src.ctypes.data_as(C.c_void_p), cout, k, krow, 0, dst.ctypes.data_as(C.c_void_p)))
+            self._pk = dict(key=key, device=device, w=torch.from_numpy(dst).to(device),
+                            bias=None if self.bias_ is None else self.bias_.to(device=device, dtype=torch.float32).contiguous())
+        return self._pk
+
+    def _desc(self, x, B, H, Cin, Cout, ks, pad):
+        c = _lib.ConvDesc()
+        c.B, c.H, c.W, c.Cin, c.Cout, c.ksize, c.stride, c.pad = B, H, H, Cin, Cout, ks, 1, pad
+        c.s_x, c.z_x = x.scale, x.zero_point
+        c.s_w, c.z_w = self._weight.q_scale(), self._weight.q_zero_point()
+        c.s_y, c.z_y = self.scale, self.zero_point
+        c.relu, c.a_hi, c.has_bias = int(self.relu), _a_hi(self.args), int(self.bias_ is not None)
+        return c
+
     def _run(self, x, w_ohwi, H, W, Cin, Cout, ks, stride, pad, out_shape):
         d = x.data
         if d.device.type != "cuda":
@@ -164,6 +187,49 @@ class QConv2d(_QDeterministic):
             out_q = (s_o, z_o)
         return m._conv(x, pk["mu"].reshape(1, -1), x.samples, w_shared=True, post=dict(desc=q, masks=masks, other=other, out_qparams=out_q))
 
+    _SMALL = {(14, 20, 50, 5, 1, 2)}        # qbnn_conv_pool_drop_i8_mc geometries: (H, Cin, Cout, k, stride, pad)
+
+    def is_small(self, x):
+        _, B, H, W, Cin = x.data.shape
+        return (H == W and (H, Cin, self.out_channels, self.kernel_size, self.stride, self.padding) in self._SMALL
+                and _a_hi(self.args) <= 127 and 0 <= x.zero_point <= 127 and 0 <= self.zero_point <= 127)
+
+    def forward_pool_drop_flat(self, x, pool, drop, masks=None, drop_in=None, masks_in=None):
+        """[BernoulliDropout `drop_in` on x ->] conv -> clamp -> MaxPool2d(2,2) -> BernoulliDropout -> Flatten (NHWC order) in ONE launch:
+        rows [S, B, ld] with a 16-byte multiple pitch (bytes beyond the map are 0).  Returns (MCQTensor of the rows, row width)."""
+        _, B, H, W, Cin = x.data.shape
+        S = _MC.samples
+        din, s_in, z_in = None, 0.0, 0
+        if drop_in is not None and float(drop_in.p) > 0.0:
+            din = _lib.DropoutDesc(float(np.float32(1.0) - np.float32(drop_in.p.item())), drop_in.mul_mask.scale, drop_in.mul_mask.zero_point,
+                                   drop_in.layer_id)
+            s_in, z_in = x.scale, x.zero_point
+            x = MCQTensor(x.data, drop_in.mul_mask.scale * float(np.float32(drop_in.multiplier.item())), drop_in.mul_mask.zero_point, shared=x.shared)
+            if masks_in is not None:
+                masks_in = masks_in.to(device=x.data.device, dtype=torch.float32).contiguous()
+                assert masks_in.numel() == S * B * Cin
+        w = self._weight.int_repr().transpose(0, 2, 3, 1).reshape(self.out_channels, -1)
+        pk = self._packed_mfma(x.data.device, w, self.kernel_size * Cin)
+        Ho = H // 2 if pool else H
+        width = Ho * Ho * self.out_channels
+        ld = (width + 15) // 16 * 16
+        y = torch.empty((S, B, ld), dtype=torch.uint8, device=x.data.device)
+        c = self._desc(x, B, H, Cin, self.out_channels, self.kernel_size, self.padding)
+        dd, out_q = None, (self.scale, self.zero_point)
+        if drop is not None and float(drop.p) > 0.0:
+            dd = _lib.DropoutDesc(float(np.float32(1.0) - np.float32(drop.p.item())), drop.mul_mask.scale, drop.mul_mask.zero_point, drop.layer_id)
+            out_q = (drop.mul_mask.scale * float(np.float32(drop.multiplier.item())), drop.mul_mask.zero_point)
+        if masks is not None:
+            masks = masks.to(device=y.device, dtype=torch.float32).contiguous()
+            assert masks.numel() == S * B * self.out_channels
+        with timed("conv_pool_drop_i8 %d->%d k%d" % (Cin, self.out_channels, self.kernel_size)):
+            _lib.check(_lib.lib().qbnn_conv_pool_drop_i8_mc(_lib.ptr(x.data), x.sample_stride(), _lib.ptr(pk["w"]), 0, _lib.ptr(pk["bias"]),
+                                                            _lib.ptr(y), y[0].numel(), ld, S, C.byref(c), int(pool),
+                                                            None if dd is None else C.byref(dd), _lib.ptr(masks if dd is not None else None),
+                                                            None if din is None else C.byref(din), _lib.ptr(masks_in if din is not None else None),
+                                                            s_in, z_in, _MC.seed, _MC.sample_begin, _lib.current_stream()))
+        return MCQTensor(y, out_q[0], out_q[1]), width
+
     def forward(self, x):
         _, B, H, W, Cin = x.data.shape
         ks, st, pd = self.kernel_size, self.stride, self.padding
@@ -197,6 +263,35 @@ class QLinear(_QDeterministic):
         return self._run(flat, w, 1, 1, self.in_features, self.out_features, 1, 1, 0, (B, self.out_features))
 
 
+    def forward_rows(self, x, width, drop=None, masks=None, dense_out=False):
+        """x: MCQTensor of rows [S|1, B, ldx] (ldx % 16 == 0, `width` = in_features real bytes per row) -> Linear(ReLU) -> clamp
+        [-> BernoulliDropout, one draw per element] on the GEMM kernel; rows [S, B, ldy] out (ldy = out_features if dense_out)."""
+        d = x.data
+        S = _MC.samples if not (x.shared and drop is None) else 1
+        B, ldx = d.shape[1], d.shape[2]
+        assert width == self.in_features and ldx % 16 == 0
+        w = self._weight.int_repr()
+        if self.nhwc_from is not None:
+            c, h, wd = self.nhwc_from
+            w = w.reshape(self.out_features, c, h, wd).transpose(0, 2, 3, 1).reshape(self.out_features, -1)
+        pk = self._packed_mfma(d.device, w, self.in_features)
+        ldy = self.out_features if dense_out else (self.out_features + 15) // 16 * 16
+        y = torch.empty((S, B, ldy), dtype=torch.uint8, device=d.device)
+        c = self._desc(x, B, 1, self.in_features, self.out_features, 1, 0)
+        dd, out_q = None, (self.scale, self.zero_point)
+        if drop is not None and float(drop.p) > 0.0:
+            dd = _lib.DropoutDesc(float(np.float32(1.0) - np.float32(drop.p.item())), drop.mul_mask.scale, drop.mul_mask.zero_point, drop.layer_id)
+            out_q = (drop.mul_mask.scale * float(np.float32(drop.multiplier.item())), drop.mul_mask.zero_point)
+        if masks is not None:
+            masks = masks.to(device=y.device, dtype=torch.float32).contiguous()
+            assert masks.numel() == S * B * self.out_features
+        with timed("linear_i8 %d->%d" % (self.in_features, self.out_features)):
+            _lib.check(_lib.lib().qbnn_linear_i8_mc(_lib.ptr(d), x.sample_stride(), ldx, _lib.ptr(pk["w"]), 0, _lib.ptr(pk["bias"]), _lib.ptr(y),
+                                                    y[0].numel(), ldy, S, C.byref(c), None if dd is None else C.byref(dd),
+                                                    _lib.ptr(masks if dd is not None else None), _MC.seed, _MC.sample_begin, _lib.current_stream()))
+        return MCQTensor(y, out_q[0], out_q[1], shared=(x.shared and drop is None)), self.out_features
+
+
 class QLinearReLU(QLinear):
     relu = True
 
@@ -218,6 +313,7 @@ class MaxPool2dQ(nn.Module):
 
 class ConvNetwork_LeNet(nn.Module):
     """reference mcdropout/models_mc.py:75-111 (`conv_lenet_mc`), converted int8 form."""
+    fast_tail = True        # layers.3 .. 10 on qbnn_conv_pool_drop_i8_mc + qbnn_linear_i8_mc (False: one any-geometry launch per op)
 
     def __init__(self, input_size, output_size, q, args):
         super().__init__()
@@ -271,6 +367,19 @@ class ConvNetwork_LeNet(nn.Module):
             record["quant.out"] = h.data
         di = 0
         skip = -1
+        if record is None and self.fast_tail:
+            # layers 0..2 (conv on the sample-shared input, pool, dropout) as below, then the rest in three launches
+            h = self.layers[2](self.layers[0](h))            # conv + pool on the sample-shared input: once per batch
+            if self.layers[3].is_small(h) and all(0 <= self.layers[i].mul_mask.zero_point <= 127 for i in (1, 4, 9)):
+                rows, width = self.layers[3].forward_pool_drop_flat(h, True, self.layers[4], None if masks is None else masks[1],
+                                                                    drop_in=self.layers[1], masks_in=None if masks is None else masks[0])
+                rows, width = self.layers[7].forward_rows(rows, width, self.layers[9], None if masks is None else masks[2])
+                rows, _ = self.layers[10].forward_rows(rows, width, dense_out=True)
+                probs = torch.empty((S, B, self.output_size), dtype=torch.float32, device=x.device)
+                _lib.check(_lib.lib().qbnn_dequant_softmax_mc(_lib.ptr(rows.data), rows.sample_stride(), B, self.output_size, rows.scale,
+                                                              rows.zero_point, _lib.ptr(probs), S, _lib.current_stream()))
+                return probs
+            h = MCQTensor(xq, self.quant.scale, self.quant.zero_point, shared=True)
         for i, layer in enumerate(self.layers):
             if isinstance(layer, nn.Identity) or i == skip:
                 continue

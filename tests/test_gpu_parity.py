@@ -1139,3 +1139,109 @@ def test_resnet_mc_fused_post_ops_equal_separate_launches():
         assert torch.equal(out[False][3][k], out[True][3][k]), k
     assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][1], out[True][1])
     assert not torch.equal(out[True][0], out[True][1])
+
+
+def _small_layer_setup(gen, S, B, shape, shared):
+    x = torch.randint(0, 128, ((1 if shared else S), B) + shape, generator=gen, dtype=torch.int32).to(torch.uint8)
+    return x
+
+
+def test_linear_i8_gemm_against_generic_kernels():
+    """qbnn_linear_i8_mc (LDS-tiled int8 GEMM, optional per-element dropout in the epilogue) through the C ABI against
+    qbnn_conv2d_i8_generic_mc (1x1) -> qbnn_dropout_q_mc on ragged shapes: K and N that are no tile multiples, fewer rows than a tile,
+    more than one row tile, sample-shared input, no bias, pitch-padded and dense output rows.  Bit-exact."""
+    import ctypes as C
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(21)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (S, B, K, N, shared, bias, relu, drop, dense) in [(3, 5, 100, 10, False, True, False, False, True), (2, 130, 2450, 500, False, True, True, True, False),
+                                                            (2, 64, 37, 64, True, False, True, False, False), (1, 257, 500, 100, False, True, False, True, False),
+                                                            (2, 16, 64, 33, False, True, True, True, True)]:
+        ldx = (K + 15) // 16 * 16
+        xr = torch.randint(0, 128, ((1 if shared else S), B, ldx), generator=gen, dtype=torch.int32).to(torch.uint8)
+        w = torch.randint(-128, 128, (N, K), generator=gen, dtype=torch.int32).to(torch.int8)
+        b = (torch.randn(N, generator=gen) * 3).float().cuda() if bias else None
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.pad = B, 1, 1, K, N, 1, 1, 0
+        d.s_x, d.z_x, d.s_w, d.z_w, d.s_y, d.z_y = 0.05, 17, 0.01, -3, 0.2 * (K / 100.0) ** 0.5, 60
+        d.relu, d.a_hi, d.has_bias = int(relu), 127, int(bias)
+        nb = L.qbnn_packed_weight_bytes(N, K, K, 0)
+        wp = np.zeros(nb, np.int8)
+        wn = np.ascontiguousarray(w.numpy())
+        _lib.check(L.qbnn_pack_weights_host(wn.ctypes.data_as(C.c_void_p), N, K, K, 0, wp.ctypes.data_as(C.c_void_p)))
+        wp = torch.from_numpy(wp).cuda()
+        xg = xr.cuda()
+        ldy = N if dense else (N + 15) // 16 * 16
+        y = torch.full((S, B, ldy), 0xAB, dtype=torch.uint8, device="cuda")
+        dd = _lib.DropoutDesc(0.75, 1.0 / 255.0 * 2, 3, 5) if drop else None
+        _lib.check(L.qbnn_linear_i8_mc(_lib.ptr(xg), 0 if shared else B * ldx, ldx, _lib.ptr(wp), 0, _lib.ptr(b), _lib.ptr(y), B * ldy, ldy, S, C.byref(d),
+                                       None if dd is None else C.byref(dd), None, 77, 4, st))
+        # reference: the any-geometry kernel on dense rows, then the stand-alone dropout
+        xd = xg[:, :, :K].contiguous()
+        wd = w.cuda().contiguous()
+        yr = torch.empty((S, B, N), dtype=torch.uint8, device="cuda")
+        _lib.check(L.qbnn_conv2d_i8_generic_mc(_lib.ptr(xd), 0 if shared else B * K, _lib.ptr(wd), 0, _lib.ptr(b), _lib.ptr(yr), B * N, S, C.byref(d), st))
+        if drop:
+            yd = torch.empty_like(yr)
+            _lib.check(L.qbnn_dropout_q_mc(_lib.ptr(yr), B * N, B, 1, N, 0.75, d.s_y, d.z_y, dd.s_m, dd.z_m, 127, 77, 5, 4, None, _lib.ptr(yd), B * N, S, st))
+            yr = yd
+        torch.cuda.synchronize()
+        assert torch.equal(y[:, :, :N], yr), (S, B, K, N)
+        assert bool((y[:, :, N:] == 0).all())
+
+
+def test_conv_pool_drop_small_map_against_generic_kernels():
+    """qbnn_conv_pool_drop_i8_mc (LeNet's 20 -> 50 5x5 conv on the 14 x 14 map with the dropout in front, the max-pool, the dropout
+    behind and the flatten fused) against the chain of any-geometry kernels, with a batch that leaves a ragged image group; every
+    combination of the optional stages.  Bit-exact."""
+    import ctypes as C
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(22)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    S, B = 3, 6
+    w = torch.randint(-128, 128, (50, 5, 5, 20), generator=gen, dtype=torch.int32).to(torch.int8)
+    bias = (torch.randn(50, generator=gen) * 2).float().cuda()
+    nb = L.qbnn_packed_weight_bytes(50, 500, 100, 0)
+    wp = np.zeros(nb, np.int8)
+    wn = np.ascontiguousarray(w.numpy().reshape(50, 500))
+    _lib.check(L.qbnn_pack_weights_host(wn.ctypes.data_as(C.c_void_p), 50, 500, 100, 0, wp.ctypes.data_as(C.c_void_p)))
+    wp, wd = torch.from_numpy(wp).cuda(), w.cuda().contiguous()
+    for (pool, drop, din, shared) in [(1, 1, 1, True), (0, 0, 0, False), (1, 0, 0, False), (0, 1, 0, False), (1, 1, 0, False), (0, 0, 1, True)]:
+        x = torch.randint(0, 128, ((1 if shared else S), B, 14, 14, 20), generator=gen, dtype=torch.int32).to(torch.uint8).cuda()
+        s_in, z_in = 0.04, 23
+        d_in = _lib.DropoutDesc(0.8, 0.0039, 2, 0)
+        d_out = _lib.DropoutDesc(0.7, 0.0041, 1, 1)
+        # reference chain
+        xin, sx, zx, xss = x, s_in, z_in, (0 if shared else B * 3920)
+        if din:
+            xd = torch.empty((S, B, 14, 14, 20), dtype=torch.uint8, device="cuda")
+            _lib.check(L.qbnn_dropout_q_mc(_lib.ptr(x), xss, B, 196, 20, 0.8, s_in, z_in, d_in.s_m, d_in.z_m, 127, 9, 0, 2, None, _lib.ptr(xd), B * 3920, S, st))
+            xin, sx, zx, xss = xd, d_in.s_m * 1.25, d_in.z_m, B * 3920
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.pad = B, 14, 14, 20, 50, 5, 1, 2
+        d.s_x, d.z_x, d.s_w, d.z_w, d.s_y, d.z_y = sx, zx, 0.01, 4, sx * 4.0, 55
+        d.relu, d.a_hi, d.has_bias = 0, 127, 1
+        Sx = S if xss else 1
+        yc = torch.empty((Sx, B, 14, 14, 50), dtype=torch.uint8, device="cuda")
+        _lib.check(L.qbnn_conv2d_i8_generic_mc(_lib.ptr(xin), xss, _lib.ptr(wd), 0, _lib.ptr(bias), _lib.ptr(yc), B * 9800, Sx, C.byref(d), st))
+        ref, ho = yc, 14
+        if pool:
+            yp = torch.empty((Sx, B, 7, 7, 50), dtype=torch.uint8, device="cuda")
+            _lib.check(L.qbnn_maxpool2_q_mc(_lib.ptr(ref), B * 9800, B, 14, 14, 50, 127, _lib.ptr(yp), B * 2450, Sx, st))
+            ref, ho = yp, 7
+        if drop:
+            yd = torch.empty((S, B, ho, ho, 50), dtype=torch.uint8, device="cuda")
+            _lib.check(L.qbnn_dropout_q_mc(_lib.ptr(ref), (B * ho * ho * 50) if Sx > 1 else 0, B, ho * ho, 50, 0.7, d.s_y, d.z_y, d_out.s_m, d_out.z_m, 127, 9, 1, 2,
+                                           None, _lib.ptr(yd), B * ho * ho * 50, S, st))
+            ref = yd
+        width = ho * ho * 50
+        ld = (width + 15) // 16 * 16
+        Sy = S if (drop or din or not shared) else 1
+        y = torch.full((Sy, B, ld), 0xCD, dtype=torch.uint8, device="cuda")
+        _lib.check(L.qbnn_conv_pool_drop_i8_mc(_lib.ptr(x), 0 if shared else B * 3920, _lib.ptr(wp), 0, _lib.ptr(bias), _lib.ptr(y), B * ld, ld, Sy, C.byref(d), pool,
+                                               C.byref(d_out) if drop else None, None, C.byref(d_in) if din else None, None, s_in, z_in, 9, 2, st))
+        torch.cuda.synchronize()
+        assert torch.equal(y[:, :, :width], ref.reshape(ref.shape[0], B, width)), (pool, drop, din)
+        assert bool((y[:, :, width:] == 0).all())
