@@ -1245,3 +1245,23 @@ def test_conv_pool_drop_small_map_against_generic_kernels():
         torch.cuda.synchronize()
         assert torch.equal(y[:, :, :width], ref.reshape(ref.shape[0], B, width)), (pool, drop, din)
         assert bool((y[:, :, width:] == 0).all())
+
+
+def test_lenet_mc_full_sample_count_against_oracle(golden_lenet_mc):
+    """BASELINE config 1 at its full MC size: 100 samples (global sample indices 0..99) of the MC-Dropout LeNet on the fused kernels
+    (qbnn_conv_pool_drop_i8_mc / qbnn_linear_i8_mc), every sample's probabilities against the oracle at batch 16; the captured-graph
+    predictor's mean against the oracle's mean."""
+    import quantised_bayesian_nets_amd as q
+    from oracle import oracle as orc
+    g = golden_lenet_mc
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=0.2)
+    m = q.ModelFactory.get_model("conv_lenet_mc", [1, 1, 28, 28], 10, True, args).load_reference_state(g["state"])
+    net = orc.Int8LeNetMCOracle(g["state"], 7)
+    S, seed = 100, 1234
+    xb = torch.rand(16, 1, 28, 28, generator=torch.Generator().manual_seed(8))
+    with q.mc_context(S, seed, 0):
+        probs = m.forward_mc(xb.cuda()).cpu().numpy()
+    ref = np.stack([net.forward(xb.numpy(), seed, s) for s in range(S)])
+    np.testing.assert_allclose(probs, ref, rtol=RTOL, atol=1e-8)
+    mean = q.GraphedPredictor(m, S)(xb.cuda(), seed).cpu().numpy()
+    np.testing.assert_allclose(mean, ref.astype(np.float64).mean(0), rtol=RTOL, atol=1e-8)
