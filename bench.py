@@ -111,6 +111,19 @@ def _wl_lenet_mc(a, world, q, load_golden):
                 describe="configs[1]: MNIST-shaped LeNet MC-Dropout (p=0.2), A7/W8 int8, %d MC samples per GPU per step, batch=%d" % (S, B))
 
 
+def _wl_resnet_mc(a, world, q, load_golden):
+    """SURVEY 8 row a6 `conv_resnet_mc`: ResNet-18 with a quantised channel dropout behind every conv, deterministic int8 weights."""
+    g = load_golden("resnet_mc_a7w8.npz")
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=g["meta"]["p"])
+    model = q.ModelFactory.get_model("conv_resnet_mc", [1, 3, 32, 32], 10, True, args).load_reference_state(g["state"])
+    S = a.samples if a.samples > 0 else 100
+    x_host = torch.randn(a.batch, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+    return dict(golden=g, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=False, cpu_baseline=False,
+                step=lambda m, x, S_, seed: q.mc_predict(m, x, S_, seed), scaling="weak", dtype="int8",
+                metric="MC forward samples/sec, ResNet-18 MC-Dropout int8 batch=%d" % a.batch, unit="MC samples/s",
+                describe="conv_resnet_mc: CIFAR-10-shaped ResNet-18 MC-Dropout (p=%.2f), A7/W8 int8, %d MC samples per GPU per step, batch=%d" % (g["meta"]["p"], S, a.batch))
+
+
 def _wl_mlp_f32(a, world, q, load_golden):
     """BASELINE configs[0]: UCI-regression-shaped 4x100 MLP, Bayes-by-backprop fp32, 10 MC samples, 1000 rows."""
     d = np.load(os.path.join(ROOT, "tests", "golden", "mlp_bbb_f32.npz"))
@@ -126,7 +139,7 @@ def _wl_mlp_f32(a, world, q, load_golden):
 
 
 WORKLOADS = {"resnet_bbb": _wl_resnet(0, 100, "configs[2]"), "resnet_bbb_w4": _wl_resnet(4, 128, "configs[4] (A7/W4, 1024 samples over 8 GPUs = 128 per GPU)"),
-             "ensemble16": _wl_ensemble16, "lenet_mc": _wl_lenet_mc, "mlp_f32": _wl_mlp_f32}
+             "ensemble16": _wl_ensemble16, "lenet_mc": _wl_lenet_mc, "mlp_f32": _wl_mlp_f32, "resnet_mc": _wl_resnet_mc}
 
 
 def cpu_baseline(a, g, x_host, seed):
@@ -166,6 +179,41 @@ def cpu_baseline(a, g, x_host, seed):
             "_p_oracle_sample0": p_or}
 
 
+SECONDARY = ("resnet_bbb_w4", "ensemble16", "lenet_mc", "mlp_f32", "resnet_mc")
+
+
+def secondary_workloads(a, q, load_golden, seed):
+    """BASELINE.json's other configs measured in the same run (N = 1, after the headline's timed region): 4 setup steps, 2 warm-up steps,
+    10 timed steps each between synchronisations, on the same code paths `--workload NAME` runs.  Failures are reported, not hidden."""
+    out = {}
+    for name in SECONDARY:
+        try:
+            b = argparse.Namespace(**vars(a))
+            b.workload, b.samples, b.batch, b.w_bits = name, 0, 256, 8
+            wl = WORKLOADS[name](b, 1, q, load_golden)
+            model, x = wl["model"], wl["x_host"].cuda()
+            S = wl["units_global"]
+            graphed = q.GraphedPredictor(model, S, **wl["graph"]) if ("graph" in wl and not a.no_graph) else None
+            run = (lambda: graphed(x, seed)) if graphed is not None else (lambda: wl["step"](model, x, S, seed))
+            for _ in range(6):
+                run()
+            torch.cuda.synchronize()
+            n = 10
+            t0 = time.perf_counter()
+            for _ in range(n):
+                run()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[name] = {"metric": wl["metric"], "value": round(S * n / dt, 2), "unit": wl["unit"], "ms_per_step": round(dt / n * 1e3, 3),
+                         "steps": n, "units_per_step": S, "batch": int(x.shape[0]), "dtype": wl["dtype"], "graph_replay": graphed is not None,
+                         "workload": wl["describe"]}
+            del wl, model, x, graphed, run
+            torch.cuda.empty_cache()
+        except Exception as e:                                       # noqa: BLE001 -- a secondary workload must not take the headline line down
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: N fresh ranks under torch.distributed.run as a CHILD process (this
     process has made no HIP call and makes none: never exec from, or fork, a process that initialised the GPU)."""
@@ -196,6 +244,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=0, help="oracle samples to time (0 = auto, about 10-30 s)")
     ap.add_argument("--no-graph", action="store_true", help="mlp_f32 (the launch-bound workload: ~25 launches of microseconds): launch eagerly instead of replaying its captured HIP graph")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (BASELINE.json's other configs, N = 1, default workload only)")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launcher test (no GPU, gloo): ranks rendezvous, all-reduce their rank, rank 0 prints one JSON line")
     a = ap.parse_args()
@@ -354,6 +403,10 @@ def main():
             p_gpu = model.forward_mc(x)[0].cpu().numpy()         # (resnet workloads only)
         cpu["gpu_matches_oracle_sample0"] = bool(np.allclose(p_gpu, cpu.pop("_p_oracle_sample0"), rtol=1e-5, atol=1e-8))
 
+    secondary = None
+    if rank == 0 and world == 1 and a.workload == "resnet_bbb" and not a.no_secondary:
+        secondary = secondary_workloads(a, q, load_golden, seed)
+
     rccl = None
     if use_dist:
         # the path's one collective in isolation: sum all-reduce of the [2, B, C] fp64 moments (40 KB), RCCL over xGMI
@@ -375,7 +428,7 @@ def main():
                "config": {"workload": wl["describe"], "samples_per_gpu": S_local, "global_samples": S_global, "batch": x_host.shape[0],
                           "image_samples_per_s": round(value * x_host.shape[0], 1), "parallelism": f"mc-sample-shard x{world}"},
                "graph_replay": graphed is not None, "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "rccl": rccl, "rccl_ranks": world if use_dist else 0,
-               "kernels": kernels}
+               "kernels": kernels, "secondary": secondary}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
