@@ -705,8 +705,9 @@ struct SamplerLayer {
 };
 struct SamplerTable { SamplerLayer l[QBNN_MAX_SAMPLER_LAYERS]; int n; };
 
+#define QBNN_SAMPLER_NS 4           // MC samples per thread: the chunk's mu / sigma are loaded, unpacked and dequantised once for all of them
 __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const SamplerTable t, uint32_t seed_lo, uint32_t seed_hi,
-                                                                   uint32_t sample_begin, const uint32_t* __restrict__ nd) {
+                                                                   uint32_t sample_begin, int n_samples, const uint32_t* __restrict__ nd) {
   if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }      // captured-graph mode: the seed lives in device memory
   int li = 0;
 #pragma unroll 1
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
   __syncthreads();
   const int chunk = ((int)blockIdx.x - L.chunk_begin) * 256 + threadIdx.x;
   if (chunk >= L.n_chunks) return;
-  const int s = blockIdx.y;
+  const int s0 = blockIdx.y * QBNN_SAMPLER_NS;
   int n = 0, kh = 0, j0 = 0;
   if (L.layout == QBNN_LAYOUT_MFMA32) {
     const int lane = chunk & 63, tile = chunk >> 6;
@@ -729,60 +730,88 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
   const bool ones_row = (L.layout == QBNN_LAYOUT_MFMA32) && (L.cout & 31) && n == L.cout;
   const v4i m4 = L.mu[chunk], s4 = L.sigma[chunk];
   int mw[4] = {m4.x, m4.y, m4.z, m4.w}, sw[4] = {s4.x, s4.y, s4.z, s4.w};
-  uint32_t ow[4] = {0u, 0u, 0u, 0u};
   const int64_t total = (int64_t)L.cout * L.K;
-  uint32_t cur_blk = 0xffffffffu;
-  qbnn::u32x4 rb = {0u, 0u, 0u, 0u};
   if (L.layout == QBNN_LAYOUT_MFMA32 && ((L.K | L.krow) & 3) == 0) {
     // Fast path (every conv but layers.0): the chunk's 16 weights are 4 whole Philox blocks -- element index
-    // n K + kh krow + j0 + j with all terms multiples of 4 -- and a block is valid or padding as a whole.  Straight-line:
-    // 4 x (Philox, 4 alias draws, 4 weights), no per-element block tracking or selects.
+    // n K + kh krow + j0 + j with all terms multiples of 4 -- and a block is valid or padding as a whole.
+    // The quantized::mul / add chain of sample_one_q in fp32 on exact small integers (same bits, a third of the instructions):
+    //   prod = (sigma_q - z_sigma) eps_q                       exact product of two small integers
+    //   t'   = rne(clamp(prod * m, -128 - z_mul, 127 - z_mul))  = t_q - z_mul  (rne and an integer-bounded clamp commute)
+    //   dt   = fma(s_mul, t', dl_mul),  dl_mul = s_mul z_mul + nzs_mul exactly (QConv::dl_y's argument)
+    //   w'   = clamp((dw + dt) / s_add, lo - z_add, hi - z_add);  byte = low byte of ((w' + 1.5 * 2^23) + z_add)
+    // dw = fma(s_w, mu_q, nzs_w) and sigma_q - z_sigma do not depend on the sample: computed once per QBNN_SAMPLER_NS samples.
+    const qbnn_sample_params& P = L.p;
+    const float tlo = (float)(-128 - P.z_mul), thi = (float)(127 - P.z_mul);
+    const float dl_mul = __builtin_fmaf(P.s_mul, (float)P.z_mul, P.nzs_mul);
+    const float wlo = (float)(max(-128, P.w_lo) - P.z_add), whi = (float)(min(127, P.w_hi) - P.z_add), zaf = (float)P.z_add;
+    const float zsf = (float)P.z_sigma;
+    float dw[16], sg[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      dw[j] = __builtin_fmaf(P.s_w, (float)((mw[j >> 2] << (24 - 8 * (j & 3))) >> 24), P.nzs_w);
+      sg[j] = (float)((sw[j >> 2] << (24 - 8 * (j & 3))) >> 24) - zsf;
+    }
     const int64_t idx0 = (int64_t)n * L.K + kh * L.krow + j0;
+#pragma unroll 1
+    for (int ss = 0; ss < QBNN_SAMPLER_NS; ++ss) {
+      const int s = s0 + ss;
+      if (s >= n_samples) break;
+      uint32_t ow[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (ones_row && j0 + 4 * g < L.krow) ow[g] = 0x01010101u;
-      if (n < L.cout && j0 + 4 * g < L.krow) {
-        const qbnn::u32x4 r4 = qbnn::philox4x32_10((uint32_t)((idx0 >> 2) + g), L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi);
-        const uint32_t uu[4] = {r4.x, r4.y, r4.z, r4.w};
-        uint32_t o = 0;
+      for (int g = 0; g < 4; ++g) {
+        if (ones_row && j0 + 4 * g < L.krow) ow[g] = 0x01010101u;
+        if (n < L.cout && j0 + 4 * g < L.krow) {
+          const qbnn::u32x4 r4 = qbnn::philox4x32_10((uint32_t)((idx0 >> 2) + g), L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi);
+          const uint32_t uu[4] = {r4.x, r4.y, r4.z, r4.w};
+          float f[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int mu_q = (mw[g] << (24 - 8 * i)) >> 24;
-          const int sg_q = (sw[g] << (24 - 8 * i)) >> 24;
-          o |= ((uint32_t)sample_one_q(mu_q, sg_q, eps_q_from_u32(uu[i], eps_tab), L.p) & 0xffu) << (8 * i);
+          for (int i = 0; i < 4; ++i) {
+            const float ef = (float)eps_q_from_u32(uu[i], eps_tab);
+            const float tq = __builtin_rintf(med3f((sg[4 * g + i] * ef) * P.mul_multiplier, tlo, thi));
+            const float dt = __builtin_fmaf(P.s_mul, tq, dl_mul);
+            f[i] = (med3f((dw[4 * g + i] + dt) * P.inv_s_add, wlo, whi) + QBNN_MAGIC) + zaf;
+          }
+          ow[g] = pack_low_bytes(f[0], f[1], f[2], f[3]);
         }
-        ow[g] = o;
+      }
+      reinterpret_cast<v4i*>(L.out + (int64_t)s * L.out_ss)[chunk] = v4i{(int)ow[0], (int)ow[1], (int)ow[2], (int)ow[3]};
+    }
+    return;
+  }
+#pragma unroll 1
+  for (int ss = 0; ss < QBNN_SAMPLER_NS; ++ss) {
+    const int s = s0 + ss;
+    if (s >= n_samples) break;
+    uint32_t ow[4] = {0u, 0u, 0u, 0u};
+    uint32_t cur_blk = 0xffffffffu;
+    qbnn::u32x4 rb = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int64_t idx;
+      bool valid;
+      if (L.layout == QBNN_LAYOUT_MFMA32) {
+        valid = (n < L.cout) && (j0 + j < L.krow);
+        idx = (int64_t)n * L.K + kh * L.krow + j0 + j;
+        if (ones_row && j0 + j < L.krow) ow[j >> 2] |= 1u << (8 * (j & 3));
+      } else {
+        idx = (int64_t)chunk * 16 + j;
+        valid = idx < total;
+      }
+      if (valid) {
+        const uint32_t blk = (uint32_t)(idx >> 2);
+        if (blk != cur_blk) {
+          cur_blk = blk;
+          rb = qbnn::philox4x32_10(blk, L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi);
+        }
+        const int l = (int)(idx & 3);
+        const uint32_t u = l == 0 ? rb.x : (l == 1 ? rb.y : (l == 2 ? rb.z : rb.w));
+        const int mu_q = (mw[j >> 2] << (24 - 8 * (j & 3))) >> 24;
+        const int sg_q = (sw[j >> 2] << (24 - 8 * (j & 3))) >> 24;
+        ow[j >> 2] |= ((uint32_t)sample_one_q(mu_q, sg_q, eps_q_from_u32(u, eps_tab), L.p) & 0xffu) << (8 * (j & 3));
       }
     }
     reinterpret_cast<v4i*>(L.out + (int64_t)s * L.out_ss)[chunk] = v4i{(int)ow[0], (int)ow[1], (int)ow[2], (int)ow[3]};
-    return;
   }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    int64_t idx;
-    bool valid;
-    if (L.layout == QBNN_LAYOUT_MFMA32) {
-      valid = (n < L.cout) && (j0 + j < L.krow);
-      idx = (int64_t)n * L.K + kh * L.krow + j0 + j;
-      if (ones_row && j0 + j < L.krow) ow[j >> 2] |= 1u << (8 * (j & 3));
-    } else {
-      idx = (int64_t)chunk * 16 + j;
-      valid = idx < total;
-    }
-    if (valid) {
-      const uint32_t blk = (uint32_t)(idx >> 2);
-      if (blk != cur_blk) {
-        cur_blk = blk;
-        rb = qbnn::philox4x32_10(blk, L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi);
-      }
-      const int l = (int)(idx & 3);
-      const uint32_t u = l == 0 ? rb.x : (l == 1 ? rb.y : (l == 2 ? rb.z : rb.w));
-      const int mu_q = (mw[j >> 2] << (24 - 8 * (j & 3))) >> 24;
-      const int sg_q = (sw[j >> 2] << (24 - 8 * (j & 3))) >> 24;
-      ow[j >> 2] |= ((uint32_t)sample_one_q(mu_q, sg_q, eps_q_from_u32(u, eps_tab), L.p) & 0xffu) << (8 * (j & 3));
-    }
-  }
-  reinterpret_cast<v4i*>(L.out + (int64_t)s * L.out_ss)[chunk] = v4i{(int)ow[0], (int)ow[1], (int)ow[2], (int)ow[3]};
 }
 
 QBNN_EXPORT int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* layers, int32_t n_layers, uint64_t seed,
@@ -809,8 +838,8 @@ QBNN_EXPORT int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* layers, i
     L.n_chunks = (int)(bytes / 16); L.chunk_begin = blocks; L.layer_id = q.layer_id; L.p = q.params;
     blocks += ceil_div(L.n_chunks, 256);
   }
-  hipLaunchKernelGGL(sample_weights_multi_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, t,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), sample_begin, g_noise_dev);
+  hipLaunchKernelGGL(sample_weights_multi_kernel, dim3(blocks, ceil_div(n_samples, QBNN_SAMPLER_NS)), dim3(256), 0, (hipStream_t)stream, t,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), sample_begin, n_samples, g_noise_dev);
   return check_launch("qbnn_sample_weights_i8_multi");
 }
 
