@@ -2926,64 +2926,89 @@ struct HeadArgs {
   float inv_kk, rcp, mult, s_y;
 };
 
+#define QBNN_HEAD_IMGS 1            // images per wave: the sample's Linear weights are loaded once for all of them
 template <int NM = 1>
 __global__ __launch_bounds__(256) void head_i8_kernel(const ArgsArr<HeadArgs, NM> all) {
   const HeadArgs& a = all.m[NM == 1 ? 0 : blockIdx.z];
   __shared__ int pooled[4][256];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.x * 4 + wave;
   const int s = blockIdx.y;
-  if (b >= a.B) return;
-  const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)b * a.kk * a.C;
-  // AvgPool2d(k) on quint8, channels-last: q = clamp(rne((sum - kk z) / kk) + z, 0, 255); then clamp_activation.
-  // Four channels per lane (one dword per pixel) when C is a multiple of 4.
-  if ((a.C & 3) == 0) {
-    for (int c4 = lane; c4 < a.C / 4; c4 += 64) {
-      int sum[4] = {0, 0, 0, 0};
-      for (int p = 0; p < a.kk; ++p) {
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(xs + p * a.C + 4 * c4);
-        sum[0] += v & 0xffu; sum[1] += (v >> 8) & 0xffu; sum[2] += (v >> 16) & 0xffu; sum[3] += v >> 24;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int q = min(max(rne_sat((float)(sum[j] - a.kk * a.z_x) * a.inv_kk) + a.z_x, 0), 255);
-        pooled[wave][4 * c4 + j] = min(q, a.a_hi) - a.z_x;
-      }
-    }
-  } else {
-    for (int c = lane; c < a.C; c += 64) {
-      int sum = 0;
-      for (int p = 0; p < a.kk; ++p) sum += xs[p * a.C + c];
-      int q = min(max(rne_sat((float)(sum - a.kk * a.z_x) * a.inv_kk) + a.z_x, 0), 255);
-      pooled[wave][c] = min(q, a.a_hi) - a.z_x;
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same-wave LDS write -> read
-  __builtin_amdgcn_wave_barrier();
-  // Linear: lane = (output n, quarter j of the channels); integer partial sums, then a 4-lane butterfly (exact, any order)
+  const int b0 = (blockIdx.x * 4 + wave) * QBNN_HEAD_IMGS;
+  if (b0 >= a.B) return;
   const int8_t* ws = a.w + (int64_t)s * a.w_ss;
   const int n = lane >> 2, j = lane & 3;
-  int acc = 0;
-  if (n < a.N) {
-    const int c_per = (a.C + 3) / 4, c0 = j * c_per, c1 = min(c0 + c_per, a.C);
-    for (int c = c0; c < c1; ++c) acc += pooled[wave][c] * ((int)ws[n * a.C + c] - a.z_w);
+  // packed form: C a multiple of 16 and dword-aligned weights -- pooled activations as int8 dwords, v_dot4 against the raw weight
+  // dwords (kept in registers for the wave's images), the weights' zero point through the channel sum:  sum p (w - z_w) = p.w - z_w sum p
+  const bool packed = (a.C & 15) == 0 && a.C <= 256 && ((reinterpret_cast<uintptr_t>(ws) | (uintptr_t)a.w_ss) & 3) == 0;
+  for (int bi = 0; bi < QBNN_HEAD_IMGS; ++bi) {
+    const int b = b0 + bi;
+    if (b >= a.B) break;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)b * a.kk * a.C;
+    // AvgPool2d(k) on quint8, channels-last: q = clamp(rne((sum - kk z) / kk) + z, 0, 255); then clamp_activation.
+    // Four channels per lane (one dword per pixel) when C is a multiple of 4.
+    if ((a.C & 3) == 0) {
+      for (int c4 = lane; c4 < a.C / 4; c4 += 64) {
+        int sum[4] = {0, 0, 0, 0};
+        for (int p = 0; p < a.kk; ++p) {
+          const uint32_t v = *reinterpret_cast<const uint32_t*>(xs + p * a.C + 4 * c4);
+          sum[0] += v & 0xffu; sum[1] += (v >> 8) & 0xffu; sum[2] += (v >> 16) & 0xffu; sum[3] += v >> 24;
+        }
+        uint32_t pk = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          int q = min(max(rne_sat((float)(sum[jj] - a.kk * a.z_x) * a.inv_kk) + a.z_x, 0), 255);
+          q = min(q, a.a_hi) - a.z_x;
+          if (packed) pk |= ((uint32_t)q & 0xffu) << (8 * jj);
+          else pooled[wave][4 * c4 + jj] = q;
+        }
+        if (packed) pooled[wave][c4] = (int)pk;
+      }
+    } else {
+      for (int c = lane; c < a.C; c += 64) {
+        int sum = 0;
+        for (int p = 0; p < a.kk; ++p) sum += xs[p * a.C + c];
+        int q = min(max(rne_sat((float)(sum - a.kk * a.z_x) * a.inv_kk) + a.z_x, 0), 255);
+        pooled[wave][c] = min(q, a.a_hi) - a.z_x;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same-wave LDS write -> read
+    __builtin_amdgcn_wave_barrier();
+    // Linear: lane = (output n, quarter j of the channels); integer partial sums, then a 4-lane butterfly (exact, any order)
+    int acc = 0;
+    if (n < a.N) {
+      if (packed) {
+        const int dpq = a.C / 16;                                  // dwords per quarter
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>(ws + n * a.C) + j * dpq;
+        int ps = 0;
+        for (int d = 0; d < dpq; ++d) {
+          const int pv = pooled[wave][j * dpq + d];
+          acc = __builtin_amdgcn_sdot4(pv, (int)wp[d], acc, false);
+          ps = __builtin_amdgcn_sdot4(pv, 0x01010101, ps, false);
+        }
+        acc -= a.z_w * ps;
+      } else {
+        const int c_per = (a.C + 3) / 4, c0 = j * c_per, c1 = min(c0 + c_per, a.C);
+        for (int c = c0; c < c1; ++c) acc += pooled[wave][c] * ((int)ws[n * a.C + c] - a.z_w);
+      }
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    float logit = -INFINITY;
+    if (n < a.N && j == 0) {
+      float xf = (float)acc;
+      if (a.bias) xf = __builtin_fmaf(a.bias[n], a.rcp, xf);
+      int q = min(max(a.z_y + rne_sat(xf * a.mult), 0), 255);
+      q = min(q, a.a_hi);
+      logit = (float)(q - a.z_y) * a.s_y;     // DeQuantStub
+    }
+    float mx = logit;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float e = (n < a.N && j == 0) ? expf(logit - mx) : 0.f;
+    float sum = e;
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (n < a.N && j == 0) a.probs[((int64_t)s * a.B + b) * a.N + n] = e / sum;
+    __builtin_amdgcn_wave_barrier();      // the next image overwrites pooled[wave]
   }
-  acc += __shfl_xor(acc, 1);
-  acc += __shfl_xor(acc, 2);
-  float logit = -INFINITY;
-  if (n < a.N && j == 0) {
-    float xf = (float)acc;
-    if (a.bias) xf = __builtin_fmaf(a.bias[n], a.rcp, xf);
-    int q = min(max(a.z_y + rne_sat(xf * a.mult), 0), 255);
-    q = min(q, a.a_hi);
-    logit = (float)(q - a.z_y) * a.s_y;     // DeQuantStub
-  }
-  float mx = logit;
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  float e = (n < a.N && j == 0) ? expf(logit - mx) : 0.f;
-  float sum = e;
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-  if (n < a.N && j == 0) a.probs[((int64_t)s * a.B + b) * a.N + n] = e / sum;
 }
 
 static int build_head_args(HeadArgs& a, const uint8_t* x, int64_t x_ss, const int8_t* w, int64_t w_ss, const float* bias, float* probs,
@@ -3003,7 +3028,7 @@ QBNN_EXPORT int qbnn_head_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* w,
   if (!x || !w || !probs || !d || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_head_i8_mc: bad argument%s");
   ArgsArr<HeadArgs, 1> one;
   if (int rc = build_head_args(one.m[0], x, x_ss, w, w_ss, bias, probs, d)) return rc;
-  hipLaunchKernelGGL(head_i8_kernel<1>, dim3(ceil_div(d->B, 4), n_samples), dim3(256), 0, (hipStream_t)stream, one);
+  hipLaunchKernelGGL(head_i8_kernel<1>, dim3(ceil_div(d->B, 4 * QBNN_HEAD_IMGS), n_samples), dim3(256), 0, (hipStream_t)stream, one);
   return check_launch("qbnn_head_i8_mc");
 }
 
@@ -3021,7 +3046,7 @@ QBNN_EXPORT int qbnn_head_i8_multi(const qbnn_head_call* calls, int32_t n_calls,
       if (k.n_samples != calls[c0].n_samples) return fail(QBNN_E_INVALID, "qbnn_head_i8_multi: the calls of one launch evaluate the same number of samples%s");
       maxB = k.desc->B > maxB ? k.desc->B : maxB; maxS = k.n_samples;
     }
-    hipLaunchKernelGGL(head_i8_kernel<QBNN_FUSED_CALLS>, dim3(ceil_div(maxB, 4), maxS, n), dim3(256), 0, (hipStream_t)stream, all);
+    hipLaunchKernelGGL(head_i8_kernel<QBNN_FUSED_CALLS>, dim3(ceil_div(maxB, 4 * QBNN_HEAD_IMGS), maxS, n), dim3(256), 0, (hipStream_t)stream, all);
     if (int rc = check_launch("qbnn_head_i8_multi")) return rc;
     c0 += n;
   }
