@@ -144,7 +144,7 @@ WORKLOADS = {"resnet_bbb": _wl_resnet(0, 100, "configs[2]"), "resnet_bbb_w4": _w
 
 def cpu_baseline(a, g, x_host, seed):
     """The reference's CPU path timed on this host, on a bounded sample of the same workload (same batch, a few MC samples).
-    Primary leg, kind "torch-fbgemm": the op sequence of the reference's int8 layers through PyTorch's own quantised CPU
+    Primary leg, kind "port", engine "torch-fbgemm" (oracle/fbgemm_baseline.py): the op sequence of the reference's int8 layers through PyTorch's own quantised CPU
     operators (ATen + FBGEMM) -- oracle/fbgemm_baseline.py, which reproduces the golden vectors recorded from the reference.
     Second leg, kind "port": the plain-C restatement oracle/qbnn_oracle.c (OpenMP), the parity checker."""
     from oracle import oracle as orc
@@ -168,13 +168,13 @@ def cpu_baseline(a, g, x_host, seed):
     for s in range(1, 1 + n_cpu):
         net.forward(xn, seed, s)
     el = time.perf_counter() - t
-    return {"value": round(1.0 / med, 4), "unit": "MC samples/s", "cores": torch.get_num_threads(), "kind": "torch-fbgemm",
+    return {"value": round(1.0 / med, 4), "unit": "MC samples/s", "cores": torch.get_num_threads(), "kind": "port", "engine": "torch-fbgemm",
             "sample": f"median of {n_fb} single MC samples of the same batch ({a.batch} images) through torch's quantised CPU ops "
                       f"(fbgemm engine; per layer normal_ -> quantize_per_tensor -> quantized.mul/add -> clamp -> conv2d_prepack -> "
                       f"quantized.conv2d(_relu) -> clamp), after 1 warm-up sample",
             "seconds_per_sample_min_med_max": [round(min(ts), 4), round(med, 4), round(max(ts), 4)],
             "host_cpus": os.cpu_count(),
-            "port": {"value": round(n_cpu / el, 4), "unit": "MC samples/s", "cores": orc.lib().qbo_num_threads(), "kind": "port",
+            "port": {"value": round(n_cpu / el, 4), "unit": "MC samples/s", "cores": orc.lib().qbo_num_threads(), "kind": "port", "engine": "plain C (oracle/qbnn_oracle.c, OpenMP)",
                      "sample": f"{n_cpu} MC samples of the same batch through oracle/qbnn_oracle.c (OpenMP), after 1 warm-up sample"},
             "_p_oracle_sample0": p_or}
 
