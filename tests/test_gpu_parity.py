@@ -1155,33 +1155,34 @@ def test_linear_i8_gemm_against_generic_kernels():
     L = _lib.lib()
     gen = torch.Generator().manual_seed(21)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for (S, B, K, N, shared, bias, relu, drop, dense) in [(3, 5, 100, 10, False, True, False, False, True), (2, 130, 2450, 500, False, True, True, True, False),
-                                                            (2, 64, 37, 64, True, False, True, False, False), (1, 257, 500, 100, False, True, False, True, False),
-                                                            (2, 16, 64, 33, False, True, True, True, True)]:
+    for (S, B, K, N, shared, bias, relu, drop, dense, wps) in [(3, 5, 100, 10, False, True, False, False, True, False), (2, 130, 2450, 500, False, True, True, True, False, False),
+                                                                 (2, 64, 37, 64, True, False, True, False, False, False), (1, 257, 500, 100, False, True, False, True, False, False),
+                                                                 (2, 16, 64, 33, False, True, True, True, True, False), (3, 40, 100, 100, True, True, True, False, False, True)]:
         ldx = (K + 15) // 16 * 16
         xr = torch.randint(0, 128, ((1 if shared else S), B, ldx), generator=gen, dtype=torch.int32).to(torch.uint8)
-        w = torch.randint(-128, 128, (N, K), generator=gen, dtype=torch.int32).to(torch.int8)
+        w = torch.randint(-128, 128, ((S if wps else 1), N, K), generator=gen, dtype=torch.int32).to(torch.int8)
         b = (torch.randn(N, generator=gen) * 3).float().cuda() if bias else None
         d = _lib.ConvDesc()
         d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.pad = B, 1, 1, K, N, 1, 1, 0
         d.s_x, d.z_x, d.s_w, d.z_w, d.s_y, d.z_y = 0.05, 17, 0.01, -3, 0.2 * (K / 100.0) ** 0.5, 60
         d.relu, d.a_hi, d.has_bias = int(relu), 127, int(bias)
         nb = L.qbnn_packed_weight_bytes(N, K, K, 0)
-        wp = np.zeros(nb, np.int8)
-        wn = np.ascontiguousarray(w.numpy())
-        _lib.check(L.qbnn_pack_weights_host(wn.ctypes.data_as(C.c_void_p), N, K, K, 0, wp.ctypes.data_as(C.c_void_p)))
+        wp = np.zeros((w.shape[0], nb), np.int8)            # per-sample weights (Bayes-by-backprop: sample stride nb) or one fixed weight
+        for si in range(w.shape[0]):
+            wn = np.ascontiguousarray(w[si].numpy())
+            _lib.check(L.qbnn_pack_weights_host(wn.ctypes.data_as(C.c_void_p), N, K, K, 0, wp[si].ctypes.data_as(C.c_void_p)))
         wp = torch.from_numpy(wp).cuda()
         xg = xr.cuda()
         ldy = N if dense else (N + 15) // 16 * 16
         y = torch.full((S, B, ldy), 0xAB, dtype=torch.uint8, device="cuda")
         dd = _lib.DropoutDesc(0.75, 1.0 / 255.0 * 2, 3, 5) if drop else None
-        _lib.check(L.qbnn_linear_i8_mc(_lib.ptr(xg), 0 if shared else B * ldx, ldx, _lib.ptr(wp), 0, _lib.ptr(b), _lib.ptr(y), B * ldy, ldy, S, C.byref(d),
+        _lib.check(L.qbnn_linear_i8_mc(_lib.ptr(xg), 0 if shared else B * ldx, ldx, _lib.ptr(wp), nb if wps else 0, _lib.ptr(b), _lib.ptr(y), B * ldy, ldy, S, C.byref(d),
                                        None if dd is None else C.byref(dd), None, 77, 4, st))
         # reference: the any-geometry kernel on dense rows, then the stand-alone dropout
         xd = xg[:, :, :K].contiguous()
         wd = w.cuda().contiguous()
         yr = torch.empty((S, B, N), dtype=torch.uint8, device="cuda")
-        _lib.check(L.qbnn_conv2d_i8_generic_mc(_lib.ptr(xd), 0 if shared else B * K, _lib.ptr(wd), 0, _lib.ptr(b), _lib.ptr(yr), B * N, S, C.byref(d), st))
+        _lib.check(L.qbnn_conv2d_i8_generic_mc(_lib.ptr(xd), 0 if shared else B * K, _lib.ptr(wd), N * K if wps else 0, _lib.ptr(b), _lib.ptr(yr), B * N, S, C.byref(d), st))
         if drop:
             yd = torch.empty_like(yr)
             _lib.check(L.qbnn_dropout_q_mc(_lib.ptr(yr), B * N, B, 1, N, 0.75, d.s_y, d.z_y, dd.s_m, dd.z_m, 127, 77, 5, 4, None, _lib.ptr(yd), B * N, S, st))
@@ -1208,7 +1209,16 @@ def test_conv_pool_drop_small_map_against_generic_kernels():
     wn = np.ascontiguousarray(w.numpy().reshape(50, 500))
     _lib.check(L.qbnn_pack_weights_host(wn.ctypes.data_as(C.c_void_p), 50, 500, 100, 0, wp.ctypes.data_as(C.c_void_p)))
     wp, wd = torch.from_numpy(wp).cuda(), w.cuda().contiguous()
-    for (pool, drop, din, shared) in [(1, 1, 1, True), (0, 0, 0, False), (1, 0, 0, False), (0, 1, 0, False), (1, 1, 0, False), (0, 0, 1, True)]:
+    # the last case: per-sample weights (a Bayes-by-backprop conv: sample stride = the packed size), 3 different weights
+    w3 = torch.randint(-128, 128, (S, 50, 5, 5, 20), generator=gen, dtype=torch.int32).to(torch.int8)
+    wp3 = np.zeros((S, nb), np.int8)
+    for si in range(S):
+        wn3 = np.ascontiguousarray(w3[si].numpy().reshape(50, 500))
+        _lib.check(L.qbnn_pack_weights_host(wn3.ctypes.data_as(C.c_void_p), 50, 500, 100, 0, wp3[si].ctypes.data_as(C.c_void_p)))
+    wp3, wd3 = torch.from_numpy(wp3).cuda(), w3.cuda().contiguous()
+    for (pool, drop, din, shared) in [(1, 1, 1, True), (0, 0, 0, False), (1, 0, 0, False), (0, 1, 0, False), (1, 1, 0, False), (0, 0, 1, True), (1, 0, 0, "wps")]:
+        wps = shared == "wps"
+        shared = False if wps else shared
         x = torch.randint(0, 128, ((1 if shared else S), B, 14, 14, 20), generator=gen, dtype=torch.int32).to(torch.uint8).cuda()
         s_in, z_in = 0.04, 23
         d_in = _lib.DropoutDesc(0.8, 0.0039, 2, 0)
@@ -1225,7 +1235,8 @@ def test_conv_pool_drop_small_map_against_generic_kernels():
         d.relu, d.a_hi, d.has_bias = 0, 127, 1
         Sx = S if xss else 1
         yc = torch.empty((Sx, B, 14, 14, 50), dtype=torch.uint8, device="cuda")
-        _lib.check(L.qbnn_conv2d_i8_generic_mc(_lib.ptr(xin), xss, _lib.ptr(wd), 0, _lib.ptr(bias), _lib.ptr(yc), B * 9800, Sx, C.byref(d), st))
+        _lib.check(L.qbnn_conv2d_i8_generic_mc(_lib.ptr(xin), xss, _lib.ptr(wd3 if wps else wd), 25000 if wps else 0, _lib.ptr(bias), _lib.ptr(yc), B * 9800, Sx,
+                                               C.byref(d), st))
         ref, ho = yc, 14
         if pool:
             yp = torch.empty((Sx, B, 7, 7, 50), dtype=torch.uint8, device="cuda")
@@ -1240,7 +1251,8 @@ def test_conv_pool_drop_small_map_against_generic_kernels():
         ld = (width + 15) // 16 * 16
         Sy = S if (drop or din or not shared) else 1
         y = torch.full((Sy, B, ld), 0xCD, dtype=torch.uint8, device="cuda")
-        _lib.check(L.qbnn_conv_pool_drop_i8_mc(_lib.ptr(x), 0 if shared else B * 3920, _lib.ptr(wp), 0, _lib.ptr(bias), _lib.ptr(y), B * ld, ld, Sy, C.byref(d), pool,
+        _lib.check(L.qbnn_conv_pool_drop_i8_mc(_lib.ptr(x), 0 if shared else B * 3920, _lib.ptr(wp3 if wps else wp), nb if wps else 0, _lib.ptr(bias), _lib.ptr(y), B * ld, ld, Sy,
+                                               C.byref(d), pool,
                                                C.byref(d_out) if drop else None, None, C.byref(d_in) if din else None, None, s_in, z_in, 9, 2, st))
         torch.cuda.synchronize()
         assert torch.equal(y[:, :, :width], ref.reshape(ref.shape[0], B, width)), (pool, drop, din)
