@@ -2485,12 +2485,16 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const ArgsAr
   load_bias<COUT, BLK_THREADS>(bias_lds + 2 * COUT, a.b.bias, tid);
 
   v4i pre[PER_T];
+  // (the thread's chunk offsets are recomputed per call from an opaque copy of tid: kept in registers across the item loop they are
+  //  what spills at 48 -> 96 channels, and a spill reload is a vmcnt wait -- at the loop top it waited for the previous item's stores)
   auto fetch = [&](int item) {
     const int s = item / groups, img0 = (item - s * groups) * CA::G;
     const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
+    int t_ = tid;
+    if constexpr (!LDSW) asm volatile("" : "+v"(t_));      // (the weights-stationary 24 -> 48 block has registers to spare and is faster without)
 #pragma unroll
     for (int j = 0; j < PER_T; ++j) {
-      const int i = tid + j * BLK_THREADS;
+      const int i = t_ + j * BLK_THREADS;
       const int g = i / CPI, rem = i - g * CPI;
       const bool ok = (i < NCH) && (img0 + g < a.B);
       const int64_t off = ok ? ((int64_t)(img0 + g) * CA::HIN) * CA::ROWB + (int64_t)rem * 16 : 0;
@@ -2501,9 +2505,11 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const ArgsAr
   auto write_tile = [&](int item) {
     const int s = item / groups, img0 = (item - s * groups) * CA::G;
     const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+    int t_ = tid;
+    if constexpr (!LDSW) asm volatile("" : "+v"(t_));      // (the weights-stationary 24 -> 48 block has registers to spare and is faster without)
 #pragma unroll
     for (int j = 0; j < PER_T; ++j) {
-      const int i = tid + j * BLK_THREADS;
+      const int i = t_ + j * BLK_THREADS;
       if (i < NCH) {
         const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
         const bool ok = img0 + g < a.B;
