@@ -1277,3 +1277,117 @@ def test_lenet_mc_full_sample_count_against_oracle(golden_lenet_mc):
     np.testing.assert_allclose(probs, ref, rtol=RTOL, atol=1e-8)
     mean = q.GraphedPredictor(m, S)(xb.cuda(), seed).cpu().numpy()
     np.testing.assert_allclose(mean, ref.astype(np.float64).mean(0), rtol=RTOL, atol=1e-8)
+
+
+def _pack_per_sample(L, w):
+    """int8 [S, Cout, KH, KW, Cin] -> QBNN_LAYOUT_MFMA32 fragments [S, nbytes] on the device (krow as layers.Conv2d chooses it)."""
+    import ctypes as C
+    from quantised_bayesian_nets_amd import _lib
+    S, cout, kh, kw, cin = w.shape
+    k = kh * kw * cin
+    krow = kw * cin if cin % 8 == 0 else k
+    nb = L.qbnn_packed_weight_bytes(cout, k, krow, 0)
+    out = np.zeros((S, nb), np.int8)
+    for s in range(S):
+        src = np.ascontiguousarray(w[s].reshape(cout, k))
+        _lib.check(L.qbnn_pack_weights_host(src.ctypes.data_as(C.c_void_p), cout, k, krow, 0, out[s].ctypes.data_as(C.c_void_p)))
+    return torch.from_numpy(out).cuda(), nb
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_fused_blocks_random_qparams_against_oracle(seed):
+    """The fused BasicBlock kernels through the C ABI with RANDOM quantisation parameters (the fixtures only carry the calibrated ones):
+    zero points over their whole range incl. negative weight zero points, scales over two decades, 7- / 6- / 5-bit activations, with and
+    without bias, per-sample weights, ragged batches -- identity blocks at 24 / 48 / 96 / 192 channels and the three down-sampling
+    blocks, each against the oracle's conv -> conv -> quantized::add chain.  Bit-exact."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(100 + seed)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    S, B = 2, 3
+
+    def qp(use_bias, a_hi):
+        """(s_w, z_w, output zero point): without a bias the weight zero point stays small (nothing would take the mean out)"""
+        s_w = float(np.float32(10 ** rng.uniform(-3, -1.5)))
+        z_w = int(rng.integers(-25, 26)) if use_bias else int(rng.integers(-2, 3))
+        return s_w, z_w, int(rng.integers(a_hi // 4, 3 * a_hi // 4 + 1))
+
+    def conv_ref(x, w, b, stride, pad, s_x, z_x, s_w, z_w, s_y, z_y, relu, a_hi):
+        return np.stack([orc.conv2d_i8(x[s], w[s], b, stride, pad, s_x, z_x, s_w, z_w, s_y, z_y, relu, a_hi) for s in range(x.shape[0])])
+
+    def out_scale(x, w, stride, pad, s_x, z_x, s_w, z_w, a_hi, use_bias):
+        """(output scale, bias): the scale spreads this conv's real-valued outputs over about half of the activation range; the bias (when
+        the case has one) takes out the mean that far-off zero points put on the accumulator, plus noise per channel"""
+        xf = torch.from_numpy(x[0].astype(np.float64) - z_x).permute(0, 3, 1, 2)
+        wf = torch.from_numpy(w[0].astype(np.float64) - z_w).permute(0, 3, 1, 2)
+        acc = torch.nn.functional.conv2d(xf, wf, stride=stride, padding=pad)
+        sd = float((acc - acc.mean(dim=(0, 2, 3), keepdim=True)).std()) if use_bias else float(acc.std())
+        s_y = float(np.float32(s_x * s_w * sd * 4.0 / a_hi * rng.uniform(0.7, 1.5)))
+        bias = None
+        if use_bias:
+            bias = (-acc.mean(dim=(0, 2, 3)).numpy() * s_x * s_w + rng.normal(size=w.shape[1]) * s_y * a_hi / 8).astype(np.float32)
+        return s_y, bias
+
+    for Cc, H in ((24, 32), (48, 16), (96, 8), (192, 4)):
+        for down in (False, True):
+            if down and Cc == 192:
+                continue
+            a_hi = int(rng.choice([127, 127, 63, 31]))
+            Ci, Co, Hi = Cc, (2 * Cc if down else Cc), H
+            Ho = Hi // 2 if down else Hi
+            use_bias = bool(rng.integers(0, 2))
+            s_x = float(np.float32(10 ** rng.uniform(-2, -1)))
+            z_x = int(rng.integers(0, a_hi + 1)) if use_bias else int(a_hi // 2 + rng.integers(-4, 5))
+            x = rng.integers(0, a_hi + 1, (S, B, Hi, Hi, Ci), dtype=np.uint8)
+            wa = rng.integers(-128, 128, (S, Co, 3, 3, Ci), dtype=np.int8)
+            wb = rng.integers(-128, 128, (S, Co, 3, 3, Co), dtype=np.int8)
+            s_wa, z_wa, z_a = qp(use_bias, a_hi)
+            s_wb, z_wb, z_b = qp(use_bias, a_hi)
+            if not use_bias:
+                z_a = int(a_hi // 8)                   # ReLU output: zero point low, and conv b's input mean near it
+            # ---- oracle
+            stride = 2 if down else 1
+            s_a, ba = out_scale(x, wa, stride, 1, s_x, z_x, s_wa, z_wa, a_hi, use_bias)
+            t = conv_ref(x, wa, ba, stride, 1, s_x, z_x, s_wa, z_wa, s_a, z_a, True, a_hi)
+            s_b, bb = out_scale(t, wb, 1, 1, s_a, z_a, s_wb, z_wb, a_hi, use_bias)
+            u = conv_ref(t, wb, bb, 1, 1, s_a, z_a, s_wb, z_wb, s_b, z_b, False, a_hi)
+            z_o = int(rng.integers(0, a_hi // 2 + 1))
+            if down:
+                ws = rng.integers(-128, 128, (S, Co, 1, 1, Ci), dtype=np.int8)
+                s_ws, z_ws, z_s = qp(use_bias, a_hi)
+                s_s, bs = out_scale(x, ws, 2, 0, s_x, z_x, s_ws, z_ws, a_hi, use_bias)
+                sc = conv_ref(x, ws, bs, 2, 0, s_x, z_x, s_ws, z_ws, s_s, z_s, False, a_hi)
+                other, s_r, z_r = sc, s_s, z_s
+            else:
+                other, s_r, z_r = x, s_x, z_x
+            real = (u.astype(np.float64) - z_b) * s_b + (other.astype(np.float64) - z_r) * s_r
+            s_o = float(np.float32(real.std() * 6.0 / a_hi * rng.uniform(0.7, 1.5)))       # the Add's output scale: its real values over the range
+            ref = orc.qadd_relu(u, s_b, z_b, other, s_r, z_r, s_o, z_o, True, a_hi)
+            assert len(np.unique(t)) > 8 and len(np.unique(u)) > 8 and len(np.unique(ref)) > 3, "degenerate case: outputs saturated"
+            # ---- fused kernel
+            wa_d, nba = _pack_per_sample(L, wa)
+            wb_d, nbb = _pack_per_sample(L, wb)
+            dev = lambda v: None if v is None else torch.from_numpy(v).cuda()
+            ba_d, bb_d = dev(ba), dev(bb)
+            blk = _lib.BlockDesc()
+            blk.w_a, blk.w_a_sample_stride, blk.bias_a = wa_d.data_ptr(), nba, (ba_d.data_ptr() if use_bias else None)
+            blk.s_wa, blk.z_wa, blk.s_a, blk.z_a = s_wa, z_wa, s_a, z_a
+            blk.w_b, blk.w_b_sample_stride, blk.bias_b = wb_d.data_ptr(), nbb, (bb_d.data_ptr() if use_bias else None)
+            blk.s_wb, blk.z_wb, blk.s_b, blk.z_b, blk.s_o, blk.z_o = s_wb, z_wb, s_b, z_b, s_o, z_o
+            xd = torch.from_numpy(x).cuda()
+            y = torch.full((S, B, Ho, Ho, Co), 0xEE, dtype=torch.uint8, device="cuda")
+            if down:
+                ws_d, nbs = _pack_per_sample(L, ws)
+                bs_d = dev(bs)
+                dd = _lib.DownDesc()
+                dd.blk = blk
+                dd.w_s, dd.w_s_sample_stride, dd.bias_s = ws_d.data_ptr(), nbs, (bs_d.data_ptr() if use_bias else None)
+                dd.s_ws, dd.z_ws, dd.s_s, dd.z_s = s_ws, z_ws, s_s, z_s
+                _lib.check(L.qbnn_block_down_i8_mc(_lib.ptr(xd), xd[0].numel(), s_x, z_x, B, Hi, Ci, a_hi, C.byref(dd), _lib.ptr(y), y[0].numel(), S, st))
+            else:
+                _lib.check(L.qbnn_block_chain_i8_mc(_lib.ptr(xd), xd[0].numel(), s_x, z_x, B, Hi, Ci, a_hi, C.byref(blk), 1, _lib.ptr(y), y[0].numel(), S, st))
+            torch.cuda.synchronize()
+            got = y.cpu().numpy()
+            assert np.array_equal(got, ref), (Cc, down, a_hi, int((got != ref).sum()))
