@@ -1391,3 +1391,40 @@ def test_fused_blocks_random_qparams_against_oracle(seed):
             torch.cuda.synchronize()
             got = y.cpu().numpy()
             assert np.array_equal(got, ref), (Cc, down, a_hi, int((got != ref).sum()))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_sampler_random_qparams_against_oracle(seed):
+    """The weight sampler (qbnn_sample_weights_i8_multi: Philox -> eps_q -> quantized::mul -> quantized::add -> clamp_weight, computed
+    in fp32 on exact small integers) with RANDOM quantisation parameters against the oracle's integer / ATen-formula chain: zero points of
+    sigma, the product and the sum over +-60, scales over two decades, 8- and 4-bit weights, the fragment layout's fast path (Cin = 48,
+    96) and its general path (Cin = 3: whole-K rows), several samples starting at a non-zero global index.  Bit-exact."""
+    import quantised_bayesian_nets_amd as q
+    from quantised_bayesian_nets_amd.layers import Conv2d as QConv
+    from oracle import oracle as orc
+    rng = np.random.default_rng(500 + seed)
+    for (cin, cout, k) in ((48, 48, 3), (96, 192, 3), (3, 24, 3), (24, 48, 1)):
+        w_bits = int(rng.choice([8, 4]))
+        args = types.SimpleNamespace(activation_precision=7, weight_precision=w_bits)
+        layer = QConv(cin, cout, (k, k), stride=1, padding=k // 2, bias=False, args=args)
+        layer.layer_id = int(rng.integers(0, 21))
+        mu = rng.integers(-128, 128, (cout, cin, k, k), dtype=np.int8)                 # OIHW, as the reference's state dict holds it
+        sg = rng.integers(-128, 128, (cout, cin, k, k), dtype=np.int8)
+        s_w, z_w = float(np.float32(10 ** rng.uniform(-3, -1.5))), int(rng.integers(-60, 61))
+        s_sg, z_sg = float(np.float32(10 ** rng.uniform(-4, -2))), int(rng.integers(-128, -60))     # softplus(rho) > 0: the reference's sigma sits above its zero point
+        s_mul, z_mul = float(np.float32(s_sg * 128 * 3.0 * rng.uniform(0.5, 2) / 127)), int(rng.integers(-60, 61))
+        s_add, z_add = float(np.float32(s_w * rng.uniform(0.8, 1.6))), int(rng.integers(-60, 61))
+        st = {"weight": mu, "weight.q_scale": s_w, "weight.q_zero_point": z_w, "std": sg, "std.q_scale": s_sg, "std.q_zero_point": z_sg,
+              "scale": 0.1, "zero_point": 3, "add_weight.scale": s_add, "add_weight.zero_point": z_add, "mul_noise.scale": s_mul,
+              "mul_noise.zero_point": z_mul}
+        layer.load_reference_state(st, "")
+        p = orc.sample_params(s_w, z_w, s_sg, z_sg, s_mul, z_mul, s_add, z_add, w_bits)
+        S, sb, sd = 5, 254, 77 + seed                                                     # 5 samples: one full group of 4 and a ragged one
+        w = layer.sample_weights("cuda", samples=S, seed=sd, sample_begin=sb).cpu().numpy()
+        mu_l, sg_l = orc.oihw_to_ohwi(mu), orc.oihw_to_ohwi(sg)
+        seen = set()
+        for s in range(S):
+            ref = orc.sample_weights_i8_philox(mu_l, sg_l, p, sd, layer.layer_id, sb + s)
+            seen.update(np.unique(ref).tolist())
+            assert np.array_equal(w[s], _pack(layer, ref)), (cin, cout, k, w_bits, s)
+        assert len(seen) > (8 if w_bits == 4 else 40), "degenerate case: the sampled weights barely vary"
