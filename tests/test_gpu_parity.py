@@ -1428,3 +1428,52 @@ def test_sampler_random_qparams_against_oracle(seed):
             seen.update(np.unique(ref).tolist())
             assert np.array_equal(w[s], _pack(layer, ref)), (cin, cout, k, w_bits, s)
         assert len(seen) > (8 if w_bits == 4 else 40), "degenerate case: the sampled weights barely vary"
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_conv_post_ops_random_qparams_against_separate_kernels(seed):
+    """qbnn_conv2d_i8_post_mc (dropout, and dropout + Add + ReLU, in the conv epilogue) with RANDOM quantisation parameters against
+    qbnn_conv2d_i8_mc -> qbnn_dropout_q_mc (-> qbnn_add_relu_q_mc), which the other tests tie to the oracle and the reference: mask zero
+    points 0..127, conv / residual / sum zero points and scales at random, keep probabilities 0.5..0.95, ragged batch.  Bit-exact."""
+    import ctypes as C
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(900 + seed)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    S, B = 3, 5
+    for (H, Ci, Co, k, stride) in ((32, 24, 24, 3, 1), (16, 48, 96, 3, 2), (8, 96, 96, 3, 1), (16, 48, 96, 1, 2), (4, 192, 192, 3, 1)):
+        Ho = H // stride
+        x = torch.from_numpy(rng.integers(0, 128, (S, B, H, H, Ci), dtype=np.uint8)).cuda()
+        w = rng.integers(-128, 128, (1, Co, k, k, Ci), dtype=np.int8)
+        wp, nb = _pack_per_sample(L, w)
+        bias = torch.from_numpy((rng.normal(size=Co) * 3).astype(np.float32)).cuda()
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.pad = B, H, H, Ci, Co, k, stride, k // 2
+        d.s_x, d.z_x = float(np.float32(10 ** rng.uniform(-2, -1))), int(rng.integers(0, 128))
+        # a {0, 1} mask quantises to about 1 / s_m; the dropout's output lives on the mask's scale, so the conv's output scale has to be of
+        # that order for anything but saturation to come out (as in the reference's calibrated models); the weight scale follows from it
+        keep, s_m, z_m, lid = float(np.float32(rng.uniform(0.5, 0.95))), float(np.float32(rng.uniform(1.0, 2.0) / 255.0)), int(rng.integers(0, 128)), int(rng.integers(0, 20))
+        d.s_y, d.z_y = float(np.float32(s_m * rng.uniform(0.4, 1.0))), int(rng.integers(20, 100))
+        d.z_w = int(rng.integers(-10, 11))
+        d.s_w = float(np.float32(d.s_y * 127 / (4 * d.s_x * 74 * 37 * np.sqrt(k * k * Ci))))
+        d.relu, d.a_hi, d.has_bias = int(rng.integers(0, 2)), 127, 1
+        mult = float(np.float32(1.0) / np.float32(keep))
+        other = torch.from_numpy(rng.integers(0, 128, (S, B, Ho, Ho, Co), dtype=np.uint8)).cuda()
+        s_b, z_b = float(np.float32(10 ** rng.uniform(-2, -1))), int(rng.integers(0, 128))
+        s_a = float(np.float32(s_m * mult))
+        s_o, z_o = float(np.float32(max(s_a, s_b) * rng.uniform(1.0, 2.5))), int(rng.integers(0, 64))
+        n = B * Ho * Ho * Co
+        yc = torch.empty((S, B, Ho, Ho, Co), dtype=torch.uint8, device="cuda")
+        yd, ya = torch.empty_like(yc), torch.empty_like(yc)
+        _lib.check(L.qbnn_conv2d_i8_mc(_lib.ptr(x), x[0].numel(), _lib.ptr(wp), 0, _lib.ptr(bias), None, 0, _lib.ptr(yc), n, S, C.byref(d), st))
+        _lib.check(L.qbnn_dropout_q_mc(_lib.ptr(yc), n, B, Ho * Ho, Co, keep, d.s_y, d.z_y, s_m, z_m, 127, 31 + seed, lid, 7, None, _lib.ptr(yd), n, S, st))
+        _lib.check(L.qbnn_add_relu_q_mc(_lib.ptr(yd), n, s_a, z_m, _lib.ptr(other), n, s_b, z_b, _lib.ptr(ya), n, n, s_o, z_o, 127, 1, S, st))
+        for add in (0, 1):
+            q = _lib.PostDesc(keep, s_m, z_m, lid, add, s_a, s_b, z_b, s_o, z_o)
+            y = torch.full_like(yc, 0x5A)
+            _lib.check(L.qbnn_conv2d_i8_post_mc(_lib.ptr(x), x[0].numel(), _lib.ptr(wp), 0, _lib.ptr(bias), _lib.ptr(y), n, S, C.byref(d), C.byref(q), None,
+                                                _lib.ptr(other) if add else None, n if add else 0, 31 + seed, 7, st))
+            torch.cuda.synchronize()
+            ref = ya if add else yd
+            assert torch.equal(y, ref), (H, Ci, Co, k, add, int((y != ref).sum()))
+        assert len(torch.unique(yd)) > 8
