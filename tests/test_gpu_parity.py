@@ -1477,3 +1477,73 @@ def test_conv_post_ops_random_qparams_against_separate_kernels(seed):
             ref = ya if add else yd
             assert torch.equal(y, ref), (H, Ci, Co, k, add, int((y != ref).sum()))
         assert len(torch.unique(yd)) > 8
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_fused_stem_chain_random_qparams_against_oracle(seed):
+    """qbnn_stem_chain_i8_mc (layers.0 on the 27-tap patches fused in front of one or two 24-channel identity blocks: the dominant kernel
+    of the benchmark) with RANDOM quantisation parameters and per-sample weights against the oracle's conv / conv / conv / add chain.
+    Bit-exact."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(1300 + seed)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    S, B, a_hi = 2, 3, 127
+    dev = lambda v: torch.from_numpy(v).cuda()
+
+    def conv_s(x, w, b, s_x, z_x, s_w, z_w, s_y, z_y, relu):
+        return np.stack([orc.conv2d_i8(x[s if x.shape[0] > 1 else 0], w[s], b, 1, 1, s_x, z_x, s_w, z_w, s_y, z_y, relu, a_hi) for s in range(S)])
+
+    def scale_bias(x, w, s_x, z_x, s_w, z_w):
+        xf = torch.from_numpy(x[0].astype(np.float64) - z_x).permute(0, 3, 1, 2)
+        wf = torch.from_numpy(w[0].astype(np.float64) - z_w).permute(0, 3, 1, 2)
+        acc = torch.nn.functional.conv2d(xf, wf, padding=1)
+        sd = float((acc - acc.mean(dim=(0, 2, 3), keepdim=True)).std())
+        s_y = float(np.float32(s_x * s_w * sd * 4.0 / a_hi * rng.uniform(0.7, 1.5)))
+        return s_y, (-acc.mean(dim=(0, 2, 3)).numpy() * s_x * s_w + rng.normal(size=w.shape[1]) * s_y * a_hi / 8).astype(np.float32)
+
+    for n_blocks in (1, 2):
+        x = rng.integers(0, a_hi + 1, (1, B, 32, 32, 3), dtype=np.uint8)            # the quantised image, shared by the samples
+        s_in, z_in = float(np.float32(10 ** rng.uniform(-2, -1))), int(rng.integers(0, 128))
+        w0 = rng.integers(-128, 128, (S, 24, 3, 3, 3), dtype=np.int8)
+        s_w0, z_w0, z_y0 = float(np.float32(10 ** rng.uniform(-3, -1.5))), int(rng.integers(-25, 26)), int(rng.integers(10, 60))
+        s_y0, b0 = scale_bias(x, w0, s_in, z_in, s_w0, z_w0)
+        h = conv_s(x, w0, b0, s_in, z_in, s_w0, z_w0, s_y0, z_y0, True)
+        s_h, z_h = s_y0, z_y0
+        blks = (_lib.BlockDesc * n_blocks)()
+        keep = []
+        for bi in range(n_blocks):
+            wa = rng.integers(-128, 128, (S, 24, 3, 3, 24), dtype=np.int8)
+            wb = rng.integers(-128, 128, (S, 24, 3, 3, 24), dtype=np.int8)
+            s_wa, z_wa, z_a = float(np.float32(10 ** rng.uniform(-3, -1.5))), int(rng.integers(-25, 26)), int(rng.integers(10, 60))
+            s_wb, z_wb, z_b = float(np.float32(10 ** rng.uniform(-3, -1.5))), int(rng.integers(-25, 26)), int(rng.integers(30, 100))
+            s_a, ba = scale_bias(h, wa, s_h, z_h, s_wa, z_wa)
+            t = conv_s(h, wa, ba, s_h, z_h, s_wa, z_wa, s_a, z_a, True)
+            s_b, bb = scale_bias(t, wb, s_a, z_a, s_wb, z_wb)
+            u = conv_s(t, wb, bb, s_a, z_a, s_wb, z_wb, s_b, z_b, False)
+            real = (u.astype(np.float64) - z_b) * s_b + (h.astype(np.float64) - z_h) * s_h
+            s_o, z_o = float(np.float32(real.std() * 6.0 / a_hi * rng.uniform(0.7, 1.5))), int(rng.integers(0, 50))
+            h = orc.qadd_relu(u, s_b, z_b, h, s_h, z_h, s_o, z_o, True, a_hi)
+            assert len(np.unique(t)) > 8 and len(np.unique(h)) > 8
+            wa_d, nba = _pack_per_sample(L, wa)
+            wb_d, nbb = _pack_per_sample(L, wb)
+            ba_d, bb_d = dev(ba), dev(bb)
+            keep += [wa_d, wb_d, ba_d, bb_d]
+            k = blks[bi]
+            k.w_a, k.w_a_sample_stride, k.bias_a, k.s_wa, k.z_wa, k.s_a, k.z_a = wa_d.data_ptr(), nba, ba_d.data_ptr(), s_wa, z_wa, s_a, z_a
+            k.w_b, k.w_b_sample_stride, k.bias_b, k.s_wb, k.z_wb, k.s_b, k.z_b = wb_d.data_ptr(), nbb, bb_d.data_ptr(), s_wb, z_wb, s_b, z_b
+            k.s_o, k.z_o = s_o, z_o
+            s_h, z_h = s_o, z_o
+        w0_d, nb0 = _pack_per_sample(L, w0)
+        b0_d = dev(b0)
+        xd = dev(x[0])
+        im = torch.empty((B, 1024, 32), dtype=torch.int8, device="cuda")
+        _lib.check(L.qbnn_im2col3x3_c3(_lib.ptr(xd), B, 32, 32, z_in, _lib.ptr(im), st))
+        y = torch.full((S, B, 32, 32, 24), 0xEE, dtype=torch.uint8, device="cuda")
+        _lib.check(L.qbnn_stem_chain_i8_mc(_lib.ptr(im), B, _lib.ptr(w0_d), nb0, _lib.ptr(b0_d), s_in, s_w0, z_w0, s_y0, z_y0, a_hi, blks, n_blocks,
+                                           _lib.ptr(y), y[0].numel(), S, st))
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        assert np.array_equal(got, h), (n_blocks, int((got != h).sum()))
