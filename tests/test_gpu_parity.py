@@ -1547,3 +1547,39 @@ def test_fused_stem_chain_random_qparams_against_oracle(seed):
         torch.cuda.synchronize()
         got = y.cpu().numpy()
         assert np.array_equal(got, h), (n_blocks, int((got != h).sum()))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_head_random_qparams_against_oracle(seed):
+    """qbnn_head_i8_mc (AvgPool -> Linear -> DeQuant -> softmax; both its forms: int8-dword dot products when C % 16 == 0, the scalar one
+    otherwise) with RANDOM quantisation parameters, per-sample weights, with and without bias against the oracle.  The integers behind the
+    probabilities are exact, so the probabilities agree to float rounding of the softmax (1e-6)."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(1700 + seed)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    S, B = 3, 7
+    for (Cc, k, N, use_bias) in ((192, 4, 10, False), (192, 4, 10, True), (24, 2, 5, True), (100, 1, 16, True)):
+        a_hi = int(rng.choice([127, 63]))
+        x = rng.integers(0, a_hi + 1, (S, B, k, k, Cc), dtype=np.uint8)
+        w = rng.integers(-128, 128, (S, N, Cc), dtype=np.int8)
+        bias = (rng.normal(size=N) * 0.5).astype(np.float32) if use_bias else None
+        # zero points near the operands' means (nothing else takes the mean off the logits); the output scale from the accumulator's spread
+        s_x, z_x = float(np.float32(10 ** rng.uniform(-2, -1))), int(a_hi // 2 + rng.integers(-12, 13))
+        s_w, z_w = float(np.float32(10 ** rng.uniform(-3, -2))), int(rng.integers(-4, 5))
+        s_y = float(np.float32(s_x * s_w * 74 * (a_hi / 3.46 / k) * np.sqrt(Cc) * 8 / a_hi * rng.uniform(0.7, 1.5)))
+        z_y = int(rng.integers(a_hi // 4, 3 * a_hi // 4))
+        d = _lib.HeadDesc(B, k, Cc, N, s_x, z_x, s_w, z_w, s_y, z_y, a_hi, int(use_bias))
+        xd, wd = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+        bd = None if bias is None else torch.from_numpy(bias).cuda()
+        probs = torch.empty((S, B, N), dtype=torch.float32, device="cuda")
+        _lib.check(L.qbnn_head_i8_mc(_lib.ptr(xd), xd[0].numel(), _lib.ptr(wd), N * Cc, _lib.ptr(bd), _lib.ptr(probs), S, C.byref(d), st))
+        torch.cuda.synchronize()
+        for s in range(S):
+            pooled = orc.avgpool_q(x[s], k, z_x, a_hi).reshape(B, Cc)
+            logits = orc.linear_i8(pooled, w[s], bias, s_x, z_x, s_w, z_w, s_y, z_y, False, a_hi)
+            assert len(np.unique(logits)) > 4
+            ref = orc.dequant_softmax(logits, s_y, z_y)
+            np.testing.assert_allclose(probs[s].cpu().numpy(), ref, rtol=1e-6, atol=1e-9, err_msg=str((Cc, k, N, s)))
