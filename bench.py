@@ -56,11 +56,8 @@ def conv_ops(S, B, H, Cin, Cout, ks, stride):
 
 
 def kernel_source_sha16():
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("qbnn_kernels.hip", "qbnn_rng.cuh", "qbnn_eps_table.h"):
-        h.update(open(os.path.join(ROOT, "quantised_bayesian_nets_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    from quantised_bayesian_nets_amd import build as _b
+    return _b.kernel_source_sha16()
 
 
 def _wl_resnet(w_bits, samples_default, tag):

@@ -1,0 +1,1176 @@
+// libqbnn_hip.so -- fused BasicBlock kernels of the int8 path (persistent workgroups, activations stay in LDS between a
+// block's convs) and their C ABI: qbnn_block_chain_i8_mc / qbnn_stem_chain_i8_mc / qbnn_block_down_i8_mc and the
+// multi-call (ensemble) forms.  Shared device code: qbnn_conv.h.
+#include "qbnn_host.h"
+
+#ifdef QBNN_STAMP
+static unsigned long long* g_stamp_buf = nullptr;
+QBNN_EXPORT void qbnn_debug_stamp_buffer(void* p) { g_stamp_buf = (unsigned long long*)p; hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_dev_ptr), &p, sizeof(p)); }
+QBNN_EXPORT void qbnn_debug_read_inner(unsigned long long* host4) {
+  hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_inner), 32);
+  unsigned long long z[4] = {0, 0, 0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_inner), z, 32);
+}
+#endif
+
+// =====================================================================================
+// Fused down-sampling BasicBlock (models_bbb.py:146-183 with stride 2): shortcut 1x1/s2 conv, stem.0 3x3/s2 ConvReLU,
+// stem.3 3x3 conv, Add, ReLU in one persistent kernel.
+//   X tile (Cin, HIN): centred block input      --conv_s-->  SC: dense quint8 [M][COUT] (the residual operand)
+//                                               --conv_a-->  T tile (COUT, HO): centred stem.0 output
+//   T --conv_b--> + SC --> SC in place (block output, quint8) --> HBM
+// =====================================================================================
+struct DownArgs {
+  const uint8_t* x; int64_t x_ss;
+  uint8_t* y; int64_t y_ss;
+  int B, n_samples, z_in;
+  QConv s, a, b; QAdd add;
+};
+
+template <class CA, class CS, class CB, bool LDSW> static int launch_block_down_ws(const DownArgs& a, hipStream_t st);
+static bool no_pingpong() {
+  static const bool v = [] { const char* e = getenv("QBNN_NO_PINGPONG"); return e && e[0] == '1'; }();
+  return v;
+}
+
+//                           CIN COUT K  S  HIN HALO G  MB NB
+using D24_a = ConvCfg<24, 48, 3, 2, 32, 1, 1, 1, 2>;
+using D24_s = ConvCfg<24, 48, 1, 2, 32, 1, 1, 1, 2>;
+using D24_b = ConvCfg<48, 48, 3, 1, 16, 1, 1, 1, 2>;
+using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 4, 1, 3, false>;
+using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 4, 1, 3, false>;
+using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, false, 36, 8>;
+using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
+using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, 1, 3, false>;
+using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
+
+static int build_down_args(DownArgs& a, const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t a_hi, const qbnn_down_desc* d,
+                           uint8_t* y, int64_t y_ss, int32_t n_samples) {
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = B; a.n_samples = n_samples; a.z_in = z_x;
+  qbnn_conv_desc c;
+  memset(&c, 0, sizeof(c));
+  c.a_hi = a_hi;
+  int rc;
+  c.s_x = s_x; c.z_x = z_x; c.s_w = d->s_ws; c.z_w = d->z_ws; c.s_y = d->s_s; c.z_y = d->z_s; c.relu = 0; c.has_bias = d->bias_s != nullptr;
+  if ((rc = fill_qconv(a.s, d->w_s, d->w_s_sample_stride, d->bias_s, &c))) return rc;
+  c.s_w = d->blk.s_wa; c.z_w = d->blk.z_wa; c.s_y = d->blk.s_a; c.z_y = d->blk.z_a; c.relu = 1; c.has_bias = d->blk.bias_a != nullptr;
+  if ((rc = fill_qconv(a.a, d->blk.w_a, d->blk.w_a_sample_stride, d->blk.bias_a, &c))) return rc;
+  c.s_x = d->blk.s_a; c.z_x = d->blk.z_a; c.s_w = d->blk.s_wb; c.z_w = d->blk.z_wb; c.s_y = d->blk.s_b; c.z_y = d->blk.z_b; c.relu = 0;
+  c.has_bias = d->blk.bias_b != nullptr;
+  if ((rc = fill_qconv(a.b, d->blk.w_b, d->blk.w_b_sample_stride, d->blk.bias_b, &c))) return rc;
+  c.s_r = d->s_s; c.z_r = d->z_s; c.s_o = d->blk.s_o; c.z_o = d->blk.z_o;
+  return fill_qadd(a.add, &c);
+}
+
+template <class CA, class CS, class CB, bool LDSW> static int launch_block_down_ws_multi(const DownArgs* arr, int n, hipStream_t st);
+
+QBNN_EXPORT int qbnn_block_down_i8_multi(const qbnn_down_call* calls, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t a_hi, void* stream) {
+  if (!calls || n_calls <= 0 || B <= 0) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: bad argument%s");
+  hipStream_t st = (hipStream_t)stream;
+  for (int c0 = 0; c0 < n_calls;) {
+    const int n = n_calls - c0 < QBNN_FUSED_CALLS ? n_calls - c0 : QBNN_FUSED_CALLS;
+    DownArgs arr[QBNN_FUSED_CALLS];
+    int rc;
+    for (int i = 0; i < n; ++i) {
+      const qbnn_down_call& k = calls[c0 + i];
+      if (!k.x || !k.y || !k.desc || k.n_samples <= 0 || !k.desc->blk.w_a || !k.desc->blk.w_b || !k.desc->w_s)
+        return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: bad call entry%s");
+      if ((rc = build_down_args(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.desc, k.y, k.y_sample_stride, k.n_samples))) return rc;
+    }
+    if (Cin == 24 && H == 32) rc = launch_block_down_ws_multi<D24_a, D24_s, D24_b, true>(arr, n, st);
+    else if (Cin == 48 && H == 16) rc = launch_block_down_ws_multi<D48_a, D48_s, D48_b, false>(arr, n, st);
+    else if (Cin == 96 && H == 8) rc = launch_block_down_ws_multi<D96_a, D96_s, D96_b, false>(arr, n, st);
+    else return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
+    if (rc) return rc;
+    c0 += n;
+  }
+  return QBNN_OK;
+}
+
+QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cin,
+                                      int32_t a_hi, const qbnn_down_desc* d, uint8_t* y, int64_t y_ss, int32_t n_samples,
+                                      void* stream) {
+  if (!x || !y || !d || n_samples <= 0 || B <= 0 || !d->blk.w_a || !d->blk.w_b || !d->w_s)
+    return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: bad argument%s");
+  DownArgs a;
+  if (int rc = build_down_args(a, x, x_ss, s_x, z_x, B, a_hi, d, y, y_ss, n_samples)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  // (a ping-pong variant of this block -- phases W / M_a / E_sa / M_b / E_b on two 4-wave groups -- measured 15 % SLOWER
+  //  than the weights-stationary kernel: five barrier intervals per image, each as long as the slower group's phase)
+  if (Cin == 24 && H == 32) return launch_block_down_ws<D24_a, D24_s, D24_b, true>(a, st);
+  if (Cin == 48 && H == 16) return launch_block_down_ws<D48_a, D48_s, D48_b, false>(a, st);
+  if (Cin == 96 && H == 8) return launch_block_down_ws<D96_a, D96_s, D96_b, false>(a, st);
+  return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
+}
+
+// LDSW = true : weights-stationary as described above (contiguous item ranges).
+// LDSW = false: the block's weights are too large for LDS -- every wave streams its fragments from L2 (conv_passes) and
+//               the workgroups walk the items interleaved per XCD (ItemWalk), so that the workgroups sharing an L2
+//               work on the same MC sample at a time and its weights stay hot there.  Same barrier / prefetch scheme.
+// STEM = true (layer 1 only): the network's first conv (3 -> 24 channels, on the pre-gathered 27-tap patches) runs inside
+//               the same kernel -- its output never goes to HBM (that tensor is the largest of the network: 629 MB per
+//               100-sample step written and read back).  The item's input is then its image's patch block (32 KiB,
+//               shared by all samples, L2-resident), staged in a dense LDS tile; conv0's epilogue writes the X tile.
+template <class C, int NBLK, bool LDSW, bool STEM = false, int NM = 1>
+__global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all) {
+  const ChainArgs<NBLK>& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  using C0 = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;      // layer 0 on the patch tensor: K = 27 -> 32, one k-step
+  static_assert(!STEM || (LDSW && C::CIN == 24 && C::HIN == 32 && C::G == 1), "the fused stem feeds the 32x32x24 chain");
+  static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int NTHR = BLK_THREADS, NWV = BLK_WAVES;
+  constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
+  constexpr int WB = LDSW ? WConv<C>::BYTES : 0;
+  uint8_t* xt = smem;
+  uint8_t* tt = smem + TILES;
+  uint8_t* wl = smem + 2 * TILES;                                            // [NBLK][2] whole convs
+  float* bias_lds = reinterpret_cast<float*>(wl + 2 * NBLK * WB);            // [NBLK][2][COUT]
+  uint8_t* im = reinterpret_cast<uint8_t*>(bias_lds + NBLK * 2 * C::COUT);   // STEM: patch tile [1024][32], stem weights, stem bias
+  uint8_t* wl0 = im + C0::TILE_BYTES;
+  float* bias0 = reinterpret_cast<float*>(wl0 + WConv<C0>::BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
+
+  constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
+  constexpr int NCH_IN = STEM ? C0::TILE_BYTES / 16 : NCH;                  // ... of its input (the patch block when STEM)
+  constexpr int PER_T = (NCH_IN + NTHR - 1) / NTHR, PER_TO = (NCH + NTHR - 1) / NTHR;
+  const int groups = (a.B + C::G - 1) / C::G;
+  int begin = 0, count;
+  const ItemWalk walk(a.n_samples * groups, blockIdx.x, gridDim.x);
+  if (LDSW) item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+  else count = walk.count;
+  auto item_at = [&](int it) { return LDSW ? begin + it : walk.item(it); };
+
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, NTHR>(xt, tid);
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, NTHR>(tt, tid);
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) {
+    load_bias<C::COUT, NTHR>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
+    load_bias<C::COUT, NTHR>(bias_lds + (2 * k + 1) * C::COUT, a.blk[k].b.bias, tid);
+  }
+  if (STEM) load_bias<C0::COUT, NTHR>(bias0, a.stem.bias, tid);
+
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    if constexpr (STEM) {
+      const uint8_t* xs = reinterpret_cast<const uint8_t*>(a.stem_x) + (int64_t)(img0 < a.B ? img0 : 0) * C0::TILE_BYTES;
+#pragma unroll
+      for (int j = 0; j < PER_T; ++j) pre[j] = *reinterpret_cast<const v4i*>(xs + (int64_t)(tid + j * NTHR) * 16);
+      return;
+    }
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = tid + j * NTHR;
+      const int g = i / CPI, rem = i - g * CPI;
+      const bool ok = (i < NCH) && (img0 + g < a.B);
+      const int64_t off = ok ? ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16 : 0;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + off);
+    }
+  };
+  // registers -> centred X tile interior.  Runs right after the same thread has read these very chunks out (end of
+  // the previous item), so no barrier separates the two.
+  auto write_tile = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    if constexpr (STEM) {          // the patches are already centred; conv0 produces the X tile
+#pragma unroll
+      for (int j = 0; j < PER_T; ++j) *reinterpret_cast<v4i*>(im + (tid + j * NTHR) * 16) = pre[j];
+      return;
+    }
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = tid + j * NTHR;
+      if (i < NCH) {
+        const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+        const bool ok = img0 + g < a.B;
+        const v4i v = pre[j];
+        uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
+        *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
+        *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
+      }
+    }
+  };
+  if (count <= 0) return;
+  fetch(item_at(0));
+  write_tile(item_at(0));
+  int cur_s = -1;
+  QBNN_STAMP_DECL
+  for (int it = 0; it < count; ++it) {
+    QBNN_STAMP_START();
+    const int item = item_at(it);
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const bool more = it + 1 < count;
+    // the next item's input: in flight for the whole of this item (unconditional, so the wait counts at its use are
+    // exact: the last iteration re-reads its own item and drops it)
+    fetch(more ? item_at(it + 1) : item);
+    if (LDSW && s != cur_s) {    // workgroup-uniform; at most a few times per launch
+      __syncthreads();           // every wave is done with the previous sample's weights (and the prologue's LDS writes)
+#pragma unroll
+      for (int k = 0; k < NBLK; ++k) {
+        dma_conv<C, NWV>(wl + (2 * k) * WB, a.blk[k].a.w + (int64_t)s * a.blk[k].a.w_ss, wave, lane);
+        dma_conv<C, NWV>(wl + (2 * k + 1) * WB, a.blk[k].b.w + (int64_t)s * a.blk[k].b.w_ss, wave, lane);
+      }
+      if (STEM) dma_conv<C0, NWV>(wl0, a.stem.w + (int64_t)s * a.stem.w_ss, wave, lane);
+      dma_barrier();             // vmcnt(0) + barrier: the weights have landed
+      cur_s = s;
+    }
+    QBNN_STAMP_AT(0);
+    lds_barrier();
+    QBNN_STAMP_AT(1);
+    if constexpr (STEM) {        // layers.0 (ConvReLU2d): patch tile -> X tile, centred on its own zero point (= a.z_in)
+      EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, a.stem};
+      conv_core<C0, decltype(epi), NWV>(im, wl0, bias0, a.stem, epi, wave, lane);
+      lds_barrier();
+    }
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+      const BlockParams& bp = a.blk[k];
+      {
+        EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{tt, bp.a};
+        if constexpr (LDSW) conv_core<C, decltype(epi), NWV>(xt, wl + (2 * k) * WB, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
+        else conv_passes<C, decltype(epi), NWV>(xt, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
+      }
+      QBNN_STAMP_AT(2);
+      lds_barrier();
+      QBNN_STAMP_AT(3);
+      {
+        EpiTileResInPlace<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, bp.b, bp.add};
+        if constexpr (LDSW) conv_core<C, decltype(epi), NWV>(tt, wl + (2 * k + 1) * WB, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
+        else conv_passes<C, decltype(epi), NWV>(tt, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
+      }
+      QBNN_STAMP_AT(4);
+      lds_barrier();
+      QBNN_STAMP_AT(5);
+    }
+    // ---- X tile interior (centred by the last add's zero point) -> quint8 registers; next item's input -> X tile;
+    //      registers -> HBM.  The stores are issued last so that nothing ever waits on them: the only vmcnt waits
+    //      of the loop are for the input loads issued a whole item earlier.
+    {
+      const uint32_t z4 = (uint32_t)a.blk[NBLK - 1].add.z_o * 0x01010101u;
+      uint8_t* ys = a.y + (int64_t)s * a.y_ss;
+      v4i outv[PER_TO];
+#pragma unroll
+      for (int j = 0; j < PER_TO; ++j) {
+        const int i = tid + j * NTHR;
+        if (i < NCH) {
+          const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
+          const v2i lo = *reinterpret_cast<const v2i*>(d), hi = *reinterpret_cast<const v2i*>(d + 8);
+          outv[j] = v4i{(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
+        }
+      }
+      if (more) write_tile(item_at(it + 1));
+#pragma unroll
+      for (int j = 0; j < PER_TO; ++j) {
+        const int i = tid + j * NTHR;
+        if (i < NCH) {
+          const int g = i / CPI, rem = i - g * CPI;
+          if (img0 + g < a.B)
+            *reinterpret_cast<v4i*>(ys + ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16) = outv[j];
+        }
+      }
+    }
+    QBNN_STAMP_AT(6);
+  }
+#ifdef QBNN_STAMP
+  if (a.dbg && (tid & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(a.dbg + wave * 8 + i, st_acc[i]);
+#endif
+}
+
+// =====================================================================================
+// Ping-pong identity chain (48 channels): the workgroup's 8 waves form two groups of 4 (one wave per SIMD each).
+// Each group owns one work item at a time (its own X0 / X1 / T tiles; the block weights in LDS are shared) and walks
+// the phase sequence   M_a  E_a  M_b  E_b   (M = the conv's MFMA K loop into parked accumulators, E = its
+// requantising epilogue), one phase per barrier interval.  Group 1 runs one interval behind group 0, so in every
+// interval each SIMD holds one wave issuing MFMAs and one wave issuing epilogue VALU -- the matrix and vector pipes
+// overlap instead of alternating.  Input write / output read-out ride along: the finished item k-1 leaves from
+// X[(k-1)&1] during M_a(k); the input of item k+1 enters X[(k+1)&1] during E_a(k).
+// =====================================================================================
+template <class C, int NBLK>
+__global__ __launch_bounds__(512) void block_chain_pp_kernel(const ChainArgs<NBLK> a) {
+  static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
+  static_assert(!C::ROWREUSE && C::NPASS == 4, "one MFMA pass per wave of a 4-wave group");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int GT = 256;                                                   // threads per group
+  constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
+  constexpr int WB = WConv<C>::BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
+  const int grp = wave >> 2, lw = wave & 3, ltid = tid & (GT - 1);
+  uint8_t* xg = smem + grp * 3 * TILES;                                     // X0, X1, T of this group
+  uint8_t* tt = xg + 2 * TILES;
+  uint8_t* wl = smem + 6 * TILES;                                           // [NBLK][2] whole convs
+  float* bias_lds = reinterpret_cast<float*>(wl + 2 * NBLK * WB);           // [NBLK][2][COUT]
+
+  constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;
+  constexpr int PER_T = (NCH + GT - 1) / GT;
+  const int groups = (a.B + C::G - 1) / C::G;                               // items per sample (host: even)
+  int pbegin, pcount;                                                       // contiguous range of item PAIRS
+  item_range(a.n_samples * groups / 2, blockIdx.x, gridDim.x, pbegin, pcount);
+
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, GT>(xg, ltid);
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, GT>(xg + TILES, ltid);
+  zero_halo<C::TW, C::PIXB, C::TILE_BYTES, C::G, GT>(tt, ltid);
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) {
+    load_bias<C::COUT, 512>(bias_lds + (2 * k) * C::COUT, a.blk[k].a.bias, tid);
+    load_bias<C::COUT, 512>(bias_lds + (2 * k + 1) * C::COUT, a.blk[k].b.bias, tid);
+  }
+  if (pcount <= 0) return;
+
+  auto item_of = [&](int k) { return 2 * (pbegin + k) + grp; };
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = ltid + j * GT;
+      const int g = i / CPI, rem = i - g * CPI;
+      const bool ok = (i < NCH) && (img0 + g < a.B);
+      const int64_t off = ok ? ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16 : 0;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + off);
+    }
+  };
+  auto write_tile = [&](uint8_t* xt, int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = ltid + j * GT;
+      if (i < NCH) {
+        const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+        const bool ok = img0 + g < a.B;
+        const v4i v = pre[j];
+        uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
+        *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
+        *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
+      }
+    }
+  };
+  auto store_tile = [&](const uint8_t* xt, int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const uint32_t z4 = (uint32_t)a.blk[NBLK - 1].add.z_o * 0x01010101u;
+    uint8_t* ys = a.y + (int64_t)s * a.y_ss;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = ltid + j * GT;
+      if (i < NCH) {
+        const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+        if (img0 + g < a.B) {
+          const uint8_t* d = xt + g * C::TILE_BYTES + (row + 1) * C::PITCH + C::row_chunk_off(within);
+          const v2i lo = *reinterpret_cast<const v2i*>(d), hi = *reinterpret_cast<const v2i*>(d + 8);
+          v4i v = {(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
+          *reinterpret_cast<v4i*>(ys + ((int64_t)(img0 + g) * C::HIN) * C::ROWB + (int64_t)rem * 16) = v;
+        }
+      }
+    }
+  };
+
+  fetch(item_of(0));
+  write_tile(xg, item_of(0));
+  fetch(item_of(pcount > 1 ? 1 : 0));
+  constexpr int NPH = 4 * NBLK;
+  const int n_int = NPH * pcount + 1;                  // group 1 finishes one interval after group 0
+  ConvAcc<C> A;
+  int cur_s = -1;
+#pragma unroll 1
+  for (int t = 0; t < n_int; ++t) {
+    // ---- interval boundary.  Group 0 enters a new pair every NPH intervals; if that pair belongs to another MC
+    // sample the block weights are replaced here -- group 1 is in its last epilogue (no weight reads) meanwhile.
+    const int k0 = t / NPH;
+    bool reload = false;
+    int s0 = cur_s;
+    if (t - k0 * NPH == 0 && k0 < pcount) { s0 = (2 * (pbegin + k0)) / groups; reload = s0 != cur_s; }
+    if (reload) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NBLK; ++k) {
+        dma_conv<C, 8>(wl + (2 * k) * WB, a.blk[k].a.w + (int64_t)s0 * a.blk[k].a.w_ss, wave, lane);
+        dma_conv<C, 8>(wl + (2 * k + 1) * WB, a.blk[k].b.w + (int64_t)s0 * a.blk[k].b.w_ss, wave, lane);
+      }
+      dma_barrier();
+      cur_s = s0;
+    } else {
+      lds_barrier();
+    }
+    const int lt = t - grp;
+    if (lt < 0 || lt >= NPH * pcount) continue;
+    const int k = lt / NPH, ph = lt - k * NPH, blk = ph >> 2, q = ph & 3;
+    uint8_t* X = xg + (k & 1) * TILES;
+    uint8_t* Xo = xg + ((k + 1) & 1) * TILES;
+    const BlockParams& bp = a.blk[blk];
+    if (q == 0) {
+      conv_mfma_phase<C>(X, wl + (2 * blk) * WB, A, lw, lane);
+      if (blk == 0 && k > 0) store_tile(Xo, item_of(k - 1));
+    } else if (q == 1) {
+      EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{tt, bp.a};
+      conv_epi_phase<C, decltype(epi)>(bias_lds + (2 * blk) * C::COUT, bp.a, epi, A, lw, lane);
+      if (blk == 0 && k + 1 < pcount) {
+        write_tile(Xo, item_of(k + 1));
+        fetch(item_of(k + 2 < pcount ? k + 2 : k + 1));
+      }
+    } else if (q == 2) {
+      conv_mfma_phase<C>(tt, wl + (2 * blk + 1) * WB, A, lw, lane);
+    } else {
+      EpiTileResInPlace<C::HO, C::PIXB, C::TILE_BYTES> epi{X, bp.b, bp.add};
+      conv_epi_phase<C, decltype(epi)>(bias_lds + (2 * blk + 1) * C::COUT, bp.b, epi, A, lw, lane);
+    }
+  }
+  lds_barrier();
+  store_tile(xg + ((pcount - 1) & 1) * TILES, item_of(pcount - 1));
+}
+
+template <class C, int NBLK> constexpr int chain_pp_lds() {
+  return 6 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + 2 * NBLK * WConv<C>::BYTES + NBLK * 2 * C::COUT * 4;
+}
+
+template <class C, int NBLK>
+static int launch_block_chain_pp(const ChainArgs<NBLK>& a, hipStream_t st) {
+  constexpr int LDS = chain_pp_lds<C, NBLK>();
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_pp_kernel<C, NBLK>, attr, LDS)) return rc_attr;
+  const int groups = (a.B + C::G - 1) / C::G;
+  const int n_pairs = a.n_samples * groups / 2;
+  const int grid = n_pairs < 256 ? n_pairs : 256;
+  hipLaunchKernelGGL((block_chain_pp_kernel<C, NBLK>), dim3(grid), dim3(512), LDS, st, a);
+  return check_launch("qbnn_block_chain_i8_mc");
+}
+
+// =====================================================================================
+// Wide identity block (96 / 192 channels): the block's weights (162 / 663 KiB per MC sample) neither fit in LDS nor
+// can every wave afford to stream its own copy from L2, so they pass ONCE per work item through a two-slab LDS ring
+// (global_load_lds) shared by the 8 waves.  To leave room for the ring the stem.0 output T overwrites the input tile X
+// IN PLACE: each conv runs as two workgroup-wide phases,
+//     M: every wave accumulates its MB x NB output tiles over all weight slabs (reads the tile),
+//     E: after a barrier, every wave requantises its accumulators and writes them over the tile,
+// and the residual operand of the Add is re-read from global memory (the block input, L2-hot, quint8) instead of
+// being kept in LDS.  One pass per wave: C::NPASS == 8.
+// The tile is DENSE.  With the 1-pixel halo an 8x8 / 4x4 map costs 1.56x / 2.25x its size
+// in LDS; stored dense ([image][oh][ow][C + 16]) twice as many images fit next to the weight ring (8 at 96 channels,
+// 16 at 192), which doubles the MFMA work per weight slab (the slab's LDS-DMA latency hides behind it) and halves the
+// weight bytes moved per image.  (A halo'd variant with 8 images per item was 15 % slower at 192 channels.)  Zero padding is then a per-lane address choice: a tap that falls outside the map
+// reads a line of zeros instead.  The tap's position is a function of the slab / k-step only, so this costs a few
+// VALU operations per slab.
+// =====================================================================================
+template <class C> struct DenseTile {
+  static constexpr int IMG = C::HO * C::HO * C::PIXB;
+  static constexpr int BYTES = C::G * IMG;                  // followed by the zero line (C::PIXB bytes)
+  static constexpr int TPS = C::SLK / C::SPT;               // taps per weight slab
+  static_assert(C::PADB > 0 && C::SLK % C::SPT == 0 && C::STRIDE == 1 && C::KSZ == 3, "slabs are whole taps");
+};
+
+template <class C, int NWV, class FNext>
+__device__ __forceinline__ void conv_ring_mfma_dense(const uint8_t* tile, uint8_t* rbase, int& rcur, const int8_t* wq, ConvAcc<C>& A,
+                                                     int wave, int lane, FNext prefetch_next) {
+  static_assert(C::NPASS == NWV, "one pass per wave");
+  using DT = DenseTile<C>;
+  const int r = lane & 31, h = lane >> 5;
+  const int mblk = wave / C::NBLKS, nblk = wave - mblk * C::NBLKS;
+  int pix0[C::MB], poh[C::MB], pow_[C::MB];               // this lane's pixel per M-tile: byte offset, row, column
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb) {
+    const int m = (mblk * C::MB + mb) * 32 + r;
+    const int rem = m % (C::HO * C::HO);
+    poh[mb] = rem / C::HO; pow_[mb] = rem % C::HO;
+    pix0[mb] = m * C::PIXB + 16 * h;
+  }
+  const uint8_t* zline = tile + DT::BYTES + 16 * h;
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb) {
+    A.rsum[mb] = 0;
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) A.acc[mb][nb][i] = 0;
+  }
+  struct Frags { v4i w[C::NB]; v4i x[C::MB]; };              // one k-step per buffer
+  QBNN_INNER_T0();
+#pragma unroll 1
+  for (int slab = 0; slab < C::NSLAB; ++slab) {
+    dma_barrier();            // slab landed; everyone is done with the other buffer; slab 0: tile complete
+    QBNN_INNER_AT(0);
+    uint8_t* other = rbase + (rcur ^ 1) * C::SLAB_BYTES;
+    if (slab + 1 < C::NSLAB) dma_slab<C, NWV>(other, wq, slab + 1, wave, lane);
+    else prefetch_next(other);
+    const uint8_t* wl = rbase + rcur * C::SLAB_BYTES + ((nblk * C::NB) * C::SLK * 64 + lane) * 16;
+    rcur ^= 1;
+    const uint8_t* tb[C::MB][DT::TPS];
+#pragma unroll
+    for (int tp = 0; tp < DT::TPS; ++tp) {
+      const int tap = slab * DT::TPS + tp, kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) {
+        const bool ok = (unsigned)(poh[mb] + kh - 1) < (unsigned)C::HO && (unsigned)(pow_[mb] + kw - 1) < (unsigned)C::HO;
+        tb[mb][tp] = ok ? tile + pix0[mb] + ((kh - 1) * C::HO + (kw - 1)) * C::PIXB : zline;
+      }
+    }
+    auto load_step = [&](Frags& f, int j) {
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb) f.w[nb] = *reinterpret_cast<const v4i*>(wl + (nb * C::SLK + j) * 1024);
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) f.x[mb] = load_xfrag<C>(tb[mb][j / C::SPT] + (j % C::SPT) * 32);
+    };
+    auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) {
+        // (no window sum here: 4 v_dot4 per fragment cost 11 % of the kernel; the epilogue gathers it from the
+        //  per-pixel channel sums kept beside the tile, see window_sum_from_table)
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+          A.acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[nb], f.x[mb], A.acc[mb][nb], 0, 0, 0);
+      }
+    };
+    Frags f0, f1;
+    load_step(f0, 0);
+#pragma unroll
+    for (int j = 0; j < C::SLK; ++j) {
+      Frags& cur = (j & 1) ? f1 : f0;
+      Frags& nxt = (j & 1) ? f0 : f1;
+      if (j + 1 < C::SLK) load_step(nxt, j + 1);
+      mfma_step(cur);
+    }
+    QBNN_INNER_AT(1);
+  }
+  QBNN_INNER_FLUSH();
+}
+
+// dense-tile epilogues: (b') centred stem.0 output, (c') Add(residual from global) + ReLU, centred block output
+template <int PIXB>
+struct EpiDenseTile {
+  uint8_t* dst; QConv p;
+  mutable int csum;            // sum of the centred bytes this lane has written since the last flush (channel-sum table)
+  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
+    const uint32_t pk = pack_rne_u8(v0, v1, v2, v3, p.vhi);      // ConvReLU2d: p.vlo == 0
+    *reinterpret_cast<uint32_t*>(dst + po + c0) = pk;
+    csum = __builtin_amdgcn_sdot4((int)pk, 0x01010101, csum, false);
+  }
+};
+
+// Window sum R(p) = sum over the 3x3 window and all channels of the centred tile bytes, needed because sampled weights
+// have a non-zero zero point (sum x'(W - z_w) = acc - z_w R).  The dense-tile kernel keeps S(p) = channel sum of pixel p in
+// a small LDS table, maintained where the tile is written (one v_dot4 per dword written, LDS atomic add), and gathers
+// the <= 9 neighbours here -- instead of 4 v_dot4 per pixel fragment inside the MFMA loop (x27 / x54 per conv).
+// Leaves R in A.rsum so that conv_epi_phase's (rsum + rsum of lane ^ 32) yields it.
+template <class C>
+__device__ __forceinline__ void window_sum_from_table(const int* tab, ConvAcc<C>& A, int pass, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int mblk = pass / C::NBLKS;
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb) {
+    const int m = (mblk * C::MB + mb) * 32 + r;
+    const int rem = m % (C::HO * C::HO), oh = rem / C::HO, ow = rem % C::HO;
+    int R = 0;
+#pragma unroll
+    for (int kh = -1; kh <= 1; ++kh)
+#pragma unroll
+      for (int kw = -1; kw <= 1; ++kw) {
+        const bool ok = (unsigned)(oh + kh) < (unsigned)C::HO && (unsigned)(ow + kw) < (unsigned)C::HO;
+        R += ok ? tab[m + kh * C::HO + kw] : 0;
+      }
+    A.rsum[mb] = h ? 0 : R;
+  }
+}
+template <int PIXB, int CCH>
+struct EpiDenseTileResGlobal {
+  uint8_t* xt; const uint8_t* res; int n_valid_px; QConv p; QAdd a;
+  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
+  __device__ __forceinline__ uint32_t load_px(int m, int c0) const {
+    return m < n_valid_px ? *reinterpret_cast<const uint32_t*>(res + (int64_t)m * CCH + c0) : 0u;
+  }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
+    const float vv[4] = {v0, v1, v2, v3};
+    const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float da = __builtin_fmaf(p.s_y, __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)), p.dl_y);
+      const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
+      t[i] = (da + db) * a.inv_s_o;
+    }
+    *reinterpret_cast<uint32_t*>(xt + po + c0) = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
+  }
+};
+
+// NWV = 8: two waves per SIMD, 256 VGPRs each (MB x NB = 2 x 3 tiles per wave).  Measured alternatives, all slower:
+// NWV = 4 (one wave per SIMD, 4 x 3 tiles in the 512-register file: -25 %, the epilogues read accumulators out of AGPRs
+// and a lone wave hides no latency); NWV = 12 (4 x 1 tiles, 168 VGPRs: -12 %) and NWV = 16 (1 x 3 tiles, 128 VGPRs:
+// -5 %), both of which spill the next item's input prefetch and so put its HBM latency back on the critical path; and two
+// independent 4-wave workgroups per CU (4 images each, 9 KiB slabs) whose M and E phases drift apart on their own: equal
+// time at 96 channels -- overlapping the phases is not what this kernel lacks.
+// Round 2 re-tested that with a full ping-pong kernel (two 4-wave groups in anti-phase sharing ONE weight ring, the E group
+// taking its epilogue in slices between the M group's slab barriers; bit-exact, no spills): 0.399 ms at 96 channels and
+// 0.454 ms at 192 against 0.341 / 0.298 ms here.  The wall is accumulator capacity: the 8 waves' 48 accumulator tiles ARE the
+// item (8 / 16 images); a group that drains its accumulators while the other multiplies halves the images per pass of the
+// block's weights (162 / 663 KiB), and the L2 -> LDS weight stream (3.5 TB/s chip-wide here, 4.7 TB/s there) is what the M
+// phase waits for.  More images per weight pass needs more accumulator registers, not more LDS.
+template <class C, int NWV, int NM = 1>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 4, NWV / 4)))
+void block_chain_ald_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
+  const ChainArgs<1>& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  static_assert(C::CIN == C::COUT && C::CIN % 32 == 0, "wide identity BasicBlock");
+  using DT = DenseTile<C>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int NTHR = 64 * NWV;
+  uint8_t* xt = smem;                                                        // dense tile + zero line
+  uint8_t* rbase = smem + DT::BYTES + C::PIXB;                               // two weight slabs
+  static_assert((DT::BYTES + C::PIXB) % 16 == 0, "ring alignment");
+  int rcur = 0;
+  float* bias_lds = reinterpret_cast<float*>(rbase + 2 * C::SLAB_BYTES);     // [2][COUT]
+  int* sx = reinterpret_cast<int*>(bias_lds + 2 * C::COUT);                  // channel sums of the X tile  [G * HO * HO]
+  int* stab = sx + C::G * C::HO * C::HO;                                     // ... of the T tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
+  const BlockParams& bp = a.blk[0];
+
+  constexpr int IMG_PX = C::HO * C::HO;
+  constexpr int CPP = C::CIN / 16;                                           // 16-byte chunks per pixel
+  constexpr int NCH = C::G * IMG_PX * CPP;
+  constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
+  const int groups = (a.B + C::G - 1) / C::G;
+  const ItemWalk walk(a.n_samples * groups, blockIdx.x, gridDim.x);     // interleaved per XCD: a sample's weights stay in ONE L2
+  const int count = walk.count;
+
+  for (int i = tid; i < C::PIXB / 4; i += NTHR) reinterpret_cast<uint32_t*>(xt + DT::BYTES)[i] = 0u;
+  for (int i = tid; i < 2 * C::G * C::HO * C::HO; i += NTHR) sx[i] = 0;
+  load_bias<C::COUT, NTHR>(bias_lds, bp.a.bias, tid);
+  load_bias<C::COUT, NTHR>(bias_lds + C::COUT, bp.b.bias, tid);
+  if (count <= 0) return;
+  __syncthreads();                                   // tables are zero before the first tile write adds into them
+  auto dot16 = [](const v4i& c) {
+    int d = __builtin_amdgcn_sdot4(c.x, 0x01010101, 0, false);
+    d = __builtin_amdgcn_sdot4(c.y, 0x01010101, d, false);
+    d = __builtin_amdgcn_sdot4(c.z, 0x01010101, d, false);
+    return __builtin_amdgcn_sdot4(c.w, 0x01010101, d, false);
+  };
+
+  // an item's images are contiguous in HBM: chunk i of the item is byte 16 i of that block
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_PX * C::CIN;
+    const int valid = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX * CPP;
+    int t = tid;
+    asm volatile("" : "+v"(t));         // per-thread addresses are recomputed here, not hoisted out of the item loop (spills)
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = t + j * NTHR;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + (i < valid ? (int64_t)i * 16 : 0));
+    }
+  };
+  auto write_tile = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const int valid = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX * CPP;
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+    int t = tid;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = t + j * NTHR;
+      if (i < NCH) {
+        const int px = i / CPP, within = i - px * CPP;
+        const v4i v = pre[j];
+        const v4i c = i < valid ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v4i{0, 0, 0, 0};
+        *reinterpret_cast<v4i*>(xt + px * C::PIXB + within * 16) = c;
+        __hip_atomic_fetch_add(&sx[px], dot16(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  };
+  auto wbase = [&](const QConv& q, int item) { return q.w + (int64_t)(item / groups) * q.w_ss; };
+
+  fetch(walk.item(0));
+  write_tile(walk.item(0));
+  dma_slab<C, NWV>(rbase, wbase(bp.a, walk.item(0)), 0, wave, lane);
+  ConvAcc<C> A;
+  QBNN_STAMP_DECL
+  for (int it = 0; it < count; ++it) {
+    QBNN_STAMP_START();
+    const int item = walk.item(it);
+    const int s = item / groups, img0 = (item - s * groups) * C::G;
+    const bool more = it + 1 < count;
+    const int next = more ? walk.item(it + 1) : item;
+    // ---- stem.0: M over the X tile, then T over it
+    conv_ring_mfma_dense<C, NWV>(xt, rbase, rcur, wbase(bp.a, item), A, wave, lane,
+                            [&](uint8_t* dst) { dma_slab<C, NWV>(dst, wbase(bp.b, item), 0, wave, lane); });
+    QBNN_STAMP_AT(0);
+    lds_barrier();                                       // every wave has read its last X fragment
+    QBNN_STAMP_AT(1);
+    {
+      // stem.0 epilogue: window sums from the X table; the T table collects the channel sums of what is written
+      window_sum_from_table<C>(sx, A, wave, lane);
+      EpiDenseTile<C::PIXB> epi{xt, bp.a, 0};
+      auto flush = [&](int mb) {
+        const int v = epi.csum + __shfl_xor(epi.csum, 32);
+        epi.csum = 0;
+        if (lane < 32) __hip_atomic_fetch_add(&stab[((wave / C::NBLKS) * C::MB + mb) * 32 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      conv_epi_phase_with<C, decltype(epi)>(bias_lds, bp.a, epi, A, wave, lane, [&](int, int, int, int, int) { return 0u; },
+                                            [&](int mb) { if (mb > 0) flush(mb - 1); });
+      flush(C::MB - 1);
+    }
+    QBNN_STAMP_AT(2);
+    // ---- stem.3: M over T; residual and next input are requested during the last slab
+    const int valid_px = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX;
+    EpiDenseTileResGlobal<C::PIXB, C::COUT> epi_b{xt, a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_PX * C::COUT, valid_px, bp.b, bp.add};
+    uint32_t resq[2][C::NB][4];
+    auto load_res = [&](int mb) {
+      const int mblk = wave / C::NBLKS, nblk = wave - mblk * C::NBLKS;
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          resq[mb & 1][nb][g4] = epi_b.load_px((mblk * C::MB + mb) * 32 + (lane & 31), (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * (lane >> 5));
+    };
+    conv_ring_mfma_dense<C, NWV>(xt, rbase, rcur, wbase(bp.b, item), A, wave, lane,
+                            [&](uint8_t* dst) { if (more) dma_slab<C, NWV>(dst, wbase(bp.a, next), 0, wave, lane); load_res(0); fetch(next); });
+    QBNN_STAMP_AT(3);
+    lds_barrier();
+    QBNN_STAMP_AT(4);
+    for (int i = tid; i < C::G * IMG_PX; i += NTHR) sx[i] = 0;          // X table: last read in the stem.0 epilogue; refilled by the tile write below
+    window_sum_from_table<C>(stab, A, wave, lane);
+    conv_epi_phase_with<C, decltype(epi_b)>(bias_lds + C::COUT, bp.b, epi_b, A, wave, lane,
+                                            [&](int mb, int nb, int g4, int, int) { return resq[mb & 1][nb][g4]; },
+                                            [&](int mb) { if (mb + 1 < C::MB) load_res(mb + 1); });
+    QBNN_STAMP_AT(5);
+    lds_barrier();
+    QBNN_STAMP_AT(6);
+    for (int i = tid; i < C::G * IMG_PX; i += NTHR) stab[i] = 0;        // T table: every wave has gathered from it
+    // ---- per 16-byte chunk: tile -> quint8 register, next item's input -> the same tile bytes, register -> HBM (the
+    //      item's output block is contiguous).  The next input is written unconditionally (the last item rewrites
+    //      itself): a prefetch left unconsumed on one path makes the compiler guard later reuses with vmcnt(0).
+    {
+      const uint32_t z4o = (uint32_t)bp.add.z_o * 0x01010101u, z4i = (uint32_t)a.z_in * 0x01010101u;
+      uint8_t* ys = a.y + (int64_t)s * a.y_ss + (int64_t)img0 * IMG_PX * C::COUT;
+      const int valid = valid_px * CPP;
+      const int nimg0 = (next - (next / groups) * groups) * C::G;
+      const int nvalid = (a.B - nimg0 < C::G ? a.B - nimg0 : C::G) * IMG_PX * CPP;
+      int t = tid;
+      asm volatile("" : "+v"(t));
+#pragma unroll
+      for (int j = 0; j < PER_T; ++j) {
+        const int i = t + j * NTHR;
+        if (i < NCH) {
+          const int px = i / CPP, within = i - px * CPP;
+          v4i* cell = reinterpret_cast<v4i*>(xt + px * C::PIXB + within * 16);
+          const v4i v = *cell, n = pre[j];
+          const v4i c = i < nvalid ? v4i{(int)sub_bytes(n.x, z4i), (int)sub_bytes(n.y, z4i), (int)sub_bytes(n.z, z4i), (int)sub_bytes(n.w, z4i)} : v4i{0, 0, 0, 0};
+          *cell = c;
+          __hip_atomic_fetch_add(&sx[px], dot16(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (i < valid)
+            *reinterpret_cast<v4i*>(ys + (int64_t)i * 16) = v4i{(int)add_bytes(v.x, z4o), (int)add_bytes(v.y, z4o), (int)add_bytes(v.z, z4o), (int)add_bytes(v.w, z4o)};
+        }
+      }
+    }
+    QBNN_STAMP_AT(7);
+  }
+#ifdef QBNN_STAMP
+  if (a.dbg && (tid & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(a.dbg + wave * 8 + i, st_acc[i]);
+#endif
+}
+
+template <class C, int NWV>
+static int launch_block_chain_ald(const ChainArgs<1>& a, hipStream_t st) {
+  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV, 1>, attr, LDS)) return rc_attr;
+  const int groups = (a.B + C::G - 1) / C::G;
+  const int n_items = a.n_samples * groups;
+  const int grid = n_items < 256 ? n_items : 256;
+  ArgsArr<ChainArgs<1>, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, 1>), dim3(grid), dim3(64 * NWV), LDS, st, one);
+  return check_launch("qbnn_block_chain_i8_mc");
+}
+
+// grid of a fused multi-call launch: every call gets the same number of workgroups (<= its item count), 256 in total
+static int fused_grid_x(int max_items, int n_calls) {
+  const int per = 256 / n_calls > 0 ? 256 / n_calls : 1;
+  return max_items < per ? (max_items > 0 ? max_items : 1) : per;
+}
+
+template <class C, int NWV>
+static int launch_block_chain_ald_multi(const ChainArgs<1>* arr, int n, hipStream_t st) {
+  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4;
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV, QBNN_FUSED_CALLS>, attr, LDS)) return rc_attr;
+  ArgsArr<ChainArgs<1>, QBNN_FUSED_CALLS> all;
+  memset(&all, 0, sizeof(all));                   // unused blocks: n_samples = 0 -> their workgroups (none launched) would exit at once
+  int items = 0;
+  for (int i = 0; i < n; ++i) { all.m[i] = arr[i]; const int it = arr[i].n_samples * ((arr[i].B + C::G - 1) / C::G); items = it > items ? it : items; }
+  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, QBNN_FUSED_CALLS>), dim3(fused_grid_x(items, n), n), dim3(64 * NWV), LDS, st, all);
+  return check_launch("qbnn_block_chain_i8_multi");
+}
+
+
+template <class C, int NBLK, bool LDSW = true, bool STEM = false> constexpr int chain_ws_lds() {
+  return 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + (LDSW ? 2 * NBLK * WConv<C>::BYTES : 0) + NBLK * 2 * C::COUT * 4 +
+         (STEM ? 32 * 32 * 32 + 1024 + 24 * 4 : 0);
+}
+
+template <class C, int NBLK, bool LDSW = true, bool STEM = false>
+static int launch_block_chain_ws(const ChainArgs<NBLK>& a, hipStream_t st) {
+  constexpr int LDS = chain_ws_lds<C, NBLK, LDSW, STEM>();
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, LDSW, STEM, 1>, attr, LDS)) return rc_attr;
+  const int groups = (a.B + C::G - 1) / C::G;
+  const int n_items = a.n_samples * groups;
+  const int grid = n_items < 256 ? n_items : 256;
+  ArgsArr<ChainArgs<NBLK>, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, LDSW, STEM, 1>), dim3(grid), dim3(BLK_THREADS), LDS, st, one);
+  return check_launch("qbnn_block_chain_i8_mc");
+}
+
+template <class C, int NBLK, bool STEM, int NM>
+static int launch_block_chain_ws_multi(const ChainArgs<NBLK>* arr, int n, hipStream_t st) {
+  constexpr int LDS = chain_ws_lds<C, NBLK, true, STEM>();
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static_assert(sizeof(ArgsArr<ChainArgs<NBLK>, NM>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, true, STEM, NM>, attr, LDS)) return rc_attr;
+  ArgsArr<ChainArgs<NBLK>, NM> all;
+  memset(&all, 0, sizeof(all));
+  int items = 0;
+  for (int i = 0; i < n; ++i) { all.m[i] = arr[i]; const int it = arr[i].n_samples * ((arr[i].B + C::G - 1) / C::G); items = it > items ? it : items; }
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, true, STEM, NM>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, all);
+  return check_launch("qbnn_block_chain_i8_multi");
+}
+
+template <class CB> struct DownSC {
+  static constexpr int PITCH = CB::COUT + 8;
+  static constexpr int BYTES = (CB::M * PITCH + 15) / 16 * 16;
+};
+
+template <class CA, class CS, class CB, bool LDSW, int NM = 1>
+__global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const ArgsArr<DownArgs, NM> all) {
+  const DownArgs& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  static_assert(CA::M == CS::M && CA::M == CB::M && CA::G == CS::G && CA::G == CB::G, "one work item, three convs");
+  static_assert(CA::COUT == CB::CIN && CA::COUT == CB::COUT && CS::COUT == CB::COUT && CA::HO == CB::HIN, "block geometry");
+  static_assert(CA::TILE_BYTES == CS::TILE_BYTES && CA::CIN == CS::CIN && CA::HIN == CS::HIN, "shared input tile");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int XB = CA::G * CA::TILE_BYTES + CA::TILE_SLACK;
+  constexpr int TB = CB::G * CB::TILE_BYTES + CB::TILE_SLACK;
+  constexpr int COUT = CB::COUT;
+  // SC: the block's shortcut / output staging buffer, quint8 [M][COUT] with the pixel pitch padded by 8 bytes: the
+  // epilogues touch it with one dword per lane at 32 consecutive pixels, and a pitch of 48 / 96 / 192 bytes is a
+  // 4- / 8- / 16-way bank conflict (32 banks for 4-byte accesses); 56 / 104 / 200 are 2-way, which is free.
+  constexpr int SCP = DownSC<CB>::PITCH, SC_BYTES = DownSC<CB>::BYTES;
+  uint8_t* xt = smem;
+  uint8_t* tt = smem + XB;
+  uint8_t* sc = tt + TB;
+  uint8_t* wl_s = sc + SC_BYTES;
+  uint8_t* wl_a = wl_s + (LDSW ? WConv<CS>::BYTES : 0);
+  uint8_t* wl_b = wl_a + (LDSW ? WConv<CA>::BYTES : 0);
+  float* bias_lds = reinterpret_cast<float*>(wl_b + (LDSW ? WConv<CB>::BYTES : 0));       // [3][COUT]: s, a, b
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
+
+  constexpr int CPR = CA::ROWB / 16, CPI = CA::HIN * CPR, NCH = CA::G * CPI;
+  constexpr int PER_T = (NCH + BLK_THREADS - 1) / BLK_THREADS;
+  const int groups = (a.B + CA::G - 1) / CA::G;
+  int begin = 0, count;
+  const ItemWalk walk(a.n_samples * groups, blockIdx.x, gridDim.x);
+  if (LDSW) item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+  else count = walk.count;
+  auto item_at = [&](int it) { return LDSW ? begin + it : walk.item(it); };
+
+  zero_halo<CA::TW, CA::PIXB, CA::TILE_BYTES, CA::G, BLK_THREADS>(xt, tid);
+  zero_halo<CB::TW, CB::PIXB, CB::TILE_BYTES, CB::G, BLK_THREADS>(tt, tid);
+  load_bias<COUT, BLK_THREADS>(bias_lds, a.s.bias, tid);
+  load_bias<COUT, BLK_THREADS>(bias_lds + COUT, a.a.bias, tid);
+  load_bias<COUT, BLK_THREADS>(bias_lds + 2 * COUT, a.b.bias, tid);
+
+  v4i pre[PER_T];
+  // (the thread's chunk offsets are recomputed per call from an opaque copy of tid: kept in registers across the item loop they are
+  //  what spills at 48 -> 96 channels, and a spill reload is a vmcnt wait -- at the loop top it waited for the previous item's stores)
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * CA::G;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
+    int t_ = tid;
+    if constexpr (!LDSW) asm volatile("" : "+v"(t_));      // (the weights-stationary 24 -> 48 block has registers to spare and is faster without)
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = t_ + j * BLK_THREADS;
+      const int g = i / CPI, rem = i - g * CPI;
+      const bool ok = (i < NCH) && (img0 + g < a.B);
+      const int64_t off = ok ? ((int64_t)(img0 + g) * CA::HIN) * CA::ROWB + (int64_t)rem * 16 : 0;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + off);
+    }
+  };
+  // the X tile is free from the barrier that follows conv_a on
+  auto write_tile = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * CA::G;
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+    int t_ = tid;
+    if constexpr (!LDSW) asm volatile("" : "+v"(t_));      // (the weights-stationary 24 -> 48 block has registers to spare and is faster without)
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = t_ + j * BLK_THREADS;
+      if (i < NCH) {
+        const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+        const bool ok = img0 + g < a.B;
+        const v4i v = pre[j];
+        uint8_t* d = xt + g * CA::TILE_BYTES + (row + 1) * CA::PITCH + CA::row_chunk_off(within);
+        *reinterpret_cast<v2i*>(d) = ok ? v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)} : v2i{0, 0};
+        *reinterpret_cast<v2i*>(d + 8) = ok ? v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v2i{0, 0};
+      }
+    }
+  };
+  if (count <= 0) return;
+  fetch(item_at(0));
+  write_tile(item_at(0));
+  int cur_s = -1;
+  QBNN_STAMP_DECL
+  for (int it = 0; it < count; ++it) {
+    QBNN_STAMP_START();
+    const int item = item_at(it);
+    const int s = item / groups, img0 = (item - s * groups) * CA::G;
+    const bool more = it + 1 < count;
+    fetch(more ? item_at(it + 1) : item);    // unconditional: exact wait counts at its use (see block_chain_ws_kernel)
+    if (LDSW && s != cur_s) {
+      __syncthreads();
+      dma_conv<CS, BLK_WAVES>(wl_s, a.s.w + (int64_t)s * a.s.w_ss, wave, lane);
+      dma_conv<CA, BLK_WAVES>(wl_a, a.a.w + (int64_t)s * a.a.w_ss, wave, lane);
+      dma_conv<CB, BLK_WAVES>(wl_b, a.b.w + (int64_t)s * a.b.w_ss, wave, lane);
+      dma_barrier();
+      cur_s = s;
+    }
+    QBNN_STAMP_AT(0);
+    lds_barrier();       // X complete; the previous item's SC has been read out by every thread
+    QBNN_STAMP_AT(1);
+    {
+      EpiDense<COUT, false, SCP> epi{sc, a.s, a.add};
+      if constexpr (LDSW) conv_core<CS, decltype(epi), BLK_WAVES>(xt, wl_s, bias_lds, a.s, epi, wave, lane);
+      else conv_passes<CS, decltype(epi), BLK_WAVES>(xt, a.s.w + (int64_t)s * a.s.w_ss, bias_lds, a.s, epi, wave, lane);
+    }
+    {
+      EpiTile<CB::HIN, CB::PIXB, CB::TILE_BYTES> epi{tt, a.a};
+      if constexpr (LDSW) conv_core<CA, decltype(epi), BLK_WAVES>(xt, wl_a, bias_lds + COUT, a.a, epi, wave, lane);
+      else conv_passes<CA, decltype(epi), BLK_WAVES>(xt, a.a.w + (int64_t)s * a.a.w_ss, bias_lds + COUT, a.a, epi, wave, lane);
+    }
+    QBNN_STAMP_AT(2);
+    lds_barrier();       // T and SC complete
+    QBNN_STAMP_AT(3);
+    {
+      EpiDense<COUT, true, SCP> epi{sc, a.b, a.add};
+      if constexpr (LDSW) conv_core<CB, decltype(epi), BLK_WAVES>(tt, wl_b, bias_lds + 2 * COUT, a.b, epi, wave, lane);
+      else conv_passes<CB, decltype(epi), BLK_WAVES>(tt, a.b.w + (int64_t)s * a.b.w_ss, bias_lds + 2 * COUT, a.b, epi, wave, lane);
+    }
+    QBNN_STAMP_AT(4);
+    lds_barrier();
+    QBNN_STAMP_AT(5);
+    // read-out of the finished block output.  Weights-stationary form (registers to spare): all LDS reads first (a rolled
+    // read -> wait -> store loop pays the LDS latency per trip), then the next X tile, then the stores -- nothing in the
+    // next item waits on them.  The streaming forms sit at the register limit and keep the rolled loop.
+    constexpr int IMG_OUT = CB::HO * CB::HO * COUT, U8 = COUT / 8;          // 8-byte units (the padded pitch is 8-aligned)
+    constexpr int NOUT = (CB::M * U8 + BLK_THREADS - 1) / BLK_THREADS;
+    uint8_t* ys = a.y + (int64_t)s * a.y_ss + (int64_t)img0 * IMG_OUT;
+    if constexpr (LDSW) {
+      v2i outv[NOUT];
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const int i = tid + j * BLK_THREADS;
+        const int px = i / U8, within = i - px * U8;
+        if (i < CB::M * U8) outv[j] = *reinterpret_cast<const v2i*>(sc + px * SCP + within * 8);
+      }
+      if (more) write_tile(item_at(it + 1));      // before the stores: its vmcnt wait then covers only the (old) input loads
+      QBNN_STAMP_AT(6);
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const int i = tid + j * BLK_THREADS;
+        if (i < CB::M * U8 && img0 + (i * 8) / IMG_OUT < a.B) *reinterpret_cast<v2i*>(ys + (int64_t)i * 8) = outv[j];
+      }
+    } else {
+      if (more) write_tile(item_at(it + 1));
+      QBNN_STAMP_AT(6);
+      for (int i = tid; i < CB::M * U8; i += BLK_THREADS)
+        if (img0 + (i * 8) / IMG_OUT < a.B) {
+          const int px = i / U8, within = i - px * U8;
+          *reinterpret_cast<v2i*>(ys + (int64_t)i * 8) = *reinterpret_cast<const v2i*>(sc + px * SCP + within * 8);
+        }
+    }
+    QBNN_STAMP_AT(7);
+  }
+#ifdef QBNN_STAMP
+  if (g_stamp_dev && (tid & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(g_stamp_dev + wave * 8 + i, st_acc[i]);
+#endif
+}
+
+template <class CA, class CS, class CB, bool LDSW>
+static int launch_block_down_ws(const DownArgs& a, hipStream_t st) {
+  constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + DownSC<CB>::BYTES +
+                      (LDSW ? WConv<CS>::BYTES + WConv<CA>::BYTES + WConv<CB>::BYTES : 0) + 3 * CB::COUT * 4;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_down_ws_kernel<CA, CS, CB, LDSW, 1>, attr, LDS)) return rc_attr;
+  const int groups = (a.B + CA::G - 1) / CA::G;
+  const int n_items = a.n_samples * groups;
+  const int grid = n_items < 256 ? n_items : 256;
+  ArgsArr<DownArgs, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW, 1>), dim3(grid), dim3(BLK_THREADS), LDS, st, one);
+  return check_launch("qbnn_block_down_i8_mc");
+}
+
+template <class CA, class CS, class CB, bool LDSW>
+static int launch_block_down_ws_multi(const DownArgs* arr, int n, hipStream_t st) {
+  constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + DownSC<CB>::BYTES +
+                      (LDSW ? WConv<CS>::BYTES + WConv<CA>::BYTES + WConv<CB>::BYTES : 0) + 3 * CB::COUT * 4;
+  static_assert(sizeof(ArgsArr<DownArgs, QBNN_FUSED_CALLS>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_down_ws_kernel<CA, CS, CB, LDSW, QBNN_FUSED_CALLS>, attr, LDS)) return rc_attr;
+  ArgsArr<DownArgs, QBNN_FUSED_CALLS> all;
+  memset(&all, 0, sizeof(all));
+  int items = 0;
+  for (int i = 0; i < n; ++i) { all.m[i] = arr[i]; const int it = arr[i].n_samples * ((arr[i].B + CA::G - 1) / CA::G); items = it > items ? it : items; }
+  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW, QBNN_FUSED_CALLS>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, all);
+  return check_launch("qbnn_block_down_i8_multi");
+}
+
+//                          CIN COUT K  S  HIN HALO G  MB NB
+using Blk_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;
+using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;
+using ALD_96  = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;      // dense aliased-tile ring kernel
+using ALD_192 = ConvCfg<192, 192, 3, 1, 4, 1, 16, 2, 3, true, 36, 16>;
+using PP_48   = ConvCfg<48, 48, 3, 1, 16, 1, 1, 2, 2>;          // per wave group of the ping-pong kernel
+
+template <int NBLK>
+static int build_chain_args(ChainArgs<NBLK>& a, const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t a_hi,
+                            const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples, const int8_t* stem_x, const QConv* stem) {
+  memset(&a, 0, sizeof(a));
+  if (stem) { a.stem_x = stem_x; a.stem = *stem; }
+  a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = B; a.n_samples = n_samples; a.z_in = z_x;
+#ifdef QBNN_STAMP
+  a.dbg = g_stamp_buf;
+#endif
+  float s_in = s_x; int z_in = z_x;
+  for (int k = 0; k < NBLK; ++k) {
+    const qbnn_block_desc& b = blk[k];
+    qbnn_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.a_hi = a_hi;
+    d.s_x = s_in; d.z_x = z_in; d.s_w = b.s_wa; d.z_w = b.z_wa; d.s_y = b.s_a; d.z_y = b.z_a; d.relu = 1; d.has_bias = b.bias_a != nullptr;
+    int rc = fill_qconv(a.blk[k].a, b.w_a, b.w_a_sample_stride, b.bias_a, &d);
+    if (rc) return rc;
+    d.s_x = b.s_a; d.z_x = b.z_a; d.s_w = b.s_wb; d.z_w = b.z_wb; d.s_y = b.s_b; d.z_y = b.z_b; d.relu = 0; d.has_bias = b.bias_b != nullptr;
+    if ((rc = fill_qconv(a.blk[k].b, b.w_b, b.w_b_sample_stride, b.bias_b, &d))) return rc;
+    d.s_r = s_in; d.z_r = z_in; d.s_o = b.s_o; d.z_o = b.z_o;
+    if ((rc = fill_qadd(a.blk[k].add, &d))) return rc;
+    s_in = b.s_o; z_in = b.z_o;
+  }
+  return QBNN_OK;
+}
+
+static int build_stem_qconv(QConv& stem, const int8_t* w0_packed, int64_t w0_ss, const float* bias0, float s_x, float s_w0, int32_t z_w0,
+                            float s_y0, int32_t z_y0, int32_t a_hi) {
+  qbnn_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.a_hi = a_hi; d.s_x = s_x; d.z_x = 0; d.s_w = s_w0; d.z_w = z_w0; d.s_y = s_y0; d.z_y = z_y0; d.relu = 1; d.has_bias = bias0 != nullptr;
+  memset(&stem, 0, sizeof(stem));
+  return fill_qconv(stem, w0_packed, w0_ss, bias0, &d);
+}
+
+template <int NBLK>
+static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
+                                int32_t a_hi, const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples,
+                                hipStream_t st, const int8_t* stem_x = nullptr, const QConv* stem = nullptr) {
+  ChainArgs<NBLK> a;
+  if (int rc = build_chain_args<NBLK>(a, x, x_ss, s_x, z_x, B, a_hi, blk, y, y_ss, n_samples, stem_x, stem)) return rc;
+  if (stem) {
+    if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
+    return launch_block_chain_ws<Blk_24, NBLK, true, true>(a, st);
+  }
+  if (Cc == 24 && H == 32) return launch_block_chain_ws<Blk_24, NBLK>(a, st);
+  if (Cc == 48 && H == 16) {
+    if constexpr (chain_pp_lds<PP_48, NBLK>() <= 160 * 1024) {
+      if (!no_pingpong() && ((B + PP_48::G - 1) / PP_48::G) % 2 == 0) return launch_block_chain_pp<PP_48, NBLK>(a, st);
+    }
+    if constexpr (chain_ws_lds<Blk_48, NBLK>() <= 160 * 1024) return launch_block_chain_ws<Blk_48, NBLK>(a, st);
+    else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one 48-channel block per launch for this batch size%s");
+  }
+  if (Cc == 96 && H == 8) {
+    if constexpr (NBLK == 1) return launch_block_chain_ald<ALD_96, 8>(a, st);
+    else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one block per launch at 96 channels (its weights stream through the LDS ring)%s");
+  }
+  if (Cc == 192 && H == 4) {
+    if constexpr (NBLK == 1) return launch_block_chain_ald<ALD_192, 8>(a, st);
+    else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one block per launch at 192 channels (its weights stream through the LDS ring)%s");
+  }
+  return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
+}
+
+QBNN_EXPORT int qbnn_block_chain_i8_mc(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
+                                       int32_t a_hi, const qbnn_block_desc* host_blocks, int32_t n_blocks, uint8_t* y,
+                                       int64_t y_ss, int32_t n_samples, void* stream) {
+  if (!x || !y || !host_blocks || n_samples <= 0 || B <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: bad argument%s");
+  for (int k = 0; k < n_blocks; ++k)
+    if (!host_blocks[k].w_a || !host_blocks[k].w_b) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: NULL weights%s");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_blocks == 1) return block_chain_dispatch<1>(x, x_ss, s_x, z_x, B, H, Cc, a_hi, host_blocks, y, y_ss, n_samples, st);
+  if (n_blocks == 2) return block_chain_dispatch<2>(x, x_ss, s_x, z_x, B, H, Cc, a_hi, host_blocks, y, y_ss, n_samples, st);
+  return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: 1 or 2 blocks per launch%s");
+}
+
+QBNN_EXPORT int qbnn_stem_chain_i8_mc(const int8_t* im2col, int32_t B, const int8_t* w0_packed, int64_t w0_ss, const float* bias0,
+                                      float s_x, float s_w0, int32_t z_w0, float s_y0, int32_t z_y0, int32_t a_hi,
+                                      const qbnn_block_desc* host_blocks, int32_t n_blocks, uint8_t* y, int64_t y_ss,
+                                      int32_t n_samples, void* stream) {
+  if (!im2col || !w0_packed || !y || !host_blocks || n_samples <= 0 || B <= 0) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: bad argument%s");
+  for (int k = 0; k < n_blocks; ++k)
+    if (!host_blocks[k].w_a || !host_blocks[k].w_b) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: NULL weights%s");
+  QConv stem;
+  if (int rc = build_stem_qconv(stem, w0_packed, w0_ss, bias0, s_x, s_w0, z_w0, s_y0, z_y0, a_hi)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  // the chain's input is conv0's output: scale s_y0, zero point z_y0
+  if (n_blocks == 1) return block_chain_dispatch<1>(nullptr, 0, s_y0, z_y0, B, 32, 24, a_hi, host_blocks, y, y_ss, n_samples, st, im2col, &stem);
+  if (n_blocks == 2) return block_chain_dispatch<2>(nullptr, 0, s_y0, z_y0, B, 32, 24, a_hi, host_blocks, y, y_ss, n_samples, st, im2col, &stem);
+  return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: 1 or 2 blocks per launch%s");
+}
+
+// ---- fused multi-call launches (ensemble members): see ArgsArr ------------------------------------------------------------
+QBNN_EXPORT int qbnn_block_chain_i8_multi(const qbnn_chain_call* calls, int32_t n_calls, int32_t with_stem, int32_t B, int32_t H,
+                                          int32_t Cc, int32_t a_hi, int32_t n_blocks, void* stream) {
+  if (!calls || n_calls <= 0 || B <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: bad argument%s");
+  hipStream_t st = (hipStream_t)stream;
+  constexpr int NM2 = 4;                              // ChainArgs<2> with the stem: 4 argument blocks fit the 4 KiB of kernel arguments
+  for (int c0 = 0; c0 < n_calls;) {
+    const int lim = (with_stem || n_blocks == 2) ? NM2 : QBNN_FUSED_CALLS;
+    const int n = n_calls - c0 < lim ? n_calls - c0 : lim;
+    int rc = QBNN_OK;
+    if (with_stem) {
+      if (n_blocks != 2 || Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: the fused stem feeds the two 32x32x24 blocks only%s");
+      ChainArgs<2> arr[NM2];
+      for (int i = 0; i < n; ++i) {
+        const qbnn_chain_call& k = calls[c0 + i];
+        if (!k.im2col || !k.w0_packed || !k.blocks || !k.y || k.n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: bad call entry%s");
+        QConv stem;
+        if ((rc = build_stem_qconv(stem, k.w0_packed, k.w0_sample_stride, k.bias0, k.s_in, k.s_w0, k.z_w0, k.s_y0, k.z_y0, a_hi))) return rc;
+        if ((rc = build_chain_args<2>(arr[i], nullptr, 0, k.s_y0, k.z_y0, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, k.im2col, &stem))) return rc;
+      }
+      rc = launch_block_chain_ws_multi<Blk_24, 2, true, NM2>(arr, n, st);
+    } else {
+      if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: one block per call (two only behind the fused stem)%s");
+      ChainArgs<1> arr[QBNN_FUSED_CALLS];
+      for (int i = 0; i < n; ++i) {
+        const qbnn_chain_call& k = calls[c0 + i];
+        if (!k.x || !k.blocks || !k.y || k.n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: bad call entry%s");
+        if ((rc = build_chain_args<1>(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, nullptr, nullptr))) return rc;
+      }
+      if (Cc == 48 && H == 16) rc = launch_block_chain_ws_multi<Blk_48, 1, false, QBNN_FUSED_CALLS>(arr, n, st);
+      else if (Cc == 96 && H == 8) rc = launch_block_chain_ald_multi<ALD_96, 8>(arr, n, st);
+      else if (Cc == 192 && H == 4) rc = launch_block_chain_ald_multi<ALD_192, 8>(arr, n, st);
+      else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
+    }
+    if (rc) return rc;
+    c0 += n;
+  }
+  return QBNN_OK;
+}

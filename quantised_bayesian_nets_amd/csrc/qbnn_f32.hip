@@ -14,7 +14,7 @@
 
 #include "../../include/qbnn.h"
 #include "qbnn_common.h"
-#include "qbnn_rng.cuh"
+#include "qbnn_rng.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));

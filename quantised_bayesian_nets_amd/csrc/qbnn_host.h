@@ -1,0 +1,51 @@
+// Host-side helpers shared by the translation units of libqbnn_hip.so (error reporting, launch checks, the qparam
+// blocks of the conv kernels).  Internal: the public interface is include/qbnn.h.
+#ifndef QBNN_HOST_H_
+#define QBNN_HOST_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+#include <string.h>
+#include <atomic>
+
+#include "../../include/qbnn.h"
+#include "qbnn_common.h"
+#include "qbnn_conv.h"
+
+static inline int fail(int code, const char* fmt, const char* a = "", long b = 0, long c = 0) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), fmt, a, b, c);
+  return qbnn_fail_msg(code, buf);
+}
+static inline int check_launch(const char* what) { return qbnn_check_launch_msg(what); }
+static inline int ensure_dyn_lds(const void* fn, std::atomic<uint64_t>& done, int bytes) { return qbnn_ensure_dyn_lds(fn, &done, bytes); }
+#define g_noise_dev (qbnn_noise_dev())      // this thread's device noise source (qbnn_set_device_noise_source) or nullptr
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+static int fill_qconv(QConv& p, const int8_t* w, int64_t w_ss, const float* bias, const qbnn_conv_desc* d) {
+  if (d->z_x < 0 || d->z_x > 127 || d->a_hi > 127 || d->a_hi < 1 || d->z_y < 0 || d->z_y > 127)
+    return fail(QBNN_E_INVALID, "qbnn conv: activations must be <= 7 bit with zero points in [0,127] (reference quant_utils.py:120)%s");
+  p.w = w; p.w_ss = w_ss; p.bias = d->has_bias ? bias : nullptr;
+  p.z_x = d->z_x; p.z_w = d->z_w; p.z_y = d->z_y;
+  const float atw = d->s_x * d->s_w;     // qconv.cpp GetQuantizationParams: float * float
+  p.rcp = 1.0f / atw;                    // FBGEMM act_times_w_rcp
+  p.mult = atw / d->s_y;                 // output_multiplier_float
+  const int lo = d->relu ? d->z_y : 0, hi = d->a_hi < 255 ? d->a_hi : 255;
+  p.vlo = (float)(lo - d->z_y); p.vhi = (float)(hi - d->z_y);
+  p.s_y = d->s_y; p.nzs_y = (float)(-d->z_y) * d->s_y;
+  p.dl_y = fmaf(d->s_y, (float)d->z_y, p.nzs_y);
+  return QBNN_OK;
+}
+
+static int fill_qadd(QAdd& a, const qbnn_conv_desc* d) {
+  if (d->z_o < 0 || d->z_o > 127 || d->z_r < 0 || d->z_r > 127)
+    return fail(QBNN_E_INVALID, "qbnn conv: add zero points must be in [0,127]%s");
+  a.s_r = d->s_r; a.nzs_r = (float)(-d->z_r) * d->s_r; a.z_r = d->z_r;
+  a.dl_r = fmaf(d->s_r, (float)d->z_r, a.nzs_r);
+  a.inv_s_o = 1.0f / d->s_o; a.z_o = d->z_o;
+  a.vhi = (float)((d->a_hi < 255 ? d->a_hi : 255) - d->z_o);
+  return QBNN_OK;
+}
+
+#endif

@@ -17,7 +17,7 @@
 
 #include "../../include/qbnn.h"
 #include "qbnn_common.h"
-#include "qbnn_rng.cuh"
+#include "qbnn_rng.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));

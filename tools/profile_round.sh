@@ -14,10 +14,10 @@ QBNN_ROUND=$R python3 - <<'PY'
 import csv, glob, collections, json, shutil, hashlib, os
 R = os.environ.get('QBNN_ROUND', 'r02')
 def src_sha():
-    h = hashlib.sha256()
-    for f in ('qbnn_kernels.hip', 'qbnn_rng.cuh', 'qbnn_eps_table.h'):
-        h.update(open(os.path.join('quantised_bayesian_nets_amd', 'csrc', f), 'rb').read())
-    return h.hexdigest()[:16]
+    import sys
+    sys.path.insert(0, os.getcwd())
+    from quantised_bayesian_nets_amd import build as _b
+    return _b.kernel_source_sha16()
 def bench_key(k):
     rules = [("block_chain_ws_kernel<ConvCfg<24, 24", "stem + block_chain_i8 x2 32x32 c24"), ("block_chain_pp_kernel<ConvCfg<48", "block_chain_i8 x1 16x16 c48"),
              ("block_chain_ws_kernel<ConvCfg<48", "block_chain_i8 x1 16x16 c48"), ("block_chain_ald_kernel<ConvCfg<96", "block_chain_i8 x1 8x8 c96"),
