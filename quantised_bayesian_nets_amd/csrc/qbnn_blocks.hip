@@ -1086,6 +1086,7 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
   if (int rc = build_chain_args<NBLK>(a, x, x_ss, s_x, z_x, B, a_hi, blk, y, y_ss, n_samples, stem_x, stem)) return rc;
   if (stem) {
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
+    if constexpr (NBLK == 2) { if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16(&a, 1, st); }
     return launch_block_chain_ws<Blk_24, NBLK, true, true>(a, st);
   }
   if (Cc == 24 && H == 32) return launch_block_chain_ws<Blk_24, NBLK>(a, st);
@@ -1155,7 +1156,7 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi(const qbnn_chain_call* calls, int32_t 
         if ((rc = build_stem_qconv(stem, k.w0_packed, k.w0_sample_stride, k.bias0, k.s_in, k.s_w0, k.z_w0, k.s_y0, k.z_y0, a_hi))) return rc;
         if ((rc = build_chain_args<2>(arr[i], nullptr, 0, k.s_y0, k.z_y0, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, k.im2col, &stem))) return rc;
       }
-      rc = launch_block_chain_ws_multi<Blk_24, 2, true, NM2>(arr, n, st);
+      rc = qbnn_use_w16() ? qbnn_launch_stem_chain_w16(arr, n, st) : launch_block_chain_ws_multi<Blk_24, 2, true, NM2>(arr, n, st);
     } else {
       if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: one block per call (two only behind the fused stem)%s");
       ChainArgs<1> arr[QBNN_FUSED_CALLS];

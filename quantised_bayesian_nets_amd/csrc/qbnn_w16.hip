@@ -1,0 +1,377 @@
+// libqbnn_hip.so -- 16-wave forms of the weights-stationary fused kernels (layers whose epilogue, not the matrix pipe, is the
+// bound: 24 / 48 channels).
+//
+// Why 16 waves.  The exact FBGEMM requantisation costs 6 vector instructions per output (13 with the residual Add), and one
+// wave issues a vector instruction only every ~6 cycles: measured in-kernel (tools/issue_bench.hip, profiles/r03_issue_bench.txt)
+// a SIMD issues the epilogue's instruction mix at 4.1 cycles per wave-instruction with 2 resident waves, 2.9 with 4 and 2.2
+// with 8, and a 9-MFMA + 72-VALU tile takes 450 / 351 / 270 cycles at 2 / 4 / 8 waves per SIMD (the MFMAs alone: 288).  The
+// 8-wave kernels of qbnn_blocks.hip hold 200+ VGPRs per wave (two waves per SIMD); the kernels here stay under 128 so that a
+// 1024-thread workgroup fits a CU: four waves per SIMD, each wave a few output rows of the image.
+//
+// Layer 1 (qbnn_stem_chain_i8_mc with two blocks): layers.0 on the 27-tap patches + 2 x [stem.0, stem.3 + Add + ReLU] on a
+// 32 x 32 x 24 map.  Work item = (MC sample, G images).  Wave w owns the 2 G output rows w * 2 G ... of the item in every conv.
+//   * the patch fragments of layers.0 come straight from global memory (one 16-byte load per lane and output row, L2 / MALL
+//     resident: the patch tensor is shared by all MC samples) -- no patch tile in LDS, no copy-in pass;
+//   * per conv a wave keeps the 9 weight fragments in registers and walks its rows with a rolling 3-row window of pixel
+//     fragments (each input row is read from LDS once per wave): 9 MFMAs, then the row's epilogue;
+//   * X tile (block input / output, updated in place) and T tile (stem.0 output) per image; weights of the 5 convs in LDS,
+//     re-read per MC sample only (contiguous item ranges per workgroup).
+// Same arithmetic, epilogue functors and packed weight layout as block_chain_ws_kernel: bit-identical results.
+#include "qbnn_host.h"
+
+// Diagnostic build only (-DQBNN_W16_STAMP, scratch library; tools/stamp_w16.py): s_memtime of every wave of workgroup 0 at the
+// phase boundaries of one work item -- after each row's MFMAs and after its epilogue -- written to a debug buffer that nothing
+// else reads.  The shipped library contains none of this.
+#ifdef QBNN_W16_STAMP
+static __device__ unsigned long long* g_w16_stamp = nullptr;
+QBNN_EXPORT void qbnn_debug_w16_stamp_buffer(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_w16_stamp), &p, sizeof(p)); }
+#define W16_STAMP() do { if (st_on) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    if ((threadIdx.x & 63) == 0) g_w16_stamp[(threadIdx.x >> 6) * 64 + (st_k & 63)] = t_; ++st_k; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define W16_STAMP_ARGS , bool st_on, int& st_k
+#define W16_STAMP_PASS , st_on, st_k
+#else
+#define W16_STAMP() do {} while (0)
+#define W16_STAMP_ARGS
+#define W16_STAMP_PASS
+#endif
+
+namespace {
+
+constexpr int W16_THREADS = 1024, W16_WAVES = 16;
+using L1 = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;      // one 32 x 32 x 24 image tile (halo 1): pitch 34 * 24 bytes
+using L0 = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;      // layers.0 on the patch tensor: K = 27 -> 32, one k-step
+
+template <int G, int NBLK> constexpr int w16_lds() {
+  return 2 * (G * L1::TILE_BYTES + L1::TILE_SLACK) + 2 * NBLK * WConv<L1>::BYTES + WConv<L0>::BYTES + (2 * NBLK + 1) * L1::COUT * 4;
+}
+
+// Timing ablations (diagnostic builds only, results are wrong): -DQBNN_W16_ABL=1 no MFMAs, 2 no epilogue arithmetic,
+// 3 no pixel-fragment reads, 4 no barriers between the convs.
+#ifndef QBNN_W16_ABL
+#define QBNN_W16_ABL 0
+#endif
+
+// requantise one 32-pixel x 24-channel accumulator tile (ones row -> window sum, see conv_core) through `epi`
+template <class Epi>
+__device__ __forceinline__ void epilogue24(const v16i& acc, const float4 (&b4)[3], const QConv& p, const Epi& epi, int po, int h) {
+#if QBNN_W16_ABL == 2
+  {
+    uint32_t* o = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(epi.base()) + po + 4 * h);
+    o[0] = (uint32_t)acc[0] & 0x3f3f3f3fu; o[2] = (uint32_t)acc[4] & 0x3f3f3f3fu; o[4] = (uint32_t)(acc[8] ^ acc[12]) & 0x3f3f3f3fu;
+    return;
+  }
+#endif
+  const int rv = acc[L1::ONES_REG];
+  const int ro = __shfl_xor(rv, 32);
+  const int zwr = p.z_w * (h ? ro : rv);
+  uint32_t pre[3];
+#pragma unroll
+  for (int g4 = 0; g4 < 3; ++g4) pre[g4] = epi.load(po, 8 * g4 + 4 * h);
+#pragma unroll
+  for (int g4 = 0; g4 < 3; ++g4) {
+    const float4 bb = b4[g4];
+    const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(acc[4 * g4 + 0] - zwr)) * p.mult;
+    const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(acc[4 * g4 + 1] - zwr)) * p.mult;
+    const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(acc[4 * g4 + 2] - zwr)) * p.mult;
+    const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(acc[4 * g4 + 3] - zwr)) * p.mult;
+    epi.store(po, 8 * g4 + 4 * h, v0, v1, v2, v3, pre[g4]);
+  }
+}
+
+// byte offset of interior pixel (oh, ow) of image g inside a tile array
+__device__ __forceinline__ int px_off(int g, int oh, int ow) { return g * L1::TILE_BYTES + ((oh + 1) * L1::TW + ow + 1) * L1::PIXB; }
+
+// 3x3 / stride 1 conv of RW consecutive output rows [oh0, oh0 + RW) of image slot g: tile -> epi.  `w` holds this conv's 9 weight
+// fragments; after the last row's MFMAs it is refilled from `wnext` (the NEXT conv's weights, which do not depend on the barrier
+// in between: the refill rides under the last epilogue instead of heading the next phase, where all 16 waves would burst it).
+template <int RW, class Epi>
+__device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[L1::KS], const uint8_t* wnext, const float* bias_lds,
+                                                 const QConv& p, const Epi& epi, int g, int oh0, int lane W16_STAMP_ARGS) {
+  int l_ = lane;
+  asm volatile("" : "+v"(l_));     // per-lane offsets are recomputed per phase (hoisted out of the item loop they spill)
+  const int r = l_ & 31, h = l_ >> 5;
+  float4 b4[3];
+#pragma unroll
+  for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * h);
+  // tile row oh0 + j is input row oh0 - 1 + j; tile column r is input column r - 1: the 72-byte window of (row, r) starts there
+  const uint8_t* base = tile + g * L1::TILE_BYTES + (oh0 * L1::TW + r) * L1::PIXB + 16 * h;
+  v4i x[RW + 2][L1::SPR];
+  auto load_row = [&](int j) {
+#if QBNN_W16_ABL == 3
+    for (int t = 0; t < L1::SPR; ++t) x[j][t] = v4i{l_ + j, l_ * 3 + t, l_ ^ j, l_ + 7 * t};
+    return;
+#endif
+#pragma unroll
+    for (int t = 0; t < L1::SPR; ++t) {
+      const v2i lo = *reinterpret_cast<const v2i*>(base + j * L1::PITCH + t * 32);
+      const v2i hi = *reinterpret_cast<const v2i*>(base + j * L1::PITCH + t * 32 + 8);
+      x[j][t] = v4i{lo.x, lo.y, hi.x, hi.y};
+    }
+  };
+  load_row(0); load_row(1); load_row(2);
+  const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // One accumulator, no software pipeline inside the wave: while this wave waits on its MFMAs the SIMD's other three waves
+  // issue their epilogues (a wave of its own issues a vector instruction every ~6 cycles, the SIMD one every ~2-3).
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    v16i acc;
+#if QBNN_W16_ABL == 1
+    acc = zero16;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int t = 0; t < L1::SPR; ++t) { acc[kh * 3 + t] = x[i + kh][t].x ^ w[kh * 3 + t].y; acc[12] ^= x[i + kh][t].z; }
+#else
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int t = 0; t < L1::SPR; ++t)
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * L1::SPR + t], x[i + kh][t], (kh == 0 && t == 0) ? zero16 : acc, 0, 0, 0);
+#endif
+    if (i + 3 < RW + 2) load_row(i + 3);
+    if (i == RW - 1 && wnext) {
+#pragma unroll
+      for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
+    }
+    W16_STAMP();
+    epilogue24(acc, b4, p, epi, px_off(g, oh0 + i, r), h);
+    W16_STAMP();
+  }
+}
+
+// Barrier of one 8-wave team (TEAMS kernels): the hardware barrier spans the workgroup, so the two teams -- which run different
+// phases of different images on purpose -- synchronise through one monotonic LDS counter each.  LDS operations of a wave execute
+// in order, so the counter add is behind the wave's tile writes; the release / acquire fences only order the compiler's view.
+__device__ __forceinline__ void team_barrier(unsigned* cnt, unsigned& target, int lane) {
+  target += 8;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (true) {
+    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if ((int)(v - target) >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ void team_wait(const unsigned* cnt, unsigned target) {      // until counter >= target
+  while (true) {
+    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if ((int)(v - target) >= 0) break;
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+// TEAMS = false: all 16 waves on one item of G images, hardware barriers between the convs.
+// TEAMS = true (G = 2 tile slots): waves 0-7 and 8-15 are two teams -- every SIMD holds two waves of each -- and each team takes
+//   one image at a time through the five convs on its own X / T tiles, half an item apart from the other team: while one team
+//   starts or drains a conv (matrix pipe busy, vector ALU idle, or the reverse), the other is in the middle of one.  The conv
+//   weights in LDS are shared.  Work items are image PAIRS (team t takes image 2 k + t), so B must be even.
+template <int G, int NBLK, int NM, bool TEAMS>
+__global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all) {
+  const ChainArgs<NBLK>& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  static_assert(!TEAMS || G == 2, "two teams, one tile slot each");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int NTEAM = TEAMS ? 2 : 1;
+  constexpr int RW = 2 * G;                                  // output rows per wave and conv (32 rows per image)
+  constexpr int TILES = G * L1::TILE_BYTES + L1::TILE_SLACK;
+  constexpr int WB = WConv<L1>::BYTES;
+  uint8_t* xt = smem;
+  uint8_t* tt = smem + TILES;
+  uint8_t* wl = smem + 2 * TILES;                            // [NBLK][2] whole convs
+  uint8_t* wl0 = wl + 2 * NBLK * WB;                         // layers.0: one fragment tile
+  float* bias_lds = reinterpret_cast<float*>(wl0 + WConv<L0>::BYTES);      // [2 NBLK][24], then layers.0's
+  float* bias0 = bias_lds + 2 * NBLK * L1::COUT;
+  unsigned* tcnt = reinterpret_cast<unsigned*>(bias0 + L0::COUT);          // TEAMS: one barrier counter per team
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = TEAMS ? wave >> 3 : 0, tw = TEAMS ? wave & 7 : wave;
+  // this wave's tile slot within the item and its first output row
+  const int wg = TEAMS ? team : (wave * RW) / 32, woh0 = TEAMS ? tw * RW : (wave * RW) % 32;
+
+  // work items: G images of one MC sample (TEAMS: the two images of a pair go to the two teams)
+  const int groups = (a.B + G - 1) / G;
+  int begin, count;
+  item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+  if (count <= 0) return;
+
+  zero_halo<L1::TW, L1::PIXB, L1::TILE_BYTES, G, W16_THREADS>(xt, tid);
+  zero_halo<L1::TW, L1::PIXB, L1::TILE_BYTES, G, W16_THREADS>(tt, tid);
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) {
+    load_bias<L1::COUT, W16_THREADS>(bias_lds + (2 * k) * L1::COUT, a.blk[k].a.bias, tid);
+    load_bias<L1::COUT, W16_THREADS>(bias_lds + (2 * k + 1) * L1::COUT, a.blk[k].b.bias, tid);
+  }
+  load_bias<L0::COUT, W16_THREADS>(bias0, a.stem.bias, tid);
+  if (TEAMS && tid < 2) tcnt[tid] = 0u;
+  unsigned ttarget = 0u;                                     // TEAMS: 8 x the team barriers this wave has passed
+  auto sync = [&]() {
+#if QBNN_W16_ABL == 4
+    return;
+#endif
+    if constexpr (TEAMS) team_barrier(tcnt + team, ttarget, lane);
+    else lds_barrier();
+  };
+
+  // layers.0's pixel fragments of this wave's rows, one 16-byte load per lane and row straight from the patch tensor
+  v4i pf[RW];
+  // (per-lane addresses are recomputed from an opaque copy of the lane / thread index wherever they are used once per item:
+  //  hoisted out of the item loop they are spilled, and a spill reload is a vmcnt wait behind the prefetch in flight)
+  auto fetch_patches = [&](int item) {
+    const int s = item / groups;
+    int img = (item - s * groups) * G + wg;
+    img = img < a.B ? img : a.B - 1;
+    int l_ = lane;
+    asm volatile("" : "+v"(l_));
+    const int8_t* ps = a.stem_x + ((int64_t)img * 1024 + woh0 * 32 + (l_ & 31)) * 32 + 16 * (l_ >> 5);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) pf[i] = *reinterpret_cast<const v4i*>(ps + i * 32 * 32);
+  };
+  fetch_patches(begin);
+
+  constexpr int CPR = L1::ROWB / 16, CPI = L1::HIN * CPR;                       // 16-byte chunks per image row / per image
+  constexpr int NCH = (TEAMS ? 1 : G) * CPI, OTHR = W16_THREADS / NTEAM;        // read-out: chunks and threads per team
+  constexpr int PER_TO = (NCH + OTHR - 1) / OTHR;
+  v4i w[L1::KS];
+  int cur_s = -1;
+  for (int it = 0; it < count; ++it) {
+    const int item = begin + it;
+    const int s = item / groups, img0 = (item - s * groups) * G;
+#ifdef QBNN_W16_STAMP
+    const bool st_on = g_w16_stamp != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && it == 2;
+    int st_k = 0;
+#endif
+    if (s != cur_s) {            // workgroup-uniform; a few times per launch.  (TEAMS: both teams pass the same number of team
+      __syncthreads();           //  barriers per item, so they meet here with equal counters.)  Every wave is done with the
+      int l_ = lane;             // previous sample's weights (and the prologue's LDS writes).
+      asm volatile("" : "+v"(l_));
+#pragma unroll
+      for (int k = 0; k < NBLK; ++k) {
+        dma_conv<L1, W16_WAVES>(wl + (2 * k) * WB, a.blk[k].a.w + (int64_t)s * a.blk[k].a.w_ss, wave, l_);
+        dma_conv<L1, W16_WAVES>(wl + (2 * k + 1) * WB, a.blk[k].b.w + (int64_t)s * a.blk[k].b.w_ss, wave, l_);
+      }
+      dma_conv<L0, W16_WAVES>(wl0, a.stem.w + (int64_t)s * a.stem.w_ss, wave, l_);
+      dma_barrier();             // vmcnt(0) + barrier: the weights have landed
+      cur_s = s;
+      // stagger: team 1 starts when team 0 is three convs into its image
+      if (TEAMS && team == 1) team_wait(tcnt, ttarget + 8 * 3);
+    }
+    {                            // stem.0's weights of the first block: live across layers.0 (which only needs one fragment)
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));
+#pragma unroll
+      for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wl + l_ * 16 + ks * 1024);
+    }
+    W16_STAMP();
+    sync();                      // the previous item's X tile has been read out by every thread
+    W16_STAMP();
+    {                            // layers.0 (ConvReLU2d): patches -> X tile, centred on its own zero point
+      EpiTile<L1::HO, L1::PIXB, L1::TILE_BYTES> epi{xt, a.stem};
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));
+      const int r = l_ & 31, h = l_ >> 5;
+      const v4i w0 = *reinterpret_cast<const v4i*>(wl0 + l_ * 16);
+      float4 b4[3];
+#pragma unroll
+      for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias0 + 8 * g4 + 4 * h);
+      const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, pf[i], zero16, 0, 0, 0);
+        W16_STAMP();
+        epilogue24(acc, b4, a.stem, epi, px_off(wg, woh0 + i, r), h);
+        W16_STAMP();
+      }
+    }
+    sync();
+    W16_STAMP();
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+      const BlockParams& bp = a.blk[k];
+      {
+        EpiTile<L1::HO, L1::PIXB, L1::TILE_BYTES> epi{tt, bp.a};
+        conv3x3_rows_w16<RW>(xt, w, wl + (2 * k + 1) * WB, bias_lds + (2 * k) * L1::COUT, bp.a, epi, wg, woh0, lane W16_STAMP_PASS);
+      }
+      sync();
+      W16_STAMP();
+      {
+        EpiTileResInPlace<L1::HO, L1::PIXB, L1::TILE_BYTES> epi{xt, bp.b, bp.add};
+        conv3x3_rows_w16<RW>(tt, w, k + 1 < NBLK ? wl + (2 * k + 2) * WB : nullptr, bias_lds + (2 * k + 1) * L1::COUT, bp.b, epi, wg, woh0,
+                             lane W16_STAMP_PASS);
+      }
+      sync();
+      W16_STAMP();
+    }
+    // the next item's patch fragments: in flight during the read-out, the stores and the barrier at the loop top
+    fetch_patches(it + 1 < count ? item + 1 : item);
+    // ---- X tile interior (centred on the last add's zero point) -> quint8 -> HBM
+    {
+      const uint32_t z4 = (uint32_t)a.blk[NBLK - 1].add.z_o * 0x01010101u;
+      uint8_t* ys = a.y + (int64_t)s * a.y_ss;
+      int t_ = TEAMS ? (tid & (OTHR - 1)) : tid;
+      asm volatile("" : "+v"(t_));
+#pragma unroll
+      for (int j = 0; j < PER_TO; ++j) {
+        const int i = t_ + j * OTHR;
+        if (i < NCH) {
+          const int g = TEAMS ? team : i / CPI, rem = TEAMS ? i : i - g * CPI, row = rem / CPR, within = rem - row * CPR;
+          const uint8_t* d = xt + g * L1::TILE_BYTES + (row + 1) * L1::PITCH + L1::row_chunk_off(within);
+          const v2i lo = *reinterpret_cast<const v2i*>(d), hi = *reinterpret_cast<const v2i*>(d + 8);
+          if (img0 + g < a.B)
+            *reinterpret_cast<v4i*>(ys + ((int64_t)(img0 + g) * L1::HIN) * L1::ROWB + (int64_t)rem * 16) =
+                v4i{(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
+        }
+      }
+    }
+    W16_STAMP();
+  }
+}
+
+template <int G, int NBLK, int NM, bool TEAMS>
+int launch_w16(const ChainArgs<NBLK>* arr, int n, hipStream_t st) {
+  constexpr int LDS = w16_lds<G, NBLK>() + 16;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static_assert(sizeof(ArgsArr<ChainArgs<NBLK>, NM>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)stem_chain_w16_kernel<G, NBLK, NM, TEAMS>, attr, LDS)) return rc_attr;
+  ArgsArr<ChainArgs<NBLK>, NM> all;
+  memset(&all, 0, sizeof(all));
+  int items = 0;
+  for (int i = 0; i < n; ++i) {
+    all.m[i] = arr[i];
+    const int it = arr[i].n_samples * ((arr[i].B + G - 1) / G);
+    items = it > items ? it : items;
+  }
+  const int per = 256 / n > 0 ? 256 / n : 1;
+  const int gx = items < per ? (items > 0 ? items : 1) : per;
+  hipLaunchKernelGGL((stem_chain_w16_kernel<G, NBLK, NM, TEAMS>), dim3(gx, n), dim3(W16_THREADS), LDS, st, all);
+  return check_launch("qbnn_stem_chain_i8_mc");
+}
+
+// QBNN_W16_MODE = g2 (default) | g1 | teams: 16 waves on 2 / 1 images with hardware barriers, or two staggered 8-wave teams
+// (measured at B = 256, S = 100: 1.097 / 1.18 / 1.10 ms against 1.205 ms for the 8-wave kernel)
+int w16_mode() {
+  static const int v = [] {
+    const char* e = getenv("QBNN_W16_MODE");
+    if (e && !strcmp(e, "g1")) return 1;
+    if (e && !strcmp(e, "teams")) return 3;
+    return 2;
+  }();
+  return v;
+}
+
+}  // namespace
+
+// entry points for qbnn_blocks.hip (declared in qbnn_host.h)
+int qbnn_launch_stem_chain_w16(const ChainArgs<2>* arr, int n, hipStream_t st) {
+  if (n < 1 || n > 4) return fail(QBNN_E_INVALID, "qbnn_launch_stem_chain_w16: 1 to 4 argument blocks per launch%s");
+  int mode = w16_mode();
+  for (int i = 0; i < n; ++i)
+    if (arr[i].B & 1) mode = mode == 3 ? 2 : mode;        // the team form takes image pairs
+  if (n == 1) {
+    if (mode == 1) return launch_w16<1, 2, 1, false>(arr, 1, st);
+    if (mode == 2) return launch_w16<2, 2, 1, false>(arr, 1, st);
+    return launch_w16<2, 2, 1, true>(arr, 1, st);
+  }
+  if (mode == 1) return launch_w16<1, 2, 4, false>(arr, n, st);
+  if (mode == 2) return launch_w16<2, 2, 4, false>(arr, n, st);
+  return launch_w16<2, 2, 4, true>(arr, n, st);
+}

@@ -1,0 +1,39 @@
+"""Timeline of one work item of the 16-wave layer-1 kernel (diagnostic library built with -DQBNN_W16_STAMP):
+    QBNN_HIPCC_EXTRA=-DQBNN_W16_STAMP QBNN_LIB_OVERRIDE=$PWD/tools/_build/libqbnn_W16STAMP.so python -m quantised_bayesian_nets_amd.build
+    QBNN_STAMP_LIB=tools/_build/libqbnn_W16STAMP.so python tools/stamp_w16.py        (on the GPU box)
+Prints, for the four waves of one SIMD (waves w, w+4, w+8, w+12), the cycles between consecutive stamps."""
+import sys, os, types, ctypes as C, numpy as np, torch
+os.environ["QBNN_LIB_OVERRIDE"] = os.path.abspath(os.environ.get("QBNN_STAMP_LIB", "tools/_build/libqbnn_W16STAMP.so"))
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from conftest import load_golden
+import quantised_bayesian_nets_amd as q
+from quantised_bayesian_nets_amd import _lib
+g = load_golden('resnet_bbb_a7w8.npz')
+args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+m = q.ModelFactory.get_model('conv_resnet_bbb', [1, 3, 32, 32], 10, True, args).load_reference_state(g['state'])
+S, B = 100, 256
+x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(2)).cuda()
+dbg = torch.zeros(16 * 64, dtype=torch.int64, device='cuda')
+L = _lib.lib(); L.qbnn_debug_w16_stamp_buffer.argtypes = [C.c_void_p]
+with q.mc_context(S, 3, 0):
+    m.forward_mc(x); torch.cuda.synchronize()
+    L.qbnn_debug_w16_stamp_buffer(C.c_void_p(dbg.data_ptr()))
+    m.forward_mc(x); torch.cuda.synchronize()
+d = dbg.cpu().numpy().reshape(16, 64)
+n = int((d[0] != 0).sum())
+t0 = d[:, 0].min()
+G = int(os.environ.get("QBNN_W16_G", "2")); RW = 2 * G
+labels = ["top", "barrier"] + sum([["c0 M%d" % i, "c0 E%d" % i] for i in range(RW)], []) + ["barrier"]
+for k in range(2):
+    for nm in ("a", "b"):
+        labels += sum([["%s%d M%d" % (nm, k, i), "%s%d E%d" % (nm, k, i)] for i in range(RW)], []) + ["barrier"]
+labels += ["read-out"]
+for w0 in (0, 1):
+    ws = [w0, w0 + 4, w0 + 8, w0 + 12]
+    print("waves", ws, "(cycles since the first stamp of the workgroup; then the step since the wave's previous stamp)")
+    for k in range(n):
+        row = "%-10s" % (labels[k] if k < len(labels) else "?")
+        for w in ws:
+            row += " %7d (%5d)" % (d[w, k] - t0, d[w, k] - d[w, k - 1] if k else 0)
+        print(row)
+print("item total:", (d[:, n - 1] - d[:, 0]).max(), "cycles")
