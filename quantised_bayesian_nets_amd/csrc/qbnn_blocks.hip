@@ -705,7 +705,7 @@ void block_chain_ald_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
       window_sum_from_table<C>(sx, A, wave, lane);
       EpiDenseTile<C::PIXB> epi{xt, bp.a, 0};
       auto flush = [&](int mb) {
-        const int v = epi.csum + __shfl_xor(epi.csum, 32);
+        const int v = half_sum(epi.csum);
         epi.csum = 0;
         if (lane < 32) __hip_atomic_fetch_add(&stab[((wave / C::NBLKS) * C::MB + mb) * 32 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };

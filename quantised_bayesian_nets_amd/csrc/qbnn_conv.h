@@ -13,6 +13,20 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v2iperm __attribute__((ext_vector_type(2)));
+
+// Cross-half exchanges of a wave in ONE vector instruction (v_permlane32_swap, gfx950): no LDS round trip (ds_bpermute, which
+// __shfl_xor(v, 32) compiles to, is ~100+ cycles of latency at the head of every epilogue's dependent chain).
+// v_permlane32_swap vdst, src: swaps vdst[lanes 32..63] with src[lanes 0..31]; with both operands = v the first result holds
+// v's lower-half value in both halves, the second its upper-half value.
+__device__ __forceinline__ int half_lo_bcast(int v) {            // lane l gets v of lane l & 31
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return (int)r[0];
+}
+__device__ __forceinline__ int half_sum(int v) {                 // lane l gets v(l & 31) + v((l & 31) + 32)
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return (int)r[0] + (int)r[1];
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
@@ -299,8 +313,7 @@ __device__ __forceinline__ void conv_passes_rows(const uint8_t* tile, const int8
       if (mb > 0) {
         const int e = mb - 1;
         const int rv = acc[e][C::ONES_REG];
-        const int ro = __shfl_xor(rv, 32);
-        const int zwr = p.z_w * (h ? ro : rv);
+        const int zwr = p.z_w * half_lo_bcast(rv);
         const int po = epi.pixel(m0 + e * 32 + r);
         uint32_t pre[4];
 #pragma unroll
@@ -448,10 +461,9 @@ __device__ __forceinline__ void conv_passes(const uint8_t* tile, const int8_t* w
       int R;
       if (C::USE_ONES) {                 // output row COUT of the ones tile holds R; it lives in the h == 0 lanes
         const int rv = acc[mb][C::ONES_TILE % C::NB][C::ONES_REG];
-        const int ro = __shfl_xor(rv, 32);
-        R = h ? ro : rv;
+        R = half_lo_bcast(rv);
       } else {
-        R = rsum[mb] + __shfl_xor(rsum[mb], 32);
+        R = half_sum(rsum[mb]);
       }
       const int zwr = p.z_w * R;
       const int m = epi.pixel((mblk * C::MB + mb) * 32 + r);
@@ -683,6 +695,16 @@ struct EpiTileResInPlace {
 //   fetched into registers while the current one computes (issue-early / write-late), so HBM latency is off the
 //   critical path.
 // =====================================================================================
+// argument block of the single-conv kernels (layer-level C ABI entry qbnn_conv2d_i8_mc)
+struct ConvArgs {
+  const uint8_t* x; int64_t x_ss;
+  const uint8_t* res; int64_t res_ss;
+  uint8_t* y; int64_t y_ss;
+  int B;
+  QConv p; QAdd a;
+  PostArgs post;                   // POST kernels only
+};
+
 #ifndef QBNN_BLK_THREADS
 #define QBNN_BLK_THREADS 512
 #endif
@@ -817,10 +839,9 @@ __device__ __forceinline__ void conv_epi_phase_with(const float* bias_lds, const
     int R;
     if (C::USE_ONES) {
       const int rv = A.acc[mb][C::ONES_TILE % C::NB][C::ONES_REG];
-      const int ro = __shfl_xor(rv, 32);
-      R = h ? ro : rv;
+      R = half_lo_bcast(rv);
     } else {
-      R = A.rsum[mb] + __shfl_xor(A.rsum[mb], 32);
+      R = half_sum(A.rsum[mb]);
     }
     const int zwr = p.z_w * R;
     const int po = epi.pixel((mblk * C::MB + mb) * 32 + r);
@@ -978,8 +999,7 @@ __device__ __forceinline__ void conv_core(const uint8_t* tile, const uint8_t* wc
         if (mb > 0) {
           const int e = mb - 1;
           const int rv = acc[e][C::ONES_REG];
-          const int ro = __shfl_xor(rv, 32);
-          const int zwr = p.z_w * (h ? ro : rv);
+          const int zwr = p.z_w * half_lo_bcast(rv);
           const int po = epi.pixel(m0 + e * 32 + r);
           uint32_t pre[4];
 #pragma unroll

@@ -62,8 +62,7 @@ __device__ __forceinline__ void epilogue24(const v16i& acc, const float4 (&b4)[3
   }
 #endif
   const int rv = acc[L1::ONES_REG];
-  const int ro = __shfl_xor(rv, 32);
-  const int zwr = p.z_w * (h ? ro : rv);
+  const int zwr = p.z_w * half_lo_bcast(rv);
   uint32_t pre[3];
 #pragma unroll
   for (int g4 = 0; g4 < 3; ++g4) pre[g4] = epi.load(po, 8 * g4 + 4 * h);

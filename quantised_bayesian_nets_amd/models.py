@@ -17,6 +17,9 @@ from .layers import Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_
 from .quant import UINT_BOUNDS, check_bits
 
 
+RS_CHANNELS = (96,)          # channel counts whose 3x3 / stride-1 convs run on the register-stationary kernels
+
+
 class Add(nn.Module):
     """reference src/utils.py:49-55 (`Add`, a FloatFunctional -> QFunctional add).  Fused into stem.3's epilogue."""
 
@@ -102,6 +105,13 @@ def run_identity_chain(blocks, x, stem=None):
     `stem` = (layers.0 module, its sampled weights, im2col patches [B, 1024, 32], input scale): the network's first conv
     runs inside the same kernel (qbnn_stem_chain_i8_mc) and `x` only carries conv0's output qparams / shape."""
     S = _MC.samples
+    if stem is None and x.data.shape[4] in RS_CHANNELS and os.environ.get("QBNN_RS_CHAIN", "1") != "0":
+        # wide identity blocks: one launch per conv on the register-stationary kernels (csrc/qbnn_rs.hip) -- the sample's weights stay in
+        # registers for the whole launch instead of streaming through LDS once per 8 / 16 images; stem.0's output goes through L2
+        h = x
+        for blk in blocks:
+            h = blk(h)
+        return h
     if stem is None and (len(blocks) > 2 or (len(blocks) == 2 and x.data.shape[4] >= 96)):
         h = x
         step = 1 if x.data.shape[4] >= 96 else 2
