@@ -24,7 +24,7 @@ import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -79,10 +79,8 @@ def _wl_resnet(w_bits, samples_default, tag):
 
 def _wl_ensemble16(a, world, q, load_golden):
     """BASELINE configs[3]: 16 SGHMC members (deterministic int8 ResNets), members = the MC samples, sharded over the ranks (strong scaling)."""
-    from conftest import synth_ensemble_members
-    d = np.load(os.path.join(ROOT, "tests", "golden", "ensemble_resnet_a7w8.npz"))
-    n0 = int(d["meta.members"])
-    ge = dict(members=[{k[len(f"member{i}/"):]: d[k] for k in d.files if k.startswith(f"member{i}/")} for i in range(n0)])
+    from fixtures import synth_ensemble_members, load_ensemble_fixture
+    ge = load_ensemble_fixture()
     n = 16
     args = types.SimpleNamespace(activation_precision=7, weight_precision=8, model="conv_resnet_sgld", samples=n)
     model = q.ModelFactory.get_model("conv_resnet_sgld", [1, 3, 32, 32], 10, True, args, training_mode=False).load_reference_state(synth_ensemble_members(ge, n))
@@ -135,7 +133,29 @@ def _wl_mlp_f32(a, world, q, load_golden):
                 describe="configs[0]: UCI-regression-shaped (in_dim %d) 4x100 MLP Bayes-by-backprop fp32, %d MC samples per GPU per step, 1000 rows" % (in_dim, S))
 
 
-WORKLOADS = {"resnet_bbb": _wl_resnet(0, 100, "configs[2]"), "resnet_bbb_w4": _wl_resnet(4, 128, "configs[4] (A7/W4, 1024 samples over 8 GPUs = 128 per GPU)"),
+def _wl_resnet_float(kind):
+    """SURVEY 8a rows a1 / a2 at the headline's shape (B = 256): the float Bayes-by-backprop ResNet-18 (fp32 MFMA convs, per-sample
+    weights) and its QAT form evaluated with live observers (fake-quantised tensors, fp64 conv sums; the MC samples are sequential
+    through the observers' EMA state, so 10 per step).  States recorded from the reference (tests/golden/resnet_bbb_{f32,qat}.npz)."""
+    def build(a, world, q, load_golden):
+        if kind == "qat":
+            g = load_golden("resnet_bbb_qat.npz")
+            args = types.SimpleNamespace(sigma_prior=-2.0, activation_precision=7, weight_precision=8, qat_eval=True)
+            model = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args).load_reference_state(g["state"])
+        else:
+            g = load_golden("resnet_bbb_f32.npz")
+            model = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, False, types.SimpleNamespace(sigma_prior=-2.0)).load_reference_state(g["state"])
+        S = a.samples if a.samples > 0 else 10
+        x_host = torch.randn(a.batch, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+        what = "QAT fake-quant evaluation with live observers (A7/W8 grids)" if kind == "qat" else "float Bayes-by-backprop"
+        return dict(golden=None, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=False, cpu_baseline=False,
+                    step=lambda m, x, S_, seed: q.mc_predict(m, x, S_, seed), scaling="weak", dtype="f64" if kind == "qat" else "f32",
+                    metric="MC forward samples/sec, ResNet-18 BBB %s batch=%d" % ("QAT-eval" if kind == "qat" else "fp32", a.batch), unit="MC samples/s",
+                    describe="rows a1/a2: CIFAR-10-shaped ResNet-18 (24/48/96/192), %s, %d MC samples per GPU per step, batch=%d" % (what, S, a.batch))
+    return build
+
+
+WORKLOADS = {"resnet_bbb": _wl_resnet(0, 100, "configs[2]"), "resnet_f32": _wl_resnet_float("f32"), "resnet_qat": _wl_resnet_float("qat"), "resnet_bbb_w4": _wl_resnet(4, 128, "configs[4] (A7/W4, 1024 samples over 8 GPUs = 128 per GPU)"),
              "ensemble16": _wl_ensemble16, "lenet_mc": _wl_lenet_mc, "mlp_f32": _wl_mlp_f32, "resnet_mc": _wl_resnet_mc}
 
 
@@ -176,7 +196,7 @@ def cpu_baseline(a, g, x_host, seed):
             "_p_oracle_sample0": p_or}
 
 
-SECONDARY = ("resnet_bbb_w4", "ensemble16", "lenet_mc", "mlp_f32", "resnet_mc")
+SECONDARY = ("resnet_bbb_w4", "ensemble16", "lenet_mc", "mlp_f32", "resnet_mc", "resnet_f32", "resnet_qat")
 
 
 def secondary_workloads(a, q, load_golden, seed):
@@ -192,10 +212,11 @@ def secondary_workloads(a, q, load_golden, seed):
             S = wl["units_global"]
             graphed = q.GraphedPredictor(model, S, **wl["graph"]) if ("graph" in wl and not a.no_graph) else None
             run = (lambda: graphed(x, seed)) if graphed is not None else (lambda: wl["step"](model, x, S, seed))
-            for _ in range(6):
+            slow = name in ("resnet_f32", "resnet_qat")           # 8-16 ms per step: fewer repetitions keep the default run short
+            for _ in range(2 if slow else 6):
                 run()
             torch.cuda.synchronize()
-            n = 10
+            n = 4 if slow else 10
             t0 = time.perf_counter()
             for _ in range(n):
                 run()
@@ -254,12 +275,21 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     if a.plumbing_check:
+        # no GPU: the launcher, the rendezvous, the partition of BASELINE configs[4] / configs[3] over the ranks and the one collective
+        # of the path (sum all-reduce of the [2, B, C] fp64 moments) over gloo
+        from quantised_bayesian_nets_amd.mc import shard_samples, all_reduce_moments
         dist.init_process_group("gloo")
         t = torch.tensor([float(rank)])
         dist.all_reduce(t)
+        mine = {"rank": rank, "samples_1024": list(shard_samples(1024, rank, world)), "members_16": list(shard_samples(16, rank, world))}
+        shards = [None] * world
+        dist.all_gather_object(shards, mine)
+        mom = torch.full((2, a.batch, 10), float(rank + 1), dtype=torch.float64)
+        all_reduce_moments(mom)
         dist.barrier()
         if rank == 0:
-            print(json.dumps({"plumbing_check": True, "ranks": dist.get_world_size(), "rank_sum": float(t.item())}))
+            print(json.dumps({"plumbing_check": True, "ranks": dist.get_world_size(), "rccl_ranks": dist.get_world_size(), "rank_sum": float(t.item()),
+                              "moments_sum": float(mom[0, 0, 0].item()), "shards": shards}))
         dist.destroy_process_group()
         return
     # rehearsal on a one-GPU box: QBNN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and QBNN_BENCH_BACKEND=gloo replaces RCCL (which
@@ -278,7 +308,7 @@ def main():
 
     import quantised_bayesian_nets_amd as q
     from quantised_bayesian_nets_amd import layers as qlayers
-    from conftest import load_golden
+    from fixtures import load_golden           # tests/golden/fixtures.py: plain readers of the committed .npz data
 
     wl = WORKLOADS[a.workload](a, world, q, load_golden)
     g, model, x_host, step_fn = wl["golden"], wl["model"], wl["x_host"], wl["step"]
@@ -429,6 +459,10 @@ def main():
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    from quantised_bayesian_nets_amd import models as qmodels
+    if qmodels.GRAPH_FALLBACKS:        # a refused HIP-graph capture silently changes what was timed: fail the run instead
+        print("bench.py: HIP graph capture fell back to eager launches: %s" % "; ".join(qmodels.GRAPH_FALLBACKS), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

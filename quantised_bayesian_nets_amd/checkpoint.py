@@ -105,7 +105,7 @@ def save_model(model, path, prefix=""):
 
 
 def _natural_keys(text):
-    return [int(c) if c.isdigit() else c for c in re.split(r"(\d+)", text)]       # src/utils.py:57-64
+    return [int(c) if c.isdigit() else c for c in re.split(r"(-?\d+)", text)]     # src/utils.py:57-61 (its regex, verbatim)
 
 
 def ensemble_files(path, samples, special_info=""):

@@ -220,8 +220,7 @@ def prepare_model_state(float_state):
         moved = False
         for bn, conv in bn_of.items():
             if k.startswith(bn + "."):
-                if not k.endswith("num_batches_tracked"):
-                    out[conv + ".bn." + k[len(bn) + 1:]] = np.asarray(v)
+                out[conv + ".bn." + k[len(bn) + 1:]] = np.asarray(v)        # incl. num_batches_tracked, as the reference's fused module keeps it
                 moved = True
                 break
         if not moved:

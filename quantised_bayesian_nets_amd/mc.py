@@ -150,6 +150,15 @@ class GraphedPredictor:
     def __init__(self, model, samples, return_var=False, regression=False, group=None):
         self.model, self.samples, self.return_var, self.regression, self.group = model, int(samples), return_var, regression, group
         self._graphs = {}
+        # A captured graph holds raw device pointers to the packed weights / qparams of the state it was captured with: loading
+        # another state into the model drops every graph (the next call captures again).
+        loader = getattr(model, "load_reference_state", None)
+        if loader is not None:
+            def _load_and_invalidate(*a, **k):
+                self._graphs.clear()
+                return loader(*a, **k)
+            model.load_reference_state = _load_and_invalidate
+        self._is_ensemble = hasattr(model, "ensemble")
 
     def _local(self, x, begin, count):
         """The rank-local part: forward of `count` samples + their fp64 moments (and mean / var when this rank is all there is)."""
@@ -163,11 +172,9 @@ class GraphedPredictor:
         return reduce_moments(out)
 
     def _capture(self, x, begin, count):
-        import numpy as np
         L = _lib.lib()
         static_x = x.clone()
         noise = torch.zeros(4, dtype=torch.int32, device=x.device)
-        host = torch.from_numpy(np.zeros(4, np.int32)).pin_memory()
         self._local(static_x, begin, count)                     # eager once: packs weights, builds every cache the launches read
         torch.cuda.synchronize()
         _lib.check(L.qbnn_set_device_noise_source(_lib.ptr(noise)))
@@ -177,7 +184,7 @@ class GraphedPredictor:
                 res = self._local(static_x, begin, count)
         finally:
             _lib.check(L.qbnn_set_device_noise_source(None))
-        return static_x, noise, host, graph, res
+        return static_x, noise, graph, res
 
     def __call__(self, x, seed, sample_begin=0):
         import numpy as np
@@ -185,14 +192,29 @@ class GraphedPredictor:
             raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
         rank, world = _rank_world(self.model, self.group)
         begin, count = shard_samples(self.samples, rank, world)
+        if self._is_ensemble and sample_begin != 0:
+            raise ValueError("GraphedPredictor: an ensemble's member indices are fixed at capture; sample_begin must be 0")
+        if count == 0:          # a rank without samples (more ranks than samples): zero moments, as mc_predict does
+            B = x.shape[0]
+            width = 2 if self.regression else self.model.output_size
+            moments = torch.zeros((2, B, width), dtype=torch.float64, device=x.device)
+            all_reduce_moments(moments, self.group)
+            if self.regression:
+                mean, uvar = finalize_moments(moments, self.samples)
+                return mean[:, 0:1], uvar[:, 0:1] + mean[:, 1:2]
+            mean, var = finalize_moments(moments, self.samples, want_var=self.return_var)
+            return (mean, var) if self.return_var else mean
         key = (tuple(x.shape), x.dtype, x.device.index, begin, count)
         ent = self._graphs.get(key)
         if ent is None:
             ent = self._graphs[key] = self._capture(x, begin, count)
-        static_x, noise, host, graph, res = ent
+        static_x, noise, graph, res = ent
         static_x.copy_(x)
-        host.numpy()[:] = np.array([seed & 0xffffffff, (seed >> 32) & 0xffffffff, (begin + sample_begin) & 0xffffffff, 0], np.uint32).view(np.int32)
-        noise.copy_(host, non_blocking=True)
+        # the three noise words go up from a FRESH pageable tensor with a blocking copy: the runtime stages pageable memory before
+        # the call returns, so a later call can never overwrite words that an earlier replay has not read yet (one reused pinned
+        # buffer with an asynchronous copy could, when replays queue up)
+        words = np.array([seed & 0xffffffff, (seed >> 32) & 0xffffffff, (begin + sample_begin) & 0xffffffff, 0], np.uint32).view(np.int32)
+        noise.copy_(torch.from_numpy(words), non_blocking=False)
         graph.replay()
         if self.regression:
             moments = res.clone()

@@ -17,6 +17,7 @@ from .layers import Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_
 from .quant import UINT_BOUNDS, check_bits
 
 
+GRAPH_FALLBACKS = []          # HIP-graph captures that were refused (the eager launch chain ran instead)
 RS_CHANNELS = (96,)          # channel counts whose 3x3 / stride-1 convs run on the register-stationary kernels
 
 
@@ -400,6 +401,7 @@ class Network(nn.Module):
                 except Exception as e:                      # capture refused: keep launching eagerly (same kernels), but say so
                     import warnings
                     warnings.warn(f"qbnn ensemble: HIP graph capture of member {idx} failed ({e!r}); launching eagerly")
+                    GRAPH_FALLBACKS.append(f"member {idx}: {e!r}")     # a benchmark must not time the fallback silently: bench.py exits non-zero
                     torch.cuda.synchronize()
                     ent = False
             self._graphs[key] = ent

@@ -84,6 +84,7 @@ class _QDeterministic(nn.Module):
         self.bias_ = None if b is None or np.asarray(b).size == 0 else torch.from_numpy(np.asarray(b, np.float32).copy())
         self.scale, self.zero_point = float(state[prefix + "scale"]), int(state[prefix + "zero_point"])
         self._dev = None
+        self._pk = None          # the packed-fragment copy too: it is keyed by (krow, device) only
         return self
 
     def _device_params(self, device, w_ohwi):

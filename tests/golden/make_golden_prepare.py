@@ -50,6 +50,12 @@ def main():
     shapes = []
     hooks = [m.register_forward_pre_hook(lambda m, i: shapes.append(tuple(m.weight.shape))) for m in model.modules() if hasattr(m, "weight_fake_quant")]
     snap = {k: v.clone() for k, v in model.state_dict().items()}
+    # Conv backend: plain ATen (mkldnn off).  The reference's calibration is NOT backend-independent: its observers start unseen, every
+    # fake-quantised activation feeds the next observer, and oneDNN sums the fp32 products in another order than ATen's own conv --
+    # the two backends end up to 3 % of an observer's range apart after three forwards (tests/golden/make_golden_prepare_spread.py
+    # measures it: mkldnn on / off x 1 / 3 / 8 threads fall into exactly two groups).  The recorded run is the ATen one.
+    mk = torch.backends.mkldnn.flags(enabled=False)
+    mk.__enter__()
     with torch.no_grad():
         model(x)
     for h in hooks:
@@ -79,6 +85,7 @@ def main():
     for k, v in model.state_dict().items():
         if k.endswith("min_val") or k.endswith("max_val"):
             out["calibrated/" + k] = v.detach().numpy().copy()
+    mk.__exit__(None, None, None)
     qu.convert(model)
     for k, v in model.state_dict().items():
         if v is None:

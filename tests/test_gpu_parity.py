@@ -2,6 +2,7 @@
 (a) the golden vectors recorded from the real reference and (b) the CPU oracle on the same seeded inputs.
 Integer tensors: bit-exact.  fp32 probabilities / moments: 1e-5 relative (BASELINE.json north_star)."""
 import ctypes as C
+import os
 import types
 
 import numpy as np
@@ -974,12 +975,13 @@ def test_native_prepare_calibrate_convert_pipeline():
     """SURVEY 8f row 4 end to end without the reference: float state -> `prepare_model_state` -> calibration by live-observer
     evaluation forwards on the GPU -> `convert_model_state`; against what the REFERENCE produced from the same float model with
     prepare_model -> 3 eval forwards (same injected eps) -> convert (tests/golden/make_golden_prepare.py).
-    Weight-side quantities (weight / std / mul_noise / add_weight observers, their qparams, the int8 tensors) depend on
-    elementwise fp32 arithmetic only: identical to 1e-5 / by hash.  Activation observers are the min / max of fake-quantised fp32
-    conv outputs of a model whose observers start UNSEEN: one element whose rounding flips (the reference sums in fp32 in mkldnn's
-    order, the build in fp64) moves a min / max by a grid step, that moves the next forward's scale, and the difference compounds
-    with depth (1 % at layer 2, 5 % at layer 4 here) -- the warmed-observer case is pinned to 1e-4 by
-    test_qat_eval_with_live_observers_matches_reference; here the activation side only has to land within 15 % of the range."""
+
+    Tolerances are measured, not assumed (tests/golden/make_golden_prepare_spread.py, resnet_bbb_prepare_spread.npz): the reference's
+    own calibration depends on its conv backend -- its observers start unseen, every fake-quantised activation feeds the next
+    observer, and oneDNN sums the fp32 products in another order than ATen's own convolution: mkldnn on / off x 1 / 3 / 8 threads fall
+    into exactly two groups, up to 3.0 % of an observer's range (4.1 % in a converted scale, 1 in a zero point) apart.  The recorded
+    fixture is the plain-ATen run (mkldnn off, thread-count independent); the build (fp64 conv sums under the fake-quantisers) lands
+    on it: 2.7e-7 of the range on the worst activation observer, scales to 2.7e-7, every zero point and every int8 tensor equal."""
     import hashlib
     import os
     import quantised_bayesian_nets_amd as q
@@ -996,6 +998,7 @@ def test_native_prepare_calibrate_convert_pipeline():
     st = m.prepared_state()
     weight_like = lambda k: any(t in k for t in ("weight_fake_quant", "std_fake_quant", "mul_noise", "add_weight"))
     n_w = n_a = 0
+    worst_act = 0.0
     for k in ref.files:                                       # observers after calibration
         if not k.startswith("calibrated/") or not k.endswith("min_val"):
             continue
@@ -1007,7 +1010,9 @@ def test_native_prepare_calibrate_convert_pipeline():
             n_w += 1
         else:
             rng = max(hi, 0.0) - min(lo, 0.0)
-            assert abs(glo - lo) <= 0.15 * rng and abs(ghi - hi) <= 0.15 * rng, (kk, glo, lo, ghi, hi)
+            dev = max(abs(glo - lo), abs(ghi - hi)) / rng
+            worst_act = max(worst_act, dev)
+            assert dev <= 1e-5, (kk, glo, lo, ghi, hi)       # measured: 2.7e-7 (the reference's two backends: up to 3.0e-2 apart)
             n_a += 1
     assert n_w == 4 * 21 and n_a == 21 + 8 + 1                 # 21 layers x (weight, std, mul, add) ; 21 outputs + 8 Adds + the stub
     args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
@@ -1021,18 +1026,29 @@ def test_native_prepare_calibrate_convert_pipeline():
             base = key[:-len(".sha1")]
             n_int8 += 1
             n_same += int(hashlib.sha1(np.ascontiguousarray(conv[base]).tobytes()).hexdigest() == str(ref[k]))
-        elif key.endswith(".q_scale") or weight_like(key) and key.endswith("scale"):
+        elif key.endswith("scale"):                            # weight-side and activation-side alike
             np.testing.assert_allclose(float(np.asarray(conv[key]).reshape(-1)[0]), float(np.asarray(ref[k]).reshape(-1)[0]), rtol=1e-5, err_msg=key)
-        elif key.endswith(".q_zero_point") or weight_like(key) and key.endswith("zero_point"):
-            assert int(np.asarray(conv[key]).reshape(-1)[0]) == int(np.asarray(ref[k]).reshape(-1)[0]), key
-        elif key.endswith("scale"):
-            np.testing.assert_allclose(float(np.asarray(conv[key]).reshape(-1)[0]), float(np.asarray(ref[k]).reshape(-1)[0]), rtol=0.15, err_msg=key)
         elif key.endswith("zero_point"):
-            assert abs(int(np.asarray(conv[key]).reshape(-1)[0]) - int(np.asarray(ref[k]).reshape(-1)[0])) <= 12, key
-    # int8 weight / std tensors bit-identical to the reference's (an observer one ulp off may move single elements of a tensor on a tie)
-    assert n_int8 == 42 and n_same >= 40, (n_same, n_int8)
+            assert int(np.asarray(conv[key]).reshape(-1)[0]) == int(np.asarray(ref[k]).reshape(-1)[0]), key
+    # int8 weight / std tensors bit-identical to the reference's (a BN-folded weight observer one ulp off may move single elements of
+    # one tensor on a rounding tie: 41 of 42 by hash here, the four tensors recorded in full must be equal)
+    assert n_int8 == 42 and n_same >= 41, (n_same, n_int8)
     for key in ("layers.0.weight", "layers.4.0.shortcut.0.weight", "layers.9.weight", "layers.0.std"):
-        assert int((np.asarray(conv[key]).astype(np.int32) != ref["converted/" + key].astype(np.int32)).sum()) <= 2, key
+        assert np.array_equal(np.asarray(conv[key]).astype(np.int32), ref["converted/" + key].astype(np.int32)), key
+    # the committed reference-vs-reference measurement: the oneDNN runs sit up to ~3 % of a range away from the ATen runs (and from the build)
+    spr = np.load(os.path.join(GOLDEN, "resnet_bbb_prepare_spread.npz"))
+    cfg = [str(c) for c in spr["meta.configs"]]
+    far = {}
+    for i, c in enumerate(cfg):
+        w = 0.0
+        for k in ref.files:
+            if k.startswith("calibrated/") and k.endswith("min_val") and not weight_like(k):
+                kk = k[len("calibrated/"):]
+                lo, hi = float(spr["run%d/calibrated/%s" % (i, kk)]), float(spr["run%d/calibrated/%s" % (i, kk.replace("min_val", "max_val"))])
+                rng = max(hi, 0.0) - min(lo, 0.0)
+                w = max(w, abs(float(st[kk]) - lo) / rng, abs(float(st[kk.replace("min_val", "max_val")]) - hi) / rng)
+        far[c] = w
+    assert all(v <= 1e-5 for c, v in far.items() if "mkldnn=0" in c) and all(0.01 < v < 0.05 for c, v in far.items() if "mkldnn=1" in c), far
     # and the converted model runs
     model = convert_model(m, "conv_resnet_bbb", [1, 3, 32, 32], 10, args)
     p = q.mc_predict(model, x, 4, 1)
@@ -1583,3 +1599,85 @@ def test_head_random_qparams_against_oracle(seed):
             assert len(np.unique(logits)) > 4
             ref = orc.dequant_softmax(logits, s_y, z_y)
             np.testing.assert_allclose(probs[s].cpu().numpy(), ref, rtol=1e-6, atol=1e-9, err_msg=str((Cc, k, N, s)))
+
+
+@pytest.mark.gpu
+def test_checkpoint_file_to_hip_matches_reference(golden_w8):
+    """SURVEY 8f row 1 end to end on the device: the file the reference's `utils.save_model` wrote (torch.save of the converted
+    qint8 state dict, keys under `module.`, src/utils.py:84-93) -> `checkpoint.load_model` (src/utils.py:112-123) -> the HIP
+    path's MC evaluation == the reference's recorded per-sample and mean probabilities."""
+    import quantised_bayesian_nets_amd as q
+    from quantised_bayesian_nets_amd import checkpoint as ck
+    g = golden_w8
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+    path = os.path.join(os.path.dirname(__file__), "golden", "resnet_bbb_a7w8_weights.pt")
+    m = ck.load_model(q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args), path)
+    x = torch.from_numpy(g["x"]).cuda()
+    S, seed = g["probs"].shape[0], g["meta"]["philox_seed"]
+    mean, probs = q.mc_predict(m, x, S, seed, return_probs=True)
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean_probs"], rtol=RTOL, atol=1e-8)
+    assert torch.equal(mean, q.mc_predict(_model(g), x, S, seed))          # and bit-identical to the model loaded from the arrays
+
+
+@pytest.mark.gpu
+def test_reloading_a_state_after_a_forward_replaces_every_cached_weight(golden_lenet_mc, golden_w8):
+    """A model that has run keeps device copies of its weights (packed MFMA fragments, biases, captured graphs).  Loading a second
+    state into the SAME model must drop all of them: state A -> run -> state B -> run == a fresh model loaded with B."""
+    import quantised_bayesian_nets_amd as q
+    g = golden_lenet_mc
+    la = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=0.2)
+    rng = np.random.default_rng(11)
+    state_b = {}
+    for k, v in g["state"].items():
+        v = np.asarray(v)
+        if k.endswith(".weight") and v.dtype == np.int8:
+            state_b[k] = np.clip(v.astype(np.int32) + rng.integers(-9, 10, v.shape), -128, 127).astype(np.int8)
+        elif k.endswith(".bias") and v.size:
+            state_b[k] = (v * 1.25).astype(np.float32)
+        else:
+            state_b[k] = v
+    x = torch.rand(128, 1, 28, 28, generator=torch.Generator().manual_seed(3)).cuda()
+    m = q.ModelFactory.get_model("conv_lenet_mc", [1, 1, 28, 28], 10, True, la).load_reference_state(g["state"])
+    gp = q.GraphedPredictor(m, 6)
+    pa, ga = q.mc_predict(m, x, 6, 21), gp(x, 21)
+    m.load_reference_state(state_b)
+    pb, gb = q.mc_predict(m, x, 6, 21), gp(x, 21)
+    fresh = q.ModelFactory.get_model("conv_lenet_mc", [1, 1, 28, 28], 10, True, la).load_reference_state(state_b)
+    want = q.mc_predict(fresh, x, 6, 21)
+    assert torch.equal(pa, ga) and not torch.equal(pa, pb)
+    assert torch.equal(pb, want) and torch.equal(gb, want)
+    # the int8 BBB ResNet through a captured graph: same check (the graph holds raw pointers to the packed mu / sigma)
+    r = _model(golden_w8)
+    gr = q.GraphedPredictor(r, 3)
+    xr = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(4)).cuda()
+    a0 = gr(xr, 5)
+    st2 = dict(golden_w8["state"])
+    k0 = "layers.9.weight"
+    st2[k0] = np.clip(np.asarray(st2[k0]).astype(np.int32) + 5, -128, 127).astype(np.int8)
+    r.load_reference_state(st2)
+    a1 = gr(xr, 5)
+    r2 = _model(dict(golden_w8, state=st2))
+    assert torch.equal(a1, q.mc_predict(r2, xr, 3, 5)) and not torch.equal(a0, a1)
+
+
+@pytest.mark.gpu
+def test_graphed_predictor_queued_replays_keep_their_own_seeds(golden_lenet_mc):
+    """Replays queued back to back without a host synchronisation in between (the launch-bound case the class exists for) must
+    each run with THEIR seed and sample offset: the noise words travel in a fresh host buffer per call."""
+    import quantised_bayesian_nets_amd as q
+    g = golden_lenet_mc
+    la = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=0.2)
+    m = q.ModelFactory.get_model("conv_lenet_mc", [1, 1, 28, 28], 10, True, la).load_reference_state(g["state"])
+    gp = q.GraphedPredictor(m, 8)
+    x = torch.rand(128, 1, 28, 28, generator=torch.Generator().manual_seed(9)).cuda()
+    gp(x, 1)
+    torch.cuda.synchronize()
+    seeds = [(101, 0), (2 ** 35 + 7, 3), (55, 9), (101, 0), (7, 1), (8, 2), (9, 3), (10, 4)]
+    outs = [gp(x, s, sample_begin=b) for s, b in seeds]                   # no synchronisation between the calls
+    torch.cuda.synchronize()
+    for (s, b), o in zip(seeds, outs):
+        with q.mc_context(8, s, b):
+            want = m.forward_mc(x).double().mean(0)
+        np.testing.assert_allclose(o.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-9)
+    assert torch.equal(outs[0], outs[3]) and not torch.equal(outs[0], outs[1])

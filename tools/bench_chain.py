@@ -1,6 +1,6 @@
 import sys, types, time, numpy as np, torch
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
-from conftest import load_golden
+sys.path.insert(0,'.'); sys.path.insert(0,'tests/golden')
+from fixtures import load_golden
 import quantised_bayesian_nets_amd as q
 from quantised_bayesian_nets_amd.layers import MCQTensor
 from quantised_bayesian_nets_amd.models import run_identity_chain

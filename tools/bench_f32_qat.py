@@ -1,9 +1,9 @@
 """Float BBB ResNet-18 (row a1) and QAT evaluation with live observers (row a2) at B = 256: samples/s; python tools/bench_f32_qat.py [f32|qat] [S]"""
 import os, sys, time, types, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import quantised_bayesian_nets_amd as q
-from conftest import load_golden
+from fixtures import load_golden
 which = sys.argv[1] if len(sys.argv) > 1 else "qat"
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 x = torch.randn(256, 3, 32, 32, generator=torch.Generator().manual_seed(2)).cuda()

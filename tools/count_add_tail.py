@@ -17,12 +17,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from conftest import load_golden  # noqa: E402
+from fixtures import load_golden  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from oracle.fbgemm_baseline import FbgemmResNetBBB  # noqa: E402
 

@@ -4,8 +4,8 @@
 Prints, for the four waves of one SIMD (waves w, w+4, w+8, w+12), the cycles between consecutive stamps."""
 import sys, os, types, ctypes as C, numpy as np, torch
 os.environ["QBNN_LIB_OVERRIDE"] = os.path.abspath(os.environ.get("QBNN_STAMP_LIB", "tools/_build/libqbnn_W16STAMP.so"))
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
-from conftest import load_golden
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests/golden')
+from fixtures import load_golden
 import quantised_bayesian_nets_amd as q
 from quantised_bayesian_nets_amd import _lib
 g = load_golden('resnet_bbb_a7w8.npz')

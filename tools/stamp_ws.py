@@ -1,7 +1,7 @@
 import sys, os, types, time, ctypes as C, numpy as np, torch
 os.environ["QBNN_LIB_OVERRIDE"] = os.path.abspath(os.environ.get("QBNN_STAMP_LIB", "tools/_build/libqbnn_STAMP0.so"))
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
-from conftest import load_golden
+sys.path.insert(0,'.'); sys.path.insert(0,'tests/golden')
+from fixtures import load_golden
 import quantised_bayesian_nets_amd as q
 from quantised_bayesian_nets_amd import _lib
 from quantised_bayesian_nets_amd.layers import MCQTensor
