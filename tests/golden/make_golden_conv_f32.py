@@ -71,7 +71,7 @@ def run(model_name, in_shape, B, S, out, logit_gain):
         t.copy_(torch.from_numpy(e))
         return t
 
-    probs = []
+    probs, probs_aten = [], []
     torch.Tensor.normal_ = normal_
     try:
         with torch.no_grad():
@@ -79,9 +79,17 @@ def run(model_name, in_shape, B, S, out, logit_gain):
                 queue[:] = [orc.fill_normal(int(np.prod(sh)), SEED, lid, s).reshape(sh) for lid, sh in enumerate(shapes)]
                 probs.append(model(x).numpy().copy())
                 assert not queue
+                # the same forward on the reference's OTHER conv backend (plain ATen instead of oneDNN: another fp32 summation order):
+                # how far the reference is from itself is the floor of any fp32 comparison against it
+                queue[:] = [orc.fill_normal(int(np.prod(sh)), SEED, lid, s).reshape(sh) for lid, sh in enumerate(shapes)]
+                with torch.backends.mkldnn.flags(enabled=False):
+                    probs_aten.append(model(x).numpy().copy())
     finally:
         torch.Tensor.normal_ = orig
-    probs = np.stack(probs)
+    probs, probs_aten = np.stack(probs), np.stack(probs_aten)
+    spread_abs = float(np.abs(probs - probs_aten).max())
+    spread_rel = float((np.abs(probs - probs_aten) / np.maximum(np.minimum(probs, probs_aten), 1e-30)).max())
+    print(f"{model_name} float: reference oneDNN vs reference ATen max abs prob diff {spread_abs:.2e}, max rel {spread_rel:.2e}")
     net = orc.F32ConvOracle(state)
     fwd = net.lenet if "lenet" in model_name else net.resnet
     o = np.stack([fwd(x.numpy(), SEED, s) for s in range(S)])
@@ -89,7 +97,8 @@ def run(model_name, in_shape, B, S, out, logit_gain):
     print(f"{model_name} float: oracle vs reference max abs prob err {err:.2e} (max prob {probs.max():.3f}, median of row max {np.median(probs.max(-1)):.3f})")
     assert err < 2e-5
     res = {"x": x.numpy(), "probs": probs, "mean_probs": torch.stack([torch.from_numpy(p) for p in probs], dim=1).mean(dim=1).numpy(),
-           "meta.philox_seed": np.int64(SEED)}
+           "meta.philox_seed": np.int64(SEED), "refspread.max_abs": np.float64(spread_abs), "refspread.max_rel": np.float64(spread_rel),
+           "probs_aten": probs_aten}
     res.update({"state/" + k: v for k, v in state.items()})
     path = os.path.join(HERE, out)
     np.savez_compressed(path, **res)

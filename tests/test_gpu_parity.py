@@ -453,11 +453,19 @@ def test_errors_are_loud():
 @pytest.mark.parametrize("name,model", [("lenet_bbb_f32.npz", "conv_lenet_bbb"), ("resnet_bbb_f32.npz", "conv_resnet_bbb")])
 def test_float_bbb_conv_graphs_match_reference(name, model):
     """float BBB conv graphs on the GPU (MFMA fp32 implicit-GEMM conv, per-sample weights, in-kernel Philox
-    eps) against the reference's per-sample softmax outputs and their MC mean; fp32 tolerance 1e-5 relative
-    (+2e-6 absolute: summation order differs from mkldnn's)."""
+    eps) against the reference's per-sample softmax outputs and their MC mean.  Tolerance: 1e-5 relative (north_star) plus an
+    absolute term that is MEASURED, not chosen: the reference evaluated on its two CPU conv backends (oneDNN / plain ATen, another fp32
+    summation order of the same arithmetic; tests/golden/make_golden_conv_f32.py records both) differs from itself by 3.0e-7 (LeNet)
+    / 1.8e-7 (ResNet) absolute and 1.13e-5 / 1.3e-6 relative -- no fp32 implementation can be closer to "the reference" than the
+    reference is to itself, so atol = 2 x that spread (6e-7 / 3.6e-7; round 2 used a flat 2e-6).  Measured on the MI355X: max |dp|
+    8.3e-7 / 1.5e-7, max relative error on a probability (= on its logit's exp) 1.04e-5 / 9.4e-7, against the closer backend."""
     import quantised_bayesian_nets_amd as q
-    from conftest import load_golden
+    from conftest import load_golden, GOLDEN
     g = load_golden(name)
+    raw = np.load(os.path.join(GOLDEN, name))
+    spread_abs, spread_rel = float(raw["refspread.max_abs"]), float(raw["refspread.max_rel"])
+    atol = 2.0 * spread_abs
+    assert 1e-8 < spread_abs < 5e-7 and atol <= 6.5e-7
     args = types.SimpleNamespace(sigma_prior=-2.0)
     shape = [1, 28, 28] if "lenet" in model else [1, 3, 32, 32]
     m = q.ModelFactory.get_model(model, shape, 10, False, args).load_reference_state(g["state"])
@@ -465,16 +473,40 @@ def test_float_bbb_conv_graphs_match_reference(name, model):
     S = g["probs"].shape[0]
     with q.mc_context(S, g["meta"]["philox_seed"], 0):
         p = m.forward_mc(x)
-    np.testing.assert_allclose(p.cpu().numpy(), g["probs"], rtol=1e-5, atol=2e-6)
+    pn = p.cpu().numpy()
+    np.testing.assert_allclose(pn, g["probs"], rtol=1e-5, atol=atol)
+    # relative error on the probabilities themselves (= on the logits up to the softmax's per-row shift: d log p), against the closer
+    # of the two reference backends per element: within 1e-5 + what the backends differ by between themselves
+    both = np.stack([g["probs"], raw["probs_aten"]]).astype(np.float64)
+    rel = (np.abs(pn.astype(np.float64)[None] - both) / both).min(0)
+    print("\n%s: max |dp| %.2e, max relative error on p (d log p) %.2e; reference oneDNN vs ATen: %.2e abs, %.2e rel" % (
+        model, np.abs(pn - g["probs"]).max(), rel.max(), spread_abs, spread_rel))
+    assert rel.max() <= 1e-5 + spread_rel
     mean = q.mc_predict(m, x, S, g["meta"]["philox_seed"])
-    np.testing.assert_allclose(mean.cpu().numpy(), g["mean_probs"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean_probs"], rtol=1e-5, atol=atol)
     # the oracle on a sample the fixture does not hold
     from oracle import oracle as orc
     net = orc.F32ConvOracle(g["state"])
     fwd = net.lenet if "lenet" in model else net.resnet
     with q.mc_context(1, 11, 5):
         p5 = m(x)
-    np.testing.assert_allclose(p5.cpu().numpy(), fwd(g["x"], 11, 5), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(p5.cpu().numpy(), fwd(g["x"], 11, 5), rtol=1e-5, atol=atol)
+
+
+def test_float_resnet_full_batch_against_oracle():
+    """Row a1 at the headline's batch: the float BBB ResNet-18 at B = 256 (every workgroup tiling of the fp32 MFMA conv in play, not
+    the B = 2 of the reference fixture) on one MC sample against the CPU oracle of reference bbb/conv.py:33-39 (F32ConvOracle, itself
+    pinned to the reference by the fixture generator), 1e-5 relative + the measured 3.6e-7."""
+    import quantised_bayesian_nets_amd as q
+    from conftest import load_golden
+    from oracle import oracle as orc
+    g = load_golden("resnet_bbb_f32.npz")
+    m = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, False, types.SimpleNamespace(sigma_prior=-2.0)).load_reference_state(g["state"])
+    x = torch.randn(256, 3, 32, 32, generator=torch.Generator().manual_seed(12))
+    with q.mc_context(1, 21, 3):
+        p = m(x.cuda())
+    want = orc.F32ConvOracle(g["state"]).resnet(x.numpy(), 21, 3)
+    np.testing.assert_allclose(p.cpu().numpy(), want, rtol=1e-5, atol=3.6e-7)
 
 
 @pytest.mark.parametrize("name,model", [("mlp_bbb_qat.npz", "linear_bbb"), ("lenet_bbb_qat.npz", "conv_lenet_bbb"),
