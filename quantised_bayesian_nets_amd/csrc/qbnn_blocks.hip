@@ -1040,6 +1040,7 @@ using Blk_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;
 using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;
 using ALD_96  = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;      // dense aliased-tile ring kernel
 using ALD_192 = ConvCfg<192, 192, 3, 1, 4, 1, 16, 2, 3, true, 36, 16>;
+using ALD_192_G8 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, true, 36, 16>;  // 8 images per item: ensemble members at B <= 256 (16 items per member leave half the CUs idle)
 using PP_48   = ConvCfg<48, 48, 3, 1, 16, 1, 1, 2, 2>;          // per wave group of the ping-pong kernel
 
 template <int NBLK>
@@ -1167,7 +1168,7 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi(const qbnn_chain_call* calls, int32_t 
       }
       if (Cc == 48 && H == 16) rc = launch_block_chain_ws_multi<Blk_48, 1, false, QBNN_FUSED_CALLS>(arr, n, st);
       else if (Cc == 96 && H == 8) rc = launch_block_chain_ald_multi<ALD_96, 8>(arr, n, st);
-      else if (Cc == 192 && H == 4) rc = launch_block_chain_ald_multi<ALD_192, 8>(arr, n, st);
+      else if (Cc == 192 && H == 4) rc = ((B + 15) / 16) * n <= 128 ? launch_block_chain_ald_multi<ALD_192_G8, 8>(arr, n, st) : launch_block_chain_ald_multi<ALD_192, 8>(arr, n, st);
       else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
     }
     if (rc) return rc;

@@ -98,37 +98,42 @@ QBNN_EXPORT int qbnn_im2col3x3_c3(const uint8_t* x, int32_t B, int32_t H, int32_
 // QuantStub + clamp_activation + the layer-0 patch gather for SEVERAL input quantisations at once (ensemble members each own
 // a `quant.scale / zero_point`): fp32 NCHW [B][3][H][W] -> centred int8 patches out[m][B][H*W][32], member m = blockIdx.y.
 struct QuantIm2colArgs { float inv[16]; int z[16]; };
+// One thread = one output pixel for ALL `n` members of the launch: the 27 fp32 taps are loaded once and quantised n times (a thread
+// per (member, pixel) re-read them per member: 74 us for 16 members at B = 256, now bound by the 8 MB of patches written per member).
 __global__ __launch_bounds__(256) void quantize_im2col3x3_c3_kernel(const float* __restrict__ x, int B, int H, int W, const QuantIm2colArgs q,
-                                                                     int a_hi, int8_t* __restrict__ out, int64_t out_stride) {
-  const int m = blockIdx.y;
-  const float inv = q.inv[m];
-  const int z = q.z[m];
+                                                                     int n, int a_hi, int8_t* __restrict__ out, int64_t out_stride) {
   const int64_t npix = (int64_t)B * H * W, plane = (int64_t)H * W;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
     const int ow = (int)(p % W);
     const int oh = (int)((p / W) % H);
     const int64_t b = p / plane;
-    uint32_t wds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int8_t* by = reinterpret_cast<int8_t*>(wds);
+    float f[27];
+    uint32_t inside = 0u;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int ih = oh + kh - 1, iw = ow + kw - 1;
         const bool in = ih >= 0 && ih < H && iw >= 0 && iw < W;
+        inside |= (in ? 1u : 0u) << (kh * 3 + kw);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          int v = 0;
-          if (in) {
-            const float f = x[((b * 3 + c) * H + ih) * W + iw];
-            v = min(min(max(z + rne_sat(f * inv), 0), 255), a_hi) - z;          // quantize_input_kernel, then im2col3x3_c3_kernel's centring
-          }
-          by[(kh * 3 + kw) * 3 + c] = (int8_t)v;
-        }
+        for (int c = 0; c < 3; ++c) f[(kh * 3 + kw) * 3 + c] = in ? x[((b * 3 + c) * H + ih) * W + iw] : 0.f;
       }
-    v4i* o = reinterpret_cast<v4i*>(out + (int64_t)m * out_stride + p * 32);
-    o[0] = v4i{(int)wds[0], (int)wds[1], (int)wds[2], (int)wds[3]};
-    o[1] = v4i{(int)wds[4], (int)wds[5], (int)wds[6], (int)wds[7]};
+#pragma unroll 1
+    for (int m = 0; m < n; ++m) {
+      const float inv = q.inv[m];
+      const int z = q.z[m];
+      uint32_t wds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        int v = 0;
+        if ((inside >> (t / 3)) & 1u) v = min(min(max(z + rne_sat(f[t] * inv), 0), 255), a_hi) - z;     // quantize_input_kernel, then im2col3x3_c3_kernel's centring
+        wds[t >> 2] |= ((uint32_t)v & 0xffu) << (8 * (t & 3));
+      }
+      v4i* o = reinterpret_cast<v4i*>(out + (int64_t)m * out_stride + p * 32);
+      o[0] = v4i{(int)wds[0], (int)wds[1], (int)wds[2], (int)wds[3]};
+      o[1] = v4i{(int)wds[4], (int)wds[5], (int)wds[6], (int)wds[7]};
+    }
   }
 }
 
@@ -145,7 +150,7 @@ QBNN_EXPORT int qbnn_quantize_im2col3x3_c3_multi(const float* x, int32_t B, int3
       if (zero_points[c0 + i] < 0 || zero_points[c0 + i] > 127) return fail(QBNN_E_INVALID, "qbnn_quantize_im2col3x3_c3_multi: zero points must be in [0,127]%s");
       q.inv[i] = 1.0f / scales[c0 + i]; q.z[i] = zero_points[c0 + i];
     }
-    hipLaunchKernelGGL(quantize_im2col3x3_c3_kernel, dim3(blocks, k), dim3(256), 0, (hipStream_t)stream, x, B, H, W, q, a_hi,
+    hipLaunchKernelGGL(quantize_im2col3x3_c3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, B, H, W, q, k, a_hi,
                        out + (int64_t)c0 * out_stride, out_stride);
     if (int rc = check_launch("qbnn_quantize_im2col3x3_c3_multi")) return rc;
   }
