@@ -32,13 +32,14 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_I8_PEAK_TOPS = 5000.0   # int8 dense = 2x bf16 (2.5 PF)
-VALU_PEAK_LANE_OPS = 1024 * 16 * 2.4e9   # 256 CUs x 4 SIMDs, 16 lanes per cycle, 2.4 GHz
-VALU_OPS_PLAIN, VALU_OPS_RES = 6, 13     # epilogue lane-ops per output element in the shipped ISA (profiles/r02_isa_epilogue.txt)
-# the same instructions weighted by their measured issue cost (tools/valu_rate_bench.hip, profiles/r02_valu_rates.txt: SIMD cycles per
-# wave64 instruction at 2.4 GHz with every SIMD busy -- add / sub / mul / fma / and / or ~3.1, min / max / med3 / cvt* / rndne / bfe ~6.8):
-#   requant            = sub 3.05 + cvt_f32_i32 6.84 + fmac 3.34 + mul 3.27 + min 6.78 + cvt_pk_u8 6.85          = 30.1
-#   requant + add/relu = ... + med3 6.86 + rndne 6.78 + fma 3.34 + cvt_sdwa 6.72 + fma 3.34 + add 3.11 + mul 3.27 = 63.5
-VALU_CYC_PLAIN, VALU_CYC_RES = 30.1, 63.5
+VALU_OPS_PLAIN, VALU_OPS_RES = 6, 13     # epilogue vector instructions per output element in the shipped ISA (profiles/r02_isa_epilogue.txt)
+# What a SIMD issues of that instruction mix, measured IN the kernel clock domain (tools/issue_bench.hip, profiles/r03_issue_bench.txt:
+# s_memtime cycles, every SIMD busy, the epilogue's own dependent sequence sub / cvt / fma / mul / min / cvt_pk): 4.09 cycles per
+# wave-instruction with 2 resident waves per SIMD, 2.92 with 4, 2.21 with 8 (one wave alone: 8.2; "fast" add / mul / fma / sub 3.0 /
+# 1.9 / 1.4-1.6, "slow" min / med3 / cvt* / perm 4.5-5.3 / 3.4-3.5 / 1.7-2.3).  Round 2's table (3.1 / 6.8 "at 2.4 GHz") assumed a
+# clock the chip does not hold and its cost-weighted roof is dropped; the roof below is issue-slot time at the kernel's occupancy.
+VALU_ISSUE_CYCLES = {2: 4.09, 4: 2.92, 8: 2.21}
+SHADER_CLOCK_HZ = 2.4e9                   # GRBM_GUI_ACTIVE / 8 / duration of the conv kernels: 2.37-2.43 GHz (profiles/r02_pmc_util.json)
 MFMA_I8_SUSTAINED_TOPS = 3260.0   # measured: pure v_mfma_i32_32x32x32_i8 loop on random int8 operands, whole chip
                                   # (tools/mfma_sustained.hip, profiles/r01_mfma_sustained.txt; 4700 on all-zero operands)
 
@@ -374,29 +375,28 @@ def main():
         # (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs) -- but ONLY while that file was measured on this very kernel source
         # and workload shape; otherwise null (never a stale number)
         traffic, traffic_note = None, "no PMC summary for this kernel source: run tools/profile_round.sh"
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("kernel_source_sha16") != kernel_source_sha16():
-                traffic_note = "profiles/r02_pmc_traffic.json was measured on an older kernel source"
+                traffic_note = "profiles/r03_pmc_traffic.json was measured on an older kernel source"
             elif (tj.get("samples"), tj.get("batch"), tj.get("workload")) != (S_local, x_host.shape[0], a.workload):
-                traffic_note = "profiles/r02_pmc_traffic.json was measured on another workload shape"
+                traffic_note = "profiles/r03_pmc_traffic.json was measured on another workload shape"
             else:
-                traffic, traffic_note = tj["by_bench_key"].get(dom), "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this source)"
-        # vector-ALU roof of the exact-arithmetic epilogue: lane-operations per output element counted in the shipped ISA
-        # (profiles/r02_isa_epilogue.txt): 6 for a plain requantisation (sub, cvt, fma, mul, min, cvt_pk), 13 for stem.3 +
-        # quantized::add + ReLU; 1024 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s
+                traffic, traffic_note = tj["by_bench_key"].get(dom), "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this source)"
+        # vector-ALU roof of the exact-arithmetic epilogue: instructions per output element counted in the shipped ISA (6 for a plain
+        # requantisation: sub, cvt, fma, mul, min, cvt_pk; 13 for stem.3 + quantized::add + ReLU) x the measured issue cost of that
+        # mix at the kernel's occupancy (the 16-wave layer-1 kernel: 4 waves per SIMD; the 8-wave block kernels: 2)
         outs = [S_local * Bx * (H // st) ** 2 * co for (H, ci, co, ks, st, nw) in m["convs"]]
         n_res = sum(1 for i, c in enumerate(m["convs"]) if m.get("res_convs") and i in m["res_convs"])
         lane_ops = sum(o * (VALU_OPS_RES if (m.get("res_convs") and i in m["res_convs"]) else VALU_OPS_PLAIN) for i, o in enumerate(outs))
-        simd_cycles = sum(o / 64.0 * (VALU_CYC_RES if (m.get("res_convs") and i in m["res_convs"]) else VALU_CYC_PLAIN) for i, o in enumerate(outs))
-        floor_w = simd_cycles / 1024 / 2.4e9
-        valu = {"epilogue_lane_ops_per_launch": lane_ops, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "floor_ms": round(lane_ops / VALU_PEAK_LANE_OPS * 1e3, 4),
-                "frac": round(lane_ops / VALU_PEAK_LANE_OPS / avg_s, 4), "ops_per_output": {"requant": VALU_OPS_PLAIN, "requant+add+relu": VALU_OPS_RES},
-                "residual_convs": n_res,
-                "cost_weighted": {"simd_cycles_per_output": {"requant": VALU_CYC_PLAIN, "requant+add+relu": VALU_CYC_RES},
-                                  "floor_ms": round(floor_w * 1e3, 4), "frac": round(floor_w / avg_s, 4),
-                                  "note": "instructions weighted by their measured issue cost (profiles/r02_valu_rates.txt)"}}
+        wps = 4 if (dom.startswith("stem") and os.environ.get("QBNN_W16", "1") != "0") else 2
+        floor_s = lane_ops / 64.0 * VALU_ISSUE_CYCLES[wps] / 1024 / SHADER_CLOCK_HZ
+        valu = {"epilogue_wave_instructions_per_launch": lane_ops / 64.0, "waves_per_simd": wps, "issue_cycles_per_instruction_measured": VALU_ISSUE_CYCLES[wps],
+                "floor_ms": round(floor_s * 1e3, 4), "frac": round(floor_s / avg_s, 4),
+                "ops_per_output": {"requant": VALU_OPS_PLAIN, "requant+add+relu": VALU_OPS_RES}, "residual_convs": n_res,
+                "note": "issue-slot time of the epilogue's vector instructions alone (profiles/r03_issue_bench.txt); the MFMAs of the same "
+                        "launch take further issue slots (a 9-MFMA + 72-VALU tile: 351 cycles at 4 waves per SIMD against 210 for the VALU alone)"}
         common = {"kernel": dom, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": d["n"],
                   "share_of_step_time": round(d["ms"] / (dt * 1e3), 3), "convs_in_launch": len(m["convs"]),
                   "algorithmic_bytes_per_launch": abytes, "algorithmic_ops_per_launch": ops, "traffic": traffic, "traffic_source": traffic_note,

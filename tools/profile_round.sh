@@ -1,9 +1,10 @@
 #!/bin/bash
 # Round-end evidence: bench line, rocprofv3 kernel stats of the same command, HBM-traffic and utilisation counters.
-# usage (GPU box, repo root): tools/profile_round.sh [round tag, default r02]
-R=${1:-r02}
+# usage (GPU box, repo root): tools/profile_round.sh [round tag, default r03]
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
+rm -rf gpurun_out/final/stats gpurun_out/final/pmc_*
 timeout 300 python3 bench.py --steps 20 --warmup 5 > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > gpurun_out/final/bench_prof.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/final/pmc_f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
@@ -12,14 +13,14 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYC
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/final/pmc_b -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 QBNN_ROUND=$R python3 - <<'PY'
 import csv, glob, collections, json, shutil, hashlib, os
-R = os.environ.get('QBNN_ROUND', 'r02')
+R = os.environ.get('QBNN_ROUND', 'r03')
 def src_sha():
     import sys
     sys.path.insert(0, os.getcwd())
     from quantised_bayesian_nets_amd import build as _b
     return _b.kernel_source_sha16()
 def bench_key(k):
-    rules = [("block_chain_ws_kernel<ConvCfg<24, 24", "stem + block_chain_i8 x2 32x32 c24"), ("block_chain_pp_kernel<ConvCfg<48", "block_chain_i8 x1 16x16 c48"),
+    rules = [("stem_chain_w16_kernel", "stem + block_chain_i8 x2 32x32 c24"), ("block_chain_ws_kernel<ConvCfg<24, 24", "stem + block_chain_i8 x2 32x32 c24"), ("block_chain_pp_kernel<ConvCfg<48", "block_chain_i8 x1 16x16 c48"),
              ("block_chain_ws_kernel<ConvCfg<48", "block_chain_i8 x1 16x16 c48"), ("block_chain_ald_kernel<ConvCfg<96", "block_chain_i8 x1 8x8 c96"),
              ("block_chain_ald_kernel<ConvCfg<192", "block_chain_i8 x1 4x4 c192"), ("block_down_ws_kernel<ConvCfg<24", "block_down_i8 32x32 24->48"),
              ("block_down_ws_kernel<ConvCfg<48", "block_down_i8 16x16 48->96"), ("block_down_ws_kernel<ConvCfg<96", "block_down_i8 8x8 96->192"),
