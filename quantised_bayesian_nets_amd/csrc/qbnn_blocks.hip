@@ -112,14 +112,14 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
 //               the same kernel -- its output never goes to HBM (that tensor is the largest of the network: 629 MB per
 //               100-sample step written and read back).  The item's input is then its image's patch block (32 KiB,
 //               shared by all samples, L2-resident), staged in a dense LDS tile; conv0's epilogue writes the X tile.
-template <class C, int NBLK, bool LDSW, bool STEM = false, int NM = 1>
-__global__ __launch_bounds__(BLK_THREADS) void block_chain_ws_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all) {
+template <class C, int NBLK, bool LDSW, bool STEM = false, int NM = 1, int NTHR_ = BLK_THREADS>
+__global__ __launch_bounds__(NTHR_) void block_chain_ws_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all) {
   const ChainArgs<NBLK>& a = all.m[NM == 1 ? 0 : blockIdx.y];
   using C0 = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;      // layer 0 on the patch tensor: K = 27 -> 32, one k-step
   static_assert(!STEM || (LDSW && C::CIN == 24 && C::HIN == 32 && C::G == 1), "the fused stem feeds the 32x32x24 chain");
   static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr int NTHR = BLK_THREADS, NWV = BLK_WAVES;
+  constexpr int NTHR = NTHR_, NWV = NTHR_ / 64;
   constexpr int TILES = C::G * C::TILE_BYTES + C::TILE_SLACK;
   constexpr int WB = LDSW ? WConv<C>::BYTES : 0;
   uint8_t* xt = smem;
@@ -814,18 +814,18 @@ template <class C, int NBLK, bool LDSW = true, bool STEM = false> constexpr int 
          (STEM ? 32 * 32 * 32 + 1024 + 24 * 4 : 0);
 }
 
-template <class C, int NBLK, bool LDSW = true, bool STEM = false>
+template <class C, int NBLK, bool LDSW = true, bool STEM = false, int NTHR = BLK_THREADS>
 static int launch_block_chain_ws(const ChainArgs<NBLK>& a, hipStream_t st) {
   constexpr int LDS = chain_ws_lds<C, NBLK, LDSW, STEM>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, LDSW, STEM, 1>, attr, LDS)) return rc_attr;
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, LDSW, STEM, 1, NTHR>, attr, LDS)) return rc_attr;
   const int groups = (a.B + C::G - 1) / C::G;
   const int n_items = a.n_samples * groups;
   const int grid = n_items < 256 ? n_items : 256;
   ArgsArr<ChainArgs<NBLK>, 1> one;
   one.m[0] = a;
-  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, LDSW, STEM, 1>), dim3(grid), dim3(BLK_THREADS), LDS, st, one);
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, LDSW, STEM, 1, NTHR>), dim3(grid), dim3(NTHR), LDS, st, one);
   return check_launch("qbnn_block_chain_i8_mc");
 }
 
@@ -1042,6 +1042,8 @@ using ALD_96  = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;      // dens
 using ALD_192 = ConvCfg<192, 192, 3, 1, 4, 1, 16, 2, 3, true, 36, 16>;
 using ALD_192_G8 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, true, 36, 16>;  // 8 images per item: ensemble members at B <= 256 (16 items per member leave half the CUs idle)
 using PP_48   = ConvCfg<48, 48, 3, 1, 16, 1, 1, 2, 2>;          // per wave group of the ping-pong kernel
+// (A 16-wave instantiation of the 48-channel chain -- ConvCfg<48, 48, 3, 1, 16, 1, 2, 1, 2> at 1024 threads, 88 VGPRs, one pass per
+//  wave and conv -- takes the same 0.389 ms as the 8-wave kernels (0.391): occupancy alone does not buy the overlap, round 3.)
 
 template <int NBLK>
 static int build_chain_args(ChainArgs<NBLK>& a, const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t a_hi,
