@@ -390,6 +390,20 @@ int qbnn_softmax_f32_mc(const float* x, int64_t x_sample_stride, int32_t B, int3
 
 #define QBNN_OBSERVER_BLOCKS 512        /* workspace: n_samples * QBNN_OBSERVER_BLOCKS * 2 floats */
 
+/* The whole float Bayes-by-backprop MLP of reference models_bbb.LinearNetwork (:32-78, eval branch of bbb/linear.py:42-50) for all S
+ * samples in two launches: layers[0..2] = Linear + ReLU, layers[3] = `mu` head, layers[4] = `log_var` head (one output each);
+ *   mu_out[s][b], var_out[s][b] = exp(log_var).  Weights are drawn as qbnn_sample_weights_f32 draws them (same Philox stream per
+ * layer_id; honours qbnn_set_device_noise_source) into w_workspace[n_samples][qbnn_mlp_bbb_f32_workspace_floats(layers)].
+ * Widths <= 128.  Equals qbnn_sample_weights_f32 + qbnn_linear_f32_mc per layer up to the fp32 summation order of the dot products. */
+typedef struct qbnn_mlp_layer {
+  const float* mu; const float* sigma; const float* bias;      /* [out][in], [out][in] (softplus(rho)), [out] or NULL */
+  int32_t out_features, in_features;
+  uint32_t layer_id;
+} qbnn_mlp_layer;
+int qbnn_mlp_bbb_f32_mc(const float* x, int32_t B, const qbnn_mlp_layer* layers, uint64_t seed, uint32_t sample_begin, int32_t n_samples,
+                        float* w_workspace, float* mu_out, float* var_out, void* stream);
+int64_t qbnn_mlp_bbb_f32_workspace_floats(const qbnn_mlp_layer* layers);
+
 /* W[s][i] = mu[s][i] + eps(s,i) * sigma[s][i] with per-sample operands (strides in elements, 0 = shared); mu NULL gives
  * the noise term alone (conv_qat.py:45 / linear_qat.py:33: mul_noise.mul(noise, std)).  Noise stream as qbnn_sample_weights_f32. */
 int qbnn_sample_weights_f32_strided(const float* mu, int64_t mu_sample_stride, const float* sigma, int64_t sigma_sample_stride,

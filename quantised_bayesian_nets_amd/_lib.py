@@ -53,6 +53,11 @@ class BlockDesc(C.Structure):
                 ("s_o", C.c_float), ("z_o", C.c_int32)]
 
 
+class MlpLayer(C.Structure):
+    _fields_ = [("mu", C.c_void_p), ("sigma", C.c_void_p), ("bias", C.c_void_p), ("out_features", C.c_int32), ("in_features", C.c_int32),
+                ("layer_id", C.c_uint32)]
+
+
 class DownDesc(C.Structure):
     _fields_ = [("blk", BlockDesc), ("w_s", C.c_void_p), ("w_s_sample_stride", C.c_int64), ("bias_s", C.c_void_p),
                 ("s_ws", C.c_float), ("z_ws", C.c_int32), ("s_s", C.c_float), ("z_s", C.c_int32)]
@@ -83,7 +88,7 @@ class HeadCall(C.Structure):
                 ("probs", C.c_void_p), ("n_samples", C.c_int32), ("desc", C.POINTER(HeadDesc))]
 
 
-EXPORTS = ["qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_set_device_noise_source", "qbnn_conv2d_i8_mc", "qbnn_conv2d_i8_post_mc", "qbnn_conv_pool_drop_i8_mc", "qbnn_linear_i8_mc",
+EXPORTS = ["qbnn_mlp_bbb_f32_mc", "qbnn_mlp_bbb_f32_workspace_floats", "qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_set_device_noise_source", "qbnn_conv2d_i8_mc", "qbnn_conv2d_i8_post_mc", "qbnn_conv_pool_drop_i8_mc", "qbnn_linear_i8_mc",
            "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_conv2d_i8_generic_mc", "qbnn_conv2d_i8_generic_scalar_mc", "qbnn_dropout_q_mc", "qbnn_maxpool2_q_mc",
            "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
@@ -151,6 +156,9 @@ def lib():
         L.qbnn_observe_f32_mc.argtypes = [vp, i64, i64, i32, vp, f, i32, i32, vp, vp, vp, vp]
         L.qbnn_fake_quant_f32_mc.argtypes = [vp, i64, vp, i64, i64, vp, vp, i32, i32, i32, i32, vp]
         L.qbnn_sample_weights_f32_strided.argtypes = [vp, i64, vp, i64, i64, u64, u32, u32, i32, vp, vp, vp]
+        L.qbnn_mlp_bbb_f32_mc.argtypes = [vp, i32, C.POINTER(MlpLayer), u64, u32, i32, vp, vp, vp, vp]
+        L.qbnn_mlp_bbb_f32_workspace_floats.argtypes = [C.POINTER(MlpLayer)]
+        L.qbnn_mlp_bbb_f32_workspace_floats.restype = i64
         L.qbnn_sample_weights_f32_ohwi.argtypes = [vp, i64, vp, i64, i32, i32, i32, u64, u32, u32, i32, vp, vp, vp]
         _LIB = L
     return _LIB

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <string.h>
 
 #include "../../include/qbnn.h"
 #include "qbnn_common.h"
@@ -572,4 +573,183 @@ QBNN_EXPORT int qbnn_conv2d_f32_mc(const float* x, int64_t x_ss, const float* w,
                                    int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream) {
   return qbnn_conv2d_f32_fused_mc(x, x_ss, w, w_ss, nullptr, bias, nullptr, nullptr, nullptr, 0, y, y_ss, B, H, W, Cin, Cout, ksize, stride, pad, relu,
                                   n_samples, nullptr, stream);
+}
+
+// =====================================================================================
+// Fused fp32 Bayes-by-backprop MLP (BASELINE config 0: reference models_bbb.LinearNetwork, :32-78, eval branch of
+// bbb/linear.py:42-50): 3 x (Linear + ReLU), heads mu and log_var -> (mu, exp(log_var)).
+// The layer-by-layer path is ~25 launches of a few microseconds for a network of 21.5 k weights -- launches, not arithmetic.
+// Here: ONE launch draws the S sampled weight sets of all five layers (the Philox normal stream of qbnn_sample_weights_f32:
+// ctr = {i >> 2, layer, sample, 0}, W = mu + (eps * sigma), two roundings), ONE launch runs the whole network for a tile of
+// 32 rows of one MC sample: the layer's sampled weights and the activations sit in LDS, thread (row, part) owns every 8th
+// neuron of its row and accumulates  acc = fma(h[k], W[n][k], acc)  for k ascending, then + bias, ReLU -- the reference's
+// x @ W^T + b in fp32.
+// =====================================================================================
+#define QBNN_MLP_LAYERS 5
+#define QBNN_MLP_MAXW 128          // widest layer (inputs or outputs)
+struct MlpArgs {
+  const float* mu[QBNN_MLP_LAYERS]; const float* sigma[QBNN_MLP_LAYERS]; const float* bias[QBNN_MLP_LAYERS];
+  int out[QBNN_MLP_LAYERS], in[QBNN_MLP_LAYERS];
+  uint32_t layer_id[QBNN_MLP_LAYERS];
+  int64_t woff[QBNN_MLP_LAYERS + 1];      // element offset of each layer inside one sample's weight block
+  int goff[QBNN_MLP_LAYERS + 1];          // the same in 4-weight groups (a group never straddles layers)
+  const float* x; int B;
+  float* w; float* mu_out; float* var_out;
+};
+
+__global__ __launch_bounds__(256) void mlp_sample_weights_kernel(const MlpArgs a, uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_begin,
+                                                                 const uint32_t* __restrict__ nd) {
+  if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= a.goff[QBNN_MLP_LAYERS]) return;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < QBNN_MLP_LAYERS; ++i) l = g >= a.goff[i] ? i : l;
+  const int s = blockIdx.y;
+  const int64_t gl = g - a.goff[l], n = (int64_t)a.out[l] * a.in[l];
+  float e[4];
+  qbnn::normal4(qbnn::philox4x32_10((uint32_t)gl, a.layer_id[l], sample_begin + s, 0u, seed_lo, seed_hi), e);
+  float* w = a.w + (int64_t)s * a.woff[QBNN_MLP_LAYERS] + a.woff[l];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = gl * 4 + j;
+    if (i < n) { const float t = e[j] * a.sigma[l][i]; w[i] = a.mu[l][i] + t; }
+  }
+}
+
+// J = neurons per thread (every 8th): ceil(widest hidden layer / 8).  The layer's weight rows are zero-padded to 8 J rows in LDS, so
+// the inner loop carries no per-neuron condition (a lane-dependent `n < N` test per accumulator made it 16 divergent branches per step).
+// LDS is sized by the launch for the network at hand (wmax = widest padded input row, HP = activation pitch): the 4 x 100 MLP takes
+// 68 KB, so two workgroups share a CU -- with the compile-time maximum (87 KB) the 320 workgroups of config 0 ran in two rounds.
+template <int J>
+__global__ __launch_bounds__(256) void mlp_forward_kernel(const MlpArgs a, const int wmax, const int HP) {
+  constexpr int ROWS = 32;
+  extern __shared__ __attribute__((aligned(16))) float mlp_smem[];
+  float* wl = mlp_smem;                                     // [8 J][KP] weights of the current layer
+  float* hbuf0 = wl + 8 * J * wmax;                         // two activation buffers [ROWS][HP]
+  float* hbuf[2] = {hbuf0, hbuf0 + ROWS * HP};
+  const int tid = threadIdx.x, r = tid >> 3, o = tid & 7;
+  const int s = blockIdx.y, row0 = blockIdx.x * ROWS;
+  const float* ws = a.w + (int64_t)s * a.woff[QBNN_MLP_LAYERS];
+  // input rows (zero beyond B and beyond in_dim, up to the next multiple of 4)
+  const int K0 = a.in[0], K0P = (K0 + 3) & ~3;
+  for (int i = tid; i < ROWS * K0P; i += 256) {
+    const int rr = i / K0P, k = i - rr * K0P;
+    hbuf[0][rr * HP + k] = (row0 + rr < a.B && k < K0) ? a.x[(int64_t)(row0 + rr) * K0 + k] : 0.f;
+  }
+  int cur = 0;
+#pragma unroll 1
+  for (int l = 0; l < 3; ++l) {
+    const int K = a.in[l], KP = (K + 3) & ~3, N = a.out[l];
+    __syncthreads();                                        // previous layer done with wl; its outputs complete
+    const float* wsl = ws + a.woff[l];
+    if ((K & 3) == 0) {              // whole float4s (layer offsets and rows are 16-byte aligned): several loads in flight per thread
+      const int Q = KP / 4;
+#pragma unroll 4
+      for (int i = tid; i < 8 * J * Q; i += 256) {
+        const int n = i / Q, q4 = i - n * Q;
+        const float4 v = n < N ? *reinterpret_cast<const float4*>(wsl + (int64_t)n * K + 4 * q4) : float4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<float4*>(wl + n * KP + 4 * q4) = v;
+      }
+    } else {
+#pragma unroll 4
+      for (int i = tid; i < 8 * J * KP; i += 256) {
+        const int n = i / KP, k = i - n * KP;
+        wl[i] = (n < N && k < K) ? wsl[(int64_t)n * K + k] : 0.f;
+      }
+    }
+    __syncthreads();
+    const float* h = hbuf[cur] + r * HP;
+    float* ho = hbuf[cur ^ 1] + r * HP;
+    const float* wr = wl + o * KP;
+    float acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = 0.f;
+    for (int k4 = 0; k4 < KP; k4 += 4) {
+      const float4 hv = *reinterpret_cast<const float4*>(h + k4);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const float4 wv = *reinterpret_cast<const float4*>(wr + 8 * j * KP + k4);
+        float v = acc[j];
+        v = __builtin_fmaf(hv.x, wv.x, v); v = __builtin_fmaf(hv.y, wv.y, v); v = __builtin_fmaf(hv.z, wv.z, v); v = __builtin_fmaf(hv.w, wv.w, v);
+        acc[j] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int n = o + 8 * j;
+      if (n < N) {
+        float v = acc[j];
+        if (a.bias[l]) v = v + a.bias[l][n];
+        ho[n] = fmaxf(v, 0.f);
+      }
+    }
+    if (o == 0) for (int n = N; n < ((N + 3) & ~3); ++n) ho[n] = 0.f;       // zero the k padding of the next layer
+    cur ^= 1;
+  }
+  __syncthreads();
+  // heads: mu (layer 3) and log_var (layer 4), one output each; var = exp(log_var) (models_bbb.py:78)
+  if (o < 2 && row0 + r < a.B) {
+    const int l = 3 + o, K = a.in[l];
+    const float* wv = ws + a.woff[l];
+    const float* h = hbuf[cur] + r * HP;
+    float v = 0.f;
+    for (int k = 0; k < K; ++k) v = __builtin_fmaf(h[k], wv[k], v);
+    if (a.bias[l]) v = v + a.bias[l][0];
+    if (o == 0) a.mu_out[(int64_t)s * a.B + row0 + r] = v;
+    else a.var_out[(int64_t)s * a.B + row0 + r] = expf(v);
+  }
+}
+
+QBNN_EXPORT int qbnn_mlp_bbb_f32_mc(const float* x, int32_t B, const qbnn_mlp_layer* layers, uint64_t seed, uint32_t sample_begin,
+                                    int32_t n_samples, float* w_workspace, float* mu_out, float* var_out, void* stream) {
+  if (!x || !layers || !w_workspace || !mu_out || !var_out || B <= 0 || n_samples <= 0)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_mlp_bbb_f32_mc: bad argument");
+  MlpArgs a;
+  memset(&a, 0, sizeof(a));
+  int64_t off = 0;
+  int goff = 0;
+  for (int l = 0; l < QBNN_MLP_LAYERS; ++l) {
+    const qbnn_mlp_layer& q = layers[l];
+    if (!q.mu || !q.sigma || q.out_features <= 0 || q.in_features <= 0 || q.in_features > QBNN_MLP_MAXW || q.out_features > QBNN_MLP_MAXW)
+      return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_mlp_bbb_f32_mc: layer widths must be in [1, 128]");
+    if (l >= 3 && q.out_features != 1) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_mlp_bbb_f32_mc: layers 3 and 4 are the mu / log_var heads (one output each)");
+    if (l > 0 && l < 3 && q.in_features != layers[l - 1].out_features) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_mlp_bbb_f32_mc: layer widths do not chain");
+    if (l >= 3 && q.in_features != layers[2].out_features) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_mlp_bbb_f32_mc: the heads read the last hidden layer");
+    a.mu[l] = q.mu; a.sigma[l] = q.sigma; a.bias[l] = q.bias; a.out[l] = q.out_features; a.in[l] = q.in_features; a.layer_id[l] = q.layer_id;
+    a.woff[l] = off; a.goff[l] = goff;
+    const int64_t n = (int64_t)q.out_features * q.in_features;
+    off += (n + 3) / 4 * 4;                 // every layer starts on a group boundary
+    goff += (int)((n + 3) / 4);
+  }
+  a.woff[QBNN_MLP_LAYERS] = off; a.goff[QBNN_MLP_LAYERS] = goff;
+  a.x = x; a.B = B; a.w = w_workspace; a.mu_out = mu_out; a.var_out = var_out;
+  hipLaunchKernelGGL(mlp_sample_weights_kernel, dim3((goff + 255) / 256, n_samples), dim3(256), 0, (hipStream_t)stream, a, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), sample_begin, qbnn_noise_dev());
+  int widest = 0, wmax = 0;
+  for (int l = 0; l < 3; ++l) {
+    widest = layers[l].out_features > widest ? layers[l].out_features : widest;
+    const int kp = (layers[l].in_features + 3) & ~3;
+    wmax = kp > wmax ? kp : wmax;
+  }
+  const int hp = ((widest > wmax ? widest : wmax) + 3) / 4 * 4 + 4;
+  const dim3 grid((B + 31) / 32, n_samples);
+  if (widest <= 104) {
+    const int lds = (8 * 13 * wmax + 2 * 32 * hp) * 4;
+    static std::atomic<uint64_t> attr13{0};
+    if (int rc = qbnn_ensure_dyn_lds((const void*)mlp_forward_kernel<13>, &attr13, lds)) return rc;
+    hipLaunchKernelGGL(mlp_forward_kernel<13>, grid, dim3(256), lds, (hipStream_t)stream, a, wmax, hp);
+  } else {
+    const int lds = (8 * 16 * wmax + 2 * 32 * hp) * 4;
+    static std::atomic<uint64_t> attr16{0};
+    if (int rc = qbnn_ensure_dyn_lds((const void*)mlp_forward_kernel<16>, &attr16, lds)) return rc;
+    hipLaunchKernelGGL(mlp_forward_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, a, wmax, hp);
+  }
+  return qbnn_check_launch_msg("qbnn_mlp_bbb_f32_mc");
+}
+
+QBNN_EXPORT int64_t qbnn_mlp_bbb_f32_workspace_floats(const qbnn_mlp_layer* layers) {
+  int64_t off = 0;
+  for (int l = 0; l < QBNN_MLP_LAYERS; ++l) off += ((int64_t)layers[l].out_features * layers[l].in_features + 3) / 4 * 4;
+  return off;
 }

@@ -104,8 +104,36 @@ class LinearNetwork(nn.Module):
         return sum(m.get_kl_divergence() for m in self.stochastic_layers())
 
     def forward_mc(self, x):
-        """All S samples -> (mu [S,B,1], var [S,B,1])."""
-        h = x.to(torch.float32).reshape(1, x.shape[0], -1)
+        """All S samples -> (mu [S,B,1], var [S,B,1]).  One sampler launch + one network launch (qbnn_mlp_bbb_f32_mc: weights and
+        activations in LDS); QBNN_MLP_LAYERWISE=1 runs a sampler and a GEMM launch per layer instead (same values up to the fp32
+        summation order of the dot products)."""
+        import os
+        if x.device.type != "cuda":
+            raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
+        x2 = x.to(torch.float32).reshape(x.shape[0], -1).contiguous()
+        widths_ok = all(m.in_features <= 128 and m.out_features <= 128 for m in self.stochastic_layers())
+        if widths_ok and os.environ.get("QBNN_MLP_LAYERWISE", "0") != "1":
+            import ctypes as C
+            S, B, dev = _MC.samples, x2.shape[0], x2.device
+            arr = (_lib.MlpLayer * 5)()
+            keep = []
+            for d, m in zip(arr, self.stochastic_layers()):
+                if m._sigma is None or m._sigma.device != dev:
+                    m._sigma = F.softplus(m.std.detach().cpu().float()).to(dev).contiguous()      # one-time, same op as the reference
+                    m._mu_dev = m.weight.detach().to(dev).contiguous()
+                    m._bias_dev = None if m.bias is None else m.bias.detach().to(dev).contiguous()
+                d.mu, d.sigma, d.bias = m._mu_dev.data_ptr(), m._sigma.data_ptr(), (None if m._bias_dev is None else m._bias_dev.data_ptr())
+                d.out_features, d.in_features, d.layer_id = m.out_features, m.in_features, m.layer_id
+                keep.append(m)
+            L = _lib.lib()
+            ws = torch.empty((S, int(L.qbnn_mlp_bbb_f32_workspace_floats(arr))), dtype=torch.float32, device=dev)
+            mu = torch.empty((S, B, 1), dtype=torch.float32, device=dev)
+            var = torch.empty((S, B, 1), dtype=torch.float32, device=dev)
+            with timed("mlp_bbb_f32"):
+                _lib.check(L.qbnn_mlp_bbb_f32_mc(_lib.ptr(x2), B, arr, _MC.seed, _MC.sample_begin, S, _lib.ptr(ws), _lib.ptr(mu), _lib.ptr(var),
+                                                 _lib.current_stream()))
+            return mu, var
+        h = x2.reshape(1, x2.shape[0], -1)
         for m in (self.layers[0], self.layers[2], self.layers[4]):
             h = m(h, act=1)
         return self.mu(h, act=0), self.log_var(h, act=2)

@@ -1713,3 +1713,38 @@ def test_graphed_predictor_queued_replays_keep_their_own_seeds(golden_lenet_mc):
             want = m.forward_mc(x).double().mean(0)
         np.testing.assert_allclose(o.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-9)
     assert torch.equal(outs[0], outs[3]) and not torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_fused_float_mlp_equals_layerwise_and_reference(golden_mlp_f32, monkeypatch):
+    """BASELINE config 0 on the fused path (qbnn_mlp_bbb_f32_mc: one sampler launch + one launch for the whole 4 x 100 network)
+    against the layer-by-layer kernels -- same Philox weights, so only the fp32 summation order of the dot products may differ
+    (a few 1e-6 absolute on O(1) outputs) -- and against the reference's recorded (mu, var) and MC reduction (1e-5, as test_float_bbb_mlp_matches_reference);
+    ragged batches and another input width too."""
+    import quantised_bayesian_nets_amd as q
+    g = golden_mlp_f32
+    m = q.ModelFactory.get_model("linear_bbb", [g["in_dim"]], 1, False, types.SimpleNamespace(sigma_prior=-2.0)).load_reference_state(g["state"])
+    x = torch.from_numpy(g["x"]).cuda()
+    S = g["mu"].shape[0]
+    with q.mc_context(S, g["seed"], 0):
+        mu, var = m.forward_mc(x)
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(var.cpu().numpy(), g["var"], rtol=1e-5, atol=1e-8)
+    monkeypatch.setenv("QBNN_MLP_LAYERWISE", "1")
+    with q.mc_context(S, g["seed"], 0):
+        mu_l, var_l = m.forward_mc(x)
+    monkeypatch.delenv("QBNN_MLP_LAYERWISE")
+    np.testing.assert_allclose(mu.cpu().numpy(), mu_l.cpu().numpy(), rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(var.cpu().numpy(), var_l.cpu().numpy(), rtol=2e-5, atol=1e-8)
+    gen = torch.Generator().manual_seed(5)
+    for B, in_dim in ((1, g["in_dim"]), (33, g["in_dim"]), (1000, g["in_dim"])):
+        xb = torch.randn(B, in_dim, generator=gen).cuda()
+        with q.mc_context(3, 77, 4):
+            a, b = m.forward_mc(xb)
+        monkeypatch.setenv("QBNN_MLP_LAYERWISE", "1")
+        with q.mc_context(3, 77, 4):
+            c, d = m.forward_mc(xb)
+        monkeypatch.delenv("QBNN_MLP_LAYERWISE")
+        assert a.shape == (3, B, 1)
+        np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(b.cpu().numpy(), d.cpu().numpy(), rtol=2e-5, atol=1e-8)

@@ -14,15 +14,16 @@
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v4acc __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define OP16(ASM) _Pragma("unroll") for (int i = 0; i < 16; ++i) asm volatile(ASM : "+v"(v[i]) : "v"(a), "v"(b));
 
-enum Mode { FMA, ADD, MUL, SUBU, MIN, MED3, CVT_I2F, CVT_PK, PERM, PKFMA, PKMUL, EPI6, EPI5, MFMA, MIX_WAVE, MIX_ROLE, MIX_WAVE_INTER, NMODES };
+enum Mode { FMA, ADD, MUL, SUBU, MIN, MED3, CVT_I2F, CVT_PK, PERM, PKFMA, PKMUL, EPI6, EPI5, MFMA, MIX_WAVE, MIX_ROLE, MIX_WAVE_INTER, MFMA16, MIX_WAVE16, MIX_WAVE_INDEP, NMODES };
 static const char* mode_name[NMODES] = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_sub_u32", "v_min_f32", "v_med3_f32", "v_cvt_f32_i32",
   "v_cvt_pk_u8_f32", "v_perm_b32", "v_pk_fma_f32", "v_pk_mul_f32", "epilogue x16 (6 ops: sub cvt fma mul min cvt_pk)",
   "epilogue x16 (5 ops: sub cvt fma min cvt_pk)", "v_mfma_i32_32x32x32_i8", "same wave: 9 MFMA then 72 VALU", "partner waves: 0-3 MFMA / 4-7 epilogue",
-  "same wave: 9 x (MFMA + 8 VALU)"};
+  "same wave: 9 x (MFMA + 8 VALU)", "v_mfma_i32_16x16x64_i8", "same wave: 18 MFMA 16x16x64 then 72 VALU", "same wave: 9 MFMA (3 accumulators) then 72 VALU"};
 
 // one requantisation of 4 accumulator values into one dword: 6 ops per value (or 5 without the separate multiply)
 template <bool MUL6>
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256 * WPS) void k(unsigned long long* stamps, float
 #pragma unroll
   for (int i = 0; i < 16; ++i) { v[i] = (float)(threadIdx.x + i) * 0.37f; q[i] = (int)threadIdx.x * 3 + i; }
   v4i wa = src[threadIdx.x & 1023], xb = src[(threadIdx.x * 7 + 5) & 1023];
-  v16i acc = {};
+  v16i acc = {}, accb = {}, accc = {};
+  v4acc acc4 = {};
   const int wave = threadIdx.x >> 6;
   const int zwr = (int)threadIdx.x & 31;
   __syncthreads();
@@ -92,6 +94,25 @@ __global__ __launch_bounds__(256 * WPS) void k(unsigned long long* stamps, float
 #pragma unroll
       for (int g = 0; g < 3; ++g) requant4<true>(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3], zwr, a, b, a, 127.0f);
     }
+    if (MODE == MFMA16) {
+      acc4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb, acc4, 0, 0, 0);
+    }
+    if (MODE == MIX_WAVE16) {        // the same MACs as 9 x 32x32x32 on the 16x16x64 shape, then the epilogue
+#pragma unroll
+      for (int j = 0; j < 18; ++j) acc4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb, acc4, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) requant4<true>(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3], zwr, a, b, a, 127.0f);
+    }
+    if (MODE == MIX_WAVE_INDEP) {    // 9 MFMAs into three independent accumulators
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa, xb, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa, xb, accb, 0, 0, 0);
+        accc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa, xb, accc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) requant4<true>(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3], zwr, a, b, a, 127.0f);
+    }
     if (MODE == MIX_WAVE_INTER) {    // the same work, source order MFMA, 8 VALU, MFMA, 8 VALU ...
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
@@ -114,7 +135,7 @@ __global__ __launch_bounds__(256 * WPS) void k(unsigned long long* stamps, float
   asm volatile("s_nop 0" ::: "memory");
   float s = 0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s += v[i] + (float)q[i] + (float)acc[i];
+  for (int i = 0; i < 16; ++i) s += v[i] + (float)q[i] + (float)acc[i] + (float)accb[i] + (float)accc[i] + (float)acc4[i & 3];
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -184,12 +205,19 @@ int main() {
   std::vector<int> h(4096);
   for (auto& x : h) x = rand() ^ (rand() << 16);
   (void)hipMemcpy(d_src, h.data(), 4096 * 4, hipMemcpyHostToDevice);
+  if (getenv("ISSUE_BENCH_QUICK")) {
+    run<MFMA>(0, 1, 20000); run<MFMA16>(0, 1, 20000); run<MIX_WAVE>(72, 9, 1000); run<MIX_WAVE16>(72, 18, 1000); run<MIX_WAVE_INDEP>(72, 9, 1000);
+    return 0;
+  }
   run<FMA>(16, 0); run<ADD>(16, 0); run<MUL>(16, 0); run<SUBU>(16, 0); run<MIN>(16, 0); run<MED3>(16, 0);
   run<CVT_I2F>(16, 0); run<CVT_PK>(16, 0); run<PERM>(16, 0); run<PKFMA>(8, 0); run<PKMUL>(8, 0);
   run<EPI6>(96, 0, 1000); run<EPI5>(80, 0, 1000);
   run<MFMA>(0, 1, 20000);
   run<MIX_WAVE>(72, 9, 1000);
   run<MIX_WAVE_INTER>(72, 9, 1000);
+  run<MFMA16>(0, 1, 20000);
+  run<MIX_WAVE16>(72, 18, 1000);
+  run<MIX_WAVE_INDEP>(72, 9, 1000);
   run1<MIX_ROLE, 2>(1, 1000, 72, 9);
   run1<MIX_ROLE, 4>(1, 1000, 72, 9);
   return 0;
