@@ -647,7 +647,6 @@ template <int HO, int PIXB, int TILE_BYTES>
 struct EpiTile {
   static constexpr int VALU_PER_MFMA = 10;
   uint8_t* dst; QConv p;
-  __device__ __forceinline__ const uint8_t* base() const { return dst; }
   __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, PIXB, TILE_BYTES>(m, 0); }
   __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
   __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
@@ -662,7 +661,6 @@ template <int HO, int PIXB, int TILE_BYTES>
 struct EpiTileResInPlace {
   static constexpr int VALU_PER_MFMA = 22;
   uint8_t* xt; QConv p; QAdd a;
-  __device__ __forceinline__ const uint8_t* base() const { return xt; }
   __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, PIXB, TILE_BYTES>(m, 0); }
   __device__ __forceinline__ uint32_t load(int po, int c0) const {
     return *reinterpret_cast<const uint32_t*>(xt + po + c0);

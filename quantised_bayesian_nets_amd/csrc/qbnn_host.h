@@ -56,11 +56,4 @@ static inline bool qbnn_use_w16() {
   static const bool v = [] { const char* e = getenv("QBNN_W16"); return !(e && e[0] == '0'); }();
   return v;
 }
-// register-stationary single-conv kernels of the wide layers (qbnn_rs.hip), entered through qbnn_conv2d_i8_mc
-int qbnn_launch_rs_conv(const ConvArgs& a, int cin, int hin, int n_samples, bool has_res, hipStream_t st);
-// QBNN_RS=0: the LDS-tiled layer kernel (conv_i8_kernel) for those geometries too (A/B checks)
-static inline bool qbnn_use_rs() {
-  static const bool v = [] { const char* e = getenv("QBNN_RS"); return !(e && e[0] == '0'); }();
-  return v;
-}
 #endif

@@ -468,9 +468,6 @@ QBNN_EXPORT int qbnn_conv2d_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* 
 }
 
 static int dispatch_conv(const ConvArgs& a, const qbnn_conv_desc* d, int n_samples, bool hr, bool post, hipStream_t st) {
-  if (!post && !d->x_is_centered_im2col && d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->Cin == d->Cout && d->Cin == 96 && d->H == 8 &&
-      qbnn_use_rs())
-    return qbnn_launch_rs_conv(a, d->Cin, d->H, n_samples, hr, st);
 #define QBNN_CASE(CFG, cin, cout, ks, sd, hin, im2c)                                                      \
   if (d->Cin == (cin) && d->Cout == (cout) && d->ksize == (ks) && d->stride == (sd) && d->H == (hin) &&   \
       d->pad == ((ks) - 1) / 2 && (d->x_is_centered_im2col != 0) == (im2c))                                \

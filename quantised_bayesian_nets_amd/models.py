@@ -18,7 +18,6 @@ from .quant import UINT_BOUNDS, check_bits
 
 
 GRAPH_FALLBACKS = []          # HIP-graph captures that were refused (the eager launch chain ran instead)
-RS_CHANNELS = (96,)          # channel counts whose 3x3 / stride-1 convs run on the register-stationary kernels
 
 
 class Add(nn.Module):
@@ -106,14 +105,6 @@ def run_identity_chain(blocks, x, stem=None):
     `stem` = (layers.0 module, its sampled weights, im2col patches [B, 1024, 32], input scale): the network's first conv
     runs inside the same kernel (qbnn_stem_chain_i8_mc) and `x` only carries conv0's output qparams / shape."""
     S = _MC.samples
-    if stem is None and x.data.shape[4] in RS_CHANNELS and os.environ.get("QBNN_RS_CHAIN", "0") == "1":
-        # experiment, off by default (measured slower: 0.146 + 0.224 ms against 0.340 ms for the fused ring kernel, DESIGN.md 4.3): wide
-        # identity blocks as one launch per conv on the register-stationary kernels (csrc/qbnn_rs.hip) -- the sample's weights stay in
-        # registers for the whole launch instead of streaming through LDS once per 8 images; stem.0's output goes through L2
-        h = x
-        for blk in blocks:
-            h = blk(h)
-        return h
     if stem is None and (len(blocks) > 2 or (len(blocks) == 2 and x.data.shape[4] >= 96)):
         h = x
         step = 1 if x.data.shape[4] >= 96 else 2

@@ -22,7 +22,7 @@ with q.mc_context(S, 3, 0):
 d = dbg.cpu().numpy().reshape(16, 64)
 n = int((d[0] != 0).sum())
 t0 = d[:, 0].min()
-G = int(os.environ.get("QBNN_W16_G", "2")); RW = 2 * G
+G = 2; RW = 2 * G
 labels = ["top", "barrier"] + sum([["c0 M%d" % i, "c0 E%d" % i] for i in range(RW)], []) + ["barrier"]
 for k in range(2):
     for nm in ("a", "b"):
