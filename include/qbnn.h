@@ -182,6 +182,41 @@ int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x, 
                           int32_t Cin, int32_t a_hi, const qbnn_down_desc* host_desc, uint8_t* y, int64_t y_sample_stride,
                           int32_t n_samples, void* stream);
 
+/* ---- the fused blocks with a quantised channel dropout behind every conv (conv_resnet_mc) ---------------------------------
+ * reference mcdropout/models_mc.py:116-160 (BasicBlock: stem = ConvReLU2d, Dropout, Conv2d, Dropout; shortcut = Conv2d, Dropout;
+ * Add; ReLU) and :162-211 (layers.0 ConvReLU2d, layers.3 Dropout in front of the blocks); dropout.py:15-40 per dropout:
+ *   mask ~ Bernoulli(keep_prob) per (sample, image, channel) -> quantize_per_tensor(mask, s_m, z_m) -> quantized::mul(x, mask_q)
+ *   with output qparams (s_m, z_m) -> clamp_activation -> mul_scalar(1 / (1 - p)): scale becomes s_out, integers unchanged.
+ * The dropouts run in the convs' epilogues from per-work-item mask tables in LDS; the weights are the converted model's fixed
+ * qint8 tensors in the MFMA32 layout (sample stride 0).  Mask stream: slot i = b * C + c of MC sample s draws
+ * philox4x32_10(ctr = {i >> 2, layer_id, sample_begin + s, 1}, key = seed)[i & 3], kept when (u >> 8) * 2^-24 < keep_prob -- the
+ * stream of qbnn_dropout_q_mc / qbnn_conv2d_i8_post_mc; `mask_in` (fp32 [n_samples][B][C], Bernoulli 0 / 1) replaces the draw.
+ * Same bits as the per-layer calls (qbnn_conv2d_i8_post_mc per conv).  z_m in [0, 127]. */
+typedef struct qbnn_drop_desc {
+  float keep_prob;                 /* 1 - p                                                      */
+  float s_m; int32_t z_m;          /* mul_mask.scale / zero_point                                */
+  float s_out;                     /* scale after mul_scalar: s_m * multiplier                   */
+  uint32_t layer_id;               /* Philox tensor id: index of this dropout among the model's  */
+  const float* mask_in;            /* optional injected mask, else NULL                          */
+} qbnn_drop_desc;
+
+/* identity blocks; drops[2 k] sits behind block k's stem.0 (reference stem.3), drops[2 k + 1] behind its second conv (stem.6) */
+int qbnn_block_chain_drop_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x, int32_t z_x, int32_t B, int32_t H,
+                                int32_t C, int32_t a_hi, const qbnn_block_desc* host_blocks, const qbnn_drop_desc* drops,
+                                int32_t n_blocks, uint8_t* y, int64_t y_sample_stride, int32_t n_samples, uint64_t seed,
+                                uint32_t sample_begin, void* stream);
+/* layers.0 + layers.3 (drop0) + the two 32x32x24 identity blocks */
+int qbnn_stem_chain_drop_i8_mc(const int8_t* im2col, int32_t B, const int8_t* w0_packed, int64_t w0_sample_stride, const float* bias0,
+                               float s_x, float s_w0, int32_t z_w0, float s_y0, int32_t z_y0, int32_t a_hi,
+                               const qbnn_drop_desc* drop0, const qbnn_block_desc* host_blocks, const qbnn_drop_desc* drops,
+                               int32_t n_blocks, uint8_t* y, int64_t y_sample_stride, int32_t n_samples, uint64_t seed,
+                               uint32_t sample_begin, void* stream);
+/* down-sampling block; drops[0] behind stem.0 (reference stem.3), drops[1] behind the second conv (stem.6), drops[2] behind the
+ * shortcut conv (shortcut.2) */
+int qbnn_block_down_drop_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x, int32_t z_x, int32_t B, int32_t H,
+                               int32_t Cin, int32_t a_hi, const qbnn_down_desc* host_desc, const qbnn_drop_desc* drops, uint8_t* y,
+                               int64_t y_sample_stride, int32_t n_samples, uint64_t seed, uint32_t sample_begin, void* stream);
+
 /* ---- several independent calls in ONE launch (ensemble members) -------------------------------------------------------
  * reference sgld/models_sgld.py:214-288: `Network` holds args.samples deterministic members, each a converted network of its own
  * (own weights, biases AND quantisation parameters), evaluated one after the other.  Members cannot ride the MC-sample

@@ -39,6 +39,12 @@ class DropoutDesc(C.Structure):
     _fields_ = [("keep_prob", C.c_float), ("s_m", C.c_float), ("z_m", C.c_int32), ("layer_id", C.c_uint32)]
 
 
+class DropDesc(C.Structure):
+    """qbnn_drop_desc: a BernoulliDropout behind a conv of a fused block (conv_resnet_mc)."""
+    _fields_ = [("keep_prob", C.c_float), ("s_m", C.c_float), ("z_m", C.c_int32), ("s_out", C.c_float), ("layer_id", C.c_uint32),
+                ("mask_in", C.c_void_p)]
+
+
 class SamplerLayer(C.Structure):
     _fields_ = [("mu_packed", C.c_void_p), ("sigma_packed", C.c_void_p), ("w_out", C.c_void_p), ("w_sample_stride", C.c_int64),
                 ("cout", C.c_int32), ("k", C.c_int32), ("krow", C.c_int32), ("layout", C.c_int32),
@@ -89,7 +95,7 @@ class HeadCall(C.Structure):
 
 
 EXPORTS = ["qbnn_mlp_bbb_f32_mc", "qbnn_mlp_bbb_f32_workspace_floats", "qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_set_device_noise_source", "qbnn_conv2d_i8_mc", "qbnn_conv2d_i8_post_mc", "qbnn_conv_pool_drop_i8_mc", "qbnn_linear_i8_mc",
-           "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi",
+           "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_drop_i8_mc", "qbnn_stem_chain_drop_i8_mc", "qbnn_block_down_drop_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_conv2d_i8_generic_mc", "qbnn_conv2d_i8_generic_scalar_mc", "qbnn_dropout_q_mc", "qbnn_maxpool2_q_mc",
            "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
            "qbnn_conv2d_f32_mc", "qbnn_conv2d_f32_fused_mc", "qbnn_conv2d_f32_blocks", "qbnn_observe_partials_f32_mc", "qbnn_affine_f32_mc", "qbnn_pool2d_f32_mc", "qbnn_flatten_nchw_f32_mc", "qbnn_softmax_f32_mc", "qbnn_observe_f32_mc", "qbnn_fake_quant_f32_mc", "qbnn_sample_weights_f32_strided", "qbnn_sample_weights_f32_ohwi",
@@ -124,6 +130,10 @@ def lib():
         L.qbnn_block_chain_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(BlockDesc), i32, vp, i64, i32, vp]
         L.qbnn_stem_chain_i8_mc.argtypes = [vp, i32, vp, i64, vp, f, f, i32, f, i32, i32, C.POINTER(BlockDesc), i32, vp, i64, i32, vp]
         L.qbnn_block_down_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(DownDesc), vp, i64, i32, vp]
+        L.qbnn_block_chain_drop_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(BlockDesc), C.POINTER(DropDesc), i32, vp, i64, i32, C.c_uint64, C.c_uint32, vp]
+        L.qbnn_stem_chain_drop_i8_mc.argtypes = [vp, i32, vp, i64, vp, f, f, i32, f, i32, i32, C.POINTER(DropDesc), C.POINTER(BlockDesc), C.POINTER(DropDesc), i32, vp, i64, i32,
+                                                 C.c_uint64, C.c_uint32, vp]
+        L.qbnn_block_down_drop_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(DownDesc), C.POINTER(DropDesc), vp, i64, i32, C.c_uint64, C.c_uint32, vp]
         L.qbnn_block_chain_i8_multi.argtypes = [C.POINTER(ChainCall), i32, i32, i32, i32, i32, i32, i32, vp]
         L.qbnn_block_down_i8_multi.argtypes = [C.POINTER(DownCall), i32, i32, i32, i32, i32, vp]
         L.qbnn_head_i8_multi.argtypes = [C.POINTER(HeadCall), i32, vp]

@@ -45,7 +45,7 @@ using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, 1, 3, false>;
 using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
 
 static int build_down_args(DownArgs& a, const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t a_hi, const qbnn_down_desc* d,
-                           uint8_t* y, int64_t y_ss, int32_t n_samples) {
+                           uint8_t* y, int64_t y_ss, int32_t n_samples, const qbnn_drop_desc* drops = nullptr) {
   memset(&a, 0, sizeof(a));
   a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = B; a.n_samples = n_samples; a.z_in = z_x;
   qbnn_conv_desc c;
@@ -58,8 +58,10 @@ static int build_down_args(DownArgs& a, const uint8_t* x, int64_t x_ss, float s_
   if ((rc = fill_qconv(a.a, d->blk.w_a, d->blk.w_a_sample_stride, d->blk.bias_a, &c))) return rc;
   c.s_x = d->blk.s_a; c.z_x = d->blk.z_a; c.s_w = d->blk.s_wb; c.z_w = d->blk.z_wb; c.s_y = d->blk.s_b; c.z_y = d->blk.z_b; c.relu = 0;
   c.has_bias = d->blk.bias_b != nullptr;
+  if (drops) { c.s_x = drops[0].s_out; c.z_x = drops[0].z_m; }      // the second conv reads the dropped stem.0 output
   if ((rc = fill_qconv(a.b, d->blk.w_b, d->blk.w_b_sample_stride, d->blk.bias_b, &c))) return rc;
   c.s_r = d->s_s; c.z_r = d->z_s; c.s_o = d->blk.s_o; c.z_o = d->blk.z_o;
+  if (drops) { c.s_r = drops[2].s_out; c.z_r = drops[2].z_m; }      // the Add's second operand: the dropped shortcut
   return fill_qadd(a.add, &c);
 }
 
@@ -112,9 +114,16 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
 //               the same kernel -- its output never goes to HBM (that tensor is the largest of the network: 629 MB per
 //               100-sample step written and read back).  The item's input is then its image's patch block (32 KiB,
 //               shared by all samples, L2-resident), staged in a dense LDS tile; conv0's epilogue writes the X tile.
-template <class C, int NBLK, bool LDSW, bool STEM = false, int NM = 1, int NTHR_ = BLK_THREADS>
-__global__ __launch_bounds__(NTHR_) void block_chain_ws_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all) {
+// DROP (conv_resnet_mc: mcdropout/models_mc.py:116-160): a quantised channel dropout behind every conv (dr.d = [layers.3 when STEM],
+//               then per block stem.3, stem.6), applied in the convs' epilogues from per-item mask tables in LDS.
+template <int NBLK, bool STEM, bool DROP> constexpr int chain_ndrop() { return DROP ? 2 * NBLK + (STEM ? 1 : 0) : 0; }
+
+template <class C, int NBLK, bool LDSW, bool STEM = false, int NM = 1, int NTHR_ = BLK_THREADS, bool DROP = false>
+__global__ __launch_bounds__(NTHR_) void block_chain_ws_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all, const DropSet<chain_ndrop<NBLK, STEM, DROP>()> dr) {
   const ChainArgs<NBLK>& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  static_assert(!DROP || NM == 1, "dropout variants are single-call");
+  using MT = MaskTab<C::COUT, false>;
+  constexpr int MTB = MT::bytes(C::G), D0 = STEM ? 1 : 0;
   using C0 = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;      // layer 0 on the patch tensor: K = 27 -> 32, one k-step
   static_assert(!STEM || (LDSW && C::CIN == 24 && C::HIN == 32 && C::G == 1), "the fused stem feeds the 32x32x24 chain");
   static_assert(C::CIN == C::COUT && C::STRIDE == 1 && C::KSZ == 3 && C::HALO == 1, "identity BasicBlock geometry");
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(NTHR_) void block_chain_ws_kernel(const ArgsArr<Cha
   uint8_t* im = reinterpret_cast<uint8_t*>(bias_lds + NBLK * 2 * C::COUT);   // STEM: patch tile [1024][32], stem weights, stem bias
   uint8_t* wl0 = im + C0::TILE_BYTES;
   float* bias0 = reinterpret_cast<float*>(wl0 + WConv<C0>::BYTES);
+  uint8_t* mtab = STEM ? reinterpret_cast<uint8_t*>(bias0 + C0::COUT) : im;  // DROP: mask tables [dropout][G][COUT]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
 
   constexpr int CPR = C::ROWB / 16, CPI = C::HIN * CPR, NCH = C::G * CPI;   // 16-byte chunks of one item
@@ -217,28 +227,49 @@ __global__ __launch_bounds__(NTHR_) void block_chain_ws_kernel(const ArgsArr<Cha
       cur_s = s;
     }
     QBNN_STAMP_AT(0);
+    if constexpr (DROP) {        // this item's masks (every wave has left the previous item's last epilogue: the barrier before the read-out)
+#pragma unroll
+      for (int d = 0; d < chain_ndrop<NBLK, STEM, DROP>(); ++d) fill_mask_tab<C::G, C::COUT, false, NTHR>(mtab + d * MTB, dr.d[d], s, img0, a.B, tid);
+    }
     lds_barrier();
     QBNN_STAMP_AT(1);
     if constexpr (STEM) {        // layers.0 (ConvReLU2d): patch tile -> X tile, centred on its own zero point (= a.z_in)
-      EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, a.stem};
-      conv_core<C0, decltype(epi), NWV>(im, wl0, bias0, a.stem, epi, wave, lane);
+      if constexpr (DROP) {
+        EpiTileDrop<C::HO, C::PIXB, C::TILE_BYTES, C::COUT> epi{xt, a.stem, dr.d[0], {mtab, 0.f}};
+        conv_core<C0, decltype(epi), NWV>(im, wl0, bias0, a.stem, epi, wave, lane);
+      } else {
+        EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, a.stem};
+        conv_core<C0, decltype(epi), NWV>(im, wl0, bias0, a.stem, epi, wave, lane);
+      }
       lds_barrier();
     }
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) {
       const BlockParams& bp = a.blk[k];
-      {
+      auto conv_a = [&](auto& epi) {
+        if constexpr (LDSW) conv_core<C, std::remove_reference_t<decltype(epi)>, NWV>(xt, wl + (2 * k) * WB, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
+        else conv_passes<C, std::remove_reference_t<decltype(epi)>, NWV>(xt, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
+      };
+      auto conv_b = [&](auto& epi) {
+        if constexpr (LDSW) conv_core<C, std::remove_reference_t<decltype(epi)>, NWV>(tt, wl + (2 * k + 1) * WB, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
+        else conv_passes<C, std::remove_reference_t<decltype(epi)>, NWV>(tt, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
+      };
+      if constexpr (DROP) {
+        EpiTileDrop<C::HO, C::PIXB, C::TILE_BYTES, C::COUT> epi{tt, bp.a, dr.d[D0 + 2 * k], {mtab + (D0 + 2 * k) * MTB, 0.f}};
+        conv_a(epi);
+      } else {
         EpiTile<C::HO, C::PIXB, C::TILE_BYTES> epi{tt, bp.a};
-        if constexpr (LDSW) conv_core<C, decltype(epi), NWV>(xt, wl + (2 * k) * WB, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
-        else conv_passes<C, decltype(epi), NWV>(xt, bp.a.w + (int64_t)s * bp.a.w_ss, bias_lds + (2 * k) * C::COUT, bp.a, epi, wave, lane);
+        conv_a(epi);
       }
       QBNN_STAMP_AT(2);
       lds_barrier();
       QBNN_STAMP_AT(3);
-      {
+      if constexpr (DROP) {
+        EpiTileResInPlaceDrop<C::HO, C::PIXB, C::TILE_BYTES, C::COUT> epi{xt, bp.b, bp.add, dr.d[D0 + 2 * k + 1], {mtab + (D0 + 2 * k + 1) * MTB, 0.f}};
+        conv_b(epi);
+      } else {
         EpiTileResInPlace<C::HO, C::PIXB, C::TILE_BYTES> epi{xt, bp.b, bp.add};
-        if constexpr (LDSW) conv_core<C, decltype(epi), NWV>(tt, wl + (2 * k + 1) * WB, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
-        else conv_passes<C, decltype(epi), NWV>(tt, bp.b.w + (int64_t)s * bp.b.w_ss, bias_lds + (2 * k + 1) * C::COUT, bp.b, epi, wave, lane);
+        conv_b(epi);
       }
       QBNN_STAMP_AT(4);
       lds_barrier();
@@ -598,6 +629,44 @@ struct EpiDenseTileResGlobal {
   }
 };
 
+// the same two epilogues with a quantised channel dropout behind the conv (conv_resnet_mc)
+template <int PIXB, int COUT, int IMG_PX>
+struct EpiDenseTileDrop {
+  uint8_t* dst; QConv p; PostArgs q; MaskTab<COUT, false> mt;
+  mutable int csum;
+  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
+    const float4 m4 = mt.get(po / (IMG_PX * PIXB), c0);
+    const uint32_t pk = pack_low_bytes(drop_val(v0, p, q, m4.x) + QBNN_MAGIC, drop_val(v1, p, q, m4.y) + QBNN_MAGIC,
+                                       drop_val(v2, p, q, m4.z) + QBNN_MAGIC, drop_val(v3, p, q, m4.w) + QBNN_MAGIC);
+    *reinterpret_cast<uint32_t*>(dst + po + c0) = pk;
+    csum = __builtin_amdgcn_sdot4((int)pk, 0x01010101, csum, false);
+  }
+};
+template <int PIXB, int CCH, int IMG_PX>
+struct EpiDenseTileResGlobalDrop {
+  uint8_t* xt; const uint8_t* res; int n_valid_px; QConv p; QAdd a; PostArgs q; MaskTab<CCH, false> mt;
+  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
+  __device__ __forceinline__ uint32_t load_px(int m, int c0) const {
+    return m < n_valid_px ? *reinterpret_cast<const uint32_t*>(res + (int64_t)m * CCH + c0) : 0u;
+  }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
+    const float4 m4 = mt.get(po / (IMG_PX * PIXB), c0);
+    const float r[4] = {drop_val(v0, p, q, m4.x), drop_val(v1, p, q, m4.y), drop_val(v2, p, q, m4.z), drop_val(v3, p, q, m4.w)};
+    const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float da = __builtin_fmaf(q.s_a, __builtin_rintf(r[i]), q.dl_a);
+      const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
+      t[i] = (da + db) * a.inv_s_o;
+    }
+    *reinterpret_cast<uint32_t*>(xt + po + c0) = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
+  }
+};
+
 // NWV = 8: two waves per SIMD, 256 VGPRs each (MB x NB = 2 x 3 tiles per wave).  Measured alternatives, all slower:
 // NWV = 4 (one wave per SIMD, 4 x 3 tiles in the 512-register file: -25 %, the epilogues read accumulators out of AGPRs
 // and a lone wave hides no latency); NWV = 12 (4 x 1 tiles, 168 VGPRs: -12 %) and NWV = 16 (1 x 3 tiles, 128 VGPRs:
@@ -610,10 +679,12 @@ struct EpiDenseTileResGlobal {
 // item (8 / 16 images); a group that drains its accumulators while the other multiplies halves the images per pass of the
 // block's weights (162 / 663 KiB), and the L2 -> LDS weight stream (3.5 TB/s chip-wide here, 4.7 TB/s there) is what the M
 // phase waits for.  More images per weight pass needs more accumulator registers, not more LDS.
-template <class C, int NWV, int NM = 1>
+template <class C, int NWV, int NM = 1, bool DROP = false>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 4, NWV / 4)))
-void block_chain_ald_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
+void block_chain_ald_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<DROP ? 2 : 0> dr) {
   const ChainArgs<1>& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  static_assert(!DROP || NM == 1, "dropout variants are single-call");
+  constexpr int MTB = MaskTab<C::COUT, false>::bytes(C::G);
   static_assert(C::CIN == C::COUT && C::CIN % 32 == 0, "wide identity BasicBlock");
   using DT = DenseTile<C>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -625,6 +696,7 @@ void block_chain_ald_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
   float* bias_lds = reinterpret_cast<float*>(rbase + 2 * C::SLAB_BYTES);     // [2][COUT]
   int* sx = reinterpret_cast<int*>(bias_lds + 2 * C::COUT);                  // channel sums of the X tile  [G * HO * HO]
   int* stab = sx + C::G * C::HO * C::HO;                                     // ... of the T tile
+  uint8_t* mtab = reinterpret_cast<uint8_t*>(stab + C::G * C::HO * C::HO);   // DROP: mask tables of stem.3 and stem.6, fp32 [G][COUT] each
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
   const BlockParams& bp = a.blk[0];
 
@@ -694,6 +766,10 @@ void block_chain_ald_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
     const int s = item / groups, img0 = (item - s * groups) * C::G;
     const bool more = it + 1 < count;
     const int next = more ? walk.item(it + 1) : item;
+    if constexpr (DROP) {        // this item's masks: published by the slab barriers of the M phase that follows, first read in its epilogue
+      fill_mask_tab<C::G, C::COUT, false, NTHR>(mtab, dr.d[0], s, img0, a.B, tid);
+      fill_mask_tab<C::G, C::COUT, false, NTHR>(mtab + MTB, dr.d[1], s, img0, a.B, tid);
+    }
     // ---- stem.0: M over the X tile, then T over it
     conv_ring_mfma_dense<C, NWV>(xt, rbase, rcur, wbase(bp.a, item), A, wave, lane,
                             [&](uint8_t* dst) { dma_slab<C, NWV>(dst, wbase(bp.b, item), 0, wave, lane); });
@@ -703,20 +779,33 @@ void block_chain_ald_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
     {
       // stem.0 epilogue: window sums from the X table; the T table collects the channel sums of what is written
       window_sum_from_table<C>(sx, A, wave, lane);
-      EpiDenseTile<C::PIXB> epi{xt, bp.a, 0};
-      auto flush = [&](int mb) {
-        const int v = half_sum(epi.csum);
-        epi.csum = 0;
-        if (lane < 32) __hip_atomic_fetch_add(&stab[((wave / C::NBLKS) * C::MB + mb) * 32 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      auto run = [&](auto& epi) {
+        auto flush = [&](int mb) {
+          const int v = half_sum(epi.csum);
+          epi.csum = 0;
+          if (lane < 32) __hip_atomic_fetch_add(&stab[((wave / C::NBLKS) * C::MB + mb) * 32 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        conv_epi_phase_with<C, std::remove_reference_t<decltype(epi)>>(bias_lds, bp.a, epi, A, wave, lane, [&](int, int, int, int, int) { return 0u; },
+                                                                       [&](int mb) { if (mb > 0) flush(mb - 1); });
+        flush(C::MB - 1);
       };
-      conv_epi_phase_with<C, decltype(epi)>(bias_lds, bp.a, epi, A, wave, lane, [&](int, int, int, int, int) { return 0u; },
-                                            [&](int mb) { if (mb > 0) flush(mb - 1); });
-      flush(C::MB - 1);
+      if constexpr (DROP) {
+        EpiDenseTileDrop<C::PIXB, C::COUT, IMG_PX> epi{xt, bp.a, dr.d[0], {mtab, 0.f}, 0};
+        run(epi);
+      } else {
+        EpiDenseTile<C::PIXB> epi{xt, bp.a, 0};
+        run(epi);
+      }
     }
     QBNN_STAMP_AT(2);
     // ---- stem.3: M over T; residual and next input are requested during the last slab
     const int valid_px = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX;
-    EpiDenseTileResGlobal<C::PIXB, C::COUT> epi_b{xt, a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_PX * C::COUT, valid_px, bp.b, bp.add};
+    const uint8_t* resp = a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_PX * C::COUT;
+    auto make_epi_b = [&]() {
+      if constexpr (DROP) return EpiDenseTileResGlobalDrop<C::PIXB, C::COUT, IMG_PX>{xt, resp, valid_px, bp.b, bp.add, dr.d[1], {mtab + MTB, 0.f}};
+      else return EpiDenseTileResGlobal<C::PIXB, C::COUT>{xt, resp, valid_px, bp.b, bp.add};
+    };
+    auto epi_b = make_epi_b();
     uint32_t resq[2][C::NB][4];
     auto load_res = [&](int mb) {
       const int mblk = wave / C::NBLKS, nblk = wave - mblk * C::NBLKS;
@@ -785,8 +874,23 @@ static int launch_block_chain_ald(const ChainArgs<1>& a, hipStream_t st) {
   const int grid = n_items < 256 ? n_items : 256;
   ArgsArr<ChainArgs<1>, 1> one;
   one.m[0] = a;
-  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, 1>), dim3(grid), dim3(64 * NWV), LDS, st, one);
+  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, 1>), dim3(grid), dim3(64 * NWV), LDS, st, one, DropSet<0>{});
   return check_launch("qbnn_block_chain_i8_mc");
+}
+
+template <class C, int NWV>
+static int launch_block_chain_ald_drop(const ChainArgs<1>& a, const DropSet<2>& dr, hipStream_t st) {
+  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4 + 2 * MaskTab<C::COUT, false>::bytes(C::G);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV, 1, true>, attr, LDS)) return rc_attr;
+  const int groups = (a.B + C::G - 1) / C::G;
+  const int n_items = a.n_samples * groups;
+  const int grid = n_items < 256 ? n_items : 256;
+  ArgsArr<ChainArgs<1>, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, 1, true>), dim3(grid), dim3(64 * NWV), LDS, st, one, dr);
+  return check_launch("qbnn_block_chain_drop_i8_mc");
 }
 
 // grid of a fused multi-call launch: every call gets the same number of workgroups (<= its item count), 256 in total
@@ -804,14 +908,14 @@ static int launch_block_chain_ald_multi(const ChainArgs<1>* arr, int n, hipStrea
   memset(&all, 0, sizeof(all));                   // unused blocks: n_samples = 0 -> their workgroups (none launched) would exit at once
   int items = 0;
   for (int i = 0; i < n; ++i) { all.m[i] = arr[i]; const int it = arr[i].n_samples * ((arr[i].B + C::G - 1) / C::G); items = it > items ? it : items; }
-  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, QBNN_FUSED_CALLS>), dim3(fused_grid_x(items, n), n), dim3(64 * NWV), LDS, st, all);
+  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, QBNN_FUSED_CALLS>), dim3(fused_grid_x(items, n), n), dim3(64 * NWV), LDS, st, all, DropSet<0>{});
   return check_launch("qbnn_block_chain_i8_multi");
 }
 
 
-template <class C, int NBLK, bool LDSW = true, bool STEM = false> constexpr int chain_ws_lds() {
+template <class C, int NBLK, bool LDSW = true, bool STEM = false, bool DROP = false> constexpr int chain_ws_lds() {
   return 2 * (C::G * C::TILE_BYTES + C::TILE_SLACK) + (LDSW ? 2 * NBLK * WConv<C>::BYTES : 0) + NBLK * 2 * C::COUT * 4 +
-         (STEM ? 32 * 32 * 32 + 1024 + 24 * 4 : 0);
+         (STEM ? 32 * 32 * 32 + 1024 + 24 * 4 : 0) + chain_ndrop<NBLK, STEM, DROP>() * MaskTab<C::COUT, false>::bytes(C::G);
 }
 
 template <class C, int NBLK, bool LDSW = true, bool STEM = false, int NTHR = BLK_THREADS>
@@ -825,8 +929,23 @@ static int launch_block_chain_ws(const ChainArgs<NBLK>& a, hipStream_t st) {
   const int grid = n_items < 256 ? n_items : 256;
   ArgsArr<ChainArgs<NBLK>, 1> one;
   one.m[0] = a;
-  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, LDSW, STEM, 1, NTHR>), dim3(grid), dim3(NTHR), LDS, st, one);
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, LDSW, STEM, 1, NTHR>), dim3(grid), dim3(NTHR), LDS, st, one, DropSet<0>{});
   return check_launch("qbnn_block_chain_i8_mc");
+}
+
+template <class C, int NBLK, bool STEM>
+static int launch_block_chain_ws_drop(const ChainArgs<NBLK>& a, const DropSet<chain_ndrop<NBLK, STEM, true>()>& dr, hipStream_t st) {
+  constexpr int LDS = chain_ws_lds<C, NBLK, true, STEM, true>();
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, true, STEM, 1, BLK_THREADS, true>, attr, LDS)) return rc_attr;
+  const int groups = (a.B + C::G - 1) / C::G;
+  const int n_items = a.n_samples * groups;
+  const int grid = n_items < 256 ? n_items : 256;
+  ArgsArr<ChainArgs<NBLK>, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, true, STEM, 1, BLK_THREADS, true>), dim3(grid), dim3(BLK_THREADS), LDS, st, one, dr);
+  return check_launch("qbnn_block_chain_drop_i8_mc");
 }
 
 template <class C, int NBLK, bool STEM, int NM>
@@ -840,7 +959,7 @@ static int launch_block_chain_ws_multi(const ChainArgs<NBLK>* arr, int n, hipStr
   memset(&all, 0, sizeof(all));
   int items = 0;
   for (int i = 0; i < n; ++i) { all.m[i] = arr[i]; const int it = arr[i].n_samples * ((arr[i].B + C::G - 1) / C::G); items = it > items ? it : items; }
-  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, true, STEM, NM>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, all);
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, true, STEM, NM>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, all, DropSet<0>{});
   return check_launch("qbnn_block_chain_i8_multi");
 }
 
@@ -849,9 +968,14 @@ template <class CB> struct DownSC {
   static constexpr int BYTES = (CB::M * PITCH + 15) / 16 * 16;
 };
 
-template <class CA, class CS, class CB, bool LDSW, int NM = 1>
-__global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const ArgsArr<DownArgs, NM> all) {
+// DROP (conv_resnet_mc): dr.d = stem.3 (behind conv_a), stem.6 (behind conv_b; the Add's first operand), shortcut.2 (behind conv_s;
+// the Add's second operand).  MBITS: bit tables where LDS is short (96 -> 192).
+template <class CA, class CS, class CB, bool LDSW, int NM = 1, bool DROP = false, bool MBITS = false>
+__global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const ArgsArr<DownArgs, NM> all, const DropSet<DROP ? 3 : 0> dr) {
   const DownArgs& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  static_assert(!DROP || NM == 1, "dropout variants are single-call");
+  using MT = MaskTab<CB::COUT, MBITS>;
+  constexpr int MTB = MT::bytes(CB::G);
   static_assert(CA::M == CS::M && CA::M == CB::M && CA::G == CS::G && CA::G == CB::G, "one work item, three convs");
   static_assert(CA::COUT == CB::CIN && CA::COUT == CB::COUT && CS::COUT == CB::COUT && CA::HO == CB::HIN, "block geometry");
   static_assert(CA::TILE_BYTES == CS::TILE_BYTES && CA::CIN == CS::CIN && CA::HIN == CS::HIN, "shared input tile");
@@ -870,6 +994,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const ArgsAr
   uint8_t* wl_a = wl_s + (LDSW ? WConv<CS>::BYTES : 0);
   uint8_t* wl_b = wl_a + (LDSW ? WConv<CA>::BYTES : 0);
   float* bias_lds = reinterpret_cast<float*>(wl_b + (LDSW ? WConv<CB>::BYTES : 0));       // [3][COUT]: s, a, b
+  uint8_t* mtab = reinterpret_cast<uint8_t*>(bias_lds + 3 * COUT);                        // DROP: three mask tables
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
 
   constexpr int CPR = CA::ROWB / 16, CPI = CA::HIN * CPR, NCH = CA::G * CPI;
@@ -943,25 +1068,45 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const ArgsAr
       cur_s = s;
     }
     QBNN_STAMP_AT(0);
+    if constexpr (DROP) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) fill_mask_tab<CB::G, COUT, MBITS, BLK_THREADS>(mtab + d * MTB, dr.d[d], s, img0, a.B, tid);
+    }
     lds_barrier();       // X complete; the previous item's SC has been read out by every thread
     QBNN_STAMP_AT(1);
-    {
-      EpiDense<COUT, false, SCP> epi{sc, a.s, a.add};
-      if constexpr (LDSW) conv_core<CS, decltype(epi), BLK_WAVES>(xt, wl_s, bias_lds, a.s, epi, wave, lane);
-      else conv_passes<CS, decltype(epi), BLK_WAVES>(xt, a.s.w + (int64_t)s * a.s.w_ss, bias_lds, a.s, epi, wave, lane);
-    }
-    {
-      EpiTile<CB::HIN, CB::PIXB, CB::TILE_BYTES> epi{tt, a.a};
-      if constexpr (LDSW) conv_core<CA, decltype(epi), BLK_WAVES>(xt, wl_a, bias_lds + COUT, a.a, epi, wave, lane);
-      else conv_passes<CA, decltype(epi), BLK_WAVES>(xt, a.a.w + (int64_t)s * a.a.w_ss, bias_lds + COUT, a.a, epi, wave, lane);
+    auto conv_s = [&](auto& epi) {
+      if constexpr (LDSW) conv_core<CS, std::remove_reference_t<decltype(epi)>, BLK_WAVES>(xt, wl_s, bias_lds, a.s, epi, wave, lane);
+      else conv_passes<CS, std::remove_reference_t<decltype(epi)>, BLK_WAVES>(xt, a.s.w + (int64_t)s * a.s.w_ss, bias_lds, a.s, epi, wave, lane);
+    };
+    auto conv_a = [&](auto& epi) {
+      if constexpr (LDSW) conv_core<CA, std::remove_reference_t<decltype(epi)>, BLK_WAVES>(xt, wl_a, bias_lds + COUT, a.a, epi, wave, lane);
+      else conv_passes<CA, std::remove_reference_t<decltype(epi)>, BLK_WAVES>(xt, a.a.w + (int64_t)s * a.a.w_ss, bias_lds + COUT, a.a, epi, wave, lane);
+    };
+    auto conv_b = [&](auto& epi) {
+      if constexpr (LDSW) conv_core<CB, std::remove_reference_t<decltype(epi)>, BLK_WAVES>(tt, wl_b, bias_lds + 2 * COUT, a.b, epi, wave, lane);
+      else conv_passes<CB, std::remove_reference_t<decltype(epi)>, BLK_WAVES>(tt, a.b.w + (int64_t)s * a.b.w_ss, bias_lds + 2 * COUT, a.b, epi, wave, lane);
+    };
+    constexpr int IMG_PIX = CB::HO * CB::HO;
+    if constexpr (DROP) {
+      EpiDenseDrop<COUT, IMG_PIX, false, SCP, MBITS> epi_s{sc, a.s, a.add, dr.d[2], {mtab + 2 * MTB, dr.d[2].mq1}};
+      conv_s(epi_s);
+      EpiTileDrop<CB::HIN, CB::PIXB, CB::TILE_BYTES, COUT, MBITS> epi_a{tt, a.a, dr.d[0], {mtab, dr.d[0].mq1}};
+      conv_a(epi_a);
+    } else {
+      EpiDense<COUT, false, SCP> epi_s{sc, a.s, a.add};
+      conv_s(epi_s);
+      EpiTile<CB::HIN, CB::PIXB, CB::TILE_BYTES> epi_a{tt, a.a};
+      conv_a(epi_a);
     }
     QBNN_STAMP_AT(2);
     lds_barrier();       // T and SC complete
     QBNN_STAMP_AT(3);
-    {
-      EpiDense<COUT, true, SCP> epi{sc, a.b, a.add};
-      if constexpr (LDSW) conv_core<CB, decltype(epi), BLK_WAVES>(tt, wl_b, bias_lds + 2 * COUT, a.b, epi, wave, lane);
-      else conv_passes<CB, decltype(epi), BLK_WAVES>(tt, a.b.w + (int64_t)s * a.b.w_ss, bias_lds + 2 * COUT, a.b, epi, wave, lane);
+    if constexpr (DROP) {
+      EpiDenseDrop<COUT, IMG_PIX, true, SCP, MBITS> epi_b{sc, a.b, a.add, dr.d[1], {mtab + MTB, dr.d[1].mq1}};
+      conv_b(epi_b);
+    } else {
+      EpiDense<COUT, true, SCP> epi_b{sc, a.b, a.add};
+      conv_b(epi_b);
     }
     QBNN_STAMP_AT(4);
     lds_barrier();
@@ -1016,8 +1161,24 @@ static int launch_block_down_ws(const DownArgs& a, hipStream_t st) {
   const int grid = n_items < 256 ? n_items : 256;
   ArgsArr<DownArgs, 1> one;
   one.m[0] = a;
-  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW, 1>), dim3(grid), dim3(BLK_THREADS), LDS, st, one);
+  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW, 1>), dim3(grid), dim3(BLK_THREADS), LDS, st, one, DropSet<0>{});
   return check_launch("qbnn_block_down_i8_mc");
+}
+
+template <class CA, class CS, class CB, bool LDSW, bool MBITS>
+static int launch_block_down_ws_drop(const DownArgs& a, const DropSet<3>& dr, hipStream_t st) {
+  constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + DownSC<CB>::BYTES +
+                      (LDSW ? WConv<CS>::BYTES + WConv<CA>::BYTES + WConv<CB>::BYTES : 0) + 3 * CB::COUT * 4 + 3 * MaskTab<CB::COUT, MBITS>::bytes(CB::G);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_down_ws_kernel<CA, CS, CB, LDSW, 1, true, MBITS>, attr, LDS)) return rc_attr;
+  const int groups = (a.B + CA::G - 1) / CA::G;
+  const int n_items = a.n_samples * groups;
+  const int grid = n_items < 256 ? n_items : 256;
+  ArgsArr<DownArgs, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW, 1, true, MBITS>), dim3(grid), dim3(BLK_THREADS), LDS, st, one, dr);
+  return check_launch("qbnn_block_down_drop_i8_mc");
 }
 
 template <class CA, class CS, class CB, bool LDSW>
@@ -1031,7 +1192,7 @@ static int launch_block_down_ws_multi(const DownArgs* arr, int n, hipStream_t st
   memset(&all, 0, sizeof(all));
   int items = 0;
   for (int i = 0; i < n; ++i) { all.m[i] = arr[i]; const int it = arr[i].n_samples * ((arr[i].B + CA::G - 1) / CA::G); items = it > items ? it : items; }
-  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW, QBNN_FUSED_CALLS>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, all);
+  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW, QBNN_FUSED_CALLS>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, all, DropSet<0>{});
   return check_launch("qbnn_block_down_i8_multi");
 }
 
@@ -1045,9 +1206,31 @@ using PP_48   = ConvCfg<48, 48, 3, 1, 16, 1, 1, 2, 2>;          // per wave grou
 // (A 16-wave instantiation of the 48-channel chain -- ConvCfg<48, 48, 3, 1, 16, 1, 2, 1, 2> at 1024 threads, 88 VGPRs, one pass per
 //  wave and conv -- takes the same 0.389 ms as the 8-wave kernels (0.391): occupancy alone does not buy the overlap, round 3.)
 
+// PostArgs of one dropout behind a conv whose output scale is s_conv (qbnn_conv2d_i8_post_mc's arithmetic; s_a / dl_a: the dropped
+// tensor as the first operand of the block's Add)
+static int fill_drop(PostArgs& o, const qbnn_drop_desc& q, float s_conv, int a_hi, uint64_t seed, uint32_t sample_begin) {
+  if (q.z_m < 0 || q.z_m > 127 || !(q.s_m > 0.f) || !(q.s_out > 0.f)) return fail(QBNN_E_INVALID, "qbnn dropout: mask zero point must be in [0,127], scales positive%s");
+  memset(&o, 0, sizeof(o));
+  const int hi = a_hi < 255 ? a_hi : 255;
+  o.keep = q.keep_prob; o.inv_sm = 1.0f / q.s_m; o.z_m = q.z_m;
+  o.dmult = (float)((double)s_conv * (double)q.s_m / (double)q.s_m);       // ATen qmul: self_scale * other_scale / out_scale
+  o.dlo = (float)(-q.z_m); o.dhi = (float)(hi - q.z_m);
+  o.seed_lo = (uint32_t)seed; o.seed_hi = (uint32_t)(seed >> 32); o.layer_id = q.layer_id; o.sample_begin = sample_begin;
+  o.mask_in = q.mask_in; o.nd = g_noise_dev;
+  o.s_a = q.s_out;
+  o.dl_a = fmaf(q.s_out, (float)q.z_m, (float)(-q.z_m) * q.s_out);
+  float t = nearbyintf(1.0f * o.inv_sm);                                   // a kept element: quantize_per_tensor(1.0, s_m, z_m) - z_m
+  t = t > 2147483520.f ? 2147483520.f : t;
+  int m1 = q.z_m + (int)t;
+  m1 = m1 < 0 ? 0 : (m1 > 255 ? 255 : m1);
+  o.mq1 = (float)(m1 - q.z_m);
+  return QBNN_OK;
+}
+
 template <int NBLK>
 static int build_chain_args(ChainArgs<NBLK>& a, const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t a_hi,
-                            const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples, const int8_t* stem_x, const QConv* stem) {
+                            const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples, const int8_t* stem_x, const QConv* stem,
+                            const qbnn_drop_desc* drops = nullptr) {
   memset(&a, 0, sizeof(a));
   if (stem) { a.stem_x = stem_x; a.stem = *stem; }
   a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = B; a.n_samples = n_samples; a.z_in = z_x;
@@ -1064,6 +1247,7 @@ static int build_chain_args(ChainArgs<NBLK>& a, const uint8_t* x, int64_t x_ss, 
     int rc = fill_qconv(a.blk[k].a, b.w_a, b.w_a_sample_stride, b.bias_a, &d);
     if (rc) return rc;
     d.s_x = b.s_a; d.z_x = b.z_a; d.s_w = b.s_wb; d.z_w = b.z_wb; d.s_y = b.s_b; d.z_y = b.z_b; d.relu = 0; d.has_bias = b.bias_b != nullptr;
+    if (drops) { d.s_x = drops[2 * k].s_out; d.z_x = drops[2 * k].z_m; }      // the second conv reads the dropped stem.0 output
     if ((rc = fill_qconv(a.blk[k].b, b.w_b, b.w_b_sample_stride, b.bias_b, &d))) return rc;
     d.s_r = s_in; d.z_r = z_in; d.s_o = b.s_o; d.z_o = b.z_o;
     if ((rc = fill_qadd(a.blk[k].add, &d))) return rc;
@@ -1137,6 +1321,86 @@ QBNN_EXPORT int qbnn_stem_chain_i8_mc(const int8_t* im2col, int32_t B, const int
   if (n_blocks == 1) return block_chain_dispatch<1>(nullptr, 0, s_y0, z_y0, B, 32, 24, a_hi, host_blocks, y, y_ss, n_samples, st, im2col, &stem);
   if (n_blocks == 2) return block_chain_dispatch<2>(nullptr, 0, s_y0, z_y0, B, 32, 24, a_hi, host_blocks, y, y_ss, n_samples, st, im2col, &stem);
   return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: 1 or 2 blocks per launch%s");
+}
+
+// ---- fused blocks with dropout (conv_resnet_mc) ------------------------------------------------------------------------------
+template <int NBLK, bool STEM>
+static int chain_drop_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc, int32_t a_hi,
+                               const qbnn_block_desc* blk, const qbnn_drop_desc* drop0, const qbnn_drop_desc* drops, uint8_t* y, int64_t y_ss,
+                               int32_t n_samples, uint64_t seed, uint32_t sample_begin, hipStream_t st, const int8_t* stem_x, const QConv* stem,
+                               float s_y0) {
+  ChainArgs<NBLK> a;
+  if (int rc = build_chain_args<NBLK>(a, x, x_ss, s_x, z_x, B, a_hi, blk, y, y_ss, n_samples, stem_x, stem, drops)) return rc;
+  DropSet<chain_ndrop<NBLK, STEM, true>()> dr;
+  constexpr int D0 = STEM ? 1 : 0;
+  if constexpr (STEM) { if (int rc = fill_drop(dr.d[0], *drop0, s_y0, a_hi, seed, sample_begin)) return rc; }
+  for (int k = 0; k < NBLK; ++k) {
+    if (int rc = fill_drop(dr.d[D0 + 2 * k], drops[2 * k], blk[k].s_a, a_hi, seed, sample_begin)) return rc;
+    if (int rc = fill_drop(dr.d[D0 + 2 * k + 1], drops[2 * k + 1], blk[k].s_b, a_hi, seed, sample_begin)) return rc;
+  }
+  if constexpr (STEM) {
+    if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_drop_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
+    return launch_block_chain_ws_drop<Blk_24, NBLK, true>(a, dr, st);
+  } else {
+    if (Cc == 24 && H == 32) return launch_block_chain_ws_drop<Blk_24, NBLK, false>(a, dr, st);
+    if (Cc == 48 && H == 16) {
+      if constexpr (chain_ws_lds<Blk_48, NBLK, true, false, true>() <= 160 * 1024) return launch_block_chain_ws_drop<Blk_48, NBLK, false>(a, dr, st);
+      else return fail(QBNN_E_INVALID, "qbnn_block_chain_drop_i8_mc: one 48-channel block per launch%s");
+    }
+    if constexpr (NBLK == 1) {
+      if (Cc == 96 && H == 8) return launch_block_chain_ald_drop<ALD_96, 8>(a, dr, st);
+      if (Cc == 192 && H == 4) return launch_block_chain_ald_drop<ALD_192, 8>(a, dr, st);
+    }
+    return fail(QBNN_E_INVALID, "qbnn_block_chain_drop_i8_mc: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
+  }
+}
+
+QBNN_EXPORT int qbnn_block_chain_drop_i8_mc(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cc,
+                                            int32_t a_hi, const qbnn_block_desc* host_blocks, const qbnn_drop_desc* drops, int32_t n_blocks,
+                                            uint8_t* y, int64_t y_ss, int32_t n_samples, uint64_t seed, uint32_t sample_begin, void* stream) {
+  if (!x || !y || !host_blocks || !drops || n_samples <= 0 || B <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_drop_i8_mc: bad argument%s");
+  for (int k = 0; k < n_blocks; ++k)
+    if (!host_blocks[k].w_a || !host_blocks[k].w_b) return fail(QBNN_E_INVALID, "qbnn_block_chain_drop_i8_mc: NULL weights%s");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_blocks == 1) return chain_drop_dispatch<1, false>(x, x_ss, s_x, z_x, B, H, Cc, a_hi, host_blocks, nullptr, drops, y, y_ss, n_samples, seed, sample_begin, st, nullptr, nullptr, 0.f);
+  if (n_blocks == 2) return chain_drop_dispatch<2, false>(x, x_ss, s_x, z_x, B, H, Cc, a_hi, host_blocks, nullptr, drops, y, y_ss, n_samples, seed, sample_begin, st, nullptr, nullptr, 0.f);
+  return fail(QBNN_E_INVALID, "qbnn_block_chain_drop_i8_mc: 1 or 2 blocks per launch%s");
+}
+
+QBNN_EXPORT int qbnn_stem_chain_drop_i8_mc(const int8_t* im2col, int32_t B, const int8_t* w0_packed, int64_t w0_ss, const float* bias0,
+                                           float s_x, float s_w0, int32_t z_w0, float s_y0, int32_t z_y0, int32_t a_hi,
+                                           const qbnn_drop_desc* drop0, const qbnn_block_desc* host_blocks, const qbnn_drop_desc* drops,
+                                           int32_t n_blocks, uint8_t* y, int64_t y_ss, int32_t n_samples, uint64_t seed, uint32_t sample_begin,
+                                           void* stream) {
+  if (!im2col || !w0_packed || !y || !host_blocks || !drop0 || !drops || n_samples <= 0 || B <= 0)
+    return fail(QBNN_E_INVALID, "qbnn_stem_chain_drop_i8_mc: bad argument%s");
+  for (int k = 0; k < n_blocks; ++k)
+    if (!host_blocks[k].w_a || !host_blocks[k].w_b) return fail(QBNN_E_INVALID, "qbnn_stem_chain_drop_i8_mc: NULL weights%s");
+  QConv stem;
+  if (int rc = build_stem_qconv(stem, w0_packed, w0_ss, bias0, s_x, s_w0, z_w0, s_y0, z_y0, a_hi)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  // the chain's input is the dropped conv0 output: scale drop0->s_out, zero point drop0->z_m
+  if (n_blocks == 2) return chain_drop_dispatch<2, true>(nullptr, 0, drop0->s_out, drop0->z_m, B, 32, 24, a_hi, host_blocks, drop0, drops, y, y_ss, n_samples, seed, sample_begin, st, im2col, &stem, s_y0);
+  if (n_blocks == 1) return chain_drop_dispatch<1, true>(nullptr, 0, drop0->s_out, drop0->z_m, B, 32, 24, a_hi, host_blocks, drop0, drops, y, y_ss, n_samples, seed, sample_begin, st, im2col, &stem, s_y0);
+  return fail(QBNN_E_INVALID, "qbnn_stem_chain_drop_i8_mc: 1 or 2 blocks per launch%s");
+}
+
+QBNN_EXPORT int qbnn_block_down_drop_i8_mc(const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t H, int32_t Cin,
+                                           int32_t a_hi, const qbnn_down_desc* d, const qbnn_drop_desc* drops, uint8_t* y, int64_t y_ss,
+                                           int32_t n_samples, uint64_t seed, uint32_t sample_begin, void* stream) {
+  if (!x || !y || !d || !drops || n_samples <= 0 || B <= 0 || !d->blk.w_a || !d->blk.w_b || !d->w_s)
+    return fail(QBNN_E_INVALID, "qbnn_block_down_drop_i8_mc: bad argument%s");
+  DownArgs a;
+  if (int rc = build_down_args(a, x, x_ss, s_x, z_x, B, a_hi, d, y, y_ss, n_samples, drops)) return rc;
+  DropSet<3> dr;
+  if (int rc = fill_drop(dr.d[0], drops[0], d->blk.s_a, a_hi, seed, sample_begin)) return rc;
+  if (int rc = fill_drop(dr.d[1], drops[1], d->blk.s_b, a_hi, seed, sample_begin)) return rc;
+  if (int rc = fill_drop(dr.d[2], drops[2], d->s_s, a_hi, seed, sample_begin)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 24 && H == 32) return launch_block_down_ws_drop<D24_a, D24_s, D24_b, true, false>(a, dr, st);
+  if (Cin == 48 && H == 16) return launch_block_down_ws_drop<D48_a, D48_s, D48_b, false, false>(a, dr, st);
+  if (Cin == 96 && H == 8) return launch_block_down_ws_drop<D96_a, D96_s, D96_b, false, true>(a, dr, st);
+  return fail(QBNN_E_INVALID, "qbnn_block_down_drop_i8_mc: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
 }
 
 // ---- fused multi-call launches (ensemble members): see ArgsArr ------------------------------------------------------------

@@ -525,6 +525,7 @@ struct PostArgs {
   uint32_t seed_lo, seed_hi, layer_id, sample_begin;
   const float* mask_in; const uint32_t* nd;
   float s_a, dl_a;                 // add: first operand = the dropped conv output (s_m / (1 - p), z_m); dl_a = s_a z_m + nzs_a exactly
+  float mq1;                       // quantised value of a kept mask element minus z_m (the bit tables of the fused block kernels)
 };
 
 // quantised mask value minus its zero point for slot i = b * C + c of MC sample s (mcdropout/dropout.py:24-33)
@@ -554,6 +555,57 @@ __device__ __forceinline__ uint32_t add_relu_one(uint32_t qa, uint32_t qb, float
   q = min(q, a_hi);
   if (relu) q = max(q, z_o);
   return (uint32_t)q;
+}
+
+// ---- dropout behind the convs of a fused block (conv_resnet_mc: mcdropout/models_mc.py:116-160) -----------------------------
+// argument block of the dropouts of one launch, passed beside the kernel's own arguments (empty for the graphs without dropout)
+template <int N> struct DropSet { PostArgs d[N]; };
+template <> struct DropSet<0> {};
+
+// Mask table of one dropout for the images of a work item, in LDS: fp32 [G][COUT] (the quantised mask value minus its zero
+// point), or -- BITS, where LDS is short -- one bit per (image, channel): a Bernoulli mask has two values, 0 and mq1.
+template <int COUT, bool BITS> struct MaskTab {
+  static constexpr int WPI = (COUT + 31) / 32;                 // BITS: words per image
+  static constexpr int bytes(int G) { return BITS ? G * WPI * 4 : G * COUT * 4; }
+  const void* tab; float mq1;
+  // mask values of image g, channels c0 .. c0 + 3 (c0 a multiple of 4)
+  __device__ __forceinline__ float4 get(int g, int c0) const {
+    if constexpr (!BITS) {
+      return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(tab) + g * COUT + c0);
+    } else {
+      const int w = reinterpret_cast<const int*>(tab)[g * WPI + (c0 >> 5)] >> (c0 & 31);
+      const int mb = __float_as_int(mq1);           // bit set -> all ones (sign-extended 1-bit field) & mq1, else +0.0
+      return float4{__int_as_float(__builtin_amdgcn_sbfe(w, 0, 1) & mb), __int_as_float(__builtin_amdgcn_sbfe(w, 1, 1) & mb),
+                    __int_as_float(__builtin_amdgcn_sbfe(w, 2, 1) & mb), __int_as_float(__builtin_amdgcn_sbfe(w, 3, 1) & mb)};
+    }
+  }
+};
+// the table of MC sample s, images img0 .. img0 + G - 1 (every thread of the workgroup calls it; a barrier publishes it)
+template <int G, int COUT, bool BITS, int NTHR>
+__device__ __forceinline__ void fill_mask_tab(void* tab, const PostArgs& q, int s, int img0, int B, int tid) {
+  uint32_t seed_lo = q.seed_lo, seed_hi = q.seed_hi, sample_begin = q.sample_begin;
+  if (q.nd) { seed_lo = q.nd[0]; seed_hi = q.nd[1]; sample_begin = q.nd[2]; }
+  if constexpr (!BITS) {
+    for (int i = tid; i < G * COUT; i += NTHR) {
+      const int b = img0 + i / COUT;
+      reinterpret_cast<float*>(tab)[i] = b < B ? (float)drop_mask_q(b * COUT + i % COUT, s, (int64_t)B * COUT, q.keep, q.inv_sm, q.z_m, seed_lo,
+                                                                    seed_hi, q.layer_id, sample_begin, q.mask_in) : 0.f;
+    }
+  } else {
+    constexpr int WPI = MaskTab<COUT, true>::WPI;
+    for (int i = tid; i < G * WPI * 32; i += NTHR) {          // one lane per (image, channel), 32 consecutive lanes per word
+      const int b = img0 + i / (WPI * 32), c = i % (WPI * 32);
+      const bool on = b < B && c < COUT && drop_mask_q(b * COUT + c, s, (int64_t)B * COUT, q.keep, q.inv_sm, q.z_m, seed_lo, seed_hi, q.layer_id,
+                                                       sample_begin, q.mask_in) != 0;
+      const uint64_t bal = __ballot(on);
+      if ((tid & 31) == 0) reinterpret_cast<uint32_t*>(tab)[i >> 5] = (uint32_t)(bal >> (tid & 32));
+    }
+  }
+}
+// r' = quantized::mul(conv output, mask) centred on z_m, as an integer-valued float before its rounding (EpiDenseDrop's first lines)
+__device__ __forceinline__ float drop_val(float v, const QConv& p, const PostArgs& q, float mm) {
+  const float qc = __builtin_rintf(med3f(v, p.vlo, p.vhi));
+  return med3f((qc * mm) * q.dmult, q.dlo, q.dhi);
 }
 
 // ---- epilogue functors -----------------------------------------------------------------------------------------
@@ -599,26 +651,19 @@ struct EpiDense {
 //   r' = rne(clamp((q' * mq) * dmult))       quantized::mul(x, mask_q): (x - z_x)(mask_q - z_m) is exact in fp32; centred on z_m
 //   no Add: byte r' + z_m;   Add: fma(s_a, r', dl_a) dequantises it (QConv::dl_y's argument), the rest is EpiDense's Add + ReLU.
 // mq: fp32 [G][COUT] in LDS, the mask value (minus its zero point) of (image, channel) for this MC sample.
-template <int COUT, int IMG_PIX, bool HAS_RES>
+template <int COUT, int IMG_PIX, bool HAS_RES, int PITCH = COUT, bool BITS = false>
 struct EpiDenseDrop {
   static constexpr int VALU_PER_MFMA = HAS_RES ? 26 : 16;
-  uint8_t* outb; QConv p; QAdd a; PostArgs q; const float* mq;
-  __device__ __forceinline__ int pixel(int m) const { return m * COUT; }
+  uint8_t* outb; QConv p; QAdd a; PostArgs q; MaskTab<COUT, BITS> mt;
+  __device__ __forceinline__ int pixel(int m) const { return m * PITCH; }
   __device__ __forceinline__ uint32_t load(int po, int c0) const {
     return HAS_RES ? *reinterpret_cast<const uint32_t*>(outb + po + c0) : 0u;
   }
   __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
     uint32_t* o = reinterpret_cast<uint32_t*>(outb + po + c0);
-    const int g = po / (IMG_PIX * COUT);
-    const float4 m4 = *reinterpret_cast<const float4*>(mq + g * COUT + c0);
-    const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
-    const float vv[4] = {v0, v1, v2, v3};
-    float r[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float qc = __builtin_rintf(med3f(vv[i], p.vlo, p.vhi));
-      r[i] = med3f((qc * mm[i]) * q.dmult, q.dlo, q.dhi);
-    }
+    const int g = po / (IMG_PIX * PITCH);
+    const float4 m4 = mt.get(g, c0);
+    const float r[4] = {drop_val(v0, p, q, m4.x), drop_val(v1, p, q, m4.y), drop_val(v2, p, q, m4.z), drop_val(v3, p, q, m4.w)};
     if (!HAS_RES) {
       const float zm = (float)q.z_m;
       *o = pack_low_bytes((r[0] + QBNN_MAGIC) + zm, (r[1] + QBNN_MAGIC) + zm, (r[2] + QBNN_MAGIC) + zm, (r[3] + QBNN_MAGIC) + zm);
@@ -678,6 +723,43 @@ struct EpiTileResInPlace {
       t[i] = (da + db) * a.inv_s_o;
     }
     *o = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
+  }
+};
+
+// (b'') / (c'') the same two with a quantised channel dropout behind the conv (conv_resnet_mc): the tile then holds the dropped
+// value centred on the mask's zero point (= the next conv's input zero point); the Add takes it as its first operand.
+template <int HO, int PIXB, int TILE_BYTES, int COUT, bool BITS = false>
+struct EpiTileDrop {
+  static constexpr int VALU_PER_MFMA = 16;
+  uint8_t* dst; QConv p; PostArgs q; MaskTab<COUT, BITS> mt;
+  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, PIXB, TILE_BYTES>(m, 0); }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
+    const float4 m4 = mt.get(po / TILE_BYTES, c0);
+    *reinterpret_cast<uint32_t*>(dst + po + c0) =
+        pack_low_bytes(drop_val(v0, p, q, m4.x) + QBNN_MAGIC, drop_val(v1, p, q, m4.y) + QBNN_MAGIC, drop_val(v2, p, q, m4.z) + QBNN_MAGIC,
+                       drop_val(v3, p, q, m4.w) + QBNN_MAGIC);
+  }
+};
+template <int HO, int PIXB, int TILE_BYTES, int COUT, bool BITS = false>
+struct EpiTileResInPlaceDrop {
+  static constexpr int VALU_PER_MFMA = 28;
+  uint8_t* xt; QConv p; QAdd a; PostArgs q; MaskTab<COUT, BITS> mt;
+  __device__ __forceinline__ int pixel(int m) const { return tile_px_off<HO, PIXB, TILE_BYTES>(m, 0); }
+  __device__ __forceinline__ uint32_t load(int po, int c0) const { return *reinterpret_cast<const uint32_t*>(xt + po + c0); }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rqu) const {
+    const float4 m4 = mt.get(po / TILE_BYTES, c0);
+    const float r[4] = {drop_val(v0, p, q, m4.x), drop_val(v1, p, q, m4.y), drop_val(v2, p, q, m4.z), drop_val(v3, p, q, m4.w)};
+    const int rq = (int)rqu;
+    const float rf[4] = {(float)((rq << 24) >> 24), (float)((rq << 16) >> 24), (float)((rq << 8) >> 24), (float)(rq >> 24)};   // centred residual
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float da = __builtin_fmaf(q.s_a, __builtin_rintf(r[i]), q.dl_a);
+      const float db = __builtin_fmaf(a.s_r, rf[i], a.dl_r);
+      t[i] = (da + db) * a.inv_s_o;
+    }
+    *reinterpret_cast<uint32_t*>(xt + po + c0) = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
   }
 };
 

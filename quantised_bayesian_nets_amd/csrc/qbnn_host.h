@@ -9,6 +9,7 @@
 #include <math.h>
 #include <string.h>
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/qbnn.h"
 #include "qbnn_common.h"

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvArgs a) {
   }
   __syncthreads();
   if constexpr (POST) {
-    EpiDenseDrop<C::COUT, C::HO * C::HO, HAS_RES> epi{outb, a.p, a.a, a.post, mq_lds};
+    EpiDenseDrop<C::COUT, C::HO * C::HO, HAS_RES> epi{outb, a.p, a.a, a.post, {mq_lds, 0.f}};
     conv_passes<C>(tile, a.p.w + (int64_t)s * a.p.w_ss, bias_lds, a.p, epi, wave, lane);
   } else {
     EpiDense<C::COUT, HAS_RES> epi{outb, a.p, a.a};

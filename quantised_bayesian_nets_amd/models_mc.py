@@ -434,6 +434,91 @@ def add_relu_q(a, b, s_o, z_o, a_hi, relu=True):
     return MCQTensor(y, s_o, z_o)
 
 
+def _fill_drop(d, drop, mask, keep):
+    """qbnn_drop_desc of a BernoulliDropout behind a conv of a fused block; mask: optional fp32 [S, B, C] (kept alive in `keep`)."""
+    d.keep_prob = float(np.float32(1.0) - np.float32(drop.p.item()))
+    d.s_m, d.z_m, d.layer_id = drop.mul_mask.scale, drop.mul_mask.zero_point, drop.layer_id
+    d.s_out = drop.mul_mask.scale * float(np.float32(drop.multiplier.item()))      # mul_scalar: only the scale changes
+    if mask is not None:
+        mask = mask.to(device="cuda", dtype=torch.float32).contiguous()
+        keep.append(mask)
+    d.mask_in = _lib.ptr(mask)
+
+
+def _fill_block(d, blk, dev):
+    """qbnn_block_desc of a converted MC-Dropout BasicBlock: the fixed qint8 weights in the MFMA32 layout, sample stride 0."""
+    ca, cb = blk.stem[0]._tuned(), blk.stem[4]._tuned()
+    pa, pb = ca._ensure_packed(dev), cb._ensure_packed(dev)
+    d.w_a, d.w_a_sample_stride, d.bias_a = pa["mu"].data_ptr(), 0, (pa["bias"].data_ptr() if pa["bias"] is not None else None)
+    d.s_wa, d.z_wa, d.s_a, d.z_a = ca.add_weight.scale, ca.add_weight.zero_point, blk.stem[0].scale, blk.stem[0].zero_point
+    d.w_b, d.w_b_sample_stride, d.bias_b = pb["mu"].data_ptr(), 0, (pb["bias"].data_ptr() if pb["bias"] is not None else None)
+    d.s_wb, d.z_wb, d.s_b, d.z_b = cb.add_weight.scale, cb.add_weight.zero_point, blk.stem[4].scale, blk.stem[4].zero_point
+    d.s_o, d.z_o = blk.add.scale, blk.add.zero_point
+
+
+def run_identity_chain_drop(blocks, x, masks, stem=None):
+    """Identity MC-Dropout blocks in ONE fused kernel (qbnn_block_chain_drop_i8_mc / qbnn_stem_chain_drop_i8_mc): both convs, both
+    dropouts, the Add and the ReLU per block; activations stay in LDS.  masks: the model's remaining injected masks in draw
+    order (consumed here) or None.  stem = (layers.0, layers.3, patches [B, 1024, 32], input scale)."""
+    S = _MC.samples
+    dev = x.data.device if stem is None else stem[2].device
+    keep = []
+    n = len(blocks)
+    descs, drops = (_lib.BlockDesc * n)(), (_lib.DropDesc * (2 * n))()
+    d0 = _lib.DropDesc()
+    if stem is not None:
+        _fill_drop(d0, stem[1], masks.pop(0) if masks is not None else None, keep)
+    for k, blk in enumerate(blocks):
+        assert len(blk.shortcut) == 0
+        _fill_block(descs[k], blk, dev)
+        _fill_drop(drops[2 * k], blk.stem[3], masks.pop(0) if masks is not None else None, keep)
+        _fill_drop(drops[2 * k + 1], blk.stem[6], masks.pop(0) if masks is not None else None, keep)
+    a_hi = _a_hi(blocks[0].args)
+    last = blocks[-1].add
+    if stem is not None:
+        l0, _, col, s_in = stem
+        m0 = l0._tuned()
+        pk0 = m0._ensure_packed(dev)
+        B = col.shape[0]
+        y = torch.empty((S, B, 32, 32, 24), dtype=torch.uint8, device=dev)
+        with timed("stem + block_chain_drop_i8 x%d 32x32 c24" % n):
+            _lib.check(_lib.lib().qbnn_stem_chain_drop_i8_mc(_lib.ptr(col), B, _lib.ptr(pk0["mu"]), 0, _lib.ptr(pk0["bias"]), s_in,
+                                                             m0.add_weight.scale, m0.add_weight.zero_point, l0.scale, l0.zero_point, a_hi,
+                                                             C.byref(d0), descs, drops, n, _lib.ptr(y), y[0].numel(), S, _MC.seed, _MC.sample_begin,
+                                                             _lib.current_stream()))
+        return MCQTensor(y, last.scale, last.zero_point)
+    _, B, H, W, Cc = x.data.shape
+    y = torch.empty((S, B, H, W, Cc), dtype=torch.uint8, device=dev)
+    with timed("block_chain_drop_i8 x%d %dx%d c%d" % (n, H, W, Cc)):
+        _lib.check(_lib.lib().qbnn_block_chain_drop_i8_mc(_lib.ptr(x.data), x.sample_stride(), x.scale, x.zero_point, B, H, Cc, a_hi, descs, drops, n,
+                                                          _lib.ptr(y), y[0].numel(), S, _MC.seed, _MC.sample_begin, _lib.current_stream()))
+    return MCQTensor(y, last.scale, last.zero_point)
+
+
+def run_down_block_drop(blk, x, masks):
+    """A down-sampling MC-Dropout block (shortcut conv + stem + three dropouts + Add + ReLU) in ONE fused kernel."""
+    S = _MC.samples
+    dev = x.data.device
+    keep = []
+    d = _lib.DownDesc()
+    _fill_block(d.blk, blk, dev)
+    cs = blk.shortcut[0]._tuned()
+    ps = cs._ensure_packed(dev)
+    d.w_s, d.w_s_sample_stride, d.bias_s = ps["mu"].data_ptr(), 0, (ps["bias"].data_ptr() if ps["bias"] is not None else None)
+    d.s_ws, d.z_ws, d.s_s, d.z_s = cs.add_weight.scale, cs.add_weight.zero_point, blk.shortcut[0].scale, blk.shortcut[0].zero_point
+    drops = (_lib.DropDesc * 3)()
+    for i, dm in enumerate((blk.stem[3], blk.stem[6], blk.shortcut[2])):            # the reference's draw order
+        _fill_drop(drops[i], dm, masks.pop(0) if masks is not None else None, keep)
+    _, B, H, W, Cin = x.data.shape
+    Cout = blk.stem[0].out_channels
+    y = torch.empty((S, B, H // 2, W // 2, Cout), dtype=torch.uint8, device=dev)
+    with timed("block_down_drop_i8 %dx%d %d->%d" % (H, W, Cin, Cout)):
+        _lib.check(_lib.lib().qbnn_block_down_drop_i8_mc(_lib.ptr(x.data), x.sample_stride(), x.scale, x.zero_point, B, H, Cin, _a_hi(blk.args),
+                                                         C.byref(d), drops, _lib.ptr(y), y[0].numel(), S, _MC.seed, _MC.sample_begin,
+                                                         _lib.current_stream()))
+    return MCQTensor(y, blk.add.scale, blk.add.zero_point)
+
+
 class BasicBlock(nn.Module):
     """reference mcdropout/models_mc.py:116-160 after fuse_model + convert: stem = ConvReLU2d, -, -, Dropout, Conv2d, -, Dropout;
     shortcut = Conv2d(1x1, stride), -, Dropout where the shape changes; add; end ReLU."""
@@ -515,6 +600,14 @@ class ConvNetwork_ResNet(nn.Module):
         from .models import QuantStub
         self.quant = QuantStub()
 
+    fuse_blocks = True        # False: one launch per conv (dropout / Add in its epilogue), the A/B and recording path
+
+    def _can_fuse_blocks(self, x, record):
+        drops = self.dropouts()
+        return (self.fuse_blocks and record is None and tuple(x.shape[1:]) == (3, 32, 32) and float(self.layers[3].p) > 0.0
+                and all(float(d.p) > 0.0 and 0 <= d.mul_mask.zero_point <= 127 for d in drops) and _a_hi(self.args) <= 127
+                and len(self.layers[4][0].shortcut) == 0 and all(len(self.layers[li][0].shortcut) == 3 for li in (5, 6, 7)))
+
     def dropouts(self):
         out = [self.layers[3]]
         for li in (4, 5, 6, 7):
@@ -546,14 +639,24 @@ class ConvNetwork_ResNet(nn.Module):
                                                        _lib.current_stream()))
         masks = list(masks) if masks is not None else None
         h = MCQTensor(xq, self.quant.scale, self.quant.zero_point, shared=True)
-        h = self.layers[3](self.layers[0](h), masks.pop(0) if masks is not None else None)
-        if record is not None:
-            record["layers.3.out"] = h.data
-        for li in (4, 5, 6, 7):
-            for bi, blk in enumerate(self.layers[li]):
-                h = blk(h, masks)
-                if record is not None:
-                    record[f"layers.{li}.{bi}.out"] = h.data
+        if self._can_fuse_blocks(x, record):
+            # whole BasicBlocks per launch (csrc/qbnn_blocks.hip, DROP kernels): dropouts, Add and ReLU in the convs' epilogues,
+            # activations in LDS between a block's convs; layers.0 + layers.3 run inside the layer-1 kernel on the 27-tap patches
+            col = torch.empty((B, H * W, 32), dtype=torch.int8, device=x.device)
+            _lib.check(_lib.lib().qbnn_im2col3x3_c3(_lib.ptr(xq), B, H, W, self.quant.zero_point, _lib.ptr(col), _lib.current_stream()))
+            h = run_identity_chain_drop(list(self.layers[4]), None, masks, stem=(self.layers[0], self.layers[3], col, self.quant.scale))
+            for li in (5, 6, 7):
+                h = run_down_block_drop(self.layers[li][0], h, masks)
+                h = run_identity_chain_drop([self.layers[li][1]], h, masks)
+        else:
+            h = self.layers[3](self.layers[0](h), masks.pop(0) if masks is not None else None)
+            if record is not None:
+                record["layers.3.out"] = h.data
+            for li in (4, 5, 6, 7):
+                for bi, blk in enumerate(self.layers[li]):
+                    h = blk(h, masks)
+                    if record is not None:
+                        record[f"layers.{li}.{bi}.out"] = h.data
         fc = self.layers[10]
         dev = fc._device_params(x.device, fc._weight.int_repr())
         probs = torch.empty((S, B, self.output_size), dtype=torch.float32, device=x.device)

@@ -1189,6 +1189,47 @@ def test_resnet_mc_fused_post_ops_equal_separate_launches():
     assert not torch.equal(out[True][0], out[True][1])
 
 
+@pytest.mark.parametrize("B", [7, 70])
+def test_resnet_mc_fused_blocks_equal_per_conv_launches(B):
+    """`conv_resnet_mc` on the fused block kernels with dropout (qbnn_stem_chain_drop_i8_mc / qbnn_block_chain_drop_i8_mc /
+    qbnn_block_down_drop_i8_mc: both convs, the dropouts, the Add and the ReLU of a BasicBlock in one launch) against one launch per conv:
+    every block's output and the probabilities bit-identical, with Philox masks and with injected masks, at a sample offset, on batches
+    that leave ragged image groups in every kernel (and, B = 70, several work items per workgroup range)."""
+    import quantised_bayesian_nets_amd as q
+    from quantised_bayesian_nets_amd import models_mc, _lib
+    from conftest import load_golden
+    g = load_golden("resnet_mc_a7w8.npz")
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=g["meta"]["p"])
+    m = q.ModelFactory.get_model("conv_resnet_mc", [1, 3, 32, 32], 10, True, args).load_reference_state(g["state"])
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(B, 3, 32, 32, generator=gen).cuda()
+    S = 3
+    widths = [24] + [24] * 4 + [48] * 5 + [96] * 5 + [192] * 5
+    masks = [(torch.rand(S, B, c, generator=gen) < 0.8).float() for c in widths]
+    for inj in (None, masks):
+        rec = {}
+        with q.mc_context(S, 99, 5):
+            p_ref = m.forward_mc(x, record=rec, masks=inj)              # one launch per conv (recording path)
+            assert m._can_fuse_blocks(x, None)
+            p_fused = m.forward_mc(x, masks=inj)
+            # block by block on the recorded inputs
+            mk = list(inj) if inj is not None else None
+            xq = torch.empty((1, B, 32, 32, 3), dtype=torch.uint8, device="cuda")
+            _lib.check(_lib.lib().qbnn_quantize_input_nchw(_lib.ptr(x), B, 3, 32, 32, m.quant.scale, m.quant.zero_point, 127, _lib.ptr(xq), _lib.current_stream()))
+            col = torch.empty((B, 1024, 32), dtype=torch.int8, device="cuda")
+            _lib.check(_lib.lib().qbnn_im2col3x3_c3(_lib.ptr(xq), B, 32, 32, m.quant.zero_point, _lib.ptr(col), _lib.current_stream()))
+            h = models_mc.run_identity_chain_drop(list(m.layers[4]), None, mk, stem=(m.layers[0], m.layers[3], col, m.quant.scale))
+            assert torch.equal(h.data, rec["layers.4.1.out"]), "stem + layer 1"
+            for li in (5, 6, 7):
+                prev = h
+                h = models_mc.run_down_block_drop(m.layers[li][0], prev, mk)
+                assert torch.equal(h.data, rec[f"layers.{li}.0.out"]), f"down block {li}"
+                h = models_mc.run_identity_chain_drop([m.layers[li][1]], h, mk)
+                assert torch.equal(h.data, rec[f"layers.{li}.1.out"]), f"identity block {li}"
+            assert mk is None or len(mk) == 0
+        assert torch.equal(p_ref, p_fused)
+
+
 def _small_layer_setup(gen, S, B, shape, shared):
     x = torch.randint(0, 128, ((1 if shared else S), B) + shape, generator=gen, dtype=torch.int32).to(torch.uint8)
     return x
