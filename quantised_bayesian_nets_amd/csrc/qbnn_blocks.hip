@@ -1340,6 +1340,7 @@ static int chain_drop_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_
   }
   if constexpr (STEM) {
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_drop_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
+    if constexpr (NBLK == 2) { if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16_drop(a, dr, st); }
     return launch_block_chain_ws_drop<Blk_24, NBLK, true>(a, dr, st);
   } else {
     if (Cc == 24 && H == 32) return launch_block_chain_ws_drop<Blk_24, NBLK, false>(a, dr, st);

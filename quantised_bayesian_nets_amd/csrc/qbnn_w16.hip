@@ -41,8 +41,9 @@ constexpr int W16_THREADS = 1024, W16_WAVES = 16;
 using L1 = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;      // one 32 x 32 x 24 image tile (halo 1): pitch 34 * 24 bytes
 using L0 = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;      // layers.0 on the patch tensor: K = 27 -> 32, one k-step
 
-template <int G, int NBLK> constexpr int w16_lds() {
-  return 2 * (G * L1::TILE_BYTES + L1::TILE_SLACK) + 2 * NBLK * WConv<L1>::BYTES + WConv<L0>::BYTES + (2 * NBLK + 1) * L1::COUT * 4;
+template <int G, int NBLK, bool DROP = false> constexpr int w16_lds() {
+  return 2 * (G * L1::TILE_BYTES + L1::TILE_SLACK) + 2 * NBLK * WConv<L1>::BYTES + WConv<L0>::BYTES + (2 * NBLK + 1) * L1::COUT * 4 +
+         (DROP ? (2 * NBLK + 1) * MaskTab<L1::COUT, false>::bytes(G) : 0);
 }
 
 // requantise one 32-pixel x 24-channel accumulator tile (ones row -> window sum, see conv_core) through `epi`
@@ -119,9 +120,13 @@ __device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[L
 //  takes the issue slots (53 k against 97 k cycles per image) and the sum does not change; the upper half of the waves started
 //  3 / 6 / 10 x 64 cycles late after every barrier: no change.  Timing ablations of the same source: without the MFMAs 0.93 ms,
 //  without the epilogue arithmetic 0.61, without the pixel-fragment reads 1.08, without the barriers 1.04.)
-template <int G, int NBLK, int NM>
-__global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all) {
+// DROP (conv_resnet_mc): a quantised channel dropout behind every conv -- dr.d = layers.3, then per block stem.3, stem.6 -- applied in the
+// epilogues from per-item mask tables in LDS (block_chain_ws_kernel's DROP form on 16 waves).
+template <int G, int NBLK, int NM, bool DROP = false>
+__global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all, const DropSet<DROP ? 2 * NBLK + 1 : 0> dr) {
   const ChainArgs<NBLK>& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  static_assert(!DROP || NM == 1, "dropout variants are single-call");
+  constexpr int MTB = MaskTab<L1::COUT, false>::bytes(G);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int RW = 2 * G;                                  // output rows per wave and conv (32 rows per image)
   constexpr int TILES = G * L1::TILE_BYTES + L1::TILE_SLACK;
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
   uint8_t* wl0 = wl + 2 * NBLK * WB;                         // layers.0: one fragment tile
   float* bias_lds = reinterpret_cast<float*>(wl0 + WConv<L0>::BYTES);      // [2 NBLK][24], then layers.0's
   float* bias0 = bias_lds + 2 * NBLK * L1::COUT;
+  uint8_t* mtab = reinterpret_cast<uint8_t*>(bias0 + L0::COUT);              // DROP: mask tables [2 NBLK + 1][G][24]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = (wave * RW) / 32, woh0 = (wave * RW) % 32;  // this wave's image within the item and its first output row
 
@@ -198,10 +204,15 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
       for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wl + l_ * 16 + ks * 1024);
     }
     W16_STAMP();
+    if constexpr (DROP) {        // this item's masks (every wave has left the previous item's last epilogue)
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+#pragma unroll
+      for (int d = 0; d < 2 * NBLK + 1; ++d) fill_mask_tab<G, L1::COUT, false, W16_THREADS>(mtab + d * MTB, dr.d[d], s, img0, a.B, t_);
+    }
     sync();                      // the previous item's X tile has been read out by every thread
     W16_STAMP();
-    {                            // layers.0 (ConvReLU2d): patches -> X tile, centred on its own zero point
-      EpiTile<L1::HO, L1::PIXB, L1::TILE_BYTES> epi{xt, a.stem};
+    auto stem_conv = [&](const auto& epi) {        // layers.0 (ConvReLU2d): patches -> X tile, centred on its own zero point
       int l_ = lane;
       asm volatile("" : "+v"(l_));
       const int r = l_ & 31, h = l_ >> 5;
@@ -217,23 +228,27 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
         epilogue24(acc, b4, a.stem, epi, px_off(wg, woh0 + i, r), h);
         W16_STAMP();
       }
-    }
+    };
+    if constexpr (DROP) stem_conv(EpiTileDrop<L1::HO, L1::PIXB, L1::TILE_BYTES, L1::COUT>{xt, a.stem, dr.d[0], {mtab, 0.f}});
+    else stem_conv(EpiTile<L1::HO, L1::PIXB, L1::TILE_BYTES>{xt, a.stem});
     sync();
     W16_STAMP();
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) {
       const BlockParams& bp = a.blk[k];
-      {
-        EpiTile<L1::HO, L1::PIXB, L1::TILE_BYTES> epi{tt, bp.a};
+      auto conv_a = [&](const auto& epi) {
         conv3x3_rows_w16<RW>(xt, w, wl + (2 * k + 1) * WB, bias_lds + (2 * k) * L1::COUT, bp.a, epi, wg, woh0, lane W16_STAMP_PASS);
-      }
-      sync();
-      W16_STAMP();
-      {
-        EpiTileResInPlace<L1::HO, L1::PIXB, L1::TILE_BYTES> epi{xt, bp.b, bp.add};
+      };
+      auto conv_b = [&](const auto& epi) {
         conv3x3_rows_w16<RW>(tt, w, k + 1 < NBLK ? wl + (2 * k + 2) * WB : nullptr, bias_lds + (2 * k + 1) * L1::COUT, bp.b, epi, wg, woh0,
                              lane W16_STAMP_PASS);
-      }
+      };
+      if constexpr (DROP) conv_a(EpiTileDrop<L1::HO, L1::PIXB, L1::TILE_BYTES, L1::COUT>{tt, bp.a, dr.d[1 + 2 * k], {mtab + (1 + 2 * k) * MTB, 0.f}});
+      else conv_a(EpiTile<L1::HO, L1::PIXB, L1::TILE_BYTES>{tt, bp.a});
+      sync();
+      W16_STAMP();
+      if constexpr (DROP) conv_b(EpiTileResInPlaceDrop<L1::HO, L1::PIXB, L1::TILE_BYTES, L1::COUT>{xt, bp.b, bp.add, dr.d[2 + 2 * k], {mtab + (2 + 2 * k) * MTB, 0.f}});
+      else conv_b(EpiTileResInPlace<L1::HO, L1::PIXB, L1::TILE_BYTES>{xt, bp.b, bp.add});
       sync();
       W16_STAMP();
     }
@@ -279,11 +294,26 @@ int launch_w16(const ChainArgs<NBLK>* arr, int n, hipStream_t st) {
   }
   const int per = 256 / n > 0 ? 256 / n : 1;
   const int gx = items < per ? (items > 0 ? items : 1) : per;
-  hipLaunchKernelGGL((stem_chain_w16_kernel<G, NBLK, NM>), dim3(gx, n), dim3(W16_THREADS), LDS, st, all);
+  hipLaunchKernelGGL((stem_chain_w16_kernel<G, NBLK, NM>), dim3(gx, n), dim3(W16_THREADS), LDS, st, all, DropSet<0>{});
   return check_launch("qbnn_stem_chain_i8_mc");
 }
 
+template <int G, int NBLK>
+int launch_w16_drop(const ChainArgs<NBLK>& a, const DropSet<2 * NBLK + 1>& dr, hipStream_t st) {
+  constexpr int LDS = w16_lds<G, NBLK, true>();
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)stem_chain_w16_kernel<G, NBLK, 1, true>, attr, LDS)) return rc_attr;
+  ArgsArr<ChainArgs<NBLK>, 1> one;
+  one.m[0] = a;
+  const int items = a.n_samples * ((a.B + G - 1) / G);
+  hipLaunchKernelGGL((stem_chain_w16_kernel<G, NBLK, 1, true>), dim3(items < 256 ? items : 256), dim3(W16_THREADS), LDS, st, one, dr);
+  return check_launch("qbnn_stem_chain_drop_i8_mc");
+}
+
 }  // namespace
+
+int qbnn_launch_stem_chain_w16_drop(const ChainArgs<2>& a, const DropSet<5>& dr, hipStream_t st) { return launch_w16_drop<2, 2>(a, dr, st); }
 
 // entry point for qbnn_blocks.hip (declared in qbnn_host.h): 1 to 4 argument blocks in one grid, two images per work item
 int qbnn_launch_stem_chain_w16(const ChainArgs<2>* arr, int n, hipStream_t st) {
