@@ -95,7 +95,7 @@ class HeadCall(C.Structure):
 
 
 EXPORTS = ["qbnn_mlp_bbb_f32_mc", "qbnn_mlp_bbb_f32_workspace_floats", "qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_set_device_noise_source", "qbnn_conv2d_i8_mc", "qbnn_conv2d_i8_post_mc", "qbnn_conv_pool_drop_i8_mc", "qbnn_linear_i8_mc",
-           "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_drop_i8_mc", "qbnn_stem_chain_drop_i8_mc", "qbnn_block_down_drop_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi",
+           "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_drop_i8_mc", "qbnn_stem_chain_drop_i8_mc", "qbnn_block_down_drop_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_chain_multi_args_bytes", "qbnn_down_multi_args_bytes", "qbnn_block_chain_i8_multi_prepare", "qbnn_block_chain_i8_multi_launch", "qbnn_block_down_i8_multi_prepare", "qbnn_block_down_i8_multi_launch", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_conv2d_i8_generic_mc", "qbnn_conv2d_i8_generic_scalar_mc", "qbnn_dropout_q_mc", "qbnn_maxpool2_q_mc",
            "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
            "qbnn_conv2d_f32_mc", "qbnn_conv2d_f32_fused_mc", "qbnn_conv2d_f32_blocks", "qbnn_observe_partials_f32_mc", "qbnn_affine_f32_mc", "qbnn_pool2d_f32_mc", "qbnn_flatten_nchw_f32_mc", "qbnn_softmax_f32_mc", "qbnn_observe_f32_mc", "qbnn_fake_quant_f32_mc", "qbnn_sample_weights_f32_strided", "qbnn_sample_weights_f32_ohwi",
@@ -136,6 +136,14 @@ def lib():
         L.qbnn_block_down_drop_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(DownDesc), C.POINTER(DropDesc), vp, i64, i32, C.c_uint64, C.c_uint32, vp]
         L.qbnn_block_chain_i8_multi.argtypes = [C.POINTER(ChainCall), i32, i32, i32, i32, i32, i32, i32, vp]
         L.qbnn_block_down_i8_multi.argtypes = [C.POINTER(DownCall), i32, i32, i32, i32, i32, vp]
+        L.qbnn_chain_multi_args_bytes.restype = C.c_size_t
+        L.qbnn_chain_multi_args_bytes.argtypes = [i32, i32]
+        L.qbnn_down_multi_args_bytes.restype = C.c_size_t
+        L.qbnn_down_multi_args_bytes.argtypes = [i32]
+        L.qbnn_block_chain_i8_multi_prepare.argtypes = [C.POINTER(ChainCall), i32, i32, i32, i32, i32, vp]
+        L.qbnn_block_chain_i8_multi_launch.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.qbnn_block_down_i8_multi_prepare.argtypes = [C.POINTER(DownCall), i32, i32, i32, vp]
+        L.qbnn_block_down_i8_multi_launch.argtypes = [vp, i32, i32, i32, i32, i32, vp]
         L.qbnn_head_i8_multi.argtypes = [C.POINTER(HeadCall), i32, vp]
         L.qbnn_quantize_im2col3x3_c3_multi.argtypes = [vp, i32, i32, i32, C.POINTER(f), C.POINTER(i32), i32, i32, vp, i64, vp]
         L.qbnn_conv2d_i8_generic_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, C.POINTER(ConvDesc), vp]

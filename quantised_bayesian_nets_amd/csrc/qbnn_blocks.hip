@@ -2,6 +2,7 @@
 // block's convs) and their C ABI: qbnn_block_chain_i8_mc / qbnn_stem_chain_i8_mc / qbnn_block_down_i8_mc and the
 // multi-call (ensemble) forms.  Shared device code: qbnn_conv.h.
 #include "qbnn_host.h"
+#include <vector>
 
 #ifdef QBNN_STAMP
 static unsigned long long* g_stamp_buf = nullptr;
@@ -1321,6 +1322,113 @@ QBNN_EXPORT int qbnn_stem_chain_i8_mc(const int8_t* im2col, int32_t B, const int
   if (n_blocks == 1) return block_chain_dispatch<1>(nullptr, 0, s_y0, z_y0, B, 32, 24, a_hi, host_blocks, y, y_ss, n_samples, st, im2col, &stem);
   if (n_blocks == 2) return block_chain_dispatch<2>(nullptr, 0, s_y0, z_y0, B, 32, 24, a_hi, host_blocks, y, y_ss, n_samples, st, im2col, &stem);
   return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: 1 or 2 blocks per launch%s");
+}
+
+// ---- prepared multi-call launches: the argument blocks live in device memory (ArgsArr<A, 0>) ---------------------------------------
+template <class C, int NWV>
+static int launch_block_chain_ald_dev(const ChainArgs<1>* dev, int n, int items, hipStream_t st) {
+  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4;
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV, 0>, attr, LDS)) return rc_attr;
+  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, 0>), dim3(fused_grid_x(items, n), n), dim3(64 * NWV), LDS, st, ArgsArr<ChainArgs<1>, 0>{dev}, DropSet<0>{});
+  return check_launch("qbnn_block_chain_i8_multi_launch");
+}
+template <class C, int NBLK>
+static int launch_block_chain_ws_dev(const ChainArgs<NBLK>* dev, int n, int items, hipStream_t st) {
+  constexpr int LDS = chain_ws_lds<C, NBLK, true, false>();
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, true, false, 0>, attr, LDS)) return rc_attr;
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, true, false, 0>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, ArgsArr<ChainArgs<NBLK>, 0>{dev},
+                     DropSet<0>{});
+  return check_launch("qbnn_block_chain_i8_multi_launch");
+}
+template <class CA, class CS, class CB, bool LDSW>
+static int launch_block_down_ws_dev(const DownArgs* dev, int n, int items, hipStream_t st) {
+  constexpr int LDS = CA::G * CA::TILE_BYTES + CA::TILE_SLACK + CB::G * CB::TILE_BYTES + CB::TILE_SLACK + DownSC<CB>::BYTES +
+                      (LDSW ? WConv<CS>::BYTES + WConv<CA>::BYTES + WConv<CB>::BYTES : 0) + 3 * CB::COUT * 4;
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)block_down_ws_kernel<CA, CS, CB, LDSW, 0>, attr, LDS)) return rc_attr;
+  hipLaunchKernelGGL((block_down_ws_kernel<CA, CS, CB, LDSW, 0>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, ArgsArr<DownArgs, 0>{dev}, DropSet<0>{});
+  return check_launch("qbnn_block_down_i8_multi_launch");
+}
+
+QBNN_EXPORT size_t qbnn_chain_multi_args_bytes(int32_t n_calls, int32_t n_blocks) {
+  return (size_t)(n_calls > 0 ? n_calls : 0) * (n_blocks == 2 ? sizeof(ChainArgs<2>) : sizeof(ChainArgs<1>));
+}
+QBNN_EXPORT size_t qbnn_down_multi_args_bytes(int32_t n_calls) { return (size_t)(n_calls > 0 ? n_calls : 0) * sizeof(DownArgs); }
+
+static int upload_args(void* dev, const void* host, size_t bytes, const char* what) {
+  if (hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(QBNN_E_LAUNCH, "%s: copying the argument blocks to the device failed", what);
+  return QBNN_OK;
+}
+
+QBNN_EXPORT int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, int32_t n_calls, int32_t with_stem, int32_t B, int32_t a_hi,
+                                                  int32_t n_blocks, void* dev_args) {
+  if (!calls || n_calls <= 0 || B <= 0 || !dev_args) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: bad argument%s");
+  int rc = QBNN_OK;
+  if (with_stem) {
+    if (n_blocks != 2) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: the fused stem feeds the two 32x32x24 blocks%s");
+    std::vector<ChainArgs<2>> arr(n_calls);
+    for (int i = 0; i < n_calls; ++i) {
+      const qbnn_chain_call& k = calls[i];
+      if (!k.im2col || !k.w0_packed || !k.blocks || !k.y || k.n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: bad call entry%s");
+      QConv stem;
+      if ((rc = build_stem_qconv(stem, k.w0_packed, k.w0_sample_stride, k.bias0, k.s_in, k.s_w0, k.z_w0, k.s_y0, k.z_y0, a_hi))) return rc;
+      if ((rc = build_chain_args<2>(arr[i], nullptr, 0, k.s_y0, k.z_y0, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, k.im2col, &stem))) return rc;
+    }
+    return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_chain_i8_multi_prepare");
+  }
+  if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: one block per call (two only behind the fused stem)%s");
+  std::vector<ChainArgs<1>> arr(n_calls);
+  for (int i = 0; i < n_calls; ++i) {
+    const qbnn_chain_call& k = calls[i];
+    if (!k.x || !k.blocks || !k.y || k.n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: bad call entry%s");
+    if ((rc = build_chain_args<1>(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, nullptr, nullptr))) return rc;
+  }
+  return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_chain_i8_multi_prepare");
+}
+
+QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t with_stem, int32_t B, int32_t H, int32_t Cc,
+                                                 int32_t n_blocks, int32_t max_samples, void* stream) {
+  if (!dev_args || n_calls <= 0 || B <= 0 || max_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: bad argument%s");
+  hipStream_t st = (hipStream_t)stream;
+  auto items = [&](int G) { return max_samples * ((B + G - 1) / G); };
+  if (with_stem) {
+    if (n_blocks != 2 || Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: the fused stem feeds the two 32x32x24 blocks only%s");
+    return qbnn_launch_stem_chain_w16_dev(reinterpret_cast<const ChainArgs<2>*>(dev_args), n_calls, items(2), st);
+  }
+  if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: one block per call (two only behind the fused stem)%s");
+  const ChainArgs<1>* dev = reinterpret_cast<const ChainArgs<1>*>(dev_args);
+  if (Cc == 48 && H == 16) return launch_block_chain_ws_dev<Blk_48, 1>(dev, n_calls, items(Blk_48::G), st);
+  if (Cc == 96 && H == 8) return launch_block_chain_ald_dev<ALD_96, 8>(dev, n_calls, items(ALD_96::G), st);
+  if (Cc == 192 && H == 4)
+    return ((B + 15) / 16) * n_calls * max_samples <= 128 ? launch_block_chain_ald_dev<ALD_192_G8, 8>(dev, n_calls, items(8), st)
+                                                           : launch_block_chain_ald_dev<ALD_192, 8>(dev, n_calls, items(16), st);
+  return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
+}
+
+QBNN_EXPORT int qbnn_block_down_i8_multi_prepare(const qbnn_down_call* calls, int32_t n_calls, int32_t B, int32_t a_hi, void* dev_args) {
+  if (!calls || n_calls <= 0 || B <= 0 || !dev_args) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_prepare: bad argument%s");
+  std::vector<DownArgs> arr(n_calls);
+  for (int i = 0; i < n_calls; ++i) {
+    const qbnn_down_call& k = calls[i];
+    if (!k.x || !k.y || !k.desc || k.n_samples <= 0 || !k.desc->blk.w_a || !k.desc->blk.w_b || !k.desc->w_s)
+      return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_prepare: bad call entry%s");
+    if (int rc = build_down_args(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.desc, k.y, k.y_sample_stride, k.n_samples)) return rc;
+  }
+  return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_down_i8_multi_prepare");
+}
+
+QBNN_EXPORT int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t max_samples,
+                                                void* stream) {
+  if (!dev_args || n_calls <= 0 || B <= 0 || max_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_launch: bad argument%s");
+  hipStream_t st = (hipStream_t)stream;
+  const DownArgs* dev = reinterpret_cast<const DownArgs*>(dev_args);
+  auto items = [&](int G) { return max_samples * ((B + G - 1) / G); };
+  if (Cin == 24 && H == 32) return launch_block_down_ws_dev<D24_a, D24_s, D24_b, true>(dev, n_calls, items(D24_a::G), st);
+  if (Cin == 48 && H == 16) return launch_block_down_ws_dev<D48_a, D48_s, D48_b, false>(dev, n_calls, items(D48_a::G), st);
+  if (Cin == 96 && H == 8) return launch_block_down_ws_dev<D96_a, D96_s, D96_b, false>(dev, n_calls, items(D96_a::G), st);
+  return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_launch: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
 }
 
 // ---- fused blocks with dropout (conv_resnet_mc) ------------------------------------------------------------------------------

@@ -810,6 +810,9 @@ struct ChainArgs {
 // m+1's.  NM = 1 is the ordinary launch (same code, argument block 0).
 #define QBNN_FUSED_CALLS 8            // argument blocks per launch (kernel arguments are limited to 4 KiB)
 template <class A, int NM> struct ArgsArr { A m[NM]; };
+// NM = 0: any number of argument blocks, in DEVICE memory (the prepared multi-call launches: qbnn_*_multi_prepare / _launch) -- the
+// blocks are read with scalar loads instead of arriving as kernel arguments, so one grid holds all 16 members of an ensemble.
+template <class A> struct ArgsArr<A, 0> { const A* m; };
 
 // =====================================================================================
 // Weights-stationary fused kernels (layers whose block weights fit in LDS next to the tiles: 24 and 48 channels).

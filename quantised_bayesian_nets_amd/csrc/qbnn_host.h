@@ -52,6 +52,7 @@ static int fill_qadd(QAdd& a, const qbnn_conv_desc* d) {
 
 // 16-wave layer-1 kernel (qbnn_w16.hip): layers.0 + two identity blocks at 32 x 32 x 24, `n` <= 4 argument blocks in one grid
 int qbnn_launch_stem_chain_w16(const ChainArgs<2>* arr, int n, hipStream_t st);
+int qbnn_launch_stem_chain_w16_dev(const ChainArgs<2>* dev, int n, int items, hipStream_t st);               // ... any number of argument blocks in device memory
 int qbnn_launch_stem_chain_w16_drop(const ChainArgs<2>& a, const DropSet<5>& dr, hipStream_t st);      // ... with the five dropouts of conv_resnet_mc
 // QBNN_W16=0 selects the 8-wave kernels of qbnn_blocks.hip everywhere (A/B checks)
 static inline bool qbnn_use_w16() {

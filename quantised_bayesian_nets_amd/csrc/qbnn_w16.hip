@@ -313,6 +313,16 @@ int launch_w16_drop(const ChainArgs<NBLK>& a, const DropSet<2 * NBLK + 1>& dr, h
 
 }  // namespace
 
+int qbnn_launch_stem_chain_w16_dev(const ChainArgs<2>* dev, int n, int items, hipStream_t st) {
+  constexpr int LDS = w16_lds<2, 2>();
+  static std::atomic<uint64_t> attr{0};
+  if (int rc_attr = ensure_dyn_lds((const void*)stem_chain_w16_kernel<2, 2, 0>, attr, LDS)) return rc_attr;
+  const int per = 256 / n > 0 ? 256 / n : 1;
+  const int gx = items < per ? (items > 0 ? items : 1) : per;
+  hipLaunchKernelGGL((stem_chain_w16_kernel<2, 2, 0>), dim3(gx, n), dim3(W16_THREADS), LDS, st, ArgsArr<ChainArgs<2>, 0>{dev}, DropSet<0>{});
+  return check_launch("qbnn_block_chain_i8_multi_launch");
+}
+
 int qbnn_launch_stem_chain_w16_drop(const ChainArgs<2>& a, const DropSet<5>& dr, hipStream_t st) { return launch_w16_drop<2, 2>(a, dr, st); }
 
 // entry point for qbnn_blocks.hip (declared in qbnn_host.h): 1 to 4 argument blocks in one grid, two images per work item

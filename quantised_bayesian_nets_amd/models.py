@@ -352,6 +352,7 @@ class Network(nn.Module):
         self._streams = []
         # members side by side in fused multi-call launches (the ResNet template's default); False: one launch chain per member
         self.fused_members = args.model == "conv_resnet_sgld"
+        self.prepared_launches = os.environ.get("QBNN_ENSEMBLE_BY_VALUE", "0") != "1"     # argument blocks in device memory: one launch per stage for all members
         self._plans = {}
 
     def load_reference_state(self, member_states):
@@ -417,12 +418,16 @@ class Network(nn.Module):
         a_hi = UINT_BOUNDS[self.args.activation_precision][1]
         keep = []
         u8 = lambda *shape: torch.empty(shape, dtype=torch.uint8, device=dev)
-        col = torch.empty((M, B, 1024, 32), dtype=torch.int8, device=dev)
+        # layer-0 patches: one tensor per DISTINCT input quantisation.  The QuantStub observes the network input, not the member's weights,
+        # so members calibrated on the same data share (scale, zero point) -- and then the patches (8 MB at B = 256, L2-resident) too.
+        qin = sorted({(float(m.quant.scale), int(m.quant.zero_point)) for m in mem})
+        col_of = [qin.index((float(m.quant.scale), int(m.quant.zero_point))) for m in mem]
+        col = torch.empty((len(qin), B, 1024, 32), dtype=torch.int8, device=dev)
         acts = {3: u8(M, B, 32, 32, 24), "4d": u8(M, B, 16, 16, 48), 4: u8(M, B, 16, 16, 48), "5d": u8(M, B, 8, 8, 96), 5: u8(M, B, 8, 8, 96),
                 "6d": u8(M, B, 4, 4, 192), 6: u8(M, B, 4, 4, 192)}
         probs = torch.empty((M, B, self.output_size), dtype=torch.float32, device=dev)
-        scales = (C.c_float * M)(*[m.quant.scale for m in mem])
-        zps = (C.c_int32 * M)(*[m.quant.zero_point for m in mem])
+        scales = (C.c_float * len(qin))(*[q[0] for q in qin])
+        zps = (C.c_int32 * len(qin))(*[q[1] for q in qin])
         with mc_context(1, 0, 0):
             # layers.0 + layers.3 (two identity blocks) behind the fused stem
             stem_calls = (_lib.ChainCall * M)()
@@ -435,7 +440,7 @@ class Network(nn.Module):
                 keep.append(descs)
                 c = stem_calls[i]
                 c.blocks, c.y, c.y_sample_stride, c.n_samples = descs, acts[3][i].data_ptr(), acts[3][i].numel(), 1
-                c.im2col, c.w0_packed, c.w0_sample_stride = col[i].data_ptr(), pk0["mu"].data_ptr(), 0
+                c.im2col, c.w0_packed, c.w0_sample_stride = col[col_of[i]].data_ptr(), pk0["mu"].data_ptr(), 0
                 c.bias0 = pk0["bias"].data_ptr() if pk0["bias"] is not None else None
                 c.s_in, c.s_w0, c.z_w0, c.s_y0, c.z_y0 = m.quant.scale, l0.add_weight.scale, l0.add_weight.zero_point, l0.scale, l0.zero_point
             steps = [("stem", stem_calls)]
@@ -476,7 +481,20 @@ class Network(nn.Module):
                 h = hcalls[i]
                 h.x, h.x_sample_stride, h.w, h.w_sample_stride = acts[6][i].data_ptr(), acts[6][i].numel(), pk["mu"].data_ptr(), 0
                 h.bias, h.probs, h.n_samples, h.desc = (pk["bias"].data_ptr() if pk["bias"] is not None else None), probs[i].data_ptr(), 1, C.pointer(hd)
-        plan = dict(M=M, col=col, acts=acts, probs=probs, scales=scales, zps=zps, steps=steps, head=hcalls, keep=keep, a_hi=a_hi)
+        # the argument blocks of every stage go to device memory once (qbnn_*_multi_prepare): a stage is then ONE launch for all M members
+        # (by value, 4 KiB of kernel arguments hold 4 - 8 of them).  Not under stream capture: the plan is built by the first eager call.
+        dev_steps = []
+        if self.prepared_launches and not torch.cuda.is_current_stream_capturing():
+            for step in steps:
+                if step[0] == "down":
+                    buf = torch.empty(int(L.qbnn_down_multi_args_bytes(M)), dtype=torch.uint8, device=dev)
+                    _lib.check(L.qbnn_block_down_i8_multi_prepare(step[1], M, B, a_hi, _lib.ptr(buf)))
+                else:
+                    nb = 2 if step[0] == "stem" else 1
+                    buf = torch.empty(int(L.qbnn_chain_multi_args_bytes(M, nb)), dtype=torch.uint8, device=dev)
+                    _lib.check(L.qbnn_block_chain_i8_multi_prepare(step[1], M, int(step[0] == "stem"), B, a_hi, nb, _lib.ptr(buf)))
+                dev_steps.append(buf)
+        plan = dict(M=M, col=col, acts=acts, probs=probs, scales=scales, zps=zps, steps=steps, dev_steps=dev_steps, head=hcalls, keep=keep, a_hi=a_hi)
         self._plans[key] = plan
         return plan
 
@@ -492,17 +510,28 @@ class Network(nn.Module):
         p = self._member_plan(idx, B, x.device)
         L, st, M = _lib.lib(), _lib.current_stream(), p["M"]
         with timed("ensemble quantize + im2col"):
-            _lib.check(L.qbnn_quantize_im2col3x3_c3_multi(_lib.ptr(x), B, H, W, p["scales"], p["zps"], M, p["a_hi"], _lib.ptr(p["col"]), p["col"][0].numel(), st))
-        for step in p["steps"]:
+            _lib.check(L.qbnn_quantize_im2col3x3_c3_multi(_lib.ptr(x), B, H, W, p["scales"], p["zps"], p["col"].shape[0], p["a_hi"], _lib.ptr(p["col"]),
+                                                          p["col"][0].numel(), st))
+        for si, step in enumerate(p["steps"]):
+            dargs = _lib.ptr(p["dev_steps"][si]) if p["dev_steps"] else None
             if step[0] == "stem":
                 with timed("ensemble stem + layer 1"):
-                    _lib.check(L.qbnn_block_chain_i8_multi(step[1], M, 1, B, 32, 24, p["a_hi"], 2, st))
+                    if dargs:
+                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 1, B, 32, 24, 2, 1, st))
+                    else:
+                        _lib.check(L.qbnn_block_chain_i8_multi(step[1], M, 1, B, 32, 24, p["a_hi"], 2, st))
             elif step[0] == "down":
                 with timed("ensemble down %d" % step[3]):
-                    _lib.check(L.qbnn_block_down_i8_multi(step[1], M, B, step[2], step[3], p["a_hi"], st))
+                    if dargs:
+                        _lib.check(L.qbnn_block_down_i8_multi_launch(dargs, M, B, step[2], step[3], 1, st))
+                    else:
+                        _lib.check(L.qbnn_block_down_i8_multi(step[1], M, B, step[2], step[3], p["a_hi"], st))
             else:
                 with timed("ensemble chain %d" % step[3]):
-                    _lib.check(L.qbnn_block_chain_i8_multi(step[1], M, 0, B, step[2], step[3], p["a_hi"], 1, st))
+                    if dargs:
+                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 0, B, step[2], step[3], 1, 1, st))
+                    else:
+                        _lib.check(L.qbnn_block_chain_i8_multi(step[1], M, 0, B, step[2], step[3], p["a_hi"], 1, st))
         with timed("ensemble head"):
             _lib.check(L.qbnn_head_i8_multi(p["head"], M, st))
         return p["probs"].clone()

@@ -793,6 +793,43 @@ def test_ensemble_16_members_full_batch_against_oracle(golden_ensemble):
         np.testing.assert_allclose(net(xc).cpu().numpy(), ref[i], rtol=RTOL, atol=1e-8)
 
 
+def test_ensemble_members_with_their_own_qparams(golden_ensemble):
+    """Members whose quantisation parameters ALL differ -- input QuantStub scale and zero point (three distinct values over 8 members: the
+    layer-0 patches are shared per distinct value), every conv's output scale, the Add scales -- through the one-launch-per-stage form
+    (argument blocks in device memory), the by-value multi-call form and the per-member chains: bit-identical to each other and
+    1e-5 to the deterministic-member oracle."""
+    import quantised_bayesian_nets_amd as q
+    from conftest import synth_ensemble_members
+    from oracle import oracle as orc
+    n = 8
+    members = [dict(m) for m in synth_ensemble_members(golden_ensemble, n)]
+    for i, st in enumerate(members):
+        f = 1.0 + 0.03 * (i % 3)
+        for k in list(st):
+            v = np.asarray(st[k])
+            if k == "quant.scale" or (k.endswith(".scale") and v.dtype.kind == "f" and v.size == 1):
+                st[k] = (v * np.float32(f if k == "quant.scale" else 1.0 + 0.01 * ((i + len(k)) % 5))).astype(v.dtype)
+            elif k == "quant.zero_point":
+                st[k] = (v + (i % 3)).astype(v.dtype)
+    assert len({(float(np.asarray(st["quant.scale"]).reshape(-1)[0]), int(np.asarray(st["quant.zero_point"]).reshape(-1)[0])) for st in members}) == 3
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, model="conv_resnet_sgld", samples=n)
+    x = torch.randn(21, 3, 32, 32, generator=torch.Generator().manual_seed(4))
+    xc = x.cuda()
+    ref = np.stack([orc.Int8ResNetDetOracle(st, 7).forward(x.numpy()) for st in members])
+    outs = []
+    for mode in ("prepared", "by_value", "chains"):
+        net = q.ModelFactory.get_model("conv_resnet_sgld", [1, 3, 32, 32], 10, True, args, training_mode=False).load_reference_state(members)
+        net.prepared_launches = mode == "prepared"
+        net.fused_members = mode != "chains"
+        with q.mc_context(n, 0, 0):
+            outs.append(net.forward_mc(xc))
+        if mode == "prepared":
+            plan = next(iter(net._plans.values()))
+            assert plan["col"].shape[0] == 3 and len(plan["dev_steps"]) == 7
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref, rtol=RTOL, atol=1e-8)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 _DIST_WORKER = r"""
 import os, sys, types, numpy as np, torch, torch.distributed as dist
 root = sys.argv[1]
