@@ -671,7 +671,8 @@ struct EpiDenseTileResGlobalDrop {
 // NWV = 8: two waves per SIMD, 256 VGPRs each (MB x NB = 2 x 3 tiles per wave).  Measured alternatives, all slower:
 // NWV = 4 (one wave per SIMD, 4 x 3 tiles in the 512-register file: -25 %, the epilogues read accumulators out of AGPRs
 // and a lone wave hides no latency); NWV = 12 (4 x 1 tiles, 168 VGPRs: -12 %) and NWV = 16 (1 x 3 tiles, 128 VGPRs:
-// -5 %), both of which spill the next item's input prefetch and so put its HBM latency back on the critical path; and two
+// -5 %; round 3 re-ran it at 96 channels with the per-lane addresses kept out of the item loop -- 126 VGPRs, no spills -- and it takes the
+// same 0.343 ms as 8 waves: four waves per SIMD buy these kernels nothing), both of which spill the next item's input prefetch and so put its HBM latency back on the critical path; and two
 // independent 4-wave workgroups per CU (4 images each, 9 KiB slabs) whose M and E phases drift apart on their own: equal
 // time at 96 channels -- overlapping the phases is not what this kernel lacks.
 // Round 2 re-tested that with a full ping-pong kernel (two 4-wave groups in anti-phase sharing ONE weight ring, the E group
