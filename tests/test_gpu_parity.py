@@ -1226,18 +1226,35 @@ def test_resnet_mc_fused_post_ops_equal_separate_launches():
     assert not torch.equal(out[True][0], out[True][1])
 
 
-@pytest.mark.parametrize("B", [7, 70])
-def test_resnet_mc_fused_blocks_equal_per_conv_launches(B):
+def _perturb_activation_qparams(state, seed):
+    """Random output scales / zero points for every conv, dropout, Add and the input QuantStub of a converted MC-Dropout state."""
+    rng = np.random.default_rng(seed)
+    st = dict(state)
+    for k in list(st):
+        v = np.asarray(st[k])
+        if k.endswith("weight.q_scale") or k.endswith("weight.q_zero_point") or "multiplier" in k or k.endswith(".p"):
+            continue
+        if k.endswith("scale") and v.size == 1:
+            st[k] = (v.astype(np.float64) * np.exp(rng.uniform(-0.6, 0.6))).astype(v.dtype)
+        elif k.endswith("zero_point") and v.size == 1:
+            st[k] = np.asarray(rng.integers(0, 31 if "mul_mask" in k else 90)).astype(v.dtype).reshape(v.shape)
+    return st
+
+
+@pytest.mark.parametrize("B,qseed", [(7, None), (70, None), (9, 1), (21, 2)])
+def test_resnet_mc_fused_blocks_equal_per_conv_launches(B, qseed):
     """`conv_resnet_mc` on the fused block kernels with dropout (qbnn_stem_chain_drop_i8_mc / qbnn_block_chain_drop_i8_mc /
     qbnn_block_down_drop_i8_mc: both convs, the dropouts, the Add and the ReLU of a BasicBlock in one launch) against one launch per conv:
     every block's output and the probabilities bit-identical, with Philox masks and with injected masks, at a sample offset, on batches
-    that leave ragged image groups in every kernel (and, B = 70, several work items per workgroup range)."""
+    that leave ragged image groups in every kernel (and, B = 70, several work items per workgroup range); qseed: the same with random
+    output scales and zero points of every conv, dropout mask and Add (the per-conv path is what the reference fixtures pin)."""
     import quantised_bayesian_nets_amd as q
     from quantised_bayesian_nets_amd import models_mc, _lib
     from conftest import load_golden
     g = load_golden("resnet_mc_a7w8.npz")
     args = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=g["meta"]["p"])
-    m = q.ModelFactory.get_model("conv_resnet_mc", [1, 3, 32, 32], 10, True, args).load_reference_state(g["state"])
+    state = g["state"] if qseed is None else _perturb_activation_qparams(g["state"], qseed)      # qseed: random activation qparams everywhere
+    m = q.ModelFactory.get_model("conv_resnet_mc", [1, 3, 32, 32], 10, True, args).load_reference_state(state)
     gen = torch.Generator().manual_seed(12)
     x = torch.randn(B, 3, 32, 32, generator=gen).cuda()
     S = 3
