@@ -366,6 +366,11 @@ int qbnn_maxpool2_q_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int
 int qbnn_flatten_nchw_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int32_t HW, int32_t C, uint8_t* y,
                          int64_t y_sample_stride, int32_t n_samples, void* stream);
 
+/* The same on pitched rows: x [S][B][ldx] (NHWC order in the first HW * C bytes, as qbnn_conv_pool_drop_i8_mc writes them) ->
+ * y [S][B][ldy] in NCHW order, bytes HW * C .. ldy - 1 written 0 (what qbnn_linear_i8_mc reads). */
+int qbnn_flatten_nchw_rows_mc(const uint8_t* x, int64_t x_sample_stride, int32_t ldx, int32_t B, int32_t HW, int32_t C, uint8_t* y,
+                              int64_t y_sample_stride, int32_t ldy, int32_t n_samples, void* stream);
+
 /* DeQuantStub + F.softmax(dim=-1): x [S][B][N] uint8 -> probs [S][B][N] fp32. */
 int qbnn_dequant_softmax_mc(const uint8_t* x, int64_t x_sample_stride, int32_t B, int32_t N, float scale, int32_t zero_point,
                             float* probs, int32_t n_samples, void* stream);

@@ -97,7 +97,7 @@ class HeadCall(C.Structure):
 EXPORTS = ["qbnn_mlp_bbb_f32_mc", "qbnn_mlp_bbb_f32_workspace_floats", "qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_set_device_noise_source", "qbnn_conv2d_i8_mc", "qbnn_conv2d_i8_post_mc", "qbnn_conv_pool_drop_i8_mc", "qbnn_linear_i8_mc",
            "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_drop_i8_mc", "qbnn_stem_chain_drop_i8_mc", "qbnn_block_down_drop_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_chain_multi_args_bytes", "qbnn_down_multi_args_bytes", "qbnn_block_chain_i8_multi_prepare", "qbnn_block_chain_i8_multi_launch", "qbnn_block_down_i8_multi_prepare", "qbnn_block_down_i8_multi_launch", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_conv2d_i8_generic_mc", "qbnn_conv2d_i8_generic_scalar_mc", "qbnn_dropout_q_mc", "qbnn_maxpool2_q_mc",
-           "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
+           "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_flatten_nchw_rows_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
            "qbnn_conv2d_f32_mc", "qbnn_conv2d_f32_fused_mc", "qbnn_conv2d_f32_blocks", "qbnn_observe_partials_f32_mc", "qbnn_affine_f32_mc", "qbnn_pool2d_f32_mc", "qbnn_flatten_nchw_f32_mc", "qbnn_softmax_f32_mc", "qbnn_observe_f32_mc", "qbnn_fake_quant_f32_mc", "qbnn_sample_weights_f32_strided", "qbnn_sample_weights_f32_ohwi",
            "qbnn_last_error", "qbnn_version"]
 
@@ -157,6 +157,7 @@ def lib():
         L.qbnn_classification_metrics.argtypes = [vp, vp, i32, i32, vp, vp]
         L.qbnn_regression_metrics.argtypes = [vp, vp, vp, i32, vp, vp]
         L.qbnn_flatten_nchw_mc.argtypes = [vp, i64, i32, i32, i32, vp, i64, i32, vp]
+        L.qbnn_flatten_nchw_rows_mc.argtypes = [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, vp]
         L.qbnn_quantize_input_nchw.argtypes = [vp, i32, i32, i32, i32, f, i32, i32, vp, vp]
         L.qbnn_im2col3x3_c3.argtypes = [vp, i32, i32, i32, i32, vp, vp]
         L.qbnn_head_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i32, C.POINTER(HeadDesc), vp]

@@ -838,6 +838,32 @@ __global__ __launch_bounds__(256) void flatten_nchw_kernel(const uint8_t* __rest
   y[(int64_t)s * y_ss + idx] = x[(int64_t)s * x_ss + (b * HW + p) * C + c];
 }
 
+// the same on pitched rows (the small networks' fused kernels write one row per image, pitch a multiple of 16): y[b][c * HW + p] = x[b][p * C + c],
+// bytes C * HW .. ldy - 1 of every output row are written 0
+__global__ __launch_bounds__(256) void flatten_nchw_rows_kernel(const uint8_t* __restrict__ x, int64_t x_ss, int ldx, int B, int HW, int C,
+                                                                 uint8_t* __restrict__ y, int64_t y_ss, int ldy) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * ldy) return;
+  const int s = blockIdx.y;
+  const int b = (int)(idx / ldy), r = (int)(idx - (int64_t)b * ldy);
+  uint8_t v = 0;
+  if (r < C * HW) {
+    const int c = r / HW, p = r - c * HW;
+    v = x[(int64_t)s * x_ss + (int64_t)b * ldx + p * C + c];
+  }
+  y[(int64_t)s * y_ss + idx] = v;
+}
+
+QBNN_EXPORT int qbnn_flatten_nchw_rows_mc(const uint8_t* x, int64_t x_ss, int32_t ldx, int32_t B, int32_t HW, int32_t C, uint8_t* y, int64_t y_ss,
+                                          int32_t ldy, int32_t n_samples, void* stream) {
+  if (!x || !y || B <= 0 || HW <= 0 || C <= 0 || n_samples <= 0 || ldx < HW * C || ldy < HW * C)
+    return fail(QBNN_E_INVALID, "qbnn_flatten_nchw_rows_mc: bad argument%s");
+  const int64_t total = (int64_t)B * ldy;
+  hipLaunchKernelGGL(flatten_nchw_rows_kernel, dim3((unsigned)((total + 255) / 256), n_samples), dim3(256), 0, (hipStream_t)stream,
+                     x, x_ss, ldx, B, HW, C, y, y_ss, ldy);
+  return check_launch("qbnn_flatten_nchw_rows_mc");
+}
+
 QBNN_EXPORT int qbnn_flatten_nchw_mc(const uint8_t* x, int64_t x_ss, int32_t B, int32_t HW, int32_t C, uint8_t* y, int64_t y_ss,
                                      int32_t n_samples, void* stream) {
   if (!x || !y || B <= 0 || HW <= 0 || C <= 0 || n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_flatten_nchw_mc: bad argument%s");

@@ -266,9 +266,18 @@ class _BBBInt8(nn.Module):
         self._packed = dict(device=device, mu=out[0], sigma=out[1], cout=cout, k=k, krow=krow, nbytes=int(nbytes), sp=sp, bias=bias)
         return self._packed
 
+    def set_layout(self, layout, krow=None):
+        """Packed layout of this layer's mu / sigma / sampled weights (the small networks switch between the row-major form of the
+        any-geometry kernel and the fragment form of their own kernels); a change drops the packed copies."""
+        if layout != self.layout or krow != getattr(self, "krow_override", None):
+            self.layout, self.krow_override = layout, krow
+            self._packed, self._presampled = None, None
+
     def _krow(self, w_ohwi):
         """Bytes of one kernel row (kw, c) in the OHWI weight: the unit the packed K axis is padded by.  The 3-channel
         first layer runs as a 1x1 conv over 27-tap im2col patches, so its whole K is one row."""
+        if getattr(self, "krow_override", None):
+            return int(self.krow_override)
         if w_ohwi.ndim == 4 and w_ohwi.shape[3] % 8 == 0:
             return int(w_ohwi.shape[2] * w_ohwi.shape[3])
         return int(np.prod(w_ohwi.shape[1:]))

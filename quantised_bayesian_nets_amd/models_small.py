@@ -9,7 +9,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .layers import LAYOUT_ROWMAJOR, Conv2d, Linear, LinearReLU, MCQTensor, _MC, mc_context, sample_all_weights
+import ctypes as C
+
+from .layers import LAYOUT_MFMA32, LAYOUT_ROWMAJOR, Conv2d, Linear, LinearReLU, MCQTensor, _MC, mc_context, sample_all_weights, timed
 from .models import QuantStub
 from .models_mc import MaxPool2dQ
 from .quant import UINT_BOUNDS, check_bits
@@ -67,15 +69,78 @@ class ConvNetwork_LeNet(_SmallBase):
     def stochastic_layer_names(self):
         return ["layers.0", "layers.2", "layers.5", "layers.7"]
 
+    fast_path = True        # False: every layer on the any-geometry kernel (the recording / A-B path)
+
+    def _can_run_fast(self, x, record):
+        l2 = self.layers[2]
+        return (self.fast_path and record is None and not self.deterministic and tuple(x.shape[1:]) == (1, 28, 28) and self.a_hi <= 127
+                and all(0 <= m.zero_point <= 127 for m in self.stochastic_layers()) and 0 <= self.quant.zero_point <= 127
+                and all(m.bias_ is None for m in self.stochastic_layers()))
+
+    def _set_layouts(self, fast):
+        l0, l2, l5, l7 = self.stochastic_layers()
+        l0.set_layout(LAYOUT_ROWMAJOR)
+        if fast:      # fragment layouts of qbnn_conv_pool_drop_i8_mc (krow = k * Cin) and qbnn_linear_i8_mc (krow = K)
+            l2.set_layout(LAYOUT_MFMA32, 5 * 20); l5.set_layout(LAYOUT_MFMA32, 50 * 7 * 7); l7.set_layout(LAYOUT_MFMA32, 500)
+        else:
+            l2.set_layout(LAYOUT_ROWMAJOR); l5.set_layout(LAYOUT_ROWMAJOR); l7.set_layout(LAYOUT_ROWMAJOR)
+
+    def _forward_fast(self, h, S, dev):
+        """layers.2 .. softmax on the small networks' own kernels with per-sample (sampled) weights: conv 20 -> 50 + clamp + max-pool + Flatten
+        (NHWC rows) in one launch, a pitched NHWC -> NCHW flatten (the stochastic LinearReLU's noise follows the reference's column order),
+        two int8 GEMMs, softmax.  Same bits as the any-geometry kernels."""
+        L = _lib.lib()
+        l2, l5, l7 = self.layers[2], self.layers[5], self.layers[7]
+        B = h.data.shape[1]
+
+        def desc(m, x, Bn, H, Cin, Cout, ks, pad, relu):
+            c = _lib.ConvDesc()
+            c.B, c.H, c.W, c.Cin, c.Cout, c.ksize, c.stride, c.pad = Bn, H, H, Cin, Cout, ks, 1, pad
+            c.s_x, c.z_x, c.s_w, c.z_w = x.scale, x.zero_point, m.add_weight.scale, m.add_weight.zero_point
+            c.s_y, c.z_y, c.relu, c.a_hi, c.has_bias = m.scale, m.zero_point, int(relu), self.a_hi, 0
+            return c
+
+        w2, w5, w7 = l2.sample_weights(dev), l5.sample_weights(dev), l7.sample_weights(dev)
+        ld = (7 * 7 * 50 + 15) // 16 * 16
+        rows = torch.empty((S, B, ld), dtype=torch.uint8, device=dev)
+        c2 = desc(l2, h, B, 14, 20, 50, 5, 2, False)
+        with timed("conv_pool_drop_i8 20->50 k5 (sampled)"):
+            _lib.check(L.qbnn_conv_pool_drop_i8_mc(_lib.ptr(h.data), h.sample_stride(), _lib.ptr(w2), w2.shape[1], None, _lib.ptr(rows), rows[0].numel(), ld, S,
+                                                   C.byref(c2), 1, None, None, None, None, 0.0, 0, _MC.seed, _MC.sample_begin, _lib.current_stream()))
+        flat = torch.empty((S, B, ld), dtype=torch.uint8, device=dev)
+        with timed("flatten_nchw_rows"):
+            _lib.check(L.qbnn_flatten_nchw_rows_mc(_lib.ptr(rows), rows[0].numel(), ld, B, 49, 50, _lib.ptr(flat), flat[0].numel(), ld, S, _lib.current_stream()))
+        x5 = MCQTensor(flat, l2.scale, l2.zero_point)
+        ld5 = (500 + 15) // 16 * 16
+        y5 = torch.empty((S, B, ld5), dtype=torch.uint8, device=dev)
+        c5 = desc(l5, x5, B, 1, 2450, 500, 1, 0, True)
+        with timed("linear_i8 2450->500 (sampled)"):
+            _lib.check(L.qbnn_linear_i8_mc(_lib.ptr(flat), flat[0].numel(), ld, _lib.ptr(w5), w5.shape[1], None, _lib.ptr(y5), y5[0].numel(), ld5, S, C.byref(c5),
+                                           None, None, _MC.seed, _MC.sample_begin, _lib.current_stream()))
+        x7 = MCQTensor(y5, l5.scale, l5.zero_point)
+        y7 = torch.empty((S, B, self.output_size), dtype=torch.uint8, device=dev)
+        c7 = desc(l7, x7, B, 1, 500, self.output_size, 1, 0, False)
+        with timed("linear_i8 500->%d (sampled)" % self.output_size):
+            _lib.check(L.qbnn_linear_i8_mc(_lib.ptr(y5), y5[0].numel(), ld5, _lib.ptr(w7), w7.shape[1], None, _lib.ptr(y7), y7[0].numel(), self.output_size, S,
+                                           C.byref(c7), None, None, _MC.seed, _MC.sample_begin, _lib.current_stream()))
+        probs = torch.empty((S, B, self.output_size), dtype=torch.float32, device=dev)
+        _lib.check(L.qbnn_dequant_softmax_mc(_lib.ptr(y7), y7[0].numel(), B, self.output_size, l7.scale, l7.zero_point, _lib.ptr(probs), S, _lib.current_stream()))
+        return probs
+
     def forward_mc(self, x, record=None):
         if x.device.type != "cuda":
             raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
         S, dev = _MC.samples, x.device
         rec = (lambda k, v: record.__setitem__(k, v)) if record is not None else (lambda k, v: None)
+        fast = self._can_run_fast(x, record)
+        if not self.deterministic:
+            self._set_layouts(fast)
         h = _quantize(x.to(torch.float32).contiguous(), self.quant, self.a_hi); rec("quant.out", h.data)
         if not self.deterministic:
             sample_all_weights(self.stochastic_layers(), dev)
         h = self.layers[0]._conv(h, self.layers[0].sample_weights(dev), S); rec("layers.0.out", h.data)
+        if fast:
+            return self._forward_fast(self.layers[1](h), S, dev)
         h = self.layers[1](h); rec("layers.1.out", h.data)
         h = self.layers[2]._conv(h, self.layers[2].sample_weights(dev), S); rec("layers.2.out", h.data)
         h = self.layers[3](h); rec("layers.3.out", h.data)

@@ -438,6 +438,33 @@ def test_small_bbb_int8_graphs_match_reference(golden_lenet_bbb, golden_mlp_bbb_
     np.testing.assert_allclose(mean.cpu().numpy(), mm["mu"].mean(0), rtol=1e-5, atol=1e-6)
 
 
+def test_lenet_bbb_fast_path_equals_generic_kernels_and_reference(golden_lenet_bbb):
+    """int8 BBB LeNet with sampled weights on the small networks' own kernels (fused conv + pool + Flatten, pitched NHWC -> NCHW flatten,
+    int8 GEMMs; the sampler writes the fragment layouts) against the any-geometry kernels: bit-identical probabilities on the fixture's
+    batch, on a ragged batch and at a sample offset; and the fixture's recorded probabilities from the real reference through the fast path."""
+    import quantised_bayesian_nets_amd as q
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+    g = golden_lenet_bbb
+    m = q.ModelFactory.get_model("conv_lenet_bbb", [1, 1, 28, 28], 10, True, args).load_reference_state(g["state"])
+    S, seed = g["probs"].shape[0], g["meta"]["philox_seed"]
+    xg = torch.from_numpy(g["x"]).cuda()
+    assert m._can_run_fast(xg, None)
+    with q.mc_context(S, seed, 0):
+        fast = m.forward_mc(xg)
+    np.testing.assert_allclose(fast.cpu().numpy(), g["probs"], rtol=RTOL, atol=1e-8)
+    x = torch.rand(37, 1, 28, 28, generator=torch.Generator().manual_seed(3)).cuda()
+    for sb in (0, 250):
+        with q.mc_context(5, 11, sb):
+            a = m.forward_mc(x)
+            m.fast_path = False
+            try:
+                b = m.forward_mc(x)
+            finally:
+                m.fast_path = True
+            c = m.forward_mc(x)                         # and back: the packed layouts switch with the path
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_errors_are_loud():
     from quantised_bayesian_nets_amd import _lib
     d = _lib.ConvDesc()
