@@ -349,6 +349,16 @@ int qbnn_conv_pool_drop_i8_mc(const uint8_t* x, int64_t x_sample_stride, const i
                               const qbnn_dropout_desc* drop_in, const float* mask_in_in, float s_in, int32_t z_in,
                               uint64_t seed, uint32_t sample_begin, void* stream);
 
+/* LeNet's first conv with sampled weights (bbb/models_bbb.py:120-133 layers.0 -> layers.1): k x k conv on a ONE-channel image -> clamp ->
+ * MaxPool2d(2,2) in one launch.  qbnn_im2col5x5_c1 builds the centred 25-tap patches [B][H * W][32] (int8, taps in (kh, kw) order, 7 zero
+ * bytes) once per batch; the conv is then one MFMA per 32 pixels against the sample's fragment tile (weights packed / sampled with
+ * krow = k = 25: 1 KiB per sample) and only the pooled map y [S][B][H/2][W/2][Cout] is written.  Same bits as
+ * qbnn_conv2d_i8_generic_mc -> qbnn_maxpool2_q_mc.  Built geometry: 28 x 28, 1 -> 20, 5 x 5, pad 2; desc->relu must be 0. */
+int qbnn_im2col5x5_c1(const uint8_t* x, int32_t B, int32_t H, int32_t W, int32_t z_x, int8_t* out, void* stream);
+int qbnn_conv_c1_pool_i8_mc(const int8_t* patches, int64_t patches_sample_stride, const int8_t* w_packed, int64_t w_sample_stride,
+                            const float* bias, uint8_t* y, int64_t y_sample_stride, int32_t n_samples, const qbnn_conv_desc* host_desc,
+                            void* stream);
+
 /* Linear / LinearReLU (desc: B rows, Cin = K, Cout = N, H = W = ksize = stride = 1; weights packed with krow = k = K) -> clamp
  * [-> BernoulliDropout on the 2-D activation: one draw per element, index b * N + n]: x [S|1][B][ldx] (ldx % 16 == 0, bytes K..ldx-1
  * ignored), y [S][B][ldy] (ldy % 4 == 0, bytes N..ldy-1 written 0; or ldy == N: dense rows).  mask_in fp32 [S][B][N]: parity mode. */

@@ -94,7 +94,7 @@ class HeadCall(C.Structure):
                 ("probs", C.c_void_p), ("n_samples", C.c_int32), ("desc", C.POINTER(HeadDesc))]
 
 
-EXPORTS = ["qbnn_mlp_bbb_f32_mc", "qbnn_mlp_bbb_f32_workspace_floats", "qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_set_device_noise_source", "qbnn_conv2d_i8_mc", "qbnn_conv2d_i8_post_mc", "qbnn_conv_pool_drop_i8_mc", "qbnn_linear_i8_mc",
+EXPORTS = ["qbnn_mlp_bbb_f32_mc", "qbnn_mlp_bbb_f32_workspace_floats", "qbnn_packed_weight_bytes", "qbnn_pack_weights_host", "qbnn_sample_weights_i8", "qbnn_sample_weights_i8_multi", "qbnn_set_device_noise_source", "qbnn_conv2d_i8_mc", "qbnn_conv2d_i8_post_mc", "qbnn_conv_pool_drop_i8_mc", "qbnn_linear_i8_mc", "qbnn_im2col5x5_c1", "qbnn_conv_c1_pool_i8_mc",
            "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_drop_i8_mc", "qbnn_stem_chain_drop_i8_mc", "qbnn_block_down_drop_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_chain_multi_args_bytes", "qbnn_down_multi_args_bytes", "qbnn_block_chain_i8_multi_prepare", "qbnn_block_chain_i8_multi_launch", "qbnn_block_down_i8_multi_prepare", "qbnn_block_down_i8_multi_launch", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_conv2d_i8_generic_mc", "qbnn_conv2d_i8_generic_scalar_mc", "qbnn_dropout_q_mc", "qbnn_maxpool2_q_mc",
            "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_flatten_nchw_rows_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
@@ -126,6 +126,8 @@ def lib():
         L.qbnn_conv2d_i8_post_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, C.POINTER(ConvDesc), C.POINTER(PostDesc), vp, vp, i64, u64, u32, vp]
         L.qbnn_conv_pool_drop_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, C.POINTER(ConvDesc), i32, C.POINTER(DropoutDesc), vp,
                                                 C.POINTER(DropoutDesc), vp, f, i32, u64, u32, vp]
+        L.qbnn_im2col5x5_c1.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+        L.qbnn_conv_c1_pool_i8_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, C.POINTER(ConvDesc), vp]
         L.qbnn_linear_i8_mc.argtypes = [vp, i64, i32, vp, i64, vp, vp, i64, i32, i32, C.POINTER(ConvDesc), C.POINTER(DropoutDesc), vp, u64, u32, vp]
         L.qbnn_block_chain_i8_mc.argtypes = [vp, i64, f, i32, i32, i32, i32, i32, C.POINTER(BlockDesc), i32, vp, i64, i32, vp]
         L.qbnn_stem_chain_i8_mc.argtypes = [vp, i32, vp, i64, vp, f, f, i32, f, i32, i32, C.POINTER(BlockDesc), i32, vp, i64, i32, vp]

@@ -478,7 +478,110 @@ __global__ __launch_bounds__(256) void linear_i8_kernel(const LinearArgs a) {
   }
 }
 
+// ---- k x k conv on a ONE-channel image + clamp + MaxPool2d(2,2): LeNet's first conv with per-sample (sampled) weights -----------------
+// (bbb/models_bbb.py:120-133 layers.0 -> layers.1.)  With one input channel the whole receptive field of a pixel is k * k = 25 bytes:
+// the centred patches [B][H * W][32] are built once per batch (qbnn_im2col5x5_c1; the network input is shared by the MC samples) and a
+// 32-pixel tile of the conv is ONE MFMA against the sample's single weight fragment (<= 31 output channels + the ones row of the
+// QBNN_LAYOUT_MFMA32 layout = the window sum).  A tile is 2 image rows x W / 2 columns, so the 2 x 2 pooling window of a pixel lives in
+// lanes l, l ^ 1, l +- W / 2 of the same wave: the conv output never reaches memory, only the pooled map [S][B][H/2][W/2][COUT] does.
+struct Conv1Args {
+  const int8_t* patches; int64_t p_ss;      // [S | 1][B][H * W][32]
+  const int8_t* w; int64_t w_ss;            // [S | 1][1024]: the layer's fragment tile
+  uint8_t* y; int64_t y_ss;
+  int B; Requant q; float vlo, vhi;
+};
+
+__device__ __forceinline__ int half_sum32(int v) {             // lane l gets v(l & 31) + v((l & 31) + 32)
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return (int)r[0] + (int)r[1];
+}
+
+template <int W, int COUT>
+__global__ __launch_bounds__(256) void conv_c1_pool_kernel(const Conv1Args a) {
+  constexpr int TW = W / 2, NTILE = W;                         // W / 2 row pairs x 2 column halves
+  static_assert(2 * TW <= 32 && (TW % 2) == 0 && (COUT % 4) == 0 && COUT < 32, "tile = 2 rows x W/2 columns of one wave half; channel groups of 4");
+  constexpr int OJ = 4 * (COUT / 8) + (COUT & 3), OH = (COUT >> 2) & 1;      // accumulator register / lane half of the ones row (row COUT)
+  const int s = blockIdx.y, b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const bool act = r < 2 * TW;
+  const int pr = r / TW, pc = r - pr * TW;
+  const v4i wf = *reinterpret_cast<const v4i*>(a.w + (int64_t)s * a.w_ss + lane * 16);
+  const int8_t* pb = a.patches + (int64_t)s * a.p_ss + (int64_t)b * W * W * 32 + 16 * h;
+  uint8_t* yb = a.y + (int64_t)s * a.y_ss + (int64_t)b * (W / 2) * (W / 2) * COUT + 4 * h;
+  const float zy = (float)a.q.z_y;
+  const int partner = pr == 0 ? lane + TW : lane - TW;         // the pixel one row down / up
+  for (int t = wave; t < NTILE; t += 4) {
+    const int i = t >> 1, c = t & 1;
+    v4i xf = {0, 0, 0, 0};
+    if (act) xf = *reinterpret_cast<const v4i*>(pb + ((2 * i + pr) * W + c * TW + pc) * 32);
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf, zero16, 0, 0, 0);
+    const int zwr = a.q.z_w * half_sum32(h == OH ? acc[OJ] : 0);
+    uint8_t* yo = yb + ((i * (W / 2)) + c * (TW / 2) + (pc >> 1)) * COUT;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      if (8 * g4 >= COUT) continue;                            // (a group beyond COUT on one half only: computed, never stored)
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float xv = (float)(acc[4 * g4 + k] - zwr);
+        if (a.q.bias) xv = __builtin_fmaf(a.q.bias[min(8 * g4 + 4 * h + k, COUT - 1)], a.q.rcp, xv);
+        v[k] = (med3f(xv * a.q.mult, a.vlo, a.vhi) + QBNN_MAGIC) + zy;
+      }
+      uint32_t d = pack_low_bytes(v[0], v[1], v[2], v[3]);
+      d = max4_u7(d, (uint32_t)__shfl_xor((int)d, 1));
+      d = max4_u7(d, (uint32_t)__shfl((int)d, partner));
+      if (act && pr == 0 && (pc & 1) == 0 && 8 * g4 + 4 * h < COUT) *reinterpret_cast<uint32_t*>(yo + 8 * g4) = d;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void im2col5x5_c1_kernel(const uint8_t* __restrict__ x, int B, int H, int W, int z_x, int8_t* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * H * W) return;
+  const int b = (int)(idx / (H * W)), p = (int)(idx - (int64_t)b * H * W), oh = p / W, ow = p - oh * W;
+  const uint8_t* xb = x + (int64_t)b * H * W;
+  uint32_t wd[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 25; ++k) {
+    const int ih = oh + k / 5 - 2, iw = ow + k % 5 - 2;
+    const int v = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? (int)xb[ih * W + iw] - z_x : 0;
+    wd[k >> 2] |= (uint32_t)(v & 0xff) << (8 * (k & 3));
+  }
+  v4i* o = reinterpret_cast<v4i*>(out + idx * 32);
+  o[0] = v4i{(int)wd[0], (int)wd[1], (int)wd[2], (int)wd[3]};
+  o[1] = v4i{(int)wd[4], (int)wd[5], (int)wd[6], (int)wd[7]};
+}
+
 }  // namespace
+
+QBNN_EXPORT int qbnn_im2col5x5_c1(const uint8_t* x, int32_t B, int32_t H, int32_t W, int32_t z_x, int8_t* out, void* stream) {
+  if (!x || !out || B <= 0 || H <= 0 || W <= 0 || z_x < 0 || z_x > 127) return failf(QBNN_E_INVALID, "qbnn_im2col5x5_c1: bad argument");
+  const int64_t n = (int64_t)B * H * W;
+  hipLaunchKernelGGL(im2col5x5_c1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, H, W, z_x, out);
+  return qbnn_check_launch_msg("qbnn_im2col5x5_c1");
+}
+
+QBNN_EXPORT int qbnn_conv_c1_pool_i8_mc(const int8_t* patches, int64_t patches_ss, const int8_t* w_packed, int64_t w_ss, const float* bias,
+                                        uint8_t* y, int64_t y_ss, int32_t n_samples, const qbnn_conv_desc* d, void* stream) {
+  if (!patches || !w_packed || !y || !d || n_samples <= 0 || d->B <= 0) return failf(QBNN_E_INVALID, "qbnn_conv_c1_pool_i8_mc: bad argument");
+  if (d->has_bias && !bias) return failf(QBNN_E_INVALID, "qbnn_conv_c1_pool_i8_mc: has_bias set but bias is NULL");
+  if ((patches_ss & 15) || (w_ss & 15) || (reinterpret_cast<uintptr_t>(patches) & 15) || (reinterpret_cast<uintptr_t>(w_packed) & 15) ||
+      (reinterpret_cast<uintptr_t>(y) & 3) || (y_ss & 3))
+    return failf(QBNN_E_INVALID, "qbnn_conv_c1_pool_i8_mc: operands must be 16-byte (y: 4-byte) aligned");
+  if (d->relu) return failf(QBNN_E_INVALID, "qbnn_conv_c1_pool_i8_mc: plain conv only (the LeNet graphs have no ReLU behind their convs)");
+  Conv1Args a;
+  memset(&a, 0, sizeof(a));
+  a.patches = patches; a.p_ss = patches_ss; a.w = w_packed; a.w_ss = w_ss; a.y = y; a.y_ss = y_ss; a.B = d->B;
+  if (int rc = fill_requant(a.q, d, bias)) return rc;
+  a.vlo = (float)(a.q.lo - a.q.z_y); a.vhi = (float)(a.q.hi - a.q.z_y);
+  if (d->H == 28 && d->W == 28 && d->Cin == 1 && d->Cout == 20 && d->ksize == 5 && d->stride == 1 && d->pad == 2) {
+    hipLaunchKernelGGL((conv_c1_pool_kernel<28, 20>), dim3((unsigned)d->B, (unsigned)n_samples), dim3(256), 0, (hipStream_t)stream, a);
+    return qbnn_check_launch_msg("qbnn_conv_c1_pool_i8_mc");
+  }
+  return failf(QBNN_E_INVALID, "qbnn_conv_c1_pool_i8_mc: unsupported geometry (built: 28x28, 1 -> 20, 5x5, pad 2)");
+}
 
 QBNN_EXPORT int qbnn_conv_pool_drop_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* w_packed, int64_t w_ss, const float* bias,
                                           uint8_t* y, int64_t y_ss, int32_t ldy, int32_t n_samples, const qbnn_conv_desc* d,

@@ -79,7 +79,7 @@ class ConvNetwork_LeNet(_SmallBase):
 
     def _set_layouts(self, fast):
         l0, l2, l5, l7 = self.stochastic_layers()
-        l0.set_layout(LAYOUT_ROWMAJOR)
+        l0.set_layout(LAYOUT_MFMA32 if fast else LAYOUT_ROWMAJOR)      # fast: one fragment tile (krow = k = 25) for qbnn_conv_c1_pool_i8_mc
         if fast:      # fragment layouts of qbnn_conv_pool_drop_i8_mc (krow = k * Cin) and qbnn_linear_i8_mc (krow = K)
             l2.set_layout(LAYOUT_MFMA32, 5 * 20); l5.set_layout(LAYOUT_MFMA32, 50 * 7 * 7); l7.set_layout(LAYOUT_MFMA32, 500)
         else:
@@ -138,9 +138,23 @@ class ConvNetwork_LeNet(_SmallBase):
         h = _quantize(x.to(torch.float32).contiguous(), self.quant, self.a_hi); rec("quant.out", h.data)
         if not self.deterministic:
             sample_all_weights(self.stochastic_layers(), dev)
-        h = self.layers[0]._conv(h, self.layers[0].sample_weights(dev), S); rec("layers.0.out", h.data)
         if fast:
-            return self._forward_fast(self.layers[1](h), S, dev)
+            # layers.0 + layers.1: patches of the shared input once, then one MFMA per 32 pixels and sample; only the pooled map is written
+            l0, L = self.layers[0], _lib.lib()
+            B = h.data.shape[1]
+            col = torch.empty((B, 28 * 28, 32), dtype=torch.int8, device=dev)
+            _lib.check(L.qbnn_im2col5x5_c1(_lib.ptr(h.data), B, 28, 28, h.zero_point, _lib.ptr(col), _lib.current_stream()))
+            w0 = l0.sample_weights(dev)
+            c0 = _lib.ConvDesc()
+            c0.B, c0.H, c0.W, c0.Cin, c0.Cout, c0.ksize, c0.stride, c0.pad = B, 28, 28, 1, 20, 5, 1, 2
+            c0.s_x, c0.z_x, c0.s_w, c0.z_w = h.scale, h.zero_point, l0.add_weight.scale, l0.add_weight.zero_point
+            c0.s_y, c0.z_y, c0.relu, c0.a_hi, c0.has_bias = l0.scale, l0.zero_point, 0, self.a_hi, 0
+            p1 = torch.empty((S, B, 14, 14, 20), dtype=torch.uint8, device=dev)
+            with timed("conv_c1_pool_i8 1->20 k5 (sampled)"):
+                _lib.check(L.qbnn_conv_c1_pool_i8_mc(_lib.ptr(col), 0, _lib.ptr(w0), w0.shape[1], None, _lib.ptr(p1), p1[0].numel(), S, C.byref(c0),
+                                                     _lib.current_stream()))
+            return self._forward_fast(MCQTensor(p1, l0.scale, l0.zero_point), S, dev)
+        h = self.layers[0]._conv(h, self.layers[0].sample_weights(dev), S); rec("layers.0.out", h.data)
         h = self.layers[1](h); rec("layers.1.out", h.data)
         h = self.layers[2]._conv(h, self.layers[2].sample_weights(dev), S); rec("layers.2.out", h.data)
         h = self.layers[3](h); rec("layers.3.out", h.data)
