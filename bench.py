@@ -107,6 +107,20 @@ def _wl_lenet_mc(a, world, q, load_golden):
                 describe="configs[1]: MNIST-shaped LeNet MC-Dropout (p=0.2), A7/W8 int8, %d MC samples per GPU per step, batch=%d" % (S, B))
 
 
+def _wl_lenet_bbb(a, world, q, load_golden):
+    """SURVEY 8 row a6 `conv_lenet_bbb`: MNIST-shaped LeNet, int8 Bayes-by-backprop (sampled weights in every layer), 100 MC samples, batch 128."""
+    g = load_golden("lenet_bbb_a7w8.npz")
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+    model = q.ModelFactory.get_model("conv_lenet_bbb", [1, 1, 28, 28], 10, True, args).load_reference_state(g["state"])
+    S = a.samples if a.samples > 0 else 100
+    B = 128 if a.batch == 256 else a.batch
+    x_host = torch.rand(B, 1, 28, 28, generator=torch.Generator().manual_seed(2))
+    return dict(golden=g, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=False, cpu_baseline=False,
+                step=lambda m, x, S_, seed: q.mc_predict(m, x, S_, seed), scaling="weak", dtype="int8",
+                metric="MC forward samples/sec, LeNet BBB int8 batch=%d" % B, unit="MC samples/s",
+                describe="conv_lenet_bbb: MNIST-shaped LeNet Bayes-by-backprop, A7/W8 int8, %d MC samples per GPU per step, batch=%d" % (S, B))
+
+
 def _wl_resnet_mc(a, world, q, load_golden):
     """SURVEY 8 row a6 `conv_resnet_mc`: ResNet-18 with a quantised channel dropout behind every conv, deterministic int8 weights."""
     g = load_golden("resnet_mc_a7w8.npz")
@@ -157,7 +171,7 @@ def _wl_resnet_float(kind):
 
 
 WORKLOADS = {"resnet_bbb": _wl_resnet(0, 100, "configs[2]"), "resnet_f32": _wl_resnet_float("f32"), "resnet_qat": _wl_resnet_float("qat"), "resnet_bbb_w4": _wl_resnet(4, 128, "configs[4] (A7/W4, 1024 samples over 8 GPUs = 128 per GPU)"),
-             "ensemble16": _wl_ensemble16, "lenet_mc": _wl_lenet_mc, "mlp_f32": _wl_mlp_f32, "resnet_mc": _wl_resnet_mc}
+             "ensemble16": _wl_ensemble16, "lenet_mc": _wl_lenet_mc, "lenet_bbb": _wl_lenet_bbb, "mlp_f32": _wl_mlp_f32, "resnet_mc": _wl_resnet_mc}
 
 
 def cpu_baseline(a, g, x_host, seed):
@@ -197,7 +211,7 @@ def cpu_baseline(a, g, x_host, seed):
             "_p_oracle_sample0": p_or}
 
 
-SECONDARY = ("resnet_bbb_w4", "ensemble16", "lenet_mc", "mlp_f32", "resnet_mc", "resnet_f32", "resnet_qat")
+SECONDARY = ("resnet_bbb_w4", "ensemble16", "lenet_mc", "lenet_bbb", "mlp_f32", "resnet_mc", "resnet_f32", "resnet_qat")
 
 
 def secondary_workloads(a, q, load_golden, seed):

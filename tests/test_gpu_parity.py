@@ -1429,6 +1429,44 @@ def test_conv_pool_drop_small_map_against_generic_kernels():
         assert bool((y[:, :, width:] == 0).all())
 
 
+def test_conv_c1_pool_against_generic_kernels():
+    """qbnn_im2col5x5_c1 + qbnn_conv_c1_pool_i8_mc (LeNet's first conv: one input channel, per-sample weights, max-pool in the wave) through
+    the C ABI against qbnn_conv2d_i8_generic_mc -> qbnn_maxpool2_q_mc: random quantisation parameters (negative weight zero point included),
+    with and without bias, a batch of 5, the input shared by the samples.  Bit-exact."""
+    import ctypes as C
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(31)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    S, B = 4, 5
+    nb = L.qbnn_packed_weight_bytes(20, 25, 25, 0)
+    assert nb == 1024
+    for case, (z_x, z_w, z_y, s_y, has_bias) in enumerate([(0, 0, 64, 0.9, 0), (33, -7, 5, 2.5, 1), (127, 11, 120, 0.4, 1)]):
+        w = torch.randint(-128, 128, (S, 20, 5, 5, 1), generator=gen, dtype=torch.int32).to(torch.int8)
+        wp = np.zeros((S, nb), np.int8)
+        for si in range(S):
+            wn = np.ascontiguousarray(w[si].numpy().reshape(20, 25))
+            _lib.check(L.qbnn_pack_weights_host(wn.ctypes.data_as(C.c_void_p), 20, 25, 25, 0, wp[si].ctypes.data_as(C.c_void_p)))
+        wp, wd = torch.from_numpy(wp).cuda(), w.cuda().contiguous()
+        bias = (torch.randn(20, generator=gen) * 3).float().cuda()
+        x = torch.randint(0, 128, (1, B, 28, 28, 1), generator=gen, dtype=torch.int32).to(torch.uint8).cuda()
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.pad = B, 28, 28, 1, 20, 5, 1, 2
+        d.s_x, d.z_x, d.s_w, d.z_w, d.s_y, d.z_y = 0.03, z_x, 0.011, z_w, s_y, z_y
+        d.relu, d.a_hi, d.has_bias = 0, 127, has_bias
+        yc = torch.empty((S, B, 28, 28, 20), dtype=torch.uint8, device="cuda")
+        _lib.check(L.qbnn_conv2d_i8_generic_mc(_lib.ptr(x), 0, _lib.ptr(wd), 500, _lib.ptr(bias) if has_bias else None, _lib.ptr(yc), B * 15680, S, C.byref(d), st))
+        ref = torch.empty((S, B, 14, 14, 20), dtype=torch.uint8, device="cuda")
+        _lib.check(L.qbnn_maxpool2_q_mc(_lib.ptr(yc), B * 15680, B, 28, 28, 20, 127, _lib.ptr(ref), B * 3920, S, st))
+        col = torch.empty((B, 784, 32), dtype=torch.int8, device="cuda")
+        _lib.check(L.qbnn_im2col5x5_c1(_lib.ptr(x), B, 28, 28, z_x, _lib.ptr(col), st))
+        y = torch.full((S, B, 14, 14, 20), 0xCD, dtype=torch.uint8, device="cuda")
+        _lib.check(L.qbnn_conv_c1_pool_i8_mc(_lib.ptr(col), 0, _lib.ptr(wp), nb, _lib.ptr(bias) if has_bias else None, _lib.ptr(y), B * 3920, S, C.byref(d), st))
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref), case
+        assert len(torch.unique(ref)) > 8, "the case must not saturate"
+
+
 def test_lenet_mc_full_sample_count_against_oracle(golden_lenet_mc):
     """BASELINE config 1 at its full MC size: 100 samples (global sample indices 0..99) of the MC-Dropout LeNet on the fused kernels
     (qbnn_conv_pool_drop_i8_mc / qbnn_linear_i8_mc), every sample's probabilities against the oracle at batch 16; the captured-graph
