@@ -221,7 +221,7 @@ int qbnn_block_down_drop_i8_mc(const uint8_t* x, int64_t x_sample_stride, float 
  * reference sgld/models_sgld.py:214-288: `Network` holds args.samples deterministic members, each a converted network of its own
  * (own weights, biases AND quantisation parameters), evaluated one after the other.  Members cannot ride the MC-sample
  * dimension of the calls above (qparams are per call), so these entry points take an ARRAY of calls and run them side by
- * side in one grid (any n_calls; the library splits them into launches of up to 8 -- 4 with the fused stem).  Every call
+ * side in one grid (any n_calls; the library splits them into launches of up to 8 -- 4 with the fused stem, 32 for the head).  Every call
  * means exactly what the single-call entry point means; all calls of one array share the geometry arguments. */
 typedef struct qbnn_chain_call {
   const uint8_t* x; int64_t x_sample_stride; float s_x; int32_t z_x;      /* as qbnn_block_chain_i8_mc (unused behind the stem) */

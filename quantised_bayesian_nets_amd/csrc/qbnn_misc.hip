@@ -274,11 +274,13 @@ QBNN_EXPORT int qbnn_head_i8_mc(const uint8_t* x, int64_t x_ss, const int8_t* w,
   return check_launch("qbnn_head_i8_mc");
 }
 
+#define QBNN_HEAD_CALLS 32           // a head's argument block is 96 bytes: 32 of them fit the 4 KiB of kernel arguments (one launch for a 16-member ensemble)
+static_assert(sizeof(ArgsArr<HeadArgs, QBNN_HEAD_CALLS>) <= 3840, "kernel arguments are limited to 4 KiB");
 QBNN_EXPORT int qbnn_head_i8_multi(const qbnn_head_call* calls, int32_t n_calls, void* stream) {
   if (!calls || n_calls <= 0) return fail(QBNN_E_INVALID, "qbnn_head_i8_multi: bad argument%s");
   for (int c0 = 0; c0 < n_calls;) {
-    const int n = n_calls - c0 < QBNN_FUSED_CALLS ? n_calls - c0 : QBNN_FUSED_CALLS;
-    ArgsArr<HeadArgs, QBNN_FUSED_CALLS> all;
+    const int n = n_calls - c0 < QBNN_HEAD_CALLS ? n_calls - c0 : QBNN_HEAD_CALLS;
+    ArgsArr<HeadArgs, QBNN_HEAD_CALLS> all;
     memset(&all, 0, sizeof(all));
     int maxB = 0, maxS = 0;
     for (int i = 0; i < n; ++i) {
@@ -288,7 +290,7 @@ QBNN_EXPORT int qbnn_head_i8_multi(const qbnn_head_call* calls, int32_t n_calls,
       if (k.n_samples != calls[c0].n_samples) return fail(QBNN_E_INVALID, "qbnn_head_i8_multi: the calls of one launch evaluate the same number of samples%s");
       maxB = k.desc->B > maxB ? k.desc->B : maxB; maxS = k.n_samples;
     }
-    hipLaunchKernelGGL(head_i8_kernel<QBNN_FUSED_CALLS>, dim3(ceil_div(maxB, 4 * QBNN_HEAD_IMGS), maxS, n), dim3(256), 0, (hipStream_t)stream, all);
+    hipLaunchKernelGGL(head_i8_kernel<QBNN_HEAD_CALLS>, dim3(ceil_div(maxB, 4 * QBNN_HEAD_IMGS), maxS, n), dim3(256), 0, (hipStream_t)stream, all);
     if (int rc = check_launch("qbnn_head_i8_multi")) return rc;
     c0 += n;
   }
