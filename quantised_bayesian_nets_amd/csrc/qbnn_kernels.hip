@@ -290,6 +290,57 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
     }
     return;
   }
+  if (L.layout == QBNN_LAYOUT_MFMA32) {
+    // Any K / kernel-row length (layers.0: K = 27; LeNet's 2450-wide Linear): the chunk's 16 weights are still CONSECUTIVE elements
+    // idx0 .. idx0 + 15 of the reference's order (a chunk never straddles a padded kernel row), only not aligned to a Philox block:
+    // five blocks cover them, and a lane picks its 16 words at offset idx0 & 3.  Uniform control flow -- the element-wise form below
+    // re-draws a block wherever ANY lane of the wave crosses one, 8 - 16 times per chunk when the rows' alignments differ.  Same
+    // fp32 chain as the aligned path; padding bytes (row >= cout, byte >= krow) stay 0 (1 in the ones row).
+    const qbnn_sample_params& P = L.p;
+    const float tlo = (float)(-128 - P.z_mul), thi = (float)(127 - P.z_mul);
+    const float dl_mul = __builtin_fmaf(P.s_mul, (float)P.z_mul, P.nzs_mul);
+    const float wlo = (float)(max(-128, P.w_lo) - P.z_add), whi = (float)(min(127, P.w_hi) - P.z_add), zaf = (float)P.z_add;
+    const float zsf = (float)P.z_sigma;
+    float dw[16], sg[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      dw[j] = __builtin_fmaf(P.s_w, (float)((mw[j >> 2] << (24 - 8 * (j & 3))) >> 24), P.nzs_w);
+      sg[j] = (float)((sw[j >> 2] << (24 - 8 * (j & 3))) >> 24) - zsf;
+    }
+    const int64_t idx0 = (int64_t)n * L.K + kh * L.krow + j0;
+    const int sh = (int)(idx0 & 3);
+    const int nvalid = n < L.cout ? min(max(L.krow - j0, 0), 16) : 0;       // valid bytes of the chunk: 0 .. nvalid - 1
+    const int nones = ones_row ? min(max(L.krow - j0, 0), 16) : 0;
+#pragma unroll 1
+    for (int ss = 0; ss < QBNN_SAMPLER_NS; ++ss) {
+      const int s = s0 + ss;
+      if (s >= n_samples) break;
+      uint32_t W[20];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const qbnn::u32x4 r4 = qbnn::philox4x32_10((uint32_t)((idx0 >> 2) + t), L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi);
+        W[4 * t] = r4.x; W[4 * t + 1] = r4.y; W[4 * t + 2] = r4.z; W[4 * t + 3] = r4.w;
+      }
+      uint32_t ow[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = 4 * g + i;
+          const uint32_t ua = (sh & 1) ? W[j + 1] : W[j], ub = (sh & 1) ? W[j + 3] : W[j + 2];
+          const float ef = (float)eps_q_from_u32((sh & 2) ? ub : ua, eps_tab);
+          const float tq = __builtin_rintf(med3f((sg[j] * ef) * P.mul_multiplier, tlo, thi));
+          const float dt = __builtin_fmaf(P.s_mul, tq, dl_mul);
+          const float fv = (med3f((dw[j] + dt) * P.inv_s_add, wlo, whi) + QBNN_MAGIC) + zaf;
+          f[i] = j < nvalid ? fv : (j < nones ? 1.0f + QBNN_MAGIC : QBNN_MAGIC);      // low byte: the weight, the ones row's 1, or 0
+        }
+        ow[g] = pack_low_bytes(f[0], f[1], f[2], f[3]);
+      }
+      reinterpret_cast<v4i*>(L.out + (int64_t)s * L.out_ss)[chunk] = v4i{(int)ow[0], (int)ow[1], (int)ow[2], (int)ow[3]};
+    }
+    return;
+  }
 #pragma unroll 1
   for (int ss = 0; ss < QBNN_SAMPLER_NS; ++ss) {
     const int s = s0 + ss;
