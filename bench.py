@@ -148,6 +148,20 @@ def _wl_mlp_f32(a, world, q, load_golden):
                 describe="configs[0]: UCI-regression-shaped (in_dim %d) 4x100 MLP Bayes-by-backprop fp32, %d MC samples per GPU per step, 1000 rows" % (in_dim, S))
 
 
+def _wl_mlp_bbb(a, world, q, load_golden):
+    """SURVEY 8 row a6 `linear_bbb` with q=True: the UCI-regression-shaped MLP in its converted int8 form (sampled int8 weights), 10 MC samples, 1000 rows."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "mlp_bbb_a7w8.npz"), allow_pickle=True)
+    st = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+    model = q.ModelFactory.get_model("linear_bbb", [13], 1, True, args).load_reference_state(st)
+    S = a.samples if a.samples > 0 else 10
+    x_host = torch.randn(1000, 13, generator=torch.Generator().manual_seed(2))
+    return dict(golden=None, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=False, cpu_baseline=False,
+                step=lambda m, x, S_, seed: q.mc_predict_regression(m, x, S_, seed), scaling="weak", dtype="int8", graph=dict(regression=True),
+                metric="MC forward samples/sec, 4x100 MLP BBB int8, 1000 rows", unit="MC samples/s",
+                describe="linear_bbb (q=True): UCI-regression-shaped (in_dim 13) 4x100 MLP Bayes-by-backprop, A7/W8 int8, %d MC samples per GPU per step, 1000 rows" % S)
+
+
 def _wl_resnet_float(kind):
     """SURVEY 8a rows a1 / a2 at the headline's shape (B = 256): the float Bayes-by-backprop ResNet-18 (fp32 MFMA convs, per-sample
     weights) and its QAT form evaluated with live observers (fake-quantised tensors, fp64 conv sums; the MC samples are sequential
@@ -171,7 +185,7 @@ def _wl_resnet_float(kind):
 
 
 WORKLOADS = {"resnet_bbb": _wl_resnet(0, 100, "configs[2]"), "resnet_f32": _wl_resnet_float("f32"), "resnet_qat": _wl_resnet_float("qat"), "resnet_bbb_w4": _wl_resnet(4, 128, "configs[4] (A7/W4, 1024 samples over 8 GPUs = 128 per GPU)"),
-             "ensemble16": _wl_ensemble16, "lenet_mc": _wl_lenet_mc, "lenet_bbb": _wl_lenet_bbb, "mlp_f32": _wl_mlp_f32, "resnet_mc": _wl_resnet_mc}
+             "ensemble16": _wl_ensemble16, "lenet_mc": _wl_lenet_mc, "lenet_bbb": _wl_lenet_bbb, "mlp_bbb": _wl_mlp_bbb, "mlp_f32": _wl_mlp_f32, "resnet_mc": _wl_resnet_mc}
 
 
 def cpu_baseline(a, g, x_host, seed):
@@ -211,7 +225,7 @@ def cpu_baseline(a, g, x_host, seed):
             "_p_oracle_sample0": p_or}
 
 
-SECONDARY = ("resnet_bbb_w4", "ensemble16", "lenet_mc", "lenet_bbb", "mlp_f32", "resnet_mc", "resnet_f32", "resnet_qat")
+SECONDARY = ("resnet_bbb_w4", "ensemble16", "lenet_mc", "lenet_bbb", "mlp_f32", "mlp_bbb", "resnet_mc", "resnet_f32", "resnet_qat")
 
 
 def secondary_workloads(a, q, load_golden, seed):

@@ -975,10 +975,10 @@ def test_environment_switches_give_the_same_results(switch, tmp_path):
     assert r.returncode == 0 and "SWITCH-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_graphed_predictor_equals_eager(golden_w8, golden_lenet_mc, golden_mlp_f32, golden_ensemble):
+def test_graphed_predictor_equals_eager(golden_w8, golden_lenet_mc, golden_mlp_f32, golden_ensemble, golden_mlp_bbb_q, golden_lenet_bbb):
     """One captured HIP graph per (model, input shape), replayed with new inputs and new seeds (read from device memory):
     bit-identical to the eager `mc_predict` for the int8 BBB ResNet, the MC-Dropout LeNet (dropout masks), the fp32 BBB MLP
-    (regression reduction) and the 16-member ensemble."""
+    (regression reduction), the small int8 BBB graphs and the 16-member ensemble."""
     import quantised_bayesian_nets_amd as q
     from conftest import synth_ensemble_members
     gen = torch.Generator().manual_seed(31)
@@ -1010,6 +1010,22 @@ def test_graphed_predictor_equals_eager(golden_w8, golden_lenet_mc, golden_mlp_f
         a, b = gr(x, seed)
         c, d = q.mc_predict_regression(mm, x, 10, seed)
         assert torch.equal(a, c) and torch.equal(b, d)
+    # the small int8 BBB graphs (sampled weights in the fragment / row-major layouts of their own kernels): MLP (regression) and LeNet
+    qa = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+    gq = golden_mlp_bbb_q
+    mq = q.ModelFactory.get_model("linear_bbb", [13], 1, True, qa).load_reference_state(gq["state"])
+    gq_ = q.GraphedPredictor(mq, 10, regression=True)
+    for seed in (5, 2 ** 33 + 1):
+        x = torch.randn(1000, 13, generator=gen).cuda()
+        a, b = gq_(x, seed)
+        c, d = q.mc_predict_regression(mq, x, 10, seed)
+        assert torch.equal(a, c) and torch.equal(b, d)
+    gb = golden_lenet_bbb
+    lb = q.ModelFactory.get_model("conv_lenet_bbb", [1, 1, 28, 28], 10, True, qa).load_reference_state(gb["state"])
+    glb = q.GraphedPredictor(lb, 6)
+    for seed in (7, 70):
+        x = torch.rand(40, 1, 28, 28, generator=gen).cuda()
+        assert torch.equal(glb(x, seed), q.mc_predict(lb, x, 6, seed))
     # ensemble (no noise at all: the graph only saves the launches)
     n = 16
     args = types.SimpleNamespace(activation_precision=7, weight_precision=8, model="conv_resnet_sgld", samples=n)
