@@ -43,7 +43,7 @@ using L0 = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;      // layers.0 on the patch 
 
 template <int G, int NBLK, bool DROP = false> constexpr int w16_lds() {
   return 2 * (G * L1::TILE_BYTES + L1::TILE_SLACK) + 2 * NBLK * WConv<L1>::BYTES + WConv<L0>::BYTES + (2 * NBLK + 1) * L1::COUT * 4 +
-         (DROP ? (2 * NBLK + 1) * MaskTab<L1::COUT, false>::bytes(G) : 0);
+         (DROP ? 2 * (2 * NBLK + 1) * MaskTab<L1::COUT, false>::bytes(G) : 0);      // two sets of mask tables: consecutive items alternate
 }
 
 // requantise one 32-pixel x 24-channel accumulator tile (ones row -> window sum, see conv_core) through `epi`
@@ -67,6 +67,42 @@ __device__ __forceinline__ void epilogue24(const v16i& acc, const float4 (&b4)[3
 
 // byte offset of interior pixel (oh, ow) of image g inside a tile array
 __device__ __forceinline__ int px_off(int g, int oh, int ow) { return g * L1::TILE_BYTES + ((oh + 1) * L1::TW + ow + 1) * L1::PIXB; }
+
+// The chain's LAST conv: Add(residual from the X tile) + ReLU as EpiTileResInPlace, but the block output leaves as quint8 straight to
+// global memory (three dwords per lane and row: the 24-byte pixel records of a row are contiguous) -- nothing reads the X tile after
+// it, so the item needs no read-out pass (tile -> registers -> + z_o -> HBM by all threads) and no barrier in front of one.
+struct OutRow { uint8_t* y; int ok; };        // this lane's pixel column of the wave's image in the output tensor (row 0); ok: the image exists (ragged batch)
+template <bool DROP>
+struct EpiResToGlobal {
+  const uint8_t* xt; OutRow o; QConv p; QAdd a; PostArgs q; MaskTab<L1::COUT, false> mt;
+  mutable uint8_t* yrow;
+  __device__ __forceinline__ void set_row(int oh) const { yrow = o.y + oh * (L1::HIN * L1::COUT); }      // called before a row's stores (oh: wave-uniform)
+  __device__ __forceinline__ uint32_t load(int po, int c0) const { return *reinterpret_cast<const uint32_t*>(xt + po + c0); }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rqu) const {
+    float r[4] = {v0, v1, v2, v3};
+    float sa = p.s_y, dl = p.dl_y;
+    if constexpr (DROP) {
+      const float4 m4 = mt.get(po / L1::TILE_BYTES, c0);
+      r[0] = drop_val(v0, p, q, m4.x); r[1] = drop_val(v1, p, q, m4.y); r[2] = drop_val(v2, p, q, m4.z); r[3] = drop_val(v3, p, q, m4.w);
+      sa = q.s_a; dl = q.dl_a;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = med3f(r[i], p.vlo, p.vhi);
+    }
+    const int rq = (int)rqu;
+    const float rf[4] = {(float)((rq << 24) >> 24), (float)((rq << 16) >> 24), (float)((rq << 8) >> 24), (float)(rq >> 24)};
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float da = __builtin_fmaf(sa, __builtin_rintf(r[i]), dl);
+      const float db = __builtin_fmaf(a.s_r, rf[i], a.dl_r);
+      t[i] = (da + db) * a.inv_s_o;
+    }
+    if (o.ok) *reinterpret_cast<uint32_t*>(yrow + c0) = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi) + (uint32_t)a.z_o * 0x01010101u;
+  }
+};
+template <class E> __device__ __forceinline__ auto epi_set_row(const E& e, int oh, int) -> decltype(e.set_row(oh), void()) { e.set_row(oh); }
+template <class E> __device__ __forceinline__ void epi_set_row(const E&, int, long) {}
 
 // 3x3 / stride 1 conv of RW consecutive output rows [oh0, oh0 + RW) of image slot g: tile -> epi.  `w` holds this conv's 9 weight
 // fragments; after the last row's MFMAs it is refilled from `wnext` (the NEXT conv's weights, which do not depend on the barrier
@@ -109,6 +145,7 @@ __device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[L
       for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
     }
     W16_STAMP();
+    epi_set_row(epi, oh0 + i, 0);
     epilogue24(acc, b4, p, epi, px_off(g, oh0 + i, r), h);
     W16_STAMP();
   }
@@ -137,7 +174,7 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
   uint8_t* wl0 = wl + 2 * NBLK * WB;                         // layers.0: one fragment tile
   float* bias_lds = reinterpret_cast<float*>(wl0 + WConv<L0>::BYTES);      // [2 NBLK][24], then layers.0's
   float* bias0 = bias_lds + 2 * NBLK * L1::COUT;
-  uint8_t* mtab = reinterpret_cast<uint8_t*>(bias0 + L0::COUT);              // DROP: mask tables [2 NBLK + 1][G][24]
+  uint8_t* mtab0 = reinterpret_cast<uint8_t*>(bias0 + L0::COUT);             // DROP: mask tables [2][2 NBLK + 1][G][24]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = (wave * RW) / 32, woh0 = (wave * RW) % 32;  // this wave's image within the item and its first output row
 
@@ -204,7 +241,10 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
       for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wl + l_ * 16 + ks * 1024);
     }
     W16_STAMP();
-    if constexpr (DROP) {        // this item's masks (every wave has left the previous item's last epilogue)
+    // (the item's last epilogue -- straight to HBM -- is not followed by a barrier: a wave may fill the next item's tables while
+    //  another still reads this item's, so consecutive items use different table sets)
+    uint8_t* mtab = mtab0 + (it & 1) * (2 * NBLK + 1) * MTB;
+    if constexpr (DROP) {        // this item's masks
       int t_ = tid;
       asm volatile("" : "+v"(t_));
 #pragma unroll
@@ -247,32 +287,21 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
       else conv_a(EpiTile<L1::HO, L1::PIXB, L1::TILE_BYTES>{tt, bp.a});
       sync();
       W16_STAMP();
-      if constexpr (DROP) conv_b(EpiTileResInPlaceDrop<L1::HO, L1::PIXB, L1::TILE_BYTES, L1::COUT>{xt, bp.b, bp.add, dr.d[2 + 2 * k], {mtab + (2 + 2 * k) * MTB, 0.f}});
-      else conv_b(EpiTileResInPlace<L1::HO, L1::PIXB, L1::TILE_BYTES>{xt, bp.b, bp.add});
-      sync();
+      if (k + 1 == NBLK) {             // the chain's output: quint8 straight to HBM
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+        const OutRow orow{a.y + (int64_t)s * a.y_ss + (int64_t)(img0 + wg) * (L1::HIN * L1::HIN * L1::COUT) + (l_ & 31) * L1::COUT, img0 + wg < a.B};
+        if constexpr (DROP) conv_b(EpiResToGlobal<true>{xt, orow, bp.b, bp.add, dr.d[2 + 2 * k], {mtab + (2 + 2 * k) * MTB, 0.f}, nullptr});
+        else conv_b(EpiResToGlobal<false>{xt, orow, bp.b, bp.add, PostArgs{}, {nullptr, 0.f}, nullptr});
+      } else {
+        if constexpr (DROP) conv_b(EpiTileResInPlaceDrop<L1::HO, L1::PIXB, L1::TILE_BYTES, L1::COUT>{xt, bp.b, bp.add, dr.d[2 + 2 * k], {mtab + (2 + 2 * k) * MTB, 0.f}});
+        else conv_b(EpiTileResInPlace<L1::HO, L1::PIXB, L1::TILE_BYTES>{xt, bp.b, bp.add});
+        sync();
+      }
       W16_STAMP();
     }
     // the next item's patch fragments: in flight during the read-out, the stores and the barrier at the loop top
     fetch_patches(it + 1 < count ? item + 1 : item);
-    // ---- X tile interior (centred on the last add's zero point) -> quint8 -> HBM
-    {
-      const uint32_t z4 = (uint32_t)a.blk[NBLK - 1].add.z_o * 0x01010101u;
-      uint8_t* ys = a.y + (int64_t)s * a.y_ss;
-      int t_ = tid;
-      asm volatile("" : "+v"(t_));
-#pragma unroll
-      for (int j = 0; j < PER_TO; ++j) {
-        const int i = t_ + j * OTHR;
-        if (i < NCH) {
-          const int g = i / CPI, rem = i - g * CPI, row = rem / CPR, within = rem - row * CPR;
-          const uint8_t* d = xt + g * L1::TILE_BYTES + (row + 1) * L1::PITCH + L1::row_chunk_off(within);
-          const v2i lo = *reinterpret_cast<const v2i*>(d), hi = *reinterpret_cast<const v2i*>(d + 8);
-          if (img0 + g < a.B)
-            *reinterpret_cast<v4i*>(ys + ((int64_t)(img0 + g) * L1::HIN) * L1::ROWB + (int64_t)rem * 16) =
-                v4i{(int)add_bytes(lo.x, z4), (int)add_bytes(lo.y, z4), (int)add_bytes(hi.x, z4), (int)add_bytes(hi.y, z4)};
-        }
-      }
-    }
     W16_STAMP();
   }
 }
