@@ -1113,6 +1113,8 @@ __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const ArgsAr
     QBNN_STAMP_AT(4);
     lds_barrier();
     QBNN_STAMP_AT(5);
+    // (Round 3: conv_b's epilogue writing its dwords straight to HBM instead -- what the 16-wave layer-1 kernel does -- is SLOWER here:
+    //  0.493 / 0.42 / 0.36 ms against 0.46 / 0.40 / 0.36 for the three blocks; the staged, coalesced read-out stays.)
     // read-out of the finished block output.  Weights-stationary form (registers to spare): all LDS reads first (a rolled
     // read -> wait -> store loop pays the LDS latency per trip), then the next X tile, then the stores -- nothing in the
     // next item waits on them.  The streaming forms sit at the register limit and keep the rolled loop.
