@@ -218,6 +218,10 @@ struct SamplerLayer {
 struct SamplerTable { SamplerLayer l[QBNN_MAX_SAMPLER_LAYERS]; int n; };
 
 #define QBNN_SAMPLER_NS 4           // MC samples per thread: the chunk's mu / sigma are loaded, unpacked and dequantised once for all of them
+// UNALIGNED: the kernel of the layers whose chunks are not aligned to Philox blocks (K or the kernel-row length no multiple of 4) and are
+// large enough to matter (LeNet's 2450-wide Linear); a kernel of its own, because compiled into the same kernel that path costs the
+// aligned one 8 % (register allocation).  Small unaligned layers (layers.0: K = 27) stay on the element-wise path of the main kernel.
+template <bool UNALIGNED>
 __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const SamplerTable t, uint32_t seed_lo, uint32_t seed_hi,
                                                                    uint32_t sample_begin, int n_samples, const uint32_t* __restrict__ nd) {
   if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }      // captured-graph mode: the seed lives in device memory
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
   const v4i m4 = L.mu[chunk], s4 = L.sigma[chunk];
   int mw[4] = {m4.x, m4.y, m4.z, m4.w}, sw[4] = {s4.x, s4.y, s4.z, s4.w};
   const int64_t total = (int64_t)L.cout * L.K;
-  if (L.layout == QBNN_LAYOUT_MFMA32 && ((L.K | L.krow) & 3) == 0) {
+  if (!UNALIGNED && L.layout == QBNN_LAYOUT_MFMA32 && ((L.K | L.krow) & 3) == 0) {
     // Fast path (every conv but layers.0): the chunk's 16 weights are 4 whole Philox blocks -- element index
     // n K + kh krow + j0 + j with all terms multiples of 4 -- and a block is valid or padding as a whole.
     // The quantized::mul / add chain of sample_one_q in fp32 on exact small integers (same bits, a third of the instructions):
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
     }
     return;
   }
-  if (L.layout == QBNN_LAYOUT_MFMA32) {
+  if constexpr (UNALIGNED) {
     // Any K / kernel-row length (layers.0: K = 27; LeNet's 2450-wide Linear): the chunk's 16 weights are still CONSECUTIVE elements
     // idx0 .. idx0 + 15 of the reference's order (a chunk never straddles a padded kernel row), only not aligned to a Philox block:
     // five blocks cover them, and a lane picks its 16 words at offset idx0 & 3.  Uniform control flow -- the element-wise form below
@@ -381,10 +385,10 @@ QBNN_EXPORT int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* layers, i
                                              uint32_t sample_begin, int32_t n_samples, void* stream) {
   if (!layers || n_layers <= 0 || n_layers > QBNN_MAX_SAMPLER_LAYERS || n_samples <= 0)
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: bad argument (at most 24 layers per call)%s");
-  SamplerTable t;
+  SamplerTable t, tu;               // tu: large MFMA32 layers whose chunks are not aligned to Philox blocks -> their own kernel
   memset(&t, 0, sizeof(t));
-  t.n = n_layers;
-  int blocks = 0;
+  memset(&tu, 0, sizeof(tu));
+  int blocks = 0, blocks_u = 0;
   for (int i = 0; i < n_layers; ++i) {
     const qbnn_sampler_layer& q = layers[i];
     if (!q.mu_packed || !q.sigma_packed || !q.w_out || q.cout <= 0 || q.k <= 0)
@@ -395,14 +399,22 @@ QBNN_EXPORT int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* layers, i
     if ((size_t)q.w_sample_stride < bytes || (q.w_sample_stride & 15))
       return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: w_sample_stride too small or unaligned%s");
     const PackGeom g = pack_geom(q.cout, q.k, q.layout == QBNN_LAYOUT_MFMA32 ? q.krow : q.k);
-    SamplerLayer& L = t.l[i];
+    const bool unaligned = q.layout == QBNN_LAYOUT_MFMA32 && ((q.k | g.krow) & 3) != 0 && bytes / 16 >= 4096;
+    SamplerTable& tt = unaligned ? tu : t;
+    int& bb = unaligned ? blocks_u : blocks;
+    SamplerLayer& L = tt.l[tt.n++];
     L.mu = (const v4i*)q.mu_packed; L.sigma = (const v4i*)q.sigma_packed; L.out = q.w_out; L.out_ss = q.w_sample_stride;
     L.cout = q.cout; L.K = q.k; L.krow = g.krow; L.rbp = g.rbp; L.KS = g.KS; L.layout = q.layout;
-    L.n_chunks = (int)(bytes / 16); L.chunk_begin = blocks; L.layer_id = q.layer_id; L.p = q.params;
-    blocks += ceil_div(L.n_chunks, 256);
+    L.n_chunks = (int)(bytes / 16); L.chunk_begin = bb; L.layer_id = q.layer_id; L.p = q.params;
+    bb += ceil_div(L.n_chunks, 256);
   }
-  hipLaunchKernelGGL(sample_weights_multi_kernel, dim3(blocks, ceil_div(n_samples, QBNN_SAMPLER_NS)), dim3(256), 0, (hipStream_t)stream, t,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), sample_begin, n_samples, g_noise_dev);
+  const dim3 gy(1, ceil_div(n_samples, QBNN_SAMPLER_NS));
+  if (t.n)
+    hipLaunchKernelGGL(sample_weights_multi_kernel<false>, dim3(blocks, gy.y), dim3(256), 0, (hipStream_t)stream, t, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       sample_begin, n_samples, g_noise_dev);
+  if (tu.n)
+    hipLaunchKernelGGL(sample_weights_multi_kernel<true>, dim3(blocks_u, gy.y), dim3(256), 0, (hipStream_t)stream, tu, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       sample_begin, n_samples, g_noise_dev);
   return check_launch("qbnn_sample_weights_i8_multi");
 }
 
