@@ -490,7 +490,7 @@ def main():
                           "image_samples_per_s": round(value * x_host.shape[0], 1), "parallelism": f"mc-sample-shard x{world}"},
                "graph_replay": graphed is not None, "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "rccl": rccl, "rccl_ranks": world if use_dist else 0,
                "kernels": kernels, "secondary": secondary}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)          # the line is out before any process-group teardown
     if use_dist:
         dist.destroy_process_group()
     from quantised_bayesian_nets_amd import models as qmodels
