@@ -259,20 +259,32 @@ class ConvNetwork_ResNet(nn.Module):
         """All S samples of the current mc_context: returns per-sample softmax probabilities [S, B, classes]."""
         S = _MC.samples
         L = _lib.lib()
-        xq = self.quantize_input(x)
         dev = x.device
-        _, B, H, W, Cc = xq.data.shape
-        if record is not None:
-            record["quant.out"] = xq.data[0]
-        if Cc != 3 or H != 32 or W != 32:
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 32, 32):
             raise NotImplementedError("conv_resnet_bbb expects 3x32x32 inputs")
-        col = torch.empty((B, H * W, 32), dtype=torch.int8, device=dev)
-        with timed("im2col3x3_c3"):
-            _lib.check(L.qbnn_im2col3x3_c3(_lib.ptr(xq.data), B, H, W, xq.zero_point, _lib.ptr(col), _lib.current_stream()))
-        if not self.deterministic:
-            sample_all_weights(self.stochastic_layers(), dev)      # one launch for the 21 layers of this MC batch
         l0 = self.layers[0]
         fuse_stem = self.fuse_blocks and self.fuse_stem and record is None and len(self.layers[3][0].shortcut) == 0
+        B, Cc, H, W = x.shape
+        col = torch.empty((B, H * W, 32), dtype=torch.int8, device=dev)
+        if fuse_stem and 0 <= self.quant.zero_point <= 127:
+            # QuantStub + clamp + the layer-0 patch gather in ONE pass over the fp32 input (the quantised image itself is not needed:
+            # layers.0 runs on the patches inside the layer-1 kernel)
+            if x.device.type != "cuda":
+                raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
+            xf = x.to(torch.float32).contiguous()
+            xq = _QParamsOnly(self.quant.scale, self.quant.zero_point)
+            a_hi = UINT_BOUNDS[self.args.activation_precision][1]
+            with timed("quantize + im2col3x3_c3"):
+                _lib.check(L.qbnn_quantize_im2col3x3_c3_multi(_lib.ptr(xf), B, H, W, (C.c_float * 1)(self.quant.scale), (C.c_int32 * 1)(self.quant.zero_point), 1, a_hi,
+                                                              _lib.ptr(col), col.numel(), _lib.current_stream()))
+        else:
+            xq = self.quantize_input(x)
+            if record is not None:
+                record["quant.out"] = xq.data[0]
+            with timed("im2col3x3_c3"):
+                _lib.check(L.qbnn_im2col3x3_c3(_lib.ptr(xq.data), B, H, W, xq.zero_point, _lib.ptr(col), _lib.current_stream()))
+        if not self.deterministic:
+            sample_all_weights(self.stochastic_layers(), dev)      # one launch for the 21 layers of this MC batch
         if fuse_stem:
             # layers.0 runs inside the layer-1 chain kernel: its output (the largest activation of the net) stays on chip
             h = run_identity_chain(list(self.layers[3]), _QParamsOnly(l0.scale, l0.zero_point), stem=(l0, l0.sample_weights(dev), col, xq.scale))
