@@ -974,18 +974,19 @@ print("SWITCH-OK")
 """
 
 
-@pytest.mark.parametrize("switch", ["QBNN_NO_PINGPONG", "QBNN_NO_STEM_FUSION", "QBNN_GENERIC_NAIVE"])
+@pytest.mark.parametrize("switch", ["QBNN_NO_PINGPONG", "QBNN_NO_STEM_FUSION", "QBNN_GENERIC_NAIVE", "QBNN_W16=0"])
 def test_environment_switches_give_the_same_results(switch, tmp_path):
     """The A/B switches of README.md select other kernels for the same arithmetic (weights-stationary instead of ping-pong
-    48-channel block; layers.0 as its own launch; the scalar any-geometry conv): each, in a child process (the switches are
-    read once), reproduces the golden probabilities and the fused == layer-wise identity."""
+    48-channel block; layers.0 as its own launch; the scalar any-geometry conv; the 8-wave layer-1 kernel instead of the 16-wave one):
+    each, in a child process (the switches are read once), reproduces the golden probabilities and the fused == layer-wise identity."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "switch_worker.py"
     script.write_text(_SWITCH_WORKER)
-    r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, **{switch: "1"}), capture_output=True, text=True, timeout=600)
+    name, _, value = switch.partition("=")
+    r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, **{name: value or "1"}), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SWITCH-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
