@@ -441,6 +441,30 @@ int qbnn_affine_f32_mc(const float* x, int64_t x_sample_stride, const float* res
                        const float* p1, float* y, int64_t y_sample_stride, int64_t n, int32_t C, int32_t mode, int32_t relu,
                        int32_t n_samples, void* stream);
 
+/* ---- float MC-Dropout (row a6+/a7: reference mcdropout/dropout.py:15-40 with FloatFunctional, models_mc.py graphs with q=False) --- */
+
+/* The Bernoulli(keep_prob) mask of a float BernoulliDropout as fp32 0 / 1, mask_out [S][n_slots]: slot = b * C + c for a 4-D
+ * activation (dropout.py:24-29: whole channels), the element index for a 2-D one (:19-23).  Same Philox uniform stream as
+ * qbnn_dropout_q_mc ({ctr = {i >> 2, layer_id, sample_begin + s, 1}}[i & 3] < keep_prob); honours qbnn_set_device_noise_source. */
+int qbnn_dropout_mask_f32_mc(int64_t n_slots, float keep_prob, uint64_t seed, uint32_t layer_id, uint32_t sample_begin, int32_t n_samples,
+                             float* mask_out, void* stream);
+
+/* y = (x * mask[s][b][c]) * multiplier  (+ res) (ReLU)  on x [S|1][B][HW][C]: mul_mask.mul then mul_scalar.mul_scalar
+ * (dropout.py:38-39), each rounded to fp32; res / ReLU = the Add + `end` of a BasicBlock behind its last dropout (models_mc.py:156-159).
+ * mask [S][B][C] is caller-provided (qbnn_dropout_mask_f32_mc, or injected in parity tests). */
+int qbnn_dropout_f32_mc(const float* x, int64_t x_sample_stride, const float* mask, int32_t B, int32_t HW, int32_t C, float multiplier,
+                        const float* res, int64_t res_sample_stride, int32_t relu, float* y, int64_t y_sample_stride, int32_t n_samples,
+                        void* stream);
+
+/* qbnn_conv2d_f32_fused_mc with a float BernoulliDropout in the tail: v = conv; v += bias[n]; v = v * alpha[n] + beta[n] (BatchNorm
+ * eval); v = (v * drop_mask[s][b][n]) * drop_mult; v += res; ReLU (flags bit 0; a ReLU that the graph places in front of the dropout
+ * commutes with it exactly: mask and multiplier are >= 0).  conv -> bn -> relu -> dropout and conv -> bn -> dropout -> Add -> relu of
+ * models_mc.py:124-160 in one launch each.  drop_mask NULL = no dropout. */
+int qbnn_conv2d_f32_drop_mc(const float* x, int64_t x_sample_stride, const float* w, int64_t w_sample_stride, const float* bias,
+                            const float* alpha, const float* beta, const float* drop_mask, float drop_mult, const float* res,
+                            int64_t res_sample_stride, float* y, int64_t y_sample_stride, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                            int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream);
+
 /* nn.MaxPool2d(k, k) (mode 0) / nn.AvgPool2d(k) (mode 1) on NHWC fp32. */
 int qbnn_pool2d_f32_mc(const float* x, int64_t x_sample_stride, float* y, int64_t y_sample_stride, int32_t B, int32_t H, int32_t W,
                        int32_t C, int32_t k, int32_t mode, int32_t n_samples, void* stream);

@@ -839,3 +839,133 @@ class Int8ResNetMCOracle:
         b = st.get("layers.10.bias", None)
         logits = linear_i8(h, w, None if b is None else np.asarray(b, np.float32), s, z, sw, zw, sy, zy, False, self.a_hi)
         return dequant_softmax(logits, sy, zy)
+
+
+# --------------------------------------------- MC-Dropout MLP, int8 ---
+class Int8MLPMCOracle:
+    """`linear_mc` after prepare_model -> convert: reference mcdropout/models_mc.py:10-73 (3 x LinearReLU(100) with a
+    per-element BernoulliDropout between them and one in front of each of the heads `mu` and `log_var`), dropout.py:15-40
+    (quantised masks, one draw per element of the 2-D activation).  Mask draw order = execution order: layers.2, layers.5,
+    mu.0, log_var.0.  State: torch.nn.quantized Linear(ReLU) as `<name>.weight` (+ .q_scale / .q_zero_point), `.bias`,
+    `.scale`, `.zero_point`; dropouts as `<name>.mul_mask.scale / .zero_point`, `.p`, `.multiplier`."""
+    DROPS = ("layers.2", "layers.5", "mu.0", "log_var.0")
+
+    def __init__(self, state, a_bits=7):
+        self.st, self.a_hi = state, UINT_BOUNDS[a_bits][1]
+
+    def linear(self, name, x, s, z, relu):
+        g = lambda k: self.st[name + k]
+        w = np.asarray(g(".weight"), np.int8)
+        b = self.st.get(name + ".bias", None)
+        sy, zy = float(g(".scale")), int(g(".zero_point"))
+        y = linear_i8(x, w, None if b is None or np.asarray(b).size == 0 else np.asarray(b, np.float32), s, z,
+                      float(g(".weight.q_scale")), int(g(".weight.q_zero_point")), sy, zy, relu, self.a_hi)
+        return y, sy, zy
+
+    def drop(self, di, x, s, z, seed, sample, masks):
+        name = self.DROPS[di]
+        s_m, z_m = float(self.st[name + ".mul_mask.scale"]), int(self.st[name + ".mul_mask.zero_point"])
+        mult = float(np.float32(np.asarray(self.st[name + ".multiplier"]).reshape(-1)[0]))
+        if masks is not None:
+            m = masks[di]
+        else:
+            keep = np.float32(1.0) - np.float32(np.asarray(self.st[name + ".p"]).reshape(-1)[0])
+            m = (fill_uniform(x.size, seed, di, sample) < keep).astype(np.float32).reshape(x.shape)
+        return dropout_q(x, m, z, s, s_m, z_m, self.a_hi), s_m * mult, z_m
+
+    def forward(self, x, seed, sample, masks=None, record=None):
+        rec = (lambda k, v: record.__setitem__(k, v)) if record is not None else (lambda k, v: None)
+        x = np.asarray(x, np.float32)
+        s, z = float(np.asarray(self.st["quant.scale"]).reshape(-1)[0]), int(np.asarray(self.st["quant.zero_point"]).reshape(-1)[0])
+        h = quantize_input_nchw(x.reshape(x.shape[0], x.shape[1], 1, 1), s, z, self.a_hi).reshape(x.shape); rec("quant.out", h)
+        h, s, z = self.linear("layers.0", h, s, z, True); rec("layers.0.out", h)
+        h, s, z = self.drop(0, h, s, z, seed, sample, masks); rec("layers.2.out", h)
+        h, s, z = self.linear("layers.3", h, s, z, True); rec("layers.3.out", h)
+        h, s, z = self.drop(1, h, s, z, seed, sample, masks); rec("layers.5.out", h)
+        h, s, z = self.linear("layers.6", h, s, z, True); rec("layers.6.out", h)
+        hm, sm, zm = self.drop(2, h, s, z, seed, sample, masks); rec("mu.0.out", hm)
+        qm, sm, zm = self.linear("mu.1", hm, sm, zm, False); rec("mu.1.out", qm)
+        hv, sv, zv = self.drop(3, h, s, z, seed, sample, masks); rec("log_var.0.out", hv)
+        qv, sv, zv = self.linear("log_var.1", hv, sv, zv, False); rec("log_var.1.out", qv)
+        mu = (qm.astype(np.float32) - np.float32(zm)) * np.float32(sm)
+        lv = (qv.astype(np.float32) - np.float32(zv)) * np.float32(sv)
+        return mu, np.exp(lv)
+
+    def mc_predict(self, x, samples, seed):
+        """experiments/utils.py:348-353: (mean_s mu, var_unbiased_s(mu) + mean_s var)."""
+        mus, vs = zip(*[self.forward(x, seed, s) for s in range(samples)])
+        mus, vs = np.stack(mus).astype(np.float64), np.stack(vs).astype(np.float64)
+        return mus.mean(0).astype(np.float32), (mus.var(0, ddof=1) + vs.mean(0)).astype(np.float32)
+
+
+# ------------------------------------------- float MC-Dropout graphs (rows a6 / a7, q=False) ---
+class F32MCOracle:
+    """`linear_mc`, `conv_lenet_mc`, `conv_resnet_mc` with q=False in eval mode: reference mcdropout/models_mc.py:10-226 (graphs) and
+    dropout.py:15-40 with FloatFunctional (`(x * mask) * multiplier`, two fp32 roundings; 4-D inputs drop whole channels).  Deterministic
+    nn.Linear / nn.Conv2d / nn.BatchNorm2d (eval) weights; masks from the Philox uniform stream (seed, dropout index in execution
+    order, sample) or injected.  fp32 with fp64 accumulation inside conv / matmul."""
+
+    def __init__(self, state):
+        self.st = state
+
+    def drop(self, name, di, x, seed, sample, masks):
+        p = np.float32(np.asarray(self.st[name + ".p"]).reshape(-1)[0])
+        mult = np.float32(np.asarray(self.st[name + ".multiplier"]).reshape(-1)[0])
+        B, C = x.shape[0], x.shape[-1]
+        if masks is not None:
+            m = np.asarray(masks[di], np.float32).reshape(B, C)
+        else:
+            m = (fill_uniform(B * C, seed, di, sample) < (np.float32(1.0) - p)).astype(np.float32).reshape(B, C)
+        m = m.reshape((B,) + (1,) * (x.ndim - 2) + (C,))
+        return ((x * m).astype(np.float32) * mult).astype(np.float32)
+
+    def linear(self, name, x, relu=False):
+        w = np.asarray(self.st[name + ".weight"], np.float32)
+        y = x.astype(np.float64) @ w.astype(np.float64).T
+        if (name + ".bias") in self.st:
+            y = y + np.asarray(self.st[name + ".bias"], np.float32).astype(np.float64)
+        y = y.astype(np.float32)
+        return np.maximum(y, 0) if relu else y
+
+    def conv(self, name, x, stride, pad):
+        w = np.asarray(self.st[name + ".weight"], np.float32)
+        return conv2d_f32(x, np.ascontiguousarray(w.transpose(0, 2, 3, 1)), None, stride, pad)
+
+    def mlp(self, x, seed, sample, masks=None):
+        h = np.asarray(x, np.float32)
+        h = self.drop("layers.2", 0, self.linear("layers.0", h, True), seed, sample, masks)
+        h = self.drop("layers.5", 1, self.linear("layers.3", h, True), seed, sample, masks)
+        h = self.linear("layers.6", h, True)
+        mu = self.linear("mu.1", self.drop("mu.0", 2, h, seed, sample, masks))
+        lv = self.linear("log_var.1", self.drop("log_var.0", 3, h, seed, sample, masks))
+        return mu, np.exp(lv)
+
+    def lenet(self, x_nchw, seed, sample, masks=None):
+        h = np.ascontiguousarray(np.asarray(x_nchw, np.float32).transpose(0, 2, 3, 1))
+        h = _pool_f32(self.drop("layers.1", 0, self.conv("layers.0", h, 1, 2), seed, sample, masks), 2, False)
+        h = _pool_f32(self.drop("layers.4", 1, self.conv("layers.3", h, 1, 2), seed, sample, masks), 2, False)
+        h = np.ascontiguousarray(h.transpose(0, 3, 1, 2)).reshape(h.shape[0], -1)
+        h = self.drop("layers.9", 2, self.linear("layers.7", h, True), seed, sample, masks)
+        return _softmax_f32(self.linear("layers.10", h))
+
+    def resnet(self, x_nchw, seed, sample, masks=None):
+        h = np.ascontiguousarray(np.asarray(x_nchw, np.float32).transpose(0, 2, 3, 1))
+        di = 0
+        h = np.maximum(_bn_eval(self.conv("layers.0", h, 1, 1), self.st, "layers.1"), 0)
+        h = self.drop("layers.3", di, h, seed, sample, masks); di += 1
+        inp = 24
+        for li, planes, stride in ((4, 24, 1), (5, 48, 2), (6, 96, 2), (7, 192, 2)):
+            for bi, st in enumerate((stride, 1)):
+                p = f"layers.{li}.{bi}"
+                out = np.maximum(_bn_eval(self.conv(p + ".stem.0", h, st, 1), self.st, p + ".stem.1"), 0)
+                out = self.drop(p + ".stem.3", di, out, seed, sample, masks); di += 1
+                out = _bn_eval(self.conv(p + ".stem.4", out, 1, 1), self.st, p + ".stem.5")
+                out = self.drop(p + ".stem.6", di, out, seed, sample, masks); di += 1
+                sc = h
+                if st != 1 or inp != planes:
+                    sc = _bn_eval(self.conv(p + ".shortcut.0", h, st, 0), self.st, p + ".shortcut.1")
+                    sc = self.drop(p + ".shortcut.2", di, sc, seed, sample, masks); di += 1
+                h = np.maximum((out + sc).astype(np.float32), 0)
+                inp = planes
+        h = _pool_f32(h, 4, True).reshape(h.shape[0], -1)
+        return _softmax_f32(self.linear("layers.10", h))

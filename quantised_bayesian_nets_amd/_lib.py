@@ -99,6 +99,7 @@ EXPORTS = ["qbnn_mlp_bbb_f32_mc", "qbnn_mlp_bbb_f32_workspace_floats", "qbnn_pac
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_conv2d_i8_generic_mc", "qbnn_conv2d_i8_generic_scalar_mc", "qbnn_dropout_q_mc", "qbnn_maxpool2_q_mc",
            "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_flatten_nchw_rows_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
            "qbnn_conv2d_f32_mc", "qbnn_conv2d_f32_fused_mc", "qbnn_conv2d_f32_blocks", "qbnn_observe_partials_f32_mc", "qbnn_affine_f32_mc", "qbnn_pool2d_f32_mc", "qbnn_flatten_nchw_f32_mc", "qbnn_softmax_f32_mc", "qbnn_observe_f32_mc", "qbnn_fake_quant_f32_mc", "qbnn_sample_weights_f32_strided", "qbnn_sample_weights_f32_ohwi",
+           "qbnn_dropout_mask_f32_mc", "qbnn_dropout_f32_mc", "qbnn_conv2d_f32_drop_mc",
            "qbnn_last_error", "qbnn_version"]
 
 
@@ -181,6 +182,9 @@ def lib():
         L.qbnn_mlp_bbb_f32_workspace_floats.argtypes = [C.POINTER(MlpLayer)]
         L.qbnn_mlp_bbb_f32_workspace_floats.restype = i64
         L.qbnn_sample_weights_f32_ohwi.argtypes = [vp, i64, vp, i64, i32, i32, i32, u64, u32, u32, i32, vp, vp, vp]
+        L.qbnn_dropout_mask_f32_mc.argtypes = [i64, f, u64, u32, u32, i32, vp, vp]
+        L.qbnn_dropout_f32_mc.argtypes = [vp, i64, vp, i32, i32, i32, f, vp, i64, i32, vp, i64, i32, vp]
+        L.qbnn_conv2d_f32_drop_mc.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, f, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         _LIB = L
     return _LIB
 

@@ -37,13 +37,17 @@ struct ConvF32Args {
   // v = v + res; ReLU -- each step rounded to fp32 exactly as the separate pointwise kernels would
   const float* div; const float* alpha; const float* beta; const float* res; int64_t res_ss;
   float* mm_partials;                // optional [S][workgroups per sample][2]: (min, max) of each workgroup's outputs (QAT observers)
+  // float BernoulliDropout behind the conv (mcdropout/dropout.py:15-40 with FloatFunctional: (v * mask) * multiplier), between
+  // BatchNorm and the Add: drop_mask [S][B][Cout] of 0 / 1 (qbnn_dropout_mask_f32_mc), one value per (sample, image, channel)
+  const float* drop_mask; float drop_mult;
 };
 
-__device__ __forceinline__ float conv_f32_tail(const ConvF32Args& a, float v, int n, int s, int64_t off) {
+__device__ __forceinline__ float conv_f32_tail(const ConvF32Args& a, float v, int n, int s, int64_t off, const float* drop_row = nullptr) {
   if (a.div) v = v / a.div[n];
   if (a.bias) v = v + a.bias[n];
   if (a.alpha) v = v * a.alpha[n];
   if (a.beta) v = v + a.beta[n];
+  if (drop_row) { v = v * drop_row[n]; v = v * a.drop_mult; }     // mul_mask.mul, then mul_scalar.mul_scalar: two roundings
   if (a.res) v = v + a.res[(int64_t)s * a.res_ss + off];
   if (a.relu) v = fmaxf(v, 0.f);
   return v;
@@ -175,13 +179,14 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
     const int po = p0 + wm * 32 + (lane & 31);
     if (po < npix) {
       float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
+      const float* dr = a.drop_mask ? a.drop_mask + ((int64_t)s * a.B + po / (a.Ho * a.Wo)) * a.Cout : nullptr;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int no = n0 + wn * 32 + 8 * g + 4 * (lane >> 5) + i;
           if (no < a.Cout) {
-            const float v = conv_f32_tail(a, acc[4 * g + i], no, s, (int64_t)po * a.Cout + no);
+            const float v = conv_f32_tail(a, acc[4 * g + i], no, s, (int64_t)po * a.Cout + no, dr);
             yp[no] = v; vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
           }
         }
@@ -194,11 +199,12 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
         const int po = p0 + wm * 32 + i * 16 + 4 * r + q;
         if (po >= npix) continue;
         float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
+        const float* dr = a.drop_mask ? a.drop_mask + ((int64_t)s * a.B + po / (a.Ho * a.Wo)) * a.Cout : nullptr;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int no = n0 + wn * 32 + j * 16 + l15;
           if (no < a.Cout) {
-            const float v = conv_f32_tail(a, (float)acc64[i][j][r], no, s, (int64_t)po * a.Cout + no);
+            const float v = conv_f32_tail(a, (float)acc64[i][j][r], no, s, (int64_t)po * a.Cout + no, dr);
             yp[no] = v; vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
           }
         }
@@ -229,13 +235,35 @@ QBNN_EXPORT int32_t qbnn_conv2d_f32_blocks(int32_t B, int32_t H, int32_t W, int3
   return conv_f32_narrow(Cout) ? (int32_t)(((npix + 127) / 128) * ((Cout + 31) / 32)) : (int32_t)(((npix + 63) / 64) * ((Cout + 63) / 64));
 }
 
+static int conv2d_f32_launch(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* div, const float* bias,
+                             const float* alpha, const float* beta, const float* drop_mask, float drop_mult, const float* res, int64_t res_ss,
+                             float* y, int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
+                             int32_t pad, int32_t relu, int32_t n_samples, float* minmax_partials, void* stream);
+
 QBNN_EXPORT int qbnn_conv2d_f32_fused_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* div, const float* bias,
                                          const float* alpha, const float* beta, const float* res, int64_t res_ss, float* y, int64_t y_ss, int32_t B, int32_t H,
                                          int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu,
                                          int32_t n_samples, float* minmax_partials, void* stream) {
+  return conv2d_f32_launch(x, x_ss, w, w_ss, div, bias, alpha, beta, nullptr, 1.0f, res, res_ss, y, y_ss, B, H, W, Cin, Cout, ksize, stride, pad, relu,
+                           n_samples, minmax_partials, stream);
+}
+
+QBNN_EXPORT int qbnn_conv2d_f32_drop_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* bias, const float* alpha,
+                                        const float* beta, const float* drop_mask, float drop_mult, const float* res, int64_t res_ss, float* y,
+                                        int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
+                                        int32_t pad, int32_t relu, int32_t n_samples, void* stream) {
+  return conv2d_f32_launch(x, x_ss, w, w_ss, nullptr, bias, alpha, beta, drop_mask, drop_mult, res, res_ss, y, y_ss, B, H, W, Cin, Cout, ksize, stride, pad,
+                           relu, n_samples, nullptr, stream);
+}
+
+static int conv2d_f32_launch(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* div, const float* bias,
+                             const float* alpha, const float* beta, const float* drop_mask, float drop_mult, const float* res, int64_t res_ss,
+                             float* y, int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
+                             int32_t pad, int32_t relu, int32_t n_samples, float* minmax_partials, void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || n_samples <= 0)
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: bad argument");
   ConvF32Args a;
+  a.drop_mask = drop_mask; a.drop_mult = drop_mult;
   a.div = div; a.alpha = alpha; a.beta = beta; a.res = res; a.res_ss = res_ss; a.mm_partials = minmax_partials;
   a.x = x; a.x_ss = x_ss; a.w = w; a.w_ss = w_ss; a.bias = bias; a.y = y; a.y_ss = y_ss;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = ksize; a.stride = stride; a.pad = pad; a.relu = relu & 1; a.w_ohwi = (relu >> 2) & 1;
@@ -293,6 +321,58 @@ QBNN_EXPORT int qbnn_affine_f32_mc(const float* x, int64_t x_ss, const float* re
   hipLaunchKernelGGL(affine_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, res, res_ss, p0, p1, y,
                      y_ss, n, C, mode, relu);
   return qbnn_check_launch_msg("qbnn_affine_f32_mc");
+}
+
+// ---- float BernoulliDropout (mcdropout/dropout.py:15-40 with FloatFunctional, q=False) --------------------------------------
+// The mask: one Bernoulli(keep) draw per slot (slot = b * C + c for a 4-D activation: whole channels drop; the element index for a
+// 2-D one) from the SAME Philox uniform stream as the quantised dropout, {ctr = {i >> 2, layer, sample, 1}}[i & 3], as fp32 0 / 1.
+__global__ __launch_bounds__(256) void dropout_mask_f32_kernel(int64_t n_slots, float keep, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_id,
+                                                                uint32_t sample_begin, float* __restrict__ mask, const uint32_t* __restrict__ nd) {
+  if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }      // captured-graph mode: the seed lives in device memory
+  const int s = blockIdx.y;
+  for (int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x; 4 * blk < n_slots; blk += (int64_t)gridDim.x * 256) {
+    const qbnn::u32x4 r = qbnn::philox4x32_10((uint32_t)blk, layer_id, sample_begin + s, 1u, seed_lo, seed_hi);
+    const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * blk + j < n_slots) mask[(int64_t)s * n_slots + 4 * blk + j] = ((float)(rv[j] >> 8) * 5.9604644775390625e-8f) < keep ? 1.0f : 0.0f;
+  }
+}
+
+QBNN_EXPORT int qbnn_dropout_mask_f32_mc(int64_t n_slots, float keep_prob, uint64_t seed, uint32_t layer_id, uint32_t sample_begin,
+                                         int32_t n_samples, float* mask_out, void* stream) {
+  if (!mask_out || n_slots <= 0 || n_samples <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_dropout_mask_f32_mc: bad argument");
+  const int64_t nb = (n_slots + 3) / 4;
+  const int blocks = (int)((nb + 255) / 256 < 1024 ? (nb + 255) / 256 : 1024);
+  hipLaunchKernelGGL(dropout_mask_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, n_slots, keep_prob, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), layer_id, sample_begin, mask_out, qbnn_noise_dev());
+  return qbnn_check_launch_msg("qbnn_dropout_mask_f32_mc");
+}
+
+// y = ((x * mask[s][b][c]) * multiplier (+ res)) (ReLU) on x [S|1][B][HW][C]: FloatFunctional.mul then mul_scalar, two fp32 roundings.
+__global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ x, int64_t x_ss, const float* __restrict__ mask, int64_t HWC,
+                                                           int C, float mult, const float* __restrict__ res, int64_t res_ss, int relu,
+                                                           float* __restrict__ y, int64_t y_ss, int64_t n, int64_t n_slots) {
+  const int s = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / HWC;
+    const int c = (int)(i % C);
+    float v = x[(int64_t)s * x_ss + i] * mask[(int64_t)s * n_slots + b * C + c];
+    v = v * mult;
+    if (res) v = v + res[(int64_t)s * res_ss + i];
+    if (relu) v = fmaxf(v, 0.f);
+    y[(int64_t)s * y_ss + i] = v;
+  }
+}
+
+QBNN_EXPORT int qbnn_dropout_f32_mc(const float* x, int64_t x_ss, const float* mask, int32_t B, int32_t HW, int32_t C, float multiplier,
+                                    const float* res, int64_t res_ss, int32_t relu, float* y, int64_t y_ss, int32_t n_samples, void* stream) {
+  if (!x || !mask || !y || B <= 0 || HW <= 0 || C <= 0 || n_samples <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_dropout_f32_mc: bad argument");
+  const int64_t n = (int64_t)B * HW * C;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, mask, (int64_t)HW * C, C, multiplier, res,
+                     res_ss, relu, y, y_ss, n, (int64_t)B * C);
+  return qbnn_check_launch_msg("qbnn_dropout_f32_mc");
 }
 
 // ---- pooling (NHWC, kernel = stride = k, no padding): mode 0 max (nn.MaxPool2d), 1 average (nn.AvgPool2d) ----------

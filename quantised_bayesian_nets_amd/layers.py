@@ -21,6 +21,19 @@ from .quant import INT_BOUNDS, UINT_BOUNDS, make_sample_params
 
 LAYOUT_MFMA32, LAYOUT_ROWMAJOR = 0, 1
 
+# State epoch: bumped whenever device-side parameter images may be dropped or replaced (a state dict loaded into any layer, a packed
+# layout switched).  A captured HIP graph holds raw pointers to those images; mc.GraphedPredictor records the epoch at capture and
+# captures again when it has moved (a replay over freed / repacked buffers would be silently wrong).
+_STATE_EPOCH = [0]
+
+
+def bump_state_epoch():
+    _STATE_EPOCH[0] += 1
+
+
+def state_epoch():
+    return _STATE_EPOCH[0]
+
 # bench.py sets this to a list: kernel launches then append (key, meta, start_event, end_event), HIP events recorded on the
 # launch stream (torch's current stream).  PROFILE_FILTER (a predicate on meta) limits the events to the launches of
 # interest, and back-to-back profiled launches share one event (end of one = start of the next): every event is a marker
@@ -202,6 +215,7 @@ class _BBBInt8(nn.Module):
             self.add_weight = QFunctional(self.weight.q_scale(), self.weight.q_zero_point())
             self.mul_noise = QFunctional()
             self._packed = None
+            bump_state_epoch()
             return self
         self.std = QuantizedParam(g("std"), g("std.q_scale"), g("std.q_zero_point"))
         b = state.get(prefix + "bias_", None)
@@ -212,6 +226,7 @@ class _BBBInt8(nn.Module):
         if (prefix + "std_prior") in state:          # carried through conversion untouched (conv_q.py:160, linear_q.py:131)
             self.std_prior.data = torch.from_numpy(np.asarray(state[prefix + "std_prior"], np.float32).reshape(-1).copy())
         self._packed = None
+        bump_state_epoch()
         return self
 
     def reference_state(self, prefix=""):
@@ -272,6 +287,7 @@ class _BBBInt8(nn.Module):
         if layout != self.layout or krow != getattr(self, "krow_override", None):
             self.layout, self.krow_override = layout, krow
             self._packed, self._presampled = None, None
+            bump_state_epoch()
 
     def _krow(self, w_ohwi):
         """Bytes of one kernel row (kw, c) in the OHWI weight: the unit the packed K axis is padded by.  The 3-channel

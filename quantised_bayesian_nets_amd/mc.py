@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .layers import mc_context, timed
+from .layers import mc_context, state_epoch, timed
 
 
 def shard_samples(samples, rank, world_size):
@@ -149,15 +149,10 @@ class GraphedPredictor:
 
     def __init__(self, model, samples, return_var=False, regression=False, group=None):
         self.model, self.samples, self.return_var, self.regression, self.group = model, int(samples), return_var, regression, group
+        # A captured graph holds raw device pointers to the packed weights / qparams of the state it was captured with.  Every path
+        # that may drop or replace such a buffer (a state dict loaded into any layer, a packed layout switched by an eager call with
+        # `record=` / another fast-path flag) bumps layers.state_epoch(); an entry captured under an older epoch is captured again.
         self._graphs = {}
-        # A captured graph holds raw device pointers to the packed weights / qparams of the state it was captured with: loading
-        # another state into the model drops every graph (the next call captures again).
-        loader = getattr(model, "load_reference_state", None)
-        if loader is not None:
-            def _load_and_invalidate(*a, **k):
-                self._graphs.clear()
-                return loader(*a, **k)
-            model.load_reference_state = _load_and_invalidate
         self._is_ensemble = hasattr(model, "ensemble")
 
     def _local(self, x, begin, count):
@@ -184,7 +179,7 @@ class GraphedPredictor:
                 res = self._local(static_x, begin, count)
         finally:
             _lib.check(L.qbnn_set_device_noise_source(None))
-        return static_x, noise, graph, res
+        return static_x, noise, graph, res, state_epoch()        # the epoch AFTER the warm-up call has settled layouts and caches
 
     def __call__(self, x, seed, sample_begin=0):
         import numpy as np
@@ -206,9 +201,9 @@ class GraphedPredictor:
             return (mean, var) if self.return_var else mean
         key = (tuple(x.shape), x.dtype, x.device.index, begin, count)
         ent = self._graphs.get(key)
-        if ent is None:
+        if ent is None or ent[4] != state_epoch():
             ent = self._graphs[key] = self._capture(x, begin, count)
-        static_x, noise, graph, res = ent
+        static_x, noise, graph, res, _epoch = ent
         static_x.copy_(x)
         # the three noise words go up from a FRESH pageable tensor with a blocking copy: the runtime stages pageable memory before
         # the call returns, so a later call can never overwrite words that an earlier replay has not read yet (one reused pinned

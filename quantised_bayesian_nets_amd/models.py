@@ -172,7 +172,7 @@ class ConvNetwork_ResNet(nn.Module):
     def __init__(self, input_size, output_size, q, args, deterministic=False):
         super().__init__()
         if not q:
-            raise NotImplementedError("only the converted int8 model (q=True) is built so far")
+            raise NotImplementedError("this class is the converted int8 graph; ModelFactory routes q=False to models_f32.ConvNetwork_ResNet")
         check_bits(args)
         self.args, self.q = args, q
         self.deterministic = deterministic       # True: an ensemble member (standard quantised layers, no weight noise)
@@ -618,10 +618,10 @@ class ModelFactory:
                 return ConvNetwork_LeNetF32(input_size, output_size, q, args)
             from .models_small import ConvNetwork_LeNet as ConvNetwork_LeNetBBB
             return ConvNetwork_LeNetBBB(input_size, output_size, q, args)
-        if model == "conv_resnet_mc":
-            from .models_mc import ConvNetwork_ResNet as ConvNetwork_ResNetMC
-            return ConvNetwork_ResNetMC(input_size, output_size, q, args)
-        if model == "conv_lenet_mc":
-            from .models_mc import ConvNetwork_LeNet as ConvNetwork_LeNetMC
-            return ConvNetwork_LeNetMC(input_size, output_size, q, args)
+        if model in ("linear_mc", "conv_lenet_mc", "conv_resnet_mc"):
+            # q=True: the converted int8 graph (models_mc); q=False: the float graph with the FloatFunctional dropout (models_mc_f32)
+            from . import models_mc, models_mc_f32
+            mod = models_mc if q else models_mc_f32
+            cls = {"linear_mc": mod.LinearNetwork, "conv_lenet_mc": mod.ConvNetwork_LeNet, "conv_resnet_mc": mod.ConvNetwork_ResNet}[model]
+            return cls(input_size, output_size, q, args)
         raise NotImplementedError("Other models not implemented")

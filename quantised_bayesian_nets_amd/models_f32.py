@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .layers import _MC, mc_context, timed
+from .layers import _MC, bump_state_epoch, mc_context, timed
 
 
 class Linear(nn.Module):
@@ -98,6 +98,7 @@ class LinearNetwork(nn.Module):
             m.std.data = torch.from_numpy(np.asarray(state[n + ".std"], np.float32).copy())
             m.bias.data = torch.from_numpy(np.asarray(state[n + ".bias"], np.float32).copy())
             m._sigma = None
+        bump_state_epoch()
         return self
 
     def get_kl_divergence(self):
@@ -307,6 +308,7 @@ def _load_bbb(m, state, name):
     if getattr(m, "bias", None) is not None and name + ".bias" in state:
         m.bias.data = torch.from_numpy(np.asarray(state[name + ".bias"], np.float32).copy())
     m._sigma = None
+    bump_state_epoch()
 
 
 def _load_bn(m, state, name):
@@ -315,6 +317,7 @@ def _load_bn(m, state, name):
     m.running_mean = torch.from_numpy(np.asarray(state[name + ".running_mean"], np.float32).copy())
     m.running_var = torch.from_numpy(np.asarray(state[name + ".running_var"], np.float32).copy())
     m._ab = None
+    bump_state_epoch()
 
 
 class ConvNetwork_LeNet(nn.Module):

@@ -1,7 +1,7 @@
 """MC-Dropout models behind the reference's API (BASELINE config 2).
 
 Mirror of reference src/models/stochastic/mcdropout/dropout.py (`BernoulliDropout`, :6-46) and
-models_mc.py (`ConvNetwork_LeNet`, :75-111) in their converted int8 form (quant_utils.prepare_model -> convert):
+models_mc.py (`LinearNetwork`, :10-73; `ConvNetwork_LeNet`, :75-111; `ConvNetwork_ResNet`, :162-226) in their converted int8 form (quant_utils.prepare_model -> convert):
 deterministic torch.nn.quantized Conv2d / Linear(ReLU) layers with an always-on quantised Bernoulli dropout.
 All S MC samples of the active mc_context are evaluated per call; masks come from the Philox uniform stream
 (seed, dropout index, global sample index) instead of torch's global generator.
@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .layers import MCQTensor, QFunctional, QuantizedParam, _MC, mc_context, timed
+from .layers import MCQTensor, QFunctional, QuantizedParam, _MC, bump_state_epoch, mc_context, timed
 from .quant import UINT_BOUNDS, check_bits
 
 
@@ -85,6 +85,7 @@ class _QDeterministic(nn.Module):
         self.scale, self.zero_point = float(state[prefix + "scale"]), int(state[prefix + "zero_point"])
         self._dev = None
         self._pk = None          # the packed-fragment copy too: it is keyed by (krow, device) only
+        bump_state_epoch()
         return self
 
     def _device_params(self, device, w_ohwi):
@@ -312,6 +313,76 @@ class MaxPool2dQ(nn.Module):
         return MCQTensor(y, x.scale, x.zero_point, shared=x.shared)
 
 
+class LinearNetwork(nn.Module):
+    """reference mcdropout/models_mc.py:10-73 (`linear_mc`, the MC-Dropout regression MLP), converted int8 form: QuantStub ->
+    3 x LinearReLU(100) with a per-element BernoulliDropout after the first two -> heads `mu` / `log_var` = [BernoulliDropout,
+    Linear(100, 1)] -> DeQuant -> (mu, exp(log_var)).  Mask draw order = execution order: layers.2, layers.5, mu.0, log_var.0."""
+
+    def __init__(self, input_size, output_size, q, args):
+        super().__init__()
+        if not q:
+            raise NotImplementedError("this class is the converted int8 graph; ModelFactory routes q=False to models_mc_f32.LinearNetwork")
+        check_bits(args)
+        self.args, self.q = args, q
+        self.input_size = 1
+        for i in input_size:
+            self.input_size *= int(i)
+        self.output_size = int(output_size)
+        ident = nn.Identity
+        self.layers = nn.ModuleList([QLinearReLU(self.input_size, 100, bias=True, args=args), ident(), BernoulliDropout(args.p),
+                                     QLinearReLU(100, 100, bias=True, args=args), ident(), BernoulliDropout(args.p),
+                                     QLinearReLU(100, 100, bias=True, args=args), ident()])
+        self.mu = nn.ModuleList([BernoulliDropout(args.p), QLinear(100, 1, bias=True, args=args)])
+        self.log_var = nn.ModuleList([BernoulliDropout(args.p), QLinear(100, 1, bias=True, args=args)])
+        for i, m in enumerate(self.dropouts()):
+            m.layer_id, m.args = i, args
+        from .models import QuantStub
+        self.quant = QuantStub()
+
+    def dropouts(self):
+        return [self.layers[2], self.layers[5], self.mu[0], self.log_var[0]]
+
+    def load_reference_state(self, state):
+        for n, m in (("layers.0.", self.layers[0]), ("layers.3.", self.layers[3]), ("layers.6.", self.layers[6]), ("mu.1.", self.mu[1]),
+                     ("log_var.1.", self.log_var[1])):
+            m.load_reference_state(state, n)
+        for n, d in zip(("layers.2.", "layers.5.", "mu.0.", "log_var.0."), self.dropouts()):
+            _load_dropout(d, state, n)
+        self.quant.scale = float(np.asarray(state["quant.scale"]).reshape(-1)[0])
+        self.quant.zero_point = int(np.asarray(state["quant.zero_point"]).reshape(-1)[0])
+        return self
+
+    def forward_mc(self, x, record=None, masks=None):
+        """All S samples of the current mc_context -> (mu [S,B,1], var [S,B,1]) fp32.  masks: optional list of fp32 [S, B, 100] in draw
+        order (parity mode); record: optional dict that receives every layer's quint8 output."""
+        if x.device.type != "cuda":
+            raise RuntimeError("qbnn models run on an MI355X only (no CPU fallback)")
+        rec = (lambda k, v: record.__setitem__(k, v)) if record is not None else (lambda k, v: None)
+        masks = list(masks) if masks is not None else None
+        take = lambda: masks.pop(0) if masks is not None else None
+        x2 = x.to(torch.float32).reshape(x.shape[0], -1).contiguous()
+        B, K = x2.shape
+        xq = torch.empty((1, B, K), dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.lib().qbnn_quantize_input_nchw(_lib.ptr(x2), B, K, 1, 1, self.quant.scale, self.quant.zero_point, _a_hi(self.args),
+                                                       _lib.ptr(xq), _lib.current_stream()))
+        h = MCQTensor(xq, self.quant.scale, self.quant.zero_point, shared=True); rec("quant.out", h.data)
+        h = self.layers[0](h); rec("layers.0.out", h.data)
+        h = self.layers[2](h, take()); rec("layers.2.out", h.data)
+        h = self.layers[3](h); rec("layers.3.out", h.data)
+        h = self.layers[5](h, take()); rec("layers.5.out", h.data)
+        h = self.layers[6](h); rec("layers.6.out", h.data)
+        hm = self.mu[0](h, take()); rec("mu.0.out", hm.data)
+        qm = self.mu[1](hm); rec("mu.1.out", qm.data)
+        hv = self.log_var[0](h, take()); rec("log_var.0.out", hv.data)
+        qv = self.log_var[1](hv); rec("log_var.1.out", qv.data)
+        return qm.dequantize(), torch.exp(qv.dequantize())
+
+    def forward(self, x):
+        with mc_context(1, _MC.seed, _MC.sample_begin, _MC.eps):
+            mu, var = self.forward_mc(x)
+        return mu[0], var[0]
+
+
 class ConvNetwork_LeNet(nn.Module):
     """reference mcdropout/models_mc.py:75-111 (`conv_lenet_mc`), converted int8 form."""
     fast_tail = True        # layers.3 .. 10 on qbnn_conv_pool_drop_i8_mc + qbnn_linear_i8_mc (False: one any-geometry launch per op)
@@ -319,7 +390,7 @@ class ConvNetwork_LeNet(nn.Module):
     def __init__(self, input_size, output_size, q, args):
         super().__init__()
         if not q:
-            raise NotImplementedError("only the converted int8 model (q=True) is built so far")
+            raise NotImplementedError("this class is the converted int8 graph; ModelFactory routes q=False to models_mc_f32.ConvNetwork_LeNet")
         check_bits(args)
         self.args, self.q = args, q
         self.init_channels = input_size[0]
@@ -579,7 +650,7 @@ class ConvNetwork_ResNet(nn.Module):
     def __init__(self, input_size, output_size, q, args):
         super().__init__()
         if not q:
-            raise NotImplementedError("only the converted int8 model (q=True) is built")
+            raise NotImplementedError("this class is the converted int8 graph; ModelFactory routes q=False to models_mc_f32.ConvNetwork_ResNet")
         check_bits(args)
         self.args, self.q = args, q
         self.output_size = int(output_size)

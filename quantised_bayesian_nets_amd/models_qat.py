@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .layers import _MC, mc_context, timed
+from .layers import _MC, bump_state_epoch, mc_context, timed
 from .models_f32 import (affine_f32, conv2d_f32, flatten_f32, nchw_to_mc_nhwc, pool2d_f32, sample_conv_weights_f32, softmax_f32)
 from .quant import INT_BOUNDS, UINT_BOUNDS
 
@@ -285,6 +285,7 @@ class ConvNetwork_LeNet(nn.Module):
         return prepared_state(self)
 
     def load_reference_state(self, st):
+        bump_state_epoch()
         self._prepared = st
         self.quant.activation_post_process.load(st, "quant.activation_post_process")
         for n, m in zip(self.stochastic_layer_names(), self.stochastic_layers()):
@@ -336,6 +337,7 @@ class LinearNetwork(nn.Module):
         return prepared_state(self)
 
     def load_reference_state(self, st):
+        bump_state_epoch()
         self._prepared = st
         self.quant.activation_post_process.load(st, "quant.activation_post_process")
         for n, m in zip(self.stochastic_layer_names(), self.stochastic_layers()):
@@ -414,6 +416,7 @@ class ConvNetwork_ResNet(nn.Module):
         return prepared_state(self)
 
     def load_reference_state(self, st):
+        bump_state_epoch()
         self._prepared = st
         self.quant.activation_post_process.load(st, "quant.activation_post_process")
         for n, m in self.stochastic_named():

@@ -56,3 +56,28 @@ def golden_mlp_bbb_q():
     return dict(state={k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")},
                 rec={k[len("rec/"):]: d[k] for k in d.files if k.startswith("rec/")}, x=d["x"], mu=d["mu"], var=d["var"],
                 seed=int(d["meta.philox_seed"]))
+
+
+def _npz(name):
+    d = np.load(os.path.join(GOLDEN, name))
+    out = {k: d[k] for k in d.files if "/" not in k and not k.startswith("meta.") and not k.startswith("refspread.")}
+    out["state"] = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    out["rec"] = {k[len("rec/"):]: d[k] for k in d.files if k.startswith("rec/")}
+    out["meta"] = {k[len("meta."):]: (float(d[k]) if d[k].dtype.kind == "f" else int(d[k])) for k in d.files if k.startswith("meta.")}
+    out["refspread"] = {k[len("refspread."):]: float(d[k]) for k in d.files if k.startswith("refspread.")}
+    return out
+
+
+@pytest.fixture(scope="session")
+def golden_mlp_mc_q():
+    """`linear_mc` int8 A7/W8 (tests/golden/make_golden_linear_mc.py)."""
+    return _npz("mlp_mc_a7w8.npz")
+
+
+@pytest.fixture(scope="session", params=[("mlp_mc_f32.npz", "linear_mc"), ("lenet_mc_f32.npz", "conv_lenet_mc"), ("resnet_mc_f32.npz", "conv_resnet_mc")],
+                ids=["mlp", "lenet", "resnet"])
+def golden_mc_f32(request):
+    """The float MC-Dropout graphs (tests/golden/make_golden_mc_f32.py): (fixture, factory name)."""
+    g = _npz(request.param[0])
+    g["model"] = request.param[1]
+    return g

@@ -267,3 +267,47 @@ def test_int8_noise_stream_alias_sampler():
     import torch
     back = torch.quantize_per_tensor(torch.from_numpy(orc.eps_from_eps_q(kk)), orc.NOISE_SCALE, 0, torch.qint8).int_repr().numpy()
     assert np.array_equal(back, kk)
+
+
+def test_linear_mc_int8_bit_exact(golden_mlp_mc_q):
+    """Row a6+ (`linear_mc`, mcdropout/models_mc.py:10-73), int8: every layer of sample 0 bit for bit, every sample's (mu, var) and the
+    regression reduction of experiments/utils.py:348-353 against the reference's recorded outputs."""
+    g = golden_mlp_mc_q
+    net = orc.Int8MLPMCOracle(g["state"], 7)
+    seed = g["meta"]["philox_seed"]
+    rec = {}
+    net.forward(g["x"], seed, 0, record=rec)
+    assert set(g["rec"]) <= set(rec) and len(g["rec"]) == 10
+    for k, v in g["rec"].items():
+        assert np.array_equal(rec[k].reshape(v.shape), v), k
+    for s in range(g["mu"].shape[0]):
+        mu, var = net.forward(g["x"], seed, s)
+        np.testing.assert_allclose(mu, g["mu"][s], rtol=1e-6, atol=0)
+        np.testing.assert_allclose(var, g["var"][s], rtol=1e-6, atol=0)
+    mean, pv = net.mc_predict(g["x"], g["mu"].shape[0], seed)
+    np.testing.assert_allclose(mean, g["mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pv, g["pred_var"], rtol=1e-5, atol=1e-9)
+    # injected masks == the Philox masks
+    keep = np.float32(1.0) - np.float32(g["meta"]["p"])
+    B = g["x"].shape[0]
+    masks = [(orc.fill_uniform(B * 100, seed, di, 2) < keep).astype(np.float32).reshape(B, 100) for di in range(4)]
+    mu_i, var_i = net.forward(g["x"], 12345, 0, masks=masks)
+    assert np.array_equal(mu_i, net.forward(g["x"], seed, 2)[0])
+
+
+def test_float_mc_dropout_graphs_match_reference(golden_mc_f32):
+    """Rows a6+ / a7 with q=False: the float MC-Dropout MLP, LeNet and ResNet against the reference's recorded outputs.  Tolerance: the
+    reference's own spread between its two CPU backends (recorded in the fixture) plus the oracle's fp64-accumulation offset (1e-5 rel)."""
+    g = golden_mc_f32
+    net = orc.F32MCOracle(g["state"])
+    seed = g["meta"]["philox_seed"]
+    if g["model"] == "linear_mc":
+        for s in range(g["mu"].shape[0]):
+            mu, var = net.mlp(g["x"], seed, s)
+            np.testing.assert_allclose(mu, g["mu"][s], rtol=1e-5, atol=1e-5 * np.abs(g["mu"]).max())
+            np.testing.assert_allclose(var, g["var"][s], rtol=1e-5, atol=0)
+        return
+    fwd = net.lenet if "lenet" in g["model"] else net.resnet
+    atol = 2 * g["refspread"]["max_abs"] + 1e-7
+    for s in range(g["probs"].shape[0]):
+        np.testing.assert_allclose(fwd(g["x"], seed, s), g["probs"][s], rtol=1e-5, atol=atol)
