@@ -21,12 +21,7 @@ QBNN_EXPORT void qbnn_debug_read_inner(unsigned long long* host4) {
 //                                               --conv_a-->  T tile (COUT, HO): centred stem.0 output
 //   T --conv_b--> + SC --> SC in place (block output, quint8) --> HBM
 // =====================================================================================
-struct DownArgs {
-  const uint8_t* x; int64_t x_ss;
-  uint8_t* y; int64_t y_ss;
-  int B, n_samples, z_in;
-  QConv s, a, b; QAdd add;
-};
+// (DownArgs: qbnn_conv.h -- shared with the ring form of the wide blocks, qbnn_down_ring.hip)
 
 template <class CA, class CS, class CB, bool LDSW> static int launch_block_down_ws(const DownArgs& a, hipStream_t st);
 static bool no_pingpong() {
@@ -82,8 +77,8 @@ QBNN_EXPORT int qbnn_block_down_i8_multi(const qbnn_down_call* calls, int32_t n_
       if ((rc = build_down_args(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.desc, k.y, k.y_sample_stride, k.n_samples))) return rc;
     }
     if (Cin == 24 && H == 32) rc = launch_block_down_ws_multi<D24_a, D24_s, D24_b, true>(arr, n, st);
-    else if (Cin == 48 && H == 16) rc = launch_block_down_ws_multi<D48_a, D48_s, D48_b, false>(arr, n, st);
-    else if (Cin == 96 && H == 8) rc = launch_block_down_ws_multi<D96_a, D96_s, D96_b, false>(arr, n, st);
+    else if (Cin == 48 && H == 16) rc = qbnn_use_down_ring() ? qbnn_launch_block_down_ring(arr, n, 48, st) : launch_block_down_ws_multi<D48_a, D48_s, D48_b, false>(arr, n, st);
+    else if (Cin == 96 && H == 8) rc = qbnn_use_down_ring() ? qbnn_launch_block_down_ring(arr, n, 96, st) : launch_block_down_ws_multi<D96_a, D96_s, D96_b, false>(arr, n, st);
     else return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
     if (rc) return rc;
     c0 += n;
@@ -102,8 +97,9 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
   // (a ping-pong variant of this block -- phases W / M_a / E_sa / M_b / E_b on two 4-wave groups -- measured 15 % SLOWER
   //  than the weights-stationary kernel: five barrier intervals per image, each as long as the slower group's phase)
   if (Cin == 24 && H == 32) return launch_block_down_ws<D24_a, D24_s, D24_b, true>(a, st);
-  if (Cin == 48 && H == 16) return launch_block_down_ws<D48_a, D48_s, D48_b, false>(a, st);
-  if (Cin == 96 && H == 8) return launch_block_down_ws<D96_a, D96_s, D96_b, false>(a, st);
+  // 48 -> 96 and 96 -> 192: the block's weights through the LDS slab ring (qbnn_down_ring.hip, round 4); QBNN_DOWN_RING=0: per-wave L2 streaming
+  if (Cin == 48 && H == 16) return qbnn_use_down_ring() ? qbnn_launch_block_down_ring(&a, 1, 48, st) : launch_block_down_ws<D48_a, D48_s, D48_b, false>(a, st);
+  if (Cin == 96 && H == 8) return qbnn_use_down_ring() ? qbnn_launch_block_down_ring(&a, 1, 96, st) : launch_block_down_ws<D96_a, D96_s, D96_b, false>(a, st);
   return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
 }
 
@@ -1429,8 +1425,10 @@ QBNN_EXPORT int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_
   const DownArgs* dev = reinterpret_cast<const DownArgs*>(dev_args);
   auto items = [&](int G) { return max_samples * ((B + G - 1) / G); };
   if (Cin == 24 && H == 32) return launch_block_down_ws_dev<D24_a, D24_s, D24_b, true>(dev, n_calls, items(D24_a::G), st);
-  if (Cin == 48 && H == 16) return launch_block_down_ws_dev<D48_a, D48_s, D48_b, false>(dev, n_calls, items(D48_a::G), st);
-  if (Cin == 96 && H == 8) return launch_block_down_ws_dev<D96_a, D96_s, D96_b, false>(dev, n_calls, items(D96_a::G), st);
+  if (Cin == 48 && H == 16)
+    return qbnn_use_down_ring() ? qbnn_launch_block_down_ring_dev(dev, n_calls, items(D48_a::G), 48, st) : launch_block_down_ws_dev<D48_a, D48_s, D48_b, false>(dev, n_calls, items(D48_a::G), st);
+  if (Cin == 96 && H == 8)
+    return qbnn_use_down_ring() ? qbnn_launch_block_down_ring_dev(dev, n_calls, items(D96_a::G), 96, st) : launch_block_down_ws_dev<D96_a, D96_s, D96_b, false>(dev, n_calls, items(D96_a::G), st);
   return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_launch: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
 }
 

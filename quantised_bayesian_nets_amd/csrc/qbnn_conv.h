@@ -804,6 +804,14 @@ struct ChainArgs {
   QConv stem;
 };
 
+// argument block of the fused down-sampling BasicBlock kernels (qbnn_blocks.hip: block_down_ws_kernel; qbnn_down_ring.hip)
+struct DownArgs {
+  const uint8_t* x; int64_t x_ss;
+  uint8_t* y; int64_t y_ss;
+  int B, n_samples, z_in;
+  QConv s, a, b; QAdd add;      // shortcut 1x1/s2, stem.0 3x3/s2 (ReLU), stem.3 3x3, Add
+};
+
 // Several independent launches of one fused kernel in ONE grid: gridDim.y (head: gridDim.z) picks the argument block.  Used for
 // ensemble members (reference sgld/models_sgld.py:277-288): every member has its own tensors, weights AND quantisation
 // parameters, so it cannot ride the MC-sample dimension of a launch -- but member m's workgroups can sit next to member

@@ -1,0 +1,423 @@
+// libqbnn_hip.so -- ring form of the WIDE down-sampling BasicBlocks (reference models_bbb.py:146-183 with stride 2:
+// shortcut 1x1/s2 conv, stem.0 3x3/s2 ConvReLU, stem.3 3x3 conv, Add, ReLU) at 48 -> 96 channels (16 x 16 -> 8 x 8) and
+// 96 -> 192 (8 x 8 -> 4 x 4).  Same arithmetic, epilogue functors and argument block as block_down_ws_kernel (qbnn_blocks.hip).
+//
+// Why a second form (round 4): block_down_ws_kernel streams every weight fragment of these blocks per WAVE from L2 through the
+// vector L1 -- one pixel tile per wave, so 1 KiB of weights per MFMA, 1.0 / 2.0 MB per work item through a 64 B/clk L1 (counters:
+// issue-stalled 36 / 47 % of wave-cycles, MFMA busy 23 / 24 %).  Here the block's weights reach the CU ONCE per work item: the 8 waves
+// DMA them (global_load_lds) into an LDS slab ring and read their fragments with ds_read_b128, as the identity chains of these widths do.
+// A two-slab ring (one slab in flight) was measured first and is DMA-latency-bound here: these items have 12 MFMAs per wave and slab
+// against an L2 -> LDS latency of 2.5 - 3 k cycles under load (one 30 KiB slab in flight = 10 B/clk per CU; profiles/r04_stamp_down_ring.txt).
+// So the ring is NBUF = 4 slabs deep with THREE in flight (72 KiB per CU, the guide's figure for the full L2 -> LDS rate):
+//   * the DMA is issued from inline assembly -- the compiler otherwise puts `s_waitcnt vmcnt(0)` in front of every LDS access that
+//     follows a global_load_lds it cannot prove disjoint (all of the epilogues' bias reads / tile writes), draining the ring each time;
+//   * a wave waits for ITS share of slab q with `s_waitcnt vmcnt((NBUF - 2) * C)` (C = its DMA instructions per slab: counters retire in
+//     order, and any other vector-memory operation in between only makes the wait stricter), then the workgroup barrier publishes
+//     the slab and frees the buffer of slab q - 1, into which slab q + NBUF - 1 is requested.
+//
+// LDS: X tile (centred block input, zero halo on the top / left only -- a stride-2, pad-1 window never leaves the map at the
+//        bottom / right; kernel rows stay contiguous, so k-steps may straddle taps: Cin = 48), rows padded by 16 B at 48 channels (bank conflicts
+//        of the stride-2 fragment reads: 4-way -> 2-way; tools/lds_conflicts.py)
+//      T tile (centred stem.0 output, dense [M][COUT + 16] + a zero line that taps outside the map read) and SC (shortcut output =
+//        residual = block output staging, quint8 [M][COUT + 8]) both ALIAS X: stem.0 and the shortcut accumulate first (two accumulator
+//        sets), a barrier marks the last read of X, then both epilogues run; the next item's X is written after SC's read-out
+//      four weight slabs of 24 KiB, biases.
+// Phases per work item (M = MFMA K loop over the ring, E = requantising epilogue):
+//      M_a M_s | barrier | E_a(-> T) E_s(-> SC)   M_b E_b(SC += , ReLU)   | barrier, read-out, barrier, next X
+// Window sums (sampled weights have a non-zero zero point: sum x'(W - z_w) = acc - z_w R) by v_dot4 on the pixel fragments in the K loop.
+#include "qbnn_host.h"
+
+#ifdef QBNN_STAMP      // diagnostic build only (tools/stamp_ring.py): per-phase s_memtime sums; the shipped library has none of this
+QBNN_EXPORT void qbnn_debug_stamp_buffer_ring(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_dev_ptr), &p, sizeof(p)); }
+QBNN_EXPORT void qbnn_debug_read_inner_ring(unsigned long long* host4) {
+  hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_inner), 32);
+  unsigned long long z[4] = {0, 0, 0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_inner), z, 32);
+}
+#endif
+
+namespace {
+
+//                      CIN COUT HIN  G  SLK (k-steps per weight slab)  XROWPAD (bytes behind every X row)
+template <int CIN_, int COUT_, int HIN_, int G_, int SLK_, int XROWPAD_>
+struct DRCfg {
+  static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, HO = HIN_ / 2, G = G_, SLK = SLK_;
+  static constexpr int XTW = HIN + 1;                       // top / left halo
+  static constexpr int XROW = XTW * CIN + XROWPAD_;         // row pitch: bank conflicts of the stride-2 fragment reads (tools/lds_conflicts.py)
+  static constexpr int XIMG = XTW * XROW;
+  static constexpr int X_BYTES = G * XIMG + ((3 * CIN) % 32 ? 32 : 0);      // the last k-step of a ragged kernel row over-reads < 32 bytes
+  static constexpr int RB_A = 3 * CIN, SPR_A = (RB_A + 31) / 32, KS_A = 3 * SPR_A;      // stem.0: 3x3 / s2 on X
+  static constexpr int KS_S = (CIN + 31) / 32;                                          // shortcut: 1x1 / s2 on X
+  static constexpr int SPT_B = COUT / 32, KS_B = 9 * SPT_B;                             // stem.3: 3x3 / s1 on T
+  static constexpr int NT = COUT / 32, NB = 3, NBLKS = NT / NB;
+  static constexpr int M = G * HO * HO, MT = M / 32;
+  static constexpr int PIXB_T = COUT + 16;                  // 112 / 208 bytes: conflict-free ds_read_b128 of 32 consecutive pixels
+  static constexpr int T_BYTES = M * PIXB_T + PIXB_T;       // + the zero line
+  static constexpr int SCP = COUT + 8, SC_BYTES = M * SCP;
+  static constexpr int SC_OFF = T_BYTES;                    // T at byte 0 of the X region, SC behind it
+  // the weight ring: NBUF slabs of SLK k-steps x NT channel tiles (1 KiB fragments); a slab never spans two convs, a conv's last
+  // slab may be short (its spare fragments are loaded twice: every wave issues the same number of DMA instructions per slab)
+  static constexpr int NBUF = 4;
+  static constexpr int NF = NT * SLK, DMA_PER_WAVE = NF / 8;
+  static constexpr int SLABB = NF * 1024;
+  static constexpr int NS_A = (KS_A + SLK - 1) / SLK, NS_S = (KS_S + SLK - 1) / SLK, NS_B = (KS_B + SLK - 1) / SLK, NSI = NS_A + NS_S + NS_B;
+  static constexpr int LDS = X_BYTES + NBUF * SLABB + 3 * COUT * 4;
+  static constexpr int ROWB = HIN * CIN, CPR = ROWB / 16, CPI = HIN * CPR, NCH = G * CPI;      // 16-byte chunks of the item's input
+  static constexpr int NHALO = XTW * CIN / 16 + HIN * (CIN / 16);                              // ... of one image's halo
+  static_assert(MT * NBLKS == 8, "one (pixel tile, channel half) pass per wave");
+  static_assert(NF % 8 == 0, "every wave issues the same number of DMA instructions per slab");
+  static_assert(XROW % 16 == 0 && XIMG % 16 == 0 && CIN % 16 == 0 && COUT % 96 == 0 && M % 32 == 0 && T_BYTES % 16 == 0, "alignment");
+  static_assert(SC_OFF + SC_BYTES <= G * XIMG, "T and SC alias the X tile");
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+using DR48 = DRCfg<48, 96, 16, 4, 8, 16>;     // 24 KiB slabs (NT = 3); X reads 2-way conflicted (4-way without the row pad)
+using DR96 = DRCfg<96, 192, 8, 8, 4, 0>;      // 24 KiB slabs (NT = 6); X reads 2-way conflicted -- a 16-byte row pad makes them conflict-free,
+                                              // but then the fourth slab buffer no longer fits (164,000 B), and three slabs in flight matter more
+// epilogue blocking (MB = 1 pixel tile x NB = 3 channel tiles per wave): conv_epi_phase reads MB / NB / NBLKS / COUT of these
+using E48 = ConvCfg<48, 96, 3, 2, 16, 1, 4, 1, 3, false>;
+using E96 = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
+
+// 16 bytes per lane, global -> LDS at lds_addr + 16 * lane, without passing through registers.  Issued from inline assembly: see the
+// header comment (the compiler must not know that LDS is written behind its back; this file does its own vmcnt accounting).
+__device__ __forceinline__ void dma16(const void* gptr, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const uint8_t* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// s_waitcnt vmcnt(K) only (gfx9 encoding: vmcnt = {[15:14], [3:0]}, expcnt [6:4] and lgkmcnt [11:8] left at "no wait")
+template <int K> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(K >= 0 && K < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt((K & 0xf) | ((K >> 4) << 14) | 0x0f70);
+}
+
+// stem.0's epilogue: ConvReLU2d output, centred on its zero point, into the dense T tile [M][PIXB]
+template <int PIXB>
+struct EpiT {
+  uint8_t* dst; QConv p;
+  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
+    *reinterpret_cast<uint32_t*>(dst + po + c0) = pack_rne_u8(v0, v1, v2, v3, p.vhi);      // p.vlo == 0 (fill_qconv, relu = 1)
+  }
+};
+
+struct StepSrc { const uint8_t* p; int m0, m1; };      // a k-step's pixel fragment address and the dot4 masks of its two 8-byte pieces
+
+// The workgroup's weight ring: consumer position (buffer of the slab being multiplied) and producer position (flat index of the next
+// slab to request; one item = NSI slabs: stem.0's, the shortcut's, stem.3's).
+template <class D>
+struct Ring {
+  uint8_t* base; int cbuf, pbuf, pnext;
+};
+
+// One conv's M phase: its KS k-steps as ONE software-pipelined stream (fragments are requested PD k-steps ahead of their MFMAs -- with
+// three MFMAs per k-step and wave, one step ahead exposed the LDS latency at every step: 625 cycles per k-step against 96 of MFMAs,
+// profiles/r04_stamp_down_ring.txt), fully unrolled, so every tile offset is an immediate.  Where the stream of requests enters a new
+// weight slab the ring advances IN the stream: wait for the slab, barrier, request slab + NBUF - 1 -- the MFMAs of the previous slab's
+// last steps are still to issue, so the pipeline does not drain at slab boundaries.  This wave accumulates its pixel tile against the
+// channel tiles nblk * 3 .. + 2.  step(ks) -> StepSrc of k-step ks; issue(q, buffer) requests flat slab q.
+template <class D, int KS, class StepFn, class IssueFn>
+__device__ __forceinline__ void ring_mfma(StepFn step, Ring<D>& rg, ConvAccMN<1, 3>& A, int nblk, int wave, int lane, IssueFn issue) {
+  constexpr int SLK = D::SLK, PD = 3;
+  A.rsum[0] = 0;
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) A.acc[0][nb][i] = 0;
+  struct Frag { v4i w[3]; v4i x; int m0, m1; };
+  Frag f[PD + 1];
+  const uint8_t* wl = nullptr;
+  auto advance = [&]() {
+    wait_vmcnt<(D::NBUF - 2) * D::DMA_PER_WAVE>();      // this wave's share of the slab has landed ...
+    lds_barrier();                                      // ... everyone's has; everyone has read the previous slab's last fragments
+    issue(rg.pnext, rg.pbuf);
+    ++rg.pnext;
+    rg.pbuf = rg.pbuf + 1 == D::NBUF ? 0 : rg.pbuf + 1;
+    wl = rg.base + rg.cbuf * D::SLABB + ((nblk * 3) * SLK * 64 + lane) * 16;
+    rg.cbuf = rg.cbuf + 1 == D::NBUF ? 0 : rg.cbuf + 1;
+  };
+  auto load = [&](Frag& fr, int ks) {
+    const int j = ks % SLK;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) fr.w[nb] = *reinterpret_cast<const v4i*>(wl + (nb * SLK + j) * 1024);
+    const StepSrc s = step(ks);
+    fr.x = *reinterpret_cast<const v4i*>(s.p);
+    fr.m0 = s.m0; fr.m1 = s.m1;
+  };
+  auto mfma = [&](const Frag& fr) {
+    int rs = A.rsum[0];
+    rs = __builtin_amdgcn_sdot4(fr.x.x, fr.m0, rs, false);
+    rs = __builtin_amdgcn_sdot4(fr.x.y, fr.m0, rs, false);
+    rs = __builtin_amdgcn_sdot4(fr.x.z, fr.m1, rs, false);
+    rs = __builtin_amdgcn_sdot4(fr.x.w, fr.m1, rs, false);
+    A.rsum[0] = rs;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) A.acc[0][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr.w[nb], fr.x, A.acc[0][nb], 0, 0, 0);
+  };
+#pragma unroll
+  for (int p = 0; p < PD && p < KS; ++p) {
+    if (p % SLK == 0) advance();
+    load(f[p % (PD + 1)], p);
+  }
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    const int p = j + PD;
+    if (p < KS) {
+      if (p % SLK == 0) advance();
+      load(f[p % (PD + 1)], p);
+    }
+    mfma(f[j % (PD + 1)]);
+    // keep the steps apart: left alone, the scheduler hoists the v_dot4 of a fragment to right behind its ds_read (they only depend on the
+    // window-sum chain) and waits for the read there -- the request distance is gone
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <class D, class EC, int NM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
+  const DownArgs& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  constexpr int NTHR = 512;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* xt = smem;
+  uint8_t* tt = smem;                                        // T and SC alias X (see the header comment)
+  uint8_t* zline = tt + D::M * D::PIXB_T;
+  uint8_t* sc = smem + D::SC_OFF;
+  uint8_t* rbase = smem + D::X_BYTES;
+  float* bias_lds = reinterpret_cast<float*>(rbase + D::NBUF * D::SLABB);               // [3][COUT]: s, a, b
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mblk = wave / D::NBLKS, nblk = wave - mblk * D::NBLKS;
+
+  constexpr int PER_T = (D::NCH + NTHR - 1) / NTHR;
+  constexpr int IMG_IN = D::HIN * D::HIN * D::CIN, IMG_OUT = D::HO * D::HO * D::COUT, U8 = D::COUT / 8;
+  constexpr int NOUT = (D::M * U8 + NTHR - 1) / NTHR;
+  const int groups = (a.B + D::G - 1) / D::G;
+  const ItemWalk walk(a.n_samples * groups, blockIdx.x, gridDim.x);      // interleaved per XCD: a sample's weights stay in ONE L2
+  const int count = walk.count;
+
+  load_bias<D::COUT, NTHR>(bias_lds, a.s.bias, tid);
+  load_bias<D::COUT, NTHR>(bias_lds + D::COUT, a.a.bias, tid);
+  load_bias<D::COUT, NTHR>(bias_lds + 2 * D::COUT, a.b.bias, tid);
+  if (count <= 0) return;
+
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * D::G;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_IN;            // an item's images are contiguous in HBM
+    const int valid = (a.B - img0 < D::G ? a.B - img0 : D::G) * D::CPI;
+    int t = tid;
+    asm volatile("" : "+v"(t));         // per-thread addresses are recomputed here, not hoisted out of the item loop (spills)
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = t + j * NTHR;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + (i < valid ? (int64_t)i * 16 : 0));
+    }
+  };
+  // registers -> centred X interior, and the halo zeros (T / SC, which share these bytes, have overwritten them)
+  auto write_tile = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * D::G;
+    const int valid = (a.B - img0 < D::G ? a.B - img0 : D::G) * D::CPI;
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+    int t = tid;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = t + j * NTHR;
+      if (i < D::NCH) {
+        const int g = i / D::CPI, rem = i - g * D::CPI, row = rem / D::CPR, within = rem - row * D::CPR;
+        const v4i v = pre[j];
+        const v4i c = i < valid ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v4i{0, 0, 0, 0};
+        *reinterpret_cast<v4i*>(xt + g * D::XIMG + (row + 1) * D::XROW + D::CIN + within * 16) = c;
+      }
+    }
+    constexpr int TOP = D::XTW * D::CIN / 16, CW = D::CIN / 16;
+    for (int i = t; i < D::G * D::NHALO; i += NTHR) {
+      const int g = i / D::NHALO, q = i - g * D::NHALO;
+      const int off = q < TOP ? q * 16 : (1 + (q - TOP) / CW) * D::XROW + ((q - TOP) % CW) * 16;
+      *reinterpret_cast<v4i*>(xt + g * D::XIMG + off) = v4i{0, 0, 0, 0};
+    }
+  };
+  // request flat slab q (item q / NSI of this workgroup's walk; beyond its last item: that item's slabs again -- harmless, and every
+  // wave keeps issuing DMA_PER_WAVE instructions per slab, which is what the vmcnt accounting counts on) into ring buffer `buf`
+  auto issue = [&](int q, int buf) {
+    int itx = q / D::NSI;
+    const int loc = q - itx * D::NSI;
+    itx = itx < count ? itx : count - 1;
+    const int s = walk.item(itx) / groups;
+    const int8_t* wq; int KS, slab;
+    if (loc < D::NS_A) { wq = a.a.w + (int64_t)s * a.a.w_ss; KS = D::KS_A; slab = loc; }
+    else if (loc < D::NS_A + D::NS_S) { wq = a.s.w + (int64_t)s * a.s.w_ss; KS = D::KS_S; slab = loc - D::NS_A; }
+    else { wq = a.b.w + (int64_t)s * a.b.w_ss; KS = D::KS_B; slab = loc - D::NS_A - D::NS_S; }
+    const uint32_t dst = lds_addr_of(rbase + buf * D::SLABB);
+#pragma unroll
+    for (int k = 0; k < D::DMA_PER_WAVE; ++k) {
+      const int f = wave + 8 * k;
+      const int nt = f / D::SLK, u = f - nt * D::SLK;
+      int ks = slab * D::SLK + u;
+      ks = ks < KS ? ks : KS - 1;
+      dma16(wq + ((int64_t)(nt * KS + ks) * 64 + lane) * 16, dst + f * 1024);
+    }
+  };
+
+  fetch(walk.item(0));
+  write_tile(walk.item(0));
+  Ring<D> rg{rbase, 0, D::NBUF - 1, D::NBUF - 1};
+#pragma unroll
+  for (int q = 0; q < D::NBUF - 1; ++q) issue(q, q);
+  ConvAccMN<1, 3> A, S;
+  QBNN_STAMP_DECL
+  for (int it = 0; it < count; ++it) {
+    QBNN_STAMP_START();
+    const int item = walk.item(it);
+    const int s = item / groups, img0 = (item - s * groups) * D::G;
+    const bool more = it + 1 < count;
+    const int next = more ? walk.item(it + 1) : item;
+    // this lane's output pixel (recomputed per item from an opaque lane index: held across the loop the addresses below spill)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int r = ln & 31, h = ln >> 5;
+    const int m = mblk * 32 + r;
+    const int g = m / (D::HO * D::HO), rem = m - g * (D::HO * D::HO), oh = rem / D::HO, ow = rem - oh * D::HO;
+    const uint8_t* xlane = xt + g * D::XIMG + (2 * oh) * D::XROW + (2 * ow) * D::CIN + 16 * h;      // tap (0, 0) of this pixel's 3x3 / s2 window
+    // ---- stem.0: M over X (3x3 / s2)
+    ring_mfma<D, D::KS_A>(
+        [&](int ks) {
+          const int kh = ks / D::SPR_A, t = ks - kh * D::SPR_A;
+          StepSrc q;
+          q.p = xlane + kh * D::XROW + t * 32;
+          if constexpr (D::RB_A % 32 == 0) { q.m0 = 0x01010101; q.m1 = 0x01010101; }
+          else { q.m0 = t * 32 + 16 * h < D::RB_A ? 0x01010101 : 0; q.m1 = t * 32 + 16 * h + 8 < D::RB_A ? 0x01010101 : 0; }
+          return q;
+        },
+        rg, A, nblk, wave, lane, issue);
+    QBNN_STAMP_AT(0);
+    // ---- shortcut: M over the centre taps of X (1x1 / s2)
+    ring_mfma<D, D::KS_S>(
+        [&](int ks) {
+          StepSrc q;
+          q.p = xlane + D::XROW + D::CIN + ks * 32;
+          if constexpr (D::CIN % 32 == 0) { q.m0 = 0x01010101; q.m1 = 0x01010101; }
+          else { q.m0 = ks * 32 + 16 * h < D::CIN ? 0x01010101 : 0; q.m1 = ks * 32 + 16 * h + 8 < D::CIN ? 0x01010101 : 0; }
+          return q;
+        },
+        rg, S, nblk, wave, lane, issue);
+    QBNN_STAMP_AT(1);
+    lds_barrier();                       // every wave has read X for the last time: T and SC may overwrite it
+    QBNN_STAMP_AT(2);
+    {
+      EpiT<D::PIXB_T> epi{tt, a.a};
+      conv_epi_phase<EC, decltype(epi)>(bias_lds + D::COUT, a.a, epi, A, wave, lane);
+    }
+    {
+      EpiDense<D::COUT, false, D::SCP> epi{sc, a.s, a.add};
+      conv_epi_phase<EC, decltype(epi)>(bias_lds, a.s, epi, S, wave, lane);
+    }
+    for (int i = tid; i < D::PIXB_T / 4; i += NTHR) reinterpret_cast<uint32_t*>(zline)[i] = 0u;      // (X shared these bytes)
+    QBNN_STAMP_AT(3);
+    // ---- stem.3: M over T (3x3 / s1, dense tile: taps outside the map read the zero line); E: + SC, ReLU -> SC in place
+    {
+      int vmask = 0;                   // bit tap = that tap of this pixel's window lies inside the map
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        if ((unsigned)(oh + kh - 1) < (unsigned)D::HO && (unsigned)(ow + kw - 1) < (unsigned)D::HO) vmask |= 1 << tap;
+      }
+      const uint8_t* tlane = tt + m * D::PIXB_T + 16 * h;
+      const uint8_t* zl = zline + 16 * h;
+      ring_mfma<D, D::KS_B>(
+          [&](int ks) {
+            const int tap = ks / D::SPT_B, sub = ks - tap * D::SPT_B, kh = tap / 3, kw = tap - 3 * kh;
+            StepSrc q;
+            q.p = ((vmask >> tap) & 1 ? tlane + ((kh - 1) * D::HO + (kw - 1)) * D::PIXB_T : zl) + sub * 32;
+            q.m0 = 0x01010101; q.m1 = 0x01010101;
+            return q;
+          },
+          rg, A, nblk, wave, lane, issue);
+    }
+    QBNN_STAMP_AT(4);
+    fetch(next);                         // the next item's input: in flight during this epilogue and the read-out
+    {
+      EpiDense<D::COUT, true, D::SCP> epi{sc, a.b, a.add};
+      conv_epi_phase<EC, decltype(epi)>(bias_lds + 2 * D::COUT, a.b, epi, A, wave, lane);
+    }
+    QBNN_STAMP_AT(5);
+    lds_barrier();
+    QBNN_STAMP_AT(6);
+    // ---- read-out: SC -> registers; barrier (SC shares its bytes with X); next item's input -> X; registers -> HBM (the item's
+    //      output block is contiguous)
+    {
+      uint8_t* ys = a.y + (int64_t)s * a.y_ss + (int64_t)img0 * IMG_OUT;
+      int t = tid;
+      asm volatile("" : "+v"(t));
+      v2i outv[NOUT];
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const int i = t + j * NTHR;
+        const int px = i / U8, within = i - px * U8;
+        if (i < D::M * U8) outv[j] = *reinterpret_cast<const v2i*>(sc + px * D::SCP + within * 8);
+      }
+      lds_barrier();
+      write_tile(next);                // unconditional (the last item rewrites its own input): an unconsumed prefetch costs a vmcnt(0) guard
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const int i = t + j * NTHR;
+        if (i < D::M * U8 && img0 + (i * 8) / IMG_OUT < a.B) *reinterpret_cast<v2i*>(ys + (int64_t)i * 8) = outv[j];
+      }
+    }
+    QBNN_STAMP_AT(7);
+  }
+  wait_vmcnt<0>();                       // the ring's tail requests land before the workgroup's LDS is handed on
+#ifdef QBNN_STAMP
+  if (g_stamp_dev && (tid & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(g_stamp_dev + wave * 8 + i, st_acc[i]);
+#endif
+}
+
+template <class D, class EC>
+int launch_by_value(const DownArgs* arr, int n, hipStream_t st) {
+  static std::atomic<uint64_t> attr1{0}, attrN{0};
+  int items = 0;
+  for (int i = 0; i < n; ++i) { const int it = arr[i].n_samples * ((arr[i].B + D::G - 1) / D::G); items = it > items ? it : items; }
+  if (n == 1) {
+    if (int rc = ensure_dyn_lds((const void*)block_down_ring_kernel<D, EC, 1>, attr1, D::LDS)) return rc;
+    ArgsArr<DownArgs, 1> one;
+    one.m[0] = arr[0];
+    hipLaunchKernelGGL((block_down_ring_kernel<D, EC, 1>), dim3(items < 256 ? items : 256), dim3(512), D::LDS, st, one);
+    return check_launch("qbnn_block_down_i8_mc");
+  }
+  static_assert(sizeof(ArgsArr<DownArgs, QBNN_FUSED_CALLS>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
+  if (int rc = ensure_dyn_lds((const void*)block_down_ring_kernel<D, EC, QBNN_FUSED_CALLS>, attrN, D::LDS)) return rc;
+  ArgsArr<DownArgs, QBNN_FUSED_CALLS> all;
+  memset(&all, 0, sizeof(all));
+  for (int i = 0; i < n; ++i) all.m[i] = arr[i];
+  const int per = 256 / n > 0 ? 256 / n : 1;
+  hipLaunchKernelGGL((block_down_ring_kernel<D, EC, QBNN_FUSED_CALLS>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, all);
+  return check_launch("qbnn_block_down_i8_multi");
+}
+
+template <class D, class EC>
+int launch_dev(const DownArgs* dev, int n, int items, hipStream_t st) {
+  static std::atomic<uint64_t> attr{0};
+  if (int rc = ensure_dyn_lds((const void*)block_down_ring_kernel<D, EC, 0>, attr, D::LDS)) return rc;
+  const int per = 256 / n > 0 ? 256 / n : 1;
+  hipLaunchKernelGGL((block_down_ring_kernel<D, EC, 0>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, ArgsArr<DownArgs, 0>{dev});
+  return check_launch("qbnn_block_down_i8_multi_launch");
+}
+
+}  // namespace
+
+int qbnn_launch_block_down_ring(const DownArgs* arr, int n, int Cin, hipStream_t st) {
+  if (n <= 0 || n > QBNN_FUSED_CALLS) return fail(QBNN_E_INVALID, "qbnn_block_down (ring): 1 .. 8 argument blocks per launch%s");
+  if (Cin == 48) return launch_by_value<DR48, E48>(arr, n, st);
+  if (Cin == 96) return launch_by_value<DR96, E96>(arr, n, st);
+  return fail(QBNN_E_INVALID, "qbnn_block_down (ring): 48 -> 96 and 96 -> 192 channels only%s");
+}
+
+int qbnn_launch_block_down_ring_dev(const DownArgs* dev, int n, int items, int Cin, hipStream_t st) {
+  if (Cin == 48) return launch_dev<DR48, E48>(dev, n, items, st);
+  if (Cin == 96) return launch_dev<DR96, E96>(dev, n, items, st);
+  return fail(QBNN_E_INVALID, "qbnn_block_down (ring): 48 -> 96 and 96 -> 192 channels only%s");
+}
