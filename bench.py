@@ -162,6 +162,35 @@ def _wl_mlp_bbb(a, world, q, load_golden):
                 describe="linear_bbb (q=True): UCI-regression-shaped (in_dim 13) 4x100 MLP Bayes-by-backprop, A7/W8 int8, %d MC samples per GPU per step, 1000 rows" % S)
 
 
+def _wl_mlp_mc(a, world, q, load_golden):
+    """SURVEY 8 row a6+ `linear_mc` (mcdropout/models_mc.py:10-73): the MC-Dropout regression MLP in its converted int8 form, 10 MC samples, 1000 rows."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "mlp_mc_a7w8.npz"))
+    st = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    in_dim, p = int(d["meta.in_dim"]), float(d["meta.p"])
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=p)
+    model = q.ModelFactory.get_model("linear_mc", [in_dim], 1, True, args).load_reference_state(st)
+    S = a.samples if a.samples > 0 else 10
+    x_host = torch.randn(1000, in_dim, generator=torch.Generator().manual_seed(2))
+    return dict(golden=None, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=False, cpu_baseline=False,
+                step=lambda m, x, S_, seed: q.mc_predict_regression(m, x, S_, seed), scaling="weak", dtype="int8", graph=dict(regression=True),
+                metric="MC forward samples/sec, 4x100 MLP MC-Dropout int8, 1000 rows", unit="MC samples/s",
+                describe="linear_mc (q=True): UCI-regression-shaped (in_dim %d) 4x100 MLP MC-Dropout (p=%.2f), A7/W8 int8, %d MC samples per GPU per step, 1000 rows" % (in_dim, p, S))
+
+
+def _wl_resnet_mc_f32(a, world, q, load_golden):
+    """SURVEY 8 rows a6+ / a7 with q=False: the float MC-Dropout ResNet-18 (FloatFunctional BernoulliDropout behind every conv, dropout.py:15-40)."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "resnet_mc_f32.npz"))
+    st = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    p = float(d["meta.p"])
+    model = q.ModelFactory.get_model("conv_resnet_mc", [1, 3, 32, 32], 10, False, types.SimpleNamespace(p=p)).load_reference_state(st)
+    S = a.samples if a.samples > 0 else 10
+    x_host = torch.randn(a.batch, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+    return dict(golden=None, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=False, cpu_baseline=False,
+                step=lambda m, x, S_, seed: q.mc_predict(m, x, S_, seed), scaling="weak", dtype="f32",
+                metric="MC forward samples/sec, ResNet-18 MC-Dropout fp32 batch=%d" % a.batch, unit="MC samples/s",
+                describe="conv_resnet_mc (q=False): CIFAR-10-shaped ResNet-18 MC-Dropout (p=%.2f), fp32, %d MC samples per GPU per step, batch=%d" % (p, S, a.batch))
+
+
 def _wl_resnet_float(kind):
     """SURVEY 8a rows a1 / a2 at the headline's shape (B = 256): the float Bayes-by-backprop ResNet-18 (fp32 MFMA convs, per-sample
     weights) and its QAT form evaluated with live observers (fake-quantised tensors, fp64 conv sums; the MC samples are sequential
@@ -185,7 +214,8 @@ def _wl_resnet_float(kind):
 
 
 WORKLOADS = {"resnet_bbb": _wl_resnet(0, 100, "configs[2]"), "resnet_f32": _wl_resnet_float("f32"), "resnet_qat": _wl_resnet_float("qat"), "resnet_bbb_w4": _wl_resnet(4, 128, "configs[4] (A7/W4, 1024 samples over 8 GPUs = 128 per GPU)"),
-             "ensemble16": _wl_ensemble16, "lenet_mc": _wl_lenet_mc, "lenet_bbb": _wl_lenet_bbb, "mlp_bbb": _wl_mlp_bbb, "mlp_f32": _wl_mlp_f32, "resnet_mc": _wl_resnet_mc}
+             "ensemble16": _wl_ensemble16, "lenet_mc": _wl_lenet_mc, "lenet_bbb": _wl_lenet_bbb, "mlp_bbb": _wl_mlp_bbb, "mlp_f32": _wl_mlp_f32, "resnet_mc": _wl_resnet_mc,
+             "mlp_mc": _wl_mlp_mc, "resnet_mc_f32": _wl_resnet_mc_f32}
 
 
 def cpu_baseline(a, g, x_host, seed):
@@ -225,7 +255,7 @@ def cpu_baseline(a, g, x_host, seed):
             "_p_oracle_sample0": p_or}
 
 
-SECONDARY = ("resnet_bbb_w4", "ensemble16", "lenet_mc", "lenet_bbb", "mlp_f32", "mlp_bbb", "resnet_mc", "resnet_f32", "resnet_qat")
+SECONDARY = ("resnet_bbb_w4", "ensemble16", "lenet_mc", "lenet_bbb", "mlp_f32", "mlp_bbb", "mlp_mc", "resnet_mc", "resnet_f32", "resnet_qat", "resnet_mc_f32")
 
 
 def secondary_workloads(a, q, load_golden, seed):
@@ -241,11 +271,11 @@ def secondary_workloads(a, q, load_golden, seed):
             S = wl["units_global"]
             graphed = q.GraphedPredictor(model, S, **wl["graph"]) if ("graph" in wl and not a.no_graph) else None
             run = (lambda: graphed(x, seed)) if graphed is not None else (lambda: wl["step"](model, x, S, seed))
-            slow = name in ("resnet_f32", "resnet_qat")           # 8-16 ms per step: fewer repetitions keep the default run short
-            for _ in range(2 if slow else 6):
+            slow = name in ("resnet_f32", "resnet_qat", "resnet_mc_f32")       # 6-16 ms per step
+            for _ in range(6):                                    # (round 3 gave the slow ones 2 + 4 steps: a cold clock, -17 % against their own --workload runs)
                 run()
             torch.cuda.synchronize()
-            n = 4 if slow else 10
+            n = 10
             if not slow:                                          # sub-millisecond steps: time >= ~60 ms of them (clock ramp, host jitter)
                 t0 = time.perf_counter()
                 for _ in range(3):
@@ -298,6 +328,7 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=0, help="oracle samples to time (0 = auto, about 10-30 s)")
     ap.add_argument("--no-graph", action="store_true", help="mlp_f32 (the launch-bound workload: ~25 launches of microseconds): launch eagerly instead of replaying its captured HIP graph")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (BASELINE.json's other configs, N = 1, default workload only)")
+    ap.add_argument("--no-rccl-probe", action="store_true", help="skip the one-rank RCCL all-reduce latency probe of the N = 1 run")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launcher test (no GPU, gloo): ranks rendezvous, all-reduce their rank, rank 0 prints one JSON line")
     a = ap.parse_args()
@@ -323,7 +354,8 @@ def main():
         all_reduce_moments(mom)
         dist.barrier()
         if rank == 0:
-            print(json.dumps({"plumbing_check": True, "ranks": dist.get_world_size(), "rccl_ranks": dist.get_world_size(), "rank_sum": float(t.item()),
+            # (no RCCL call happens here: the line names the backend it ran on; `rccl_ranks` appears only on lines that used nccl)
+            print(json.dumps({"plumbing_check": True, "ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank_sum": float(t.item()),
                               "moments_sum": float(mom[0, 0, 0].item()), "shards": shards}))
         dist.destroy_process_group()
         return
@@ -482,13 +514,36 @@ def main():
         rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_bytes": mom.numel() * 8,
                 "allreduce_us": round((time.perf_counter() - t) / 50 * 1e6, 1), "collectives_per_step": 1}
 
+    rccl_one_rank_us = None
+    if not use_dist and world == 1 and not a.no_rccl_probe:
+        # Multi-GPU readiness on a one-GPU box: the path's one collective (sum all-reduce of the [2, B, C] fp64 moments, 40 KB) through
+        # RCCL with a single rank, timed after everything else -- a reference point for the first 8-GPU run (there is no curve to report here).
+        try:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, device_id=torch.device("cuda", dev_index))
+            mom = torch.zeros((2, a.batch, 10), dtype=torch.float64, device="cuda")
+            for _ in range(5):
+                dist.all_reduce(mom)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(50):
+                dist.all_reduce(mom)
+            torch.cuda.synchronize()
+            rccl_one_rank_us = round((time.perf_counter() - t) / 50 * 1e6, 1)
+            dist.destroy_process_group()
+        except Exception as e:                                       # noqa: BLE001 -- a probe: report why it did not run
+            rccl_one_rank_us = "unavailable: %s" % type(e).__name__
+
     if rank == 0:
         out = {"metric": wl["metric"], "value": round(value, 2), "unit": wl["unit"],
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": wl["scaling"], "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
                "config": {"workload": wl["describe"], "samples_per_gpu": S_local, "global_samples": S_global, "batch": x_host.shape[0],
                           "image_samples_per_s": round(value * x_host.shape[0], 1), "parallelism": f"mc-sample-shard x{world}"},
-               "graph_replay": graphed is not None, "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "rccl": rccl, "rccl_ranks": world if use_dist else 0,
+               "graph_replay": graphed is not None, "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "rccl": rccl, "rccl_ranks": world if (use_dist and backend == "nccl") else 0, "rccl_one_rank_us": rccl_one_rank_us,
                "kernels": kernels, "secondary": secondary}
         print(json.dumps(out), flush=True)          # the line is out before any process-group teardown
     if use_dist:

@@ -243,17 +243,18 @@ int qbnn_block_down_i8_multi(const qbnn_down_call* calls, int32_t n_calls, int32
 
 /* Prepared form of the two calls above, for call arrays that are replayed (an ensemble's members at a fixed batch size): _prepare
  * writes the argument blocks of ALL n_calls calls into caller-owned device memory once (qbnn_*_multi_args_bytes bytes, 16-byte aligned;
- * a synchronous copy -- do not call it under stream capture), _launch then runs them in ONE grid however many they are (the by-value
+ * copied on `stream` -- the device block typically comes from a stream-ordered allocator -- and the call returns once the copy has
+ * landed: do not call it under stream capture), _launch then runs them in ONE grid however many they are (the by-value
  * forms above are limited to 8 / 4 calls per launch by the 4 KiB of kernel arguments): with 16 members every workgroup walks 2 - 16
  * work items of its member instead of 1 - 4, and a stage is one launch instead of two or four.  max_samples = the largest n_samples
  * of the calls.  Same results as the by-value forms. */
 size_t qbnn_chain_multi_args_bytes(int32_t n_calls, int32_t n_blocks);
 size_t qbnn_down_multi_args_bytes(int32_t n_calls);
 int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, int32_t n_calls, int32_t with_stem, int32_t B, int32_t a_hi,
-                                      int32_t n_blocks, void* dev_args);
+                                      int32_t n_blocks, void* dev_args, void* stream);
 int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t with_stem, int32_t B, int32_t H, int32_t C,
                                      int32_t n_blocks, int32_t max_samples, void* stream);
-int qbnn_block_down_i8_multi_prepare(const qbnn_down_call* calls, int32_t n_calls, int32_t B, int32_t a_hi, void* dev_args);
+int qbnn_block_down_i8_multi_prepare(const qbnn_down_call* calls, int32_t n_calls, int32_t B, int32_t a_hi, void* dev_args, void* stream);
 int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t max_samples,
                                     void* stream);
 

@@ -143,9 +143,9 @@ def lib():
         L.qbnn_chain_multi_args_bytes.argtypes = [i32, i32]
         L.qbnn_down_multi_args_bytes.restype = C.c_size_t
         L.qbnn_down_multi_args_bytes.argtypes = [i32]
-        L.qbnn_block_chain_i8_multi_prepare.argtypes = [C.POINTER(ChainCall), i32, i32, i32, i32, i32, vp]
+        L.qbnn_block_chain_i8_multi_prepare.argtypes = [C.POINTER(ChainCall), i32, i32, i32, i32, i32, vp, vp]
         L.qbnn_block_chain_i8_multi_launch.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
-        L.qbnn_block_down_i8_multi_prepare.argtypes = [C.POINTER(DownCall), i32, i32, i32, vp]
+        L.qbnn_block_down_i8_multi_prepare.argtypes = [C.POINTER(DownCall), i32, i32, i32, vp, vp]
         L.qbnn_block_down_i8_multi_launch.argtypes = [vp, i32, i32, i32, i32, i32, vp]
         L.qbnn_head_i8_multi.argtypes = [C.POINTER(HeadCall), i32, vp]
         L.qbnn_quantize_im2col3x3_c3_multi.argtypes = [vp, i32, i32, i32, C.POINTER(f), C.POINTER(i32), i32, i32, vp, i64, vp]

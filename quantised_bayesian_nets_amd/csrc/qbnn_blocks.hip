@@ -1332,12 +1332,12 @@ static int launch_block_chain_ald_dev(const ChainArgs<1>* dev, int n, int items,
   hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, 0>), dim3(fused_grid_x(items, n), n), dim3(64 * NWV), LDS, st, ArgsArr<ChainArgs<1>, 0>{dev}, DropSet<0>{});
   return check_launch("qbnn_block_chain_i8_multi_launch");
 }
-template <class C, int NBLK>
+template <class C, int NBLK, bool STEM = false>
 static int launch_block_chain_ws_dev(const ChainArgs<NBLK>* dev, int n, int items, hipStream_t st) {
-  constexpr int LDS = chain_ws_lds<C, NBLK, true, false>();
+  constexpr int LDS = chain_ws_lds<C, NBLK, true, STEM>();
   static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, true, false, 0>, attr, LDS)) return rc_attr;
-  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, true, false, 0>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, ArgsArr<ChainArgs<NBLK>, 0>{dev},
+  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ws_kernel<C, NBLK, true, STEM, 0>, attr, LDS)) return rc_attr;
+  hipLaunchKernelGGL((block_chain_ws_kernel<C, NBLK, true, STEM, 0>), dim3(fused_grid_x(items, n), n), dim3(BLK_THREADS), LDS, st, ArgsArr<ChainArgs<NBLK>, 0>{dev},
                      DropSet<0>{});
   return check_launch("qbnn_block_chain_i8_multi_launch");
 }
@@ -1356,13 +1356,17 @@ QBNN_EXPORT size_t qbnn_chain_multi_args_bytes(int32_t n_calls, int32_t n_blocks
 }
 QBNN_EXPORT size_t qbnn_down_multi_args_bytes(int32_t n_calls) { return (size_t)(n_calls > 0 ? n_calls : 0) * sizeof(DownArgs); }
 
-static int upload_args(void* dev, const void* host, size_t bytes, const char* what) {
-  if (hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(QBNN_E_LAUNCH, "%s: copying the argument blocks to the device failed", what);
+// The argument blocks go up ON the caller's stream (the destination comes from a stream-ordered allocator: a recycled block may still be
+// read by earlier work of that stream, which a null-stream copy would not wait for) and the call returns when they have landed (the
+// staging vector dies with the caller's frame).
+static int upload_args(void* dev, const void* host, size_t bytes, const char* what, hipStream_t st) {
+  if (hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return fail(QBNN_E_LAUNCH, "%s: copying the argument blocks to the device failed", what);
   return QBNN_OK;
 }
 
 QBNN_EXPORT int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, int32_t n_calls, int32_t with_stem, int32_t B, int32_t a_hi,
-                                                  int32_t n_blocks, void* dev_args) {
+                                                  int32_t n_blocks, void* dev_args, void* stream) {
   if (!calls || n_calls <= 0 || B <= 0 || !dev_args) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: bad argument%s");
   int rc = QBNN_OK;
   if (with_stem) {
@@ -1375,7 +1379,7 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, 
       if ((rc = build_stem_qconv(stem, k.w0_packed, k.w0_sample_stride, k.bias0, k.s_in, k.s_w0, k.z_w0, k.s_y0, k.z_y0, a_hi))) return rc;
       if ((rc = build_chain_args<2>(arr[i], nullptr, 0, k.s_y0, k.z_y0, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, k.im2col, &stem))) return rc;
     }
-    return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_chain_i8_multi_prepare");
+    return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_chain_i8_multi_prepare", (hipStream_t)stream);
   }
   if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: one block per call (two only behind the fused stem)%s");
   std::vector<ChainArgs<1>> arr(n_calls);
@@ -1384,7 +1388,7 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, 
     if (!k.x || !k.blocks || !k.y || k.n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: bad call entry%s");
     if ((rc = build_chain_args<1>(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, nullptr, nullptr))) return rc;
   }
-  return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_chain_i8_multi_prepare");
+  return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_chain_i8_multi_prepare", (hipStream_t)stream);
 }
 
 QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t with_stem, int32_t B, int32_t H, int32_t Cc,
@@ -1394,7 +1398,8 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n
   auto items = [&](int G) { return max_samples * ((B + G - 1) / G); };
   if (with_stem) {
     if (n_blocks != 2 || Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: the fused stem feeds the two 32x32x24 blocks only%s");
-    return qbnn_launch_stem_chain_w16_dev(reinterpret_cast<const ChainArgs<2>*>(dev_args), n_calls, items(2), st);
+    if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16_dev(reinterpret_cast<const ChainArgs<2>*>(dev_args), n_calls, items(2), st);
+    return launch_block_chain_ws_dev<Blk_24, 2, true>(reinterpret_cast<const ChainArgs<2>*>(dev_args), n_calls, items(Blk_24::G), st);      // QBNN_W16=0: the 8-wave kernel
   }
   if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: one block per call (two only behind the fused stem)%s");
   const ChainArgs<1>* dev = reinterpret_cast<const ChainArgs<1>*>(dev_args);
@@ -1406,7 +1411,7 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n
   return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
 }
 
-QBNN_EXPORT int qbnn_block_down_i8_multi_prepare(const qbnn_down_call* calls, int32_t n_calls, int32_t B, int32_t a_hi, void* dev_args) {
+QBNN_EXPORT int qbnn_block_down_i8_multi_prepare(const qbnn_down_call* calls, int32_t n_calls, int32_t B, int32_t a_hi, void* dev_args, void* stream) {
   if (!calls || n_calls <= 0 || B <= 0 || !dev_args) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_prepare: bad argument%s");
   std::vector<DownArgs> arr(n_calls);
   for (int i = 0; i < n_calls; ++i) {
@@ -1415,7 +1420,7 @@ QBNN_EXPORT int qbnn_block_down_i8_multi_prepare(const qbnn_down_call* calls, in
       return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_prepare: bad call entry%s");
     if (int rc = build_down_args(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.desc, k.y, k.y_sample_stride, k.n_samples)) return rc;
   }
-  return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_down_i8_multi_prepare");
+  return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_down_i8_multi_prepare", (hipStream_t)stream);
 }
 
 QBNN_EXPORT int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t max_samples,

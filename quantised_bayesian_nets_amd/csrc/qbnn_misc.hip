@@ -148,6 +148,8 @@ QBNN_EXPORT int qbnn_quantize_im2col3x3_c3_multi(const float* x, int32_t B, int3
     memset(&q, 0, sizeof(q));
     for (int i = 0; i < k; ++i) {
       if (zero_points[c0 + i] < 0 || zero_points[c0 + i] > 127) return fail(QBNN_E_INVALID, "qbnn_quantize_im2col3x3_c3_multi: zero points must be in [0,127]%s");
+      if ((a_hi < 255 ? a_hi : 255) - zero_points[c0 + i] > 127)      // the centred patch bytes are int8
+        return fail(QBNN_E_INVALID, "qbnn_quantize_im2col3x3_c3_multi: a_hi - zero_point must be <= 127 (the patches are centred int8)%s");
       q.inv[i] = 1.0f / scales[c0 + i]; q.z[i] = zero_points[c0 + i];
     }
     hipLaunchKernelGGL(quantize_im2col3x3_c3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, B, H, W, q, k, a_hi,
@@ -181,7 +183,10 @@ __global__ __launch_bounds__(256) void head_i8_kernel(const ArgsArr<HeadArgs, NM
   const int n = lane >> 2, j = lane & 3;
   // packed form: C a multiple of 16 and dword-aligned weights -- pooled activations as int8 dwords, v_dot4 against the raw weight
   // dwords (kept in registers for the wave's images), the weights' zero point through the channel sum:  sum p (w - z_w) = p.w - z_w sum p
-  const bool packed = (a.C & 15) == 0 && a.C <= 256 && ((reinterpret_cast<uintptr_t>(ws) | (uintptr_t)a.w_ss) & 3) == 0;
+  // (the pooled value q - z_x must fit an int8 for the signed dot product: z_x <= 128 and a_hi - z_x <= 127; any other qparams -- legal for a
+  //  C-ABI caller, e.g. 8-bit activations -- take the exact scalar path below)
+  const bool packed = (a.C & 15) == 0 && a.C <= 256 && ((reinterpret_cast<uintptr_t>(ws) | (uintptr_t)a.w_ss) & 3) == 0 &&
+                      a.z_x >= 0 && a.z_x <= 128 && min(a.a_hi, 255) - a.z_x <= 127;
   for (int bi = 0; bi < QBNN_HEAD_IMGS; ++bi) {
     const int b = b0 + bi;
     if (b >= a.B) break;

@@ -500,11 +500,11 @@ class Network(nn.Module):
             for step in steps:
                 if step[0] == "down":
                     buf = torch.empty(int(L.qbnn_down_multi_args_bytes(M)), dtype=torch.uint8, device=dev)
-                    _lib.check(L.qbnn_block_down_i8_multi_prepare(step[1], M, B, a_hi, _lib.ptr(buf)))
+                    _lib.check(L.qbnn_block_down_i8_multi_prepare(step[1], M, B, a_hi, _lib.ptr(buf), _lib.current_stream()))
                 else:
                     nb = 2 if step[0] == "stem" else 1
                     buf = torch.empty(int(L.qbnn_chain_multi_args_bytes(M, nb)), dtype=torch.uint8, device=dev)
-                    _lib.check(L.qbnn_block_chain_i8_multi_prepare(step[1], M, int(step[0] == "stem"), B, a_hi, nb, _lib.ptr(buf)))
+                    _lib.check(L.qbnn_block_chain_i8_multi_prepare(step[1], M, int(step[0] == "stem"), B, a_hi, nb, _lib.ptr(buf), _lib.current_stream()))
                 dev_steps.append(buf)
         plan = dict(M=M, col=col, acts=acts, probs=probs, scales=scales, zps=zps, steps=steps, dev_steps=dev_steps, head=hcalls, keep=keep, a_hi=a_hi)
         self._plans[key] = plan

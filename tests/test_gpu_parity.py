@@ -970,6 +970,14 @@ lm = q.ModelFactory.get_model("conv_lenet_mc", [1, 1, 28, 28], 10, True, la).loa
 with q.mc_context(gl["probs"].shape[0], gl["meta"]["philox_seed"], 0):
     pl = lm.forward_mc(torch.from_numpy(gl["x"]).cuda())
 np.testing.assert_allclose(pl.cpu().numpy(), gl["probs"], rtol=1e-5, atol=1e-8)
+# the ensemble's prepared multi-call launches (argument blocks in device memory) honour the switches too (advisor, round 3)
+from conftest import load_ensemble_fixture
+ge = load_ensemble_fixture()
+ea = types.SimpleNamespace(activation_precision=7, weight_precision=8, model="conv_resnet_sgld", samples=len(ge["members"]))
+net = q.ModelFactory.get_model("conv_resnet_sgld", [1, 3, 32, 32], 10, True, ea, training_mode=False).load_reference_state(ge["members"])
+with q.mc_context(len(ge["members"]), 0, 0):
+    pe = net.forward_mc(torch.from_numpy(ge["x"]).cuda())
+np.testing.assert_allclose(pe.cpu().numpy(), ge["probs"], rtol=1e-5, atol=1e-8)
 print("SWITCH-OK")
 """
 

@@ -227,13 +227,13 @@ def test_bench_self_launches_n_ranks():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1
     out = json.loads(line[0])
-    assert out["plumbing_check"] is True and out["ranks"] == 2 and out["rccl_ranks"] == 2 and out["rank_sum"] == 1.0 and out["moments_sum"] == 3.0
+    assert out["plumbing_check"] is True and out["ranks"] == 2 and out["backend"] == "gloo" and "rccl_ranks" not in out and out["rank_sum"] == 1.0 and out["moments_sum"] == 3.0
 
 
 def test_bench_self_launches_eight_ranks_with_the_baseline_partitions():
     """The driver's N = 8 case, rehearsed without GPUs: `python bench.py --gpus 8` spawns 8 fresh ranks (gloo), every rank takes its
     contiguous block of BASELINE configs[4] (1024 MC samples -> 8 x 128, global Philox sample indices) and of configs[3] (16 ensemble
-    members -> 8 x 2), the fp64 moments are sum-all-reduced, and rank 0's one JSON line carries rccl_ranks = 8."""
+    members -> 8 x 2), the fp64 moments are sum-all-reduced, and rank 0's one JSON line names the 8 ranks and the backend it ran on (gloo: no RCCL claim)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plumbing-check"], env=env,
@@ -243,7 +243,7 @@ def test_bench_self_launches_eight_ranks_with_the_baseline_partitions():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1
     out = json.loads(line[0])
-    assert out["ranks"] == 8 and out["rccl_ranks"] == 8 and out["rank_sum"] == 28.0 and out["moments_sum"] == 36.0
+    assert out["ranks"] == 8 and out["backend"] == "gloo" and "rccl_ranks" not in out and out["rank_sum"] == 28.0 and out["moments_sum"] == 36.0
     by_rank = sorted(out["shards"], key=lambda d: d["rank"])
     assert [d["samples_1024"] for d in by_rank] == [[128 * r, 128] for r in range(8)]
     assert [d["members_16"] for d in by_rank] == [[2 * r, 2] for r in range(8)]
