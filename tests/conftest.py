@@ -36,8 +36,22 @@ def golden_lenet_mc():
 @pytest.fixture(scope="session")
 def golden_mlp_f32():
     d = np.load(os.path.join(GOLDEN, "mlp_bbb_f32.npz"))
+    return _mlp_f32(d)
+
+
+def _mlp_f32(d):
+    """Float BBB MLP fixture (make_golden_mlp_f32.py).  mu_atol: the absolute floor that goes with the 1e-5 relative bound on mu -- FOUR times
+    the reference's own distance from itself between its AVX-512 and AVX2 code paths (`refspread.mu_abs`, 0.7 - 1.4e-6 on outputs of range
+    5 - 7: the reference and the build are each one fp32 summation order away from the exact value; measured on the GPU 1.0 - 2.4e-6)."""
     return dict(state={k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}, x=d["x"], mu=d["mu"], var=d["var"],
-                mean=d["mean"], pred_var=d["pred_var"], seed=int(d["meta.philox_seed"]), in_dim=int(d["meta.in_dim"]))
+                mean=d["mean"], pred_var=d["pred_var"], seed=int(d["meta.philox_seed"]), in_dim=int(d["meta.in_dim"]),
+                mu_atol=4.0 * float(d["refspread.mu_abs"]), refspread_var_rel=float(d["refspread.var_rel"]))
+
+
+@pytest.fixture(scope="session", params=[1, 4, 6, 8, 11], ids=lambda d: "in%d" % d)
+def golden_mlp_f32_width(request):
+    """BASELINE config 0 at SURVEY 8(d) C1's other input widths (13 is golden_mlp_f32)."""
+    return _mlp_f32(np.load(os.path.join(GOLDEN, "mlp_bbb_f32_in%d.npz" % request.param)))
 
 
 @pytest.fixture(scope="session")

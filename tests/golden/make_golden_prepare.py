@@ -94,7 +94,9 @@ def main():
             out["converted/" + k + ".q_scale"] = np.float64(v.q_scale())
             out["converted/" + k + ".q_zero_point"] = np.int64(v.q_zero_point())
             out["converted/" + k + ".sha1"] = np.array(hashlib.sha1(v.int_repr().numpy().tobytes()).hexdigest())
-            if k in ("layers.0.weight", "layers.4.0.shortcut.0.weight", "layers.9.weight", "layers.0.std"):
+            # recorded in full: four tensors the test compares element by element, and the ONE whose hash the native pipeline does not
+            # reproduce (layers.6.1.stem.0.weight: elements on a rounding tie of its BN-folded weight observer) -- the test counts them
+            if k in ("layers.0.weight", "layers.4.0.shortcut.0.weight", "layers.9.weight", "layers.0.std", "layers.6.1.stem.0.weight"):
                 out["converted/" + k] = v.int_repr().numpy()
         elif isinstance(v, torch.Tensor):
             out["converted/" + k] = v.detach().numpy()

@@ -4,7 +4,9 @@ Imports the real reference, prepares the model for QAT (quant_utils.prepare_mode
 train-mode and one eval-mode forward, snapshots the state_dict (parameters, BN statistics, every observer's min/max),
 then runs S eval-mode forwards of the same batch with the build's Philox eps injected into Tensor.normal_ and records
 the per-sample outputs and the observers' final min/max.
-Output: tests/golden/{lenet,mlp,resnet}_bbb_qat.npz (inputs + expected outputs only)."""
+Output: tests/golden/{lenet,mlp,resnet}_bbb_qat.npz (inputs + expected outputs only).  Each fixture also records how far the reference
+is from itself when the whole pipeline (calibration forwards included) runs on another CPU code path (altref.py; conv graphs: oneDNN
+off as well): `refspread.*`."""
 import os
 import sys
 import types
@@ -20,9 +22,11 @@ import ref_shim  # noqa: E402
 ref_shim.install()
 import torch  # noqa: E402
 
+import altref  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 SEED = 3
+ALT = altref.alt_out_path() is not None
 
 
 def flat(model):
@@ -54,6 +58,8 @@ def run(model_name, in_shape, B, S, out, logit_gain, regression=False):
     if not regression:
         last.weight.data *= logit_gain
     qu.prepare_model(model, args)
+    if ALT and not regression:
+        torch.backends.mkldnn.enabled = False                # the alternative run of a conv graph: plain ATen convs on the AVX2 kernels
     if regression:
         x = torch.randn(B, in_shape[0], generator=g)
     elif len(in_shape) == 4:
@@ -97,6 +103,19 @@ def run(model_name, in_shape, B, S, out, logit_gain, regression=False):
     finally:
         torch.Tensor.normal_ = orig
     final = flat(model)
+    if ALT:                                    # this process is the reference on the other code path: outputs only
+        if altref.alt_tag() == out:
+            np.savez(altref.alt_out_path(), **({"mu": np.stack([o[0] for o in outs]), "var": np.stack([o[1] for o in outs])} if regression
+                                               else {"probs": np.stack(outs)}))
+        return
+    alt = altref.run_alt(os.path.abspath(__file__), out)
+    if regression:
+        sp = altref.spread(np.stack([o[0] for o in outs]), alt["mu"]), altref.spread(np.stack([o[1] for o in outs]), alt["var"])
+        spread_abs, spread_rel = sp[0][0], sp[1][1]
+        print(f"{model_name} QAT eval: reference vs reference on another code path: mu max abs {spread_abs:.2e} (range {np.abs(alt['mu']).max():.2f}), var max rel {spread_rel:.2e}")
+    else:
+        spread_abs, spread_rel = altref.spread(np.stack(outs), alt["probs"])
+        print(f"{model_name} QAT eval: reference vs reference on another code path: probs max abs {spread_abs:.2e}, max rel {spread_rel:.2e}")
     net = orc.QATOracle(state)
     fwd = net.mlp if regression else (net.lenet if "lenet" in model_name else net.resnet)
     xin = x.numpy()
@@ -110,7 +129,7 @@ def run(model_name, in_shape, B, S, out, logit_gain, regression=False):
     obs_err = max(abs(float(v.state[0]) - float(final[k + ".activation_post_process.min_val"])) +
                   abs(float(v.state[1]) - float(final[k + ".activation_post_process.max_val"])) for k, v in net.obs.items())
     print(f"{model_name} QAT eval: oracle vs reference max abs err {worst:.2e}; observer state err {obs_err:.2e}; {len(net.obs)} observers")
-    res = {"x": xin, "meta.philox_seed": np.int64(SEED)}
+    res = {"x": xin, "meta.philox_seed": np.int64(SEED), "refspread.max_abs": np.float64(spread_abs), "refspread.max_rel": np.float64(spread_rel)}
     if regression:
         res["mu"] = np.stack([o[0] for o in outs]); res["var"] = np.stack([o[1] for o in outs])
     else:
@@ -123,7 +142,10 @@ def run(model_name, in_shape, B, S, out, logit_gain, regression=False):
     print("wrote", path, round(os.path.getsize(path) / 1e6, 2), "MB")
 
 
+CASES = [("linear_bbb", [13], 64, 4, "mlp_bbb_qat.npz", 1.0, True), ("conv_lenet_bbb", [1, 28, 28], 4, 3, "lenet_bbb_qat.npz", 0.2, False),
+         ("conv_resnet_bbb", [1, 3, 32, 32], 2, 3, "resnet_bbb_qat.npz", 0.05, False)]
+
 if __name__ == "__main__":
-    run("linear_bbb", [13], 64, 4, "mlp_bbb_qat.npz", 1.0, regression=True)
-    run("conv_lenet_bbb", [1, 28, 28], 4, 3, "lenet_bbb_qat.npz", 0.2)
-    run("conv_resnet_bbb", [1, 3, 32, 32], 2, 3, "resnet_bbb_qat.npz", 0.05)
+    for c in CASES:
+        if altref.alt_tag() in (None, c[4]):
+            run(*c[:6], regression=c[6])

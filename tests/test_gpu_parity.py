@@ -315,16 +315,16 @@ def test_float_bbb_mlp_matches_reference(golden_mlp_f32):
     S = g["mu"].shape[0]
     with q.mc_context(S, g["seed"], 0):
         mu, var = m.forward_mc(x)
-    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(var.cpu().numpy(), g["var"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=1e-5, atol=g["mu_atol"])      # measured floor: conftest._mlp_f32
+    np.testing.assert_allclose(var.cpu().numpy(), g["var"], rtol=1e-5, atol=0)
     mean, pv = q.mc_predict_regression(m, x, S, g["seed"])
-    np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=1e-5, atol=g["mu_atol"])
     np.testing.assert_allclose(pv.cpu().numpy(), g["pred_var"], rtol=1e-4, atol=1e-7)
     own = mu.double().var(dim=0) + var.double().mean(dim=0)                # experiments/utils.py:352-353 on the device's own samples
     np.testing.assert_allclose(pv.cpu().numpy(), own.cpu().numpy(), rtol=1e-5, atol=1e-12)
     with q.mc_context(1, g["seed"], 4):
         mu4, var4 = m(x)
-    np.testing.assert_allclose(mu4.cpu().numpy(), g["mu"][4], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(mu4.cpu().numpy(), g["mu"][4], rtol=1e-5, atol=g["mu_atol"])
 
 
 def test_ensemble_matches_reference(golden_ensemble):
@@ -541,7 +541,7 @@ def test_float_resnet_full_batch_against_oracle():
 def test_qat_eval_with_live_observers_matches_reference(name, model):
     """the prepared (QAT) model in eval mode on the GPU -- all S samples in one batched pass with the
     observer recurrence resolved on the device -- against S sequential reference forwards (same injected eps): per-sample
-    outputs, and every observer's final (min, max).  fp32 tolerance 1e-5 relative (+2e-6 absolute)."""
+    outputs, and every observer's final (min, max).  fp32 tolerance 1e-5 relative + a measured absolute floor (below)."""
     import os
     import quantised_bayesian_nets_amd as q
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
@@ -551,17 +551,22 @@ def test_qat_eval_with_live_observers_matches_reference(name, model):
     m = q.ModelFactory.get_model(model, shape, 1 if model == "linear_bbb" else 10, True, args).load_reference_state(st)
     x = torch.from_numpy(d["x"]).cuda()
     seed = int(d["meta.philox_seed"])
+    # Absolute floor beside the 1e-5 relative bound: four times the reference's own distance from itself on another CPU code path
+    # (`refspread.max_abs`: MLP 9.5e-7, LeNet 1.8e-7; measured here: 0 and 6e-8).  The ResNet's own spread is 2.0e-3 -- on another code
+    # path some of the reference's fake-quantisers round the other way, which is NOT what the build is allowed: it reproduces the recorded
+    # run's roundings, and its floor is 1e-6 (measured 4.9e-7 absolute, 1.1e-5 relative on probabilities of 0.009 - 0.25).
+    atol = min(4.0 * float(d["refspread.max_abs"]), 1e-6 if model == "conv_resnet_bbb" else 1.0)
     if model == "linear_bbb":
         S = d["mu"].shape[0]
         with q.mc_context(S, seed, 0):
             mu, var = m.forward_mc(x)
-        np.testing.assert_allclose(mu.cpu().numpy(), d["mu"], rtol=1e-5, atol=2e-6)
-        np.testing.assert_allclose(var.cpu().numpy(), d["var"], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(mu.cpu().numpy(), d["mu"], rtol=1e-5, atol=atol)
+        np.testing.assert_allclose(var.cpu().numpy(), d["var"], rtol=1e-5, atol=0)
     else:
         S = d["probs"].shape[0]
         with q.mc_context(S, seed, 0):
             p = m.forward_mc(x)
-        np.testing.assert_allclose(p.cpu().numpy(), d["probs"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(p.cpu().numpy(), d["probs"], rtol=1e-5, atol=atol)
     checked = 0
     for k in d.files:
         if k.startswith("final/") and k.endswith("min_val"):
@@ -1116,7 +1121,8 @@ def test_native_prepare_calibrate_convert_pipeline():
     observer, and oneDNN sums the fp32 products in another order than ATen's own convolution: mkldnn on / off x 1 / 3 / 8 threads fall
     into exactly two groups, up to 3.0 % of an observer's range (4.1 % in a converted scale, 1 in a zero point) apart.  The recorded
     fixture is the plain-ATen run (mkldnn off, thread-count independent); the build (fp64 conv sums under the fake-quantisers) lands
-    on it: 2.7e-7 of the range on the worst activation observer, scales to 2.7e-7, every zero point and every int8 tensor equal."""
+    on it: 2.7e-7 of the range on the worst activation observer, scales to 2.7e-7, every zero point equal, 41 of the 42 int8 tensors equal and
+    the 42nd (named below) in all but one element."""
     import hashlib
     import os
     import quantised_bayesian_nets_amd as q
@@ -1153,6 +1159,7 @@ def test_native_prepare_calibrate_convert_pipeline():
     args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
     conv = convert_model_state(st, args)
     n_same = n_int8 = 0
+    differing = []
     for k in ref.files:
         if not k.startswith("converted/"):
             continue
@@ -1160,14 +1167,21 @@ def test_native_prepare_calibrate_convert_pipeline():
         if key.endswith(".sha1"):
             base = key[:-len(".sha1")]
             n_int8 += 1
-            n_same += int(hashlib.sha1(np.ascontiguousarray(conv[base]).tobytes()).hexdigest() == str(ref[k]))
+            same = hashlib.sha1(np.ascontiguousarray(conv[base]).tobytes()).hexdigest() == str(ref[k])
+            n_same += int(same)
+            if not same:
+                differing.append(base)
         elif key.endswith("scale"):                            # weight-side and activation-side alike
             np.testing.assert_allclose(float(np.asarray(conv[key]).reshape(-1)[0]), float(np.asarray(ref[k]).reshape(-1)[0]), rtol=1e-5, err_msg=key)
         elif key.endswith("zero_point"):
             assert int(np.asarray(conv[key]).reshape(-1)[0]) == int(np.asarray(ref[k]).reshape(-1)[0]), key
-    # int8 weight / std tensors bit-identical to the reference's (a BN-folded weight observer one ulp off may move single elements of
-    # one tensor on a rounding tie: 41 of 42 by hash here, the four tensors recorded in full must be equal)
-    assert n_int8 == 42 and n_same >= 41, (n_same, n_int8)
+    # int8 weight / std tensors bit-identical to the reference's, with ONE named exception: layers.6.1.stem.0.weight (192 x 192 x 3 x 3), whose
+    # BN-folded weight observer lands one fp32 ulp from the reference's (scale 0.0018490724 against 0.0018490722, inside the 1e-5 bound
+    # above) -- ONE of its 331,776 elements sits on a rounding tie and comes out one step higher.  The fixture holds that tensor in full.
+    assert n_int8 == 42 and n_same >= 41 and set(differing) <= {"layers.6.1.stem.0.weight"}, (n_same, n_int8, differing)
+    for key in differing:
+        dd = np.asarray(conv[key]).astype(np.int32) - ref["converted/" + key].astype(np.int32)
+        assert int((dd != 0).sum()) <= 1 and int(np.abs(dd).max()) <= 1, (key, int((dd != 0).sum()), int(np.abs(dd).max()))
     for key in ("layers.0.weight", "layers.4.0.shortcut.0.weight", "layers.9.weight", "layers.0.std"):
         assert np.array_equal(np.asarray(conv[key]).astype(np.int32), ref["converted/" + key].astype(np.int32)), key
     # the committed reference-vs-reference measurement: the oneDNN runs sit up to ~3 % of a range away from the ATen runs (and from the build)
@@ -1927,8 +1941,8 @@ def test_fused_float_mlp_equals_layerwise_and_reference(golden_mlp_f32, monkeypa
     S = g["mu"].shape[0]
     with q.mc_context(S, g["seed"], 0):
         mu, var = m.forward_mc(x)
-    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(var.cpu().numpy(), g["var"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=1e-5, atol=g["mu_atol"])
+    np.testing.assert_allclose(var.cpu().numpy(), g["var"], rtol=1e-5, atol=0)
     monkeypatch.setenv("QBNN_MLP_LAYERWISE", "1")
     with q.mc_context(S, g["seed"], 0):
         mu_l, var_l = m.forward_mc(x)
@@ -1997,7 +2011,7 @@ def test_float_mc_dropout_graphs_match_reference(golden_mc_f32):
     """Rows a6+ / a7 with q=False: `linear_mc`, `conv_lenet_mc`, `conv_resnet_mc` as float graphs with the FloatFunctional
     BernoulliDropout (dropout.py:15-40) -- in-kernel Philox masks == injected masks bit for bit, and the outputs against the reference's
     recorded ones.  Tolerance = 1e-5 relative (north_star) plus twice the reference's own oneDNN-vs-ATen spread (recorded in the fixture)
-    absolute; the MLP (whose two reference backends agree exactly) 1e-5 of the output range."""
+    absolute; the MLP: four times its AVX-512-vs-AVX2 spread."""
     import quantised_bayesian_nets_amd as q
     from oracle import oracle as orc
     g = golden_mc_f32
@@ -2014,10 +2028,11 @@ def test_float_mc_dropout_graphs_match_reference(golden_mc_f32):
         S = g["mu"].shape[0]
         with q.mc_context(S, seed, 0):
             mu, var = m.forward_mc(x)
-        np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=RTOL, atol=1e-5 * float(np.abs(g["mu"]).max()))
+        mu_atol = 4.0 * g["refspread"]["max_abs"]          # four times the reference's AVX-512-vs-AVX2 distance from itself (conftest._mlp_f32)
+        np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=RTOL, atol=mu_atol)
         np.testing.assert_allclose(var.cpu().numpy(), g["var"], rtol=RTOL, atol=0)
         mean, pv = q.mc_predict_regression(m, x, S, seed)
-        np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=RTOL, atol=1e-5 * float(np.abs(g["mean"]).max()))
+        np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=RTOL, atol=mu_atol)
         np.testing.assert_allclose(pv.cpu().numpy(), g["pred_var"], rtol=1e-4, atol=0)
         masks = [torch.from_numpy(np.stack([(orc.fill_uniform(B * 100, seed, di, s) < keep).astype(np.float32).reshape(B, 100) for s in range(S)]))
                  for di in range(4)]
@@ -2084,3 +2099,25 @@ def test_graphed_predictor_survives_a_layout_switch(golden_lenet_bbb):
     assert torch.equal(gp(x, 77), want)                  # and the re-captured graph replays
     assert not hasattr(m.load_reference_state, "__wrapped__") and "load_reference_state" not in m.__dict__      # no monkey-patched loader
     del junk
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layerwise", [False, True], ids=["fused", "layerwise"])
+def test_float_bbb_mlp_every_input_width(golden_mlp_f32_width, layerwise, monkeypatch):
+    """BASELINE config 0 at SURVEY 8(d) C1's other input widths (in_dim 1, 4, 6, 8, 11; 13 is the benchmark's): the fused two-launch MLP
+    (rows padded to 4 floats: 1 and 6 are the widths that padding has to get right) and the layer-by-layer path, per-sample (mu, var)
+    and the regression reduction against the reference; same measured tolerance as in_dim 13."""
+    import quantised_bayesian_nets_amd as q
+    g = golden_mlp_f32_width
+    if layerwise:
+        monkeypatch.setenv("QBNN_MLP_LAYERWISE", "1")
+    m = q.ModelFactory.get_model("linear_bbb", [g["in_dim"]], 1, False, types.SimpleNamespace(sigma_prior=-2.0)).load_reference_state(g["state"])
+    x = torch.from_numpy(g["x"]).cuda()
+    S = g["mu"].shape[0]
+    with q.mc_context(S, g["seed"], 0):
+        mu, var = m.forward_mc(x)
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=1e-5, atol=g["mu_atol"])
+    np.testing.assert_allclose(var.cpu().numpy(), g["var"], rtol=1e-5, atol=0)
+    mean, pv = q.mc_predict_regression(m, x, S, g["seed"])
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=1e-5, atol=g["mu_atol"])
+    np.testing.assert_allclose(pv.cpu().numpy(), g["pred_var"], rtol=1e-4, atol=0)
