@@ -11,6 +11,8 @@ and the result equals S sequential reference forwards.  Activations are fp32 NHW
 
 State-dict names follow the reference's prepared model (`<layer>.weight_fake_quant.activation_post_process.min_val`, ...).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -125,6 +127,13 @@ class _QATBBB(nn.Module):
         return None
 
     def sampled_weights(self, dev, eps=None):
+        pre = getattr(self, "_presampled", None)
+        if pre is not None and eps is None:          # produced ahead of the activation path on a side stream (presample_weights)
+            self._presampled = None
+            W, ev = pre
+            torch.cuda.current_stream().wait_event(ev)
+            W.record_stream(torch.cuda.current_stream())
+            return W
         S = _MC.samples
         mu0, sg0 = self._folded_params(dev)
         w = self.weight_fake_quant(mu0)                                  # [S, n]
@@ -155,6 +164,30 @@ class _QATBBB(nn.Module):
         self.add_weight.load(st, name + ".add_weight.activation_post_process")
         self.activation_post_process.load(st, name + ".activation_post_process")
         self._folded = None
+
+
+_SIDE_STREAMS = []
+
+
+def presample_weights(layers, dev, n_streams=4):
+    """The weight pipelines of all stochastic layers (4 fake-quantisers each: 12 launches of a few microseconds per layer, none of
+    which depends on an activation) up front on side streams, so that they run beside the activation path's convs instead of in
+    front of each of them.  Each layer's own observers are only touched by its own pipeline: the order across layers is free."""
+    if os.environ.get("QBNN_QAT_PRESAMPLE", "1") == "0" or _MC.eps is not None or torch.cuda.is_current_stream_capturing():
+        return
+    main = torch.cuda.current_stream()
+    while len(_SIDE_STREAMS) < n_streams:
+        _SIDE_STREAMS.append(torch.cuda.Stream())
+    for st in _SIDE_STREAMS[:n_streams]:
+        st.wait_stream(main)
+    for i, m in enumerate(layers):
+        st = _SIDE_STREAMS[i % n_streams]
+        with torch.cuda.stream(st):
+            m._presampled = None
+            W = m.sampled_weights(dev)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            m._presampled = (W, ev)
 
 
 class Conv2d(_QATBBB):
@@ -427,6 +460,7 @@ class ConvNetwork_ResNet(nn.Module):
         return self
 
     def forward_mc(self, x):
+        presample_weights([m for _, m in self.stochastic_named()], x.device)
         h = self.layers[0](self.quant(nchw_to_mc_nhwc(x)))
         for li in (3, 4, 5, 6):
             for blk in self.layers[li]:
