@@ -441,15 +441,16 @@ def main():
         # (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs) -- but ONLY while that file was measured on this very kernel source
         # and workload shape; otherwise null (never a stale number)
         traffic, traffic_note = None, "no PMC summary for this kernel source: run tools/profile_round.sh"
-        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        tname = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]      # the latest round's
+        tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("kernel_source_sha16") != kernel_source_sha16():
-                traffic_note = "profiles/r03_pmc_traffic.json was measured on an older kernel source"
+                traffic_note = "profiles/%s was measured on an older kernel source" % tname
             elif (tj.get("samples"), tj.get("batch"), tj.get("workload")) != (S_local, x_host.shape[0], a.workload):
-                traffic_note = "profiles/r03_pmc_traffic.json was measured on another workload shape"
+                traffic_note = "profiles/%s was measured on another workload shape" % tname
             else:
-                traffic, traffic_note = tj["by_bench_key"].get(dom), "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this source)"
+                traffic, traffic_note = tj["by_bench_key"].get(dom), "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this source)" % tname
         # vector-ALU roof of the exact-arithmetic epilogue: instructions per output element counted in the shipped ISA (6 for a plain
         # requantisation: sub, cvt, fma, mul, min, cvt_pk; 13 for stem.3 + quantized::add + ReLU) x the measured issue cost of that
         # mix at the kernel's occupancy (the 16-wave layer-1 kernel: 4 waves per SIMD; the 8-wave block kernels: 2)
