@@ -566,65 +566,7 @@ __device__ __forceinline__ void conv_ring_mfma_dense(const uint8_t* tile, uint8_
   QBNN_INNER_FLUSH();
 }
 
-// dense-tile epilogues: (b') centred stem.0 output, (c') Add(residual from global) + ReLU, centred block output
-template <int PIXB>
-struct EpiDenseTile {
-  uint8_t* dst; QConv p;
-  mutable int csum;            // sum of the centred bytes this lane has written since the last flush (channel-sum table)
-  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
-  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
-  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
-    const uint32_t pk = pack_rne_u8(v0, v1, v2, v3, p.vhi);      // ConvReLU2d: p.vlo == 0
-    *reinterpret_cast<uint32_t*>(dst + po + c0) = pk;
-    csum = __builtin_amdgcn_sdot4((int)pk, 0x01010101, csum, false);
-  }
-};
-
-// Window sum R(p) = sum over the 3x3 window and all channels of the centred tile bytes, needed because sampled weights
-// have a non-zero zero point (sum x'(W - z_w) = acc - z_w R).  The dense-tile kernel keeps S(p) = channel sum of pixel p in
-// a small LDS table, maintained where the tile is written (one v_dot4 per dword written, LDS atomic add), and gathers
-// the <= 9 neighbours here -- instead of 4 v_dot4 per pixel fragment inside the MFMA loop (x27 / x54 per conv).
-// Leaves R in A.rsum so that conv_epi_phase's (rsum + rsum of lane ^ 32) yields it.
-template <class C>
-__device__ __forceinline__ void window_sum_from_table(const int* tab, ConvAcc<C>& A, int pass, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  const int mblk = pass / C::NBLKS;
-#pragma unroll
-  for (int mb = 0; mb < C::MB; ++mb) {
-    const int m = (mblk * C::MB + mb) * 32 + r;
-    const int rem = m % (C::HO * C::HO), oh = rem / C::HO, ow = rem % C::HO;
-    int R = 0;
-#pragma unroll
-    for (int kh = -1; kh <= 1; ++kh)
-#pragma unroll
-      for (int kw = -1; kw <= 1; ++kw) {
-        const bool ok = (unsigned)(oh + kh) < (unsigned)C::HO && (unsigned)(ow + kw) < (unsigned)C::HO;
-        R += ok ? tab[m + kh * C::HO + kw] : 0;
-      }
-    A.rsum[mb] = h ? 0 : R;
-  }
-}
-template <int PIXB, int CCH>
-struct EpiDenseTileResGlobal {
-  uint8_t* xt; const uint8_t* res; int n_valid_px; QConv p; QAdd a;
-  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
-  __device__ __forceinline__ uint32_t load_px(int m, int c0) const {
-    return m < n_valid_px ? *reinterpret_cast<const uint32_t*>(res + (int64_t)m * CCH + c0) : 0u;
-  }
-  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
-  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
-    const float vv[4] = {v0, v1, v2, v3};
-    const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
-    float t[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float da = __builtin_fmaf(p.s_y, __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)), p.dl_y);
-      const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
-      t[i] = (da + db) * a.inv_s_o;
-    }
-    *reinterpret_cast<uint32_t*>(xt + po + c0) = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
-  }
-};
+// (EpiDenseTile, window_sum_from_table and EpiDenseTileResGlobal live in qbnn_conv.h: qbnn_chain_ring.hip uses them too)
 
 // the same two epilogues with a quantised channel dropout behind the conv (conv_resnet_mc)
 template <int PIXB, int COUT, int IMG_PX>
@@ -822,10 +764,20 @@ void block_chain_ald_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<D
     window_sum_from_table<C>(stab, A, wave, lane);
     conv_epi_phase_with<C, decltype(epi_b)>(bias_lds + C::COUT, bp.b, epi_b, A, wave, lane,
                                             [&](int mb, int nb, int g4, int, int) { return resq[mb & 1][nb][g4]; },
-                                            [&](int mb) { if (mb + 1 < C::MB) load_res(mb + 1); });
-    QBNN_STAMP_AT(5);
-    lds_barrier();
+                                            [&](int mb) {
+#ifdef QBNN_STAMP_EB
+                                              QBNN_STAMP_AT(4 + mb);
+#endif
+                                              if (mb + 1 < C::MB) load_res(mb + 1); });
+#ifdef QBNN_STAMP_EB
     QBNN_STAMP_AT(6);
+#else
+    QBNN_STAMP_AT(5);
+#endif
+    lds_barrier();
+#ifndef QBNN_STAMP_EB
+    QBNN_STAMP_AT(6);
+#endif
     for (int i = tid; i < C::G * IMG_PX; i += NTHR) stab[i] = 0;        // T table: every wave has gathered from it
     // ---- per 16-byte chunk: tile -> quint8 register, next item's input -> the same tile bytes, register -> HBM (the
     //      item's output block is contiguous).  The next input is written unconditionally (the last item rewrites
@@ -1285,11 +1237,11 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
     else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one 48-channel block per launch for this batch size%s");
   }
   if (Cc == 96 && H == 8) {
-    if constexpr (NBLK == 1) return launch_block_chain_ald<ALD_96, 8>(a, st);
+    if constexpr (NBLK == 1) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring(&a, 1, 96, false, st) : launch_block_chain_ald<ALD_96, 8>(a, st);
     else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one block per launch at 96 channels (its weights stream through the LDS ring)%s");
   }
   if (Cc == 192 && H == 4) {
-    if constexpr (NBLK == 1) return launch_block_chain_ald<ALD_192, 8>(a, st);
+    if constexpr (NBLK == 1) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring(&a, 1, 192, false, st) : launch_block_chain_ald<ALD_192, 8>(a, st);
     else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one block per launch at 192 channels (its weights stream through the LDS ring)%s");
   }
   return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
@@ -1404,10 +1356,12 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n
   if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: one block per call (two only behind the fused stem)%s");
   const ChainArgs<1>* dev = reinterpret_cast<const ChainArgs<1>*>(dev_args);
   if (Cc == 48 && H == 16) return launch_block_chain_ws_dev<Blk_48, 1>(dev, n_calls, items(Blk_48::G), st);
-  if (Cc == 96 && H == 8) return launch_block_chain_ald_dev<ALD_96, 8>(dev, n_calls, items(ALD_96::G), st);
-  if (Cc == 192 && H == 4)
-    return ((B + 15) / 16) * n_calls * max_samples <= 128 ? launch_block_chain_ald_dev<ALD_192_G8, 8>(dev, n_calls, items(8), st)
-                                                           : launch_block_chain_ald_dev<ALD_192, 8>(dev, n_calls, items(16), st);
+  if (Cc == 96 && H == 8) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring_dev(dev, n_calls, items(ALD_96::G), 96, false, st) : launch_block_chain_ald_dev<ALD_96, 8>(dev, n_calls, items(ALD_96::G), st);
+  if (Cc == 192 && H == 4) {
+    const bool small_items = ((B + 15) / 16) * n_calls * max_samples <= 128;
+    if (qbnn_use_chain_ring()) return qbnn_launch_block_chain_ring_dev(dev, n_calls, items(small_items ? 8 : 16), 192, small_items, st);
+    return small_items ? launch_block_chain_ald_dev<ALD_192_G8, 8>(dev, n_calls, items(8), st) : launch_block_chain_ald_dev<ALD_192, 8>(dev, n_calls, items(16), st);
+  }
   return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
 }
 
@@ -1548,8 +1502,12 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi(const qbnn_chain_call* calls, int32_t 
         if ((rc = build_chain_args<1>(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, nullptr, nullptr))) return rc;
       }
       if (Cc == 48 && H == 16) rc = launch_block_chain_ws_multi<Blk_48, 1, false, QBNN_FUSED_CALLS>(arr, n, st);
-      else if (Cc == 96 && H == 8) rc = launch_block_chain_ald_multi<ALD_96, 8>(arr, n, st);
-      else if (Cc == 192 && H == 4) rc = ((B + 15) / 16) * n <= 128 ? launch_block_chain_ald_multi<ALD_192_G8, 8>(arr, n, st) : launch_block_chain_ald_multi<ALD_192, 8>(arr, n, st);
+      else if (Cc == 96 && H == 8) rc = qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring(arr, n, 96, false, st) : launch_block_chain_ald_multi<ALD_96, 8>(arr, n, st);
+      else if (Cc == 192 && H == 4) {
+        const bool small_items = ((B + 15) / 16) * n <= 128;
+        rc = qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring(arr, n, 192, small_items, st)
+                                   : small_items ? launch_block_chain_ald_multi<ALD_192_G8, 8>(arr, n, st) : launch_block_chain_ald_multi<ALD_192, 8>(arr, n, st);
+      }
       else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
     }
     if (rc) return rc;

@@ -515,6 +515,30 @@ __device__ __forceinline__ void dma_slab(uint8_t* dst, const int8_t* wq, int sla
   }
 }
 
+// ---- the explicit form of the LDS-DMA ring (qbnn_down_ring.hip, qbnn_chain_ring.hip): NBUF slabs, NBUF - 1 in flight, per-wave vmcnt accounting
+// 16 bytes per lane, global -> LDS at lds_addr + 16 * lane, without passing through registers.  Issued from inline assembly: see the
+// header comment (the compiler must not know that LDS is written behind its back; this file does its own vmcnt accounting).
+__device__ __forceinline__ void dma16(const void* gptr, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const uint8_t* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// s_waitcnt vmcnt(K) only (gfx9 encoding: vmcnt = {[15:14], [3:0]}, expcnt [6:4] and lgkmcnt [11:8] left at "no wait")
+template <int K> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(K >= 0 && K < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt((K & 0xf) | ((K >> 4) << 14) | 0x0f70);
+}
+
+// The workgroup's weight ring: consumer position (buffer of the slab being multiplied) and producer position (flat index of the next
+// slab to request; one item = NSI slabs, conv after conv).
+struct WeightRing {
+  uint8_t* base; int cbuf, pbuf, pnext;
+};
+
+
 // Post-ops of the layer kernel for graphs with a dropout behind every conv (mcdropout/models_mc.py:116-160): quantised
 // BernoulliDropout on the conv output, then optionally quantized::add with the block's other branch + ReLU -- in the conv's
 // epilogue (EpiDenseDrop), on the centred integer it already holds.  Same bits as the stand-alone kernels
@@ -1132,6 +1156,66 @@ __device__ __forceinline__ void item_range(int n_items, int b, int nb, int& begi
   begin = b * q + (b < rm ? b : rm);
   count = q + (b < rm ? 1 : 0);
 }
+
+// dense-tile epilogues: (b') centred stem.0 output, (c') Add(residual from global) + ReLU, centred block output
+template <int PIXB>
+struct EpiDenseTile {
+  uint8_t* dst; QConv p;
+  mutable int csum;            // sum of the centred bytes this lane has written since the last flush (channel-sum table)
+  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
+    const uint32_t pk = pack_rne_u8(v0, v1, v2, v3, p.vhi);      // ConvReLU2d: p.vlo == 0
+    *reinterpret_cast<uint32_t*>(dst + po + c0) = pk;
+    csum = __builtin_amdgcn_sdot4((int)pk, 0x01010101, csum, false);
+  }
+};
+
+// Window sum R(p) = sum over the 3x3 window and all channels of the centred tile bytes, needed because sampled weights
+// have a non-zero zero point (sum x'(W - z_w) = acc - z_w R).  The dense-tile kernel keeps S(p) = channel sum of pixel p in
+// a small LDS table, maintained where the tile is written (one v_dot4 per dword written, LDS atomic add), and gathers
+// the <= 9 neighbours here -- instead of 4 v_dot4 per pixel fragment inside the MFMA loop (x27 / x54 per conv).
+// Leaves R in A.rsum so that conv_epi_phase's (rsum + rsum of lane ^ 32) yields it.
+template <class C>
+__device__ __forceinline__ void window_sum_from_table(const int* tab, ConvAcc<C>& A, int pass, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int mblk = pass / C::NBLKS;
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb) {
+    const int m = (mblk * C::MB + mb) * 32 + r;
+    const int rem = m % (C::HO * C::HO), oh = rem / C::HO, ow = rem % C::HO;
+    int R = 0;
+#pragma unroll
+    for (int kh = -1; kh <= 1; ++kh)
+#pragma unroll
+      for (int kw = -1; kw <= 1; ++kw) {
+        const bool ok = (unsigned)(oh + kh) < (unsigned)C::HO && (unsigned)(ow + kw) < (unsigned)C::HO;
+        R += ok ? tab[m + kh * C::HO + kw] : 0;
+      }
+    A.rsum[mb] = h ? 0 : R;
+  }
+}
+template <int PIXB, int CCH>
+struct EpiDenseTileResGlobal {
+  uint8_t* xt; const uint8_t* res; int n_valid_px; QConv p; QAdd a;
+  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
+  __device__ __forceinline__ uint32_t load_px(int m, int c0) const {
+    return m < n_valid_px ? *reinterpret_cast<const uint32_t*>(res + (int64_t)m * CCH + c0) : 0u;
+  }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
+    const float vv[4] = {v0, v1, v2, v3};
+    const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float da = __builtin_fmaf(p.s_y, __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)), p.dl_y);
+      const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
+      t[i] = (da + db) * a.inv_s_o;
+    }
+    *reinterpret_cast<uint32_t*>(xt + po + c0) = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
+  }
+};
 
 // Interleaved, XCD-aware walk for the kernels that stream their weights per item (no weights-stationary LDS copy).
 // Workgroup b runs on XCD b % 8 (round-robin dispatch, one workgroup per CU), and every XCD has its own 4 MiB L2.  XCD x

@@ -77,22 +77,6 @@ using DR96 = DRCfg<96, 192, 8, 8, 4, 0>;      // 24 KiB slabs (NT = 6); X reads 
 using E48 = ConvCfg<48, 96, 3, 2, 16, 1, 4, 1, 3, false>;
 using E96 = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
 
-// 16 bytes per lane, global -> LDS at lds_addr + 16 * lane, without passing through registers.  Issued from inline assembly: see the
-// header comment (the compiler must not know that LDS is written behind its back; this file does its own vmcnt accounting).
-__device__ __forceinline__ void dma16(const void* gptr, uint32_t lds_addr) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gptr), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ uint32_t lds_addr_of(const uint8_t* p) {
-  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
-// s_waitcnt vmcnt(K) only (gfx9 encoding: vmcnt = {[15:14], [3:0]}, expcnt [6:4] and lgkmcnt [11:8] left at "no wait")
-template <int K> __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(K >= 0 && K < 64, "vmcnt is a 6-bit counter");
-  __builtin_amdgcn_s_waitcnt((K & 0xf) | ((K >> 4) << 14) | 0x0f70);
-}
-
 // stem.0's epilogue: ConvReLU2d output, centred on its zero point, into the dense T tile [M][PIXB]
 template <int PIXB>
 struct EpiT {
@@ -106,13 +90,6 @@ struct EpiT {
 
 struct StepSrc { const uint8_t* p; int m0, m1; };      // a k-step's pixel fragment address and the dot4 masks of its two 8-byte pieces
 
-// The workgroup's weight ring: consumer position (buffer of the slab being multiplied) and producer position (flat index of the next
-// slab to request; one item = NSI slabs: stem.0's, the shortcut's, stem.3's).
-template <class D>
-struct Ring {
-  uint8_t* base; int cbuf, pbuf, pnext;
-};
-
 // One conv's M phase: its KS k-steps as ONE software-pipelined stream (fragments are requested PD k-steps ahead of their MFMAs -- with
 // three MFMAs per k-step and wave, one step ahead exposed the LDS latency at every step: 625 cycles per k-step against 96 of MFMAs,
 // profiles/r04_stamp_down_ring.txt), fully unrolled, so every tile offset is an immediate.  Where the stream of requests enters a new
@@ -120,7 +97,7 @@ struct Ring {
 // last steps are still to issue, so the pipeline does not drain at slab boundaries.  This wave accumulates its pixel tile against the
 // channel tiles nblk * 3 .. + 2.  step(ks) -> StepSrc of k-step ks; issue(q, buffer) requests flat slab q.
 template <class D, int KS, class StepFn, class IssueFn>
-__device__ __forceinline__ void ring_mfma(StepFn step, Ring<D>& rg, ConvAccMN<1, 3>& A, int nblk, int wave, int lane, IssueFn issue) {
+__device__ __forceinline__ void ring_mfma(StepFn step, WeightRing& rg, ConvAccMN<1, 3>& A, int nblk, int wave, int lane, IssueFn issue) {
   constexpr int SLK = D::SLK, PD = 3;
   A.rsum[0] = 0;
 #pragma unroll
@@ -264,7 +241,7 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
 
   fetch(walk.item(0));
   write_tile(walk.item(0));
-  Ring<D> rg{rbase, 0, D::NBUF - 1, D::NBUF - 1};
+  WeightRing rg{rbase, 0, D::NBUF - 1, D::NBUF - 1};
 #pragma unroll
   for (int q = 0; q < D::NBUF - 1; ++q) issue(q, q);
   ConvAccMN<1, 3> A, S;

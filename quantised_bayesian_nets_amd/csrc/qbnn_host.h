@@ -62,6 +62,14 @@ static inline bool qbnn_use_down_ring() {
   static const bool v = [] { const char* e = getenv("QBNN_DOWN_RING"); return !(e && e[0] == '0'); }();
   return v;
 }
+// The wide identity blocks with the same K loop (qbnn_chain_ring.hip): 96 channels at 8 x 8, 192 at 4 x 4 (`small_items`: 8 instead of 16 images per
+// work item).  QBNN_CHAIN_RING=0 selects block_chain_ald_kernel (qbnn_blocks.hip).
+int qbnn_launch_block_chain_ring(const ChainArgs<1>* arr, int n, int Cc, bool small_items, hipStream_t st);
+int qbnn_launch_block_chain_ring_dev(const ChainArgs<1>* dev, int n, int items, int Cc, bool small_items, hipStream_t st);
+static inline bool qbnn_use_chain_ring() {
+  static const bool v = [] { const char* e = getenv("QBNN_CHAIN_RING"); return !(e && e[0] == '0'); }();
+  return v;
+}
 // QBNN_W16=0 selects the 8-wave kernels of qbnn_blocks.hip everywhere (A/B checks)
 static inline bool qbnn_use_w16() {
   static const bool v = [] { const char* e = getenv("QBNN_W16"); return !(e && e[0] == '0'); }();
