@@ -24,7 +24,11 @@
 //      four weight slabs of 24 KiB, biases.
 // Phases per work item (M = MFMA K loop over the ring, E = requantising epilogue):
 //      M_a M_s | barrier | E_a(-> T) E_s(-> SC)   M_b E_b(SC += , ReLU)   | barrier, read-out, barrier, next X
-// Window sums (sampled weights have a non-zero zero point: sum x'(W - z_w) = acc - z_w R) by v_dot4 on the pixel fragments in the K loop.
+// Window sums (sampled weights have a non-zero zero point: sum x'(W - z_w) = acc - z_w R) from per-pixel channel sums kept beside the tiles,
+// as in the wide identity blocks: S_X (written with the X tile by the thread that moves the pixel: one v_dot4 per dword, one 16-bit store
+// per pixel) serves stem.0 (its 3x3 / s2 window) and the shortcut (the centre pixel); S_T (one plain store per pixel and channel block from stem.0's epilogue) serves stem.3.  The first version of this
+// kernel took them by 4 v_dot4 per k-step on the pixel fragments inside the K loop: 15 % of the M phases by ablation
+// (profiles/r04_stamp_down_ring.txt).
 #include "qbnn_host.h"
 
 #ifdef QBNN_STAMP      // diagnostic build only (tools/stamp_ring.py): per-phase s_memtime sums; the shipped library has none of this
@@ -61,13 +65,15 @@ struct DRCfg {
   static constexpr int NF = NT * SLK, DMA_PER_WAVE = NF / 8;
   static constexpr int SLABB = NF * 1024;
   static constexpr int NS_A = (KS_A + SLK - 1) / SLK, NS_S = (KS_S + SLK - 1) / SLK, NS_B = (KS_B + SLK - 1) / SLK, NSI = NS_A + NS_S + NS_B;
-  static constexpr int LDS = X_BYTES + NBUF * SLABB + 3 * COUT * 4;
-  static constexpr int ROWB = HIN * CIN, CPR = ROWB / 16, CPI = HIN * CPR, NCH = G * CPI;      // 16-byte chunks of the item's input
+  static constexpr int NPX = G * HIN * HIN;                 // S_X: int16 [NPX]
+  static constexpr int ST_OFF = SC_OFF + SC_BYTES;          // S_T [NBLKS][M] ints: in the X region behind SC (X is dead while T lives)
+  static constexpr int LDS = X_BYTES + NBUF * SLABB + 3 * COUT * 4 + NPX * 2;
   static constexpr int NHALO = XTW * CIN / 16 + HIN * (CIN / 16);                              // ... of one image's halo
   static_assert(MT * NBLKS == 8, "one (pixel tile, channel half) pass per wave");
   static_assert(NF % 8 == 0, "every wave issues the same number of DMA instructions per slab");
   static_assert(XROW % 16 == 0 && XIMG % 16 == 0 && CIN % 16 == 0 && COUT % 96 == 0 && M % 32 == 0 && T_BYTES % 16 == 0, "alignment");
-  static_assert(SC_OFF + SC_BYTES <= G * XIMG, "T and SC alias the X tile");
+  static_assert(ST_OFF % 16 == 0 && ST_OFF + (NBLKS * M + HO + 1) * 4 <= G * XIMG, "T, SC and the S_T table alias the X tile");
+  static_assert(HIN % 2 == 0 && CIN * 128 < 16384, "S_X fields: column parity = pixel parity; |channel sum| < 2^14");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 using DR48 = DRCfg<48, 96, 16, 4, 8, 16>;     // 24 KiB slabs (NT = 3); X reads 2-way conflicted (4-way without the row pad)
@@ -77,34 +83,20 @@ using DR96 = DRCfg<96, 192, 8, 8, 4, 0>;      // 24 KiB slabs (NT = 6); X reads 
 using E48 = ConvCfg<48, 96, 3, 2, 16, 1, 4, 1, 3, false>;
 using E96 = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
 
-// stem.0's epilogue: ConvReLU2d output, centred on its zero point, into the dense T tile [M][PIXB]
-template <int PIXB>
-struct EpiT {
-  uint8_t* dst; QConv p;
-  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
-  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
-  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
-    *reinterpret_cast<uint32_t*>(dst + po + c0) = pack_rne_u8(v0, v1, v2, v3, p.vhi);      // p.vlo == 0 (fill_qconv, relu = 1)
-  }
-};
-
-struct StepSrc { const uint8_t* p; int m0, m1; };      // a k-step's pixel fragment address and the dot4 masks of its two 8-byte pieces
-
 // One conv's M phase: its KS k-steps as ONE software-pipelined stream (fragments are requested PD k-steps ahead of their MFMAs -- with
 // three MFMAs per k-step and wave, one step ahead exposed the LDS latency at every step: 625 cycles per k-step against 96 of MFMAs,
 // profiles/r04_stamp_down_ring.txt), fully unrolled, so every tile offset is an immediate.  Where the stream of requests enters a new
 // weight slab the ring advances IN the stream: wait for the slab, barrier, request slab + NBUF - 1 -- the MFMAs of the previous slab's
 // last steps are still to issue, so the pipeline does not drain at slab boundaries.  This wave accumulates its pixel tile against the
-// channel tiles nblk * 3 .. + 2.  step(ks) -> StepSrc of k-step ks; issue(q, buffer) requests flat slab q.
+// channel tiles nblk * 3 .. + 2.  step(ks) -> address of k-step ks's pixel fragment; issue(q, buffer) requests flat slab q.
 template <class D, int KS, class StepFn, class IssueFn>
 __device__ __forceinline__ void ring_mfma(StepFn step, WeightRing& rg, ConvAccMN<1, 3>& A, int nblk, int wave, int lane, IssueFn issue) {
   constexpr int SLK = D::SLK, PD = 3;
-  A.rsum[0] = 0;
 #pragma unroll
   for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) A.acc[0][nb][i] = 0;
-  struct Frag { v4i w[3]; v4i x; int m0, m1; };
+  struct Frag { v4i w[3]; v4i x; };
   Frag f[PD + 1];
   const uint8_t* wl = nullptr;
   auto advance = [&]() {
@@ -120,17 +112,9 @@ __device__ __forceinline__ void ring_mfma(StepFn step, WeightRing& rg, ConvAccMN
     const int j = ks % SLK;
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) fr.w[nb] = *reinterpret_cast<const v4i*>(wl + (nb * SLK + j) * 1024);
-    const StepSrc s = step(ks);
-    fr.x = *reinterpret_cast<const v4i*>(s.p);
-    fr.m0 = s.m0; fr.m1 = s.m1;
+    fr.x = *reinterpret_cast<const v4i*>(step(ks));
   };
   auto mfma = [&](const Frag& fr) {
-    int rs = A.rsum[0];
-    rs = __builtin_amdgcn_sdot4(fr.x.x, fr.m0, rs, false);
-    rs = __builtin_amdgcn_sdot4(fr.x.y, fr.m0, rs, false);
-    rs = __builtin_amdgcn_sdot4(fr.x.z, fr.m1, rs, false);
-    rs = __builtin_amdgcn_sdot4(fr.x.w, fr.m1, rs, false);
-    A.rsum[0] = rs;
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) A.acc[0][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr.w[nb], fr.x, A.acc[0][nb], 0, 0, 0);
   };
@@ -147,9 +131,7 @@ __device__ __forceinline__ void ring_mfma(StepFn step, WeightRing& rg, ConvAccMN
       load(f[p % (PD + 1)], p);
     }
     mfma(f[j % (PD + 1)]);
-    // keep the steps apart: left alone, the scheduler hoists the v_dot4 of a fragment to right behind its ds_read (they only depend on the
-    // window-sum chain) and waits for the read there -- the request distance is gone
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);                  // keep the steps apart: the request distance is the point
   }
 }
 
@@ -165,10 +147,13 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
   uint8_t* sc = smem + D::SC_OFF;
   uint8_t* rbase = smem + D::X_BYTES;
   float* bias_lds = reinterpret_cast<float*>(rbase + D::NBUF * D::SLABB);               // [3][COUT]: s, a, b
+  int16_t* sx16 = reinterpret_cast<int16_t*>(bias_lds + 3 * D::COUT);                   // S_X: channel sums of the X tile's interior pixels
+  int* stt = reinterpret_cast<int*>(smem + D::ST_OFF);                                  // S_T: ... of the T tile, per channel block
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mblk = wave / D::NBLKS, nblk = wave - mblk * D::NBLKS;
 
-  constexpr int PER_T = (D::NCH + NTHR - 1) / NTHR;
+  constexpr int CPP = D::CIN / 16, PPT = D::NPX / NTHR, PER_T = PPT * CPP;              // a thread moves whole pixels: PPT pixels of CPP 16-byte chunks
+  static_assert(D::NPX % NTHR == 0, "whole pixels per thread");
   constexpr int IMG_IN = D::HIN * D::HIN * D::CIN, IMG_OUT = D::HO * D::HO * D::COUT, U8 = D::COUT / 8;
   constexpr int NOUT = (D::M * U8 + NTHR - 1) / NTHR;
   const int groups = (a.B + D::G - 1) / D::G;
@@ -180,35 +165,47 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
   load_bias<D::COUT, NTHR>(bias_lds + 2 * D::COUT, a.b.bias, tid);
   if (count <= 0) return;
 
+  // A thread moves WHOLE pixels (pixel t + j * 512 of the item, CPP consecutive 16-byte chunks): the pixel's channel sum is then thread-local --
+  // one 16-bit store into S_X, no atomics -- and the lanes' tile writes sit 48 / 96 bytes apart (conflict-free / 2-way).
   v4i pre[PER_T];
   auto fetch = [&](int item) {
     const int s = item / groups, img0 = (item - s * groups) * D::G;
     const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_IN;            // an item's images are contiguous in HBM
-    const int valid = (a.B - img0 < D::G ? a.B - img0 : D::G) * D::CPI;
+    const int valid = (a.B - img0 < D::G ? a.B - img0 : D::G) * D::HIN * D::HIN;
     int t = tid;
     asm volatile("" : "+v"(t));         // per-thread addresses are recomputed here, not hoisted out of the item loop (spills)
 #pragma unroll
-    for (int j = 0; j < PER_T; ++j) {
-      const int i = t + j * NTHR;
-      pre[j] = *reinterpret_cast<const v4i*>(xs + (i < valid ? (int64_t)i * 16 : 0));
+    for (int j = 0; j < PPT; ++j) {
+      const int px = t + j * NTHR;
+      const uint8_t* p = xs + (px < valid ? (int64_t)px * D::CIN : 0);
+#pragma unroll
+      for (int c = 0; c < CPP; ++c) pre[j * CPP + c] = *reinterpret_cast<const v4i*>(p + 16 * c);
     }
   };
-  // registers -> centred X interior, and the halo zeros (T / SC, which share these bytes, have overwritten them)
+  // registers -> centred X interior + S_X, and the halo zeros (T / SC, which share these bytes, have overwritten them)
   auto write_tile = [&](int item) {
     const int s = item / groups, img0 = (item - s * groups) * D::G;
-    const int valid = (a.B - img0 < D::G ? a.B - img0 : D::G) * D::CPI;
+    const int valid = (a.B - img0 < D::G ? a.B - img0 : D::G) * D::HIN * D::HIN;
     const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
     int t = tid;
     asm volatile("" : "+v"(t));
 #pragma unroll
-    for (int j = 0; j < PER_T; ++j) {
-      const int i = t + j * NTHR;
-      if (i < D::NCH) {
-        const int g = i / D::CPI, rem = i - g * D::CPI, row = rem / D::CPR, within = rem - row * D::CPR;
-        const v4i v = pre[j];
-        const v4i c = i < valid ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v4i{0, 0, 0, 0};
-        *reinterpret_cast<v4i*>(xt + g * D::XIMG + (row + 1) * D::XROW + D::CIN + within * 16) = c;
+    for (int j = 0; j < PPT; ++j) {
+      const int px = t + j * NTHR;
+      const int g = px / (D::HIN * D::HIN), rem = px - g * (D::HIN * D::HIN), row = rem / D::HIN, col = rem - row * D::HIN;
+      uint8_t* dst = xt + g * D::XIMG + (row + 1) * D::XROW + (col + 1) * D::CIN;
+      int sum = 0;
+#pragma unroll
+      for (int c = 0; c < CPP; ++c) {
+        const v4i v = pre[j * CPP + c];
+        const v4i q = px < valid ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v4i{0, 0, 0, 0};
+        *reinterpret_cast<v4i*>(dst + 16 * c) = q;
+        sum = __builtin_amdgcn_sdot4(q.x, 0x01010101, sum, false);
+        sum = __builtin_amdgcn_sdot4(q.y, 0x01010101, sum, false);
+        sum = __builtin_amdgcn_sdot4(q.z, 0x01010101, sum, false);
+        sum = __builtin_amdgcn_sdot4(q.w, 0x01010101, sum, false);
       }
+      sx16[px] = (int16_t)sum;
     }
     constexpr int TOP = D::XTW * D::CIN / 16, CW = D::CIN / 16;
     for (int i = t; i < D::G * D::NHALO; i += NTHR) {
@@ -263,30 +260,40 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
     ring_mfma<D, D::KS_A>(
         [&](int ks) {
           const int kh = ks / D::SPR_A, t = ks - kh * D::SPR_A;
-          StepSrc q;
-          q.p = xlane + kh * D::XROW + t * 32;
-          if constexpr (D::RB_A % 32 == 0) { q.m0 = 0x01010101; q.m1 = 0x01010101; }
-          else { q.m0 = t * 32 + 16 * h < D::RB_A ? 0x01010101 : 0; q.m1 = t * 32 + 16 * h + 8 < D::RB_A ? 0x01010101 : 0; }
-          return q;
+          return xlane + kh * D::XROW + t * 32;
         },
         rg, A, nblk, wave, lane, issue);
     QBNN_STAMP_AT(0);
     // ---- shortcut: M over the centre taps of X (1x1 / s2)
     ring_mfma<D, D::KS_S>(
-        [&](int ks) {
-          StepSrc q;
-          q.p = xlane + D::XROW + D::CIN + ks * 32;
-          if constexpr (D::CIN % 32 == 0) { q.m0 = 0x01010101; q.m1 = 0x01010101; }
-          else { q.m0 = ks * 32 + 16 * h < D::CIN ? 0x01010101 : 0; q.m1 = ks * 32 + 16 * h + 8 < D::CIN ? 0x01010101 : 0; }
-          return q;
-        },
+        [&](int ks) { return xlane + D::XROW + D::CIN + ks * 32; },
         rg, S, nblk, wave, lane, issue);
     QBNN_STAMP_AT(1);
     lds_barrier();                       // every wave has read X for the last time: T and SC may overwrite it
     QBNN_STAMP_AT(2);
     {
-      EpiT<D::PIXB_T> epi{tt, a.a};
+      // window sums of stem.0 (3x3 / s2: rows 2 oh - 1 .. 2 oh + 1, columns likewise; only the top / left can leave the map) and of the
+      // shortcut (the centre pixel) from S_X; a pixel's field: low half for even columns
+      // (the centre pixel (2 oh, 2 ow) has an even index: with sb = the dword that holds it, row kh's three pixels are the high half of
+      //  sb[.. - 1] and both halves of sb[..] -- two reads at immediate offsets per kernel row; a read in front of the table is masked out)
+      const int* sb = reinterpret_cast<const int*>(sx16) + (((g * D::HIN + 2 * oh) * D::HIN + 2 * ow) >> 1);
+      int ra = 0, centre = 0;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int u = sb[(kh - 1) * (D::HIN / 2) - 1], v = sb[(kh - 1) * (D::HIN / 2)];
+        const int mid = (int)(int16_t)v;
+        const int row = (ow > 0 ? u >> 16 : 0) + mid + (v >> 16);
+        ra += (kh > 0 || oh > 0) ? row : 0;
+        if (kh == 1) centre = mid;
+      }
+      A.rsum[0] = h ? 0 : ra;                                      // conv_epi_phase adds the two k-halves' sums
+      S.rsum[0] = h ? 0 : centre;
+    }
+    {
+      EpiDenseTile<D::PIXB_T> epi{tt, a.a, 0};
       conv_epi_phase<EC, decltype(epi)>(bias_lds + D::COUT, a.a, epi, A, wave, lane);
+      const int v = half_sum(epi.csum);                            // channel sum of this wave's 96 channels of T, per pixel
+      if (lane < 32) stt[nblk * D::M + mblk * 32 + lane] = v;
     }
     {
       EpiDense<D::COUT, false, D::SCP> epi{sc, a.s, a.add};
@@ -307,15 +314,26 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
       ring_mfma<D, D::KS_B>(
           [&](int ks) {
             const int tap = ks / D::SPT_B, sub = ks - tap * D::SPT_B, kh = tap / 3, kw = tap - 3 * kh;
-            StepSrc q;
-            q.p = ((vmask >> tap) & 1 ? tlane + ((kh - 1) * D::HO + (kw - 1)) * D::PIXB_T : zl) + sub * 32;
-            q.m0 = 0x01010101; q.m1 = 0x01010101;
-            return q;
+            return ((vmask >> tap) & 1 ? tlane + ((kh - 1) * D::HO + (kw - 1)) * D::PIXB_T : zl) + sub * 32;
           },
           rg, A, nblk, wave, lane, issue);
     }
     QBNN_STAMP_AT(4);
     fetch(next);                         // the next item's input: in flight during this epilogue and the read-out
+    {
+      int rb = 0;                        // (reads at immediate offsets from the pixel's own entry; one outside the map is masked out, and lands inside the X region)
+      const int* sp = stt + m;
+#pragma unroll
+      for (int kh = -1; kh <= 1; ++kh)
+#pragma unroll
+        for (int kw = -1; kw <= 1; ++kw) {
+          const bool ok = (unsigned)(oh + kh) < (unsigned)D::HO && (unsigned)(ow + kw) < (unsigned)D::HO;
+          int sv = sp[kh * D::HO + kw];
+          if constexpr (D::NBLKS == 2) sv += sp[D::M + kh * D::HO + kw];
+          rb += ok ? sv : 0;
+        }
+      A.rsum[0] = h ? 0 : rb;
+    }
     {
       EpiDense<D::COUT, true, D::SCP> epi{sc, a.b, a.add};
       conv_epi_phase<EC, decltype(epi)>(bias_lds + 2 * D::COUT, a.b, epi, A, wave, lane);
