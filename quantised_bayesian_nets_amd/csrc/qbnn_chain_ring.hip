@@ -30,7 +30,7 @@ struct CRCfg {
   static constexpr int NBUF = 4;
   static constexpr int NF = 24, SLK = NF / NT, DMA_PER_WAVE = NF / 8, SLABB = NF * 1024;
   static constexpr int NS = (KS + SLK - 1) / SLK, NSI = 2 * NS;
-  static constexpr int LDS = TILE + PIXB + NBUF * SLABB + 2 * C::COUT * 4 + 2 * M * 4;
+  static constexpr int LDS = TILE + PIXB + NBUF * SLABB + 2 * C::COUT * 4 + 2 * M * 4 + 64;      // (+ slack: a masked window-sum read may lie HO + 1 entries behind the tables)
   static_assert(C::NB == 3 && NT % 3 == 0 && NF % NT == 0, "three channel tiles per wave; 24 fragments per slab");
   static_assert(C::NPASS == 8, "one (MB pixel tiles, channel block) pass per wave");
   static_assert(C::CIN == C::COUT && C::CIN % 32 == 0 && C::PADB > 0 && C::STRIDE == 1 && C::KSZ == 3, "wide identity BasicBlock on a dense padded tile");
@@ -122,23 +122,29 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
 
   constexpr int IMG_PX = D::IMG_PX;
   constexpr int CPP = C::CIN / 16;                                           // 16-byte chunks per pixel
-  constexpr int NCH = D::M * CPP;
-  constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
+  // tile traffic: TPP adjacent lanes share a pixel, each moves CPT consecutive 16-byte chunks of it -- the pixel's channel sum is then a
+  // thread-local v_dot4 chain (+ a DPP exchange between the TPP lanes) and ONE plain store into the table, no LDS atomics
+  constexpr int TPP = NTHR / D::M, CPT = CPP / TPP, PER_T = CPT;
+  static_assert(TPP * D::M == NTHR && CPT * TPP == CPP && (TPP == 1 || TPP == 2 || TPP == 4), "every thread moves the same share of one pixel");
   const int groups = (a.B + C::G - 1) / C::G;
   const ItemWalk walk(a.n_samples * groups, blockIdx.x, gridDim.x);          // interleaved per XCD: a sample's weights stay in ONE L2
   const int count = walk.count;
 
   for (int i = tid; i < D::PIXB / 4; i += NTHR) reinterpret_cast<uint32_t*>(xt + D::TILE)[i] = 0u;
-  for (int i = tid; i < 2 * D::M; i += NTHR) sx[i] = 0;
+  for (int i = tid; i < D::M; i += NTHR) stab[i] = 0;
   load_bias<C::COUT, NTHR>(bias_lds, bp.a.bias, tid);
   load_bias<C::COUT, NTHR>(bias_lds + C::COUT, bp.b.bias, tid);
   if (count <= 0) return;
-  __syncthreads();                                   // tables are zero before the first tile write adds into them
-  auto dot16 = [](const v4i& c) {
-    int d = __builtin_amdgcn_sdot4(c.x, 0x01010101, 0, false);
+  auto dot16 = [](const v4i& c, int d) {
+    d = __builtin_amdgcn_sdot4(c.x, 0x01010101, d, false);
     d = __builtin_amdgcn_sdot4(c.y, 0x01010101, d, false);
     d = __builtin_amdgcn_sdot4(c.z, 0x01010101, d, false);
     return __builtin_amdgcn_sdot4(c.w, 0x01010101, d, false);
+  };
+  auto pixel_sum = [](int d) {       // over the TPP lanes of a pixel (adjacent lanes of one quad)
+    if constexpr (TPP >= 2) d += __builtin_amdgcn_update_dpp(0, d, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]
+    if constexpr (TPP == 4) d += __builtin_amdgcn_update_dpp(0, d, 0x4E, 0xf, 0xf, false);      // quad_perm [2, 3, 0, 1]
+    return d;
   };
 
   // an item's images are contiguous in HBM: chunk i of the item is byte 16 i of that block
@@ -146,32 +152,32 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
   auto fetch = [&](int item) {
     const int s = item / groups, img0 = (item - s * groups) * C::G;
     const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_PX * C::CIN;
-    const int valid = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX * CPP;
+    const int valid = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX;
     int t = tid;
     asm volatile("" : "+v"(t));         // per-thread addresses are recomputed here, not hoisted out of the item loop (spills)
+    const int px = t / TPP, part = t - px * TPP;
+    const uint8_t* p = xs + (px < valid ? (int64_t)px * C::CIN + part * (CPT * 16) : 0);
 #pragma unroll
-    for (int j = 0; j < PER_T; ++j) {
-      const int i = t + j * NTHR;
-      pre[j] = *reinterpret_cast<const v4i*>(xs + (i < valid ? (int64_t)i * 16 : 0));
-    }
+    for (int j = 0; j < CPT; ++j) pre[j] = *reinterpret_cast<const v4i*>(p + 16 * j);
   };
   auto write_tile = [&](int item) {
     const int s = item / groups, img0 = (item - s * groups) * C::G;
-    const int valid = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX * CPP;
+    const int valid = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX;
     const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
     int t = tid;
     asm volatile("" : "+v"(t));
+    const int px = t / TPP, part = t - px * TPP;
+    uint8_t* dst = xt + px * D::PIXB + part * (CPT * 16);
+    int sum = 0;
 #pragma unroll
-    for (int j = 0; j < PER_T; ++j) {
-      const int i = t + j * NTHR;
-      if (i < NCH) {
-        const int px = i / CPP, within = i - px * CPP;
-        const v4i v = pre[j];
-        const v4i c = i < valid ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v4i{0, 0, 0, 0};
-        *reinterpret_cast<v4i*>(xt + px * D::PIXB + within * 16) = c;
-        __hip_atomic_fetch_add(&sx[px], dot16(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+    for (int j = 0; j < CPT; ++j) {
+      const v4i v = pre[j];
+      const v4i c = px < valid ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v4i{0, 0, 0, 0};
+      *reinterpret_cast<v4i*>(dst + 16 * j) = c;
+      sum = dot16(c, sum);
     }
+    sum = pixel_sum(sum);
+    if (part == 0) sx[px] = sum;
   };
   // request flat slab q (item q / NSI of this workgroup's walk; beyond its last item: that item's slabs again -- harmless, and every
   // wave keeps issuing DMA_PER_WAVE instructions per slab, which is what the vmcnt accounting counts on) into ring buffer `buf`
@@ -196,6 +202,7 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
 
   fetch(walk.item(0));
   write_tile(walk.item(0));
+  __syncthreads();                                   // (the T table is zero before stem.0's first epilogue adds into it)
   WeightRing rg{rbase, 0, D::NBUF - 1, D::NBUF - 1};
 #pragma unroll
   for (int q = 0; q < D::NBUF - 1; ++q) issue(q, q);
@@ -227,6 +234,22 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
       tl[mb] = xt + m * D::PIXB + 16 * h;
     }
     const uint8_t* zl = xt + D::TILE + 16 * h;
+    // window sum R(p) of the centred tile bytes from the per-pixel channel sums: the pixel's own entry and its 8 neighbours at immediate
+    // offsets (an entry outside the map is read -- it lies inside the workgroup's LDS -- and masked out); left where conv_epi_phase_with's
+    // (rsum + rsum of the other k-half) finds it
+    auto window_sums = [&](const int* tab) {
+#pragma unroll
+      for (int mb = 0; mb < D::MB; ++mb) {
+        const int* sp = tab + (mblk * D::MB + mb) * 32 + r;
+        int R = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int v = sp[(tap / 3 - 1) * D::HO + (tap % 3 - 1)];
+          R += (vm[mb] >> tap) & 1 ? v : 0;
+        }
+        A.rsum[mb] = h ? 0 : R;
+      }
+    };
     // ---- stem.0: M over the X tile, then T over it
     ring_mfma_dense<D, PD, 0>(tl, vm, zl, rg, A, nblk, lane, issue, [] {});
     QBNN_STAMP_AT(0);
@@ -234,7 +257,7 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
     QBNN_STAMP_AT(1);
     {
       // stem.0 epilogue: window sums from the X table; the T table collects the channel sums of what is written
-      window_sum_from_table<C>(sx, A, wave, lane);
+      window_sums(sx);
       EpiDenseTile<C::PIXB> epi{xt, bp.a, 0};
       auto flush = [&](int mb) {
         const int v = half_sum(epi.csum);
@@ -279,8 +302,7 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
     QBNN_STAMP_AT(3);
     lds_barrier();
     QBNN_STAMP_AT(4);
-    for (int i = tid; i < D::M; i += NTHR) sx[i] = 0;               // X table: last read in the stem.0 epilogue; refilled by the tile write below
-    window_sum_from_table<C>(stab, A, wave, lane);
+    window_sums(stab);
     conv_epi_phase_with<C, decltype(epi_b)>(bias_lds + C::COUT, bp.b, epi_b, A, wave, lane,
                                             [&](int, int nb, int g4, int, int) { return resq[nb][g4]; },
                                             [&](int mb) {
@@ -302,27 +324,29 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
     // ---- per 16-byte chunk: tile -> quint8 register, next item's input -> the same tile bytes, register -> HBM (the
     //      item's output block is contiguous).  The next input is written unconditionally (the last item rewrites
     //      itself): a prefetch left unconsumed on one path makes the compiler guard later reuses with vmcnt(0).
+    // ---- read-out: tile -> registers (chunk i of the item's contiguous output block per thread: coalesced stores); barrier; next item's input
+    //      over the same bytes (whole pixels per thread, see write_tile); registers -> HBM.  (One loop that reads and rewrites each cell in the
+    //      per-pixel mapping needs no barrier, but its 16-byte stores land 96 / 192 bytes apart and slowed the next item's first conv by 8 %.)
     {
-      const uint32_t z4o = (uint32_t)bp.add.z_o * 0x01010101u, z4i = (uint32_t)a.z_in * 0x01010101u;
+      const uint32_t z4o = (uint32_t)bp.add.z_o * 0x01010101u;
       uint8_t* ys = a.y + (int64_t)s * a.y_ss + (int64_t)img0 * IMG_PX * C::COUT;
       const int valid = valid_px * CPP;
-      const int nimg0 = (next - (next / groups) * groups) * C::G;
-      const int nvalid = (a.B - nimg0 < C::G ? a.B - nimg0 : C::G) * IMG_PX * CPP;
       int t = tid;
       asm volatile("" : "+v"(t));
+      v4i outv[CPT];
 #pragma unroll
-      for (int j = 0; j < PER_T; ++j) {
+      for (int j = 0; j < CPT; ++j) {
+        const int i = t + j * NTHR, px = i / CPP, within = i - px * CPP;
+        outv[j] = *reinterpret_cast<const v4i*>(xt + px * D::PIXB + within * 16);
+      }
+      lds_barrier();
+      write_tile(next);                // unconditional (the last item rewrites its own input): an unconsumed prefetch costs a vmcnt(0) guard
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
         const int i = t + j * NTHR;
-        if (i < NCH) {
-          const int px = i / CPP, within = i - px * CPP;
-          v4i* cell = reinterpret_cast<v4i*>(xt + px * D::PIXB + within * 16);
-          const v4i v = *cell, n = pre[j];
-          const v4i c = i < nvalid ? v4i{(int)sub_bytes(n.x, z4i), (int)sub_bytes(n.y, z4i), (int)sub_bytes(n.z, z4i), (int)sub_bytes(n.w, z4i)} : v4i{0, 0, 0, 0};
-          *cell = c;
-          __hip_atomic_fetch_add(&sx[px], dot16(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (i < valid)
-            *reinterpret_cast<v4i*>(ys + (int64_t)i * 16) = v4i{(int)add_bytes(v.x, z4o), (int)add_bytes(v.y, z4o), (int)add_bytes(v.z, z4o), (int)add_bytes(v.w, z4o)};
-        }
+        const v4i v = outv[j];
+        if (i < valid)
+          *reinterpret_cast<v4i*>(ys + (int64_t)i * 16) = v4i{(int)add_bytes(v.x, z4o), (int)add_bytes(v.y, z4o), (int)add_bytes(v.z, z4o), (int)add_bytes(v.w, z4o)};
       }
     }
     QBNN_STAMP_AT(7);
