@@ -45,17 +45,30 @@ struct CRCfg {
 // the conv's last ring advance -- the place for global loads that should be in flight during the last slab (nothing is requested from the
 // ring after it, so the compiler's own vmcnt waits for those loads are not made stricter by DMA traffic it cannot see).
 template <class D, int PD, int EXTRA, class IssueFn, class TailFn>
-__device__ __forceinline__ void ring_mfma_dense(const uint8_t* const (&tl)[D::MB], const int (&vm)[D::MB], const uint8_t* zl, WeightRing& rg,
-                                                ConvAccMN<D::MB, 3>& A, int nblk, int lane, IssueFn issue, TailFn tail) {
+__device__ __forceinline__ void ring_mfma_dense(const uint8_t* const (&tl)[D::MB], const int (&vm)[D::MB], const uint8_t* zl, const int* tab, int z_w,
+                                                int mblk, WeightRing& rg, ConvAccMN<D::MB, 3>& A, int nblk, int lane, IssueFn issue, TailFn tail) {
   constexpr int SLK = D::SLK, KS = D::KS, MB = D::MB;
+  // The accumulators start at -z_w R(p) (sampled weights have a non-zero zero point: sum x'(W - z_w) = acc - z_w R), R = the window sum of
+  // the centred tile bytes from the per-pixel channel sums in `tab`: the pixel's own entry and its 8 neighbours at immediate offsets (an
+  // entry outside the map is read -- it lies inside the workgroup's LDS -- and masked out).  The table is complete once the conv's first
+  // ring barrier has passed (its writers: the tile write / the previous conv's epilogue), hence init() in the stream below.
+  auto init = [&]() {
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    A.rsum[mb] = 0;
+    for (int mb = 0; mb < MB; ++mb) {
+      const int* sp = tab + (mblk * MB + mb) * 32 + (lane & 31);
+      int R = 0;
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb)
+      for (int tap = 0; tap < 9; ++tap) {
+        const int v = sp[(tap / 3 - 1) * D::HO + (tap % 3 - 1)];
+        R += (vm[mb] >> tap) & 1 ? v : 0;
+      }
+      const int a0 = -z_w * R;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) A.acc[mb][nb][i] = 0;
-  }
+      for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) A.acc[mb][nb][i] = a0;
+    }
+  };
   struct Frag { v4i w[3]; v4i x[MB]; };
   Frag f[PD + 1];
   const uint8_t* wl = nullptr;
@@ -90,6 +103,7 @@ __device__ __forceinline__ void ring_mfma_dense(const uint8_t* const (&tl)[D::MB
     if (p % SLK == 0) {
       if (p / SLK < D::NBUF - 1) advance(std::integral_constant<int, EXTRA>{});
       else advance(std::integral_constant<int, 0>{});
+      if (p == 0) init();
       if (p == LAST) tail();
     }
     load(f[p % (PD + 1)], p);
@@ -234,38 +248,22 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
       tl[mb] = xt + m * D::PIXB + 16 * h;
     }
     const uint8_t* zl = xt + D::TILE + 16 * h;
-    // window sum R(p) of the centred tile bytes from the per-pixel channel sums: the pixel's own entry and its 8 neighbours at immediate
-    // offsets (an entry outside the map is read -- it lies inside the workgroup's LDS -- and masked out); left where conv_epi_phase_with's
-    // (rsum + rsum of the other k-half) finds it
-    auto window_sums = [&](const int* tab) {
-#pragma unroll
-      for (int mb = 0; mb < D::MB; ++mb) {
-        const int* sp = tab + (mblk * D::MB + mb) * 32 + r;
-        int R = 0;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int v = sp[(tap / 3 - 1) * D::HO + (tap % 3 - 1)];
-          R += (vm[mb] >> tap) & 1 ? v : 0;
-        }
-        A.rsum[mb] = h ? 0 : R;
-      }
-    };
     // ---- stem.0: M over the X tile, then T over it
-    ring_mfma_dense<D, PD, 0>(tl, vm, zl, rg, A, nblk, lane, issue, [] {});
+    ring_mfma_dense<D, PD, 0>(tl, vm, zl, sx, bp.a.z_w, mblk, rg, A, nblk, lane, issue, [] {});
     QBNN_STAMP_AT(0);
     lds_barrier();                                       // every wave has read its last X fragment
     QBNN_STAMP_AT(1);
     {
       // stem.0 epilogue: window sums from the X table; the T table collects the channel sums of what is written
-      window_sums(sx);
       EpiDenseTile<C::PIXB> epi{xt, bp.a, 0};
       auto flush = [&](int mb) {
         const int v = half_sum(epi.csum);
         epi.csum = 0;
         if (lane < 32) __hip_atomic_fetch_add(&stab[(mblk * C::MB + mb) * 32 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
-      conv_epi_phase_with<C, decltype(epi)>(bias_lds, bp.a, epi, A, wave, lane, [&](int, int, int, int, int) { return 0u; },
-                                            [&](int mb) { if (mb > 0) flush(mb - 1); });
+      auto no_res = [](int, int, int, int, int) { return 0u; };
+      auto ahead = [&](int mb) { if (mb > 0) flush(mb - 1); };
+      conv_epi_phase_with<C, decltype(epi), decltype(no_res), decltype(ahead), true>(bias_lds, bp.a, epi, A, wave, lane, no_res, ahead);
       flush(C::MB - 1);
     }
     QBNN_STAMP_AT(2);
@@ -298,20 +296,21 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
       }
     };
     load_res(0);
-    ring_mfma_dense<D, PD, 3>(tl, vm, zl, rg, A, nblk, lane, issue, [&] { if (C::MB > 1) load_res(1); });
+    ring_mfma_dense<D, PD, 3>(tl, vm, zl, stab, bp.b.z_w, mblk, rg, A, nblk, lane, issue, [&] { if (C::MB > 1) load_res(1); });
     QBNN_STAMP_AT(3);
     lds_barrier();
     QBNN_STAMP_AT(4);
-    window_sums(stab);
-    conv_epi_phase_with<C, decltype(epi_b)>(bias_lds + C::COUT, bp.b, epi_b, A, wave, lane,
-                                            [&](int, int nb, int g4, int, int) { return resq[nb][g4]; },
-                                            [&](int mb) {
+    {
+      auto res_of = [&](int, int nb, int g4, int, int) { return resq[nb][g4]; };
+      auto ahead = [&](int mb) {
 #ifdef QBNN_STAMP_EB
-                                              QBNN_STAMP_AT(4 + mb);
+        QBNN_STAMP_AT(4 + mb);
 #endif
-                                              trade_res(mb);
-                                              if (mb + 1 == C::MB) fetch(next);      // the next item's input: behind the last residual request (vmcnt retires in order)
-                                            });
+        trade_res(mb);
+        if (mb + 1 == C::MB) fetch(next);      // the next item's input: behind the last residual request (vmcnt retires in order)
+      };
+      conv_epi_phase_with<C, decltype(epi_b), decltype(res_of), decltype(ahead), true>(bias_lds + C::COUT, bp.b, epi_b, A, wave, lane, res_of, ahead);
+    }
 #ifdef QBNN_STAMP_EB
     QBNN_STAMP_AT(6);
     lds_barrier();

@@ -944,21 +944,24 @@ __device__ __forceinline__ void conv_mfma_phase(const uint8_t* tile, const uint8
 
 // resfn(mb, nb, g4, po, c0): the residual dword of that output group (default: the functor's own load)
 //   ahead(mb): called before the arithmetic of M-tile mb -- the place to request the residual of M-tile mb + 1
-template <class C, class Epi, class ResFn, class AheadFn>
+//   PRESUB: the accumulators were initialised with -z_w R (the window sum was known before the K loop: channel-sum tables), so they already
+//   hold sum x' (W - z_w) -- one vector instruction fewer per output
+template <class C, class Epi, class ResFn, class AheadFn, bool PRESUB = false>
 __device__ __forceinline__ void conv_epi_phase_with(const float* bias_lds, const QConv& p, Epi& epi, ConvAcc<C>& A, int pass, int lane,
                                                     ResFn resfn, AheadFn ahead) {
   const int r = lane & 31, h = lane >> 5;
   const int mblk = pass / C::NBLKS, nblk = pass - mblk * C::NBLKS;
 #pragma unroll
   for (int mb = 0; mb < C::MB; ++mb) {
-    int R;
-    if (C::USE_ONES) {
+    int R = 0;
+    if constexpr (PRESUB) {
+    } else if (C::USE_ONES) {
       const int rv = A.acc[mb][C::ONES_TILE % C::NB][C::ONES_REG];
       R = half_lo_bcast(rv);
     } else {
       R = half_sum(A.rsum[mb]);
     }
-    const int zwr = p.z_w * R;
+    const int zwr = PRESUB ? 0 : p.z_w * R;
     const int po = epi.pixel((mblk * C::MB + mb) * 32 + r);
     ahead(mb);
 #pragma unroll

@@ -31,6 +31,10 @@
 // (profiles/r04_stamp_down_ring.txt).
 #include "qbnn_host.h"
 
+#ifndef QBNN_DOWN_PD
+#define QBNN_DOWN_PD 3      // k-steps between a fragment's LDS request and its MFMAs
+#endif
+
 #ifdef QBNN_STAMP      // diagnostic build only (tools/stamp_ring.py): per-phase s_memtime sums; the shipped library has none of this
 QBNN_EXPORT void qbnn_debug_stamp_buffer_ring(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_dev_ptr), &p, sizeof(p)); }
 QBNN_EXPORT void qbnn_debug_read_inner_ring(unsigned long long* host4) {
@@ -89,13 +93,11 @@ using E96 = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
 // weight slab the ring advances IN the stream: wait for the slab, barrier, request slab + NBUF - 1 -- the MFMAs of the previous slab's
 // last steps are still to issue, so the pipeline does not drain at slab boundaries.  This wave accumulates its pixel tile against the
 // channel tiles nblk * 3 .. + 2.  step(ks) -> address of k-step ks's pixel fragment; issue(q, buffer) requests flat slab q.
-template <class D, int KS, class StepFn, class IssueFn>
-__device__ __forceinline__ void ring_mfma(StepFn step, WeightRing& rg, ConvAccMN<1, 3>& A, int nblk, int wave, int lane, IssueFn issue) {
-  constexpr int SLK = D::SLK, PD = 3;
-#pragma unroll
-  for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) A.acc[0][nb][i] = 0;
+// init() -> the accumulators' start value -z_w R (R = this pixel's window sum, from the channel-sum tables: the epilogue then has one vector
+// instruction fewer per output); called once the conv's first ring barrier has passed -- the tables' writers lie before it.
+template <class D, int KS, class StepFn, class IssueFn, class InitFn>
+__device__ __forceinline__ void ring_mfma(StepFn step, WeightRing& rg, ConvAccMN<1, 3>& A, int nblk, int wave, int lane, IssueFn issue, InitFn init) {
+  constexpr int SLK = D::SLK, PD = QBNN_DOWN_PD;
   struct Frag { v4i w[3]; v4i x; };
   Frag f[PD + 1];
   const uint8_t* wl = nullptr;
@@ -121,6 +123,13 @@ __device__ __forceinline__ void ring_mfma(StepFn step, WeightRing& rg, ConvAccMN
 #pragma unroll
   for (int p = 0; p < PD && p < KS; ++p) {
     if (p % SLK == 0) advance();
+    if (p == 0) {
+      const int a0 = init();
+#pragma unroll
+      for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) A.acc[0][nb][i] = a0;
+    }
     load(f[p % (PD + 1)], p);
   }
 #pragma unroll
@@ -133,6 +142,14 @@ __device__ __forceinline__ void ring_mfma(StepFn step, WeightRing& rg, ConvAccMN
     mfma(f[j % (PD + 1)]);
     __builtin_amdgcn_sched_barrier(0);                  // keep the steps apart: the request distance is the point
   }
+}
+
+// epilogue over accumulators that already hold sum x'(W - z_w)
+template <class EC, class Epi>
+__device__ __forceinline__ void epi_presub(const float* bias_lds, const QConv& p, Epi& epi, ConvAcc<EC>& A, int wave, int lane) {
+  auto ld = [&](int, int, int, int po, int c0) { return epi.load(po, c0); };
+  auto none = [](int) {};
+  conv_epi_phase_with<EC, Epi, decltype(ld), decltype(none), true>(bias_lds, p, epi, A, wave, lane, ld, none);
 }
 
 template <class D, class EC, int NM>
@@ -256,48 +273,45 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
     const int m = mblk * 32 + r;
     const int g = m / (D::HO * D::HO), rem = m - g * (D::HO * D::HO), oh = rem / D::HO, ow = rem - oh * D::HO;
     const uint8_t* xlane = xt + g * D::XIMG + (2 * oh) * D::XROW + (2 * ow) * D::CIN + 16 * h;      // tap (0, 0) of this pixel's 3x3 / s2 window
+    // window sums of stem.0 (3x3 / s2: rows 2 oh - 1 .. 2 oh + 1, columns likewise; only the top / left can leave the map) and of the
+    // shortcut (the centre pixel) from S_X.  The centre pixel (2 oh, 2 ow) has an even index: with sb = the dword that holds it, row kh's
+    // three pixels are the high half of sb[.. - 1] and both halves of sb[..] -- two reads at immediate offsets per kernel row; a read in
+    // front of the table is masked out.
+    const int* sb = reinterpret_cast<const int*>(sx16) + (((g * D::HIN + 2 * oh) * D::HIN + 2 * ow) >> 1);
     // ---- stem.0: M over X (3x3 / s2)
     ring_mfma<D, D::KS_A>(
         [&](int ks) {
           const int kh = ks / D::SPR_A, t = ks - kh * D::SPR_A;
           return xlane + kh * D::XROW + t * 32;
         },
-        rg, A, nblk, wave, lane, issue);
+        rg, A, nblk, wave, lane, issue,
+        [&] {
+          int ra = 0;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const int u = sb[(kh - 1) * (D::HIN / 2) - 1], v = sb[(kh - 1) * (D::HIN / 2)];
+            const int row = (ow > 0 ? u >> 16 : 0) + (int)(int16_t)v + (v >> 16);
+            ra += (kh > 0 || oh > 0) ? row : 0;
+          }
+          return -a.a.z_w * ra;
+        });
     QBNN_STAMP_AT(0);
     // ---- shortcut: M over the centre taps of X (1x1 / s2)
     ring_mfma<D, D::KS_S>(
         [&](int ks) { return xlane + D::XROW + D::CIN + ks * 32; },
-        rg, S, nblk, wave, lane, issue);
+        rg, S, nblk, wave, lane, issue, [&] { return -a.s.z_w * (int)(int16_t)sb[0]; });
     QBNN_STAMP_AT(1);
     lds_barrier();                       // every wave has read X for the last time: T and SC may overwrite it
     QBNN_STAMP_AT(2);
     {
-      // window sums of stem.0 (3x3 / s2: rows 2 oh - 1 .. 2 oh + 1, columns likewise; only the top / left can leave the map) and of the
-      // shortcut (the centre pixel) from S_X; a pixel's field: low half for even columns
-      // (the centre pixel (2 oh, 2 ow) has an even index: with sb = the dword that holds it, row kh's three pixels are the high half of
-      //  sb[.. - 1] and both halves of sb[..] -- two reads at immediate offsets per kernel row; a read in front of the table is masked out)
-      const int* sb = reinterpret_cast<const int*>(sx16) + (((g * D::HIN + 2 * oh) * D::HIN + 2 * ow) >> 1);
-      int ra = 0, centre = 0;
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int u = sb[(kh - 1) * (D::HIN / 2) - 1], v = sb[(kh - 1) * (D::HIN / 2)];
-        const int mid = (int)(int16_t)v;
-        const int row = (ow > 0 ? u >> 16 : 0) + mid + (v >> 16);
-        ra += (kh > 0 || oh > 0) ? row : 0;
-        if (kh == 1) centre = mid;
-      }
-      A.rsum[0] = h ? 0 : ra;                                      // conv_epi_phase adds the two k-halves' sums
-      S.rsum[0] = h ? 0 : centre;
-    }
-    {
       EpiDenseTile<D::PIXB_T> epi{tt, a.a, 0};
-      conv_epi_phase<EC, decltype(epi)>(bias_lds + D::COUT, a.a, epi, A, wave, lane);
+      epi_presub<EC>(bias_lds + D::COUT, a.a, epi, A, wave, lane);
       const int v = half_sum(epi.csum);                            // channel sum of this wave's 96 channels of T, per pixel
       if (lane < 32) stt[nblk * D::M + mblk * 32 + lane] = v;
     }
     {
       EpiDense<D::COUT, false, D::SCP> epi{sc, a.s, a.add};
-      conv_epi_phase<EC, decltype(epi)>(bias_lds, a.s, epi, S, wave, lane);
+      epi_presub<EC>(bias_lds, a.s, epi, S, wave, lane);
     }
     for (int i = tid; i < D::PIXB_T / 4; i += NTHR) reinterpret_cast<uint32_t*>(zline)[i] = 0u;      // (X shared these bytes)
     QBNN_STAMP_AT(3);
@@ -316,27 +330,24 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
             const int tap = ks / D::SPT_B, sub = ks - tap * D::SPT_B, kh = tap / 3, kw = tap - 3 * kh;
             return ((vmask >> tap) & 1 ? tlane + ((kh - 1) * D::HO + (kw - 1)) * D::PIXB_T : zl) + sub * 32;
           },
-          rg, A, nblk, wave, lane, issue);
+          rg, A, nblk, wave, lane, issue,
+          [&] {                          // window sum from S_T: reads at immediate offsets from the pixel's own entry; one outside the map is masked out (it lands inside the X region)
+            int rb = 0;
+            const int* sp = stt + m;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+              int sv = sp[(tap / 3 - 1) * D::HO + (tap % 3 - 1)];
+              if constexpr (D::NBLKS == 2) sv += sp[D::M + (tap / 3 - 1) * D::HO + (tap % 3 - 1)];
+              rb += (vmask >> tap) & 1 ? sv : 0;
+            }
+            return -a.b.z_w * rb;
+          });
     }
     QBNN_STAMP_AT(4);
     fetch(next);                         // the next item's input: in flight during this epilogue and the read-out
     {
-      int rb = 0;                        // (reads at immediate offsets from the pixel's own entry; one outside the map is masked out, and lands inside the X region)
-      const int* sp = stt + m;
-#pragma unroll
-      for (int kh = -1; kh <= 1; ++kh)
-#pragma unroll
-        for (int kw = -1; kw <= 1; ++kw) {
-          const bool ok = (unsigned)(oh + kh) < (unsigned)D::HO && (unsigned)(ow + kw) < (unsigned)D::HO;
-          int sv = sp[kh * D::HO + kw];
-          if constexpr (D::NBLKS == 2) sv += sp[D::M + kh * D::HO + kw];
-          rb += ok ? sv : 0;
-        }
-      A.rsum[0] = h ? 0 : rb;
-    }
-    {
       EpiDense<D::COUT, true, D::SCP> epi{sc, a.b, a.add};
-      conv_epi_phase<EC, decltype(epi)>(bias_lds + 2 * D::COUT, a.b, epi, A, wave, lane);
+      epi_presub<EC>(bias_lds + 2 * D::COUT, a.b, epi, A, wave, lane);
     }
     QBNN_STAMP_AT(5);
     lds_barrier();

@@ -175,6 +175,7 @@ template <int NM = 1>
 __global__ __launch_bounds__(256) void head_i8_kernel(const ArgsArr<HeadArgs, NM> all) {
   const HeadArgs& a = all.m[NM == 1 ? 0 : blockIdx.z];
   __shared__ int pooled[4][256];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[4][4096];      // an image's kk x C bytes, fetched with 16-byte loads (see below)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int s = blockIdx.y;
   const int b0 = (blockIdx.x * 4 + wave) * QBNN_HEAD_IMGS;
@@ -191,13 +192,24 @@ __global__ __launch_bounds__(256) void head_i8_kernel(const ArgsArr<HeadArgs, NM
     const int b = b0 + bi;
     if (b >= a.B) break;
     const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)b * a.kk * a.C;
+    // The pooling loop below reads one dword per lane and pixel -- C bytes per load instruction, kk dependent-latency loads in a row.
+    // Where the image is a whole number of 16-byte chunks (ResNet: 16 x 192 = 3 KiB) it is brought into LDS with kk C / 1024 wide loads
+    // per lane first and the loop reads it from there.
+    const int img_bytes = a.kk * a.C;
+    const bool staged = (img_bytes & 15) == 0 && img_bytes <= 4096 && ((reinterpret_cast<uintptr_t>(xs)) & 15) == 0;
+    if (staged) {
+      for (int i = lane; i < img_bytes / 16; i += 64)
+        *reinterpret_cast<v4i*>(&stage[wave][16 * i]) = *reinterpret_cast<const v4i*>(xs + 16 * i);
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same-wave LDS write -> read
+      __builtin_amdgcn_wave_barrier();
+    }
     // AvgPool2d(k) on quint8, channels-last: q = clamp(rne((sum - kk z) / kk) + z, 0, 255); then clamp_activation.
     // Four channels per lane (one dword per pixel) when C is a multiple of 4.
     if ((a.C & 3) == 0) {
       for (int c4 = lane; c4 < a.C / 4; c4 += 64) {
         int sum[4] = {0, 0, 0, 0};
         for (int p = 0; p < a.kk; ++p) {
-          const uint32_t v = *reinterpret_cast<const uint32_t*>(xs + p * a.C + 4 * c4);
+          const uint32_t v = staged ? *reinterpret_cast<const uint32_t*>(&stage[wave][p * a.C + 4 * c4]) : *reinterpret_cast<const uint32_t*>(xs + p * a.C + 4 * c4);
           sum[0] += v & 0xffu; sum[1] += (v >> 8) & 0xffu; sum[2] += (v >> 16) & 0xffu; sum[3] += v >> 24;
         }
         uint32_t pk = 0;
