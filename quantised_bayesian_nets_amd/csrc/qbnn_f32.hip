@@ -40,6 +40,7 @@ struct ConvF32Args {
   // float BernoulliDropout behind the conv (mcdropout/dropout.py:15-40 with FloatFunctional: (v * mask) * multiplier), between
   // BatchNorm and the Add: drop_mask [S][B][Cout] of 0 / 1 (qbnn_dropout_mask_f32_mc), one value per (sample, image, channel)
   const float* drop_mask; float drop_mult;
+  int tail4;                         // Cout % 4 == 0 and every epilogue operand 16-byte aligned: the fp32 epilogue moves float4s
 };
 
 __device__ __forceinline__ float conv_f32_tail(const ConvF32Args& a, float v, int n, int s, int64_t off, const float* drop_row = nullptr) {
@@ -68,7 +69,8 @@ constexpr int CF_KC = 16;
 // of the chunk (fp64: quarter q takes 4 q .. 4 q + 3), so every operand read is a conflict-free ds_read_b128.
 constexpr int CF_LD4 = 20;           // row pitch in floats: 16-byte aligned rows for the float4 stores
 typedef double v4d __attribute__((ext_vector_type(4)));
-template <int PT, int NT, bool ACC64, bool VEC>
+//   VEC = 2: the same with the gather's addressing precomputed per row (KS KS <= 32 taps, a sample's input below 2^31 elements) -- see below.
+template <int PT, int NT, bool ACC64, int VEC>
 __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a) {
   static_assert(PT * NT == 4096 && PT % 64 == 0 && NT % 32 == 0, "4 waves of 32 x 32");
   __shared__ __attribute__((aligned(16))) float As[NT * CF_LD4];     // weights [n][k]
@@ -97,6 +99,24 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
   // tap); advanced by 16 per chunk without divisions
   int gkh, gkw, gc;
   { const int tap = kq / a.Cin; gc = kq - tap * a.Cin; gkh = tap / a.KS; gkw = tap - gkh * a.KS; }
+  // Round 4: the gather's index arithmetic was 40 % of this kernel's vector issue slots (MFMA busy 46 - 53 %, profiles/r04_pmc_util_resnet_f32.json):
+  // per row and chunk a chain of 64-bit multiplies and four compares.  Now a row keeps the address of its window's tap (0, 0) and one validity bit
+  // per tap (KS KS <= 32; larger kernels keep the compares), and a chunk adds ONE per-thread offset (tap row / column / channel) to it.
+  constexpr bool tapmask = VEC == 2;
+  int roff[XP];                  // element offset of the row's window tap (0, 0) in the sample's input (may be negative: padding)
+  uint32_t rmask[XP];
+  if constexpr (tapmask) {
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      roff[j] = (((pb[j] < 0 ? 0 : pb[j]) * a.H + ih0[j]) * a.W + iw0[j]) * a.Cin;
+      uint32_t m = 0;
+      if (pb[j] >= 0)
+        for (int kh = 0; kh < a.KS; ++kh)
+          for (int kw = 0; kw < a.KS; ++kw)
+            if ((unsigned)(ih0[j] + kh) < (unsigned)a.H && (unsigned)(iw0[j] + kw) < (unsigned)a.W) m |= 1u << (kh * a.KS + kw);
+      rmask[j] = m;
+    }
+  }
   auto gather = [&](int k0, v4f (&xv)[XP], v4f& wv) {
     if constexpr (!VEC) {
       // any Cin, either weight order: the same four k of the chunk, element by element (index arithmetic per element)
@@ -118,11 +138,18 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
       return;
     }
     const bool kok = k0 + kq < K;
+    if constexpr (tapmask) {
+      const int tap = gkh * a.KS + gkw, toff = (gkh * a.W + gkw) * a.Cin + gc;
 #pragma unroll
-    for (int j = 0; j < XP; ++j) {
-      const int ih = ih0[j] + gkh, iw = iw0[j] + gkw;
-      const bool ok = kok && pb[j] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-      xv[j] = ok ? *reinterpret_cast<const v4f*>(xs + (((int64_t)pb[j] * a.H + ih) * a.W + iw) * a.Cin + gc) : zero4;
+      for (int j = 0; j < XP; ++j)
+        xv[j] = (kok && ((rmask[j] >> tap) & 1u)) ? *reinterpret_cast<const v4f*>(xs + (roff[j] + toff)) : zero4;
+    } else {
+#pragma unroll
+      for (int j = 0; j < XP; ++j) {
+        const int ih = ih0[j] + gkh, iw = iw0[j] + gkw;
+        const bool ok = kok && pb[j] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        xv[j] = ok ? *reinterpret_cast<const v4f*>(xs + (((int64_t)pb[j] * a.H + ih) * a.W + iw) * a.Cin + gc) : zero4;
+      }
     }
     wv = (kok && wrow_ok) ? *reinterpret_cast<const v4f*>(wrow + k0) : zero4;
     gc += CF_KC;
@@ -180,6 +207,28 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
     if (po < npix) {
       float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
       const float* dr = a.drop_mask ? a.drop_mask + ((int64_t)s * a.B + po / (a.Ho * a.Wo)) * a.Cout : nullptr;
+      if (a.tail4) {
+        // the lane's four registers of a group are four CONSECUTIVE channels of its pixel: one 16-byte store (and 16-byte loads of the
+        // per-channel parameters and the residual) instead of four 4-byte ones 4 Cout bytes apart from the neighbouring lane's -- with
+        // K = 216 (24 channels) the scalar form's 16 scattered stores per lane were a third of the launch
+        const float* rp = a.res ? a.res + (int64_t)s * a.res_ss + (int64_t)po * a.Cout : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int no = n0 + wn * 32 + 8 * g + 4 * (lane >> 5);
+          if (no < a.Cout) {            // Cout % 4 == 0: all four channels exist
+            v4f v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            if (a.div) { const v4f d = *reinterpret_cast<const v4f*>(a.div + no); for (int i = 0; i < 4; ++i) v[i] = v[i] / d[i]; }
+            if (a.bias) { const v4f d = *reinterpret_cast<const v4f*>(a.bias + no); for (int i = 0; i < 4; ++i) v[i] = v[i] + d[i]; }
+            if (a.alpha) { const v4f d = *reinterpret_cast<const v4f*>(a.alpha + no); for (int i = 0; i < 4; ++i) v[i] = v[i] * d[i]; }
+            if (a.beta) { const v4f d = *reinterpret_cast<const v4f*>(a.beta + no); for (int i = 0; i < 4; ++i) v[i] = v[i] + d[i]; }
+            if (dr) { const v4f d = *reinterpret_cast<const v4f*>(dr + no); for (int i = 0; i < 4; ++i) { v[i] = v[i] * d[i]; v[i] = v[i] * a.drop_mult; } }
+            if (rp) { const v4f d = *reinterpret_cast<const v4f*>(rp + no); for (int i = 0; i < 4; ++i) v[i] = v[i] + d[i]; }
+            if (a.relu) for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            *reinterpret_cast<v4f*>(yp + no) = v;
+            for (int i = 0; i < 4; ++i) { vmin = fminf(vmin, v[i]); vmax = fmaxf(vmax, v[i]); }
+          }
+        }
+      } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -190,6 +239,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
             yp[no] = v; vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
           }
         }
+      }
     }
   } else {
 #pragma unroll
@@ -264,6 +314,10 @@ static int conv2d_f32_launch(const float* x, int64_t x_ss, const float* w, int64
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_f32_mc: bad argument");
   ConvF32Args a;
   a.drop_mask = drop_mask; a.drop_mult = drop_mult;
+  {
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    a.tail4 = (Cout % 4) == 0 && al16(y) && (y_ss % 4) == 0 && al16(div) && al16(bias) && al16(alpha) && al16(beta) && al16(drop_mask) && al16(res) && (res_ss % 4) == 0;
+  }
   a.div = div; a.alpha = alpha; a.beta = beta; a.res = res; a.res_ss = res_ss; a.mm_partials = minmax_partials;
   a.x = x; a.x_ss = x_ss; a.w = w; a.w_ss = w_ss; a.bias = bias; a.y = y; a.y_ss = y_ss;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = ksize; a.stride = stride; a.pad = pad; a.relu = relu & 1; a.w_ohwi = (relu >> 2) & 1;
@@ -273,6 +327,8 @@ static int conv2d_f32_launch(const float* x, int64_t x_ss, const float* w, int64
   dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)n_samples);
   const bool vec = a.w_ohwi && (Cin % 4) == 0 && (x_ss % 4) == 0 && (w_ss % 4) == 0 &&
                    (reinterpret_cast<uintptr_t>(x) % 16) == 0 && (reinterpret_cast<uintptr_t>(w) % 16) == 0;
+  static const bool no_tapmask = [] { const char* e = getenv("QBNN_F32_TAPMASK"); return e && e[0] == '0'; }();
+  const bool tapmask = !no_tapmask && vec && ksize * ksize <= 32 && (int64_t)B * H * W * Cin < (int64_t(1) << 30);
   const bool acc64 = (relu & 2) != 0;
   hipStream_t st = (hipStream_t)stream;
   // 128 pixels x 32 channels per workgroup where 32-wide channel tiles pad less than 64-wide ones (Cout = 24, 96, ...)
@@ -283,10 +339,12 @@ static int conv2d_f32_launch(const float* x, int64_t x_ss, const float* w, int64
     if (narrow) hipLaunchKernelGGL((conv2d_f32_vec_kernel<128, 32, A64, V>), g2, dim3(256), 0, st, a);                       \
     else hipLaunchKernelGGL((conv2d_f32_vec_kernel<64, 64, A64, V>), grid, dim3(256), 0, st, a);                             \
   } while (0)
-  if (acc64 && vec) QBNN_F32_LAUNCH(true, true);
-  else if (acc64) QBNN_F32_LAUNCH(true, false);
-  else if (vec) QBNN_F32_LAUNCH(false, true);
-  else QBNN_F32_LAUNCH(false, false);
+  if (acc64 && tapmask) QBNN_F32_LAUNCH(true, 2);
+  else if (acc64 && vec) QBNN_F32_LAUNCH(true, 1);
+  else if (acc64) QBNN_F32_LAUNCH(true, 0);
+  else if (tapmask) QBNN_F32_LAUNCH(false, 2);
+  else if (vec) QBNN_F32_LAUNCH(false, 1);
+  else QBNN_F32_LAUNCH(false, 0);
 #undef QBNN_F32_LAUNCH
   return qbnn_check_launch_msg("qbnn_conv2d_f32_mc");
 }
