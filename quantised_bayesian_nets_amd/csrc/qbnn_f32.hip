@@ -242,6 +242,16 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
       }
     }
   } else {
+    // a lane's 16 outputs are 8 pixels of TWO channels: the per-channel parameters are loaded once (inside conv_f32_tail they were re-read for
+    // every output -- the stores in between may alias them as far as the compiler knows)
+    float pdiv[2], pbias[2], palpha[2], pbeta[2];
+    int nn[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      nn[j] = n0 + wn * 32 + j * 16 + l15;
+      const int nc = nn[j] < a.Cout ? nn[j] : 0;
+      pdiv[j] = a.div ? a.div[nc] : 1.f; pbias[j] = a.bias ? a.bias[nc] : 0.f; palpha[j] = a.alpha ? a.alpha[nc] : 1.f; pbeta[j] = a.beta ? a.beta[nc] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -250,11 +260,19 @@ __global__ __launch_bounds__(256) void conv2d_f32_vec_kernel(const ConvF32Args a
         if (po >= npix) continue;
         float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
         const float* dr = a.drop_mask ? a.drop_mask + ((int64_t)s * a.B + po / (a.Ho * a.Wo)) * a.Cout : nullptr;
+        const float* rp = a.res ? a.res + (int64_t)s * a.res_ss + (int64_t)po * a.Cout : nullptr;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int no = n0 + wn * 32 + j * 16 + l15;
+          const int no = nn[j];
           if (no < a.Cout) {
-            const float v = conv_f32_tail(a, (float)acc64[i][j][r], no, s, (int64_t)po * a.Cout + no, dr);
+            float v = (float)acc64[i][j][r];            // the same steps, each rounded to fp32, as conv_f32_tail
+            if (a.div) v = v / pdiv[j];
+            if (a.bias) v = v + pbias[j];
+            if (a.alpha) v = v * palpha[j];
+            if (a.beta) v = v + pbeta[j];
+            if (dr) { v = v * dr[no]; v = v * a.drop_mult; }
+            if (rp) v = v + rp[no];
+            if (a.relu) v = fmaxf(v, 0.f);
             yp[no] = v; vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
           }
         }
@@ -538,34 +556,40 @@ __global__ __launch_bounds__(256) void minmax_f32_kernel(const float* __restrict
 // state[0..1] = (min, max), state[2] = 0 until the observer has seen data (all fp32, read and written back).
 __global__ __launch_bounds__(256) void observer_scan_kernel(const float* __restrict__ partials, int nblk, int n_samples, float* __restrict__ state,
                                                              float avg_const, int qmin, int qmax, float* __restrict__ scale, int* __restrict__ zp) {
-  __shared__ float smin[4], smax[4];
-  float mn_state = state[0], mx_state = state[1];
-  bool init = state[2] != 0.f;
-  for (int s = 0; s < n_samples; ++s) {
-    float mn = INFINITY, mx = -INFINITY;
-    for (int i = threadIdx.x; i < nblk; i += 256) {
-      mn = fminf(mn, partials[((int64_t)s * nblk + i) * 2]);
-      mx = fmaxf(mx, partials[((int64_t)s * nblk + i) * 2 + 1]);
-    }
+  // Round 4: every sample's (min, max) over its partials first, all samples in flight at once (wave w takes samples w, w + 4, ...; min / max are
+  // exact in any order), then the S-step recurrence on one thread -- instead of S serial rounds of load -> reduce -> two barriers (10.8 us per
+  // observer, 114 observers per QAT forward).
+  __shared__ float smin[256], smax[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int s0 = 0; s0 < n_samples; s0 += 256) {             // (more than 256 samples: in rounds)
+    const int ns = n_samples - s0 < 256 ? n_samples - s0 : 256;
+    for (int s = wave; s < ns; s += 4) {
+      float mn = INFINITY, mx = -INFINITY;
+      const float* ps = partials + (int64_t)(s0 + s) * nblk * 2;
+      for (int i = lane; i < nblk; i += 64) { mn = fminf(mn, ps[2 * i]); mx = fmaxf(mx, ps[2 * i + 1]); }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+      for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+      if (lane == 0) { smin[s] = mn; smax[s] = mx; }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-      mn = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
-      mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
-      if (!init) { mn_state = mn; mx_state = mx; init = true; }
-      else { mn_state = mn_state + avg_const * (mn - mn_state); mx_state = mx_state + avg_const * (mx - mx_state); }
-      const float lo = fminf(mn_state, 0.f), hi = fmaxf(mx_state, 0.f);
-      float sc = (hi - lo) / (float)(qmax - qmin);
-      sc = fmaxf(sc, 1.1920928955078125e-07f);
-      float z = (float)qmin - rintf(lo / sc);
-      z = fminf(fmaxf(z, (float)qmin), (float)qmax);
-      scale[s] = sc; zp[s] = (int)z;
+      float mn_state = state[0], mx_state = state[1];
+      bool init = state[2] != 0.f;
+      for (int s = 0; s < ns; ++s) {
+        const float mn = smin[s], mx = smax[s];
+        if (!init) { mn_state = mn; mx_state = mx; init = true; }
+        else { mn_state = mn_state + avg_const * (mn - mn_state); mx_state = mx_state + avg_const * (mx - mx_state); }
+        const float lo = fminf(mn_state, 0.f), hi = fmaxf(mx_state, 0.f);
+        float sc = (hi - lo) / (float)(qmax - qmin);
+        sc = fmaxf(sc, 1.1920928955078125e-07f);
+        float z = (float)qmin - rintf(lo / sc);
+        z = fminf(fmaxf(z, (float)qmin), (float)qmax);
+        scale[s0 + s] = sc; zp[s0 + s] = (int)z;
+      }
+      state[0] = mn_state; state[1] = mx_state; state[2] = 1.f;
     }
+    __syncthreads();
   }
-  if (threadIdx.x == 0) { state[0] = mn_state; state[1] = mx_state; state[2] = 1.f; }
 }
 
 // The observer recurrence alone, on per-workgroup (min, max) partials a producer already wrote (qbnn_conv2d_f32_fused_mc's
