@@ -388,11 +388,40 @@ __global__ __launch_bounds__(256) void affine_f32_kernel(const float* __restrict
   }
 }
 
+// the same on float4s (n, C, strides multiples of 4, 16-byte aligned operands, n < 2^31): a quarter of the memory instructions and a 32-bit
+// channel index instead of a 64-bit modulo per element
+static inline bool f32_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__global__ __launch_bounds__(256) void affine_f32_v4_kernel(const float* __restrict__ x, int64_t x_ss, const float* __restrict__ res,
+                                                             int64_t res_ss, const float* __restrict__ p0, const float* __restrict__ p1,
+                                                             float* __restrict__ y, int64_t y_ss, uint32_t n4, uint32_t C, int mode, int relu) {
+  const int s = blockIdx.y;
+  const v4f* xs = reinterpret_cast<const v4f*>(x + (int64_t)s * x_ss);
+  const v4f* rs = res ? reinterpret_cast<const v4f*>(res + (int64_t)s * res_ss) : nullptr;
+  v4f* ys = reinterpret_cast<v4f*>(y + (int64_t)s * y_ss);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+    const uint32_t c = (i * 4u) % C;
+    v4f v = xs[i];
+    if (p0) { const v4f d = *reinterpret_cast<const v4f*>(p0 + c); for (int k = 0; k < 4; ++k) v[k] = mode == 0 ? v[k] * d[k] : v[k] / d[k]; }
+    if (p1) { const v4f d = *reinterpret_cast<const v4f*>(p1 + c); for (int k = 0; k < 4; ++k) v[k] = v[k] + d[k]; }
+    if (rs) { const v4f d = rs[i]; for (int k = 0; k < 4; ++k) v[k] = v[k] + d[k]; }
+    if (relu) for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+    ys[i] = v;
+  }
+}
+
 QBNN_EXPORT int qbnn_affine_f32_mc(const float* x, int64_t x_ss, const float* res, int64_t res_ss, const float* p0, const float* p1,
                                    float* y, int64_t y_ss, int64_t n, int32_t C, int32_t mode, int32_t relu, int32_t n_samples,
                                    void* stream) {
   if (!x || !y || n <= 0 || C <= 0 || n_samples <= 0 || mode < 0 || mode > 1)
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_affine_f32_mc: bad argument");
+  if ((n & 3) == 0 && (C & 3) == 0 && n < (int64_t(1) << 31) && ((x_ss | y_ss | res_ss) & 3) == 0 && f32_al16(x) && f32_al16(y) && f32_al16(res) &&
+      f32_al16(p0) && f32_al16(p1)) {
+    const int64_t n4 = n / 4;
+    const int blocks4 = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(affine_f32_v4_kernel, dim3(blocks4, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, res, res_ss, p0, p1, y, y_ss,
+                       (uint32_t)n4, (uint32_t)C, mode, relu);
+    return qbnn_check_launch_msg("qbnn_affine_f32_mc");
+  }
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(affine_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, res, res_ss, p0, p1, y,
                      y_ss, n, C, mode, relu);
@@ -533,9 +562,18 @@ __global__ __launch_bounds__(256) void minmax_f32_kernel(const float* __restrict
   __shared__ float smin[4], smax[4];
   const int s = blockIdx.y;
   float mn = INFINITY, mx = -INFINITY;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float v = x[(int64_t)s * x_ss + i];
-    mn = fminf(mn, v); mx = fmaxf(mx, v);
+  const float* xs = x + (int64_t)s * x_ss;
+  if ((n & 3) == 0 && (x_ss & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {      // float4s: a quarter of the load instructions
+    const v4f* x4 = reinterpret_cast<const v4f*>(xs);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256) {
+      const v4f v = x4[i];
+      mn = fminf(fminf(mn, v[0]), fminf(v[1], fminf(v[2], v[3]))); mx = fmaxf(fmaxf(mx, v[0]), fmaxf(v[1], fmaxf(v[2], v[3])));
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const float v = xs[i];
+      mn = fminf(mn, v); mx = fmaxf(mx, v);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
@@ -621,6 +659,17 @@ __global__ __launch_bounds__(256) void fake_quant_f32_kernel(const float* __rest
   const int s = blockIdx.y;
   const float sc = scale[s * qp_stride], inv = 1.0f / sc;
   const float z = (float)zp[s * qp_stride], lo = (float)qmin, hi = (float)qmax;
+  if ((n & 3) == 0 && ((x_ss | y_ss) & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {      // float4s
+    const v4f* x4 = reinterpret_cast<const v4f*>(x + (int64_t)s * x_ss);
+    v4f* y4 = reinterpret_cast<v4f*>(y + (int64_t)s * y_ss);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256) {
+      v4f v = x4[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (fminf(fmaxf(rintf(v[k] * inv) + z, lo), hi) - z) * sc;
+      y4[i] = v;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float q = fminf(fmaxf(rintf(x[(int64_t)s * x_ss + i] * inv) + z, lo), hi);
     y[(int64_t)s * y_ss + i] = (q - z) * sc;
