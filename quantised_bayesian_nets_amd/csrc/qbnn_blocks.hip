@@ -568,43 +568,7 @@ __device__ __forceinline__ void conv_ring_mfma_dense(const uint8_t* tile, uint8_
 
 // (EpiDenseTile, window_sum_from_table and EpiDenseTileResGlobal live in qbnn_conv.h: qbnn_chain_ring.hip uses them too)
 
-// the same two epilogues with a quantised channel dropout behind the conv (conv_resnet_mc)
-template <int PIXB, int COUT, int IMG_PX>
-struct EpiDenseTileDrop {
-  uint8_t* dst; QConv p; PostArgs q; MaskTab<COUT, false> mt;
-  mutable int csum;
-  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
-  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
-  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
-    const float4 m4 = mt.get(po / (IMG_PX * PIXB), c0);
-    const uint32_t pk = pack_low_bytes(drop_val(v0, p, q, m4.x) + QBNN_MAGIC, drop_val(v1, p, q, m4.y) + QBNN_MAGIC,
-                                       drop_val(v2, p, q, m4.z) + QBNN_MAGIC, drop_val(v3, p, q, m4.w) + QBNN_MAGIC);
-    *reinterpret_cast<uint32_t*>(dst + po + c0) = pk;
-    csum = __builtin_amdgcn_sdot4((int)pk, 0x01010101, csum, false);
-  }
-};
-template <int PIXB, int CCH, int IMG_PX>
-struct EpiDenseTileResGlobalDrop {
-  uint8_t* xt; const uint8_t* res; int n_valid_px; QConv p; QAdd a; PostArgs q; MaskTab<CCH, false> mt;
-  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
-  __device__ __forceinline__ uint32_t load_px(int m, int c0) const {
-    return m < n_valid_px ? *reinterpret_cast<const uint32_t*>(res + (int64_t)m * CCH + c0) : 0u;
-  }
-  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
-  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
-    const float4 m4 = mt.get(po / (IMG_PX * PIXB), c0);
-    const float r[4] = {drop_val(v0, p, q, m4.x), drop_val(v1, p, q, m4.y), drop_val(v2, p, q, m4.z), drop_val(v3, p, q, m4.w)};
-    const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
-    float t[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float da = __builtin_fmaf(q.s_a, __builtin_rintf(r[i]), q.dl_a);
-      const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
-      t[i] = (da + db) * a.inv_s_o;
-    }
-    *reinterpret_cast<uint32_t*>(xt + po + c0) = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
-  }
-};
+// (EpiDenseTileDrop / EpiDenseTileResGlobalDrop: qbnn_conv.h)
 
 // NWV = 8: two waves per SIMD, 256 VGPRs each (MB x NB = 2 x 3 tiles per wave).  Measured alternatives, all slower:
 // NWV = 4 (one wave per SIMD, 4 x 3 tiles in the 512-register file: -25 %, the epilogues read accumulators out of AGPRs
@@ -1417,8 +1381,8 @@ static int chain_drop_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_
       else return fail(QBNN_E_INVALID, "qbnn_block_chain_drop_i8_mc: one 48-channel block per launch%s");
     }
     if constexpr (NBLK == 1) {
-      if (Cc == 96 && H == 8) return launch_block_chain_ald_drop<ALD_96, 8>(a, dr, st);
-      if (Cc == 192 && H == 4) return launch_block_chain_ald_drop<ALD_192, 8>(a, dr, st);
+      if (Cc == 96 && H == 8) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring_drop(a, dr, 96, st) : launch_block_chain_ald_drop<ALD_96, 8>(a, dr, st);
+      if (Cc == 192 && H == 4) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring_drop(a, dr, 192, st) : launch_block_chain_ald_drop<ALD_192, 8>(a, dr, st);
     }
     return fail(QBNN_E_INVALID, "qbnn_block_chain_drop_i8_mc: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
   }

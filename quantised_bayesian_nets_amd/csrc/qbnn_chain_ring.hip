@@ -118,10 +118,15 @@ __device__ __forceinline__ void ring_mfma_dense(const uint8_t* const (&tl)[D::MB
   }
 }
 
-template <class C, int PD, int NM>
+// DROP (conv_resnet_mc, mcdropout/models_mc.py:116-160): a quantised channel dropout behind each conv -- dr.d[0] behind stem.0 (stem.3 of the
+// reference's Sequential), dr.d[1] behind stem.3 (the Add's first operand); one bit per (image, channel) in LDS (a Bernoulli mask has two quantised
+// values), applied by the epilogues to the centred integer they hold.
+template <class C, int PD, int NM, bool DROP = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
+void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<DROP ? 2 : 0> dr) {
   using D = CRCfg<C>;
+  static_assert(!DROP || NM == 1, "dropout variants are single-call");
+  constexpr int MTB = MaskTab<C::COUT, true>::bytes(C::G);
   const ChainArgs<1>& a = all.m[NM == 1 ? 0 : blockIdx.y];
   constexpr int NTHR = 512;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -130,6 +135,7 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
   float* bias_lds = reinterpret_cast<float*>(rbase + D::NBUF * D::SLABB);    // [2][COUT]
   int* sx = reinterpret_cast<int*>(bias_lds + 2 * C::COUT);                  // channel sums of the X tile  [M]
   int* stab = sx + D::M;                                                     // ... of the T tile
+  uint8_t* mtab = reinterpret_cast<uint8_t*>(stab + D::M) + 64;              // DROP: bit tables of the two dropouts (behind the tables' slack)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mblk = wave / D::NBLKS, nblk = wave - mblk * D::NBLKS;
   const BlockParams& bp = a.blk[0];
@@ -248,6 +254,10 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
       tl[mb] = xt + m * D::PIXB + 16 * h;
     }
     const uint8_t* zl = xt + D::TILE + 16 * h;
+    if constexpr (DROP) {        // this item's masks: published by stem.0's ring barriers, first read in its epilogue (the previous item's last reader lies before two barriers)
+      fill_mask_tab<C::G, C::COUT, true, NTHR>(mtab, dr.d[0], s, img0, a.B, tid);
+      fill_mask_tab<C::G, C::COUT, true, NTHR>(mtab + MTB, dr.d[1], s, img0, a.B, tid);
+    }
     // ---- stem.0: M over the X tile, then T over it
     ring_mfma_dense<D, PD, 0>(tl, vm, zl, sx, bp.a.z_w, mblk, rg, A, nblk, lane, issue, [] {});
     QBNN_STAMP_AT(0);
@@ -255,7 +265,11 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
     QBNN_STAMP_AT(1);
     {
       // stem.0 epilogue: window sums from the X table; the T table collects the channel sums of what is written
-      EpiDenseTile<C::PIXB> epi{xt, bp.a, 0};
+      auto make_epi_a = [&]() {
+        if constexpr (DROP) return EpiDenseTileDrop<C::PIXB, C::COUT, IMG_PX, true>{xt, bp.a, dr.d[0], {mtab, dr.d[0].mq1}, 0};
+        else return EpiDenseTile<C::PIXB>{xt, bp.a, 0};
+      };
+      auto epi = make_epi_a();
       auto flush = [&](int mb) {
         const int v = half_sum(epi.csum);
         epi.csum = 0;
@@ -276,7 +290,11 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
     // two halves trade dwords with v_permlane32_swap when the epilogue starts.
     const int valid_px = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX;
     const uint8_t* resp = a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_PX * C::COUT;
-    EpiDenseTileResGlobal<C::PIXB, C::COUT> epi_b{xt, resp, valid_px, bp.b, bp.add};
+    auto make_epi_b = [&]() {
+      if constexpr (DROP) return EpiDenseTileResGlobalDrop<C::PIXB, C::COUT, IMG_PX, true>{xt, resp, valid_px, bp.b, bp.add, dr.d[1], {mtab + MTB, dr.d[1].mq1}};
+      else return EpiDenseTileResGlobal<C::PIXB, C::COUT>{xt, resp, valid_px, bp.b, bp.add};
+    };
+    auto epi_b = make_epi_b();
     v4i rraw[2][3];
     auto load_res = [&](int mb) {
       const int m = (mblk * C::MB + mb) * 32 + r;
@@ -371,7 +389,7 @@ int launch_by_value(const ChainArgs<1>* arr, int n, hipStream_t st) {
     if (int rc = ensure_dyn_lds((const void*)block_chain_ring_kernel<C, QBNN_CHAIN_PD, 1>, attr1, D::LDS)) return rc;
     ArgsArr<ChainArgs<1>, 1> one;
     one.m[0] = arr[0];
-    hipLaunchKernelGGL((block_chain_ring_kernel<C, QBNN_CHAIN_PD, 1>), dim3(items < 256 ? (items > 0 ? items : 1) : 256), dim3(512), D::LDS, st, one);
+    hipLaunchKernelGGL((block_chain_ring_kernel<C, QBNN_CHAIN_PD, 1>), dim3(items < 256 ? (items > 0 ? items : 1) : 256), dim3(512), D::LDS, st, one, DropSet<0>{});
     return check_launch("qbnn_block_chain_i8_mc");
   }
   static_assert(sizeof(ArgsArr<ChainArgs<1>, QBNN_FUSED_CALLS>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
@@ -380,7 +398,7 @@ int launch_by_value(const ChainArgs<1>* arr, int n, hipStream_t st) {
   memset(&all, 0, sizeof(all));
   for (int i = 0; i < n; ++i) all.m[i] = arr[i];
   const int per = 256 / n > 0 ? 256 / n : 1;
-  hipLaunchKernelGGL((block_chain_ring_kernel<C, QBNN_CHAIN_PD, QBNN_FUSED_CALLS>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, all);
+  hipLaunchKernelGGL((block_chain_ring_kernel<C, QBNN_CHAIN_PD, QBNN_FUSED_CALLS>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, all, DropSet<0>{});
   return check_launch("qbnn_block_chain_i8_multi");
 }
 
@@ -390,8 +408,22 @@ int launch_dev(const ChainArgs<1>* dev, int n, int items, hipStream_t st) {
   static std::atomic<uint64_t> attr{0};
   if (int rc = ensure_dyn_lds((const void*)block_chain_ring_kernel<C, QBNN_CHAIN_PD, 0>, attr, D::LDS)) return rc;
   const int per = 256 / n > 0 ? 256 / n : 1;
-  hipLaunchKernelGGL((block_chain_ring_kernel<C, QBNN_CHAIN_PD, 0>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, ArgsArr<ChainArgs<1>, 0>{dev});
+  hipLaunchKernelGGL((block_chain_ring_kernel<C, QBNN_CHAIN_PD, 0>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, ArgsArr<ChainArgs<1>, 0>{dev}, DropSet<0>{});
   return check_launch("qbnn_block_chain_i8_multi_launch");
+}
+
+template <class C>
+int launch_drop(const ChainArgs<1>& a, const DropSet<2>& dr, hipStream_t st) {
+  using D = CRCfg<C>;
+  constexpr int LDS = D::LDS + 2 * MaskTab<C::COUT, true>::bytes(C::G);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc = ensure_dyn_lds((const void*)block_chain_ring_kernel<C, QBNN_CHAIN_PD, 1, true>, attr, LDS)) return rc;
+  const int items = a.n_samples * ((a.B + C::G - 1) / C::G);
+  ArgsArr<ChainArgs<1>, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_chain_ring_kernel<C, QBNN_CHAIN_PD, 1, true>), dim3(items < 256 ? (items > 0 ? items : 1) : 256), dim3(512), LDS, st, one, dr);
+  return check_launch("qbnn_block_chain_drop_i8_mc");
 }
 
 using CR_96  = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;        // 8 images per item: 16 pixel tiles x 3 channel tiles
@@ -412,4 +444,10 @@ int qbnn_launch_block_chain_ring_dev(const ChainArgs<1>* dev, int n, int items, 
   if (Cc == 96) return launch_dev<CR_96>(dev, n, items, st);
   if (Cc == 192) return small_items ? launch_dev<CR_192_G8>(dev, n, items, st) : launch_dev<CR_192>(dev, n, items, st);
   return fail(QBNN_E_INVALID, "qbnn_block_chain (ring): 96 and 192 channels only%s");
+}
+
+int qbnn_launch_block_chain_ring_drop(const ChainArgs<1>& a, const DropSet<2>& dr, int Cc, hipStream_t st) {
+  if (Cc == 96) return launch_drop<CR_96>(a, dr, st);
+  if (Cc == 192) return launch_drop<CR_192>(a, dr, st);
+  return fail(QBNN_E_INVALID, "qbnn_block_chain_drop (ring): 96 and 192 channels only%s");
 }

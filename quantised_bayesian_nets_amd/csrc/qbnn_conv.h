@@ -1220,6 +1220,44 @@ struct EpiDenseTileResGlobal {
   }
 };
 
+// the same two epilogues with a quantised channel dropout behind the conv (conv_resnet_mc)
+template <int PIXB, int COUT, int IMG_PX, bool BITS = false>
+struct EpiDenseTileDrop {
+  uint8_t* dst; QConv p; PostArgs q; MaskTab<COUT, BITS> mt;
+  mutable int csum;
+  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
+    const float4 m4 = mt.get(po / (IMG_PX * PIXB), c0);
+    const uint32_t pk = pack_low_bytes(drop_val(v0, p, q, m4.x) + QBNN_MAGIC, drop_val(v1, p, q, m4.y) + QBNN_MAGIC,
+                                       drop_val(v2, p, q, m4.z) + QBNN_MAGIC, drop_val(v3, p, q, m4.w) + QBNN_MAGIC);
+    *reinterpret_cast<uint32_t*>(dst + po + c0) = pk;
+    csum = __builtin_amdgcn_sdot4((int)pk, 0x01010101, csum, false);
+  }
+};
+template <int PIXB, int CCH, int IMG_PX, bool BITS = false>
+struct EpiDenseTileResGlobalDrop {
+  uint8_t* xt; const uint8_t* res; int n_valid_px; QConv p; QAdd a; PostArgs q; MaskTab<CCH, BITS> mt;
+  __device__ __forceinline__ int pixel(int m) const { return m * PIXB; }
+  __device__ __forceinline__ uint32_t load_px(int m, int c0) const {
+    return m < n_valid_px ? *reinterpret_cast<const uint32_t*>(res + (int64_t)m * CCH + c0) : 0u;
+  }
+  __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
+  __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rq) const {
+    const float4 m4 = mt.get(po / (IMG_PX * PIXB), c0);
+    const float r[4] = {drop_val(v0, p, q, m4.x), drop_val(v1, p, q, m4.y), drop_val(v2, p, q, m4.z), drop_val(v3, p, q, m4.w)};
+    const float rf[4] = {(float)(rq & 0xffu), (float)((rq >> 8) & 0xffu), (float)((rq >> 16) & 0xffu), (float)(rq >> 24)};
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float da = __builtin_fmaf(q.s_a, __builtin_rintf(r[i]), q.dl_a);
+      const float db = __builtin_fmaf(a.s_r, rf[i], a.nzs_r);
+      t[i] = (da + db) * a.inv_s_o;
+    }
+    *reinterpret_cast<uint32_t*>(xt + po + c0) = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi);
+  }
+};
+
 // Interleaved, XCD-aware walk for the kernels that stream their weights per item (no weights-stationary LDS copy).
 // Workgroup b runs on XCD b % 8 (round-robin dispatch, one workgroup per CU), and every XCD has its own 4 MiB L2.  XCD x
 // takes the x-th eighth of the sample-major item list, and its 32 workgroups walk that range interleaved: at any time
