@@ -1003,6 +1003,49 @@ def test_environment_switches_give_the_same_results(switch, tmp_path):
     assert r.returncode == 0 and "SWITCH-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+_F32_SWITCH_WORKER = r"""
+import os, sys, types, numpy as np, torch
+root, out = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from conftest import load_golden
+import quantised_bayesian_nets_amd as q
+res = {}
+g = load_golden("resnet_bbb_f32.npz")
+m = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, False, types.SimpleNamespace(sigma_prior=-2.0)).load_reference_state(g["state"])
+x = torch.randn(70, 3, 32, 32, generator=torch.Generator().manual_seed(9)).cuda()
+with q.mc_context(3, 11, 2):
+    res["f32"] = m.forward_mc(x).cpu().numpy()
+gq = load_golden("resnet_bbb_qat.npz")
+qa = types.SimpleNamespace(sigma_prior=-2.0, activation_precision=7, weight_precision=8, qat_eval=True)
+mq = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, qa).load_reference_state(gq["state"])
+with q.mc_context(3, 11, 2):
+    res["qat"] = mq.forward_mc(x).cpu().numpy()
+np.savez(out, **res)
+print("F32-SWITCH-OK")
+"""
+
+
+@pytest.mark.parametrize("switch", ["QBNN_F32_TAPMASK=0", "QBNN_QAT_PRESAMPLE=0"])
+def test_float_path_switches_give_the_same_bits(switch, tmp_path):
+    """The fp32 / fp64 conv's two gather forms (per-row tap masks against per-element bounds compares) and the QAT weight pipelines on side
+    streams against in line: the float BBB ResNet and the QAT evaluation, ragged batch of 70, give bit-identical probabilities either way."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "f32_switch_worker.py"
+    script.write_text(_F32_SWITCH_WORKER)
+    outs = []
+    name, _, value = switch.partition("=")
+    for env in ({}, {name: value}):
+        out = tmp_path / ("probs_%d.npz" % len(outs))
+        r = subprocess.run([sys.executable, str(script), root, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "F32-SWITCH-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        outs.append(np.load(out))
+    for k in ("f32", "qat"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
 def test_graphed_predictor_equals_eager(golden_w8, golden_lenet_mc, golden_mlp_f32, golden_ensemble, golden_mlp_bbb_q, golden_lenet_bbb):
     """One captured HIP graph per (model, input shape), replayed with new inputs and new seeds (read from device memory):
     bit-identical to the eager `mc_predict` for the int8 BBB ResNet, the MC-Dropout LeNet (dropout masks), the fp32 BBB MLP
