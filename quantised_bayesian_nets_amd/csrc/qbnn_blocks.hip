@@ -117,7 +117,7 @@ template <int NBLK, bool STEM, bool DROP> constexpr int chain_ndrop() { return D
 
 template <class C, int NBLK, bool LDSW, bool STEM = false, int NM = 1, int NTHR_ = BLK_THREADS, bool DROP = false>
 __global__ __launch_bounds__(NTHR_) void block_chain_ws_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all, const DropSet<chain_ndrop<NBLK, STEM, DROP>()> dr) {
-  const ChainArgs<NBLK>& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  const ChainArgs<NBLK> a = args_of(all, blockIdx.y);
   static_assert(!DROP || NM == 1, "dropout variants are single-call");
   using MT = MaskTab<C::COUT, false>;
   constexpr int MTB = MT::bytes(C::G), D0 = STEM ? 1 : 0;
@@ -586,7 +586,7 @@ __device__ __forceinline__ void conv_ring_mfma_dense(const uint8_t* tile, uint8_
 template <class C, int NWV, int NM = 1, bool DROP = false>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 4, NWV / 4)))
 void block_chain_ald_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<DROP ? 2 : 0> dr) {
-  const ChainArgs<1>& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  const ChainArgs<1> a = args_of(all, blockIdx.y);
   static_assert(!DROP || NM == 1, "dropout variants are single-call");
   constexpr int MTB = MaskTab<C::COUT, false>::bytes(C::G);
   static_assert(C::CIN == C::COUT && C::CIN % 32 == 0, "wide identity BasicBlock");
@@ -886,7 +886,7 @@ template <class CB> struct DownSC {
 // the Add's second operand).  MBITS: bit tables where LDS is short (96 -> 192).
 template <class CA, class CS, class CB, bool LDSW, int NM = 1, bool DROP = false, bool MBITS = false>
 __global__ __launch_bounds__(BLK_THREADS) void block_down_ws_kernel(const ArgsArr<DownArgs, NM> all, const DropSet<DROP ? 3 : 0> dr) {
-  const DownArgs& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  const DownArgs a = args_of(all, blockIdx.y);
   static_assert(!DROP || NM == 1, "dropout variants are single-call");
   using MT = MaskTab<CB::COUT, MBITS>;
   constexpr int MTB = MT::bytes(CB::G);

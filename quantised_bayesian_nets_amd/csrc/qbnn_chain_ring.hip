@@ -127,7 +127,7 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<
   using D = CRCfg<C>;
   static_assert(!DROP || NM == 1, "dropout variants are single-call");
   constexpr int MTB = MaskTab<C::COUT, true>::bytes(C::G);
-  const ChainArgs<1>& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  const ChainArgs<1> a = args_of(all, blockIdx.y);
   constexpr int NTHR = 512;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* xt = smem;                                                        // dense tile + zero line

@@ -845,6 +845,37 @@ template <class A, int NM> struct ArgsArr { A m[NM]; };
 // NM = 0: any number of argument blocks, in DEVICE memory (the prepared multi-call launches: qbnn_*_multi_prepare / _launch) -- the
 // blocks are read with scalar loads instead of arriving as kernel arguments, so one grid holds all 16 members of an ensemble.
 template <class A> struct ArgsArr<A, 0> { const A* m; };
+// The argument block of this workgroup's call.  NM = 0: read through the CONSTANT address space, i.e. with scalar loads into SGPRs once, like
+// kernel arguments -- as plain global memory the compiler fetched every field with (uniform) VECTOR loads wherever it was used: 20 - 35 extra
+// global / flat loads and as many `s_waitcnt vmcnt` per kernel, inside the item loops, where they also wait for whatever else is in flight
+// (the weight ring's slabs).  The blocks are written by qbnn_*_multi_prepare before the launch and never during it.
+// (pointers that arrive as kernel arguments are known to point to global memory; pointers loaded from an argument block in memory are
+//  "generic" to the compiler, and every access through them a flat_load / flat_store, which counts on the LDS counter too: tell it)
+template <class T> __device__ __forceinline__ T* as_global(T* p) {
+  return (T*)reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p));      // integer -> global pointer -> generic
+}
+__device__ __forceinline__ void globalize(QConv& q) { q.w = as_global(q.w); q.bias = as_global(q.bias); }
+__device__ __forceinline__ void globalize(DownArgs& a) { a.x = as_global(a.x); a.y = as_global(a.y); globalize(a.s); globalize(a.a); globalize(a.b); }
+template <int NBLK> __device__ __forceinline__ void globalize(ChainArgs<NBLK>& a) {
+  a.x = as_global(a.x); a.y = as_global(a.y); a.stem_x = as_global(a.stem_x); globalize(a.stem);
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) { globalize(a.blk[k].a); globalize(a.blk[k].b); }
+}
+template <class A, int NM>
+__device__ __forceinline__ A args_of(const ArgsArr<A, NM>& all, int idx) {
+  if constexpr (NM == 0) {
+    static_assert(sizeof(A) % 4 == 0, "argument blocks are whole dwords");
+    union U { A a; uint32_t w[sizeof(A) / 4]; __device__ U() {} } u;
+    const __attribute__((address_space(4))) uint32_t* q =
+        reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(all.m + idx));
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(A) / 4); ++i) u.w[i] = q[i];
+    globalize(u.a);
+    return u.a;
+  } else {
+    return all.m[NM == 1 ? 0 : idx];
+  }
+}
 
 // =====================================================================================
 // Weights-stationary fused kernels (layers whose block weights fit in LDS next to the tiles: 24 and 48 channels).

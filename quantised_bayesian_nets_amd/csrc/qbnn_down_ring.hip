@@ -155,7 +155,7 @@ __device__ __forceinline__ void epi_presub(const float* bias_lds, const QConv& p
 template <class D, class EC, int NM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
-  const DownArgs& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  const DownArgs a = args_of(all, blockIdx.y);
   constexpr int NTHR = 512;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* xt = smem;

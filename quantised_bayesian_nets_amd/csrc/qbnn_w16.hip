@@ -161,7 +161,7 @@ __device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[L
 // epilogues from per-item mask tables in LDS (block_chain_ws_kernel's DROP form on 16 waves).
 template <int G, int NBLK, int NM, bool DROP = false>
 __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all, const DropSet<DROP ? 2 * NBLK + 1 : 0> dr) {
-  const ChainArgs<NBLK>& a = all.m[NM == 1 ? 0 : blockIdx.y];
+  const ChainArgs<NBLK> a = args_of(all, blockIdx.y);
   static_assert(!DROP || NM == 1, "dropout variants are single-call");
   constexpr int MTB = MaskTab<L1::COUT, false>::bytes(G);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
