@@ -27,6 +27,10 @@
 extern "C" {
 #endif
 
+/* ABI version of this header: qbnn_version() of the loaded library must equal it (bumped whenever a prototype below changes;
+ * 2 = round 5: qbnn_block_chain_i8_multi_launch takes a_hi; round 4's `stream` argument of the _multi_prepare calls). */
+#define QBNN_ABI_VERSION 2
+
 #define QBNN_OK 0
 #define QBNN_E_INVALID (-1)     /* bad argument / unsupported shape   */
 #define QBNN_E_LAUNCH (-2)      /* HIP launch error                   */
@@ -243,8 +247,9 @@ int qbnn_block_down_i8_multi(const qbnn_down_call* calls, int32_t n_calls, int32
 
 /* Prepared form of the two calls above, for call arrays that are replayed (an ensemble's members at a fixed batch size): _prepare
  * writes the argument blocks of ALL n_calls calls into caller-owned device memory once (qbnn_*_multi_args_bytes bytes, 16-byte aligned;
- * copied on `stream` -- the device block typically comes from a stream-ordered allocator -- and the call returns once the copy has
- * landed: do not call it under stream capture), _launch then runs them in ONE grid however many they are (the by-value
+ * copied on `stream` -- the device block typically comes from a stream-ordered allocator -- and, UNLIKE every other entry point of this
+ * header, the call returns only once the copy has landed (it synchronises `stream`: the staging copy of the blocks is a host vector
+ * that dies with the call): do not call it under stream capture), _launch then runs them in ONE grid however many they are (the by-value
  * forms above are limited to 8 / 4 calls per launch by the 4 KiB of kernel arguments): with 16 members every workgroup walks 2 - 16
  * work items of its member instead of 1 - 4, and a stage is one launch instead of two or four.  max_samples = the largest n_samples
  * of the calls.  Same results as the by-value forms. */
@@ -253,7 +258,7 @@ size_t qbnn_down_multi_args_bytes(int32_t n_calls);
 int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, int32_t n_calls, int32_t with_stem, int32_t B, int32_t a_hi,
                                       int32_t n_blocks, void* dev_args, void* stream);
 int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t with_stem, int32_t B, int32_t H, int32_t C,
-                                     int32_t n_blocks, int32_t max_samples, void* stream);
+                                     int32_t a_hi, int32_t n_blocks, int32_t max_samples, void* stream);      /* a_hi: as given to _prepare */
 int qbnn_block_down_i8_multi_prepare(const qbnn_down_call* calls, int32_t n_calls, int32_t B, int32_t a_hi, void* dev_args, void* stream);
 int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t max_samples,
                                     void* stream);

@@ -103,6 +103,9 @@ EXPORTS = ["qbnn_mlp_bbb_f32_mc", "qbnn_mlp_bbb_f32_workspace_floats", "qbnn_pac
            "qbnn_last_error", "qbnn_version"]
 
 
+ABI_VERSION = 2      # = QBNN_ABI_VERSION of include/qbnn.h
+
+
 def lib_path():
     return _build.LIB
 
@@ -116,6 +119,9 @@ def lib():
                                "(there is no CPU fallback for the qbnn HIP path)")
         L = C.CDLL(path)
         L.qbnn_last_error.restype = C.c_char_p
+        if L.qbnn_version() != ABI_VERSION:      # a stale in-tree build against an older include/qbnn.h: argument lists differ
+            raise RuntimeError(f"{path} reports ABI version {L.qbnn_version()}, this binding is written against {ABI_VERSION} "
+                               "(include/qbnn.h: QBNN_ABI_VERSION): rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
         L.qbnn_packed_weight_bytes.restype = C.c_size_t
         L.qbnn_packed_weight_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         vp, i32, i64, u32, u64, f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
@@ -144,7 +150,7 @@ def lib():
         L.qbnn_down_multi_args_bytes.restype = C.c_size_t
         L.qbnn_down_multi_args_bytes.argtypes = [i32]
         L.qbnn_block_chain_i8_multi_prepare.argtypes = [C.POINTER(ChainCall), i32, i32, i32, i32, i32, vp, vp]
-        L.qbnn_block_chain_i8_multi_launch.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.qbnn_block_chain_i8_multi_launch.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         L.qbnn_block_down_i8_multi_prepare.argtypes = [C.POINTER(DownCall), i32, i32, i32, vp, vp]
         L.qbnn_block_down_i8_multi_launch.argtypes = [vp, i32, i32, i32, i32, i32, vp]
         L.qbnn_head_i8_multi.argtypes = [C.POINTER(HeadCall), i32, vp]

@@ -1189,7 +1189,7 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
   if (int rc = build_chain_args<NBLK>(a, x, x_ss, s_x, z_x, B, a_hi, blk, y, y_ss, n_samples, stem_x, stem)) return rc;
   if (stem) {
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
-    if constexpr (NBLK == 2) { if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16(&a, 1, st); }
+    if constexpr (NBLK == 2) { if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16(&a, 1, a_hi, st); }
     return launch_block_chain_ws<Blk_24, NBLK, true, true>(a, st);
   }
   if (Cc == 24 && H == 32) return launch_block_chain_ws<Blk_24, NBLK>(a, st);
@@ -1308,13 +1308,13 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, 
 }
 
 QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t with_stem, int32_t B, int32_t H, int32_t Cc,
-                                                 int32_t n_blocks, int32_t max_samples, void* stream) {
+                                                 int32_t a_hi, int32_t n_blocks, int32_t max_samples, void* stream) {
   if (!dev_args || n_calls <= 0 || B <= 0 || max_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: bad argument%s");
   hipStream_t st = (hipStream_t)stream;
   auto items = [&](int G) { return max_samples * ((B + G - 1) / G); };
   if (with_stem) {
     if (n_blocks != 2 || Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: the fused stem feeds the two 32x32x24 blocks only%s");
-    if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16_dev(reinterpret_cast<const ChainArgs<2>*>(dev_args), n_calls, items(2), st);
+    if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16_dev(reinterpret_cast<const ChainArgs<2>*>(dev_args), n_calls, items(2), a_hi, st);
     return launch_block_chain_ws_dev<Blk_24, 2, true>(reinterpret_cast<const ChainArgs<2>*>(dev_args), n_calls, items(Blk_24::G), st);      // QBNN_W16=0: the 8-wave kernel
   }
   if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: one block per call (two only behind the fused stem)%s");
@@ -1456,7 +1456,7 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi(const qbnn_chain_call* calls, int32_t 
         if ((rc = build_stem_qconv(stem, k.w0_packed, k.w0_sample_stride, k.bias0, k.s_in, k.s_w0, k.z_w0, k.s_y0, k.z_y0, a_hi))) return rc;
         if ((rc = build_chain_args<2>(arr[i], nullptr, 0, k.s_y0, k.z_y0, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, k.im2col, &stem))) return rc;
       }
-      rc = qbnn_use_w16() ? qbnn_launch_stem_chain_w16(arr, n, st) : launch_block_chain_ws_multi<Blk_24, 2, true, NM2>(arr, n, st);
+      rc = qbnn_use_w16() ? qbnn_launch_stem_chain_w16(arr, n, a_hi, st) : launch_block_chain_ws_multi<Blk_24, 2, true, NM2>(arr, n, st);
     } else {
       if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: one block per call (two only behind the fused stem)%s");
       ChainArgs<1> arr[QBNN_FUSED_CALLS];

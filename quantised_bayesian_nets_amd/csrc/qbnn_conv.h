@@ -726,7 +726,9 @@ struct EpiTile {
 
 // (c) conv -> Add(residual) -> ReLU, residual read as centred int8 (x' = q_r - z_r) from a halo'd tile of the same
 //     geometry and overwritten in place with the centred block output (q_o - z_o).
-template <int HO, int PIXB, int TILE_BYTES>
+// RES_U8: the residual bytes are known to be non-negative (a tile written by ReLU-fused epilogues of the same kernel): one
+//     v_cvt_f32_ubyteN per value instead of v_bfe_i32 + v_cvt_f32_i32.
+template <int HO, int PIXB, int TILE_BYTES, bool RES_U8 = false>
 struct EpiTileResInPlace {
   static constexpr int VALU_PER_MFMA = 22;
   uint8_t* xt; QConv p; QAdd a;
@@ -738,7 +740,8 @@ struct EpiTileResInPlace {
     uint32_t* o = reinterpret_cast<uint32_t*>(xt + po + c0);
     const int rq = (int)rqu;
     const float vv[4] = {v0, v1, v2, v3};
-    const float rf[4] = {(float)((rq << 24) >> 24), (float)((rq << 16) >> 24), (float)((rq << 8) >> 24), (float)(rq >> 24)};   // centred r'
+    const float rf[4] = {RES_U8 ? (float)(rqu & 0xffu) : (float)((rq << 24) >> 24), RES_U8 ? (float)((rqu >> 8) & 0xffu) : (float)((rq << 16) >> 24),
+                         RES_U8 ? (float)((rqu >> 16) & 0xffu) : (float)((rq << 8) >> 24), RES_U8 ? (float)(rqu >> 24) : (float)(rq >> 24)};   // centred r'
     float t[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

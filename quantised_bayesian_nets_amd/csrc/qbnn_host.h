@@ -51,8 +51,8 @@ static int fill_qadd(QAdd& a, const qbnn_conv_desc* d) {
 }
 
 // 16-wave layer-1 kernel (qbnn_w16.hip): layers.0 + two identity blocks at 32 x 32 x 24, `n` <= 4 argument blocks in one grid
-int qbnn_launch_stem_chain_w16(const ChainArgs<2>* arr, int n, hipStream_t st);
-int qbnn_launch_stem_chain_w16_dev(const ChainArgs<2>* dev, int n, int items, hipStream_t st);               // ... any number of argument blocks in device memory
+int qbnn_launch_stem_chain_w16(const ChainArgs<2>* arr, int n, int a_hi, hipStream_t st);
+int qbnn_launch_stem_chain_w16_dev(const ChainArgs<2>* dev, int n, int items, int a_hi, hipStream_t st);               // ... any number of argument blocks in device memory
 int qbnn_launch_stem_chain_w16_drop(const ChainArgs<2>& a, const DropSet<5>& dr, hipStream_t st);      // ... with the five dropouts of conv_resnet_mc
 // Ring form of the wide down-sampling blocks (qbnn_down_ring.hip): 48 -> 96 at 16 x 16 and 96 -> 192 at 8 x 8; `n` argument blocks by value
 // (n <= QBNN_FUSED_CALLS) or any number in device memory.  QBNN_DOWN_RING=0 selects the L2-streaming kernels of qbnn_blocks.hip (A/B checks).

@@ -46,7 +46,7 @@ int qbnn_check_launch_msg(const char* what) {
 }
 
 QBNN_EXPORT const char* qbnn_last_error(void) { return g_err; }
-QBNN_EXPORT int qbnn_version(void) { return 1; }
+QBNN_EXPORT int qbnn_version(void) { return QBNN_ABI_VERSION; }
 
 // =====================================================================================
 // Packed weight layout (QBNN_LAYOUT_MFMA32): the weight operand of v_mfma_i32_32x32x32_i8.

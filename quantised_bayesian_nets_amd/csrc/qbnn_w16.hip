@@ -35,34 +35,83 @@ QBNN_EXPORT void qbnn_debug_w16_stamp_buffer(void* p) { hipMemcpyToSymbol(HIP_SY
 #define W16_STAMP_PASS
 #endif
 
+// Progress-based issue priority (round 5; -DQBNN_W16_PRIO=0 for the A/B): a wave lowers its priority with every output row it finishes
+// inside a conv phase (3, 2, 1, 0), so the waves of a SIMD that are behind win arbitration over those ahead -- the hardware's oldest-first
+// rule lets the four waves of a SIMD finish a phase 2 - 7 k cycles apart (profiles/r03_stamp_w16_g2.txt), and the tail of every phase runs
+// at one or two waves per SIMD, where a vector instruction costs 4 - 8 cycles instead of 2.9.  s_setprio is also a scheduling fence: the
+// rows of a wave are issued one after the other.  Measured: 1.044 -> 1.014 ms (plain), 0.989 -> 0.940 ms (MAGIC).
+#ifndef QBNN_W16_PRIO
+#define QBNN_W16_PRIO 1
+#endif
+#if QBNN_W16_PRIO
+#define W16_PRIO(i) do { if ((i) == 0) __builtin_amdgcn_s_setprio(3); else if ((i) == 1) __builtin_amdgcn_s_setprio(2); \
+                         else if ((i) == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
+#else
+#define W16_PRIO(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int W16_THREADS = 1024, W16_WAVES = 16;
 using L1 = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;      // one 32 x 32 x 24 image tile (halo 1): pitch 34 * 24 bytes
 using L0 = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;      // layers.0 on the patch tensor: K = 27 -> 32, one k-step
 
+#ifndef QBNN_W16_STEAL
+#define QBNN_W16_STEAL 0
+#endif
 template <int G, int NBLK, bool DROP = false> constexpr int w16_lds() {
-  return 2 * (G * L1::TILE_BYTES + L1::TILE_SLACK) + 2 * NBLK * WConv<L1>::BYTES + WConv<L0>::BYTES + (2 * NBLK + 1) * L1::COUT * 4 +
+  return (QBNN_W16_STEAL ? 16 * 2 * NBLK : 0) + 2 * (G * L1::TILE_BYTES + L1::TILE_SLACK) + 2 * NBLK * WConv<L1>::BYTES + WConv<L0>::BYTES + (2 * NBLK + 1) * L1::COUT * 4 +
          (DROP ? 2 * (2 * NBLK + 1) * MaskTab<L1::COUT, false>::bytes(G) : 0);      // two sets of mask tables: consecutive items alternate
 }
 
-// requantise one 32-pixel x 24-channel accumulator tile (ones row -> window sum, see conv_core) through `epi`
-template <class Epi>
+// requantise one 32-pixel x 24-channel accumulator tile (ones row -> window sum, see conv_core) through `epi`.
+// MAGIC: the accumulators were started at the bit pattern of 1.5 * 2^23 (MAGIC16) instead of 0, so a register read as fp32 IS
+// 1.5 * 2^23 + sum exactly while |sum| < 2^22 -- K * 128 * max|x'| = 216 * 128 * 127 = 3.5 M here (the launcher checks the activation
+// bound) -- and (float)(sum - z_w R) = as_float(acc) - (1.5 * 2^23 + z_w R): ONE v_sub_f32 of two exactly represented integers with an
+// exactly representable difference, where the plain form needs v_sub_u32 + v_cvt_f32_i32.  The window sum leaves the ones row the
+// same way: R = as_float(acc[ones]) - 1.5 * 2^23, and 1.5 * 2^23 + z_w R is one fma on integers below 2^24.  Same bits.
+#define QBNN_MAGIC_BITS 0x4B400000
+template <bool MAGIC, class Epi>
 __device__ __forceinline__ void epilogue24(const v16i& acc, const float4 (&b4)[3], const QConv& p, const Epi& epi, int po, int h) {
   const int rv = acc[L1::ONES_REG];
-  const int zwr = p.z_w * half_lo_bcast(rv);
+  int zwr = 0;
+  float cm = 0.f;
+  if constexpr (MAGIC) cm = __builtin_fmaf((float)p.z_w, __int_as_float(half_lo_bcast(rv)) - QBNN_MAGIC, QBNN_MAGIC);
+  else zwr = p.z_w * half_lo_bcast(rv);
   uint32_t pre[3];
 #pragma unroll
   for (int g4 = 0; g4 < 3; ++g4) pre[g4] = epi.load(po, 8 * g4 + 4 * h);
 #pragma unroll
   for (int g4 = 0; g4 < 3; ++g4) {
     const float4 bb = b4[g4];
-    const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)(acc[4 * g4 + 0] - zwr)) * p.mult;
-    const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)(acc[4 * g4 + 1] - zwr)) * p.mult;
-    const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)(acc[4 * g4 + 2] - zwr)) * p.mult;
-    const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)(acc[4 * g4 + 3] - zwr)) * p.mult;
+    float a0, a1, a2, a3;
+    if constexpr (MAGIC) {
+      a0 = __int_as_float(acc[4 * g4 + 0]) - cm; a1 = __int_as_float(acc[4 * g4 + 1]) - cm;
+      a2 = __int_as_float(acc[4 * g4 + 2]) - cm; a3 = __int_as_float(acc[4 * g4 + 3]) - cm;
+    } else {
+      a0 = (float)(acc[4 * g4 + 0] - zwr); a1 = (float)(acc[4 * g4 + 1] - zwr);
+      a2 = (float)(acc[4 * g4 + 2] - zwr); a3 = (float)(acc[4 * g4 + 3] - zwr);
+    }
+    const float v0 = __builtin_fmaf(bb.x, p.rcp, a0) * p.mult;
+    const float v1 = __builtin_fmaf(bb.y, p.rcp, a1) * p.mult;
+    const float v2 = __builtin_fmaf(bb.z, p.rcp, a2) * p.mult;
+    const float v3 = __builtin_fmaf(bb.w, p.rcp, a3) * p.mult;
     epi.store(po, 8 * g4 + 4 * h, v0, v1, v2, v3, pre[g4]);
   }
+}
+template <bool MAGIC> __device__ __forceinline__ v16i acc_start() {
+  constexpr int m = MAGIC ? QBNN_MAGIC_BITS : 0;
+  return v16i{m, m, m, m, m, m, m, m, m, m, m, m, m, m, m, m};
+}
+// The start block of a conv phase, built INSIDE the phase from an opaque register (16 moves per phase and wave).  As a plain constant
+// the compiler builds it once per kernel and keeps it in scratch across the item loop: a scratch reload per phase is a vector-memory
+// round trip behind a vmcnt(0) that also drains the output stores and the patch prefetch (measured: 1.29 against 1.10 ms).
+__device__ __forceinline__ v16i magic_block() {
+  int m = QBNN_MAGIC_BITS;
+  asm volatile("" : "+v"(m));
+  v16i b = v16i{m, m, m, m, m, m, m, m, m, m, m, m, m, m, m, m};
+  asm volatile("" : "+v"(b));
+  return b;
 }
 
 // byte offset of interior pixel (oh, ow) of image g inside a tile array
@@ -71,12 +120,13 @@ __device__ __forceinline__ int px_off(int g, int oh, int ow) { return g * L1::TI
 // The chain's LAST conv: Add(residual from the X tile) + ReLU as EpiTileResInPlace, but the block output leaves as quint8 straight to
 // global memory (three dwords per lane and row: the 24-byte pixel records of a row are contiguous) -- nothing reads the X tile after
 // it, so the item needs no read-out pass (tile -> registers -> + z_o -> HBM by all threads) and no barrier in front of one.
-struct OutRow { uint8_t* y; int ok; };        // this lane's pixel column of the wave's image in the output tensor (row 0); ok: the image exists (ragged batch)
+struct OutRow { uint8_t* y; int n_ok; };      // this lane's pixel column of the ITEM's first image in the output tensor (row 0); n_ok: images of the item that exist (ragged batch)
 template <bool DROP>
 struct EpiResToGlobal {
   const uint8_t* xt; OutRow o; QConv p; QAdd a; PostArgs q; MaskTab<L1::COUT, false> mt;
-  mutable uint8_t* yrow;
-  __device__ __forceinline__ void set_row(int oh) const { yrow = o.y + oh * (L1::HIN * L1::COUT); }      // called before a row's stores (oh: wave-uniform)
+  mutable uint8_t* yrow; mutable bool ok;
+  // called before a row's stores (image slot g and output row oh: wave-uniform)
+  __device__ __forceinline__ void set_row(int g, int oh) const { yrow = o.y + (g * L1::HIN + oh) * (L1::HIN * L1::COUT); ok = g < o.n_ok; }
   __device__ __forceinline__ uint32_t load(int po, int c0) const { return *reinterpret_cast<const uint32_t*>(xt + po + c0); }
   __device__ __forceinline__ void store(int po, int c0, float v0, float v1, float v2, float v3, uint32_t rqu) const {
     float r[4] = {v0, v1, v2, v3};
@@ -90,7 +140,10 @@ struct EpiResToGlobal {
       for (int i = 0; i < 4; ++i) r[i] = med3f(r[i], p.vlo, p.vhi);
     }
     const int rq = (int)rqu;
-    const float rf[4] = {(float)((rq << 24) >> 24), (float)((rq << 16) >> 24), (float)((rq << 8) >> 24), (float)(rq >> 24)};
+    // the residual is the X tile: without dropout its bytes come from ReLU-fused epilogues of this kernel (layers.0, the previous
+    // block's Add + ReLU), centred and non-negative -- one v_cvt_f32_ubyteN each; a dropped value may lie below the mask's zero point
+    const float rf[4] = {DROP ? (float)((rq << 24) >> 24) : (float)(rqu & 0xffu), DROP ? (float)((rq << 16) >> 24) : (float)((rqu >> 8) & 0xffu),
+                         DROP ? (float)((rq << 8) >> 24) : (float)((rqu >> 16) & 0xffu), DROP ? (float)(rq >> 24) : (float)(rqu >> 24)};
     float t[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -98,24 +151,21 @@ struct EpiResToGlobal {
       const float db = __builtin_fmaf(a.s_r, rf[i], a.dl_r);
       t[i] = (da + db) * a.inv_s_o;
     }
-    if (o.ok) *reinterpret_cast<uint32_t*>(yrow + c0) = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi) + (uint32_t)a.z_o * 0x01010101u;
+    if (ok) *reinterpret_cast<uint32_t*>(yrow + c0) = pack_rne_u8(t[0], t[1], t[2], t[3], a.vhi) + (uint32_t)a.z_o * 0x01010101u;
   }
 };
-template <class E> __device__ __forceinline__ auto epi_set_row(const E& e, int oh, int) -> decltype(e.set_row(oh), void()) { e.set_row(oh); }
-template <class E> __device__ __forceinline__ void epi_set_row(const E&, int, long) {}
+template <class E> __device__ __forceinline__ auto epi_set_row(const E& e, int g, int oh, int) -> decltype(e.set_row(g, oh), void()) { e.set_row(g, oh); }
+template <class E> __device__ __forceinline__ void epi_set_row(const E&, int, int, long) {}
 
 // 3x3 / stride 1 conv of RW consecutive output rows [oh0, oh0 + RW) of image slot g: tile -> epi.  `w` holds this conv's 9 weight
 // fragments; after the last row's MFMAs it is refilled from `wnext` (the NEXT conv's weights, which do not depend on the barrier
 // in between: the refill rides under the last epilogue instead of heading the next phase, where all 16 waves would burst it).
-template <int RW, class Epi>
+template <int RW, bool MAGIC, class Epi>
 __device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[L1::KS], const uint8_t* wnext, const float* bias_lds,
                                                  const QConv& p, const Epi& epi, int g, int oh0, int lane W16_STAMP_ARGS) {
   int l_ = lane;
   asm volatile("" : "+v"(l_));     // per-lane offsets are recomputed per phase (hoisted out of the item loop they spill)
   const int r = l_ & 31, h = l_ >> 5;
-  float4 b4[3];
-#pragma unroll
-  for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * h);
   // tile row oh0 + j is input row oh0 - 1 + j; tile column r is input column r - 1: the 72-byte window of (row, r) starts there
   const uint8_t* base = tile + g * L1::TILE_BYTES + (oh0 * L1::TW + r) * L1::PIXB + 16 * h;
   v4i x[RW + 2][L1::SPR];
@@ -127,12 +177,47 @@ __device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[L
       x[j][t] = v4i{lo.x, lo.y, hi.x, hi.y};
     }
   };
+  if constexpr (MAGIC) {
+    // ONE live copy of the start block, one accumulator, the rows one after the other (a scheduling fence per row: with all four rows'
+    // MFMAs run ahead, as the compiler schedules the plain form, 4 x 16 accumulators + the start block do not fit 128 VGPRs); an input
+    // row is read when its first output row needs it and the bias table per row, after the MFMAs are issued.
+    const v16i mg = magic_block();
+    load_row(0); load_row(1);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      W16_PRIO(i);
+      load_row(i + 2);
+      v16i acc;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int t = 0; t < L1::SPR; ++t)
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * L1::SPR + t], x[i + kh][t], (kh == 0 && t == 0) ? mg : acc, 0, 0, 0);
+      if (i == RW - 1 && wnext) {
+#pragma unroll
+        for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
+      }
+      float4 bb[3];
+#pragma unroll
+      for (int g4 = 0; g4 < 3; ++g4) bb[g4] = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * h);
+      W16_STAMP();
+      epi_set_row(epi, g, oh0 + i, 0);
+      epilogue24<true>(acc, bb, p, epi, px_off(g, oh0 + i, r), h);
+      W16_STAMP();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   load_row(0); load_row(1); load_row(2);
-  const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float4 b4[3];
+#pragma unroll
+  for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * h);
+  const v16i zero16 = acc_start<MAGIC>();
   // One accumulator, no software pipeline inside the wave: while this wave waits on its MFMAs the SIMD's other three waves
   // issue their epilogues (a wave of its own issues a vector instruction every ~6 cycles, the SIMD one every ~2-3).
 #pragma unroll
   for (int i = 0; i < RW; ++i) {
+    W16_PRIO(i);
     v16i acc;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
@@ -145,9 +230,75 @@ __device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[L
       for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
     }
     W16_STAMP();
-    epi_set_row(epi, oh0 + i, 0);
-    epilogue24(acc, b4, p, epi, px_off(g, oh0 + i, r), h);
+    epi_set_row(epi, g, oh0 + i, 0);
+    epilogue24<MAGIC>(acc, b4, p, epi, px_off(g, oh0 + i, r), h);
     W16_STAMP();
+  }
+}
+
+// Row stealing (-DQBNN_W16_STEAL=1, experiment): the same conv with the item's NROWS = 32 G output rows handed out one at a time.  A wave
+// starts on row `wave` and takes its next row from an LDS ticket counter (requested while it works on the current one).  The hardware
+// arbitrates oldest-first, so with a static split (conv3x3_rows_w16) the four waves of a SIMD finish a phase 2 - 7 k cycles apart and the
+// phase's tail runs at one or two waves per SIMD (profiles/r03_stamp_w16_g2.txt); here a wave that is ahead simply takes more rows.
+// Tickets are never reset: a phase of an item hands out exactly NROWS of them (NROWS - 16 rows + one refusal per wave), so the phase's
+// first ticket is ticket_base = (item ordinal of the workgroup) * NROWS.  The 3-row window is loaded per row (no reuse across rows).
+// Ticket request / receipt.  The request is ONE ds_add_rtn_u32 by lane 0 (EXEC narrowed around it), issued from inline assembly so that
+// it stays where it is put -- as a C++ atomic the compiler's atomic optimiser rewrites it into a ballot + add + readfirstlane sequence
+// and waits for the result on the spot.  The compiler's own lgkmcnt accounting stays valid with one more (older or interleaved) LDS
+// operation in flight: LDS operations complete in order, so its waits only become stricter.  ticket_take drains the LDS counter first.
+__device__ __forceinline__ int ticket_request(const int* ctr) {
+  int v; unsigned long long keep;
+  const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)ctr;
+  asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1"
+               : "=&v"(v), "=&s"(keep) : "v"(addr), "v"(1) : "memory");
+  return v;
+}
+__device__ __forceinline__ int ticket_take(int v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <int NROWS, bool MAGIC, class Epi>
+__device__ __forceinline__ void conv3x3_steal_w16(const uint8_t* tile, v4i (&w)[L1::KS], const uint8_t* wnext, const float* bias_lds,
+                                                  const QConv& p, const Epi& epi, int* ctr, int ticket_base, int wave, int lane) {
+  int l_ = lane;
+  asm volatile("" : "+v"(l_));
+  const int r = l_ & 31, h = l_ >> 5;
+  const uint8_t* lane_base = tile + r * L1::PIXB + 16 * h;
+  v16i c0 = acc_start<false>();
+  if constexpr (MAGIC) c0 = magic_block();
+  int c = wave;
+  while ((unsigned)c < (unsigned)NROWS) {      // (unsigned: a ticket below the phase base can only come from a broken count -- stop instead of addressing with it)
+    const int nxt = ticket_request(ctr);
+    const int g = c >> 5, oh = c & 31;
+    const uint8_t* base = lane_base + g * L1::TILE_BYTES + oh * L1::PITCH;
+    v4i x[3][L1::SPR];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int t = 0; t < L1::SPR; ++t) {
+        const v2i lo = *reinterpret_cast<const v2i*>(base + j * L1::PITCH + t * 32);
+        const v2i hi = *reinterpret_cast<const v2i*>(base + j * L1::PITCH + t * 32 + 8);
+        x[j][t] = v4i{lo.x, lo.y, hi.x, hi.y};
+      }
+    __builtin_amdgcn_sched_barrier(0);      // all nine fragment reads in flight before the first MFMA waits for one
+    v16i acc;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int t = 0; t < L1::SPR; ++t)
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * L1::SPR + t], x[kh][t], (kh == 0 && t == 0) ? c0 : acc, 0, 0, 0);
+    float4 b4[3];                           // per row: held across the loop they are 12 VGPRs beside the nine fragments
+#pragma unroll
+    for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * h);
+    __builtin_amdgcn_sched_barrier(0);
+    c = 16 + ticket_take(nxt) - ticket_base;
+    epi_set_row(epi, g, oh, 0);
+    epilogue24<MAGIC>(acc, b4, p, epi, px_off(g, oh, r), h);
+  }
+  if (wnext) {
+#pragma unroll
+    for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
   }
 }
 
@@ -159,7 +310,7 @@ __device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[L
 //  without the epilogue arithmetic 0.61, without the pixel-fragment reads 1.08, without the barriers 1.04.)
 // DROP (conv_resnet_mc): a quantised channel dropout behind every conv -- dr.d = layers.3, then per block stem.3, stem.6 -- applied in the
 // epilogues from per-item mask tables in LDS (block_chain_ws_kernel's DROP form on 16 waves).
-template <int G, int NBLK, int NM, bool DROP = false>
+template <int G, int NBLK, int NM, bool DROP = false, bool MAGIC = false>
 __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsArr<ChainArgs<NBLK>, NM> all, const DropSet<DROP ? 2 * NBLK + 1 : 0> dr) {
   const ChainArgs<NBLK> a = args_of(all, blockIdx.y);
   static_assert(!DROP || NM == 1, "dropout variants are single-call");
@@ -175,6 +326,7 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
   float* bias_lds = reinterpret_cast<float*>(wl0 + WConv<L0>::BYTES);      // [2 NBLK][24], then layers.0's
   float* bias0 = bias_lds + 2 * NBLK * L1::COUT;
   uint8_t* mtab0 = reinterpret_cast<uint8_t*>(bias0 + L0::COUT);             // DROP: mask tables [2][2 NBLK + 1][G][24]
+  int* tickets = reinterpret_cast<int*>(mtab0 + (DROP ? 2 * (2 * NBLK + 1) * MTB : 0));      // STEAL: one counter per 3x3 conv, 16 bytes apart
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = (wave * RW) / 32, woh0 = (wave * RW) % 32;  // this wave's image within the item and its first output row
 
@@ -191,6 +343,7 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
     load_bias<L1::COUT, W16_THREADS>(bias_lds + (2 * k + 1) * L1::COUT, a.blk[k].b.bias, tid);
   }
   load_bias<L0::COUT, W16_THREADS>(bias0, a.stem.bias, tid);
+  if (QBNN_W16_STEAL && tid < 2 * NBLK) tickets[4 * tid] = 0;
   auto sync = [&]() { lds_barrier(); };
 
   // layers.0's pixel fragments of this wave's rows, one 16-byte load per lane and row straight from the patch tensor
@@ -260,12 +413,14 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
       float4 b4[3];
 #pragma unroll
       for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias0 + 8 * g4 + 4 * h);
-      const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      v16i zero16 = acc_start<false>();
+      if constexpr (MAGIC) zero16 = magic_block();
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
+        W16_PRIO(i);
         const v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, pf[i], zero16, 0, 0, 0);
         W16_STAMP();
-        epilogue24(acc, b4, a.stem, epi, px_off(wg, woh0 + i, r), h);
+        epilogue24<MAGIC>(acc, b4, a.stem, epi, px_off(wg, woh0 + i, r), h);
         W16_STAMP();
       }
     };
@@ -277,11 +432,18 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
     for (int k = 0; k < NBLK; ++k) {
       const BlockParams& bp = a.blk[k];
       auto conv_a = [&](const auto& epi) {
-        conv3x3_rows_w16<RW>(xt, w, wl + (2 * k + 1) * WB, bias_lds + (2 * k) * L1::COUT, bp.a, epi, wg, woh0, lane W16_STAMP_PASS);
+        if constexpr (QBNN_W16_STEAL)
+          conv3x3_steal_w16<32 * G, MAGIC>(xt, w, wl + (2 * k + 1) * WB, bias_lds + (2 * k) * L1::COUT, bp.a, epi, tickets + 4 * (2 * k), it * (32 * G), wave, lane);
+        else
+          conv3x3_rows_w16<RW, MAGIC>(xt, w, wl + (2 * k + 1) * WB, bias_lds + (2 * k) * L1::COUT, bp.a, epi, wg, woh0, lane W16_STAMP_PASS);
       };
       auto conv_b = [&](const auto& epi) {
-        conv3x3_rows_w16<RW>(tt, w, k + 1 < NBLK ? wl + (2 * k + 2) * WB : nullptr, bias_lds + (2 * k + 1) * L1::COUT, bp.b, epi, wg, woh0,
-                             lane W16_STAMP_PASS);
+        if constexpr (QBNN_W16_STEAL)
+          conv3x3_steal_w16<32 * G, MAGIC>(tt, w, k + 1 < NBLK ? wl + (2 * k + 2) * WB : nullptr, bias_lds + (2 * k + 1) * L1::COUT, bp.b, epi, tickets + 4 * (2 * k + 1),
+                                          it * (32 * G), wave, lane);
+        else
+          conv3x3_rows_w16<RW, MAGIC>(tt, w, k + 1 < NBLK ? wl + (2 * k + 2) * WB : nullptr, bias_lds + (2 * k + 1) * L1::COUT, bp.b, epi, wg, woh0,
+                               lane W16_STAMP_PASS);
       };
       if constexpr (DROP) conv_a(EpiTileDrop<L1::HO, L1::PIXB, L1::TILE_BYTES, L1::COUT>{tt, bp.a, dr.d[1 + 2 * k], {mtab + (1 + 2 * k) * MTB, 0.f}});
       else conv_a(EpiTile<L1::HO, L1::PIXB, L1::TILE_BYTES>{tt, bp.a});
@@ -290,12 +452,12 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
       if (k + 1 == NBLK) {             // the chain's output: quint8 straight to HBM
         int l_ = lane;
         asm volatile("" : "+v"(l_));
-        const OutRow orow{a.y + (int64_t)s * a.y_ss + (int64_t)(img0 + wg) * (L1::HIN * L1::HIN * L1::COUT) + (l_ & 31) * L1::COUT, img0 + wg < a.B};
-        if constexpr (DROP) conv_b(EpiResToGlobal<true>{xt, orow, bp.b, bp.add, dr.d[2 + 2 * k], {mtab + (2 + 2 * k) * MTB, 0.f}, nullptr});
-        else conv_b(EpiResToGlobal<false>{xt, orow, bp.b, bp.add, PostArgs{}, {nullptr, 0.f}, nullptr});
+        const OutRow orow{a.y + (int64_t)s * a.y_ss + (int64_t)img0 * (L1::HIN * L1::HIN * L1::COUT) + (l_ & 31) * L1::COUT, a.B - img0};
+        if constexpr (DROP) conv_b(EpiResToGlobal<true>{xt, orow, bp.b, bp.add, dr.d[2 + 2 * k], {mtab + (2 + 2 * k) * MTB, 0.f}, nullptr, false});
+        else conv_b(EpiResToGlobal<false>{xt, orow, bp.b, bp.add, PostArgs{}, {nullptr, 0.f}, nullptr, false});
       } else {
         if constexpr (DROP) conv_b(EpiTileResInPlaceDrop<L1::HO, L1::PIXB, L1::TILE_BYTES, L1::COUT>{xt, bp.b, bp.add, dr.d[2 + 2 * k], {mtab + (2 + 2 * k) * MTB, 0.f}});
-        else conv_b(EpiTileResInPlace<L1::HO, L1::PIXB, L1::TILE_BYTES>{xt, bp.b, bp.add});
+        else conv_b(EpiTileResInPlace<L1::HO, L1::PIXB, L1::TILE_BYTES, true>{xt, bp.b, bp.add});      // RES_U8: see EpiResToGlobal
         sync();
       }
       W16_STAMP();
@@ -306,13 +468,22 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
   }
 }
 
-template <int G, int NBLK, int NM>
+// May the accumulators start at 1.5 * 2^23 (epilogue24, MAGIC)?  Every 3x3 conv of the launch reads a tile whose bytes lie in
+// [0, min(255, a_hi) - z] (ReLU-fused requantisation / Add + ReLU centred on their zero points), so |sum| <= 216 * 128 * min(255, a_hi):
+// below 2^22 for a_hi <= 151 -- every activation precision the reference allows (quant_utils.py:120 caps it at 7 bits).  layers.0
+// reads int8 patches: 27 * 128 * 128.  QBNN_W16_MAGIC=0 keeps the plain form (A/B checks).
+bool w16_magic_ok(int a_hi) {
+  static const bool on = [] { const char* e = getenv("QBNN_W16_MAGIC"); return !(e && e[0] == '0'); }();
+  return on && a_hi >= 0 && (int64_t)L1::KSZ * L1::KSZ * L1::CIN * 128 * (a_hi < 255 ? a_hi : 255) < (1 << 22);
+}
+
+template <int G, int NBLK, int NM, bool MAGIC>
 int launch_w16(const ChainArgs<NBLK>* arr, int n, hipStream_t st) {
   constexpr int LDS = w16_lds<G, NBLK>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert(sizeof(ArgsArr<ChainArgs<NBLK>, NM>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
   static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)stem_chain_w16_kernel<G, NBLK, NM>, attr, LDS)) return rc_attr;
+  if (int rc_attr = ensure_dyn_lds((const void*)stem_chain_w16_kernel<G, NBLK, NM, false, MAGIC>, attr, LDS)) return rc_attr;
   ArgsArr<ChainArgs<NBLK>, NM> all;
   memset(&all, 0, sizeof(all));
   int items = 0;
@@ -323,7 +494,7 @@ int launch_w16(const ChainArgs<NBLK>* arr, int n, hipStream_t st) {
   }
   const int per = 256 / n > 0 ? 256 / n : 1;
   const int gx = items < per ? (items > 0 ? items : 1) : per;
-  hipLaunchKernelGGL((stem_chain_w16_kernel<G, NBLK, NM>), dim3(gx, n), dim3(W16_THREADS), LDS, st, all, DropSet<0>{});
+  hipLaunchKernelGGL((stem_chain_w16_kernel<G, NBLK, NM, false, MAGIC>), dim3(gx, n), dim3(W16_THREADS), LDS, st, all, DropSet<0>{});
   return check_launch("qbnn_stem_chain_i8_mc");
 }
 
@@ -340,23 +511,29 @@ int launch_w16_drop(const ChainArgs<NBLK>& a, const DropSet<2 * NBLK + 1>& dr, h
   return check_launch("qbnn_stem_chain_drop_i8_mc");
 }
 
-}  // namespace
-
-int qbnn_launch_stem_chain_w16_dev(const ChainArgs<2>* dev, int n, int items, hipStream_t st) {
+template <bool MAGIC>
+int launch_w16_dev(const ChainArgs<2>* dev, int n, int items, hipStream_t st) {
   constexpr int LDS = w16_lds<2, 2>();
   static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)stem_chain_w16_kernel<2, 2, 0>, attr, LDS)) return rc_attr;
+  if (int rc_attr = ensure_dyn_lds((const void*)stem_chain_w16_kernel<2, 2, 0, false, MAGIC>, attr, LDS)) return rc_attr;
   const int per = 256 / n > 0 ? 256 / n : 1;
   const int gx = items < per ? (items > 0 ? items : 1) : per;
-  hipLaunchKernelGGL((stem_chain_w16_kernel<2, 2, 0>), dim3(gx, n), dim3(W16_THREADS), LDS, st, ArgsArr<ChainArgs<2>, 0>{dev}, DropSet<0>{});
+  hipLaunchKernelGGL((stem_chain_w16_kernel<2, 2, 0, false, MAGIC>), dim3(gx, n), dim3(W16_THREADS), LDS, st, ArgsArr<ChainArgs<2>, 0>{dev}, DropSet<0>{});
   return check_launch("qbnn_block_chain_i8_multi_launch");
+}
+
+}  // namespace
+
+int qbnn_launch_stem_chain_w16_dev(const ChainArgs<2>* dev, int n, int items, int a_hi, hipStream_t st) {
+  return w16_magic_ok(a_hi) ? launch_w16_dev<true>(dev, n, items, st) : launch_w16_dev<false>(dev, n, items, st);
 }
 
 int qbnn_launch_stem_chain_w16_drop(const ChainArgs<2>& a, const DropSet<5>& dr, hipStream_t st) { return launch_w16_drop<2, 2>(a, dr, st); }
 
 // entry point for qbnn_blocks.hip (declared in qbnn_host.h): 1 to 4 argument blocks in one grid, two images per work item
-int qbnn_launch_stem_chain_w16(const ChainArgs<2>* arr, int n, hipStream_t st) {
+int qbnn_launch_stem_chain_w16(const ChainArgs<2>* arr, int n, int a_hi, hipStream_t st) {
   if (n < 1 || n > 4) return fail(QBNN_E_INVALID, "qbnn_launch_stem_chain_w16: 1 to 4 argument blocks per launch%s");
-  if (n == 1) return launch_w16<2, 2, 1>(arr, 1, st);
-  return launch_w16<2, 2, 4>(arr, n, st);
+  const bool mg = w16_magic_ok(a_hi);
+  if (n == 1) return mg ? launch_w16<2, 2, 1, true>(arr, 1, st) : launch_w16<2, 2, 1, false>(arr, 1, st);
+  return mg ? launch_w16<2, 2, 4, true>(arr, n, st) : launch_w16<2, 2, 4, false>(arr, n, st);
 }

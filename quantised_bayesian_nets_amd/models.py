@@ -529,7 +529,7 @@ class Network(nn.Module):
             if step[0] == "stem":
                 with timed("ensemble stem + layer 1"):
                     if dargs:
-                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 1, B, 32, 24, 2, 1, st))
+                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 1, B, 32, 24, p["a_hi"], 2, 1, st))
                     else:
                         _lib.check(L.qbnn_block_chain_i8_multi(step[1], M, 1, B, 32, 24, p["a_hi"], 2, st))
             elif step[0] == "down":
@@ -541,7 +541,7 @@ class Network(nn.Module):
             else:
                 with timed("ensemble chain %d" % step[3]):
                     if dargs:
-                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 0, B, step[2], step[3], 1, 1, st))
+                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 0, B, step[2], step[3], p["a_hi"], 1, 1, st))
                     else:
                         _lib.check(L.qbnn_block_chain_i8_multi(step[1], M, 0, B, step[2], step[3], p["a_hi"], 1, st))
         with timed("ensemble head"):

@@ -40,7 +40,7 @@ def _pack(layer, w_logical):
 
 def test_library_is_the_hip_one():
     from quantised_bayesian_nets_amd import _lib
-    assert _lib.lib().qbnn_version() >= 1
+    assert _lib.lib().qbnn_version() == _lib.ABI_VERSION
     assert torch.cuda.is_available()
 
 

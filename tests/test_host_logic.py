@@ -23,7 +23,8 @@ def test_c_abi_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(L, sym), sym
     assert set(_lib.EXPORTS) == declared
-    assert L.qbnn_version() >= 1
+    # the loaded library, the header and the ctypes binding agree on the ABI version (a changed prototype bumps all three)
+    assert L.qbnn_version() == _lib.ABI_VERSION == int(re.search(r"#define QBNN_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_errors_without_gpu_are_loud(golden_w8):
