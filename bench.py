@@ -17,6 +17,7 @@ reference algorithm, bit-identical to it on the golden vectors) on this host's c
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -313,7 +314,52 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_probe_child(batch, dev_index):
+    """Child side of the one-rank RCCL probe (`bench.py --rccl-probe-child B DEV`): prints the mean all-reduce time in microseconds."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(dev_index)
+    last = None
+    for _ in range(3):                      # the free-port pick can lose a race: try again with another port
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        try:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, device_id=torch.device("cuda", dev_index))
+            break
+        except Exception as e:              # noqa: BLE001
+            last = e
+    else:
+        raise last
+    mom = torch.zeros((2, batch, 10), dtype=torch.float64, device="cuda")
+    for _ in range(5):
+        dist.all_reduce(mom)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(50):
+        dist.all_reduce(mom)
+    torch.cuda.synchronize()
+    print("RCCL_ONE_RANK_US %.1f" % ((time.perf_counter() - t) / 50 * 1e6), flush=True)
+    dist.destroy_process_group()
+
+
+def rccl_probe_in_child(batch, dev_index, timeout_s=90):
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-probe-child", str(batch), str(dev_index)],
+                           capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return "unavailable: timeout after %d s" % timeout_s
+    for line in r.stdout.splitlines():
+        if line.startswith("RCCL_ONE_RANK_US "):
+            return float(line.split()[1])
+    return "unavailable: child exit %d" % r.returncode
+
+
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--rccl-probe-child":
+        return rccl_probe_child(int(sys.argv[2]), int(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -441,9 +487,15 @@ def main():
         # (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs) -- but ONLY while that file was measured on this very kernel source
         # and workload shape; otherwise null (never a stale number)
         traffic, traffic_note = None, "no PMC summary for this kernel source: run tools/profile_round.sh"
-        tname = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]      # the latest round's
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tpath):
+        # the PMC summary measured on THIS kernel source if there is one, else the latest round's (by round number, not by name order)
+        cands = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_pmc_traffic\.json$", f)),
+                       key=lambda f: int(re.match(r"r(\d+)_", f).group(1)))
+        for f in cands:
+            if json.load(open(os.path.join(ROOT, "profiles", f))).get("kernel_source_sha16") == kernel_source_sha16():
+                cands = [f]
+        tname = cands[-1] if cands else None
+        if tname:
+            tpath = os.path.join(ROOT, "profiles", tname)
             tj = json.load(open(tpath))
             if tj.get("kernel_source_sha16") != kernel_source_sha16():
                 traffic_note = "profiles/%s was measured on an older kernel source" % tname
@@ -518,25 +570,9 @@ def main():
     rccl_one_rank_us = None
     if not use_dist and world == 1 and not a.no_rccl_probe:
         # Multi-GPU readiness on a one-GPU box: the path's one collective (sum all-reduce of the [2, B, C] fp64 moments, 40 KB) through
-        # RCCL with a single rank, timed after everything else -- a reference point for the first 8-GPU run (there is no curve to report here).
-        try:
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, device_id=torch.device("cuda", dev_index))
-            mom = torch.zeros((2, a.batch, 10), dtype=torch.float64, device="cuda")
-            for _ in range(5):
-                dist.all_reduce(mom)
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for _ in range(50):
-                dist.all_reduce(mom)
-            torch.cuda.synchronize()
-            rccl_one_rank_us = round((time.perf_counter() - t) / 50 * 1e6, 1)
-            dist.destroy_process_group()
-        except Exception as e:                                       # noqa: BLE001 -- a probe: report why it did not run
-            rccl_one_rank_us = "unavailable: %s" % type(e).__name__
+        # RCCL with a single rank -- a reference point for the first 8-GPU run (there is no curve to report here).  It runs in a FRESH
+        # CHILD process under a timeout: an RCCL bootstrap that hangs or aborts (no exception to catch) must not cost the bench line.
+        rccl_one_rank_us = rccl_probe_in_child(a.batch, dev_index)
 
     if rank == 0:
         out = {"metric": wl["metric"], "value": round(value, 2), "unit": wl["unit"],

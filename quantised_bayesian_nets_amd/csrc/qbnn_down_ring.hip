@@ -391,7 +391,7 @@ int launch_by_value(const DownArgs* arr, int n, hipStream_t st) {
     if (int rc = ensure_dyn_lds((const void*)block_down_ring_kernel<D, EC, 1>, attr1, D::LDS)) return rc;
     ArgsArr<DownArgs, 1> one;
     one.m[0] = arr[0];
-    hipLaunchKernelGGL((block_down_ring_kernel<D, EC, 1>), dim3(items < 256 ? items : 256), dim3(512), D::LDS, st, one);
+    hipLaunchKernelGGL((block_down_ring_kernel<D, EC, 1>), dim3(items < 256 ? (items > 0 ? items : 1) : 256), dim3(512), D::LDS, st, one);
     return check_launch("qbnn_block_down_i8_mc");
   }
   static_assert(sizeof(ArgsArr<DownArgs, QBNN_FUSED_CALLS>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");

@@ -128,9 +128,12 @@ class _QATBBB(nn.Module):
 
     def sampled_weights(self, dev, eps=None):
         pre = getattr(self, "_presampled", None)
-        if pre is not None and eps is None:          # produced ahead of the activation path on a side stream (presample_weights)
-            self._presampled = None
-            W, ev = pre
+        self._presampled = None
+        # produced ahead of the activation path on a side stream (presample_weights) -- for THIS MC context on THIS device: an entry left
+        # behind by a forward that raised, or drawn under another (samples, seed, first sample index), is dropped, and nothing recorded
+        # outside a capture is waited on inside one
+        if pre is not None and eps is None and pre[2] == _presample_key(dev) and not torch.cuda.is_current_stream_capturing():
+            W, ev = pre[0], pre[1]
             torch.cuda.current_stream().wait_event(ev)
             W.record_stream(torch.cuda.current_stream())
             return W
@@ -166,28 +169,39 @@ class _QATBBB(nn.Module):
         self._folded = None
 
 
-_SIDE_STREAMS = []
+_SIDE_STREAMS = {}          # device index -> side streams
+
+
+def _presample_key(dev):
+    dev = torch.device(dev)
+    return (_MC.samples, _MC.seed, _MC.sample_begin, dev.index if dev.index is not None else torch.cuda.current_device())
 
 
 def presample_weights(layers, dev, n_streams=4):
     """The weight pipelines of all stochastic layers (4 fake-quantisers each: 12 launches of a few microseconds per layer, none of
     which depends on an activation) up front on side streams, so that they run beside the activation path's convs instead of in
     front of each of them.  Each layer's own observers are only touched by its own pipeline: the order across layers is free."""
-    if os.environ.get("QBNN_QAT_PRESAMPLE", "1") == "0" or _MC.eps is not None or torch.cuda.is_current_stream_capturing():
+    from . import layers as _layers
+    if (os.environ.get("QBNN_QAT_PRESAMPLE", "1") == "0" or _MC.eps is not None or torch.cuda.is_current_stream_capturing()
+            or _layers.PROFILE is not None):      # (profiling pairs events on ONE stream: keep everything in line)
+        for m in layers:
+            m._presampled = None
         return
+    key = _presample_key(dev)
     main = torch.cuda.current_stream()
-    while len(_SIDE_STREAMS) < n_streams:
-        _SIDE_STREAMS.append(torch.cuda.Stream())
-    for st in _SIDE_STREAMS[:n_streams]:
+    streams = _SIDE_STREAMS.setdefault(key[3], [])
+    while len(streams) < n_streams:
+        streams.append(torch.cuda.Stream(device=key[3]))
+    for st in streams[:n_streams]:
         st.wait_stream(main)
     for i, m in enumerate(layers):
-        st = _SIDE_STREAMS[i % n_streams]
+        st = streams[i % n_streams]
         with torch.cuda.stream(st):
             m._presampled = None
             W = m.sampled_weights(dev)
             ev = torch.cuda.Event()
             ev.record(st)
-            m._presampled = (W, ev)
+            m._presampled = (W, ev, key)
 
 
 class Conv2d(_QATBBB):

@@ -4,7 +4,9 @@ A fixture's fp32 outputs are compared at 1e-5 relative; what absolute floor goes
 re-runs ITSELF in a child process with `--alt-out FILE` under ALT_ENV (ATen and MKL restricted to their AVX2 kernels instead of
 AVX-512: other vector widths, other summation orders in sgemm / the vectorised pointwise kernels; conv graphs also switch oneDNN off
 inside the generator) and records how far the reference is from itself (`refspread.*` in the fixture).  The tests bound the build's
-deviation by twice that spread."""
+deviation by a small multiple of that spread, stated beside each assertion: twice for the conv graphs (whose two reference runs
+also differ in the conv backend, oneDNN against plain ATen), four times for the MLPs (two runs of the same sgemm on two vector widths:
+the spread of ONE pair of summation orders, and the build's order is a third one)."""
 import os
 import subprocess
 import sys

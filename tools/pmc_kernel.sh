@@ -4,9 +4,9 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc_$TAG
 for v in "$@"; do export "$v"; done
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG/a -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG/b -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG/c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG/a -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-rccl-probe > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG/b -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-rccl-probe > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG/c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-rccl-probe > /dev/null 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -6,11 +6,11 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 rm -rf gpurun_out/final/stats gpurun_out/final/pmc_*
 timeout 300 python3 bench.py --steps 20 --warmup 5 > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > gpurun_out/final/bench_prof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/final/pmc_f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/final/pmc_w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d gpurun_out/final/pmc_a -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/final/pmc_b -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-rccl-probe > gpurun_out/final/bench_prof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/final/pmc_f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-rccl-probe > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/final/pmc_w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-rccl-probe > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d gpurun_out/final/pmc_a -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-rccl-probe > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/final/pmc_b -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-rccl-probe > /dev/null 2>&1
 QBNN_ROUND=$R python3 - <<'PY'
 import csv, glob, collections, json, shutil, hashlib, os
 R = os.environ.get('QBNN_ROUND', 'r04')
