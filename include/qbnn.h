@@ -28,7 +28,8 @@ extern "C" {
 #endif
 
 /* ABI version of this header: qbnn_version() of the loaded library must equal it (bumped whenever a prototype below changes;
- * 2 = round 5: qbnn_block_chain_i8_multi_launch takes a_hi; round 4's `stream` argument of the _multi_prepare calls). */
+ * 2 = round 5: qbnn_block_chain_i8_multi_launch takes a_hi and w_layout, qbnn_block_desc carries w_layout; round 4's `stream` argument
+ * of the _multi_prepare calls). */
 #define QBNN_ABI_VERSION 2
 
 #define QBNN_OK 0
@@ -37,6 +38,7 @@ extern "C" {
 
 #define QBNN_LAYOUT_MFMA32 0    /* [NT][KS][64 lanes][16 B] fragments */
 #define QBNN_LAYOUT_ROWMAJOR 1  /* [Cout][K]                          */
+#define QBNN_LAYOUT_MFMA32_N24 2 /* fragments with 24 output channels (+ a ones row) per tile: the fused 48-channel kernels of round 5 */
 
 /* Scalars of the int8 weight-sampling chain
  *   noise  = quantize_per_tensor(eps, NOISE_SCALE, 0, qint8)      conv_q.py:113-115, linear_q.py:86-88
@@ -157,6 +159,9 @@ typedef struct qbnn_block_desc {
   float s_wb; int32_t z_wb;
   float s_b; int32_t z_b;
   float s_o; int32_t z_o;                                              /* add.add.scale / zero_point                  */
+  int32_t w_layout;                /* packed layout of w_a / w_b (and of a down block's w_s): QBNN_LAYOUT_MFMA32 (0, the default of a zeroed
+                                    * descriptor) or QBNN_LAYOUT_MFMA32_N24 -- 48-channel identity blocks only: selects the 16-wave kernel   */
+  int32_t reserved_;
 } qbnn_block_desc;
 
 int qbnn_block_chain_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x, int32_t z_x, int32_t B, int32_t H,
@@ -258,7 +263,8 @@ size_t qbnn_down_multi_args_bytes(int32_t n_calls);
 int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, int32_t n_calls, int32_t with_stem, int32_t B, int32_t a_hi,
                                       int32_t n_blocks, void* dev_args, void* stream);
 int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t with_stem, int32_t B, int32_t H, int32_t C,
-                                     int32_t a_hi, int32_t n_blocks, int32_t max_samples, void* stream);      /* a_hi: as given to _prepare */
+                                     int32_t a_hi, int32_t w_layout, int32_t n_blocks, int32_t max_samples, void* stream);
+                                     /* a_hi, w_layout: as given to _prepare (w_layout: the calls' blocks[0].w_layout -- one layout per launch) */
 int qbnn_block_down_i8_multi_prepare(const qbnn_down_call* calls, int32_t n_calls, int32_t B, int32_t a_hi, void* dev_args, void* stream);
 int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t max_samples,
                                     void* stream);

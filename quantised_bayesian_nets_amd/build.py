@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-UNITS = ["qbnn_kernels.hip", "qbnn_blocks.hip", "qbnn_down_ring.hip", "qbnn_chain_ring.hip", "qbnn_w16.hip", "qbnn_misc.hip", "qbnn_f32.hip", "qbnn_small.hip"]
+UNITS = ["qbnn_kernels.hip", "qbnn_blocks.hip", "qbnn_down_ring.hip", "qbnn_chain_ring.hip", "qbnn_w16.hip", "qbnn_c48.hip", "qbnn_misc.hip", "qbnn_f32.hip", "qbnn_small.hip"]
 HEADERS = ["qbnn_conv.h", "qbnn_host.h", "qbnn_rng.h", "qbnn_common.h", "qbnn_eps_table.h"]
 SRC = [os.path.join(CSRC, u) for u in UNITS if os.path.exists(os.path.join(CSRC, u))]
 DEPS = SRC + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(os.path.dirname(HERE), "include", "qbnn.h")]
@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(7, len(SRC))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SRC))) as ex:
         objs = list(ex.map(compile_one, SRC))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", LIB]
     if verbose:

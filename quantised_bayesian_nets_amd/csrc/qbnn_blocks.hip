@@ -91,6 +91,7 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
                                       void* stream) {
   if (!x || !y || !d || n_samples <= 0 || B <= 0 || !d->blk.w_a || !d->blk.w_b || !d->w_s)
     return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: bad argument%s");
+  if (d->blk.w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: the down-sampling blocks take MFMA32 weights%s");
   DownArgs a;
   if (int rc = build_down_args(a, x, x_ss, s_x, z_x, B, a_hi, d, y, y_ss, n_samples)) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -1187,10 +1188,18 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
                                 hipStream_t st, const int8_t* stem_x = nullptr, const QConv* stem = nullptr) {
   ChainArgs<NBLK> a;
   if (int rc = build_chain_args<NBLK>(a, x, x_ss, s_x, z_x, B, a_hi, blk, y, y_ss, n_samples, stem_x, stem)) return rc;
+  if (stem && blk[0].w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the 24-channel blocks take MFMA32 weights%s");
   if (stem) {
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
     if constexpr (NBLK == 2) { if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16(&a, 1, a_hi, st); }
     return launch_block_chain_ws<Blk_24, NBLK, true, true>(a, st);
+  }
+  for (int k = 0; k < NBLK; ++k)
+    if (blk[k].w_layout != blk[0].w_layout || (blk[k].w_layout != QBNN_LAYOUT_MFMA32 && blk[k].w_layout != QBNN_LAYOUT_MFMA32_N24))
+      return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one packed weight layout per launch (MFMA32 or MFMA32_N24)%s");
+  if (blk[0].w_layout == QBNN_LAYOUT_MFMA32_N24) {       // the 16-wave 48-channel kernel (qbnn_c48.hip)
+    if constexpr (NBLK == 1) { if (Cc == 48 && H == 16) return qbnn_launch_chain48_w16(&a, 1, st); }
+    return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: the MFMA32_N24 layout serves one 16x16x48 identity block per launch%s");
   }
   if (Cc == 24 && H == 32) return launch_block_chain_ws<Blk_24, NBLK>(a, st);
   if (Cc == 48 && H == 16) {
@@ -1308,7 +1317,7 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, 
 }
 
 QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t with_stem, int32_t B, int32_t H, int32_t Cc,
-                                                 int32_t a_hi, int32_t n_blocks, int32_t max_samples, void* stream) {
+                                                 int32_t a_hi, int32_t w_layout, int32_t n_blocks, int32_t max_samples, void* stream) {
   if (!dev_args || n_calls <= 0 || B <= 0 || max_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: bad argument%s");
   hipStream_t st = (hipStream_t)stream;
   auto items = [&](int G) { return max_samples * ((B + G - 1) / G); };
@@ -1319,6 +1328,11 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n
   }
   if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: one block per call (two only behind the fused stem)%s");
   const ChainArgs<1>* dev = reinterpret_cast<const ChainArgs<1>*>(dev_args);
+  if (w_layout == QBNN_LAYOUT_MFMA32_N24) {
+    if (Cc == 48 && H == 16) return qbnn_launch_chain48_w16_dev(dev, n_calls, items(2), st);
+    return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: the MFMA32_N24 layout serves the 16x16x48 identity block%s");
+  }
+  if (w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: unknown weight layout%s");
   if (Cc == 48 && H == 16) return launch_block_chain_ws_dev<Blk_48, 1>(dev, n_calls, items(Blk_48::G), st);
   if (Cc == 96 && H == 8) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring_dev(dev, n_calls, items(ALD_96::G), 96, false, st) : launch_block_chain_ald_dev<ALD_96, 8>(dev, n_calls, items(ALD_96::G), st);
   if (Cc == 192 && H == 4) {
@@ -1465,7 +1479,15 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi(const qbnn_chain_call* calls, int32_t 
         if (!k.x || !k.blocks || !k.y || k.n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: bad call entry%s");
         if ((rc = build_chain_args<1>(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, nullptr, nullptr))) return rc;
       }
-      if (Cc == 48 && H == 16) rc = launch_block_chain_ws_multi<Blk_48, 1, false, QBNN_FUSED_CALLS>(arr, n, st);
+      bool n24 = false;
+      for (int i = 0; i < n; ++i) {
+        const int lay = calls[c0 + i].blocks[0].w_layout;
+        if (lay != QBNN_LAYOUT_MFMA32 && lay != QBNN_LAYOUT_MFMA32_N24) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: unknown weight layout%s");
+        if (i && (lay == QBNN_LAYOUT_MFMA32_N24) != n24) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: one weight layout per call array%s");
+        n24 = lay == QBNN_LAYOUT_MFMA32_N24;
+      }
+      if (n24 && !(Cc == 48 && H == 16)) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: the MFMA32_N24 layout serves the 16x16x48 identity block%s");
+      if (Cc == 48 && H == 16) rc = n24 ? qbnn_launch_chain48_w16(arr, n, st) : launch_block_chain_ws_multi<Blk_48, 1, false, QBNN_FUSED_CALLS>(arr, n, st);
       else if (Cc == 96 && H == 8) rc = qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring(arr, n, 96, false, st) : launch_block_chain_ald_multi<ALD_96, 8>(arr, n, st);
       else if (Cc == 192 && H == 4) {
         const bool small_items = ((B + 15) / 16) * n <= 128;

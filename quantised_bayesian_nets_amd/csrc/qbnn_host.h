@@ -54,6 +54,10 @@ static int fill_qadd(QAdd& a, const qbnn_conv_desc* d) {
 int qbnn_launch_stem_chain_w16(const ChainArgs<2>* arr, int n, int a_hi, hipStream_t st);
 int qbnn_launch_stem_chain_w16_dev(const ChainArgs<2>* dev, int n, int items, int a_hi, hipStream_t st);               // ... any number of argument blocks in device memory
 int qbnn_launch_stem_chain_w16_drop(const ChainArgs<2>& a, const DropSet<5>& dr, hipStream_t st);      // ... with the five dropouts of conv_resnet_mc
+// 16-wave 48-channel identity block on QBNN_LAYOUT_MFMA32_N24 weights (qbnn_c48.hip, round 5): `n` <= QBNN_FUSED_CALLS argument blocks by
+// value, or any number in device memory
+int qbnn_launch_chain48_w16(const ChainArgs<1>* arr, int n, hipStream_t st);
+int qbnn_launch_chain48_w16_dev(const ChainArgs<1>* dev, int n, int items, hipStream_t st);
 // Ring form of the wide down-sampling blocks (qbnn_down_ring.hip): 48 -> 96 at 16 x 16 and 96 -> 192 at 8 x 8; `n` argument blocks by value
 // (n <= QBNN_FUSED_CALLS) or any number in device memory.  QBNN_DOWN_RING=0 selects the L2-streaming kernels of qbnn_blocks.hip (A/B checks).
 int qbnn_launch_block_down_ring(const DownArgs* arr, int n, int Cin, hipStream_t st);

@@ -58,20 +58,26 @@ QBNN_EXPORT int qbnn_version(void) { return QBNN_ABI_VERSION; }
 //   byte offset = ((nt * KS + ks) * 64 + l) * 16 + b.
 //   Ragged cout (cout % 32 != 0): row n = cout is the "ones row" (1 at every valid k, 0 at pads); the MFMA then
 //       delivers the activation window sum R in that output row for free.
+//   QBNN_LAYOUT_MFMA32_N24 (round 5; cout % 24 == 0): the same with 24 output channels per tile -- tile nt covers channels
+//       [24 nt, 24 nt + 24), row 24 of EVERY tile is a ones row, rows 25..31 are 0.  A 48-channel conv is then two independent
+//       (24 + 1)-row halves: each half's MFMAs deliver its own window sum, so a wave can requantise one half while the other half's
+//       MFMAs are still in flight (qbnn_c48.hip); with the 32-row tiling the window sum of tile 0 lives in tile 1.
 // =====================================================================================
 
-struct PackGeom { int cout, k, krow, rows, rbp, kp, KS, NT; };
-static inline PackGeom pack_geom(int cout, int k, int krow) {
+struct PackGeom { int cout, k, krow, rows, rbp, kp, KS, NT, tr; };      // tr: output channels per tile (32, or 24 for _N24)
+static inline PackGeom pack_geom(int cout, int k, int krow, int layout = QBNN_LAYOUT_MFMA32) {
   PackGeom g;
   g.cout = cout; g.k = k; g.krow = krow; g.rows = k / krow; g.rbp = ceil_div(krow, 32) * 32;
-  g.kp = g.rows * g.rbp; g.KS = g.kp / 32; g.NT = ceil_div(cout, 32);
+  g.tr = layout == QBNN_LAYOUT_MFMA32_N24 ? 24 : 32;
+  g.kp = g.rows * g.rbp; g.KS = g.kp / 32; g.NT = ceil_div(cout, g.tr);
   return g;
 }
+static inline bool is_mfma_layout(int layout) { return layout == QBNN_LAYOUT_MFMA32 || layout == QBNN_LAYOUT_MFMA32_N24; }
 
 QBNN_EXPORT size_t qbnn_packed_weight_bytes(int32_t cout, int32_t k, int32_t krow, int32_t layout) {
   if (layout == QBNN_LAYOUT_ROWMAJOR) return ((size_t)cout * k + 15) / 16 * 16;
-  if (krow <= 0 || k % krow) return 0;
-  const PackGeom g = pack_geom(cout, k, krow);
+  if (!is_mfma_layout(layout) || krow <= 0 || k % krow || (layout == QBNN_LAYOUT_MFMA32_N24 && cout % 24)) return 0;
+  const PackGeom g = pack_geom(cout, k, krow, layout);
   return (size_t)g.NT * g.KS * 1024;
 }
 
@@ -82,16 +88,22 @@ QBNN_EXPORT int qbnn_pack_weights_host(const int8_t* src, int32_t cout, int32_t 
     memcpy(dst, src, (size_t)cout * k);
     return QBNN_OK;
   }
+  if (!is_mfma_layout(layout)) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: unknown layout%s");
   if (krow <= 0 || k % krow) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: k must be a multiple of krow%s");
-  const PackGeom g = pack_geom(cout, k, krow);
+  if (layout == QBNN_LAYOUT_MFMA32_N24 && cout % 24) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: the N24 layout takes cout % 24 == 0%s");
+  const PackGeom g = pack_geom(cout, k, krow, layout);
   memset(dst, 0, (size_t)g.NT * g.KS * 1024);
-  const bool ones = (cout % 32) != 0;
-  for (int n = 0; n < cout + (ones ? 1 : 0); ++n)
-    for (int kk = 0; kk < k; ++kk) {
-      const int kp = (kk / krow) * g.rbp + kk % krow;
-      const int nt = n >> 5, col = n & 31, ks = kp >> 5, half = (kp >> 4) & 1, b = kp & 15;
-      dst[(((size_t)nt * g.KS + ks) * 64 + half * 32 + col) * 16 + b] = n < cout ? src[(size_t)n * k + kk] : (int8_t)1;
-    }
+  auto put = [&](int nt, int col, int kk, int8_t v) {
+    const int kp = (kk / krow) * g.rbp + kk % krow;
+    const int ks = kp >> 5, half = (kp >> 4) & 1, b = kp & 15;
+    dst[(((size_t)nt * g.KS + ks) * 64 + half * 32 + col) * 16 + b] = v;
+  };
+  for (int n = 0; n < cout; ++n)
+    for (int kk = 0; kk < k; ++kk) put(n / g.tr, n % g.tr, kk, src[(size_t)n * k + kk]);
+  for (int kk = 0; kk < k; ++kk) {
+    if (g.tr == 24) { for (int nt = 0; nt < g.NT; ++nt) put(nt, 24, kk, (int8_t)1); }      // a ones row in every tile
+    else if (cout % 32) put(cout >> 5, cout & 31, kk, (int8_t)1);                          // the ones row behind a ragged cout
+  }
   return QBNN_OK;
 }
 
@@ -127,7 +139,7 @@ __device__ __forceinline__ int sample_one_q(int mu_q, int sigma_q, int eps_q, co
 __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
     const v4i* __restrict__ mu, const v4i* __restrict__ sigma, int cout, int K, int krow, int rbp, int KS, int layout,
     int n_chunks, qbnn_sample_params p, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_id, uint32_t sample_begin,
-    const float* __restrict__ eps_in, int8_t* __restrict__ w_out, int64_t w_sample_stride, const uint32_t* __restrict__ nd) {
+    const float* __restrict__ eps_in, int8_t* __restrict__ w_out, int64_t w_sample_stride, const uint32_t* __restrict__ nd, int tr) {
   if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }      // captured-graph mode: the seed lives in device memory
   __shared__ uint32_t eps_tab[256];
   load_eps_table(eps_tab, threadIdx.x);
@@ -135,15 +147,17 @@ __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
   const int chunk = blockIdx.x * 256 + threadIdx.x;
   if (chunk >= n_chunks) return;
   const int s = blockIdx.y;
-  int n = 0, kh = 0, j0 = 0;       // MFMA32: output row, kernel row, first byte within the (padded) kernel row
+  int n = 0, kh = 0, j0 = 0, col = 0;       // MFMA32 (tr = 32) / _N24 (tr = 24): output row, kernel row, first byte within the (padded) kernel row
   if (layout == QBNN_LAYOUT_MFMA32) {
     const int lane = chunk & 63, tile = chunk >> 6;
     const int nt = tile / KS, ks = tile - nt * KS;
-    n = nt * 32 + (lane & 31);
+    col = lane & 31;
+    n = nt * tr + col;
     const int kp0 = ks * 32 + (lane >> 5) * 16;
     kh = kp0 / rbp; j0 = kp0 - kh * rbp;
   }
-  const bool ones_row = (layout == QBNN_LAYOUT_MFMA32) && (cout & 31) && n == cout;
+  const bool ones_row = (layout == QBNN_LAYOUT_MFMA32) && (tr == 24 ? col == 24 : ((cout & 31) && n == cout));
+  const bool real_row = col < tr && n < cout;
   const v4i m4 = mu[chunk], s4 = sigma[chunk];
   int mw[4] = {m4.x, m4.y, m4.z, m4.w}, sw[4] = {s4.x, s4.y, s4.z, s4.w};
   uint32_t ow[4] = {0u, 0u, 0u, 0u};
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
     int64_t idx;
     bool valid;
     if (layout == QBNN_LAYOUT_MFMA32) {
-      valid = (n < cout) && (j0 + j < krow);
+      valid = real_row && (j0 + j < krow);
       idx = (int64_t)n * K + kh * krow + j0 + j;
       if (ones_row && j0 + j < krow) ow[j >> 2] |= 1u << (8 * (j & 3));
     } else {
@@ -191,19 +205,21 @@ QBNN_EXPORT int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* si
                                        int8_t* w_out, int64_t w_sample_stride, void* stream) {
   if (!mu_packed || !sigma_packed || !hp || !w_out || cout <= 0 || k <= 0 || n_samples <= 0)
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: bad argument%s");
-  if (layout != QBNN_LAYOUT_MFMA32 && layout != QBNN_LAYOUT_ROWMAJOR)
+  if (!is_mfma_layout(layout) && layout != QBNN_LAYOUT_ROWMAJOR)
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: unknown layout%s");
-  if (layout == QBNN_LAYOUT_MFMA32 && (krow <= 0 || k % krow))
+  if (is_mfma_layout(layout) && (krow <= 0 || k % krow))
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: k must be a multiple of krow%s");
+  if (layout == QBNN_LAYOUT_MFMA32_N24 && cout % 24) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: the N24 layout takes cout % 24 == 0%s");
   const size_t bytes = qbnn_packed_weight_bytes(cout, k, krow, layout);
   if ((size_t)w_sample_stride < bytes || (w_sample_stride & 15))
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: w_sample_stride too small or not 16-byte aligned%s");
   const int n_chunks = (int)(bytes / 16);
-  PackGeom g = pack_geom(cout, k, layout == QBNN_LAYOUT_MFMA32 ? krow : k);
+  PackGeom g = pack_geom(cout, k, is_mfma_layout(layout) ? krow : k, layout);
   dim3 grid(ceil_div(n_chunks, 256), n_samples);
+  // (inside the kernels both fragment layouts are "MFMA32" with g.tr channels per tile)
   hipLaunchKernelGGL(sample_weights_i8_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                     (const v4i*)mu_packed, (const v4i*)sigma_packed, cout, k, g.krow, g.rbp, g.KS, layout, n_chunks, *hp,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out, w_sample_stride, g_noise_dev);
+                     (const v4i*)mu_packed, (const v4i*)sigma_packed, cout, k, g.krow, g.rbp, g.KS, is_mfma_layout(layout) ? QBNN_LAYOUT_MFMA32 : layout, n_chunks, *hp,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out, w_sample_stride, g_noise_dev, g.tr);
   return check_launch("qbnn_sample_weights_i8");
 }
 
@@ -211,11 +227,13 @@ QBNN_EXPORT int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* si
 #define QBNN_MAX_SAMPLER_LAYERS 24
 struct SamplerLayer {
   const v4i* mu; const v4i* sigma; int8_t* out; int64_t out_ss;
-  int cout, K, krow, rbp, KS, layout, n_chunks, chunk_begin;     // chunk_begin: first 256-thread block of this layer
+  int cout, K, krow, rbp, KS, layout, n_chunks, chunk_begin;     // chunk_begin: first 256-thread block of this layer; layout: MFMA32 (both fragment layouts) or ROWMAJOR
+  int tr;                                                          // output channels per fragment tile: 32, or 24 (QBNN_LAYOUT_MFMA32_N24)
   uint32_t layer_id;
   qbnn_sample_params p;
 };
 struct SamplerTable { SamplerLayer l[QBNN_MAX_SAMPLER_LAYERS]; int n; };
+static_assert(sizeof(SamplerTable) <= 3968, "the sampler table travels as a kernel argument (4 KiB incl. the other arguments)");
 
 #define QBNN_SAMPLER_NS 4           // MC samples per thread: the chunk's mu / sigma are loaded, unpacked and dequantised once for all of them
 // UNALIGNED: the kernel of the layers whose chunks are not aligned to Philox blocks (K or the kernel-row length no multiple of 4) and are
@@ -235,15 +253,17 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
   const int chunk = ((int)blockIdx.x - L.chunk_begin) * 256 + threadIdx.x;
   if (chunk >= L.n_chunks) return;
   const int s0 = blockIdx.y * QBNN_SAMPLER_NS;
-  int n = 0, kh = 0, j0 = 0;
+  int n = 0, kh = 0, j0 = 0, col = 0;
   if (L.layout == QBNN_LAYOUT_MFMA32) {
     const int lane = chunk & 63, tile = chunk >> 6;
     const int nt = tile / L.KS, ks = tile - nt * L.KS;
-    n = nt * 32 + (lane & 31);
+    col = lane & 31;
+    n = nt * L.tr + col;
     const int kp0 = ks * 32 + (lane >> 5) * 16;
     kh = kp0 / L.rbp; j0 = kp0 - kh * L.rbp;
   }
-  const bool ones_row = (L.layout == QBNN_LAYOUT_MFMA32) && (L.cout & 31) && n == L.cout;
+  const bool ones_row = (L.layout == QBNN_LAYOUT_MFMA32) && (L.tr == 24 ? col == 24 : ((L.cout & 31) && n == L.cout));
+  const bool real_row = col < L.tr && n < L.cout;
   const v4i m4 = L.mu[chunk], s4 = L.sigma[chunk];
   int mw[4] = {m4.x, m4.y, m4.z, m4.w}, sw[4] = {s4.x, s4.y, s4.z, s4.w};
   const int64_t total = (int64_t)L.cout * L.K;
@@ -276,7 +296,7 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         if (ones_row && j0 + 4 * g < L.krow) ow[g] = 0x01010101u;
-        if (n < L.cout && j0 + 4 * g < L.krow) {
+        if (real_row && j0 + 4 * g < L.krow) {
           const qbnn::u32x4 r4 = qbnn::philox4x32_10((uint32_t)((idx0 >> 2) + g), L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi);
           const uint32_t uu[4] = {r4.x, r4.y, r4.z, r4.w};
           float f[4];
@@ -313,7 +333,7 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
     }
     const int64_t idx0 = (int64_t)n * L.K + kh * L.krow + j0;
     const int sh = (int)(idx0 & 3);
-    const int nvalid = n < L.cout ? min(max(L.krow - j0, 0), 16) : 0;       // valid bytes of the chunk: 0 .. nvalid - 1
+    const int nvalid = real_row ? min(max(L.krow - j0, 0), 16) : 0;       // valid bytes of the chunk: 0 .. nvalid - 1
     const int nones = ones_row ? min(max(L.krow - j0, 0), 16) : 0;
 #pragma unroll 1
     for (int ss = 0; ss < QBNN_SAMPLER_NS; ++ss) {
@@ -357,7 +377,7 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
       int64_t idx;
       bool valid;
       if (L.layout == QBNN_LAYOUT_MFMA32) {
-        valid = (n < L.cout) && (j0 + j < L.krow);
+        valid = real_row && (j0 + j < L.krow);
         idx = (int64_t)n * L.K + kh * L.krow + j0 + j;
         if (ones_row && j0 + j < L.krow) ow[j >> 2] |= 1u << (8 * (j & 3));
       } else {
@@ -393,18 +413,21 @@ QBNN_EXPORT int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* layers, i
     const qbnn_sampler_layer& q = layers[i];
     if (!q.mu_packed || !q.sigma_packed || !q.w_out || q.cout <= 0 || q.k <= 0)
       return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: bad layer entry%s");
-    if (q.layout == QBNN_LAYOUT_MFMA32 && (q.krow <= 0 || q.k % q.krow))
+    const bool frag = is_mfma_layout(q.layout);
+    if (!frag && q.layout != QBNN_LAYOUT_ROWMAJOR) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: unknown layout%s");
+    if (frag && (q.krow <= 0 || q.k % q.krow))
       return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: k must be a multiple of krow%s");
+    if (q.layout == QBNN_LAYOUT_MFMA32_N24 && q.cout % 24) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: the N24 layout takes cout % 24 == 0%s");
     const size_t bytes = qbnn_packed_weight_bytes(q.cout, q.k, q.krow, q.layout);
     if ((size_t)q.w_sample_stride < bytes || (q.w_sample_stride & 15))
       return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: w_sample_stride too small or unaligned%s");
-    const PackGeom g = pack_geom(q.cout, q.k, q.layout == QBNN_LAYOUT_MFMA32 ? q.krow : q.k);
-    const bool unaligned = q.layout == QBNN_LAYOUT_MFMA32 && ((q.k | g.krow) & 3) != 0 && bytes / 16 >= 4096;
+    const PackGeom g = pack_geom(q.cout, q.k, frag ? q.krow : q.k, q.layout);
+    const bool unaligned = frag && ((q.k | g.krow) & 3) != 0 && bytes / 16 >= 4096;
     SamplerTable& tt = unaligned ? tu : t;
     int& bb = unaligned ? blocks_u : blocks;
     SamplerLayer& L = tt.l[tt.n++];
     L.mu = (const v4i*)q.mu_packed; L.sigma = (const v4i*)q.sigma_packed; L.out = q.w_out; L.out_ss = q.w_sample_stride;
-    L.cout = q.cout; L.K = q.k; L.krow = g.krow; L.rbp = g.rbp; L.KS = g.KS; L.layout = q.layout;
+    L.cout = q.cout; L.K = q.k; L.krow = g.krow; L.rbp = g.rbp; L.KS = g.KS; L.layout = frag ? QBNN_LAYOUT_MFMA32 : q.layout; L.tr = g.tr;
     L.n_chunks = (int)(bytes / 16); L.chunk_begin = bb; L.layer_id = q.layer_id; L.p = q.params;
     bb += ceil_div(L.n_chunks, 256);
   }

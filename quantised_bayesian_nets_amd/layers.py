@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import _lib
 from .quant import INT_BOUNDS, UINT_BOUNDS, make_sample_params
 
-LAYOUT_MFMA32, LAYOUT_ROWMAJOR = 0, 1
+LAYOUT_MFMA32, LAYOUT_ROWMAJOR, LAYOUT_MFMA32_N24 = 0, 1, 2      # include/qbnn.h: QBNN_LAYOUT_*
 
 # State epoch: bumped whenever device-side parameter images may be dropped or replaced (a state dict loaded into any layer, a packed
 # layout switched).  A captured HIP graph holds raw pointers to those images; mc.GraphedPredictor records the epoch at capture and
@@ -430,6 +430,9 @@ class Conv2d(_BBBInt8):
             ks, st, pd = self.kernel_size[0], self.stride[0], self.padding[0]
             Ho, Wo = (H + 2 * pd - ks) // st + 1, (W + 2 * pd - ks) // st + 1
             return self._generic(x, w, S, H, W, Cin, self.out_channels, ks, st, pd, (B, Ho, Wo, self.out_channels))
+        if self.layout != LAYOUT_MFMA32:
+            raise RuntimeError("the layer-level conv kernel takes MFMA32 weights: this layer is packed for a fused block kernel "
+                               "(the model switches layouts per path: ConvNetwork_ResNet._apply_layouts)")
         pk = self._ensure_packed(x.data.device)
         _, B, H, W, Cin = x.data.shape
         ks, st, pd = self.kernel_size[0], self.stride[0], self.padding[0]

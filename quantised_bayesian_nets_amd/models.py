@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .layers import Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_context, timed, sample_all_weights
+from .layers import LAYOUT_MFMA32, LAYOUT_MFMA32_N24, Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_context, timed, sample_all_weights
 from .quant import UINT_BOUNDS, check_bits
 
 
@@ -70,6 +70,8 @@ def _fill_block_desc(d, blk, dev, keep):
     d.w_b, d.w_b_sample_stride, d.bias_b = wb.data_ptr(), wb.shape[1], (pb["bias"].data_ptr() if pb["bias"] is not None else None)
     d.s_wb, d.z_wb, d.s_b, d.z_b = cb.add_weight.scale, cb.add_weight.zero_point, cb.scale, cb.zero_point
     d.s_o, d.z_o = blk.add.add.scale, blk.add.add.zero_point
+    assert ca.layout == cb.layout, "a block's two convs share one packed layout"
+    d.w_layout = ca.layout
 
 
 def run_down_block(blk, x):
@@ -125,6 +127,8 @@ def run_identity_chain(blocks, x, stem=None):
         d.w_b, d.w_b_sample_stride, d.bias_b = wb.data_ptr(), wb.shape[1], (pb["bias"].data_ptr() if pb["bias"] is not None else None)
         d.s_wb, d.z_wb, d.s_b, d.z_b = cb.add_weight.scale, cb.add_weight.zero_point, cb.scale, cb.zero_point
         d.s_o, d.z_o = blk.add.add.scale, blk.add.add.zero_point
+        assert ca.layout == cb.layout, "a block's two convs share one packed layout"
+        d.w_layout = ca.layout
     a_hi = UINT_BOUNDS[blocks[0].args.activation_precision][1]
     nw = lambda l: l._packed["cout"] * l._packed["k"]
     if stem is not None:
@@ -208,6 +212,16 @@ class ConvNetwork_ResNet(nn.Module):
             self.in_planes = planes * BasicBlock.expansion
         return nn.ModuleList(blocks)
 
+    def _apply_layouts(self, fused):
+        """Packed weight layouts per execution path.  The fused 16-wave kernel of the 48-channel identity block (csrc/qbnn_c48.hip) takes
+        its two convs as (24 + 1)-row tile halves (QBNN_LAYOUT_MFMA32_N24); the layer-level conv kernel -- the recording / un-fused path --
+        and every other fused kernel take MFMA32.  A switch re-packs mu / sigma once (layers.set_layout).  QBNN_C48=0: MFMA32 everywhere
+        (the round-4 ping-pong / weights-stationary kernels, for A/B checks)."""
+        n24 = fused and os.environ.get("QBNN_C48", "1") != "0"
+        blk = self.layers[4][1]
+        for c in (blk.stem[0], blk.stem[3]):
+            c.set_layout(LAYOUT_MFMA32_N24 if n24 else LAYOUT_MFMA32)
+
     def stochastic_layers(self):
         out = [self.layers[0]]
         for li in (3, 4, 5, 6):
@@ -263,6 +277,7 @@ class ConvNetwork_ResNet(nn.Module):
         if x.dim() != 4 or tuple(x.shape[1:]) != (3, 32, 32):
             raise NotImplementedError("conv_resnet_bbb expects 3x32x32 inputs")
         l0 = self.layers[0]
+        self._apply_layouts(self.fuse_blocks and record is None)
         fuse_stem = self.fuse_blocks and self.fuse_stem and record is None and len(self.layers[3][0].shortcut) == 0
         B, Cc, H, W = x.shape
         col = torch.empty((B, H * W, 32), dtype=torch.int8, device=dev)
@@ -392,7 +407,9 @@ class Network(nn.Module):
         if record is not None or not self.use_graphs or self.regression or _layers.PROFILE is not None or x.device.type != "cuda":
             with mc_context(1, 0, 0):
                 return member.forward_mc(x, record=record)
-        key = (idx, tuple(x.shape), x.dtype, x.device.index)
+        from .layers import state_epoch
+        # (the epoch: a layout switch or a reloaded state drops the packed weights a captured chain points at)
+        key = (idx, tuple(x.shape), x.dtype, x.device.index, state_epoch())
         ent = self._graphs.get(key)
         if ent is None:
             with mc_context(1, 0, 0):
@@ -421,12 +438,15 @@ class Network(nn.Module):
     # ---- members side by side: one fused multi-call launch per layer group (qbnn_*_multi) instead of ~12 launches per member
     def _member_plan(self, idx, B, dev):
         """Static buffers + the call arrays of the fused launches for members `idx` at batch B (built once, replayed)."""
-        key = (tuple(idx), B, dev.index)
+        from .layers import state_epoch
+        mem = [self.ensemble[j] for j in idx]
+        for m in mem:
+            m._apply_layouts(True)
+        key = (tuple(idx), B, dev.index, state_epoch())      # (the epoch: see _member_forward)
         plan = self._plans.get(key)
         if plan is not None:
             return plan
         M, L = len(idx), _lib.lib()
-        mem = [self.ensemble[j] for j in idx]
         a_hi = UINT_BOUNDS[self.args.activation_precision][1]
         keep = []
         u8 = lambda *shape: torch.empty(shape, dtype=torch.uint8, device=dev)
@@ -529,7 +549,7 @@ class Network(nn.Module):
             if step[0] == "stem":
                 with timed("ensemble stem + layer 1"):
                     if dargs:
-                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 1, B, 32, 24, p["a_hi"], 2, 1, st))
+                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 1, B, 32, 24, p["a_hi"], 0, 2, 1, st))
                     else:
                         _lib.check(L.qbnn_block_chain_i8_multi(step[1], M, 1, B, 32, 24, p["a_hi"], 2, st))
             elif step[0] == "down":
@@ -541,7 +561,7 @@ class Network(nn.Module):
             else:
                 with timed("ensemble chain %d" % step[3]):
                     if dargs:
-                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 0, B, step[2], step[3], p["a_hi"], 1, 1, st))
+                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 0, B, step[2], step[3], p["a_hi"], step[1][0].blocks[0].w_layout, 1, 1, st))
                     else:
                         _lib.check(L.qbnn_block_chain_i8_multi(step[1], M, 0, B, step[2], step[3], p["a_hi"], 1, st))
         with timed("ensemble head"):

@@ -998,7 +998,8 @@ print("SWITCH-OK")
 """
 
 
-@pytest.mark.parametrize("switch", ["QBNN_NO_PINGPONG", "QBNN_NO_STEM_FUSION", "QBNN_GENERIC_NAIVE", "QBNN_W16=0", "QBNN_DOWN_RING=0", "QBNN_CHAIN_RING=0"])
+@pytest.mark.parametrize("switch", ["QBNN_NO_PINGPONG", "QBNN_NO_STEM_FUSION", "QBNN_GENERIC_NAIVE", "QBNN_W16=0", "QBNN_DOWN_RING=0", "QBNN_CHAIN_RING=0",
+                                    "QBNN_C48=0", "QBNN_W16_MAGIC=0"])
 def test_environment_switches_give_the_same_results(switch, tmp_path):
     """The A/B switches of README.md select other kernels for the same arithmetic (weights-stationary instead of ping-pong
     48-channel block; layers.0 as its own launch; the scalar any-geometry conv; the 8-wave layer-1 kernel instead of the 16-wave one; the round-3 forms of the wide down-sampling and identity blocks):
@@ -1594,18 +1595,18 @@ def test_lenet_mc_full_sample_count_against_oracle(golden_lenet_mc):
     np.testing.assert_allclose(mean, ref.astype(np.float64).mean(0), rtol=RTOL, atol=1e-8)
 
 
-def _pack_per_sample(L, w):
-    """int8 [S, Cout, KH, KW, Cin] -> QBNN_LAYOUT_MFMA32 fragments [S, nbytes] on the device (krow as layers.Conv2d chooses it)."""
+def _pack_per_sample(L, w, layout=0):
+    """int8 [S, Cout, KH, KW, Cin] -> QBNN_LAYOUT_MFMA32 (0) / _MFMA32_N24 (2) fragments [S, nbytes] on the device (krow as layers.Conv2d chooses it)."""
     import ctypes as C
     from quantised_bayesian_nets_amd import _lib
     S, cout, kh, kw, cin = w.shape
     k = kh * kw * cin
     krow = kw * cin if cin % 8 == 0 else k
-    nb = L.qbnn_packed_weight_bytes(cout, k, krow, 0)
+    nb = L.qbnn_packed_weight_bytes(cout, k, krow, layout)
     out = np.zeros((S, nb), np.int8)
     for s in range(S):
         src = np.ascontiguousarray(w[s].reshape(cout, k))
-        _lib.check(L.qbnn_pack_weights_host(src.ctypes.data_as(C.c_void_p), cout, k, krow, 0, out[s].ctypes.data_as(C.c_void_p)))
+        _lib.check(L.qbnn_pack_weights_host(src.ctypes.data_as(C.c_void_p), cout, k, krow, layout, out[s].ctypes.data_as(C.c_void_p)))
     return torch.from_numpy(out).cuda(), nb
 
 
@@ -1706,6 +1707,15 @@ def test_fused_blocks_random_qparams_against_oracle(seed):
             torch.cuda.synchronize()
             got = y.cpu().numpy()
             assert np.array_equal(got, ref), (Cc, down, a_hi, int((got != ref).sum()))
+            if Cc == 48 and not down:
+                # round 5: the same block on the 16-wave kernel (csrc/qbnn_c48.hip) -- weights as (24 + 1)-row tile halves (MFMA32_N24)
+                wa2, nba2 = _pack_per_sample(L, wa, 2)
+                wb2, nbb2 = _pack_per_sample(L, wb, 2)
+                blk.w_a, blk.w_a_sample_stride, blk.w_b, blk.w_b_sample_stride, blk.w_layout = wa2.data_ptr(), nba2, wb2.data_ptr(), nbb2, 2
+                y2 = torch.full((S, B, Ho, Ho, Co), 0xEE, dtype=torch.uint8, device="cuda")
+                _lib.check(L.qbnn_block_chain_i8_mc(_lib.ptr(xd), xd[0].numel(), s_x, z_x, B, Hi, Ci, a_hi, C.byref(blk), 1, _lib.ptr(y2), y2[0].numel(), S, st))
+                torch.cuda.synchronize()
+                assert np.array_equal(y2.cpu().numpy(), ref), ("N24", a_hi, int((y2.cpu().numpy() != ref).sum()))
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
@@ -2177,3 +2187,107 @@ def test_float_bbb_mlp_every_input_width(golden_mlp_f32_width, layerwise, monkey
     np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=1e-5, atol=g["mu_atol"])
     pv_err = np.abs(pv.cpu().numpy().astype(np.float64) - g["pred_var"])
     assert (pv_err <= 1e-5 * np.abs(g["pred_var"]) + pred_var_atol(g["mu"], g["mu_atol"]).reshape(g["pred_var"].shape)).all(), pv_err.max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 5: parity at the sizes bench.py times (verdict round 4, item 4) -- every secondary workload has an oracle check at its bench size
+@pytest.mark.gpu
+@pytest.mark.parametrize("qseed", [None, 3])
+def test_resnet_mc_int8_bench_size_against_oracle(qseed):
+    """`conv_resnet_mc` int8 at the size `bench.py --workload resnet_mc` times (B = 256): the DROP instantiations of every fused block
+    kernel -- the 16-wave layer-1 kernel, the weights-stationary 24 -> 48 block and 48-channel chain, the wide down blocks, the ring
+    chains with their one-bit mask tables -- on full work-item ranges, one MC sample at a global index beyond the first launch's
+    against the CPU oracle (Int8ResNetMCOracle, pinned to the reference by tests/golden/make_golden_resnet_mc.py).  qseed: the same with
+    random output scales / zero points of every conv, mask and Add (the reference-calibrated ones sit in a narrow band).
+    Probabilities at 1e-5 relative: the integer path is bit-exact, the softmax is fp32 on both sides."""
+    import quantised_bayesian_nets_amd as q
+    from conftest import load_golden
+    from oracle import oracle as orc
+    g = load_golden("resnet_mc_a7w8.npz")
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, p=g["meta"]["p"])
+    state = g["state"] if qseed is None else _perturb_activation_qparams(g["state"], qseed)
+    m = q.ModelFactory.get_model("conv_resnet_mc", [1, 3, 32, 32], 10, True, args).load_reference_state(state)
+    x = torch.randn(256, 3, 32, 32, generator=torch.Generator().manual_seed(31))
+    seed, first, S = 77, 40, 3
+    assert m._can_fuse_blocks(x.cuda(), None)
+    with q.mc_context(S, seed, first):
+        p = m.forward_mc(x.cuda()).cpu().numpy()
+    net = orc.Int8ResNetMCOracle(state, 7)
+    for s in (0, S - 1):
+        np.testing.assert_allclose(p[s], net.forward(x.numpy(), seed, first + s), rtol=RTOL, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_resnet_mc_f32_bench_size_against_oracle():
+    """The float MC-Dropout ResNet at the size `bench.py --workload resnet_mc_f32` times (B = 256): one MC sample against the oracle's
+    fp32 forward with fp64 accumulation (F32MCOracle.resnet), 1e-5 relative + twice the reference's own oneDNN-vs-ATen spread recorded in
+    the fixture (the tolerance of test_float_mc_dropout_graphs_match_reference)."""
+    import quantised_bayesian_nets_amd as q
+    from conftest import _npz
+    from oracle import oracle as orc
+    g = _npz("resnet_mc_f32.npz")
+    m = q.ModelFactory.get_model("conv_resnet_mc", [1, 3, 32, 32], 10, False, types.SimpleNamespace(p=g["meta"]["p"])).load_reference_state(g["state"])
+    x = torch.randn(256, 3, 32, 32, generator=torch.Generator().manual_seed(33))
+    seed = g["meta"]["philox_seed"]
+    with q.mc_context(2, seed, 8):
+        p = m.forward_mc(x.cuda())
+    atol = 2 * g["refspread"]["max_abs"] + 1e-7
+    np.testing.assert_allclose(p[1].cpu().numpy(), orc.F32MCOracle(g["state"]).resnet(x.numpy(), seed, 9), rtol=RTOL, atol=atol)
+
+
+@pytest.mark.gpu
+def test_lenet_bbb_bench_size_every_sample_against_oracle(golden_lenet_bbb):
+    """The int8 BBB LeNet at the size `bench.py --workload lenet_bbb` times: B = 128, S = 100 (global sample indices 0..99) on its fast
+    path (the sampler writing the fragment layouts, the one-MFMA conv 1, the fused 20 -> 50 conv, the int8 GEMMs), EVERY sample's
+    probabilities against the oracle, as test_lenet_mc_full_sample_count_against_oracle does for config 1."""
+    import quantised_bayesian_nets_amd as q
+    from oracle import oracle as orc
+    g = golden_lenet_bbb
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8)
+    m = q.ModelFactory.get_model("conv_lenet_bbb", [1, 1, 28, 28], 10, True, args).load_reference_state(g["state"])
+    S, seed = 100, 4321
+    x = torch.rand(128, 1, 28, 28, generator=torch.Generator().manual_seed(35))
+    assert m._can_run_fast(x.cuda(), None)
+    with q.mc_context(S, seed, 0):
+        p = m.forward_mc(x.cuda()).cpu().numpy()
+    net = orc.Int8LeNetBBBOracle(g["state"], 7, 8)
+    ref = np.stack([net.forward(x.numpy(), seed, s) for s in range(S)])
+    np.testing.assert_allclose(p, ref, rtol=RTOL, atol=1e-8)
+    mean = q.mc_predict(m, x.cuda(), S, seed).cpu().numpy()
+    np.testing.assert_allclose(mean, ref.astype(np.float64).mean(0), rtol=RTOL, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_sampler_n24_layout_draws_the_same_weights(golden_w8):
+    """The weight sampler writing QBNN_LAYOUT_MFMA32_N24 fragments (the 16-wave 48-channel kernel's operand) draws the SAME weight for
+    every logical element (n, k) as in the MFMA32 layout -- the Philox counter is the element's index in the reference's OHWI order, not
+    its position in a layout -- single-layer and all-layers-in-one-launch entry points, W8 and W4, a sample range across 256."""
+    import quantised_bayesian_nets_amd as q
+    from quantised_bayesian_nets_amd import layers as ql
+    for w_bits in (8, 4):
+        args = types.SimpleNamespace(activation_precision=7, weight_precision=w_bits)
+        m = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args).load_reference_state(golden_w8["state"])
+        layer = m.layers[4][1].stem[3]          # 48 -> 48, 3x3
+        cout, k, krow = 48, 432, 144
+        KS = 3 * 160 // 32
+
+        def logical(w, tr):
+            f = w.cpu().numpy().reshape(w.shape[0], 48 // tr if tr == 24 else 2, KS, 2, 32, 16)
+            dense = f.transpose(0, 1, 4, 2, 3, 5).reshape(w.shape[0], -1, 32, KS * 32)      # [S][tile][row][padded k]
+            kp = (np.arange(k) // krow) * 160 + np.arange(k) % krow
+            return np.stack([dense[:, n // tr, n % tr][:, kp] for n in range(cout)], axis=1), dense
+        got = {}
+        for layout, tr in ((ql.LAYOUT_MFMA32, 32), (ql.LAYOUT_MFMA32_N24, 24)):
+            layer.set_layout(layout)
+            with q.mc_context(5, 77, 254):
+                one = layer.sample_weights(torch.device("cuda"))
+                ql.sample_all_weights([layer], torch.device("cuda"))
+                multi = layer.sample_weights(torch.device("cuda"))
+            assert torch.equal(one, multi)
+            got[layout], dense = logical(one, tr)
+            if tr == 24:
+                assert (dense[:, :, 24].max() == 1) and not dense[:, :, 25:].any()
+        assert np.array_equal(got[ql.LAYOUT_MFMA32], got[ql.LAYOUT_MFMA32_N24])
+        lo, hi = (-8, 7) if w_bits == 4 else (-128, 127)
+        assert got[ql.LAYOUT_MFMA32].min() >= lo and got[ql.LAYOUT_MFMA32].max() <= hi
+        layer.set_layout(ql.LAYOUT_MFMA32)

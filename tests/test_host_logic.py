@@ -248,3 +248,34 @@ def test_bench_self_launches_eight_ranks_with_the_baseline_partitions():
     by_rank = sorted(out["shards"], key=lambda d: d["rank"])
     assert [d["samples_1024"] for d in by_rank] == [[128 * r, 128] for r in range(8)]
     assert [d["members_16"] for d in by_rank] == [[2 * r, 2] for r in range(8)]
+
+
+def test_n24_packed_layout_places_every_weight_and_a_ones_row_per_tile():
+    """QBNN_LAYOUT_MFMA32_N24 (include/qbnn.h, round 5): 24 output channels + a ones row per fragment tile.  Host packing only (no GPU):
+    every logical weight sits at tile n // 24, row n % 24 of the layout's (ks, k-half, byte) position, row 24 of EVERY tile is 1 at the
+    valid k positions, rows 25..31 and the kernel-row pads are 0 -- and the MFMA32 form of the same weights differs only in the tiling."""
+    import ctypes as C
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    cout, cin, ksz = 48, 48, 3
+    k, krow = ksz * ksz * cin, ksz * cin
+    w = rng.integers(-128, 128, (cout, k), dtype=np.int8)
+    nb = L.qbnn_packed_weight_bytes(cout, k, krow, 2)
+    rbp = (krow + 31) // 32 * 32
+    KS = ksz * rbp // 32
+    assert nb == 2 * KS * 1024 == L.qbnn_packed_weight_bytes(cout, k, krow, 0)
+    out = np.zeros(nb, np.int8)
+    _lib.check(L.qbnn_pack_weights_host(w.ctypes.data_as(C.c_void_p), cout, k, krow, 2, out.ctypes.data_as(C.c_void_p)))
+    frag = out.reshape(2, KS, 2, 32, 16)          # [tile][k-step][k-half][row][byte]
+    dense = frag.transpose(0, 3, 1, 2, 4).reshape(2, 32, KS * 32)      # [tile][row][padded k]
+    kp = (np.arange(k) // krow) * rbp + np.arange(k) % krow
+    for n in range(cout):
+        assert np.array_equal(dense[n // 24, n % 24, kp], w[n]), n
+    valid = np.zeros(KS * 32, bool)
+    valid[kp] = True
+    for t in range(2):
+        assert np.array_equal(dense[t, 24], valid.astype(np.int8))
+        assert not dense[t, 25:].any() and not dense[t, :24][:, ~valid].any()
+    assert L.qbnn_packed_weight_bytes(40, k, krow, 2) == 0            # cout % 24 != 0: not an N24 shape
+    assert L.qbnn_pack_weights_host(w.ctypes.data_as(C.c_void_p), 40, k, krow, 2, out.ctypes.data_as(C.c_void_p)) != 0
