@@ -1386,7 +1386,7 @@ static int chain_drop_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_
   }
   if constexpr (STEM) {
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_drop_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
-    if constexpr (NBLK == 2) { if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16_drop(a, dr, st); }
+    if constexpr (NBLK == 2) { if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16_drop(a, dr, a_hi, st); }
     return launch_block_chain_ws_drop<Blk_24, NBLK, true>(a, dr, st);
   } else {
     if (Cc == 24 && H == 32) return launch_block_chain_ws_drop<Blk_24, NBLK, false>(a, dr, st);
@@ -1445,8 +1445,9 @@ QBNN_EXPORT int qbnn_block_down_drop_i8_mc(const uint8_t* x, int64_t x_ss, float
   if (int rc = fill_drop(dr.d[2], drops[2], d->s_s, a_hi, seed, sample_begin)) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (Cin == 24 && H == 32) return launch_block_down_ws_drop<D24_a, D24_s, D24_b, true, false>(a, dr, st);
-  if (Cin == 48 && H == 16) return launch_block_down_ws_drop<D48_a, D48_s, D48_b, false, false>(a, dr, st);
-  if (Cin == 96 && H == 8) return launch_block_down_ws_drop<D96_a, D96_s, D96_b, false, true>(a, dr, st);
+  // 48 -> 96 and 96 -> 192: the ring form with one-bit mask tables (round 5); QBNN_DOWN_RING=0: the per-wave L2-streaming kernels
+  if (Cin == 48 && H == 16) return qbnn_use_down_ring() ? qbnn_launch_block_down_ring_drop(a, dr, 48, st) : launch_block_down_ws_drop<D48_a, D48_s, D48_b, false, false>(a, dr, st);
+  if (Cin == 96 && H == 8) return qbnn_use_down_ring() ? qbnn_launch_block_down_ring_drop(a, dr, 96, st) : launch_block_down_ws_drop<D96_a, D96_s, D96_b, false, true>(a, dr, st);
   return fail(QBNN_E_INVALID, "qbnn_block_down_drop_i8_mc: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
 }
 

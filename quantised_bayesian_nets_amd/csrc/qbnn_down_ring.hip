@@ -152,10 +152,27 @@ __device__ __forceinline__ void epi_presub(const float* bias_lds, const QConv& p
   conv_epi_phase_with<EC, Epi, decltype(ld), decltype(none), true>(bias_lds, p, epi, A, wave, lane, ld, none);
 }
 
-template <class D, class EC, int NM>
+// DROP (conv_resnet_mc, round 5): a quantised channel dropout behind every conv -- dr.d = stem.3 (behind stem.0), stem.6 (behind the second
+// conv: the Add's first operand), shortcut.2 (behind the shortcut conv: its second) -- applied in the epilogues (EpiDenseTileDrop / EpiDenseDrop of
+// block_down_ws_kernel's DROP form) from ONE-BIT mask tables: a Bernoulli mask has two quantised values, 3 dropouts x G images x COUT channels are
+// 144 / 576 bytes per work item.  At 48 -> 96 they have LDS of their own and are drawn at the top of the item; the 96 -> 192 configuration
+// uses all 160 KiB, so there they sit in the tail of the X region, which is dead once the two first convs' MFMAs are done (T, SC and S_T
+// take its head): drawn behind that barrier, published by one more.
+template <class D> struct DRMask {
+  using MT = MaskTab<D::COUT, true>;
+  static constexpr int MTB = MT::bytes(D::G);
+  static constexpr bool IN_X = D::LDS + 3 * MTB > 160 * 1024;
+  static constexpr int X_TAIL = (D::ST_OFF + (D::NBLKS * D::M + D::HO + 1) * 4 + 15) / 16 * 16;      // first free byte of the X region while T / SC / S_T live
+  static_assert(!IN_X || X_TAIL + 3 * MTB <= D::G * D::XIMG, "the mask tables fit behind S_T");
+  static constexpr int LDS = D::LDS + (IN_X ? 0 : 3 * MTB);
+};
+
+template <class D, class EC, int NM, bool DROP = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
+void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all, const DropSet<DROP ? 3 : 0> dr) {
   const DownArgs a = args_of(all, blockIdx.y);
+  static_assert(!DROP || NM == 1, "dropout variants are single-call");
+  using DM = DRMask<D>;
   constexpr int NTHR = 512;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* xt = smem;
@@ -166,6 +183,7 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
   float* bias_lds = reinterpret_cast<float*>(rbase + D::NBUF * D::SLABB);               // [3][COUT]: s, a, b
   int16_t* sx16 = reinterpret_cast<int16_t*>(bias_lds + 3 * D::COUT);                   // S_X: channel sums of the X tile's interior pixels
   int* stt = reinterpret_cast<int*>(smem + D::ST_OFF);                                  // S_T: ... of the T tile, per channel block
+  uint8_t* mtab = DM::IN_X ? smem + DM::X_TAIL : reinterpret_cast<uint8_t*>(sx16 + D::NPX);      // DROP: three one-bit mask tables
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mblk = wave / D::NBLKS, nblk = wave - mblk * D::NBLKS;
 
@@ -273,6 +291,10 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
     const int m = mblk * 32 + r;
     const int g = m / (D::HO * D::HO), rem = m - g * (D::HO * D::HO), oh = rem / D::HO, ow = rem - oh * D::HO;
     const uint8_t* xlane = xt + g * D::XIMG + (2 * oh) * D::XROW + (2 * ow) * D::CIN + 16 * h;      // tap (0, 0) of this pixel's 3x3 / s2 window
+    if constexpr (DROP && !DM::IN_X) {      // this item's masks (their readers lie behind the barrier that ends the first two convs' MFMAs)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) fill_mask_tab<D::G, D::COUT, true, NTHR>(mtab + d * DM::MTB, dr.d[d], s, img0, a.B, tid);
+    }
     // window sums of stem.0 (3x3 / s2: rows 2 oh - 1 .. 2 oh + 1, columns likewise; only the top / left can leave the map) and of the
     // shortcut (the centre pixel) from S_X.  The centre pixel (2 oh, 2 ow) has an even index: with sb = the dword that holds it, row kh's
     // three pixels are the high half of sb[.. - 1] and both halves of sb[..] -- two reads at immediate offsets per kernel row; a read in
@@ -303,15 +325,34 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
     QBNN_STAMP_AT(1);
     lds_barrier();                       // every wave has read X for the last time: T and SC may overwrite it
     QBNN_STAMP_AT(2);
-    {
-      EpiDenseTile<D::PIXB_T> epi{tt, a.a, 0};
-      epi_presub<EC>(bias_lds + D::COUT, a.a, epi, A, wave, lane);
-      const int v = half_sum(epi.csum);                            // channel sum of this wave's 96 channels of T, per pixel
-      if (lane < 32) stt[nblk * D::M + mblk * 32 + lane] = v;
+    if constexpr (DROP && DM::IN_X) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) fill_mask_tab<D::G, D::COUT, true, NTHR>(mtab + d * DM::MTB, dr.d[d], s, img0, a.B, tid);
+      lds_barrier();
     }
-    {
-      EpiDense<D::COUT, false, D::SCP> epi{sc, a.s, a.add};
-      epi_presub<EC>(bias_lds, a.s, epi, S, wave, lane);
+    constexpr int IMG_PX = D::HO * D::HO;
+    if constexpr (DROP) {
+      {
+        EpiDenseTileDrop<D::PIXB_T, D::COUT, IMG_PX, true> epi{tt, a.a, dr.d[0], {mtab, dr.d[0].mq1}, 0};
+        epi_presub<EC>(bias_lds + D::COUT, a.a, epi, A, wave, lane);
+        const int v = half_sum(epi.csum);
+        if (lane < 32) stt[nblk * D::M + mblk * 32 + lane] = v;
+      }
+      {
+        EpiDenseDrop<D::COUT, IMG_PX, false, D::SCP, true> epi{sc, a.s, a.add, dr.d[2], {mtab + 2 * DM::MTB, dr.d[2].mq1}};
+        epi_presub<EC>(bias_lds, a.s, epi, S, wave, lane);
+      }
+    } else {
+      {
+        EpiDenseTile<D::PIXB_T> epi{tt, a.a, 0};
+        epi_presub<EC>(bias_lds + D::COUT, a.a, epi, A, wave, lane);
+        const int v = half_sum(epi.csum);                            // channel sum of this wave's 96 channels of T, per pixel
+        if (lane < 32) stt[nblk * D::M + mblk * 32 + lane] = v;
+      }
+      {
+        EpiDense<D::COUT, false, D::SCP> epi{sc, a.s, a.add};
+        epi_presub<EC>(bias_lds, a.s, epi, S, wave, lane);
+      }
     }
     for (int i = tid; i < D::PIXB_T / 4; i += NTHR) reinterpret_cast<uint32_t*>(zline)[i] = 0u;      // (X shared these bytes)
     QBNN_STAMP_AT(3);
@@ -345,7 +386,10 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all) {
     }
     QBNN_STAMP_AT(4);
     fetch(next);                         // the next item's input: in flight during this epilogue and the read-out
-    {
+    if constexpr (DROP) {
+      EpiDenseDrop<D::COUT, IMG_PX, true, D::SCP, true> epi{sc, a.b, a.add, dr.d[1], {mtab + DM::MTB, dr.d[1].mq1}};
+      epi_presub<EC>(bias_lds + 2 * D::COUT, a.b, epi, A, wave, lane);
+    } else {
       EpiDense<D::COUT, true, D::SCP> epi{sc, a.b, a.add};
       epi_presub<EC>(bias_lds + 2 * D::COUT, a.b, epi, A, wave, lane);
     }
@@ -391,7 +435,7 @@ int launch_by_value(const DownArgs* arr, int n, hipStream_t st) {
     if (int rc = ensure_dyn_lds((const void*)block_down_ring_kernel<D, EC, 1>, attr1, D::LDS)) return rc;
     ArgsArr<DownArgs, 1> one;
     one.m[0] = arr[0];
-    hipLaunchKernelGGL((block_down_ring_kernel<D, EC, 1>), dim3(items < 256 ? (items > 0 ? items : 1) : 256), dim3(512), D::LDS, st, one);
+    hipLaunchKernelGGL((block_down_ring_kernel<D, EC, 1>), dim3(items < 256 ? (items > 0 ? items : 1) : 256), dim3(512), D::LDS, st, one, DropSet<0>{});
     return check_launch("qbnn_block_down_i8_mc");
   }
   static_assert(sizeof(ArgsArr<DownArgs, QBNN_FUSED_CALLS>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
@@ -400,7 +444,7 @@ int launch_by_value(const DownArgs* arr, int n, hipStream_t st) {
   memset(&all, 0, sizeof(all));
   for (int i = 0; i < n; ++i) all.m[i] = arr[i];
   const int per = 256 / n > 0 ? 256 / n : 1;
-  hipLaunchKernelGGL((block_down_ring_kernel<D, EC, QBNN_FUSED_CALLS>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, all);
+  hipLaunchKernelGGL((block_down_ring_kernel<D, EC, QBNN_FUSED_CALLS>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, all, DropSet<0>{});
   return check_launch("qbnn_block_down_i8_multi");
 }
 
@@ -409,11 +453,30 @@ int launch_dev(const DownArgs* dev, int n, int items, hipStream_t st) {
   static std::atomic<uint64_t> attr{0};
   if (int rc = ensure_dyn_lds((const void*)block_down_ring_kernel<D, EC, 0>, attr, D::LDS)) return rc;
   const int per = 256 / n > 0 ? 256 / n : 1;
-  hipLaunchKernelGGL((block_down_ring_kernel<D, EC, 0>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, ArgsArr<DownArgs, 0>{dev});
+  hipLaunchKernelGGL((block_down_ring_kernel<D, EC, 0>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, ArgsArr<DownArgs, 0>{dev}, DropSet<0>{});
   return check_launch("qbnn_block_down_i8_multi_launch");
 }
 
+template <class D, class EC>
+int launch_drop(const DownArgs& a, const DropSet<3>& dr, hipStream_t st) {
+  constexpr int LDS = DRMask<D>::LDS;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr{0};
+  if (int rc = ensure_dyn_lds((const void*)block_down_ring_kernel<D, EC, 1, true>, attr, LDS)) return rc;
+  const int items = a.n_samples * ((a.B + D::G - 1) / D::G);
+  ArgsArr<DownArgs, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_down_ring_kernel<D, EC, 1, true>), dim3(items < 256 ? (items > 0 ? items : 1) : 256), dim3(512), LDS, st, one, dr);
+  return check_launch("qbnn_block_down_drop_i8_mc");
+}
+
 }  // namespace
+
+int qbnn_launch_block_down_ring_drop(const DownArgs& a, const DropSet<3>& dr, int Cin, hipStream_t st) {
+  if (Cin == 48) return launch_drop<DR48, E48>(a, dr, st);
+  if (Cin == 96) return launch_drop<DR96, E96>(a, dr, st);
+  return fail(QBNN_E_INVALID, "qbnn_block_down_drop (ring): 48 -> 96 and 96 -> 192 channels only%s");
+}
 
 int qbnn_launch_block_down_ring(const DownArgs* arr, int n, int Cin, hipStream_t st) {
   if (n <= 0 || n > QBNN_FUSED_CALLS) return fail(QBNN_E_INVALID, "qbnn_block_down (ring): 1 .. 8 argument blocks per launch%s");

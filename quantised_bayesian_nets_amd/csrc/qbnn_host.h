@@ -53,7 +53,7 @@ static int fill_qadd(QAdd& a, const qbnn_conv_desc* d) {
 // 16-wave layer-1 kernel (qbnn_w16.hip): layers.0 + two identity blocks at 32 x 32 x 24, `n` <= 4 argument blocks in one grid
 int qbnn_launch_stem_chain_w16(const ChainArgs<2>* arr, int n, int a_hi, hipStream_t st);
 int qbnn_launch_stem_chain_w16_dev(const ChainArgs<2>* dev, int n, int items, int a_hi, hipStream_t st);               // ... any number of argument blocks in device memory
-int qbnn_launch_stem_chain_w16_drop(const ChainArgs<2>& a, const DropSet<5>& dr, hipStream_t st);      // ... with the five dropouts of conv_resnet_mc
+int qbnn_launch_stem_chain_w16_drop(const ChainArgs<2>& a, const DropSet<5>& dr, int a_hi, hipStream_t st);      // ... with the five dropouts of conv_resnet_mc
 // 16-wave 48-channel identity block on QBNN_LAYOUT_MFMA32_N24 weights (qbnn_c48.hip, round 5): `n` <= QBNN_FUSED_CALLS argument blocks by
 // value, or any number in device memory
 int qbnn_launch_chain48_w16(const ChainArgs<1>* arr, int n, hipStream_t st);
@@ -62,6 +62,7 @@ int qbnn_launch_chain48_w16_dev(const ChainArgs<1>* dev, int n, int items, hipSt
 // (n <= QBNN_FUSED_CALLS) or any number in device memory.  QBNN_DOWN_RING=0 selects the L2-streaming kernels of qbnn_blocks.hip (A/B checks).
 int qbnn_launch_block_down_ring(const DownArgs* arr, int n, int Cin, hipStream_t st);
 int qbnn_launch_block_down_ring_dev(const DownArgs* dev, int n, int items, int Cin, hipStream_t st);
+int qbnn_launch_block_down_ring_drop(const DownArgs& a, const DropSet<3>& dr, int Cin, hipStream_t st);      // ... with the block's three dropouts (conv_resnet_mc)
 static inline bool qbnn_use_down_ring() {
   static const bool v = [] { const char* e = getenv("QBNN_DOWN_RING"); return !(e && e[0] == '0'); }();
   return v;

@@ -498,16 +498,16 @@ int launch_w16(const ChainArgs<NBLK>* arr, int n, hipStream_t st) {
   return check_launch("qbnn_stem_chain_i8_mc");
 }
 
-template <int G, int NBLK>
+template <int G, int NBLK, bool MAGIC>
 int launch_w16_drop(const ChainArgs<NBLK>& a, const DropSet<2 * NBLK + 1>& dr, hipStream_t st) {
   constexpr int LDS = w16_lds<G, NBLK, true>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)stem_chain_w16_kernel<G, NBLK, 1, true>, attr, LDS)) return rc_attr;
+  if (int rc_attr = ensure_dyn_lds((const void*)stem_chain_w16_kernel<G, NBLK, 1, true, MAGIC>, attr, LDS)) return rc_attr;
   ArgsArr<ChainArgs<NBLK>, 1> one;
   one.m[0] = a;
   const int items = a.n_samples * ((a.B + G - 1) / G);
-  hipLaunchKernelGGL((stem_chain_w16_kernel<G, NBLK, 1, true>), dim3(items < 256 ? items : 256), dim3(W16_THREADS), LDS, st, one, dr);
+  hipLaunchKernelGGL((stem_chain_w16_kernel<G, NBLK, 1, true, MAGIC>), dim3(items < 256 ? items : 256), dim3(W16_THREADS), LDS, st, one, dr);
   return check_launch("qbnn_stem_chain_drop_i8_mc");
 }
 
@@ -528,7 +528,13 @@ int qbnn_launch_stem_chain_w16_dev(const ChainArgs<2>* dev, int n, int items, in
   return w16_magic_ok(a_hi) ? launch_w16_dev<true>(dev, n, items, st) : launch_w16_dev<false>(dev, n, items, st);
 }
 
-int qbnn_launch_stem_chain_w16_drop(const ChainArgs<2>& a, const DropSet<5>& dr, hipStream_t st) { return launch_w16_drop<2, 2>(a, dr, st); }
+// (with dropout a tile holds dropped values centred on the mask's zero point: bytes in [-z_m, min(255, a_hi) - z_m], |x'| <= a_hi for the
+//  z_m in [0, a_hi] the library accepts -- the same accumulator bound as without)
+int qbnn_launch_stem_chain_w16_drop(const ChainArgs<2>& a, const DropSet<5>& dr, int a_hi, hipStream_t st) {
+  bool zm_ok = true;
+  for (int d = 0; d < 5; ++d) zm_ok = zm_ok && dr.d[d].z_m >= 0 && dr.d[d].z_m <= a_hi;
+  return (w16_magic_ok(a_hi) && zm_ok) ? launch_w16_drop<2, 2, true>(a, dr, st) : launch_w16_drop<2, 2, false>(a, dr, st);
+}
 
 // entry point for qbnn_blocks.hip (declared in qbnn_host.h): 1 to 4 argument blocks in one grid, two images per work item
 int qbnn_launch_stem_chain_w16(const ChainArgs<2>* arr, int n, int a_hi, hipStream_t st) {
