@@ -461,7 +461,12 @@ def main():
     dt = time.perf_counter() - t0
     qlayers.PROFILE = None
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    rank_ms = None
     if use_dist:
+        # every rank's own time for the K steps beside the MAX the metric uses: a straggler shows as a spread, not only as a slower job
+        tall = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(tall, tmax)
+        rank_ms = [round(float(t.item()) / a.steps * 1e3, 4) for t in tall]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -581,6 +586,7 @@ def main():
                "config": {"workload": wl["describe"], "samples_per_gpu": S_local, "global_samples": S_global, "batch": x_host.shape[0],
                           "image_samples_per_s": round(value * x_host.shape[0], 1), "parallelism": f"mc-sample-shard x{world}"},
                "graph_replay": graphed is not None, "roofline": roof, "path_roofline": path, "cpu_baseline": cpu, "rccl": rccl, "rccl_ranks": world if (use_dist and backend == "nccl") else 0, "rccl_one_rank_us": rccl_one_rank_us,
+               "ms_per_step_by_rank": rank_ms, "ms_per_step_min_max_over_ranks": ([min(rank_ms), max(rank_ms)] if rank_ms else None),
                "kernels": kernels, "secondary": secondary}
         print(json.dumps(out), flush=True)          # the line is out before any process-group teardown
     if use_dist:
