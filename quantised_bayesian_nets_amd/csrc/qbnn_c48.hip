@@ -55,7 +55,7 @@ struct W48 { static constexpr int NT = 2, KS = T48::KS; };      // one conv's pa
 constexpr int C48_WHALF = T48::KS * 1024, C48_WCONV = 2 * C48_WHALF;
 constexpr int C48_TILES = C48_G * T48::TILE_BYTES + 64;          // + slack: the last k-step of a tile row over-reads 16 bytes
 constexpr int C48_IMG = T48::H * T48::H * T48::CH;               // bytes of one image in HBM
-constexpr int c48_lds() { return 3 * C48_TILES + 2 * C48_WCONV + 2 * T48::CH * 4; }      // X (two buffers), T, both convs' weights, biases
+constexpr int c48_lds() { return 3 * C48_TILES + 2 * C48_WCONV + 2 * T48::CH * 4 + 256; }      // X (two buffers), T, both convs' weights, biases, ready flags
 
 // tile offset of pixel (img, oh, col) -- interior coordinates
 __device__ __forceinline__ int px48(int img, int oh, int col) { return img * T48::TILE_BYTES + (oh + 1) * T48::PITCH + (col + 1) * T48::PIXB; }
@@ -304,12 +304,175 @@ __global__ __launch_bounds__(C48_THREADS) void chain48_w16_kernel(const ArgsArr<
   }
 }
 
+// ---- the same block WITHOUT workgroup barriers inside an item: ready flags between the stages (round 5) ---------------------------------
+// Why: with a barrier behind every conv the last wave's epilogue -- alone on its SIMD, 10 - 18 cycles per vector instruction -- is the tail of
+// every phase (profiles/r05_stamp_c48_w16.txt: 36 % / 58 % of the two phases).  Here a wave waits only for the waves whose data it reads:
+//   xr[rp][img] = i + 1 : rows 2 rp, 2 rp + 1 of image `img` of item i are in X[i & 1]        (written by wave (rp, half = img))
+//   ta[rp][half] = i + 1 : stem.0's output rows 2 rp, 2 rp + 1, channels of `half`, item i, are in T
+//   bm[rp][half] = i + 1 : that wave's stem.3 MFMAs of item i have read T (rows 2 rp - 1 .. 2 rp + 2)
+//   be[rp][half] = i + 1 : its stem.3 epilogue of item i has read the residual from X[i & 1]
+// and per item: wait xr[rp-1..rp+1] >= i + 1 | MFMAs a | wait bm[rp-1..rp+1] >= i | epilogue a -> T, ta = i + 1 | wait ta[rp-1..rp+1] >= i + 1 |
+// MFMAs b, bm = i + 1 | wait be[rp][other half] >= i, item i + 1's rows -> X[(i + 1) & 1], xr = i + 2 | epilogue b -> HBM, be = i + 1.
+// Every wait names work that lies earlier in program order of the wave it waits for, so the waves cannot wait in a cycle; the flags only grow.
+// The waves of a SIMD then stay one MFMA phase apart instead of meeting at a barrier twice per item.  A wait polls LDS with s_sleep between
+// polls and gives up after 2^20 polls (wrong results that the parity tests catch, never a hung GPU).  The sample change keeps its barrier.
+struct DFlags { int xr[16], ta[16], bm[16], be[16]; };
+__device__ __forceinline__ void df_wait(const int* f, int lo, int hi, int need) {      // f[2 lo .. 2 hi + 1] >= need
+#pragma unroll 1
+  for (int spin = 0; spin < (1 << 20); ++spin) {
+    int mn = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int idx = 2 * lo + q;
+      const int v = idx <= 2 * hi + 1 ? __hip_atomic_load(f + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+      mn = v < mn ? v : mn;
+    }
+    if (__builtin_amdgcn_readfirstlane(mn) >= need) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void df_wait1(const int* f, int need) {
+#pragma unroll 1
+  for (int spin = 0; spin < (1 << 20); ++spin) {
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= need) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void df_set(int* f, int v) {      // (every lane stores the same value)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int NM>
+__global__ __launch_bounds__(C48_THREADS) void chain48_df_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
+  const ChainArgs<1> a = args_of(all, blockIdx.y);
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* xt0 = smem;
+  uint8_t* tt = smem + 2 * C48_TILES;
+  uint8_t* wl = smem + 3 * C48_TILES;
+  float* bias_lds = reinterpret_cast<float*>(wl + 2 * C48_WCONV);
+  DFlags* fl = reinterpret_cast<DFlags*>(bias_lds + 2 * T48::CH);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave & 1, rp = wave >> 1, lo = rp > 0 ? rp - 1 : 0, hi = rp < 7 ? rp + 1 : 7, me = 2 * rp + half;
+
+  const int groups = (a.B + C48_G - 1) / C48_G;
+  int begin, count;
+  item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
+  if (count <= 0) return;
+
+  zero_halo<T48::TW, T48::PIXB, T48::TILE_BYTES, C48_G, C48_THREADS>(xt0, tid);
+  zero_halo<T48::TW, T48::PIXB, T48::TILE_BYTES, C48_G, C48_THREADS>(xt0 + C48_TILES, tid);
+  zero_halo<T48::TW, T48::PIXB, T48::TILE_BYTES, C48_G, C48_THREADS>(tt, tid);
+  load_bias<T48::CH, C48_THREADS>(bias_lds, a.blk[0].a.bias, tid);
+  load_bias<T48::CH, C48_THREADS>(bias_lds + T48::CH, a.blk[0].b.bias, tid);
+  if (tid < 64) reinterpret_cast<int*>(fl)[tid] = tid < 16 ? 1 : 0;      // xr = 1: item 0's rows are written below, in front of the first barrier
+
+  // this wave's two rows of image `half`: 2 x 768 bytes = 96 16-byte chunks over 64 lanes, fetched one item ahead
+  constexpr int RCH = T48::H * T48::CH / 16;        // chunks per image row
+  v4i pre[2];
+  auto fetch_rows = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * C48_G;
+    const int gi = img0 + half < a.B ? img0 + half : a.B - 1;             // (a missing second image: any valid address, its results are not stored)
+    int l_ = lane;
+    asm volatile("" : "+v"(l_));
+    const uint8_t* src = a.x + (int64_t)s * a.x_ss + (int64_t)gi * C48_IMG + (2 * rp) * (RCH * 16) + l_ * 16;
+    pre[0] = *reinterpret_cast<const v4i*>(src);
+    pre[1] = *reinterpret_cast<const v4i*>(src + (l_ < 32 ? 64 * 16 : 0));
+  };
+  auto write_rows = [&](uint8_t* xt) {
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+    int l_ = lane;
+    asm volatile("" : "+v"(l_));
+    uint8_t* dst = xt + half * T48::TILE_BYTES + (2 * rp + 1) * T48::PITCH + T48::PIXB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = l_ + 64 * j;
+      if (c < 2 * RCH) {
+        const int r = c >= RCH ? 1 : 0, within = c - r * RCH;
+        const v4i v = pre[j];
+        *reinterpret_cast<v4i*>(dst + r * T48::PITCH + within * 16) =
+            v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)};
+      }
+    }
+  };
+  fetch_rows(begin);
+  write_rows(xt0);
+  fetch_rows(count > 1 ? begin + 1 : begin);
+
+  v4i w[T48::KS];
+  int cur_s = -1;
+#ifdef QBNN_C48_STAMP
+  const bool st_on = false;
+  int st_k = 0;
+#endif
+  for (int it = 0; it < count; ++it) {
+    const int item = begin + it;
+    const int s = item / groups, img0 = (item - s * groups) * C48_G;
+    uint8_t* xt = xt0 + (it & 1) * C48_TILES;
+    uint8_t* xn = xt0 + ((it + 1) & 1) * C48_TILES;
+    if (s != cur_s) {            // workgroup-uniform; a few times per launch (and at the first item: publishes the prologue's LDS writes)
+      __syncthreads();
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));
+      dma_conv<W48, C48_WAVES>(wl, a.blk[0].a.w + (int64_t)s * a.blk[0].a.w_ss, wave, l_);
+      dma_conv<W48, C48_WAVES>(wl + C48_WCONV, a.blk[0].b.w + (int64_t)s * a.blk[0].b.w_ss, wave, l_);
+      dma_barrier();
+      cur_s = s;
+    }
+    {
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));
+#pragma unroll
+      for (int ks = 0; ks < T48::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wl + half * C48_WHALF + l_ * 16 + ks * 1024);
+    }
+    df_wait(fl->xr, lo, hi, it + 1);
+    conv48_pair(xt, w, wl + C48_WCONV + half * C48_WHALF, bias_lds, a.blk[0].a, EpiT48{tt, a.blk[0].a.vhi}, half, rp, lane, wave >> 2,
+                [&] { df_wait(fl->bm, lo, hi, it); } C48_STAMP_PASS);
+    df_set(fl->ta + me, it + 1);
+    df_wait(fl->ta, lo, hi, it + 1);
+    conv48_pair(tt, w, nullptr, bias_lds + T48::CH, a.blk[0].b,
+                EpiOut48{xt, a.y + (int64_t)s * a.y_ss + (int64_t)img0 * C48_IMG, a.B - img0, a.blk[0].b, a.blk[0].add}, half, rp, lane, wave >> 2,
+                [&] {
+                  df_set(fl->bm + me, it + 1);
+                  if (it + 1 < count) {
+                    df_wait1(fl->be + (me ^ 1), it);
+                    write_rows(xn);
+                    df_set(fl->xr + me, it + 2);
+                  }
+                  fetch_rows(it + 2 < count ? item + 2 : item);
+                } C48_STAMP_PASS);
+    df_set(fl->be + me, it + 1);
+  }
+}
+
+static bool c48_dataflow() {
+  static const bool v = [] { const char* e = getenv("QBNN_C48_DF"); return e && e[0] == '1'; }();      // off: measured 6 % slower than the barrier form (profiles/r05_stamp_c48_w16.txt)
+  return v;
+}
+
 template <int NM>
 int launch_c48(const ChainArgs<1>* arr, int n, hipStream_t st) {
   constexpr int LDS = c48_lds();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert(sizeof(ArgsArr<ChainArgs<1>, NM>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
-  static std::atomic<uint64_t> attr{0};
+  static std::atomic<uint64_t> attr{0}, attr_df{0};
+  if (c48_dataflow()) {
+    if (int rc_attr = ensure_dyn_lds((const void*)chain48_df_kernel<NM>, attr_df, LDS)) return rc_attr;
+    ArgsArr<ChainArgs<1>, NM> all;
+    memset(&all, 0, sizeof(all));
+    int items = 0;
+    for (int i = 0; i < n; ++i) {
+      all.m[i] = arr[i];
+      const int it = arr[i].n_samples * ((arr[i].B + C48_G - 1) / C48_G);
+      items = it > items ? it : items;
+    }
+    const int per = 256 / n > 0 ? 256 / n : 1;
+    const int gx = items < per ? (items > 0 ? items : 1) : per;
+    hipLaunchKernelGGL((chain48_df_kernel<NM>), dim3(gx, n), dim3(C48_THREADS), LDS, st, all);
+    return check_launch("qbnn_block_chain_i8_mc (48 channels, N24 layout, ready flags)");
+  }
   if (int rc_attr = ensure_dyn_lds((const void*)chain48_w16_kernel<NM>, attr, LDS)) return rc_attr;
   ArgsArr<ChainArgs<1>, NM> all;
   memset(&all, 0, sizeof(all));
@@ -335,10 +498,15 @@ int qbnn_launch_chain48_w16(const ChainArgs<1>* arr, int n, hipStream_t st) {
 }
 int qbnn_launch_chain48_w16_dev(const ChainArgs<1>* dev, int n, int items, hipStream_t st) {
   constexpr int LDS = c48_lds();
-  static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)chain48_w16_kernel<0>, attr, LDS)) return rc_attr;
+  static std::atomic<uint64_t> attr{0}, attr_df{0};
   const int per = 256 / n > 0 ? 256 / n : 1;
   const int gx = items < per ? (items > 0 ? items : 1) : per;
+  if (c48_dataflow()) {
+    if (int rc_attr = ensure_dyn_lds((const void*)chain48_df_kernel<0>, attr_df, LDS)) return rc_attr;
+    hipLaunchKernelGGL((chain48_df_kernel<0>), dim3(gx, n), dim3(C48_THREADS), LDS, st, ArgsArr<ChainArgs<1>, 0>{dev});
+    return check_launch("qbnn_block_chain_i8_multi_launch (48 channels, N24 layout, ready flags)");
+  }
+  if (int rc_attr = ensure_dyn_lds((const void*)chain48_w16_kernel<0>, attr, LDS)) return rc_attr;
   hipLaunchKernelGGL((chain48_w16_kernel<0>), dim3(gx, n), dim3(C48_THREADS), LDS, st, ArgsArr<ChainArgs<1>, 0>{dev});
   return check_launch("qbnn_block_chain_i8_multi_launch (48 channels, N24 layout)");
 }
