@@ -39,6 +39,8 @@ extern "C" {
 #define QBNN_LAYOUT_MFMA32 0    /* [NT][KS][64 lanes][16 B] fragments */
 #define QBNN_LAYOUT_ROWMAJOR 1  /* [Cout][K]                          */
 #define QBNN_LAYOUT_MFMA32_N24 2 /* fragments with 24 output channels (+ a ones row) per tile: the fused 48-channel kernels of round 5 */
+#define QBNN_LAYOUT_MFMA32_TAIL 3 /* MFMA32 with the ragged ends of the kernel rows gathered into one k-step (72-byte rows: 7 k-steps instead of
+                                   * 9): the 24-channel convs behind the fused stem (qbnn_stem_chain_i8_mc / _drop_ / the multi forms)        */
 
 /* Scalars of the int8 weight-sampling chain
  *   noise  = quantize_per_tensor(eps, NOISE_SCALE, 0, qint8)      conv_q.py:113-115, linear_q.py:86-88

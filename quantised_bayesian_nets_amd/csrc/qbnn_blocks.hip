@@ -1188,10 +1188,16 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
                                 hipStream_t st, const int8_t* stem_x = nullptr, const QConv* stem = nullptr) {
   ChainArgs<NBLK> a;
   if (int rc = build_chain_args<NBLK>(a, x, x_ss, s_x, z_x, B, a_hi, blk, y, y_ss, n_samples, stem_x, stem)) return rc;
-  if (stem && blk[0].w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the 24-channel blocks take MFMA32 weights%s");
   if (stem) {
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
-    if constexpr (NBLK == 2) { if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16(&a, 1, a_hi, st); }
+    for (int k = 0; k < NBLK; ++k)
+      if (blk[k].w_layout != blk[0].w_layout) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: one packed weight layout per launch%s");
+    // the blocks' weights as QBNN_LAYOUT_MFMA32_TAIL fragments (7 k-steps): the 16-wave kernel; as MFMA32 (9 k-steps): the 8-wave kernel
+    if (blk[0].w_layout == QBNN_LAYOUT_MFMA32_TAIL) {
+      if constexpr (NBLK == 2) return qbnn_launch_stem_chain_w16(&a, 1, a_hi, st);
+      else return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the MFMA32_TAIL layout serves layers.0 + two blocks (the 16-wave kernel)%s");
+    }
+    if (blk[0].w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the 24-channel blocks take MFMA32 or MFMA32_TAIL weights%s");
     return launch_block_chain_ws<Blk_24, NBLK, true, true>(a, st);
   }
   for (int k = 0; k < NBLK; ++k)
@@ -1323,8 +1329,9 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n
   auto items = [&](int G) { return max_samples * ((B + G - 1) / G); };
   if (with_stem) {
     if (n_blocks != 2 || Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: the fused stem feeds the two 32x32x24 blocks only%s");
-    if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16_dev(reinterpret_cast<const ChainArgs<2>*>(dev_args), n_calls, items(2), a_hi, st);
-    return launch_block_chain_ws_dev<Blk_24, 2, true>(reinterpret_cast<const ChainArgs<2>*>(dev_args), n_calls, items(Blk_24::G), st);      // QBNN_W16=0: the 8-wave kernel
+    if (w_layout == QBNN_LAYOUT_MFMA32_TAIL) return qbnn_launch_stem_chain_w16_dev(reinterpret_cast<const ChainArgs<2>*>(dev_args), n_calls, items(2), a_hi, st);
+    if (w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: the 24-channel blocks take MFMA32 or MFMA32_TAIL weights%s");
+    return launch_block_chain_ws_dev<Blk_24, 2, true>(reinterpret_cast<const ChainArgs<2>*>(dev_args), n_calls, items(Blk_24::G), st);      // MFMA32: the 8-wave kernel
   }
   if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: one block per call (two only behind the fused stem)%s");
   const ChainArgs<1>* dev = reinterpret_cast<const ChainArgs<1>*>(dev_args);
@@ -1386,9 +1393,14 @@ static int chain_drop_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_
   }
   if constexpr (STEM) {
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_drop_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
-    if constexpr (NBLK == 2) { if (qbnn_use_w16()) return qbnn_launch_stem_chain_w16_drop(a, dr, a_hi, st); }
+    if (blk[0].w_layout == QBNN_LAYOUT_MFMA32_TAIL) {
+      if constexpr (NBLK == 2) return qbnn_launch_stem_chain_w16_drop(a, dr, a_hi, st);
+      else return fail(QBNN_E_INVALID, "qbnn_stem_chain_drop_i8_mc: the MFMA32_TAIL layout serves layers.0 + two blocks (the 16-wave kernel)%s");
+    }
+    if (blk[0].w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_drop_i8_mc: the 24-channel blocks take MFMA32 or MFMA32_TAIL weights%s");
     return launch_block_chain_ws_drop<Blk_24, NBLK, true>(a, dr, st);
   } else {
+    if (blk[0].w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_block_chain_drop_i8_mc: these blocks take MFMA32 weights%s");
     if (Cc == 24 && H == 32) return launch_block_chain_ws_drop<Blk_24, NBLK, false>(a, dr, st);
     if (Cc == 48 && H == 16) {
       if constexpr (chain_ws_lds<Blk_48, NBLK, true, false, true>() <= 160 * 1024) return launch_block_chain_ws_drop<Blk_48, NBLK, false>(a, dr, st);
@@ -1471,7 +1483,13 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi(const qbnn_chain_call* calls, int32_t 
         if ((rc = build_stem_qconv(stem, k.w0_packed, k.w0_sample_stride, k.bias0, k.s_in, k.s_w0, k.z_w0, k.s_y0, k.z_y0, a_hi))) return rc;
         if ((rc = build_chain_args<2>(arr[i], nullptr, 0, k.s_y0, k.z_y0, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, k.im2col, &stem))) return rc;
       }
-      rc = qbnn_use_w16() ? qbnn_launch_stem_chain_w16(arr, n, a_hi, st) : launch_block_chain_ws_multi<Blk_24, 2, true, NM2>(arr, n, st);
+      const int lay = calls[c0].blocks[0].w_layout;
+      for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 2; ++k)
+          if (calls[c0 + i].blocks[k].w_layout != lay) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: one weight layout per call array%s");
+      if (lay == QBNN_LAYOUT_MFMA32_TAIL) rc = qbnn_launch_stem_chain_w16(arr, n, a_hi, st);
+      else if (lay == QBNN_LAYOUT_MFMA32) rc = launch_block_chain_ws_multi<Blk_24, 2, true, NM2>(arr, n, st);
+      else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: the 24-channel blocks take MFMA32 or MFMA32_TAIL weights%s");
     } else {
       if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: one block per call (two only behind the fused stem)%s");
       ChainArgs<1> arr[QBNN_FUSED_CALLS];

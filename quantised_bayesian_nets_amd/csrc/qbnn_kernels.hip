@@ -62,21 +62,39 @@ QBNN_EXPORT int qbnn_version(void) { return QBNN_ABI_VERSION; }
 //       [24 nt, 24 nt + 24), row 24 of EVERY tile is a ones row, rows 25..31 are 0.  A 48-channel conv is then two independent
 //       (24 + 1)-row halves: each half's MFMAs deliver its own window sum, so a wave can requantise one half while the other half's
 //       MFMAs are still in flight (qbnn_c48.hip); with the 32-row tiling the window sum of tile 0 lives in tile 1.
+//   QBNN_LAYOUT_MFMA32_TAIL (round 5): MFMA32 with the kernel rows' ragged ends gathered.  A kernel row of krow = 32 F + T bytes (T > 0) costs
+//       F + 1 k-steps above, the last one mostly padding: 3 x 3 taps of 24 channels = 72-byte rows -> 3 x 3 = 9 k-steps for 216 weights per
+//       output channel.  Here the packed K axis is [row 0's first 32 F bytes | row 1's | ... | the rows' T-byte tails back to back | 0]:
+//       rows * F + 1 k-steps (7 for the 24-channel convs), when rows * T <= 32 and T % 4 == 0.  Only the layer-1 kernel (qbnn_w16.hip) reads it.
 // =====================================================================================
 
-struct PackGeom { int cout, k, krow, rows, rbp, kp, KS, NT, tr; };      // tr: output channels per tile (32, or 24 for _N24)
+struct PackGeom { int cout, k, krow, rows, rbp, kp, KS, NT, tr, tail_f; };      // tr: output channels per tile (32, or 24 for _N24); tail_f: F of _TAIL, else 0
 static inline PackGeom pack_geom(int cout, int k, int krow, int layout = QBNN_LAYOUT_MFMA32) {
   PackGeom g;
   g.cout = cout; g.k = k; g.krow = krow; g.rows = k / krow; g.rbp = ceil_div(krow, 32) * 32;
   g.tr = layout == QBNN_LAYOUT_MFMA32_N24 ? 24 : 32;
-  g.kp = g.rows * g.rbp; g.KS = g.kp / 32; g.NT = ceil_div(cout, g.tr);
+  g.tail_f = layout == QBNN_LAYOUT_MFMA32_TAIL ? krow / 32 : 0;
+  g.kp = g.rows * g.rbp; g.KS = g.tail_f ? g.rows * g.tail_f + 1 : g.kp / 32; g.NT = ceil_div(cout, g.tr);
   return g;
 }
-static inline bool is_mfma_layout(int layout) { return layout == QBNN_LAYOUT_MFMA32 || layout == QBNN_LAYOUT_MFMA32_N24; }
+static inline bool is_mfma_layout(int layout) { return layout == QBNN_LAYOUT_MFMA32 || layout == QBNN_LAYOUT_MFMA32_N24 || layout == QBNN_LAYOUT_MFMA32_TAIL; }
+// shapes the layout is defined for: ragged kernel rows whose tails fit ONE k-step, whole Philox blocks per tail
+static inline bool tail_layout_ok(int k, int krow) {
+  if (krow <= 0 || k % krow) return false;
+  const int T = krow % 32, rows = k / krow;
+  return krow > 32 && T > 0 && T % 4 == 0 && rows * T <= 32;
+}
+// position on the packed K axis of byte j of kernel row kh
+static inline int packed_kp(const PackGeom& g, int kh, int j) {
+  if (!g.tail_f) return kh * g.rbp + j;
+  const int m = 32 * g.tail_f;
+  return j < m ? kh * m + j : g.rows * m + kh * (g.krow - m) + (j - m);
+}
 
 QBNN_EXPORT size_t qbnn_packed_weight_bytes(int32_t cout, int32_t k, int32_t krow, int32_t layout) {
   if (layout == QBNN_LAYOUT_ROWMAJOR) return ((size_t)cout * k + 15) / 16 * 16;
   if (!is_mfma_layout(layout) || krow <= 0 || k % krow || (layout == QBNN_LAYOUT_MFMA32_N24 && cout % 24)) return 0;
+  if (layout == QBNN_LAYOUT_MFMA32_TAIL && !tail_layout_ok(k, krow)) return 0;
   const PackGeom g = pack_geom(cout, k, krow, layout);
   return (size_t)g.NT * g.KS * 1024;
 }
@@ -93,8 +111,9 @@ QBNN_EXPORT int qbnn_pack_weights_host(const int8_t* src, int32_t cout, int32_t 
   if (layout == QBNN_LAYOUT_MFMA32_N24 && cout % 24) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: the N24 layout takes cout % 24 == 0%s");
   const PackGeom g = pack_geom(cout, k, krow, layout);
   memset(dst, 0, (size_t)g.NT * g.KS * 1024);
+  if (layout == QBNN_LAYOUT_MFMA32_TAIL && !tail_layout_ok(k, krow)) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: the TAIL layout takes ragged kernel rows whose tails fit one k-step%s");
   auto put = [&](int nt, int col, int kk, int8_t v) {
-    const int kp = (kk / krow) * g.rbp + kk % krow;
+    const int kp = packed_kp(g, kk / krow, kk % krow);
     const int ks = kp >> 5, half = (kp >> 4) & 1, b = kp & 15;
     dst[(((size_t)nt * g.KS + ks) * 64 + half * 32 + col) * 16 + b] = v;
   };
@@ -122,6 +141,20 @@ __device__ __forceinline__ void load_eps_table(uint32_t* tab, int tid) {       /
   tab[tid & 255] = QBNN_EPS_ALIAS[tid & 255];
 }
 
+// (kernel row, byte within it, valid) of byte `b` (0 .. 15) of the 16-byte chunk (k-step ks, k-half h) of a fragment tile.  tail_f = 0: the
+// padded-row layouts (kernel rows of rbp bytes); tail_f = F: QBNN_LAYOUT_MFMA32_TAIL (rows of 32 F bytes, then the rows' tails in one k-step).
+__device__ __forceinline__ void chunk_kpos(int ks, int h, int b, int rbp, int krow, int rows, int tail_f, int& kh, int& j, bool& valid) {
+  if (tail_f == 0) {
+    const int kp = ks * 32 + 16 * h + b;
+    kh = kp / rbp; j = kp - kh * rbp; valid = j < krow;
+  } else if (ks < rows * tail_f) {
+    kh = ks / tail_f; j = (ks - kh * tail_f) * 32 + 16 * h + b; valid = true;
+  } else {
+    const int T = krow - 32 * tail_f, q = 16 * h + b;
+    kh = q / T; j = 32 * tail_f + (q - kh * T); valid = q < rows * T;
+  }
+}
+
 __device__ __forceinline__ int sample_one_q(int mu_q, int sigma_q, int eps_q, const qbnn_sample_params& p);
 // injected fp32 eps (parity mode): quantise it as the reference does, then the common chain
 __device__ __forceinline__ int sample_one(int mu_q, int sigma_q, float eps, const qbnn_sample_params& p) {
@@ -139,7 +172,7 @@ __device__ __forceinline__ int sample_one_q(int mu_q, int sigma_q, int eps_q, co
 __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
     const v4i* __restrict__ mu, const v4i* __restrict__ sigma, int cout, int K, int krow, int rbp, int KS, int layout,
     int n_chunks, qbnn_sample_params p, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_id, uint32_t sample_begin,
-    const float* __restrict__ eps_in, int8_t* __restrict__ w_out, int64_t w_sample_stride, const uint32_t* __restrict__ nd, int tr) {
+    const float* __restrict__ eps_in, int8_t* __restrict__ w_out, int64_t w_sample_stride, const uint32_t* __restrict__ nd, int tr, int tail_f) {
   if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }      // captured-graph mode: the seed lives in device memory
   __shared__ uint32_t eps_tab[256];
   load_eps_table(eps_tab, threadIdx.x);
@@ -147,14 +180,14 @@ __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
   const int chunk = blockIdx.x * 256 + threadIdx.x;
   if (chunk >= n_chunks) return;
   const int s = blockIdx.y;
-  int n = 0, kh = 0, j0 = 0, col = 0;       // MFMA32 (tr = 32) / _N24 (tr = 24): output row, kernel row, first byte within the (padded) kernel row
+  int n = 0, col = 0, cks = 0, ch = 0;       // MFMA32 (tr = 32) / _N24 (tr = 24) / _TAIL: output row, this chunk's k-step and k-half
   if (layout == QBNN_LAYOUT_MFMA32) {
     const int lane = chunk & 63, tile = chunk >> 6;
-    const int nt = tile / KS, ks = tile - nt * KS;
+    const int nt = tile / KS;
+    cks = tile - nt * KS;
     col = lane & 31;
     n = nt * tr + col;
-    const int kp0 = ks * 32 + (lane >> 5) * 16;
-    kh = kp0 / rbp; j0 = kp0 - kh * rbp;
+    ch = lane >> 5;
   }
   const bool ones_row = (layout == QBNN_LAYOUT_MFMA32) && (tr == 24 ? col == 24 : ((cout & 31) && n == cout));
   const bool real_row = col < tr && n < cout;
@@ -169,9 +202,11 @@ __global__ __launch_bounds__(256) void sample_weights_i8_kernel(
     int64_t idx;
     bool valid;
     if (layout == QBNN_LAYOUT_MFMA32) {
-      valid = real_row && (j0 + j < krow);
-      idx = (int64_t)n * K + kh * krow + j0 + j;
-      if (ones_row && j0 + j < krow) ow[j >> 2] |= 1u << (8 * (j & 3));
+      int kh, jj; bool kv;
+      chunk_kpos(cks, ch, j, rbp, krow, K / krow, tail_f, kh, jj, kv);
+      valid = real_row && kv;
+      idx = (int64_t)n * K + kh * krow + jj;
+      if (ones_row && kv) ow[j >> 2] |= 1u << (8 * (j & 3));
     } else {
       idx = (int64_t)chunk * 16 + j;
       valid = idx < total;
@@ -210,6 +245,7 @@ QBNN_EXPORT int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* si
   if (is_mfma_layout(layout) && (krow <= 0 || k % krow))
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: k must be a multiple of krow%s");
   if (layout == QBNN_LAYOUT_MFMA32_N24 && cout % 24) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: the N24 layout takes cout % 24 == 0%s");
+  if (layout == QBNN_LAYOUT_MFMA32_TAIL && !tail_layout_ok(k, krow)) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: the TAIL layout takes ragged kernel rows whose tails fit one k-step%s");
   const size_t bytes = qbnn_packed_weight_bytes(cout, k, krow, layout);
   if ((size_t)w_sample_stride < bytes || (w_sample_stride & 15))
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: w_sample_stride too small or not 16-byte aligned%s");
@@ -219,7 +255,7 @@ QBNN_EXPORT int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* si
   // (inside the kernels both fragment layouts are "MFMA32" with g.tr channels per tile)
   hipLaunchKernelGGL(sample_weights_i8_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                      (const v4i*)mu_packed, (const v4i*)sigma_packed, cout, k, g.krow, g.rbp, g.KS, is_mfma_layout(layout) ? QBNN_LAYOUT_MFMA32 : layout, n_chunks, *hp,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out, w_sample_stride, g_noise_dev, g.tr);
+                     (uint32_t)seed, (uint32_t)(seed >> 32), layer_id, sample_begin, eps_in, w_out, w_sample_stride, g_noise_dev, g.tr, g.tail_f);
   return check_launch("qbnn_sample_weights_i8");
 }
 
@@ -229,6 +265,7 @@ struct SamplerLayer {
   const v4i* mu; const v4i* sigma; int8_t* out; int64_t out_ss;
   int cout, K, krow, rbp, KS, layout, n_chunks, chunk_begin;     // chunk_begin: first 256-thread block of this layer; layout: MFMA32 (both fragment layouts) or ROWMAJOR
   int tr;                                                          // output channels per fragment tile: 32, or 24 (QBNN_LAYOUT_MFMA32_N24)
+  int tail_f;                                                      // QBNN_LAYOUT_MFMA32_TAIL: full k-steps per kernel row, else 0
   uint32_t layer_id;
   qbnn_sample_params p;
 };
@@ -253,14 +290,15 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
   const int chunk = ((int)blockIdx.x - L.chunk_begin) * 256 + threadIdx.x;
   if (chunk >= L.n_chunks) return;
   const int s0 = blockIdx.y * QBNN_SAMPLER_NS;
-  int n = 0, kh = 0, j0 = 0, col = 0;
+  int n = 0, kh = 0, j0 = 0, col = 0, cks = 0, ch = 0;
   if (L.layout == QBNN_LAYOUT_MFMA32) {
     const int lane = chunk & 63, tile = chunk >> 6;
     const int nt = tile / L.KS, ks = tile - nt * L.KS;
     col = lane & 31;
     n = nt * L.tr + col;
     const int kp0 = ks * 32 + (lane >> 5) * 16;
-    kh = kp0 / L.rbp; j0 = kp0 - kh * L.rbp;
+    kh = kp0 / L.rbp; j0 = kp0 - kh * L.rbp;      // (the padded-row layouts; _TAIL goes through chunk_kpos)
+    cks = ks; ch = lane >> 5;
   }
   const bool ones_row = (L.layout == QBNN_LAYOUT_MFMA32) && (L.tr == 24 ? col == 24 : ((L.cout & 31) && n == L.cout));
   const bool real_row = col < L.tr && n < L.cout;
@@ -287,7 +325,16 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
       dw[j] = __builtin_fmaf(P.s_w, (float)((mw[j >> 2] << (24 - 8 * (j & 3))) >> 24), P.nzs_w);
       sg[j] = (float)((sw[j >> 2] << (24 - 8 * (j & 3))) >> 24) - zsf;
     }
-    const int64_t idx0 = (int64_t)n * L.K + kh * L.krow + j0;
+    // the chunk's four Philox blocks: element index and validity of each (consecutive blocks in the padded-row layouts; in the tail
+    // k-step of _TAIL they belong to different kernel rows)
+    uint32_t blk_of[4]; bool blk_ok[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int bkh, bj; bool bv;
+      chunk_kpos(cks, ch, 4 * g, L.rbp, L.krow, L.K / L.krow, L.tail_f, bkh, bj, bv);
+      blk_of[g] = (uint32_t)(((int64_t)n * L.K + bkh * L.krow + bj) >> 2);
+      blk_ok[g] = bv;
+    }
 #pragma unroll 1
     for (int ss = 0; ss < QBNN_SAMPLER_NS; ++ss) {
       const int s = s0 + ss;
@@ -295,9 +342,9 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
       uint32_t ow[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        if (ones_row && j0 + 4 * g < L.krow) ow[g] = 0x01010101u;
-        if (real_row && j0 + 4 * g < L.krow) {
-          const qbnn::u32x4 r4 = qbnn::philox4x32_10((uint32_t)((idx0 >> 2) + g), L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi);
+        if (ones_row && blk_ok[g]) ow[g] = 0x01010101u;
+        if (real_row && blk_ok[g]) {
+          const qbnn::u32x4 r4 = qbnn::philox4x32_10(blk_of[g], L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi);
           const uint32_t uu[4] = {r4.x, r4.y, r4.z, r4.w};
           float f[4];
 #pragma unroll
@@ -377,9 +424,11 @@ __global__ __launch_bounds__(256) void sample_weights_multi_kernel(const Sampler
       int64_t idx;
       bool valid;
       if (L.layout == QBNN_LAYOUT_MFMA32) {
-        valid = real_row && (j0 + j < L.krow);
-        idx = (int64_t)n * L.K + kh * L.krow + j0 + j;
-        if (ones_row && j0 + j < L.krow) ow[j >> 2] |= 1u << (8 * (j & 3));
+        int ekh, ej; bool ev;
+        chunk_kpos(cks, ch, j, L.rbp, L.krow, L.K / L.krow, L.tail_f, ekh, ej, ev);
+        valid = real_row && ev;
+        idx = (int64_t)n * L.K + ekh * L.krow + ej;
+        if (ones_row && ev) ow[j >> 2] |= 1u << (8 * (j & 3));
       } else {
         idx = (int64_t)chunk * 16 + j;
         valid = idx < total;
@@ -418,6 +467,7 @@ QBNN_EXPORT int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* layers, i
     if (frag && (q.krow <= 0 || q.k % q.krow))
       return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: k must be a multiple of krow%s");
     if (q.layout == QBNN_LAYOUT_MFMA32_N24 && q.cout % 24) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: the N24 layout takes cout % 24 == 0%s");
+    if (q.layout == QBNN_LAYOUT_MFMA32_TAIL && !tail_layout_ok(q.k, q.krow)) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: the TAIL layout takes ragged kernel rows whose tails fit one k-step%s");
     const size_t bytes = qbnn_packed_weight_bytes(q.cout, q.k, q.krow, q.layout);
     if ((size_t)q.w_sample_stride < bytes || (q.w_sample_stride & 15))
       return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: w_sample_stride too small or unaligned%s");
@@ -427,7 +477,7 @@ QBNN_EXPORT int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* layers, i
     int& bb = unaligned ? blocks_u : blocks;
     SamplerLayer& L = tt.l[tt.n++];
     L.mu = (const v4i*)q.mu_packed; L.sigma = (const v4i*)q.sigma_packed; L.out = q.w_out; L.out_ss = q.w_sample_stride;
-    L.cout = q.cout; L.K = q.k; L.krow = g.krow; L.rbp = g.rbp; L.KS = g.KS; L.layout = frag ? QBNN_LAYOUT_MFMA32 : q.layout; L.tr = g.tr;
+    L.cout = q.cout; L.K = q.k; L.krow = g.krow; L.rbp = g.rbp; L.KS = g.KS; L.layout = frag ? QBNN_LAYOUT_MFMA32 : q.layout; L.tr = g.tr; L.tail_f = g.tail_f;
     L.n_chunks = (int)(bytes / 16); L.chunk_begin = bb; L.layer_id = q.layer_id; L.p = q.params;
     bb += ceil_div(L.n_chunks, 256);
   }

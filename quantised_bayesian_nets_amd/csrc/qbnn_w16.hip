@@ -54,13 +54,12 @@ namespace {
 
 constexpr int W16_THREADS = 1024, W16_WAVES = 16;
 using L1 = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;      // one 32 x 32 x 24 image tile (halo 1): pitch 34 * 24 bytes
+constexpr int W16_KS = 7, W16_WB = W16_KS * 1024;     // k-steps / packed bytes of a 24 -> 24 3x3 conv in the QBNN_LAYOUT_MFMA32_TAIL layout
+struct W24T { static constexpr int NT = 1, KS = W16_KS; };      // (dma_conv)
 using L0 = ConvCfg<32, 24, 1, 1, 32, 0, 1, 4, 1>;      // layers.0 on the patch tensor: K = 27 -> 32, one k-step
 
-#ifndef QBNN_W16_STEAL
-#define QBNN_W16_STEAL 0
-#endif
 template <int G, int NBLK, bool DROP = false> constexpr int w16_lds() {
-  return (QBNN_W16_STEAL ? 16 * 2 * NBLK : 0) + 2 * (G * L1::TILE_BYTES + L1::TILE_SLACK) + 2 * NBLK * WConv<L1>::BYTES + WConv<L0>::BYTES + (2 * NBLK + 1) * L1::COUT * 4 +
+  return 2 * (G * L1::TILE_BYTES + L1::TILE_SLACK) + 2 * NBLK * W16_WB + WConv<L0>::BYTES + (2 * NBLK + 1) * L1::COUT * 4 +
          (DROP ? 2 * (2 * NBLK + 1) * MaskTab<L1::COUT, false>::bytes(G) : 0);      // two sets of mask tables: consecutive items alternate
 }
 
@@ -157,148 +156,89 @@ struct EpiResToGlobal {
 template <class E> __device__ __forceinline__ auto epi_set_row(const E& e, int g, int oh, int) -> decltype(e.set_row(g, oh), void()) { e.set_row(g, oh); }
 template <class E> __device__ __forceinline__ void epi_set_row(const E&, int, int, long) {}
 
-// 3x3 / stride 1 conv of RW consecutive output rows [oh0, oh0 + RW) of image slot g: tile -> epi.  `w` holds this conv's 9 weight
-// fragments; after the last row's MFMAs it is refilled from `wnext` (the NEXT conv's weights, which do not depend on the barrier
-// in between: the refill rides under the last epilogue instead of heading the next phase, where all 16 waves would burst it).
+// 3x3 / stride 1 conv of RW consecutive output rows [oh0, oh0 + RW) of image slot g: tile -> epi.  Weights in the QBNN_LAYOUT_MFMA32_TAIL
+// layout (round 5): a 72-byte kernel row is two full k-steps (bytes 0 .. 63: pixels c - 1, c and two thirds of c + 1) and an 8-byte tail (the
+// last 8 channels of pixel c + 1); the three rows' tails share ONE k-step -- 7 MFMAs per output row instead of 9 for the same 216 weights per
+// channel.  The tail step's pixel fragment is gathered per output row: k-half 0 = [tail of row i | tail of row i + 1], k-half 1 = [tail of
+// row i + 2 | anything: those weights are 0] -- one ds_read2_b64 from a per-half base.  `w` holds this conv's 7 weight fragments; after the
+// last row's MFMAs it is refilled from `wnext` (the NEXT conv's weights, which do not depend on the barrier in between: the refill rides
+// under the last epilogue instead of heading the next phase, where all 16 waves would burst it).
 template <int RW, bool MAGIC, class Epi>
-__device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[L1::KS], const uint8_t* wnext, const float* bias_lds,
+__device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[W16_KS], const uint8_t* wnext, const float* bias_lds,
                                                  const QConv& p, const Epi& epi, int g, int oh0, int lane W16_STAMP_ARGS) {
   int l_ = lane;
   asm volatile("" : "+v"(l_));     // per-lane offsets are recomputed per phase (hoisted out of the item loop they spill)
   const int r = l_ & 31, h = l_ >> 5;
   // tile row oh0 + j is input row oh0 - 1 + j; tile column r is input column r - 1: the 72-byte window of (row, r) starts there
   const uint8_t* base = tile + g * L1::TILE_BYTES + (oh0 * L1::TW + r) * L1::PIXB + 16 * h;
-  v4i x[RW + 2][L1::SPR];
+  const uint8_t* tbase = base - 16 * h + 64 + (h ? 2 * L1::PITCH : 0);      // tails: k-half 0 reads rows i, i + 1; k-half 1 rows i + 2 (, i + 3: unused)
+  v4i x[RW + 2][2];
   auto load_row = [&](int j) {
 #pragma unroll
-    for (int t = 0; t < L1::SPR; ++t) {
+    for (int t = 0; t < 2; ++t) {
       const v2i lo = *reinterpret_cast<const v2i*>(base + j * L1::PITCH + t * 32);
       const v2i hi = *reinterpret_cast<const v2i*>(base + j * L1::PITCH + t * 32 + 8);
       x[j][t] = v4i{lo.x, lo.y, hi.x, hi.y};
     }
   };
+  auto load_tail = [&](int i) {
+    const v2i lo = *reinterpret_cast<const v2i*>(tbase + i * L1::PITCH);
+    const v2i hi = *reinterpret_cast<const v2i*>(tbase + (i + 1) * L1::PITCH);
+    return v4i{lo.x, lo.y, hi.x, hi.y};
+  };
+  auto mfma_row = [&](int i, const v4i& xt, const v16i& start) {
+    v16i acc = start;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * 2 + t], x[i + kh][t], acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(w[6], xt, acc, 0, 0, 0);
+  };
+  float4 b4[3];
+#pragma unroll
+  for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * h);
   if constexpr (MAGIC) {
     // ONE live copy of the start block, one accumulator, the rows one after the other (a scheduling fence per row: with all four rows'
     // MFMAs run ahead, as the compiler schedules the plain form, 4 x 16 accumulators + the start block do not fit 128 VGPRs); an input
-    // row is read when its first output row needs it and the bias table per row, after the MFMAs are issued.
+    // row is read when its first output row needs it.
     const v16i mg = magic_block();
     load_row(0); load_row(1);
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       W16_PRIO(i);
       load_row(i + 2);
-      v16i acc;
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int t = 0; t < L1::SPR; ++t)
-          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * L1::SPR + t], x[i + kh][t], (kh == 0 && t == 0) ? mg : acc, 0, 0, 0);
+      const v4i xt = load_tail(i);
+      const v16i acc = mfma_row(i, xt, mg);
       if (i == RW - 1 && wnext) {
 #pragma unroll
-        for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
+        for (int ks = 0; ks < W16_KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
       }
-      float4 bb[3];
-#pragma unroll
-      for (int g4 = 0; g4 < 3; ++g4) bb[g4] = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * h);
       W16_STAMP();
       epi_set_row(epi, g, oh0 + i, 0);
-      epilogue24<true>(acc, bb, p, epi, px_off(g, oh0 + i, r), h);
+      epilogue24<true>(acc, b4, p, epi, px_off(g, oh0 + i, r), h);
       W16_STAMP();
       __builtin_amdgcn_sched_barrier(0);
     }
     return;
   }
   load_row(0); load_row(1); load_row(2);
-  float4 b4[3];
-#pragma unroll
-  for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * h);
-  const v16i zero16 = acc_start<MAGIC>();
+  const v16i zero16 = acc_start<false>();
   // One accumulator, no software pipeline inside the wave: while this wave waits on its MFMAs the SIMD's other three waves
   // issue their epilogues (a wave of its own issues a vector instruction every ~6 cycles, the SIMD one every ~2-3).
 #pragma unroll
   for (int i = 0; i < RW; ++i) {
     W16_PRIO(i);
-    v16i acc;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int t = 0; t < L1::SPR; ++t)
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * L1::SPR + t], x[i + kh][t], (kh == 0 && t == 0) ? zero16 : acc, 0, 0, 0);
+    const v4i xt = load_tail(i);
+    const v16i acc = mfma_row(i, xt, zero16);
     if (i + 3 < RW + 2) load_row(i + 3);
     if (i == RW - 1 && wnext) {
 #pragma unroll
-      for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
+      for (int ks = 0; ks < W16_KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
     }
     W16_STAMP();
     epi_set_row(epi, g, oh0 + i, 0);
-    epilogue24<MAGIC>(acc, b4, p, epi, px_off(g, oh0 + i, r), h);
+    epilogue24<false>(acc, b4, p, epi, px_off(g, oh0 + i, r), h);
     W16_STAMP();
-  }
-}
-
-// Row stealing (-DQBNN_W16_STEAL=1, experiment): the same conv with the item's NROWS = 32 G output rows handed out one at a time.  A wave
-// starts on row `wave` and takes its next row from an LDS ticket counter (requested while it works on the current one).  The hardware
-// arbitrates oldest-first, so with a static split (conv3x3_rows_w16) the four waves of a SIMD finish a phase 2 - 7 k cycles apart and the
-// phase's tail runs at one or two waves per SIMD (profiles/r03_stamp_w16_g2.txt); here a wave that is ahead simply takes more rows.
-// Tickets are never reset: a phase of an item hands out exactly NROWS of them (NROWS - 16 rows + one refusal per wave), so the phase's
-// first ticket is ticket_base = (item ordinal of the workgroup) * NROWS.  The 3-row window is loaded per row (no reuse across rows).
-// Ticket request / receipt.  The request is ONE ds_add_rtn_u32 by lane 0 (EXEC narrowed around it), issued from inline assembly so that
-// it stays where it is put -- as a C++ atomic the compiler's atomic optimiser rewrites it into a ballot + add + readfirstlane sequence
-// and waits for the result on the spot.  The compiler's own lgkmcnt accounting stays valid with one more (older or interleaved) LDS
-// operation in flight: LDS operations complete in order, so its waits only become stricter.  ticket_take drains the LDS counter first.
-__device__ __forceinline__ int ticket_request(const int* ctr) {
-  int v; unsigned long long keep;
-  const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)ctr;
-  asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1"
-               : "=&v"(v), "=&s"(keep) : "v"(addr), "v"(1) : "memory");
-  return v;
-}
-__device__ __forceinline__ int ticket_take(int v) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory");
-  return __builtin_amdgcn_readfirstlane(v);
-}
-
-template <int NROWS, bool MAGIC, class Epi>
-__device__ __forceinline__ void conv3x3_steal_w16(const uint8_t* tile, v4i (&w)[L1::KS], const uint8_t* wnext, const float* bias_lds,
-                                                  const QConv& p, const Epi& epi, int* ctr, int ticket_base, int wave, int lane) {
-  int l_ = lane;
-  asm volatile("" : "+v"(l_));
-  const int r = l_ & 31, h = l_ >> 5;
-  const uint8_t* lane_base = tile + r * L1::PIXB + 16 * h;
-  v16i c0 = acc_start<false>();
-  if constexpr (MAGIC) c0 = magic_block();
-  int c = wave;
-  while ((unsigned)c < (unsigned)NROWS) {      // (unsigned: a ticket below the phase base can only come from a broken count -- stop instead of addressing with it)
-    const int nxt = ticket_request(ctr);
-    const int g = c >> 5, oh = c & 31;
-    const uint8_t* base = lane_base + g * L1::TILE_BYTES + oh * L1::PITCH;
-    v4i x[3][L1::SPR];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int t = 0; t < L1::SPR; ++t) {
-        const v2i lo = *reinterpret_cast<const v2i*>(base + j * L1::PITCH + t * 32);
-        const v2i hi = *reinterpret_cast<const v2i*>(base + j * L1::PITCH + t * 32 + 8);
-        x[j][t] = v4i{lo.x, lo.y, hi.x, hi.y};
-      }
-    __builtin_amdgcn_sched_barrier(0);      // all nine fragment reads in flight before the first MFMA waits for one
-    v16i acc;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int t = 0; t < L1::SPR; ++t)
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * L1::SPR + t], x[kh][t], (kh == 0 && t == 0) ? c0 : acc, 0, 0, 0);
-    float4 b4[3];                           // per row: held across the loop they are 12 VGPRs beside the nine fragments
-#pragma unroll
-    for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * h);
-    __builtin_amdgcn_sched_barrier(0);
-    c = 16 + ticket_take(nxt) - ticket_base;
-    epi_set_row(epi, g, oh, 0);
-    epilogue24<MAGIC>(acc, b4, p, epi, px_off(g, oh, r), h);
-  }
-  if (wnext) {
-#pragma unroll
-    for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
   }
 }
 
@@ -318,7 +258,7 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int RW = 2 * G;                                  // output rows per wave and conv (32 rows per image)
   constexpr int TILES = G * L1::TILE_BYTES + L1::TILE_SLACK;
-  constexpr int WB = WConv<L1>::BYTES;
+  constexpr int WB = W16_WB;
   uint8_t* xt = smem;
   uint8_t* tt = smem + TILES;
   uint8_t* wl = smem + 2 * TILES;                            // [NBLK][2] whole convs
@@ -326,7 +266,6 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
   float* bias_lds = reinterpret_cast<float*>(wl0 + WConv<L0>::BYTES);      // [2 NBLK][24], then layers.0's
   float* bias0 = bias_lds + 2 * NBLK * L1::COUT;
   uint8_t* mtab0 = reinterpret_cast<uint8_t*>(bias0 + L0::COUT);             // DROP: mask tables [2][2 NBLK + 1][G][24]
-  int* tickets = reinterpret_cast<int*>(mtab0 + (DROP ? 2 * (2 * NBLK + 1) * MTB : 0));      // STEAL: one counter per 3x3 conv, 16 bytes apart
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = (wave * RW) / 32, woh0 = (wave * RW) % 32;  // this wave's image within the item and its first output row
 
@@ -343,7 +282,6 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
     load_bias<L1::COUT, W16_THREADS>(bias_lds + (2 * k + 1) * L1::COUT, a.blk[k].b.bias, tid);
   }
   load_bias<L0::COUT, W16_THREADS>(bias0, a.stem.bias, tid);
-  if (QBNN_W16_STEAL && tid < 2 * NBLK) tickets[4 * tid] = 0;
   auto sync = [&]() { lds_barrier(); };
 
   // layers.0's pixel fragments of this wave's rows, one 16-byte load per lane and row straight from the patch tensor
@@ -365,7 +303,7 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
   constexpr int CPR = L1::ROWB / 16, CPI = L1::HIN * CPR;                       // 16-byte chunks per image row / per image
   constexpr int NCH = G * CPI, OTHR = W16_THREADS;                            // read-out: 16-byte chunks of the item, threads
   constexpr int PER_TO = (NCH + OTHR - 1) / OTHR;
-  v4i w[L1::KS];
+  v4i w[W16_KS];
   int cur_s = -1;
   for (int it = 0; it < count; ++it) {
     const int item = begin + it;
@@ -380,8 +318,8 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
       asm volatile("" : "+v"(l_));
 #pragma unroll
       for (int k = 0; k < NBLK; ++k) {
-        dma_conv<L1, W16_WAVES>(wl + (2 * k) * WB, a.blk[k].a.w + (int64_t)s * a.blk[k].a.w_ss, wave, l_);
-        dma_conv<L1, W16_WAVES>(wl + (2 * k + 1) * WB, a.blk[k].b.w + (int64_t)s * a.blk[k].b.w_ss, wave, l_);
+        dma_conv<W24T, W16_WAVES>(wl + (2 * k) * WB, a.blk[k].a.w + (int64_t)s * a.blk[k].a.w_ss, wave, l_);
+        dma_conv<W24T, W16_WAVES>(wl + (2 * k + 1) * WB, a.blk[k].b.w + (int64_t)s * a.blk[k].b.w_ss, wave, l_);
       }
       dma_conv<L0, W16_WAVES>(wl0, a.stem.w + (int64_t)s * a.stem.w_ss, wave, l_);
       dma_barrier();             // vmcnt(0) + barrier: the weights have landed
@@ -391,7 +329,7 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
       int l_ = lane;
       asm volatile("" : "+v"(l_));
 #pragma unroll
-      for (int ks = 0; ks < L1::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wl + l_ * 16 + ks * 1024);
+      for (int ks = 0; ks < W16_KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wl + l_ * 16 + ks * 1024);
     }
     W16_STAMP();
     // (the item's last epilogue -- straight to HBM -- is not followed by a barrier: a wave may fill the next item's tables while
@@ -432,18 +370,11 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
     for (int k = 0; k < NBLK; ++k) {
       const BlockParams& bp = a.blk[k];
       auto conv_a = [&](const auto& epi) {
-        if constexpr (QBNN_W16_STEAL)
-          conv3x3_steal_w16<32 * G, MAGIC>(xt, w, wl + (2 * k + 1) * WB, bias_lds + (2 * k) * L1::COUT, bp.a, epi, tickets + 4 * (2 * k), it * (32 * G), wave, lane);
-        else
-          conv3x3_rows_w16<RW, MAGIC>(xt, w, wl + (2 * k + 1) * WB, bias_lds + (2 * k) * L1::COUT, bp.a, epi, wg, woh0, lane W16_STAMP_PASS);
+        conv3x3_rows_w16<RW, MAGIC>(xt, w, wl + (2 * k + 1) * WB, bias_lds + (2 * k) * L1::COUT, bp.a, epi, wg, woh0, lane W16_STAMP_PASS);
       };
       auto conv_b = [&](const auto& epi) {
-        if constexpr (QBNN_W16_STEAL)
-          conv3x3_steal_w16<32 * G, MAGIC>(tt, w, k + 1 < NBLK ? wl + (2 * k + 2) * WB : nullptr, bias_lds + (2 * k + 1) * L1::COUT, bp.b, epi, tickets + 4 * (2 * k + 1),
-                                          it * (32 * G), wave, lane);
-        else
-          conv3x3_rows_w16<RW, MAGIC>(tt, w, k + 1 < NBLK ? wl + (2 * k + 2) * WB : nullptr, bias_lds + (2 * k + 1) * L1::COUT, bp.b, epi, wg, woh0,
-                               lane W16_STAMP_PASS);
+        conv3x3_rows_w16<RW, MAGIC>(tt, w, k + 1 < NBLK ? wl + (2 * k + 2) * WB : nullptr, bias_lds + (2 * k + 1) * L1::COUT, bp.b, epi, wg, woh0,
+                             lane W16_STAMP_PASS);
       };
       if constexpr (DROP) conv_a(EpiTileDrop<L1::HO, L1::PIXB, L1::TILE_BYTES, L1::COUT>{tt, bp.a, dr.d[1 + 2 * k], {mtab + (1 + 2 * k) * MTB, 0.f}});
       else conv_a(EpiTile<L1::HO, L1::PIXB, L1::TILE_BYTES>{tt, bp.a});

@@ -10,6 +10,7 @@ Difference by design: a forward call processes S Monte-Carlo samples at once.  A
 from the Philox stream (seed, layer_id, sample) instead of torch's global generator.
 """
 import contextlib
+import os
 import ctypes as C
 
 import numpy as np
@@ -19,7 +20,13 @@ import torch.nn as nn
 from . import _lib
 from .quant import INT_BOUNDS, UINT_BOUNDS, make_sample_params
 
-LAYOUT_MFMA32, LAYOUT_ROWMAJOR, LAYOUT_MFMA32_N24 = 0, 1, 2      # include/qbnn.h: QBNN_LAYOUT_*
+LAYOUT_MFMA32, LAYOUT_ROWMAJOR, LAYOUT_MFMA32_N24, LAYOUT_MFMA32_TAIL = 0, 1, 2, 3      # include/qbnn.h: QBNN_LAYOUT_*
+
+
+def w16_enabled():
+    """The 16-wave layer-1 kernel (csrc/qbnn_w16.hip) is in use: its blocks' weights are packed as MFMA32_TAIL fragments (QBNN_W16=0: the 8-wave
+    kernels of round 2 on MFMA32 weights, for A/B checks)."""
+    return os.environ.get("QBNN_W16", "1") != "0"
 
 # State epoch: bumped whenever device-side parameter images may be dropped or replaced (a state dict loaded into any layer, a packed
 # layout switched).  A captured HIP graph holds raw pointers to those images; mc.GraphedPredictor records the epoch at capture and

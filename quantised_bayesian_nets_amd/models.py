@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .layers import LAYOUT_MFMA32, LAYOUT_MFMA32_N24, Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_context, timed, sample_all_weights
+from .layers import LAYOUT_MFMA32, LAYOUT_MFMA32_N24, LAYOUT_MFMA32_TAIL, w16_enabled, Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_context, timed, sample_all_weights
 from .quant import UINT_BOUNDS, check_bits
 
 
@@ -212,15 +212,22 @@ class ConvNetwork_ResNet(nn.Module):
             self.in_planes = planes * BasicBlock.expansion
         return nn.ModuleList(blocks)
 
-    def _apply_layouts(self, fused):
+    def _apply_layouts(self, fused, fused_stem=None):
         """Packed weight layouts per execution path.  The fused 16-wave kernel of the 48-channel identity block (csrc/qbnn_c48.hip) takes
-        its two convs as (24 + 1)-row tile halves (QBNN_LAYOUT_MFMA32_N24); the layer-level conv kernel -- the recording / un-fused path --
-        and every other fused kernel take MFMA32.  A switch re-packs mu / sigma once (layers.set_layout).  QBNN_C48=0: MFMA32 everywhere
-        (the round-4 ping-pong / weights-stationary kernels, for A/B checks)."""
+        its two convs as (24 + 1)-row tile halves (QBNN_LAYOUT_MFMA32_N24), the 16-wave layer-1 kernel (csrc/qbnn_w16.hip, behind the fused
+        stem) its four 24-channel convs with the kernel rows' tails gathered (QBNN_LAYOUT_MFMA32_TAIL: 7 k-steps instead of 9); the
+        layer-level conv kernel -- the recording / un-fused path -- and every other fused kernel take MFMA32.  A switch re-packs mu / sigma
+        once (layers.set_layout).  QBNN_C48=0 / QBNN_W16=0: MFMA32 there (the kernels of rounds 2 - 4, for A/B checks)."""
         n24 = fused and os.environ.get("QBNN_C48", "1") != "0"
         blk = self.layers[4][1]
         for c in (blk.stem[0], blk.stem[3]):
             c.set_layout(LAYOUT_MFMA32_N24 if n24 else LAYOUT_MFMA32)
+        if fused_stem is None:
+            fused_stem = fused and self.fuse_stem and len(self.layers[3][0].shortcut) == 0
+        tail = fused_stem and w16_enabled() and len(self.layers[3]) == 2
+        for blk in self.layers[3]:
+            for c in (blk.stem[0], blk.stem[3]):
+                c.set_layout(LAYOUT_MFMA32_TAIL if tail else LAYOUT_MFMA32)
 
     def stochastic_layers(self):
         out = [self.layers[0]]
@@ -277,10 +284,10 @@ class ConvNetwork_ResNet(nn.Module):
         if x.dim() != 4 or tuple(x.shape[1:]) != (3, 32, 32):
             raise NotImplementedError("conv_resnet_bbb expects 3x32x32 inputs")
         l0 = self.layers[0]
-        self._apply_layouts(self.fuse_blocks and record is None)
         fuse_stem = self.fuse_blocks and self.fuse_stem and record is None and len(self.layers[3][0].shortcut) == 0
         B, Cc, H, W = x.shape
         col = torch.empty((B, H * W, 32), dtype=torch.int8, device=dev)
+        self._apply_layouts(self.fuse_blocks and record is None, fuse_stem)
         if fuse_stem and 0 <= self.quant.zero_point <= 127:
             # QuantStub + clamp + the layer-0 patch gather in ONE pass over the fp32 input (the quantised image itself is not needed:
             # layers.0 runs on the patches inside the layer-1 kernel)
@@ -549,7 +556,7 @@ class Network(nn.Module):
             if step[0] == "stem":
                 with timed("ensemble stem + layer 1"):
                     if dargs:
-                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 1, B, 32, 24, p["a_hi"], 0, 2, 1, st))
+                        _lib.check(L.qbnn_block_chain_i8_multi_launch(dargs, M, 1, B, 32, 24, p["a_hi"], step[1][0].blocks[0].w_layout, 2, 1, st))
                     else:
                         _lib.check(L.qbnn_block_chain_i8_multi(step[1], M, 1, B, 32, 24, p["a_hi"], 2, st))
             elif step[0] == "down":

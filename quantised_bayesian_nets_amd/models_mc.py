@@ -148,9 +148,12 @@ class QConv2d(_QDeterministic):
     _TUNED = {(32, 24, 24, 3, 1), (32, 24, 48, 3, 2), (32, 24, 48, 1, 2), (16, 48, 48, 3, 1), (16, 48, 96, 3, 2), (16, 48, 96, 1, 2),
               (8, 96, 96, 3, 1), (8, 96, 192, 3, 2), (8, 96, 192, 1, 2), (4, 192, 192, 3, 1)}
 
-    def _tuned(self):
-        """This conv as a deterministic layers.Conv2d: the fixed qint8 weight is the one 'sample', shared by all MC samples."""
+    def _tuned(self, layout=0):
+        """This conv as a deterministic layers.Conv2d: the fixed qint8 weight is the one 'sample', shared by all MC samples.  One object per
+        packed layout (MFMA32 for the layer-level kernel and most fused ones, MFMA32_TAIL for the blocks behind the fused stem)."""
         if getattr(self, "_fast", None) is None:
+            self._fast = {}
+        if layout not in self._fast:
             from .layers import Conv2d as _Conv, ConvReLU2d as _ConvReLU
             m = (_ConvReLU if self.relu else _Conv)(self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
                                                     bias=self.bias_ is not None, args=self.args)
@@ -159,8 +162,10 @@ class QConv2d(_QDeterministic):
                   "scale": self.scale, "zero_point": self.zero_point}
             if self.bias_ is not None:
                 st["bias"] = self.bias_.cpu().numpy()
-            self._fast = m.load_reference_state(st, "")
-        return self._fast
+            m.load_reference_state(st, "")
+            m.layout = layout
+            self._fast[layout] = m
+        return self._fast[layout]
 
     def load_reference_state(self, state, prefix):
         self._fast = None
@@ -516,9 +521,11 @@ def _fill_drop(d, drop, mask, keep):
     d.mask_in = _lib.ptr(mask)
 
 
-def _fill_block(d, blk, dev):
-    """qbnn_block_desc of a converted MC-Dropout BasicBlock: the fixed qint8 weights in the MFMA32 layout, sample stride 0."""
-    ca, cb = blk.stem[0]._tuned(), blk.stem[4]._tuned()
+def _fill_block(d, blk, dev, layout=0):
+    """qbnn_block_desc of a converted MC-Dropout BasicBlock: the fixed qint8 weights as `layout` fragments (MFMA32; MFMA32_TAIL for the two
+    blocks behind the fused stem on the 16-wave kernel), sample stride 0."""
+    ca, cb = blk.stem[0]._tuned(layout), blk.stem[4]._tuned(layout)
+    d.w_layout = layout
     pa, pb = ca._ensure_packed(dev), cb._ensure_packed(dev)
     d.w_a, d.w_a_sample_stride, d.bias_a = pa["mu"].data_ptr(), 0, (pa["bias"].data_ptr() if pa["bias"] is not None else None)
     d.s_wa, d.z_wa, d.s_a, d.z_a = ca.add_weight.scale, ca.add_weight.zero_point, blk.stem[0].scale, blk.stem[0].zero_point
@@ -539,9 +546,11 @@ def run_identity_chain_drop(blocks, x, masks, stem=None):
     d0 = _lib.DropDesc()
     if stem is not None:
         _fill_drop(d0, stem[1], masks.pop(0) if masks is not None else None, keep)
+    from .layers import LAYOUT_MFMA32, LAYOUT_MFMA32_TAIL, w16_enabled
+    layout = LAYOUT_MFMA32_TAIL if (stem is not None and n == 2 and w16_enabled()) else LAYOUT_MFMA32
     for k, blk in enumerate(blocks):
         assert len(blk.shortcut) == 0
-        _fill_block(descs[k], blk, dev)
+        _fill_block(descs[k], blk, dev, layout)
         _fill_drop(drops[2 * k], blk.stem[3], masks.pop(0) if masks is not None else None, keep)
         _fill_drop(drops[2 * k + 1], blk.stem[6], masks.pop(0) if masks is not None else None, keep)
     a_hi = _a_hi(blocks[0].args)

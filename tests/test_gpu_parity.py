@@ -1838,7 +1838,7 @@ def test_fused_stem_chain_random_qparams_against_oracle(seed):
         h = conv_s(x, w0, b0, s_in, z_in, s_w0, z_w0, s_y0, z_y0, True)
         s_h, z_h = s_y0, z_y0
         blks = (_lib.BlockDesc * n_blocks)()
-        keep = []
+        keep, tails = [], []
         for bi in range(n_blocks):
             wa = rng.integers(-128, 128, (S, 24, 3, 3, 24), dtype=np.int8)
             wb = rng.integers(-128, 128, (S, 24, 3, 3, 24), dtype=np.int8)
@@ -1854,8 +1854,11 @@ def test_fused_stem_chain_random_qparams_against_oracle(seed):
             assert len(np.unique(t)) > 8 and len(np.unique(h)) > 8
             wa_d, nba = _pack_per_sample(L, wa)
             wb_d, nbb = _pack_per_sample(L, wb)
+            wa_t, nba_t = _pack_per_sample(L, wa, 3)        # QBNN_LAYOUT_MFMA32_TAIL: the 16-wave kernel's operand (two blocks)
+            wb_t, nbb_t = _pack_per_sample(L, wb, 3)
             ba_d, bb_d = dev(ba), dev(bb)
-            keep += [wa_d, wb_d, ba_d, bb_d]
+            keep += [wa_d, wb_d, ba_d, bb_d, wa_t, wb_t]
+            tails.append((wa_t.data_ptr(), nba_t, wb_t.data_ptr(), nbb_t))
             k = blks[bi]
             k.w_a, k.w_a_sample_stride, k.bias_a, k.s_wa, k.z_wa, k.s_a, k.z_a = wa_d.data_ptr(), nba, ba_d.data_ptr(), s_wa, z_wa, s_a, z_a
             k.w_b, k.w_b_sample_stride, k.bias_b, k.s_wb, k.z_wb, k.s_b, k.z_b = wb_d.data_ptr(), nbb, bb_d.data_ptr(), s_wb, z_wb, s_b, z_b
@@ -1871,7 +1874,16 @@ def test_fused_stem_chain_random_qparams_against_oracle(seed):
                                            _lib.ptr(y), y[0].numel(), S, st))
         torch.cuda.synchronize()
         got = y.cpu().numpy()
-        assert np.array_equal(got, h), (n_blocks, int((got != h).sum()))
+        assert np.array_equal(got, h), (n_blocks, int((got != h).sum()))        # MFMA32 weights: the 8-wave kernel
+        if n_blocks == 2:
+            # the same call with the blocks' weights as MFMA32_TAIL fragments (7 k-steps): the 16-wave kernel with the magic accumulator start
+            for k, (pa, na, pb, nb_) in zip(blks, tails):
+                k.w_a, k.w_a_sample_stride, k.w_b, k.w_b_sample_stride, k.w_layout = pa, na, pb, nb_, 3
+            y2 = torch.full((S, B, 32, 32, 24), 0xEE, dtype=torch.uint8, device="cuda")
+            _lib.check(L.qbnn_stem_chain_i8_mc(_lib.ptr(im), B, _lib.ptr(w0_d), nb0, _lib.ptr(b0_d), s_in, s_w0, z_w0, s_y0, z_y0, a_hi, blks, n_blocks,
+                                               _lib.ptr(y2), y2[0].numel(), S, st))
+            torch.cuda.synchronize()
+            assert np.array_equal(y2.cpu().numpy(), h), ("TAIL", int((y2.cpu().numpy() != h).sum()))
 
 
 @pytest.mark.parametrize("seed", [0, 1])
@@ -2291,3 +2303,24 @@ def test_sampler_n24_layout_draws_the_same_weights(golden_w8):
         lo, hi = (-8, 7) if w_bits == 4 else (-128, 127)
         assert got[ql.LAYOUT_MFMA32].min() >= lo and got[ql.LAYOUT_MFMA32].max() <= hi
         layer.set_layout(ql.LAYOUT_MFMA32)
+        # QBNN_LAYOUT_MFMA32_TAIL on a 24 -> 24 3x3 conv (72-byte kernel rows: 2 full k-steps each + the three tails in a seventh)
+        l24 = m.layers[3][0].stem[3]
+        k24 = 216
+        draws = {}
+        for layout in (ql.LAYOUT_MFMA32, ql.LAYOUT_MFMA32_TAIL):
+            l24.set_layout(layout)
+            with q.mc_context(5, 77, 254):
+                one = l24.sample_weights(torch.device("cuda"))
+                ql.sample_all_weights([l24], torch.device("cuda"))
+                assert torch.equal(one, l24.sample_weights(torch.device("cuda")))
+            KS24 = 9 if layout == ql.LAYOUT_MFMA32 else 7
+            assert one.shape[1] == KS24 * 1024
+            dense = one.cpu().numpy().reshape(5, KS24, 2, 32, 16).transpose(0, 3, 1, 2, 4).reshape(5, 32, KS24 * 32)      # [S][row][packed k]
+            kk = np.arange(k24)
+            kh, j = kk // 72, kk % 72
+            kp = kh * 96 + j if layout == ql.LAYOUT_MFMA32 else np.where(j < 64, kh * 64 + j, 192 + kh * 8 + (j - 64))
+            draws[layout] = dense[:, :24][:, :, kp]
+            ones = np.zeros(KS24 * 32, np.int8); ones[kp] = 1
+            assert np.array_equal(dense[0, 24], ones) and not dense[:, 25:].any()
+        assert np.array_equal(draws[ql.LAYOUT_MFMA32], draws[ql.LAYOUT_MFMA32_TAIL])
+        l24.set_layout(ql.LAYOUT_MFMA32)

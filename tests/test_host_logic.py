@@ -279,3 +279,28 @@ def test_n24_packed_layout_places_every_weight_and_a_ones_row_per_tile():
         assert not dense[t, 25:].any() and not dense[t, :24][:, ~valid].any()
     assert L.qbnn_packed_weight_bytes(40, k, krow, 2) == 0            # cout % 24 != 0: not an N24 shape
     assert L.qbnn_pack_weights_host(w.ctypes.data_as(C.c_void_p), 40, k, krow, 2, out.ctypes.data_as(C.c_void_p)) != 0
+
+
+def test_tail_packed_layout_gathers_the_kernel_rows_ragged_ends():
+    """QBNN_LAYOUT_MFMA32_TAIL (include/qbnn.h, round 5) on a 24 -> 24 3x3 conv: kernel rows of 72 bytes = two full k-steps + an 8-byte tail;
+    the three tails share the seventh k-step (7 KiB per conv instead of 9).  Host packing only: every weight at its place, the ones row,
+    zeros elsewhere; shapes the layout is not defined for are refused."""
+    import ctypes as C
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(6)
+    cout, k, krow = 24, 216, 72
+    w = rng.integers(-128, 128, (cout, k), dtype=np.int8)
+    assert L.qbnn_packed_weight_bytes(cout, k, krow, 3) == 7 * 1024 and L.qbnn_packed_weight_bytes(cout, k, krow, 0) == 9 * 1024
+    out = np.zeros(7 * 1024, np.int8)
+    _lib.check(L.qbnn_pack_weights_host(w.ctypes.data_as(C.c_void_p), cout, k, krow, 3, out.ctypes.data_as(C.c_void_p)))
+    dense = out.reshape(7, 2, 32, 16).transpose(2, 0, 1, 3).reshape(32, 7 * 32)      # [row][packed k]
+    kk = np.arange(k)
+    kh, j = kk // krow, kk % krow
+    kp = np.where(j < 64, kh * 64 + j, 192 + kh * 8 + (j - 64))
+    assert len(set(kp.tolist())) == k
+    assert np.array_equal(dense[:cout][:, kp], w)
+    valid = np.zeros(7 * 32, bool); valid[kp] = True
+    assert np.array_equal(dense[cout], valid.astype(np.int8)) and not dense[cout + 1:].any() and not dense[:cout][:, ~valid].any()
+    assert L.qbnn_packed_weight_bytes(48, 432, 144, 3) == 0              # 16-byte tails x 3 rows do not fit one k-step
+    assert L.qbnn_packed_weight_bytes(96, 864, 288, 3) == 0              # no ragged end at all
