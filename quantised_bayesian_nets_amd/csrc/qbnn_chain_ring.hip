@@ -201,6 +201,7 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<
   };
   // request flat slab q (item q / NSI of this workgroup's walk; beyond its last item: that item's slabs again -- harmless, and every
   // wave keeps issuing DMA_PER_WAVE instructions per slab, which is what the vmcnt accounting counts on) into ring buffer `buf`
+  const uint32_t lane16 = (uint32_t)lane * 16u;      // (dma16_s: the per-lane part of every fragment address)
   auto issue = [&](int q, int buf) {
     int itx = q / D::NSI;
     const int loc = q - itx * D::NSI;
@@ -216,7 +217,7 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<
       const int nt = f / D::SLK, u = f - nt * D::SLK;
       int ks = slab * D::SLK + u;
       ks = ks < D::KS ? ks : D::KS - 1;
-      dma16(wq + ((int64_t)(nt * D::KS + ks) * 64 + lane) * 16, dst + f * 1024);
+      dma16_s(wq + (int64_t)(nt * D::KS + ks) * 1024, lane16, dst + f * 1024);
     }
   };
 

@@ -523,6 +523,18 @@ __device__ __forceinline__ void dma16(const void* gptr, uint32_t lds_addr) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gptr), "s"(lds_addr) : "memory");
 }
+// The same with the global address as a wave-uniform base (SGPR pair) + a 32-bit per-lane offset: the ring kernels' fragment tiles are
+// 1 KiB blocks at uniform addresses, lane l's 16 bytes at + 16 l -- the base moves on the scalar unit and the per-lane offset is ONE
+// register for the whole kernel, where the 64-bit per-lane form costs two v_lshl_add_u64 / v_add per request (round 5: 200 vector
+// instructions per wave and work item in the 96 -> 192 block, whose vector issue slots are what the kernel is short of).
+__device__ __forceinline__ void dma16_s(const void* gbase_uniform, uint32_t lane_off, uint32_t lds_addr) {
+  uint32_t keep;
+  // (readfirstlane: a no-op where the compiler already knows the base to be uniform, and what makes it an SGPR pair where it does not)
+  const uint64_t g = (uint64_t)gbase_uniform;
+  const uint64_t gs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(g >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)g);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_off), "s"(gs), "s"(lds_addr) : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr_of(const uint8_t* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
