@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ABI version of this header: qbnn_version() of the loaded library must equal it (bumped whenever a prototype below changes;
- * 2 = round 5: qbnn_block_chain_i8_multi_launch takes a_hi and w_layout, qbnn_block_desc carries w_layout; round 4's `stream` argument
+ * 2 = round 5: qbnn_block_chain_i8_multi_launch takes a_hi and w_layout, qbnn_block_down_i8_multi_launch w_layout, qbnn_block_desc carries w_layout; round 4's `stream` argument
  * of the _multi_prepare calls). */
 #define QBNN_ABI_VERSION 2
 
@@ -39,6 +39,7 @@ extern "C" {
 #define QBNN_LAYOUT_MFMA32 0    /* [NT][KS][64 lanes][16 B] fragments */
 #define QBNN_LAYOUT_ROWMAJOR 1  /* [Cout][K]                          */
 #define QBNN_LAYOUT_MFMA32_N24 2 /* fragments with 24 output channels (+ a ones row) per tile: the fused 48-channel kernels of round 5 */
+#define QBNN_LAYOUT_MFMA32_N24_TAIL 4 /* both of the next two: stem.0 (24 -> 48, 3x3) of the first down-sampling block on the 16-wave kernel */
 #define QBNN_LAYOUT_MFMA32_TAIL 3 /* MFMA32 with the ragged ends of the kernel rows gathered into one k-step (72-byte rows: 7 k-steps instead of
                                    * 9): the 24-channel convs behind the fused stem (qbnn_stem_chain_i8_mc / _drop_ / the multi forms)        */
 
@@ -161,8 +162,11 @@ typedef struct qbnn_block_desc {
   float s_wb; int32_t z_wb;
   float s_b; int32_t z_b;
   float s_o; int32_t z_o;                                              /* add.add.scale / zero_point                  */
-  int32_t w_layout;                /* packed layout of w_a / w_b (and of a down block's w_s): QBNN_LAYOUT_MFMA32 (0, the default of a zeroed
-                                    * descriptor) or QBNN_LAYOUT_MFMA32_N24 -- 48-channel identity blocks only: selects the 16-wave kernel   */
+  int32_t w_layout;                /* packed layout of the block's weights: QBNN_LAYOUT_MFMA32 (0, the default of a zeroed descriptor: every
+                                    * geometry), or the layout set of a 16-wave kernel (round 5):
+                                    *   QBNN_LAYOUT_MFMA32_TAIL -- the two 24-channel blocks behind the fused stem (w_a, w_b in that layout);
+                                    *   QBNN_LAYOUT_MFMA32_N24  -- the 16x16x48 identity block (w_a, w_b), and the 24 -> 48 down block:
+                                    *                              w_b and w_s as MFMA32_N24, w_a (3x3 on 24 channels) as MFMA32_N24_TAIL */
   int32_t reserved_;
 } qbnn_block_desc;
 
@@ -268,8 +272,8 @@ int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n_calls, int3
                                      int32_t a_hi, int32_t w_layout, int32_t n_blocks, int32_t max_samples, void* stream);
                                      /* a_hi, w_layout: as given to _prepare (w_layout: the calls' blocks[0].w_layout -- one layout per launch) */
 int qbnn_block_down_i8_multi_prepare(const qbnn_down_call* calls, int32_t n_calls, int32_t B, int32_t a_hi, void* dev_args, void* stream);
-int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t max_samples,
-                                    void* stream);
+int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t w_layout,
+                                    int32_t max_samples, void* stream);      /* w_layout: the calls' desc->blk.w_layout (one per launch) */
 
 /* QuantStub + clamp_activation + layer-0 patch gather (qbnn_quantize_input_nchw followed by qbnn_im2col3x3_c3) for n input
  * quantisations at once: x fp32 NCHW [B][3][H][W] -> out[m][B][H*W][32] centred int8 patches, m < n (host arrays scales / zero_points). */

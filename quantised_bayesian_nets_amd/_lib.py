@@ -152,7 +152,7 @@ def lib():
         L.qbnn_block_chain_i8_multi_prepare.argtypes = [C.POINTER(ChainCall), i32, i32, i32, i32, i32, vp, vp]
         L.qbnn_block_chain_i8_multi_launch.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         L.qbnn_block_down_i8_multi_prepare.argtypes = [C.POINTER(DownCall), i32, i32, i32, vp, vp]
-        L.qbnn_block_down_i8_multi_launch.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+        L.qbnn_block_down_i8_multi_launch.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp]
         L.qbnn_head_i8_multi.argtypes = [C.POINTER(HeadCall), i32, vp]
         L.qbnn_quantize_im2col3x3_c3_multi.argtypes = [vp, i32, i32, i32, C.POINTER(f), C.POINTER(i32), i32, i32, vp, i64, vp]
         L.qbnn_conv2d_i8_generic_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, C.POINTER(ConvDesc), vp]

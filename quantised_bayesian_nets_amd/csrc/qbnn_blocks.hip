@@ -76,7 +76,12 @@ QBNN_EXPORT int qbnn_block_down_i8_multi(const qbnn_down_call* calls, int32_t n_
         return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: bad call entry%s");
       if ((rc = build_down_args(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.desc, k.y, k.y_sample_stride, k.n_samples))) return rc;
     }
-    if (Cin == 24 && H == 32) rc = launch_block_down_ws_multi<D24_a, D24_s, D24_b, true>(arr, n, st);
+    const int lay = calls[c0].desc->blk.w_layout;
+    for (int i = 0; i < n; ++i)
+      if (calls[c0 + i].desc->blk.w_layout != lay) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: one weight layout per call array%s");
+    if (lay != QBNN_LAYOUT_MFMA32 && !(lay == QBNN_LAYOUT_MFMA32_N24 && Cin == 24 && H == 32))
+      return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: MFMA32 weights (MFMA32_N24 set: the 24 -> 48 block)%s");
+    if (Cin == 24 && H == 32) rc = lay == QBNN_LAYOUT_MFMA32_N24 ? qbnn_launch_down24_w16(arr, n, st) : launch_block_down_ws_multi<D24_a, D24_s, D24_b, true>(arr, n, st);
     else if (Cin == 48 && H == 16) rc = qbnn_use_down_ring() ? qbnn_launch_block_down_ring(arr, n, 48, st) : launch_block_down_ws_multi<D48_a, D48_s, D48_b, false>(arr, n, st);
     else if (Cin == 96 && H == 8) rc = qbnn_use_down_ring() ? qbnn_launch_block_down_ring(arr, n, 96, st) : launch_block_down_ws_multi<D96_a, D96_s, D96_b, false>(arr, n, st);
     else return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
@@ -91,10 +96,14 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
                                       void* stream) {
   if (!x || !y || !d || n_samples <= 0 || B <= 0 || !d->blk.w_a || !d->blk.w_b || !d->w_s)
     return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: bad argument%s");
-  if (d->blk.w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: the down-sampling blocks take MFMA32 weights%s");
   DownArgs a;
   if (int rc = build_down_args(a, x, x_ss, s_x, z_x, B, a_hi, d, y, y_ss, n_samples)) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (d->blk.w_layout == QBNN_LAYOUT_MFMA32_N24) {       // the 16-wave kernel (qbnn_c48.hip)
+    if (Cin == 24 && H == 32) return qbnn_launch_down24_w16(&a, 1, st);
+    return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: the MFMA32_N24 layout set serves the 24 -> 48 block%s");
+  }
+  if (d->blk.w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: unknown weight layout%s");
   // (a ping-pong variant of this block -- phases W / M_a / E_sa / M_b / E_b on two 4-wave groups -- measured 15 % SLOWER
   //  than the weights-stationary kernel: five barrier intervals per image, each as long as the slower group's phase)
   if (Cin == 24 && H == 32) return launch_block_down_ws<D24_a, D24_s, D24_b, true>(a, st);
@@ -1362,12 +1371,17 @@ QBNN_EXPORT int qbnn_block_down_i8_multi_prepare(const qbnn_down_call* calls, in
   return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_down_i8_multi_prepare", (hipStream_t)stream);
 }
 
-QBNN_EXPORT int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t max_samples,
-                                                void* stream) {
+QBNN_EXPORT int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t w_layout,
+                                                int32_t max_samples, void* stream) {
   if (!dev_args || n_calls <= 0 || B <= 0 || max_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_launch: bad argument%s");
   hipStream_t st = (hipStream_t)stream;
   const DownArgs* dev = reinterpret_cast<const DownArgs*>(dev_args);
   auto items = [&](int G) { return max_samples * ((B + G - 1) / G); };
+  if (w_layout == QBNN_LAYOUT_MFMA32_N24) {
+    if (Cin == 24 && H == 32) return qbnn_launch_down24_w16_dev(dev, n_calls, items(2), st);
+    return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_launch: the MFMA32_N24 layout set serves the 24 -> 48 block%s");
+  }
+  if (w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_launch: unknown weight layout%s");
   if (Cin == 24 && H == 32) return launch_block_down_ws_dev<D24_a, D24_s, D24_b, true>(dev, n_calls, items(D24_a::G), st);
   if (Cin == 48 && H == 16)
     return qbnn_use_down_ring() ? qbnn_launch_block_down_ring_dev(dev, n_calls, items(D48_a::G), 48, st) : launch_block_down_ws_dev<D48_a, D48_s, D48_b, false>(dev, n_calls, items(D48_a::G), st);
@@ -1449,6 +1463,7 @@ QBNN_EXPORT int qbnn_block_down_drop_i8_mc(const uint8_t* x, int64_t x_ss, float
                                            int32_t n_samples, uint64_t seed, uint32_t sample_begin, void* stream) {
   if (!x || !y || !d || !drops || n_samples <= 0 || B <= 0 || !d->blk.w_a || !d->blk.w_b || !d->w_s)
     return fail(QBNN_E_INVALID, "qbnn_block_down_drop_i8_mc: bad argument%s");
+  if (d->blk.w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_block_down_drop_i8_mc: the blocks with dropout take MFMA32 weights%s");
   DownArgs a;
   if (int rc = build_down_args(a, x, x_ss, s_x, z_x, B, a_hi, d, y, y_ss, n_samples, drops)) return rc;
   DropSet<3> dr;

@@ -1,32 +1,28 @@
-// libqbnn_hip.so -- 16-wave fused kernels of the 48-channel layers (round 5): the 16 x 16 x 48 identity BasicBlock
-// (models_bbb.py:170-183 with stride 1: stem.0 ConvReLU2d, stem.3 Conv2d, Add, ReLU) on weights in the QBNN_LAYOUT_MFMA32_N24 layout.
+// libqbnn_hip.so -- 16-wave fused kernels of the layers with 48 OUTPUT channels (round 5), on weights whose fragment tiles hold 24 output
+// channels + a ones row (QBNN_LAYOUT_MFMA32_N24):
+//   chain48_w16_kernel : the 16 x 16 x 48 identity BasicBlock (models_bbb.py:170-183 with stride 1: stem.0 ConvReLU2d, stem.3 Conv2d, Add, ReLU)
+//   down24_w16_kernel  : the 24 -> 48 down-sampling BasicBlock (:146-183 with stride 2: shortcut 1x1/s2, stem.0 3x3/s2 ConvReLU, stem.3 3x3, Add, ReLU)
 //
-// Why a kernel of its own.  The 8-wave kernels of qbnn_blocks.hip run a 48-channel conv as passes of (32 pixels) x (2 channel tiles of
+// Why kernels of their own.  The 8-wave kernels of qbnn_blocks.hip run a 48-channel conv as passes of (32 pixels) x (2 channel tiles of
 // 32): both tiles in one pass, because the window sum that the sampled weights' zero point needs (sum x'(W - z_w) = acc - z_w R) lives
 // in the ones row of the LAST tile.  A pass holds 64 accumulator registers, the kernel 200+ VGPRs: two waves per SIMD, where a vector
-// instruction of the exact requantisation costs 4.1 cycles of issue instead of 2.9 (profiles/r03_issue_bench.txt), and every wave is in
-// the same phase -- MFMAs, barrier, epilogue -- so the matrix pipe idles through the epilogues (13 - 52 % co-execution).
-// With 24 + 1 rows per tile (N24 layout) a conv splits into two independent channel halves.  Here:
-//   * work item = (MC sample, 2 images); a 32-pixel fragment = output row oh of BOTH images (16 + 16 pixels), so vertically adjacent
-//     fragments share two of their three kernel rows' pixel fragments, as in the 32-wide layer-1 kernel (qbnn_w16.hip);
-//   * wave w owns channel half w & 1 and output rows 2 (w >> 1), 2 (w >> 1) + 1 of both convs: its half's 15 weight fragments stay in
-//     registers (60 VGPRs) for the whole conv, the four input rows it needs are read from LDS once each (5 fragments per row: 144-byte
-//     kernel rows padded to 160) and feed two accumulators: 30 MFMAs per 20 KiB of LDS reads;
-//   * 16 waves = four per SIMD (<= 128 VGPRs): the hardware runs the older waves' MFMA streams first, so the younger waves'
-//     MFMAs overlap the older waves' epilogues without any explicit pipeline;
-//   * stem.3's epilogue (Add with the X tile as residual, ReLU) writes quint8 straight to HBM: no read-out pass.
-// Same arithmetic and epilogue formulas as block_chain_ws_kernel / block_chain_pp_kernel: bit-identical results.
+// instruction of the exact requantisation costs 4.1 cycles of issue instead of 2.9 (profiles/r03_issue_bench.txt).  With 24 + 1 rows per tile
+// a conv splits into two independent channel halves, a wave's unit of work is (one output row of TWO images = 32 pixels) x (24 channels),
+// 16 accumulator registers, and 16 waves fit a CU:
+//   * work item = (MC sample, 2 images); a 32-pixel fragment = output row oh of BOTH images (16 + 16 pixels);
+//   * wave w owns channel half w & 1 and output rows 2 (w >> 1), 2 (w >> 1) + 1 of every conv of the block; a conv's weight fragments of that
+//     half stay in registers for the whole conv (15 fragments = 60 VGPRs for a 48 -> 48 conv; 7 for the 24 -> 48 one in the TAIL form);
+//   * in a 48 -> 48 conv the wave's two rows share two of the four input rows they read: 5 fragments per row, 30 MFMAs per 20 KiB of LDS reads;
+//   * the block's last epilogue (Add, ReLU) writes quint8 straight to HBM; in the down block the shortcut's requantised bytes never leave
+//     the wave's registers (its unit covers the same pixels and channels as the wave's stem.3 unit);
+//   * the 24 -> 48 block's first two convs (K = 216 and 24) start their accumulators at 1.5 * 2^23, as the layer-1 kernel does (qbnn_w16.hip).
+// Same arithmetic and epilogue formulas as block_chain_pp_kernel / block_down_ws_kernel: bit-identical results.
+// What was measured on the way (profiles/r05_stamp_c48_w16.txt; sources: tools/experiments/r05_c48_variants.hip.txt): staggered s_setprio,
+// a row-after-row MFMA / epilogue interleave and a barrier-free ready-flag form of the chain kernel -- equal, 12 % slower, 6 % slower.
 #include "qbnn_host.h"
 
-#ifndef QBNN_C48_PRIO
-#define QBNN_C48_PRIO 0
-#endif
-#ifndef QBNN_C48_SEQ
-#define QBNN_C48_SEQ 0
-#endif
-
 // Diagnostic build only (-DQBNN_C48_STAMP, scratch library; tools/stamp_c48.py): s_memtime of every wave of workgroup 0 at the phase
-// boundaries of one work item, written to a debug buffer that nothing else reads.  The shipped library contains none of this.
+// boundaries of one work item of the chain kernel, written to a debug buffer that nothing else reads.  The shipped library contains none of this.
 #ifdef QBNN_C48_STAMP
 static __device__ unsigned long long* g_c48_stamp = nullptr;
 QBNN_EXPORT void qbnn_debug_c48_stamp_buffer(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_c48_stamp), &p, sizeof(p)); }
@@ -48,42 +44,44 @@ struct T48 {                                   // 16 x 16 x 48 map with a one-pi
   // every group mixes pixels of both images, and with the images 15552 bytes apart (48 banks mod 64) half of image 1's lanes fall on the
   // banks of image 0's -- 8 LDS cycles per read instead of 4 (tools/lds_conflicts.py; measured: 41 % of the LDS cycles were conflicts).
   static constexpr int H = 16, CH = 48, TW = 18, PIXB = 48, PITCH = TW * PIXB, TILE_BYTES = TW * TW * PIXB + 64;
-  static constexpr int SPR = 5, KS = 15;       // k-steps per kernel row / per conv
+  static constexpr int SPR = 5, KS = 15;       // k-steps per kernel row / per conv (144-byte kernel rows padded to 160)
   static constexpr int ONES_REG = 12;          // accumulator register of tile row 24 (lanes 0..31): the window sum
 };
-struct W48 { static constexpr int NT = 2, KS = T48::KS; };      // one conv's packed weights: two halves x 15 fragment tiles (dma_conv)
+struct W48 { static constexpr int NT = 2, KS = T48::KS; };      // one 48 -> 48 conv's packed weights: two halves x 15 fragment tiles (dma_conv)
 constexpr int C48_WHALF = T48::KS * 1024, C48_WCONV = 2 * C48_WHALF;
 constexpr int C48_TILES = C48_G * T48::TILE_BYTES + 64;          // + slack: the last k-step of a tile row over-reads 16 bytes
-constexpr int C48_IMG = T48::H * T48::H * T48::CH;               // bytes of one image in HBM
-constexpr int c48_lds() { return 3 * C48_TILES + 2 * C48_WCONV + 2 * T48::CH * 4 + 256; }      // X (two buffers), T, both convs' weights, biases, ready flags
+constexpr int C48_IMG = T48::H * T48::H * T48::CH;               // bytes of one 16 x 16 x 48 image in HBM
+constexpr int c48_lds() { return 3 * C48_TILES + 2 * C48_WCONV + 2 * T48::CH * 4; }      // X (two buffers), T, both convs' weights, biases
 
 // tile offset of pixel (img, oh, col) -- interior coordinates
 __device__ __forceinline__ int px48(int img, int oh, int col) { return img * T48::TILE_BYTES + (oh + 1) * T48::PITCH + (col + 1) * T48::PIXB; }
 
 // stem.0's epilogue: ReLU-fused requantisation, centred bytes into the T tile
 struct EpiT48 {
-  static constexpr int VPM = 6;          // vector instructions of one row's epilogue per MFMA of the next row (interleave hint)
   uint8_t* tt; float vhi;
   __device__ __forceinline__ uint32_t load(int, int) const { return 0u; }
   __device__ __forceinline__ void store(int po, int, int, int, int c0, float v0, float v1, float v2, float v3, uint32_t) const {
     *reinterpret_cast<uint32_t*>(tt + po + c0) = pack_rne_u8(v0, v1, v2, v3, vhi);
   }
 };
-// stem.3's epilogue: requantise, quantized::add with the centred residual in the X tile, ReLU, quint8 straight to HBM
-// (EpiTileResInPlace's arithmetic, EpiResToGlobal's store)
+// stem.3's epilogue: requantise, quantized::add with the residual, ReLU, quint8 straight to HBM (EpiTileResInPlace's arithmetic, EpiResToGlobal's
+// store).  RES_REG = false: the residual is the centred block input in the X tile (any sign); true: the shortcut's quint8 bytes, handed in from the
+// wave's registers (the down block: EpiDense<HAS_RES>'s arithmetic).
+template <bool RES_REG>
 struct EpiOut48 {
-  static constexpr int VPM = 12;
   const uint8_t* xt; uint8_t* y; int n_ok; QConv p; QAdd a;      // y: this item's first image in the output tensor; n_ok: images of the item that exist
-  __device__ __forceinline__ uint32_t load(int po, int c0) const { return *reinterpret_cast<const uint32_t*>(xt + po + c0); }
+  __device__ __forceinline__ uint32_t load(int po, int c0) const { return RES_REG ? 0u : *reinterpret_cast<const uint32_t*>(xt + po + c0); }
   __device__ __forceinline__ void store(int, int img, int oh, int col, int c0, float v0, float v1, float v2, float v3, uint32_t rqu) const {
     const int rq = (int)rqu;
     const float vv[4] = {v0, v1, v2, v3};
-    const float rf[4] = {(float)((rq << 24) >> 24), (float)((rq << 16) >> 24), (float)((rq << 8) >> 24), (float)(rq >> 24)};      // centred residual (any sign: the block input)
+    float rf[4];
+    if constexpr (RES_REG) { rf[0] = (float)(rqu & 0xffu); rf[1] = (float)((rqu >> 8) & 0xffu); rf[2] = (float)((rqu >> 16) & 0xffu); rf[3] = (float)(rqu >> 24); }
+    else { rf[0] = (float)((rq << 24) >> 24); rf[1] = (float)((rq << 16) >> 24); rf[2] = (float)((rq << 8) >> 24); rf[3] = (float)(rq >> 24); }
     float t[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float da = __builtin_fmaf(p.s_y, __builtin_rintf(med3f(vv[i], p.vlo, p.vhi)), p.dl_y);
-      const float db = __builtin_fmaf(a.s_r, rf[i], a.dl_r);
+      const float db = __builtin_fmaf(a.s_r, rf[i], RES_REG ? a.nzs_r : a.dl_r);
       t[i] = (da + db) * a.inv_s_o;
     }
     if (img < n_ok)
@@ -91,14 +89,15 @@ struct EpiOut48 {
   }
 };
 
-// requantise one accumulator tile: 32 pixels (row oh of both images) x the 24 channels of `half`
+// requantise one accumulator tile: 32 pixels (row oh of both images) x the 24 channels of `half`; `resreg`: the residual dwords (else epi.load)
 template <class Epi>
-__device__ __forceinline__ void epilogue48(const v16i& acc, const float4 (&b4)[3], const QConv& p, const Epi& epi, int half, int img, int oh, int col, int h) {
+__device__ __forceinline__ void epilogue48(const v16i& acc, const float4 (&b4)[3], const QConv& p, const Epi& epi, int half, int img, int oh, int col, int h,
+                                           const uint32_t* resreg = nullptr) {
   const int zwr = __mul24(p.z_w, half_lo_bcast(acc[T48::ONES_REG]));      // |R| <= 432 * 127, |z_w| <= 128: a 24-bit product
   const int po = px48(img, oh, col);
   uint32_t pre[3];
 #pragma unroll
-  for (int g4 = 0; g4 < 3; ++g4) pre[g4] = epi.load(po, 24 * half + 8 * g4 + 4 * h);
+  for (int g4 = 0; g4 < 3; ++g4) pre[g4] = resreg ? resreg[g4] : epi.load(po, 24 * half + 8 * g4 + 4 * h);
 #pragma unroll
   for (int g4 = 0; g4 < 3; ++g4) {
     const float4 bb = b4[g4];
@@ -110,12 +109,13 @@ __device__ __forceinline__ void epilogue48(const v16i& acc, const float4 (&b4)[3
   }
 }
 
-// One 3x3 / stride-1 conv for this wave: channel half `half`, output rows 2 rp and 2 rp + 1 of both images.  `w` holds the half's 15
-// weight fragments; after the MFMAs are issued it is refilled from `wnext` (the next conv's half: no barrier protects or needs it).
-// `mid()` runs between the MFMAs and the epilogues (the next item's tile write: LDS stores beside the matrix pipe's tail).
+// One 3x3 / stride-1 48 -> 48 conv for this wave: channel half `half`, output rows 2 rp and 2 rp + 1 of both images, over a T48-shaped tile.
+// `w` holds the half's 15 weight fragments; after the MFMAs are issued it is refilled from `wnext` (the next conv's half: no barrier protects or
+// needs it).  `mid()` runs between the MFMAs and the epilogues (the next item's tile write: LDS stores beside the matrix pipe's tail).
+// `scr`: the residual dwords of the two rows in registers (the down block), else the epilogue functor loads them.
 template <class Epi, class Mid>
 __device__ __forceinline__ void conv48_pair(const uint8_t* tile, v4i (&w)[T48::KS], const uint8_t* wnext, const float* bias_lds, const QConv& p,
-                                            const Epi& epi, int half, int rp, int lane, int prank, Mid mid C48_STAMP_ARGS) {
+                                            const Epi& epi, int half, int rp, int lane, Mid mid, const uint32_t (*scr)[3] C48_STAMP_ARGS) {
   int l_ = lane;
   asm volatile("" : "+v"(l_));       // per-lane offsets are recomputed per phase (hoisted out of the item loop they are spilled)
   const int r = l_ & 31, h = l_ >> 5, img = r >> 4, col = r & 15, oh0 = 2 * rp;
@@ -123,56 +123,6 @@ __device__ __forceinline__ void conv48_pair(const uint8_t* tile, v4i (&w)[T48::K
   const uint8_t* base = tile + img * T48::TILE_BYTES + oh0 * T48::PITCH + col * T48::PIXB + 16 * h;
   const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   v16i acc0 = zero16, acc1 = zero16;
-  // Staggered issue priority (-DQBNN_C48_PRIO=0 for the A/B).  All 16 waves leave a barrier together, and left alone the four waves of a SIMD
-  // share the matrix pipe evenly: they finish their MFMAs together and requantise together, the pipe idle (measured: a vector instruction
-  // beside only 34 % of the MFMA cycles).  With the wave's rank on its SIMD (wave >> 2: waves w, w + 4, w + 8, w + 12 share one) as its
-  // priority while it multiplies, rank 0 takes the pipe alone -- two accumulator chains keep it full -- and requantises (priority 0, below
-  // every multiplying wave) while rank 1 multiplies, and so on down the ranks.
-#if QBNN_C48_PRIO
-  if (prank == 0) __builtin_amdgcn_s_setprio(3);
-  else if (prank == 1) __builtin_amdgcn_s_setprio(2);
-  else if (prank == 2) __builtin_amdgcn_s_setprio(1);
-#endif
-#if QBNN_C48_SEQ
-  // Row after row: the second row's 15 MFMAs are issued interleaved with the FIRST row's epilogue (one MFMA : VPM vector instructions,
-  // sched_group_barrier), so every wave carries matrix and vector work at the same time instead of 30 MFMAs, then two epilogues -- with
-  // four waves per SIMD in the same phase of a conv that is what lets the pipes overlap.  Costs the sharing of the two middle input
-  // rows' fragments (30 fragment reads per row pair instead of 20).
-  {
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int t = 0; t < T48::SPR; ++t)
-        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * T48::SPR + t], *reinterpret_cast<const v4i*>(base + kh * T48::PITCH + 32 * t), acc0, 0, 0, 0);
-    float4 b4s[3];
-#pragma unroll
-    for (int g4 = 0; g4 < 3; ++g4) b4s[g4] = *reinterpret_cast<const float4*>(bias_lds + 24 * half + 8 * g4 + 4 * h);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int t = 0; t < T48::SPR; ++t)
-        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[kh * T48::SPR + t], *reinterpret_cast<const v4i*>(base + (kh + 1) * T48::PITCH + 32 * t), acc1, 0, 0, 0);
-    epilogue48(acc0, b4s, p, epi, half, img, oh0, col, h);
-#pragma unroll
-    for (int i = 0; i < T48::KS; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, Epi::VPM, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (wnext) {
-#pragma unroll
-      for (int ks = 0; ks < T48::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
-    }
-    C48_STAMP();
-    mid();
-    C48_STAMP();
-    C48_STAMP();
-    epilogue48(acc1, b4s, p, epi, half, img, oh0 + 1, col, h);
-    C48_STAMP();
-    return;
-  }
-#endif
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     v4i x[T48::SPR];
@@ -189,20 +139,24 @@ __device__ __forceinline__ void conv48_pair(const uint8_t* tile, v4i (&w)[T48::K
     for (int ks = 0; ks < T48::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wnext + l_ * 16 + ks * 1024);
   }
   C48_STAMP();          // MFMAs issued (not yet complete)
-#if QBNN_C48_PRIO
-  __builtin_amdgcn_s_setprio(0);
-#endif
   mid();
   C48_STAMP();
+  // (the bias table is read HERE: its address is made opaque at this point -- typed as float, the reads are otherwise hoisted above the tile
+  //  stores of the phase before, a barrier earlier, and their 12 registers parked in scratch across it)
+  int boff = 24 * half + 4 * h;
+  asm volatile("" : "+v"(boff));
   float4 b4[3];
 #pragma unroll
-  for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + 24 * half + 8 * g4 + 4 * h);
-  epilogue48(acc0, b4, p, epi, half, img, oh0, col, h);
+  for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + boff + 8 * g4);
+  epilogue48(acc0, b4, p, epi, half, img, oh0, col, h, scr ? scr[0] : nullptr);
   C48_STAMP();
-  epilogue48(acc1, b4, p, epi, half, img, oh0 + 1, col, h);
+  epilogue48(acc1, b4, p, epi, half, img, oh0 + 1, col, h, scr ? scr[1] : nullptr);
   C48_STAMP();
 }
 
+// ================================================================================================================================
+// identity block, 48 channels
+// ================================================================================================================================
 template <int NM>
 __global__ __launch_bounds__(C48_THREADS) void chain48_w16_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
   const ChainArgs<1> a = args_of(all, blockIdx.y);
@@ -291,190 +245,215 @@ __global__ __launch_bounds__(C48_THREADS) void chain48_w16_kernel(const ArgsArr<
     C48_STAMP();
     lds_barrier();               // this item's X tile is complete (written during the previous item's second conv), T is free
     C48_STAMP();
-    conv48_pair(xt, w, wl + C48_WCONV + half * C48_WHALF, bias_lds, a.blk[0].a, EpiT48{tt, a.blk[0].a.vhi}, half, rp, lane, wave >> 2, [] {} C48_STAMP_PASS);
+    conv48_pair(xt, w, wl + C48_WCONV + half * C48_WHALF, bias_lds, a.blk[0].a, EpiT48{tt, a.blk[0].a.vhi}, half, rp, lane, [] {}, nullptr C48_STAMP_PASS);
     lds_barrier();               // T complete
     C48_STAMP();
     conv48_pair(tt, w, nullptr, bias_lds + T48::CH, a.blk[0].b,
-                EpiOut48{xt, a.y + (int64_t)s * a.y_ss + (int64_t)img0 * C48_IMG, a.B - img0, a.blk[0].b, a.blk[0].add}, half, rp, lane, wave >> 2,
+                EpiOut48<false>{xt, a.y + (int64_t)s * a.y_ss + (int64_t)img0 * C48_IMG, a.B - img0, a.blk[0].b, a.blk[0].add}, half, rp, lane,
                 [&] {            // the other X buffer (last read as item it - 1's residual, two barriers ago) <- item it + 1; then item it + 2 into registers
                   if (it + 1 < count) write_x(xn);
                   fetch(it + 2 < count ? item + 2 : item);
-                } C48_STAMP_PASS);
+                }, nullptr C48_STAMP_PASS);
     C48_STAMP();
   }
 }
 
-// ---- the same block WITHOUT workgroup barriers inside an item: ready flags between the stages (round 5) ---------------------------------
-// Why: with a barrier behind every conv the last wave's epilogue -- alone on its SIMD, 10 - 18 cycles per vector instruction -- is the tail of
-// every phase (profiles/r05_stamp_c48_w16.txt: 36 % / 58 % of the two phases).  Here a wave waits only for the waves whose data it reads:
-//   xr[rp][img] = i + 1 : rows 2 rp, 2 rp + 1 of image `img` of item i are in X[i & 1]        (written by wave (rp, half = img))
-//   ta[rp][half] = i + 1 : stem.0's output rows 2 rp, 2 rp + 1, channels of `half`, item i, are in T
-//   bm[rp][half] = i + 1 : that wave's stem.3 MFMAs of item i have read T (rows 2 rp - 1 .. 2 rp + 2)
-//   be[rp][half] = i + 1 : its stem.3 epilogue of item i has read the residual from X[i & 1]
-// and per item: wait xr[rp-1..rp+1] >= i + 1 | MFMAs a | wait bm[rp-1..rp+1] >= i | epilogue a -> T, ta = i + 1 | wait ta[rp-1..rp+1] >= i + 1 |
-// MFMAs b, bm = i + 1 | wait be[rp][other half] >= i, item i + 1's rows -> X[(i + 1) & 1], xr = i + 2 | epilogue b -> HBM, be = i + 1.
-// Every wait names work that lies earlier in program order of the wave it waits for, so the waves cannot wait in a cycle; the flags only grow.
-// The waves of a SIMD then stay one MFMA phase apart instead of meeting at a barrier twice per item.  A wait polls LDS with s_sleep between
-// polls and gives up after 2^20 polls (wrong results that the parity tests catch, never a hung GPU).  The sample change keeps its barrier.
-struct DFlags { int xr[16], ta[16], bm[16], be[16]; };
-__device__ __forceinline__ void df_wait(const int* f, int lo, int hi, int need) {      // f[2 lo .. 2 hi + 1] >= need
-#pragma unroll 1
-  for (int spin = 0; spin < (1 << 20); ++spin) {
-    int mn = 0x7fffffff;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const int idx = 2 * lo + q;
-      const int v = idx <= 2 * hi + 1 ? __hip_atomic_load(f + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
-      mn = v < mn ? v : mn;
-    }
-    if (__builtin_amdgcn_readfirstlane(mn) >= need) break;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__device__ __forceinline__ void df_wait1(const int* f, int need) {
-#pragma unroll 1
-  for (int spin = 0; spin < (1 << 20); ++spin) {
-    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= need) break;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__device__ __forceinline__ void df_set(int* f, int v) {      // (every lane stores the same value)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// ================================================================================================================================
+// down-sampling block 24 -> 48 (32 x 32 -> 16 x 16)
+//   LDS: X = the two images' centred 34 x 34 x 24 tiles (zero halo), T = stem.0's centred output (the chain kernel's 18 x 18 x 48 tile pair),
+//        the three convs' weights: stem.0 as N24 + TAIL fragments (2 halves x 7 k-steps), the shortcut as N24 (2 x 1), stem.3 as N24 (2 x 15).
+//   Per item:  barrier | per output row of the wave: shortcut (1 MFMA -> quint8 dwords that STAY in registers), stem.0 (7 MFMAs -> T) |
+//              barrier | stem.3 (30 MFMAs for the row pair), the next item's X tile written behind its MFMAs (X is not read in this phase),
+//              epilogue: + shortcut registers, ReLU -> HBM.
+// ================================================================================================================================
+struct X24 {                                   // 32 x 32 x 24 map with a one-pixel zero halo (the layer-1 kernel's tile)
+  static constexpr int H = 32, CH = 24, TW = 34, PIXB = 24, PITCH = TW * PIXB, TILE_BYTES = TW * TW * PIXB;
+};
+constexpr int D24_KSA = 7, D24_WA_HALF = D24_KSA * 1024, D24_WS_HALF = 1024;
+struct WA24 { static constexpr int NT = 2, KS = D24_KSA; };
+struct WS24 { static constexpr int NT = 2, KS = 1; };
+constexpr int D24_XT = C48_G * X24::TILE_BYTES + 2 * X24::PITCH + 64;      // + slack: the tail fragment of the last row pair reads one row past the tile
+constexpr int D24_IMG_IN = X24::H * X24::H * X24::CH;
+constexpr int d24_lds() { return D24_XT + C48_TILES + 2 * D24_WA_HALF + 2 * D24_WS_HALF + C48_WCONV + 3 * T48::CH * 4; }
+#define QBNN_MAGIC_BITS48 0x4B400000
+
+// 1.5 * 2^23 + z_w R for an accumulator started at 1.5 * 2^23: as_float(acc) - that = (float)(sum - z_w R) exactly (qbnn_w16.hip: epilogue24, MAGIC)
+__device__ __forceinline__ float magic_c(const v16i& acc, const QConv& p) {
+  return __builtin_fmaf((float)p.z_w, __int_as_float(half_lo_bcast(acc[T48::ONES_REG])) - QBNN_MAGIC, QBNN_MAGIC);
 }
 
 template <int NM>
-__global__ __launch_bounds__(C48_THREADS) void chain48_df_kernel(const ArgsArr<ChainArgs<1>, NM> all) {
-  const ChainArgs<1> a = args_of(all, blockIdx.y);
+__global__ __launch_bounds__(C48_THREADS) void down24_w16_kernel(const ArgsArr<DownArgs, NM> all) {
+  const DownArgs a = args_of(all, blockIdx.y);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* xt0 = smem;
-  uint8_t* tt = smem + 2 * C48_TILES;
-  uint8_t* wl = smem + 3 * C48_TILES;
-  float* bias_lds = reinterpret_cast<float*>(wl + 2 * C48_WCONV);
-  DFlags* fl = reinterpret_cast<DFlags*>(bias_lds + 2 * T48::CH);
+  uint8_t* xt = smem;                                       // centred block input, two 34 x 34 x 24 tiles
+  uint8_t* tt = smem + D24_XT;                              // centred stem.0 output (T48 tiles)
+  uint8_t* wa = tt + C48_TILES;                             // stem.0:   [half][7 fragment tiles]
+  uint8_t* ws = wa + 2 * D24_WA_HALF;                       // shortcut: [half][1]
+  uint8_t* wb = ws + 2 * D24_WS_HALF;                       // stem.3:   [half][15]
+  float* bias_lds = reinterpret_cast<float*>(wb + C48_WCONV);      // [3][48]: s, a, b
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = wave & 1, rp = wave >> 1, lo = rp > 0 ? rp - 1 : 0, hi = rp < 7 ? rp + 1 : 7, me = 2 * rp + half;
+  const int half = wave & 1, rp = wave >> 1;
 
   const int groups = (a.B + C48_G - 1) / C48_G;
   int begin, count;
   item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
   if (count <= 0) return;
 
-  zero_halo<T48::TW, T48::PIXB, T48::TILE_BYTES, C48_G, C48_THREADS>(xt0, tid);
-  zero_halo<T48::TW, T48::PIXB, T48::TILE_BYTES, C48_G, C48_THREADS>(xt0 + C48_TILES, tid);
+  zero_halo<X24::TW, X24::PIXB, X24::TILE_BYTES, C48_G, C48_THREADS>(xt, tid);
   zero_halo<T48::TW, T48::PIXB, T48::TILE_BYTES, C48_G, C48_THREADS>(tt, tid);
-  load_bias<T48::CH, C48_THREADS>(bias_lds, a.blk[0].a.bias, tid);
-  load_bias<T48::CH, C48_THREADS>(bias_lds + T48::CH, a.blk[0].b.bias, tid);
-  if (tid < 64) reinterpret_cast<int*>(fl)[tid] = tid < 16 ? 1 : 0;      // xr = 1: item 0's rows are written below, in front of the first barrier
+  load_bias<T48::CH, C48_THREADS>(bias_lds, a.s.bias, tid);
+  load_bias<T48::CH, C48_THREADS>(bias_lds + T48::CH, a.a.bias, tid);
+  load_bias<T48::CH, C48_THREADS>(bias_lds + 2 * T48::CH, a.b.bias, tid);
 
-  // this wave's two rows of image `half`: 2 x 768 bytes = 96 16-byte chunks over 64 lanes, fetched one item ahead
-  constexpr int RCH = T48::H * T48::CH / 16;        // chunks per image row
-  v4i pre[2];
-  auto fetch_rows = [&](int item) {
+  // the item's input: 2 x 24576 bytes = 3072 16-byte chunks over 1024 threads (an image row is 768 bytes = 48 chunks), fetched one item ahead
+  constexpr int CPI = D24_IMG_IN / 16, RCH = X24::H * X24::CH / 16, PER_T = C48_G * CPI / C48_THREADS;
+  static_assert(C48_G * CPI == PER_T * C48_THREADS, "whole chunks per thread");
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
     const int s = item / groups, img0 = (item - s * groups) * C48_G;
-    const int gi = img0 + half < a.B ? img0 + half : a.B - 1;             // (a missing second image: any valid address, its results are not stored)
-    int l_ = lane;
-    asm volatile("" : "+v"(l_));
-    const uint8_t* src = a.x + (int64_t)s * a.x_ss + (int64_t)gi * C48_IMG + (2 * rp) * (RCH * 16) + l_ * 16;
-    pre[0] = *reinterpret_cast<const v4i*>(src);
-    pre[1] = *reinterpret_cast<const v4i*>(src + (l_ < 32 ? 64 * 16 : 0));
-  };
-  auto write_rows = [&](uint8_t* xt) {
-    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
-    int l_ = lane;
-    asm volatile("" : "+v"(l_));
-    uint8_t* dst = xt + half * T48::TILE_BYTES + (2 * rp + 1) * T48::PITCH + T48::PIXB;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss;
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = l_ + 64 * j;
-      if (c < 2 * RCH) {
-        const int r = c >= RCH ? 1 : 0, within = c - r * RCH;
-        const v4i v = pre[j];
-        *reinterpret_cast<v4i*>(dst + r * T48::PITCH + within * 16) =
-            v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)};
-      }
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = t_ + j * C48_THREADS;
+      const int g = i / CPI, rem = i - g * CPI;
+      const int gi = img0 + g < a.B ? img0 + g : a.B - 1;
+      pre[j] = *reinterpret_cast<const v4i*>(xs + (int64_t)gi * D24_IMG_IN + (int64_t)rem * 16);
     }
   };
-  fetch_rows(begin);
-  write_rows(xt0);
-  fetch_rows(count > 1 ? begin + 1 : begin);
+  auto write_x = [&]() {
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = t_ + j * C48_THREADS;
+      const int g = i / CPI, rem = i - g * CPI, row = rem / RCH, within = rem - row * RCH;
+      const v4i v = pre[j];
+      uint8_t* d = xt + g * X24::TILE_BYTES + (row + 1) * X24::PITCH + X24::PIXB + within * 16;      // (24-byte pixels: 8-byte aligned)
+      *reinterpret_cast<v2i*>(d) = v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)};
+      *reinterpret_cast<v2i*>(d + 8) = v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)};
+    }
+  };
+  fetch(begin);
+  write_x();
 
-  v4i w[T48::KS];
   int cur_s = -1;
-#ifdef QBNN_C48_STAMP
-  const bool st_on = false;
-  int st_k = 0;
-#endif
   for (int it = 0; it < count; ++it) {
     const int item = begin + it;
     const int s = item / groups, img0 = (item - s * groups) * C48_G;
-    uint8_t* xt = xt0 + (it & 1) * C48_TILES;
-    uint8_t* xn = xt0 + ((it + 1) & 1) * C48_TILES;
-    if (s != cur_s) {            // workgroup-uniform; a few times per launch (and at the first item: publishes the prologue's LDS writes)
+    if (s != cur_s) {            // workgroup-uniform; a few times per launch
       __syncthreads();
       int l_ = lane;
       asm volatile("" : "+v"(l_));
-      dma_conv<W48, C48_WAVES>(wl, a.blk[0].a.w + (int64_t)s * a.blk[0].a.w_ss, wave, l_);
-      dma_conv<W48, C48_WAVES>(wl + C48_WCONV, a.blk[0].b.w + (int64_t)s * a.blk[0].b.w_ss, wave, l_);
+      dma_conv<WA24, C48_WAVES>(wa, a.a.w + (int64_t)s * a.a.w_ss, wave, l_);
+      dma_conv<WS24, C48_WAVES>(ws, a.s.w + (int64_t)s * a.s.w_ss, wave, l_);
+      dma_conv<W48, C48_WAVES>(wb, a.b.w + (int64_t)s * a.b.w_ss, wave, l_);
       dma_barrier();
       cur_s = s;
     }
+    uint32_t scr[2][3];          // the shortcut's quint8 output of this wave's two rows (its channel half): the residual of stem.3's epilogue
+    v4i wbr[T48::KS];
+    lds_barrier();               // X complete (written during the previous item's stem.3), T free
     {
+      // ---- phase 1: per output row, shortcut (1x1 / s2, K = 24 -> one k-step) and stem.0 (3x3 / s2, K = 216 -> 7 k-steps, TAIL form)
       int l_ = lane;
       asm volatile("" : "+v"(l_));
+      const int r = l_ & 31, h = l_ >> 5, img = r >> 4, col = r & 15;
+      v4i war[D24_KSA];
 #pragma unroll
-      for (int ks = 0; ks < T48::KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wl + half * C48_WHALF + l_ * 16 + ks * 1024);
+      for (int ks = 0; ks < D24_KSA; ++ks) war[ks] = *reinterpret_cast<const v4i*>(wa + half * D24_WA_HALF + l_ * 16 + ks * 1024);
+      const v4i wsr = *reinterpret_cast<const v4i*>(ws + half * D24_WS_HALF + l_ * 16);
+      int m = QBNN_MAGIC_BITS48;
+      asm volatile("" : "+v"(m));            // the start block is built here, per phase (kept in scratch across the item loop otherwise: qbnn_w16.hip)
+      const v16i mg = v16i{m, m, m, m, m, m, m, m, m, m, m, m, m, m, m, m};
+      // output pixel (oh, col) reads input rows 2 oh - 1 .. 2 oh + 1 = tile rows 2 oh .. 2 oh + 2, columns 2 col - 1 .. = tile columns 2 col ..
+      const uint8_t* px0 = xt + img * X24::TILE_BYTES + (2 * col) * X24::PIXB;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int oh = 2 * rp + i;
+        const uint8_t* base = px0 + (2 * oh) * X24::PITCH + 16 * h;
+        const uint8_t* tbase = px0 + (2 * oh + (h ? 2 : 0)) * X24::PITCH + 64;      // tails: k-half 0 = rows 0, 1 of the window; k-half 1 = row 2 (, 3: unused)
+        {                      // shortcut: the centre pixel = tile (2 oh + 1, 2 col + 1): its 24 channels + 8 bytes of the next pixel (weights 0)
+          const uint8_t* cp = base + X24::PITCH + X24::PIXB;
+          const v2i c0 = *reinterpret_cast<const v2i*>(cp), c1 = *reinterpret_cast<const v2i*>(cp + 8);
+          const v16i accs = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsr, v4i{c0.x, c0.y, c1.x, c1.y}, mg, 0, 0, 0);
+          // its epilogue (no ReLU): EpiDense<HAS_RES = false>'s arithmetic; the dwords stay in registers.  (One conv after the other, each with its
+          // bias table read just before: both accumulators + both tables beside stem.0's weights do not fit 128 VGPRs.)
+          float4 bs[3];
+#pragma unroll
+          for (int g4 = 0; g4 < 3; ++g4) bs[g4] = *reinterpret_cast<const float4*>(bias_lds + 24 * half + 8 * g4 + 4 * h);
+          const float cm = magic_c(accs, a.s);
+          const float zy = (float)a.s.z_y;
+#pragma unroll
+          for (int g4 = 0; g4 < 3; ++g4) {
+            float v[4];
+            const float bb[4] = {bs[g4].x, bs[g4].y, bs[g4].z, bs[g4].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = med3f(__builtin_fmaf(bb[q], a.s.rcp, __int_as_float(accs[4 * g4 + q]) - cm) * a.s.mult, a.s.vlo, a.s.vhi);
+            scr[i][g4] = pack_low_bytes((v[0] + QBNN_MAGIC) + zy, (v[1] + QBNN_MAGIC) + zy, (v[2] + QBNN_MAGIC) + zy, (v[3] + QBNN_MAGIC) + zy);
+            // (pinned: the dwords are first USED behind the next barrier, and the optimiser otherwise sinks this whole epilogue there -- with
+            //  the shortcut's 16 accumulators and its bias table parked in scratch across the barrier)
+            asm volatile("" : "+v"(scr[i][g4]));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        v16i acc = mg;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const v2i lo = *reinterpret_cast<const v2i*>(base + kh * X24::PITCH + t * 32), hi = *reinterpret_cast<const v2i*>(base + kh * X24::PITCH + t * 32 + 8);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(war[kh * 2 + t], v4i{lo.x, lo.y, hi.x, hi.y}, acc, 0, 0, 0);
+          }
+        {
+          const v2i lo = *reinterpret_cast<const v2i*>(tbase), hi = *reinterpret_cast<const v2i*>(tbase + X24::PITCH);
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(war[6], v4i{lo.x, lo.y, hi.x, hi.y}, acc, 0, 0, 0);
+        }
+        {                      // stem.0 epilogue (ReLU-fused): centred bytes into T
+          float4 ba[3];
+#pragma unroll
+          for (int g4 = 0; g4 < 3; ++g4) ba[g4] = *reinterpret_cast<const float4*>(bias_lds + T48::CH + 24 * half + 8 * g4 + 4 * h);
+          const float cm = magic_c(acc, a.a);
+          const int po = px48(img, oh, col);
+#pragma unroll
+          for (int g4 = 0; g4 < 3; ++g4) {
+            float v[4];
+            const float bb[4] = {ba[g4].x, ba[g4].y, ba[g4].z, ba[g4].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = __builtin_fmaf(bb[q], a.a.rcp, __int_as_float(acc[4 * g4 + q]) - cm) * a.a.mult;
+            *reinterpret_cast<uint32_t*>(tt + po + 24 * half + 8 * g4 + 4 * h) = pack_rne_u8(v[0], v[1], v[2], v[3], a.a.vhi);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);     // (keeps the stem.3 weight reads below behind the row loop: hoisted to the phase's top they are spilled)
+#pragma unroll
+      for (int ks = 0; ks < T48::KS; ++ks) wbr[ks] = *reinterpret_cast<const v4i*>(wb + half * C48_WHALF + l_ * 16 + ks * 1024);
     }
-    df_wait(fl->xr, lo, hi, it + 1);
-    conv48_pair(xt, w, wl + C48_WCONV + half * C48_WHALF, bias_lds, a.blk[0].a, EpiT48{tt, a.blk[0].a.vhi}, half, rp, lane, wave >> 2,
-                [&] { df_wait(fl->bm, lo, hi, it); } C48_STAMP_PASS);
-    df_set(fl->ta + me, it + 1);
-    df_wait(fl->ta, lo, hi, it + 1);
-    conv48_pair(tt, w, nullptr, bias_lds + T48::CH, a.blk[0].b,
-                EpiOut48{xt, a.y + (int64_t)s * a.y_ss + (int64_t)img0 * C48_IMG, a.B - img0, a.blk[0].b, a.blk[0].add}, half, rp, lane, wave >> 2,
-                [&] {
-                  df_set(fl->bm + me, it + 1);
-                  if (it + 1 < count) {
-                    df_wait1(fl->be + (me ^ 1), it);
-                    write_rows(xn);
-                    df_set(fl->xr + me, it + 2);
-                  }
-                  fetch_rows(it + 2 < count ? item + 2 : item);
-                } C48_STAMP_PASS);
-    df_set(fl->be + me, it + 1);
+    lds_barrier();               // T complete; X has been read for the last time in this item
+#ifdef QBNN_C48_STAMP
+    const bool st_on = false;
+    int st_k = 0;
+#endif
+    conv48_pair(tt, wbr, nullptr, bias_lds + 2 * T48::CH, a.b,
+                EpiOut48<true>{nullptr, a.y + (int64_t)s * a.y_ss + (int64_t)img0 * C48_IMG, a.B - img0, a.b, a.add}, half, rp, lane,
+                [&] { fetch(it + 1 < count ? item + 1 : item); }, scr C48_STAMP_PASS);
+    // The next item's input: requested behind stem.3's MFMAs (the 60 weight registers and the pixel fragments are dead by then), in flight under
+    // its two epilogues, written to the X tile here -- X is not read in this phase, and the barrier at the loop top publishes it.  (Fetched a whole
+    // item ahead, as the chain kernel does, the 12 registers do not fit beside stem.3's operands: the compiler parks them in scratch right behind the
+    // loads, i.e. waits for HBM at the fetch.)
+    write_x();
   }
 }
 
-static bool c48_dataflow() {
-  static const bool v = [] { const char* e = getenv("QBNN_C48_DF"); return e && e[0] == '1'; }();      // off: measured 6 % slower than the barrier form (profiles/r05_stamp_c48_w16.txt)
-  return v;
-}
-
-template <int NM>
-int launch_c48(const ChainArgs<1>* arr, int n, hipStream_t st) {
-  constexpr int LDS = c48_lds();
-  static_assert(LDS <= 160 * 1024, "LDS budget");
-  static_assert(sizeof(ArgsArr<ChainArgs<1>, NM>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
-  static std::atomic<uint64_t> attr{0}, attr_df{0};
-  if (c48_dataflow()) {
-    if (int rc_attr = ensure_dyn_lds((const void*)chain48_df_kernel<NM>, attr_df, LDS)) return rc_attr;
-    ArgsArr<ChainArgs<1>, NM> all;
-    memset(&all, 0, sizeof(all));
-    int items = 0;
-    for (int i = 0; i < n; ++i) {
-      all.m[i] = arr[i];
-      const int it = arr[i].n_samples * ((arr[i].B + C48_G - 1) / C48_G);
-      items = it > items ? it : items;
-    }
-    const int per = 256 / n > 0 ? 256 / n : 1;
-    const int gx = items < per ? (items > 0 ? items : 1) : per;
-    hipLaunchKernelGGL((chain48_df_kernel<NM>), dim3(gx, n), dim3(C48_THREADS), LDS, st, all);
-    return check_launch("qbnn_block_chain_i8_mc (48 channels, N24 layout, ready flags)");
-  }
-  if (int rc_attr = ensure_dyn_lds((const void*)chain48_w16_kernel<NM>, attr, LDS)) return rc_attr;
-  ArgsArr<ChainArgs<1>, NM> all;
+template <int NM, class A, class K>
+int launch_items(K kernel, const char* what, int lds, const A* arr, int n, hipStream_t st, std::atomic<uint64_t>& attr) {
+  static_assert(sizeof(ArgsArr<A, NM>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
+  if (int rc_attr = ensure_dyn_lds((const void*)kernel, attr, lds)) return rc_attr;
+  ArgsArr<A, NM> all;
   memset(&all, 0, sizeof(all));
   int items = 0;
   for (int i = 0; i < n; ++i) {
@@ -484,29 +463,40 @@ int launch_c48(const ChainArgs<1>* arr, int n, hipStream_t st) {
   }
   const int per = 256 / n > 0 ? 256 / n : 1;
   const int gx = items < per ? (items > 0 ? items : 1) : per;
-  hipLaunchKernelGGL((chain48_w16_kernel<NM>), dim3(gx, n), dim3(C48_THREADS), LDS, st, all);
-  return check_launch("qbnn_block_chain_i8_mc (48 channels, N24 layout)");
+  hipLaunchKernelGGL(kernel, dim3(gx, n), dim3(C48_THREADS), lds, st, all);
+  return check_launch(what);
+}
+template <class A, class K>
+int launch_items_dev(K kernel, const char* what, int lds, const A* dev, int n, int items, hipStream_t st, std::atomic<uint64_t>& attr) {
+  if (int rc_attr = ensure_dyn_lds((const void*)kernel, attr, lds)) return rc_attr;
+  const int per = 256 / n > 0 ? 256 / n : 1;
+  const int gx = items < per ? (items > 0 ? items : 1) : per;
+  hipLaunchKernelGGL(kernel, dim3(gx, n), dim3(C48_THREADS), lds, st, ArgsArr<A, 0>{dev});
+  return check_launch(what);
 }
 
 }  // namespace
 
 // entry points for qbnn_blocks.hip (declared in qbnn_host.h)
 int qbnn_launch_chain48_w16(const ChainArgs<1>* arr, int n, hipStream_t st) {
+  static_assert(c48_lds() <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr1{0}, attrN{0};
   if (n < 1 || n > QBNN_FUSED_CALLS) return fail(QBNN_E_INVALID, "qbnn_launch_chain48_w16: 1 to 8 argument blocks per launch%s");
-  if (n == 1) return launch_c48<1>(arr, 1, st);
-  return launch_c48<QBNN_FUSED_CALLS>(arr, n, st);
+  if (n == 1) return launch_items<1>(chain48_w16_kernel<1>, "qbnn_block_chain_i8_mc (48 channels, N24 layout)", c48_lds(), arr, 1, st, attr1);
+  return launch_items<QBNN_FUSED_CALLS>(chain48_w16_kernel<QBNN_FUSED_CALLS>, "qbnn_block_chain_i8_multi (48 channels, N24 layout)", c48_lds(), arr, n, st, attrN);
 }
 int qbnn_launch_chain48_w16_dev(const ChainArgs<1>* dev, int n, int items, hipStream_t st) {
-  constexpr int LDS = c48_lds();
-  static std::atomic<uint64_t> attr{0}, attr_df{0};
-  const int per = 256 / n > 0 ? 256 / n : 1;
-  const int gx = items < per ? (items > 0 ? items : 1) : per;
-  if (c48_dataflow()) {
-    if (int rc_attr = ensure_dyn_lds((const void*)chain48_df_kernel<0>, attr_df, LDS)) return rc_attr;
-    hipLaunchKernelGGL((chain48_df_kernel<0>), dim3(gx, n), dim3(C48_THREADS), LDS, st, ArgsArr<ChainArgs<1>, 0>{dev});
-    return check_launch("qbnn_block_chain_i8_multi_launch (48 channels, N24 layout, ready flags)");
-  }
-  if (int rc_attr = ensure_dyn_lds((const void*)chain48_w16_kernel<0>, attr, LDS)) return rc_attr;
-  hipLaunchKernelGGL((chain48_w16_kernel<0>), dim3(gx, n), dim3(C48_THREADS), LDS, st, ArgsArr<ChainArgs<1>, 0>{dev});
-  return check_launch("qbnn_block_chain_i8_multi_launch (48 channels, N24 layout)");
+  static std::atomic<uint64_t> attr{0};
+  return launch_items_dev(chain48_w16_kernel<0>, "qbnn_block_chain_i8_multi_launch (48 channels, N24 layout)", c48_lds(), dev, n, items, st, attr);
+}
+int qbnn_launch_down24_w16(const DownArgs* arr, int n, hipStream_t st) {
+  static_assert(d24_lds() <= 160 * 1024, "LDS budget");
+  static std::atomic<uint64_t> attr1{0}, attrN{0};
+  if (n < 1 || n > QBNN_FUSED_CALLS) return fail(QBNN_E_INVALID, "qbnn_launch_down24_w16: 1 to 8 argument blocks per launch%s");
+  if (n == 1) return launch_items<1>(down24_w16_kernel<1>, "qbnn_block_down_i8_mc (24 -> 48, N24 layout)", d24_lds(), arr, 1, st, attr1);
+  return launch_items<QBNN_FUSED_CALLS>(down24_w16_kernel<QBNN_FUSED_CALLS>, "qbnn_block_down_i8_multi (24 -> 48, N24 layout)", d24_lds(), arr, n, st, attrN);
+}
+int qbnn_launch_down24_w16_dev(const DownArgs* dev, int n, int items, hipStream_t st) {
+  static std::atomic<uint64_t> attr{0};
+  return launch_items_dev(down24_w16_kernel<0>, "qbnn_block_down_i8_multi_launch (24 -> 48, N24 layout)", d24_lds(), dev, n, items, st, attr);
 }

@@ -58,6 +58,9 @@ int qbnn_launch_stem_chain_w16_drop(const ChainArgs<2>& a, const DropSet<5>& dr,
 // value, or any number in device memory
 int qbnn_launch_chain48_w16(const ChainArgs<1>* arr, int n, hipStream_t st);
 int qbnn_launch_chain48_w16_dev(const ChainArgs<1>* dev, int n, int items, hipStream_t st);
+// ... and the 24 -> 48 down-sampling block (stem.0 as MFMA32_N24_TAIL, shortcut and stem.3 as MFMA32_N24)
+int qbnn_launch_down24_w16(const DownArgs* arr, int n, hipStream_t st);
+int qbnn_launch_down24_w16_dev(const DownArgs* dev, int n, int items, hipStream_t st);
 // Ring form of the wide down-sampling blocks (qbnn_down_ring.hip): 48 -> 96 at 16 x 16 and 96 -> 192 at 8 x 8; `n` argument blocks by value
 // (n <= QBNN_FUSED_CALLS) or any number in device memory.  QBNN_DOWN_RING=0 selects the L2-streaming kernels of qbnn_blocks.hip (A/B checks).
 int qbnn_launch_block_down_ring(const DownArgs* arr, int n, int Cin, hipStream_t st);

@@ -66,18 +66,23 @@ QBNN_EXPORT int qbnn_version(void) { return QBNN_ABI_VERSION; }
 //       F + 1 k-steps above, the last one mostly padding: 3 x 3 taps of 24 channels = 72-byte rows -> 3 x 3 = 9 k-steps for 216 weights per
 //       output channel.  Here the packed K axis is [row 0's first 32 F bytes | row 1's | ... | the rows' T-byte tails back to back | 0]:
 //       rows * F + 1 k-steps (7 for the 24-channel convs), when rows * T <= 32 and T % 4 == 0.  Only the layer-1 kernel (qbnn_w16.hip) reads it.
+//   QBNN_LAYOUT_MFMA32_N24_TAIL: both (24 output channels per tile AND gathered tails): stem.0 of the 24 -> 48 down block (qbnn_c48.hip).
 // =====================================================================================
 
 struct PackGeom { int cout, k, krow, rows, rbp, kp, KS, NT, tr, tail_f; };      // tr: output channels per tile (32, or 24 for _N24); tail_f: F of _TAIL, else 0
 static inline PackGeom pack_geom(int cout, int k, int krow, int layout = QBNN_LAYOUT_MFMA32) {
   PackGeom g;
   g.cout = cout; g.k = k; g.krow = krow; g.rows = k / krow; g.rbp = ceil_div(krow, 32) * 32;
-  g.tr = layout == QBNN_LAYOUT_MFMA32_N24 ? 24 : 32;
-  g.tail_f = layout == QBNN_LAYOUT_MFMA32_TAIL ? krow / 32 : 0;
+  g.tr = (layout == QBNN_LAYOUT_MFMA32_N24 || layout == QBNN_LAYOUT_MFMA32_N24_TAIL) ? 24 : 32;
+  g.tail_f = (layout == QBNN_LAYOUT_MFMA32_TAIL || layout == QBNN_LAYOUT_MFMA32_N24_TAIL) ? krow / 32 : 0;
   g.kp = g.rows * g.rbp; g.KS = g.tail_f ? g.rows * g.tail_f + 1 : g.kp / 32; g.NT = ceil_div(cout, g.tr);
   return g;
 }
-static inline bool is_mfma_layout(int layout) { return layout == QBNN_LAYOUT_MFMA32 || layout == QBNN_LAYOUT_MFMA32_N24 || layout == QBNN_LAYOUT_MFMA32_TAIL; }
+static inline bool is_mfma_layout(int layout) {
+  return layout == QBNN_LAYOUT_MFMA32 || layout == QBNN_LAYOUT_MFMA32_N24 || layout == QBNN_LAYOUT_MFMA32_TAIL || layout == QBNN_LAYOUT_MFMA32_N24_TAIL;
+}
+static inline bool layout_n24(int layout) { return layout == QBNN_LAYOUT_MFMA32_N24 || layout == QBNN_LAYOUT_MFMA32_N24_TAIL; }
+static inline bool layout_tail(int layout) { return layout == QBNN_LAYOUT_MFMA32_TAIL || layout == QBNN_LAYOUT_MFMA32_N24_TAIL; }
 // shapes the layout is defined for: ragged kernel rows whose tails fit ONE k-step, whole Philox blocks per tail
 static inline bool tail_layout_ok(int k, int krow) {
   if (krow <= 0 || k % krow) return false;
@@ -93,8 +98,8 @@ static inline int packed_kp(const PackGeom& g, int kh, int j) {
 
 QBNN_EXPORT size_t qbnn_packed_weight_bytes(int32_t cout, int32_t k, int32_t krow, int32_t layout) {
   if (layout == QBNN_LAYOUT_ROWMAJOR) return ((size_t)cout * k + 15) / 16 * 16;
-  if (!is_mfma_layout(layout) || krow <= 0 || k % krow || (layout == QBNN_LAYOUT_MFMA32_N24 && cout % 24)) return 0;
-  if (layout == QBNN_LAYOUT_MFMA32_TAIL && !tail_layout_ok(k, krow)) return 0;
+  if (!is_mfma_layout(layout) || krow <= 0 || k % krow || (layout_n24(layout) && cout % 24)) return 0;
+  if (layout_tail(layout) && !tail_layout_ok(k, krow)) return 0;
   const PackGeom g = pack_geom(cout, k, krow, layout);
   return (size_t)g.NT * g.KS * 1024;
 }
@@ -108,10 +113,10 @@ QBNN_EXPORT int qbnn_pack_weights_host(const int8_t* src, int32_t cout, int32_t 
   }
   if (!is_mfma_layout(layout)) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: unknown layout%s");
   if (krow <= 0 || k % krow) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: k must be a multiple of krow%s");
-  if (layout == QBNN_LAYOUT_MFMA32_N24 && cout % 24) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: the N24 layout takes cout % 24 == 0%s");
+  if (layout_n24(layout) && cout % 24) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: the N24 layout takes cout % 24 == 0%s");
   const PackGeom g = pack_geom(cout, k, krow, layout);
   memset(dst, 0, (size_t)g.NT * g.KS * 1024);
-  if (layout == QBNN_LAYOUT_MFMA32_TAIL && !tail_layout_ok(k, krow)) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: the TAIL layout takes ragged kernel rows whose tails fit one k-step%s");
+  if (layout_tail(layout) && !tail_layout_ok(k, krow)) return fail(QBNN_E_INVALID, "qbnn_pack_weights_host: the TAIL layout takes ragged kernel rows whose tails fit one k-step%s");
   auto put = [&](int nt, int col, int kk, int8_t v) {
     const int kp = packed_kp(g, kk / krow, kk % krow);
     const int ks = kp >> 5, half = (kp >> 4) & 1, b = kp & 15;
@@ -244,8 +249,8 @@ QBNN_EXPORT int qbnn_sample_weights_i8(const int8_t* mu_packed, const int8_t* si
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: unknown layout%s");
   if (is_mfma_layout(layout) && (krow <= 0 || k % krow))
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: k must be a multiple of krow%s");
-  if (layout == QBNN_LAYOUT_MFMA32_N24 && cout % 24) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: the N24 layout takes cout % 24 == 0%s");
-  if (layout == QBNN_LAYOUT_MFMA32_TAIL && !tail_layout_ok(k, krow)) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: the TAIL layout takes ragged kernel rows whose tails fit one k-step%s");
+  if (layout_n24(layout) && cout % 24) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: the N24 layout takes cout % 24 == 0%s");
+  if (layout_tail(layout) && !tail_layout_ok(k, krow)) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: the TAIL layout takes ragged kernel rows whose tails fit one k-step%s");
   const size_t bytes = qbnn_packed_weight_bytes(cout, k, krow, layout);
   if ((size_t)w_sample_stride < bytes || (w_sample_stride & 15))
     return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8: w_sample_stride too small or not 16-byte aligned%s");
@@ -466,8 +471,8 @@ QBNN_EXPORT int qbnn_sample_weights_i8_multi(const qbnn_sampler_layer* layers, i
     if (!frag && q.layout != QBNN_LAYOUT_ROWMAJOR) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: unknown layout%s");
     if (frag && (q.krow <= 0 || q.k % q.krow))
       return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: k must be a multiple of krow%s");
-    if (q.layout == QBNN_LAYOUT_MFMA32_N24 && q.cout % 24) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: the N24 layout takes cout % 24 == 0%s");
-    if (q.layout == QBNN_LAYOUT_MFMA32_TAIL && !tail_layout_ok(q.k, q.krow)) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: the TAIL layout takes ragged kernel rows whose tails fit one k-step%s");
+    if (layout_n24(q.layout) && q.cout % 24) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: the N24 layout takes cout % 24 == 0%s");
+    if (layout_tail(q.layout) && !tail_layout_ok(q.k, q.krow)) return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: the TAIL layout takes ragged kernel rows whose tails fit one k-step%s");
     const size_t bytes = qbnn_packed_weight_bytes(q.cout, q.k, q.krow, q.layout);
     if ((size_t)q.w_sample_stride < bytes || (q.w_sample_stride & 15))
       return fail(QBNN_E_INVALID, "qbnn_sample_weights_i8_multi: w_sample_stride too small or unaligned%s");

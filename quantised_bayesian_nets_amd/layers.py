@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import _lib
 from .quant import INT_BOUNDS, UINT_BOUNDS, make_sample_params
 
-LAYOUT_MFMA32, LAYOUT_ROWMAJOR, LAYOUT_MFMA32_N24, LAYOUT_MFMA32_TAIL = 0, 1, 2, 3      # include/qbnn.h: QBNN_LAYOUT_*
+LAYOUT_MFMA32, LAYOUT_ROWMAJOR, LAYOUT_MFMA32_N24, LAYOUT_MFMA32_TAIL, LAYOUT_MFMA32_N24_TAIL = 0, 1, 2, 3, 4      # include/qbnn.h: QBNN_LAYOUT_*
 
 
 def w16_enabled():

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .layers import LAYOUT_MFMA32, LAYOUT_MFMA32_N24, LAYOUT_MFMA32_TAIL, w16_enabled, Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_context, timed, sample_all_weights
+from .layers import LAYOUT_MFMA32, LAYOUT_MFMA32_N24, LAYOUT_MFMA32_TAIL, LAYOUT_MFMA32_N24_TAIL, w16_enabled, Conv2d, ConvReLU2d, Linear, MCQTensor, QFunctional, _MC, mc_context, timed, sample_all_weights
 from .quant import UINT_BOUNDS, check_bits
 
 
@@ -70,8 +70,9 @@ def _fill_block_desc(d, blk, dev, keep):
     d.w_b, d.w_b_sample_stride, d.bias_b = wb.data_ptr(), wb.shape[1], (pb["bias"].data_ptr() if pb["bias"] is not None else None)
     d.s_wb, d.z_wb, d.s_b, d.z_b = cb.add_weight.scale, cb.add_weight.zero_point, cb.scale, cb.zero_point
     d.s_o, d.z_o = blk.add.add.scale, blk.add.add.zero_point
-    assert ca.layout == cb.layout, "a block's two convs share one packed layout"
-    d.w_layout = ca.layout
+    # (the 24 -> 48 down block's layout set: stem.0 as MFMA32_N24_TAIL beside MFMA32_N24 for stem.3 and the shortcut)
+    assert ca.layout == cb.layout or (ca.layout, cb.layout) == (LAYOUT_MFMA32_N24_TAIL, LAYOUT_MFMA32_N24), "a block's convs share one packed layout set"
+    d.w_layout = cb.layout
 
 
 def run_down_block(blk, x):
@@ -222,6 +223,12 @@ class ConvNetwork_ResNet(nn.Module):
         blk = self.layers[4][1]
         for c in (blk.stem[0], blk.stem[3]):
             c.set_layout(LAYOUT_MFMA32_N24 if n24 else LAYOUT_MFMA32)
+        d24 = fused and os.environ.get("QBNN_D24", "1") != "0" and len(self.layers[4][0].shortcut) > 0      # the 24 -> 48 down block's 16-wave kernel
+        blk = self.layers[4][0]
+        blk.stem[0].set_layout(LAYOUT_MFMA32_N24_TAIL if d24 else LAYOUT_MFMA32)
+        blk.stem[3].set_layout(LAYOUT_MFMA32_N24 if d24 else LAYOUT_MFMA32)
+        if len(blk.shortcut):
+            blk.shortcut[0].set_layout(LAYOUT_MFMA32_N24 if d24 else LAYOUT_MFMA32)
         if fused_stem is None:
             fused_stem = fused and self.fuse_stem and len(self.layers[3][0].shortcut) == 0
         tail = fused_stem and w16_enabled() and len(self.layers[3]) == 2
@@ -562,7 +569,7 @@ class Network(nn.Module):
             elif step[0] == "down":
                 with timed("ensemble down %d" % step[3]):
                     if dargs:
-                        _lib.check(L.qbnn_block_down_i8_multi_launch(dargs, M, B, step[2], step[3], 1, st))
+                        _lib.check(L.qbnn_block_down_i8_multi_launch(dargs, M, B, step[2], step[3], step[1][0].desc.contents.blk.w_layout, 1, st))
                     else:
                         _lib.check(L.qbnn_block_down_i8_multi(step[1], M, B, step[2], step[3], p["a_hi"], st))
             else:

@@ -999,7 +999,7 @@ print("SWITCH-OK")
 
 
 @pytest.mark.parametrize("switch", ["QBNN_NO_PINGPONG", "QBNN_NO_STEM_FUSION", "QBNN_GENERIC_NAIVE", "QBNN_W16=0", "QBNN_DOWN_RING=0", "QBNN_CHAIN_RING=0",
-                                    "QBNN_C48=0", "QBNN_W16_MAGIC=0"])
+                                    "QBNN_C48=0", "QBNN_W16_MAGIC=0", "QBNN_D24=0"])
 def test_environment_switches_give_the_same_results(switch, tmp_path):
     """The A/B switches of README.md select other kernels for the same arithmetic (weights-stationary instead of ping-pong
     48-channel block; layers.0 as its own launch; the scalar any-geometry conv; the 8-wave layer-1 kernel instead of the 16-wave one; the round-3 forms of the wide down-sampling and identity blocks):
@@ -1707,6 +1707,17 @@ def test_fused_blocks_random_qparams_against_oracle(seed):
             torch.cuda.synchronize()
             got = y.cpu().numpy()
             assert np.array_equal(got, ref), (Cc, down, a_hi, int((got != ref).sum()))
+            if Cc == 24 and down:
+                # round 5: the 24 -> 48 block on the 16-wave kernel (csrc/qbnn_c48.hip): stem.0 as MFMA32_N24_TAIL, stem.3 and the shortcut as MFMA32_N24
+                wa2, nba2 = _pack_per_sample(L, wa, 4)
+                wb2, nbb2 = _pack_per_sample(L, wb, 2)
+                ws2, nbs2 = _pack_per_sample(L, ws, 2)
+                dd.blk.w_a, dd.blk.w_a_sample_stride, dd.blk.w_b, dd.blk.w_b_sample_stride, dd.blk.w_layout = wa2.data_ptr(), nba2, wb2.data_ptr(), nbb2, 2
+                dd.w_s, dd.w_s_sample_stride = ws2.data_ptr(), nbs2
+                y2 = torch.full((S, B, Ho, Ho, Co), 0xEE, dtype=torch.uint8, device="cuda")
+                _lib.check(L.qbnn_block_down_i8_mc(_lib.ptr(xd), xd[0].numel(), s_x, z_x, B, Hi, Ci, a_hi, C.byref(dd), _lib.ptr(y2), y2[0].numel(), S, st))
+                torch.cuda.synchronize()
+                assert np.array_equal(y2.cpu().numpy(), ref), ("down 24 -> 48, N24 set", a_hi, int((y2.cpu().numpy() != ref).sum()))
             if Cc == 48 and not down:
                 # round 5: the same block on the 16-wave kernel (csrc/qbnn_c48.hip) -- weights as (24 + 1)-row tile halves (MFMA32_N24)
                 wa2, nba2 = _pack_per_sample(L, wa, 2)
