@@ -339,6 +339,7 @@ __global__ __launch_bounds__(C48_THREADS) void down24_w16_kernel(const ArgsArr<D
   };
   fetch(begin);
   write_x();
+  fetch(count > 1 ? begin + 1 : begin);
 
   int cur_s = -1;
   for (int it = 0; it < count; ++it) {
@@ -440,12 +441,10 @@ __global__ __launch_bounds__(C48_THREADS) void down24_w16_kernel(const ArgsArr<D
 #endif
     conv48_pair(tt, wbr, nullptr, bias_lds + 2 * T48::CH, a.b,
                 EpiOut48<true>{nullptr, a.y + (int64_t)s * a.y_ss + (int64_t)img0 * C48_IMG, a.B - img0, a.b, a.add}, half, rp, lane,
-                [&] { fetch(it + 1 < count ? item + 1 : item); }, scr C48_STAMP_PASS);
-    // The next item's input: requested behind stem.3's MFMAs (the 60 weight registers and the pixel fragments are dead by then), in flight under
-    // its two epilogues, written to the X tile here -- X is not read in this phase, and the barrier at the loop top publishes it.  (Fetched a whole
-    // item ahead, as the chain kernel does, the 12 registers do not fit beside stem.3's operands: the compiler parks them in scratch right behind the
-    // loads, i.e. waits for HBM at the fetch.)
-    write_x();
+                [&] {            // X is not read in this phase: item it + 1's tile is written behind stem.3's MFMAs, item it + 2 goes into registers
+                  if (it + 1 < count) write_x();      // (requested only here, under the epilogues, and written after them: 0.431 against 0.411 ms)
+                  fetch(it + 2 < count ? item + 2 : item);
+                }, scr C48_STAMP_PASS);
   }
 }
 
