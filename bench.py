@@ -34,6 +34,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_I8_PEAK_TOPS = 5000.0   # int8 dense = 2x bf16 (2.5 PF)
 VALU_OPS_PLAIN, VALU_OPS_RES = 6, 13     # epilogue vector instructions per output element in the shipped ISA (profiles/r02_isa_epilogue.txt)
+VALU_OPS_PLAIN_MAGIC, VALU_OPS_RES_MAGIC = 5, 12      # ... where the accumulators start at 1.5 * 2^23 (round 5: the layer-1 kernel; one v_sub_f32 for sub + cvt)
 # What a SIMD issues of that instruction mix, measured IN the kernel clock domain (tools/issue_bench.hip, profiles/r03_issue_bench.txt:
 # s_memtime cycles, every SIMD busy, the epilogue's own dependent sequence sub / cvt / fma / mul / min / cvt_pk): 4.09 cycles per
 # wave-instruction with 2 resident waves per SIMD, 2.92 with 4, 2.21 with 8 (one wave alone: 8.2; "fast" add / mul / fma / sub 3.0 /
@@ -513,14 +514,17 @@ def main():
         # mix at the kernel's occupancy (the 16-wave layer-1 kernel: 4 waves per SIMD; the 8-wave block kernels: 2)
         outs = [S_local * Bx * (H // st) ** 2 * co for (H, ci, co, ks, st, nw) in m["convs"]]
         n_res = sum(1 for i, c in enumerate(m["convs"]) if m.get("res_convs") and i in m["res_convs"])
-        lane_ops = sum(o * (VALU_OPS_RES if (m.get("res_convs") and i in m["res_convs"]) else VALU_OPS_PLAIN) for i, o in enumerate(outs))
-        wps = 4 if (dom.startswith("stem") and os.environ.get("QBNN_W16", "1") != "0") else 2
+        w16 = dom.startswith("stem") and os.environ.get("QBNN_W16", "1") != "0"
+        magic = w16 and os.environ.get("QBNN_W16_MAGIC", "1") != "0"
+        ops_plain, ops_res = (VALU_OPS_PLAIN_MAGIC, VALU_OPS_RES_MAGIC) if magic else (VALU_OPS_PLAIN, VALU_OPS_RES)
+        lane_ops = sum(o * (ops_res if (m.get("res_convs") and i in m["res_convs"]) else ops_plain) for i, o in enumerate(outs))
+        wps = 4 if w16 else 2
         floor_s = lane_ops / 64.0 * VALU_ISSUE_CYCLES[wps] / 1024 / SHADER_CLOCK_HZ
         valu = {"epilogue_wave_instructions_per_launch": lane_ops / 64.0, "waves_per_simd": wps, "issue_cycles_per_instruction_measured": VALU_ISSUE_CYCLES[wps],
                 "floor_ms": round(floor_s * 1e3, 4), "frac": round(floor_s / avg_s, 4),
-                "ops_per_output": {"requant": VALU_OPS_PLAIN, "requant+add+relu": VALU_OPS_RES}, "residual_convs": n_res,
+                "ops_per_output": {"requant": ops_plain, "requant+add+relu": ops_res}, "residual_convs": n_res,
                 "note": "issue-slot time of the epilogue's vector instructions alone (profiles/r03_issue_bench.txt); the MFMAs of the same "
-                        "launch take further issue slots (a 9-MFMA + 72-VALU tile: 351 cycles at 4 waves per SIMD against 210 for the VALU alone)"}
+                        "launch take further issue slots (~16 cycles each; round 5: 7 per output row in the layer-1 kernel, whose weights are packed with the kernel rows' tails gathered)"}
         common = {"kernel": dom, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": d["n"],
                   "share_of_step_time": round(d["ms"] / (dt * 1e3), 3), "convs_in_launch": len(m["convs"]),
                   "algorithmic_bytes_per_launch": abytes, "algorithmic_ops_per_launch": ops, "traffic": traffic, "traffic_source": traffic_note,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end evidence: bench line, rocprofv3 kernel stats of the same command, HBM-traffic and utilisation counters.
 # usage (GPU box, repo root): tools/profile_round.sh [round tag, default r03]
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 rm -rf gpurun_out/final/stats gpurun_out/final/pmc_*
@@ -20,7 +20,7 @@ def src_sha():
     from quantised_bayesian_nets_amd import build as _b
     return _b.kernel_source_sha16()
 def bench_key(k):
-    rules = [("stem_chain_w16_kernel", "stem + block_chain_i8 x2 32x32 c24"), ("block_chain_ws_kernel<ConvCfg<24, 24", "stem + block_chain_i8 x2 32x32 c24"), ("block_chain_pp_kernel<ConvCfg<48", "block_chain_i8 x1 16x16 c48"),
+    rules = [("stem_chain_w16_kernel", "stem + block_chain_i8 x2 32x32 c24"), ("block_chain_ws_kernel<ConvCfg<24, 24", "stem + block_chain_i8 x2 32x32 c24"), ("block_chain_pp_kernel<ConvCfg<48", "block_chain_i8 x1 16x16 c48"), ("chain48_w16_kernel", "block_chain_i8 x1 16x16 c48"), ("down24_w16_kernel", "block_down_i8 32x32 24->48"),
              ("block_chain_ws_kernel<ConvCfg<48", "block_chain_i8 x1 16x16 c48"), ("block_chain_ald_kernel<ConvCfg<96", "block_chain_i8 x1 8x8 c96"),
              ("block_chain_ald_kernel<ConvCfg<192", "block_chain_i8 x1 4x4 c192"), ("block_down_ws_kernel<ConvCfg<24", "block_down_i8 32x32 24->48"),
              ("block_down_ws_kernel<ConvCfg<48", "block_down_i8 16x16 48->96"), ("block_down_ws_kernel<ConvCfg<96", "block_down_i8 8x8 96->192"),
