@@ -1350,10 +1350,10 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n
   }
   if (w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: unknown weight layout%s");
   if (Cc == 48 && H == 16) return launch_block_chain_ws_dev<Blk_48, 1>(dev, n_calls, items(Blk_48::G), st);
-  if (Cc == 96 && H == 8) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring_dev(dev, n_calls, items(ALD_96::G), 96, false, st) : launch_block_chain_ald_dev<ALD_96, 8>(dev, n_calls, items(ALD_96::G), st);
+  if (Cc == 96 && H == 8) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring_dev(dev, n_calls, B, max_samples, 96, false, st) : launch_block_chain_ald_dev<ALD_96, 8>(dev, n_calls, items(ALD_96::G), st);
   if (Cc == 192 && H == 4) {
     const bool small_items = ((B + 15) / 16) * n_calls * max_samples <= 128;
-    if (qbnn_use_chain_ring()) return qbnn_launch_block_chain_ring_dev(dev, n_calls, items(small_items ? 8 : 16), 192, small_items, st);
+    if (qbnn_use_chain_ring()) return qbnn_launch_block_chain_ring_dev(dev, n_calls, B, max_samples, 192, small_items, st);
     return small_items ? launch_block_chain_ald_dev<ALD_192_G8, 8>(dev, n_calls, items(8), st) : launch_block_chain_ald_dev<ALD_192, 8>(dev, n_calls, items(16), st);
   }
   return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: unsupported geometry%s C=%ld H=%ld", "", Cc, H);

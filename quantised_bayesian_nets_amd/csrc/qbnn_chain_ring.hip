@@ -21,13 +21,13 @@ QBNN_EXPORT void qbnn_debug_stamp_buffer_chain_ring(void* p) { hipMemcpyToSymbol
 
 namespace {
 
-template <class C_>
+template <class C_, int NBUF_ = 4>
 struct CRCfg {
   using C = C_;
   static constexpr int NT = C::NT, NB = 3, MB = C::MB, NBLKS = NT / NB, KS = C::KS, SPT = C::SPT, HO = C::HO, PIXB = C::PIXB;
   static constexpr int IMG_PX = HO * HO, M = C::G * IMG_PX;
   static constexpr int TILE = M * PIXB;                       // dense [image][oh][ow][C + 16], followed by the zero line (PIXB bytes)
-  static constexpr int NBUF = 4;
+  static constexpr int NBUF = NBUF_;
   static constexpr int NF = 24, SLK = NF / NT, DMA_PER_WAVE = NF / 8, SLABB = NF * 1024;
   static constexpr int NS = (KS + SLK - 1) / SLK, NSI = 2 * NS;
   static constexpr int LDS = TILE + PIXB + NBUF * SLABB + 2 * C::COUT * 4 + 2 * M * 4 + 64;      // (+ slack: a masked window-sum read may lie HO + 1 entries behind the tables)
@@ -121,10 +121,10 @@ __device__ __forceinline__ void ring_mfma_dense(const uint8_t* const (&tl)[D::MB
 // DROP (conv_resnet_mc, mcdropout/models_mc.py:116-160): a quantised channel dropout behind each conv -- dr.d[0] behind stem.0 (stem.3 of the
 // reference's Sequential), dr.d[1] behind stem.3 (the Add's first operand); one bit per (image, channel) in LDS (a Bernoulli mask has two quantised
 // values), applied by the epilogues to the centred integer they hold.
-template <class C, int PD, int NM, bool DROP = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <class C, int PD, int NM, bool DROP = false, int NBUF = 4>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 4 : 2, NBUF == 2 ? 4 : 2)))
 void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<DROP ? 2 : 0> dr) {
-  using D = CRCfg<C>;
+  using D = CRCfg<C, NBUF>;
   static_assert(!DROP || NM == 1, "dropout variants are single-call");
   constexpr int MTB = MaskTab<C::COUT, true>::bytes(C::G);
   const ChainArgs<1> a = args_of(all, blockIdx.y);
@@ -380,75 +380,108 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<
 #define QBNN_CHAIN_PD 2
 #endif
 
-template <class C>
+// A launch variant: the blocking (ConvCfg), the ring depth and the fragment request distance.
+//   V1: one workgroup per CU -- four slabs (three in flight), two pixel tiles x three channel tiles per wave where the item has them, 151 - 225 VGPRs;
+//   V2 (round 5): TWO workgroups per CU -- half the images per item, one pixel tile x three channel tiles per wave, a two-slab ring: 80 KiB of
+//       LDS and <= 128 VGPRs per workgroup.  The two workgroups of a CU run out of phase (one's epilogues under the other's K loop: MFMA cycles
+//       with a vector instruction beside them 4 / 2 % -> 21 / 13 %) and every SIMD holds four waves, where a vector instruction costs 2.0 - 3.4
+//       cycles instead of 2.9 - 4.8 (profiles/r05_issue_bench2.txt).  Each item streams its weights for half as many images, so the L2 -> LDS
+//       traffic doubles (3.8 B/clk per CU).  Measured (same box): chain 96 0.268 -> 0.251 ms, chain 192 0.236 -> 0.223 ms; QBNN_CHAIN_2WG=0 for the A/B.
+template <class C_, int NBUF_, int PD_> struct CRVar {
+  using C = C_;
+  static constexpr int NBUF = NBUF_, PD = PD_, WGS = NBUF_ == 2 ? 512 : 256;      // workgroups that fill the chip
+  using D = CRCfg<C_, NBUF_>;
+  static_assert(NBUF_ != 2 || D::LDS <= 80 * 1024, "two workgroups per CU");
+};
+
+template <class V>
 int launch_by_value(const ChainArgs<1>* arr, int n, hipStream_t st) {
-  using D = CRCfg<C>;
+  using C = typename V::C;
+  using D = typename V::D;
   static std::atomic<uint64_t> attr1{0}, attrN{0};
   int items = 0;
   for (int i = 0; i < n; ++i) { const int it = arr[i].n_samples * ((arr[i].B + C::G - 1) / C::G); items = it > items ? it : items; }
   if (n == 1) {
-    if (int rc = ensure_dyn_lds((const void*)block_chain_ring_kernel<C, QBNN_CHAIN_PD, 1>, attr1, D::LDS)) return rc;
+    if (int rc = ensure_dyn_lds((const void*)block_chain_ring_kernel<C, V::PD, 1, false, V::NBUF>, attr1, D::LDS)) return rc;
     ArgsArr<ChainArgs<1>, 1> one;
     one.m[0] = arr[0];
-    hipLaunchKernelGGL((block_chain_ring_kernel<C, QBNN_CHAIN_PD, 1>), dim3(items < 256 ? (items > 0 ? items : 1) : 256), dim3(512), D::LDS, st, one, DropSet<0>{});
+    hipLaunchKernelGGL((block_chain_ring_kernel<C, V::PD, 1, false, V::NBUF>), dim3(items < V::WGS ? (items > 0 ? items : 1) : V::WGS), dim3(512), D::LDS, st, one, DropSet<0>{});
     return check_launch("qbnn_block_chain_i8_mc");
   }
   static_assert(sizeof(ArgsArr<ChainArgs<1>, QBNN_FUSED_CALLS>) <= 3840, "kernel arguments are limited to 4 KiB (incl. the hidden ones)");
-  if (int rc = ensure_dyn_lds((const void*)block_chain_ring_kernel<C, QBNN_CHAIN_PD, QBNN_FUSED_CALLS>, attrN, D::LDS)) return rc;
+  if (int rc = ensure_dyn_lds((const void*)block_chain_ring_kernel<C, V::PD, QBNN_FUSED_CALLS, false, V::NBUF>, attrN, D::LDS)) return rc;
   ArgsArr<ChainArgs<1>, QBNN_FUSED_CALLS> all;
   memset(&all, 0, sizeof(all));
   for (int i = 0; i < n; ++i) all.m[i] = arr[i];
-  const int per = 256 / n > 0 ? 256 / n : 1;
-  hipLaunchKernelGGL((block_chain_ring_kernel<C, QBNN_CHAIN_PD, QBNN_FUSED_CALLS>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, all, DropSet<0>{});
+  const int per = V::WGS / n > 0 ? V::WGS / n : 1;
+  hipLaunchKernelGGL((block_chain_ring_kernel<C, V::PD, QBNN_FUSED_CALLS, false, V::NBUF>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, all, DropSet<0>{});
   return check_launch("qbnn_block_chain_i8_multi");
 }
 
-template <class C>
-int launch_dev(const ChainArgs<1>* dev, int n, int items, hipStream_t st) {
-  using D = CRCfg<C>;
+template <class V>
+int launch_dev(const ChainArgs<1>* dev, int n, int B, int max_samples, hipStream_t st) {
+  using C = typename V::C;
+  using D = typename V::D;
+  const int items = max_samples * ((B + C::G - 1) / C::G);
   static std::atomic<uint64_t> attr{0};
-  if (int rc = ensure_dyn_lds((const void*)block_chain_ring_kernel<C, QBNN_CHAIN_PD, 0>, attr, D::LDS)) return rc;
-  const int per = 256 / n > 0 ? 256 / n : 1;
-  hipLaunchKernelGGL((block_chain_ring_kernel<C, QBNN_CHAIN_PD, 0>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, ArgsArr<ChainArgs<1>, 0>{dev}, DropSet<0>{});
+  if (int rc = ensure_dyn_lds((const void*)block_chain_ring_kernel<C, V::PD, 0, false, V::NBUF>, attr, D::LDS)) return rc;
+  const int per = V::WGS / n > 0 ? V::WGS / n : 1;
+  hipLaunchKernelGGL((block_chain_ring_kernel<C, V::PD, 0, false, V::NBUF>), dim3(items < per ? (items > 0 ? items : 1) : per, n), dim3(512), D::LDS, st, ArgsArr<ChainArgs<1>, 0>{dev}, DropSet<0>{});
   return check_launch("qbnn_block_chain_i8_multi_launch");
 }
 
-template <class C>
+template <class V>
 int launch_drop(const ChainArgs<1>& a, const DropSet<2>& dr, hipStream_t st) {
-  using D = CRCfg<C>;
+  using C = typename V::C;
+  using D = typename V::D;
   constexpr int LDS = D::LDS + 2 * MaskTab<C::COUT, true>::bytes(C::G);
-  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static_assert(LDS <= (V::NBUF == 2 ? 80 : 160) * 1024, "LDS budget");
   static std::atomic<uint64_t> attr{0};
-  if (int rc = ensure_dyn_lds((const void*)block_chain_ring_kernel<C, QBNN_CHAIN_PD, 1, true>, attr, LDS)) return rc;
+  if (int rc = ensure_dyn_lds((const void*)block_chain_ring_kernel<C, V::PD, 1, true, V::NBUF>, attr, LDS)) return rc;
   const int items = a.n_samples * ((a.B + C::G - 1) / C::G);
   ArgsArr<ChainArgs<1>, 1> one;
   one.m[0] = a;
-  hipLaunchKernelGGL((block_chain_ring_kernel<C, QBNN_CHAIN_PD, 1, true>), dim3(items < 256 ? (items > 0 ? items : 1) : 256), dim3(512), LDS, st, one, dr);
+  hipLaunchKernelGGL((block_chain_ring_kernel<C, V::PD, 1, true, V::NBUF>), dim3(items < V::WGS ? (items > 0 ? items : 1) : V::WGS), dim3(512), LDS, st, one, dr);
   return check_launch("qbnn_block_chain_drop_i8_mc");
 }
 
 using CR_96  = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;        // 8 images per item: 16 pixel tiles x 3 channel tiles
 using CR_192 = ConvCfg<192, 192, 3, 1, 4, 1, 16, 2, 3, true, 36, 16>;     // 16 images per item: 8 x 6
-using CR_192_G8 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, true, 36, 16>;   // 8 images per item (ensemble members at B <= 256): 4 x 6
+using CR_192_G8 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, true, 36, 16>;   // 8 images per item: 4 x 6
+using CR_96_G4 = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, true, 36, 16>;      // 4 images per item: 8 x 3
+using V1_96 = CRVar<CR_96, 4, QBNN_CHAIN_PD>;
+using V1_192 = CRVar<CR_192, 4, QBNN_CHAIN_PD>;
+using V1_192_G8 = CRVar<CR_192_G8, 4, QBNN_CHAIN_PD>;       // (ensemble members at B <= 256 with QBNN_CHAIN_2WG=0)
+using V2_96 = CRVar<CR_96_G4, 2, 2>;                         // 128 VGPRs, no spill
+using V2_192 = CRVar<CR_192_G8, 2, 1>;                       // 121 VGPRs (request distance 2: two spills, the same time)
+using V2_96_DROP = CRVar<CR_96_G4, 2, 1>;                    // (the dropout form spills at distance 2)
+
+bool two_per_cu() {
+  static const bool on = [] { const char* e = getenv("QBNN_CHAIN_2WG"); return !(e && e[0] == '0'); }();
+  return on;
+}
 
 }  // namespace
 
-// `small_items`: the 192-channel block with 8 images per item (the caller's choice when 16-image items would leave CUs idle)
+// `small_items`: the 192-channel block with 8 images per item (the caller's choice when 16-image items would leave CUs idle; V1 only -- V2's items are that size)
 int qbnn_launch_block_chain_ring(const ChainArgs<1>* arr, int n, int Cc, bool small_items, hipStream_t st) {
   if (n <= 0 || n > QBNN_FUSED_CALLS) return fail(QBNN_E_INVALID, "qbnn_block_chain (ring): 1 .. 8 argument blocks per launch%s");
-  if (Cc == 96) return launch_by_value<CR_96>(arr, n, st);
-  if (Cc == 192) return small_items ? launch_by_value<CR_192_G8>(arr, n, st) : launch_by_value<CR_192>(arr, n, st);
+  const bool two = two_per_cu() && n == 1;       // side-by-side ensemble members: V1 (measured: 27.5 k against 27.2 k member forwards/s)
+  if (Cc == 96) return two ? launch_by_value<V2_96>(arr, n, st) : launch_by_value<V1_96>(arr, n, st);
+  if (Cc == 192) return two ? launch_by_value<V2_192>(arr, n, st) : small_items ? launch_by_value<V1_192_G8>(arr, n, st) : launch_by_value<V1_192>(arr, n, st);
   return fail(QBNN_E_INVALID, "qbnn_block_chain (ring): 96 and 192 channels only%s");
 }
 
-int qbnn_launch_block_chain_ring_dev(const ChainArgs<1>* dev, int n, int items, int Cc, bool small_items, hipStream_t st) {
-  if (Cc == 96) return launch_dev<CR_96>(dev, n, items, st);
-  if (Cc == 192) return small_items ? launch_dev<CR_192_G8>(dev, n, items, st) : launch_dev<CR_192>(dev, n, items, st);
+// (device-resident argument blocks: B and the largest sample count of the calls size the grid)
+int qbnn_launch_block_chain_ring_dev(const ChainArgs<1>* dev, int n, int B, int max_samples, int Cc, bool small_items, hipStream_t st) {
+  const bool two = two_per_cu() && n == 1;
+  if (Cc == 96) return two ? launch_dev<V2_96>(dev, n, B, max_samples, st) : launch_dev<V1_96>(dev, n, B, max_samples, st);
+  if (Cc == 192) return two ? launch_dev<V2_192>(dev, n, B, max_samples, st) : small_items ? launch_dev<V1_192_G8>(dev, n, B, max_samples, st) : launch_dev<V1_192>(dev, n, B, max_samples, st);
   return fail(QBNN_E_INVALID, "qbnn_block_chain (ring): 96 and 192 channels only%s");
 }
 
 int qbnn_launch_block_chain_ring_drop(const ChainArgs<1>& a, const DropSet<2>& dr, int Cc, hipStream_t st) {
-  if (Cc == 96) return launch_drop<CR_96>(a, dr, st);
-  if (Cc == 192) return launch_drop<CR_192>(a, dr, st);
+  if (Cc == 96) return two_per_cu() ? launch_drop<V2_96_DROP>(a, dr, st) : launch_drop<V1_96>(a, dr, st);
+  if (Cc == 192) return two_per_cu() ? launch_drop<V2_192>(a, dr, st) : launch_drop<V1_192>(a, dr, st);
   return fail(QBNN_E_INVALID, "qbnn_block_chain_drop (ring): 96 and 192 channels only%s");
 }

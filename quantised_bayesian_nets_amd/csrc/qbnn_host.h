@@ -73,7 +73,7 @@ static inline bool qbnn_use_down_ring() {
 // The wide identity blocks with the same K loop (qbnn_chain_ring.hip): 96 channels at 8 x 8, 192 at 4 x 4 (`small_items`: 8 instead of 16 images per
 // work item).  QBNN_CHAIN_RING=0 selects block_chain_ald_kernel (qbnn_blocks.hip).
 int qbnn_launch_block_chain_ring(const ChainArgs<1>* arr, int n, int Cc, bool small_items, hipStream_t st);
-int qbnn_launch_block_chain_ring_dev(const ChainArgs<1>* dev, int n, int items, int Cc, bool small_items, hipStream_t st);
+int qbnn_launch_block_chain_ring_dev(const ChainArgs<1>* dev, int n, int B, int max_samples, int Cc, bool small_items, hipStream_t st);
 int qbnn_launch_block_chain_ring_drop(const ChainArgs<1>& a, const DropSet<2>& dr, int Cc, hipStream_t st);      // ... with the block's two dropouts (conv_resnet_mc)
 static inline bool qbnn_use_chain_ring() {
   static const bool v = [] { const char* e = getenv("QBNN_CHAIN_RING"); return !(e && e[0] == '0'); }();
