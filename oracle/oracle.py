@@ -780,6 +780,131 @@ class QATOracle:
         return _softmax_f32(self.linear("layers.9", lid, h, seed, sample, False, False))
 
 
+# --------------------------------------------- QAT evaluation of the non-BBB graphs (quant_utils.py:139-140) ---
+class QATMCOracle(QATOracle):
+    """`linear_mc`, `conv_lenet_mc`, `conv_resnet_mc` and the SGHMC member templates (`*_sgld`: `main_net.` = the pointwise graphs of
+    models_sgld.py, no dropout) after quant_utils.prepare_model's `prepare_qat` branch (:139-140), in eval mode with live observers:
+    torch.ao.nn.qat Linear / Conv2d and intrinsic.qat LinearReLU / ConvBn2d / ConvBnReLU2d -- W = weight_fake_quant(weight * c), c = the
+    BatchNorm fold gamma / sqrt(var + eps) (conv-bn only), Z = conv(X, W), Z / c (+ bias), bn, (ReLU), activation FakeQuantize -- and
+    mcdropout/dropout.py:15-40 with the FloatFunctionals prepared: y = FQ_mul_mask(x * mask) * multiplier (mul_scalar is not observed).
+    Add = FQ(out + shortcut) (src/utils.py:49-55).  STATEFUL like QATOracle: samples in order s = 0, 1, ..."""
+
+    def __init__(self, state, a_bits=7, w_bits=8, prefix=""):
+        super().__init__(state, a_bits, w_bits)
+        self.pre = prefix
+
+    def det_weights(self, name, c=None):
+        w = np.asarray(self.st[name + ".weight"], np.float32)
+        if c is not None:
+            w = (w * c.reshape([-1] + [1] * (w.ndim - 1))).astype(np.float32)
+        return self.fq(name + ".weight_fake_quant", w, True)
+
+    def conv(self, name, x, stride, pad, bn, relu):
+        name = self.pre + name
+        c = None
+        if bn:
+            g, rv = np.asarray(self.st[name + ".bn.weight"], np.float32), np.asarray(self.st[name + ".bn.running_var"], np.float32)
+            c = (g / np.sqrt(rv + np.float32(1e-5))).astype(np.float32)
+        W = self.det_weights(name, c)
+        z = conv2d_f32(x, np.ascontiguousarray(W.transpose(0, 2, 3, 1)), None, stride, pad)
+        if bn:
+            z = _bn_eval((z / c).astype(np.float32), self.st, name + ".bn")
+        if relu:
+            z = np.maximum(z, 0)
+        return self.fq(name + ".activation_post_process", z, False)
+
+    def linear(self, name, x, relu):
+        name = self.pre + name
+        W = self.det_weights(name)
+        y = (x.astype(np.float64) @ W.astype(np.float64).T).astype(np.float32)
+        if (name + ".bias") in self.st:
+            y = (y + np.asarray(self.st[name + ".bias"], np.float32)).astype(np.float32)
+        if relu:
+            y = np.maximum(y, 0)
+        return self.fq(name + ".activation_post_process", y, False)
+
+    def drop(self, name, di, x, seed, sample):
+        name = self.pre + name
+        if (name + ".p") not in self.st:
+            return x
+        p = np.float32(np.asarray(self.st[name + ".p"]).reshape(-1)[0])
+        if p <= 0:
+            return x
+        mult = np.float32(np.asarray(self.st[name + ".multiplier"]).reshape(-1)[0])
+        B, C = x.shape[0], x.shape[-1]
+        m = (fill_uniform(B * C, seed, di, sample) < (np.float32(1.0) - p)).astype(np.float32).reshape((B,) + (1,) * (x.ndim - 2) + (C,))
+        y = self.fq(name + ".mul_mask.activation_post_process", (x * m).astype(np.float32), False)
+        return (y * mult).astype(np.float32)
+
+    def quant(self, h):
+        return self.fq(self.pre + "quant.activation_post_process", h, False)
+
+    def mlp_mc(self, x, seed, sample):
+        h = self.quant(np.asarray(x, np.float32))
+        h = self.drop("layers.2", 0, self.linear("layers.0", h, True), seed, sample)
+        h = self.drop("layers.5", 1, self.linear("layers.3", h, True), seed, sample)
+        h = self.linear("layers.6", h, True)
+        mu = self.linear("mu.1", self.drop("mu.0", 2, h, seed, sample), False)
+        lv = self.linear("log_var.1", self.drop("log_var.0", 3, h, seed, sample), False)
+        return mu, np.exp(lv)
+
+    def lenet_mc(self, x_nchw, seed, sample):
+        h = self.quant(np.ascontiguousarray(np.asarray(x_nchw, np.float32).transpose(0, 2, 3, 1)))
+        h = _pool_f32(self.drop("layers.1", 0, self.conv("layers.0", h, 1, 2, False, False), seed, sample), 2, False)
+        h = _pool_f32(self.drop("layers.4", 1, self.conv("layers.3", h, 1, 2, False, False), seed, sample), 2, False)
+        h = np.ascontiguousarray(h.transpose(0, 3, 1, 2)).reshape(h.shape[0], -1)
+        h = self.drop("layers.9", 2, self.linear("layers.7", h, True), seed, sample)
+        return _softmax_f32(self.linear("layers.10", h, False))
+
+    def resnet_mc(self, x_nchw, seed, sample):
+        """mcdropout/models_mc.py:116-226 prepared: layers.0 ConvBnReLU2d, layers.3 dropout, blocks layers.4 .. 7 (stem.0 ConvBnReLU2d, stem.3 dropout,
+        stem.4 ConvBn2d, stem.6 dropout, shortcut.0 ConvBn2d, shortcut.2 dropout, add), AvgPool, Flatten, layers.10 Linear."""
+        h = self.quant(np.ascontiguousarray(np.asarray(x_nchw, np.float32).transpose(0, 2, 3, 1)))
+        di = 0
+        h = self.drop("layers.3", di, self.conv("layers.0", h, 1, 1, True, True), seed, sample); di += 1
+        inp = 24
+        for li, planes, stride in ((4, 24, 1), (5, 48, 2), (6, 96, 2), (7, 192, 2)):
+            for bi, st in enumerate((stride, 1)):
+                p = f"layers.{li}.{bi}"
+                out = self.drop(p + ".stem.3", di, self.conv(p + ".stem.0", h, st, 1, True, True), seed, sample); di += 1
+                out = self.drop(p + ".stem.6", di, self.conv(p + ".stem.4", out, 1, 1, True, False), seed, sample); di += 1
+                sc = h
+                if st != 1 or inp != planes:
+                    sc = self.drop(p + ".shortcut.2", di, self.conv(p + ".shortcut.0", h, st, 0, True, False), seed, sample); di += 1
+                h = np.maximum(self.fq(self.pre + p + ".add.add.activation_post_process", (out + sc).astype(np.float32), False), 0)
+                inp = planes
+        h = _pool_f32(h, 4, True).reshape(h.shape[0], -1)
+        return _softmax_f32(self.linear("layers.10", h, False))
+
+    # the SGHMC member templates (models_sgld.py: the pointwise graphs; Network.forward applies the softmax, :285-287)
+    def mlp_p(self, x):
+        h = self.quant(np.asarray(x, np.float32))
+        for n in ("layers.0", "layers.2", "layers.4"):
+            h = self.linear(n, h, True)
+        return self.linear("mu", h, False), np.exp(self.linear("log_var", h, False))
+
+    def lenet_p(self, x_nchw):
+        h = self.quant(np.ascontiguousarray(np.asarray(x_nchw, np.float32).transpose(0, 2, 3, 1)))
+        h = _pool_f32(self.conv("layers.0", h, 1, 2, False, False), 2, False)
+        h = _pool_f32(self.conv("layers.2", h, 1, 2, False, False), 2, False)
+        h = np.ascontiguousarray(h.transpose(0, 3, 1, 2)).reshape(h.shape[0], -1)
+        return _softmax_f32(self.linear("layers.7", self.linear("layers.5", h, True), False))
+
+    def resnet_p(self, x_nchw):
+        h = self.quant(np.ascontiguousarray(np.asarray(x_nchw, np.float32).transpose(0, 2, 3, 1)))
+        h = self.conv("layers.0", h, 1, 1, True, True)
+        inp = 24
+        for li, planes, stride in ((3, 24, 1), (4, 48, 2), (5, 96, 2), (6, 192, 2)):
+            for bi, st in enumerate((stride, 1)):
+                p = f"layers.{li}.{bi}"
+                out = self.conv(p + ".stem.3", self.conv(p + ".stem.0", h, st, 1, True, True), 1, 1, True, False)
+                sc = self.conv(p + ".shortcut.0", h, st, 0, True, False) if (st != 1 or inp != planes) else h
+                h = np.maximum(self.fq(self.pre + p + ".add.add.activation_post_process", (out + sc).astype(np.float32), False), 0)
+                inp = planes
+        h = _pool_f32(h, 4, True).reshape(h.shape[0], -1)
+        return _softmax_f32(self.linear("layers.9", h, False))
+
+
 # --------------------------------------------- MC-Dropout ResNet, int8 (SURVEY row a7) ---
 class Int8ResNetMCOracle:
     """`conv_resnet_mc` after prepare_model -> convert: reference mcdropout/models_mc.py:116-211 (graph: a channel dropout

@@ -633,6 +633,10 @@ class ModelFactory:
             cls = {"conv_resnet_bbb": models_qat.ConvNetwork_ResNet, "conv_lenet_bbb": models_qat.ConvNetwork_LeNet,
                    "linear_bbb": models_qat.LinearNetwork}[model]
             return cls(input_size, output_size, q, args)
+        if q and getattr(args, "qat_eval", False) and model in ("linear_mc", "conv_lenet_mc", "conv_resnet_mc", "linear_sgld", "conv_lenet_sgld", "conv_resnet_sgld"):
+            # quant_utils.prepare_model's other branch (`prepare_qat`, :139-140): the MC-Dropout graphs and the SGHMC member template
+            from . import models_qat_mc
+            return models_qat_mc.get_model(model, input_size, output_size, q, args)
         if model == "conv_resnet_bbb":
             if not q:
                 from .models_f32 import ConvNetwork_ResNet as ConvNetwork_ResNetF32

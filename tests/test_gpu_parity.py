@@ -593,6 +593,49 @@ def test_qat_eval_with_live_observers_matches_reference(name, model):
     assert checked >= 20
 
 
+@pytest.mark.parametrize("name,model", [("mlp_mc_qat.npz", "linear_mc"), ("lenet_mc_qat.npz", "conv_lenet_mc"), ("resnet_mc_qat.npz", "conv_resnet_mc"),
+                                        ("resnet_sgld_qat.npz", "conv_resnet_sgld")])
+def test_qat_eval_of_the_non_bbb_graphs_matches_reference(name, model):
+    """SURVEY 8(f).3 widened to quant_utils.prepare_model's `prepare_qat` branch (:139-140): the prepared MC-Dropout graphs (FakeQuantize on the
+    dropout's mul_mask, mcdropout/dropout.py:9-40) and the SGHMC member template in eval mode on the GPU, all S samples in one batched pass,
+    against S sequential reference forwards with the same injected masks: per-sample outputs and every live observer's final (min, max).
+    Tolerance: 1e-5 relative + twice the reference's own distance from itself on another CPU code path (`refspread.max_abs`: 0 / 4.5e-8 for
+    the MLP / LeNet, i.e. the 2e-6 floor; 3.9e-4 / 5.2e-4 for the ResNets, where a few activations sit within fp32 summation noise of a
+    quantisation step -- the CPU oracle, which accumulates in fp64, is 2.4e-4 from the recorded run for the same reason)."""
+    import os
+    import quantised_bayesian_nets_amd as q
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    st = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    args = types.SimpleNamespace(p=float(d["meta.p"]), activation_precision=7, weight_precision=8, qat_eval=True, model=model)
+    shape = {"linear_mc": [13], "conv_lenet_mc": [1, 28, 28]}.get(model, [1, 3, 32, 32])
+    m = q.ModelFactory.get_model(model, shape, 1 if model == "linear_mc" else 10, True, args).load_reference_state(st)
+    assert type(m).__module__.endswith("models_qat_mc")
+    x = torch.from_numpy(d["x"]).cuda()
+    seed = int(d["meta.philox_seed"])
+    atol = max(2e-6, 2.0 * float(d["refspread.max_abs"]))
+    if model == "linear_mc":
+        S = d["mu"].shape[0]
+        with q.mc_context(S, seed, 0):
+            mu, var = m.forward_mc(x)
+        np.testing.assert_allclose(mu.cpu().numpy(), d["mu"], rtol=1e-5, atol=atol)
+        np.testing.assert_allclose(var.cpu().numpy(), d["var"], rtol=1e-5, atol=0)
+    else:
+        S = d["probs"].shape[0]
+        with q.mc_context(S, seed, 0):
+            p = m.forward_mc(x)
+        np.testing.assert_allclose(p.cpu().numpy(), d["probs"], rtol=1e-5, atol=atol)
+    otol = 1e-5 if atol < 1e-5 else 1e-2
+    st2 = m.prepared_state()
+    checked = 0
+    for k in d.files:
+        if k.startswith("final/") and k.endswith("min_val") and np.isfinite(float(d[k])):
+            key = k[len("final/"):]
+            np.testing.assert_allclose(float(st2[key]), float(d[k]), rtol=1e-4, atol=otol)
+            np.testing.assert_allclose(float(st2[key.replace("min_val", "max_val")]), float(d[k.replace("min_val", "max_val")]), rtol=1e-4, atol=otol)
+            checked += 1
+    assert checked >= 12
+
+
 def test_many_samples_fused_equals_layerwise(golden_w8):
     """BASELINE config 3 size in the sample dimension too (B = 256, S = 48: every persistent workgroup walks dozens of work
     items across several MC samples, reloading its LDS-resident weights on the way): the fully fused path (stem + chains +

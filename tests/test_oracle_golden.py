@@ -193,6 +193,35 @@ def test_qat_eval_with_live_observers_matches_reference(name, kind):
         np.testing.assert_allclose(ob.state[1], d["final/" + k + ".activation_post_process.max_val"], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("name,kind", [("mlp_mc_qat.npz", "mlp_mc"), ("lenet_mc_qat.npz", "lenet_mc"), ("resnet_mc_qat.npz", "resnet_mc"),
+                                       ("resnet_sgld_qat.npz", "resnet_p")])
+def test_qat_eval_of_the_non_bbb_graphs_matches_reference(name, kind):
+    """SURVEY 8(f).3 widened to quant_utils.prepare_model's `prepare_qat` branch (:139-140): the MC-Dropout graphs (FakeQuantize on the dropout's
+    mul_mask, mcdropout/dropout.py:9-40) and the SGHMC member template, eval mode, live observers -- the oracle sample after sample against S
+    reference forwards with the same injected masks.  Tolerance: 1e-5 relative + twice the reference's own distance from itself on another
+    CPU code path (`refspread.max_abs`: 0 / 4.5e-8 for the MLP / LeNet; 3.9e-4 / 5.2e-4 for the ResNets, where a handful of activations sit within
+    fp32 summation noise of a quantisation step and round the other way)."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    st = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    net = orc.QATMCOracle(st, prefix="main_net." if kind == "resnet_p" else "")
+    seed = int(d["meta.philox_seed"])
+    atol = max(2e-6, 2.0 * float(d["refspread.max_abs"]))
+    if kind == "mlp_mc":
+        for s in range(d["mu"].shape[0]):
+            mu, var = net.mlp_mc(d["x"], seed, s)
+            np.testing.assert_allclose(mu, d["mu"][s], rtol=1e-5, atol=atol)
+            np.testing.assert_allclose(var, d["var"][s], rtol=1e-5, atol=1e-8)
+    else:
+        for s in range(d["probs"].shape[0]):
+            got = net.resnet_p(d["x"]) if kind == "resnet_p" else getattr(net, kind)(d["x"], seed, s)
+            np.testing.assert_allclose(got, d["probs"][s], rtol=1e-5, atol=atol)
+    assert len(net.obs) >= 12
+    otol = 1e-5 if atol < 1e-5 else 1e-2          # an observer behind a flipped rounding sees another min / max (one quantisation step of ITS input)
+    for k, ob in net.obs.items():
+        np.testing.assert_allclose(ob.state[0], d["final/" + k + ".activation_post_process.min_val"], rtol=1e-4, atol=otol)
+        np.testing.assert_allclose(ob.state[1], d["final/" + k + ".activation_post_process.max_val"], rtol=1e-4, atol=otol)
+
+
 def test_resnet_mc_dropout_matches_reference():
     """SURVEY row a7 on the ResNet graph (mcdropout/models_mc.py:116-211): oracle vs the reference, bit-exact block outputs
     for sample 0, 1e-5 on every sample's softmax output."""
