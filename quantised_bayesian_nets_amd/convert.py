@@ -145,6 +145,8 @@ def convert_model_state(prepared, args, bn_eps=1e-5):
     out = {}
     tag = ".weight_fake_quant" + _OBS + "min_val"
     layers = [k[:-len(tag)] for k in prepared if k.endswith(tag)]
+    if layers and not any((p + ".std") in prepared for p in layers):
+        return _convert_deterministic_state(prepared, layers, wb, ab, bn_eps)
     for p in layers:
         bn = None
         if (p + ".bn.running_mean") in prepared:
@@ -170,6 +172,58 @@ def convert_model_state(prepared, args, bn_eps=1e-5):
     return out
 
 
+def convert_deterministic_layer(w, bias, w_obs, act_obs, bn=None):
+    """One torch.ao.nn.qat layer (Linear / LinearReLU / Conv2d / ConvBn2d / ConvBnReLU2d: deterministic weights) -> the converted int8 layer's
+    state, as torch's own `from_float` does it (torch.ao.nn.quantized.modules.conv._ConvNd.from_float / linear.Linear.from_float, reached through
+    the reference's quant_utils.convert :62-99): fold the BatchNorm (fuse_conv_bn_weights), ONE more step of the weight observer on the folded
+    weight, per-tensor-affine qint8 with the integers clamped to the observer's [quant_min, quant_max] (a no-op at 8 bits), output
+    (scale, zero point) from the activation observer."""
+    w = torch.as_tensor(w, dtype=torch.float32)
+    bias = None if bias is None else torch.as_tensor(bias, dtype=torch.float32)
+    if bn is not None:
+        rm, rv = torch.as_tensor(bn["running_mean"]), torch.as_tensor(bn["running_var"])
+        if bias is None:
+            bias = torch.zeros_like(rm)
+        rs = torch.rsqrt(rv + float(bn["eps"]))
+        w = w * (torch.as_tensor(bn["weight"]) * rs).reshape([-1] + [1] * (w.dim() - 1))
+        bias = (bias - rm) * rs * torch.as_tensor(bn["weight"]) + torch.as_tensor(bn["bias"])
+    s_w, z_w = w_obs.observe(w).qparams()
+    s_y, z_y = act_obs.qparams()
+    out = {"weight": np.clip(quantize_qint8(w, s_w, z_w), w_obs.quant_min, w_obs.quant_max).astype(np.int8), "weight.q_scale": np.float64(s_w),
+           "weight.q_zero_point": np.int64(z_w), "scale": np.float32(s_y), "zero_point": np.int64(z_y)}
+    if bias is not None:
+        out["bias"] = bias.detach().numpy()
+    return out
+
+
+def _convert_deterministic_state(prepared, layers, wb, ab, bn_eps):
+    """convert_model_state for the models quant_utils.prepare_model prepared with `prepare_qat` (:139-140): the MC-Dropout graphs and the SGHMC
+    member templates.  Besides the weighted layers: QuantStub -> Quantize, Add's FloatFunctional -> QFunctional, and each BernoulliDropout's two
+    FloatFunctionals (mcdropout/dropout.py:9-13) -> QFunctional -- `mul_mask` with its observer's qparams, `mul_scalar` (never observed:
+    FloatFunctional.mul_scalar has no observer call) with the (1.0, 0) torch gives an observer that saw nothing; `p` / `multiplier` pass through."""
+    out = {}
+    for p in layers:
+        bn = None
+        if (p + ".bn.running_mean") in prepared:
+            bn = dict(running_mean=prepared[p + ".bn.running_mean"], running_var=prepared[p + ".bn.running_var"], eps=bn_eps,
+                      weight=prepared[p + ".bn.weight"], bias=prepared[p + ".bn.bias"])
+        st = convert_deterministic_layer(prepared[p + ".weight"], prepared.get(p + ".bias"), _obs(prepared, p + ".weight_fake_quant" + _OBS, wb),
+                                         _obs(prepared, p + _OBS + "activation_post_process.", ab), bn)
+        out.update({p + "." + k: v for k, v in st.items()})
+    for k in prepared:
+        if k.endswith(_OBS + "activation_post_process.min_val") and not any(k.startswith(p + ".") for p in layers):
+            base = k[:-len(_OBS + "activation_post_process.min_val")]
+            seen = np.isfinite(float(np.asarray(prepared[k])))
+            s, z = _obs(prepared, base + _OBS + "activation_post_process.", ab).qparams() if seen else (1.0, 0)
+            if base.endswith("quant") and not base.endswith("fake_quant"):
+                out[base + ".scale"], out[base + ".zero_point"] = np.asarray([s], np.float32), np.asarray([z], np.int64)
+            else:
+                out[base + ".scale"], out[base + ".zero_point"] = np.float32(s), np.int64(z)
+        elif k.endswith(".p") or k.endswith(".multiplier"):
+            out[k] = np.asarray(prepared[k], np.float32).reshape(1)
+    return out
+
+
 def convert_model(prepared, model_name, input_size, output_size, args):
     """prepared state (or a models_qat model holding one) -> the converted int8 model of this package, ready for the HIP path:
     `ModelFactory.get_model(model_name, ..., q=True, args)` loaded with `convert_model_state(prepared, args)`."""
@@ -178,8 +232,12 @@ def convert_model(prepared, model_name, input_size, output_size, args):
     if hasattr(prepared, "prepared_state"):
         prepared = prepared.prepared_state()
     a = types.SimpleNamespace(**{k: v for k, v in vars(args).items() if k != "qat_eval"})
-    model = ModelFactory.get_model(model_name, input_size, output_size, True, a, training_mode=False) if "sgld" in model_name else \
-        ModelFactory.get_model(model_name, input_size, output_size, True, a)
+    if "sgld" in model_name:
+        # the SGHMC template (`main_net.`) converts to ONE ensemble member (models_sgld.py:245-261 loads such states member by member)
+        member = {k[len("main_net."):] if k.startswith("main_net.") else k: v for k, v in convert_model_state(prepared, a).items()}
+        a.samples = 1
+        return ModelFactory.get_model(model_name, input_size, output_size, True, a, training_mode=False).load_reference_state([member])
+    model = ModelFactory.get_model(model_name, input_size, output_size, True, a)
     return model.load_reference_state(convert_model_state(prepared, a))
 
 
@@ -209,6 +267,11 @@ def prepare_model_state(float_state):
         out[prefix + ".activation_post_process.max_val"] = -inf
 
     layers = [k[:-len(".std")] for k in float_state if k.endswith(".std")]
+    bbb = bool(layers)
+    if not bbb:
+        # the `prepare_qat` branch (quant_utils.py:139-140): every nn.Linear / nn.Conv2d (a weight of 2 or 4 dimensions) becomes a
+        # torch.ao.nn.qat layer with a weight and an output FakeQuantize; a BernoulliDropout (`<d>.p`) gets one per FloatFunctional
+        layers = [k[:-len(".weight")] for k, v in float_state.items() if k.endswith(".weight") and np.asarray(v).ndim in (2, 4)]
     bn_of = {}
     for p in layers:
         head, _, idx = p.rpartition(".")
@@ -226,10 +289,15 @@ def prepare_model_state(float_state):
         if not moved:
             out[k] = np.asarray(v)
     for p in layers:
-        for fq in ("weight_fake_quant", "std_fake_quant", "activation_post_process", "add_weight.activation_post_process",
-                   "mul_noise.activation_post_process"):
+        for fq in (("weight_fake_quant", "std_fake_quant", "activation_post_process", "add_weight.activation_post_process",
+                    "mul_noise.activation_post_process") if bbb else ("weight_fake_quant", "activation_post_process")):
             observer(p + "." + fq)
-    observer("quant.activation_post_process")
+    for k in float_state:
+        if not bbb and k.endswith(".multiplier") and (k[:-len("multiplier")] + "p") in float_state:
+            observer(k[:-len(".multiplier")] + ".mul_mask.activation_post_process")
+            observer(k[:-len(".multiplier")] + ".mul_scalar.activation_post_process")
+    root = "main_net." if any(k.startswith("main_net.") for k in float_state) else ""
+    observer(root + "quant.activation_post_process")
     for p in layers:                                        # one Add per BasicBlock: the blocks are the parents of `<blk>.stem.0`
         if p.endswith(".stem.0"):
             observer(p[:-len(".stem.0")] + ".add.add.activation_post_process")

@@ -7,6 +7,8 @@ FloatFunctionals that receive FakeQuantize observers, dropout.py:9-13) and the S
 state_dict, then runs S eval-mode forwards of the same batch with the build's Philox Bernoulli masks injected into Tensor.bernoulli_ and records
 the per-sample outputs and the observers' final (min, max).  As in make_golden_qat.py the whole pipeline also runs on another CPU code path
 (altref.py) and the distance of the reference from itself is recorded (`refspread.*`).
+Each fixture also holds `converted/*`: the flat int8 state the reference's own quant_utils.convert (:62-99) makes of the snapshot (the check of
+convert.convert_model_state's non-BBB branch).
 Output: tests/golden/{mlp,lenet,resnet}_mc_qat.npz, resnet_sgld_qat.npz (inputs + expected outputs only)."""
 import os
 import sys
@@ -33,6 +35,34 @@ ALT = altref.alt_out_path() is not None
 def flat(model):
     return {k: v.detach().numpy().copy() for k, v in model.state_dict().items()
             if v.dtype.is_floating_point and not k.endswith(".scale") and "fake_quant_enabled" not in k and "observer_enabled" not in k}
+
+
+def converted_state(model):
+    """The reference's quant_utils.convert (:62-99) on a copy of the prepared model: the flat int8 state (what make_golden_resnet_mc.py /
+    make_golden_linear_mc.py record: qint8 tensors as int_repr + q_scale + q_zero_point; quantized Linear keeps its tensors in _packed_params)."""
+    import copy
+    import src.quant_utils as qu
+    cm = copy.deepcopy(model).cpu().eval()
+    qu.convert(cm)
+    out = {}
+    for k, v in cm.state_dict().items():
+        if v is None or not torch.is_tensor(v) or "_packed_params" in k:
+            continue
+        if v.is_quantized:
+            out[k] = v.int_repr().numpy()
+            out[k + ".q_scale"] = np.float64(v.q_scale())
+            out[k + ".q_zero_point"] = np.int64(v.q_zero_point())
+        else:
+            out[k] = v.detach().numpy()
+    for n, m in cm.named_modules():
+        if isinstance(m, torch.ao.nn.quantized.Linear):
+            w = m.weight()
+            out[n + ".weight"] = w.int_repr().numpy()
+            out[n + ".weight.q_scale"] = np.float64(w.q_scale())
+            out[n + ".weight.q_zero_point"] = np.int64(w.q_zero_point())
+            if m.bias() is not None:
+                out[n + ".bias"] = m.bias().detach().numpy().copy()
+    return out
 
 
 def run(model_name, in_shape, B, S, out, logit_gain):
@@ -71,6 +101,7 @@ def run(model_name, in_shape, B, S, out, logit_gain):
     with torch.no_grad():
         model(x)
     state = flat(model)
+    conv = converted_state(model) if not ALT else {}          # what the reference's convert() makes of exactly this prepared state
     snap = {k: v.clone() for k, v in model.state_dict().items()}
     shapes = []
     orig = torch.Tensor.bernoulli_
@@ -142,6 +173,7 @@ def run(model_name, in_shape, B, S, out, logit_gain):
         res["mean_probs"] = torch.stack([torch.from_numpy(p) for p in outs], dim=1).mean(dim=1).numpy()
     res.update({"state/" + k: v for k, v in state.items()})
     res.update({"final/" + k: v for k, v in final.items() if k.endswith("min_val") or k.endswith("max_val")})
+    res.update({"converted/" + k: v for k, v in conv.items()})
     path = os.path.join(HERE, out)
     np.savez_compressed(path, **res)
     print("wrote", path, round(os.path.getsize(path) / 1e6, 2), "MB")

@@ -211,3 +211,47 @@ def test_prepare_model_state_builds_the_reference_prepared_keys():
     aq = types.SimpleNamespace(sigma_prior=-2.0, activation_precision=7, weight_precision=8, qat_eval=True)
     m = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, aq).load_reference_state(prep)
     assert m.layers[0].weight_fake_quant.min_max() == (float("inf"), float("-inf"))
+
+
+_NON_BBB = [("mlp_mc_qat.npz", "linear_mc"), ("lenet_mc_qat.npz", "conv_lenet_mc"), ("resnet_mc_qat.npz", "conv_resnet_mc"), ("resnet_sgld_qat.npz", "conv_resnet_sgld")]
+
+
+@pytest.mark.parametrize("name,model", _NON_BBB)
+def test_model_level_convert_of_the_non_bbb_graphs_matches_reference(name, model):
+    """SURVEY 8f row 4 widened to quant_utils.prepare_model's `prepare_qat` branch (:139-140): `convert_model_state` on the prepared MC-Dropout graphs
+    and the SGHMC member template gives exactly what the reference's own quant_utils.convert (:62-99, through torch's from_float) makes of the same
+    prepared state -- every key, every int8 tensor bit for bit, every scale (fixtures: tests/golden/make_golden_qat_mc.py, `converted/*`)."""
+    import types
+    from quantised_bayesian_nets_amd.convert import convert_model_state
+    d = np.load(os.path.join(GOLDEN_DIR, name))
+    st = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    want = {k[len("converted/"):]: d[k] for k in d.files if k.startswith("converted/")}
+    got = convert_model_state(st, types.SimpleNamespace(activation_precision=7, weight_precision=8))
+    assert sorted(got) == sorted(want)
+    n_int8 = 0
+    for k, w in want.items():
+        g = np.asarray(got[k])
+        if w.dtype == np.int8:
+            assert g.dtype == np.int8 and np.array_equal(w, g), k
+            n_int8 += 1
+        else:
+            np.testing.assert_allclose(g.astype(np.float64).reshape(-1), np.asarray(w, np.float64).reshape(-1), rtol=1e-7, atol=0, err_msg=k)
+    assert n_int8 >= 4
+
+
+@pytest.mark.parametrize("fname,qname", [("mlp_mc_f32.npz", "mlp_mc_qat.npz"), ("lenet_mc_f32.npz", "lenet_mc_qat.npz"), ("resnet_mc_f32.npz", "resnet_mc_qat.npz")])
+def test_prepare_model_state_of_the_mc_dropout_graphs_builds_the_reference_prepared_keys(fname, qname):
+    """The prepare side of the same branch: the float MC-Dropout state -> the key set of the reference's prepared model (conv + BatchNorm fused:
+    `<conv>.bn.*`; a weight and an output FakeQuantize per layer; two per BernoulliDropout; QuantStub; one per Add), every observer fresh.
+    The reference's keys are those of the prepared states recorded in the *_mc_qat.npz fixtures (floating-point entries, as flat() keeps them)."""
+    from quantised_bayesian_nets_amd.convert import prepare_model_state
+    d = np.load(os.path.join(GOLDEN_DIR, fname))
+    fstate = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    ref = np.load(os.path.join(GOLDEN_DIR, qname))
+    ref_keys = sorted(k[len("state/"):] for k in ref.files if k.startswith("state/"))
+    prep = prepare_model_state(fstate)
+    mine = sorted(k for k, v in prep.items() if np.asarray(v).dtype.kind == "f" and not k.endswith(".scale"))
+    assert mine == ref_keys
+    for k in mine:
+        if k.endswith("min_val"):
+            assert np.isposinf(prep[k]) and np.isneginf(prep[k.replace("min_val", "max_val")])

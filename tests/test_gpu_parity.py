@@ -636,6 +636,77 @@ def test_qat_eval_of_the_non_bbb_graphs_matches_reference(name, model):
     assert checked >= 12
 
 
+def test_native_prepare_calibrate_convert_pipeline_of_the_mc_dropout_resnet():
+    """SURVEY 8f row 4 widened to quant_utils.prepare_model's `prepare_qat` branch (:139-140), end to end without the reference: the float
+    conv_resnet_mc state -> `prepare_model_state` -> calibration by live-observer evaluation forwards on the GPU (models_qat_mc; forward i draws
+    the masks of sample index i) -> `convert_model_state` -> the int8 model on the HIP path; against what the REFERENCE produced from the same
+    float model with prepare_model -> 3 eval forwards (same injected masks, plain ATen convs) -> convert (tests/golden/make_golden_prepare_mc.py).
+    Observers: weight side 1e-5 relative; activation side within 1e-3 of the observer's range (measured: 1.4e-4 -- this fixture's BatchNorm
+    statistics let the activations grow to ~270 by the last stage, and a few of them round the other way under the upstream fake-quantisers,
+    as the reference itself does on another conv backend: resnet_mc_qat.npz `refspread`).  Converted state: zero points within one step, scales
+    1e-3, 19 of the 20 qint8 conv tensors bit-identical and the recorded ones equal up to one element on a rounding tie; the converted model's
+    int8 probabilities on the HIP path equal the reference's int8 model's."""
+    import hashlib
+    import os
+    import quantised_bayesian_nets_amd as q
+    from conftest import GOLDEN
+    from quantised_bayesian_nets_amd.convert import prepare_model_state, calibrate, convert_model_state, convert_model
+    d = np.load(os.path.join(GOLDEN, "resnet_mc_f32.npz"))
+    fstate = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    ref = np.load(os.path.join(GOLDEN, "resnet_mc_prepare_calibrate.npz"))
+    S, seed, p = int(ref["meta.samples"]), int(ref["meta.philox_seed"]), float(ref["meta.p"])
+    fstate["layers.10.weight"] = (np.asarray(fstate["layers.10.weight"]) * np.float32(ref["meta.logit_gain"])).astype(np.float32)
+    aq = types.SimpleNamespace(p=p, activation_precision=7, weight_precision=8, qat_eval=True)
+    m = q.ModelFactory.get_model("conv_resnet_mc", [1, 3, 32, 32], 10, True, aq).load_reference_state(prepare_model_state(fstate))
+    x = torch.from_numpy(d["x"]).cuda()
+    calibrate(m, [x] * S, seed)
+    st = m.prepared_state()
+    n_w = n_a = 0
+    worst = 0.0
+    for k in ref.files:
+        if not k.startswith("calibrated/") or not k.endswith("min_val") or not np.isfinite(float(ref[k])):
+            continue
+        kk = k[len("calibrated/"):]
+        lo, hi = float(ref[k]), float(ref[k.replace("min_val", "max_val")])
+        glo, ghi = float(st[kk]), float(st[kk.replace("min_val", "max_val")])
+        if "weight_fake_quant" in kk:
+            assert abs(glo - lo) <= 1e-5 * max(1e-3, abs(lo)) + 1e-9 and abs(ghi - hi) <= 1e-5 * max(1e-3, abs(hi)) + 1e-9, (kk, glo, lo, ghi, hi)
+            n_w += 1
+        else:
+            rng = max(hi, 0.0) - min(lo, 0.0)
+            dev = max(abs(glo - lo), abs(ghi - hi)) / rng
+            worst = max(worst, dev)
+            assert dev <= 1e-3, (kk, glo, lo, ghi, hi)
+            n_a += 1
+    print("worst activation-observer deviation (fraction of its range):", worst)
+    assert n_w == 21 and n_a == 21 + 20 + 8 + 1            # 21 layers; their outputs + 20 dropouts' mul_mask + 8 Adds + the stub
+    conv = convert_model_state(st, types.SimpleNamespace(activation_precision=7, weight_precision=8))
+    n_int8 = n_same = 0
+    for k in ref.files:
+        if not k.startswith("converted/"):
+            continue
+        key = k[len("converted/"):]
+        if key.endswith(".sha1"):
+            base = key[:-len(".sha1")]
+            n_int8 += 1
+            n_same += int(hashlib.sha1(np.ascontiguousarray(conv[base]).tobytes()).hexdigest() == str(ref[k]))
+        elif key.endswith("scale"):
+            np.testing.assert_allclose(float(np.asarray(conv[key]).reshape(-1)[0]), float(np.asarray(ref[k]).reshape(-1)[0]), rtol=1e-3, err_msg=key)
+        elif key.endswith("zero_point"):
+            assert abs(int(np.asarray(conv[key]).reshape(-1)[0]) - int(np.asarray(ref[k]).reshape(-1)[0])) <= 1, key
+    print("int8 tensors equal:", n_same, "of", n_int8)
+    assert n_int8 == 20 and n_same >= 19, (n_same, n_int8)
+    for key in ("layers.0.weight", "layers.5.0.shortcut.0.weight", "layers.7.1.stem.4.weight", "layers.10.weight"):
+        dd = np.asarray(conv[key]).astype(np.int32) - ref["converted/" + key].astype(np.int32)
+        assert int((dd != 0).sum()) <= 1 and int(np.abs(dd).max()) <= 1, key
+    # ... and the converted model runs on the HIP path: the int8 MC-Dropout ResNet with the masks of sample indices S, S + 1
+    a8 = types.SimpleNamespace(p=p, activation_precision=7, weight_precision=8)
+    mi = convert_model(m, "conv_resnet_mc", [1, 3, 32, 32], 10, a8)
+    with q.mc_context(ref["int8_probs"].shape[0], seed, S):
+        pi = mi.forward_mc(x)
+    np.testing.assert_allclose(pi.cpu().numpy(), ref["int8_probs"], rtol=1e-5, atol=1e-7)
+
+
 def test_many_samples_fused_equals_layerwise(golden_w8):
     """BASELINE config 3 size in the sample dimension too (B = 256, S = 48: every persistent workgroup walks dozens of work
     items across several MC samples, reloading its LDS-resident weights on the way): the fully fused path (stem + chains +
