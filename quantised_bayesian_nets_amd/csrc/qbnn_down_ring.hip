@@ -427,6 +427,340 @@ void block_down_ring_kernel(const ArgsArr<DownArgs, NM> all, const DropSet<DROP 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// 16-wave form with ROLES (round 5; single-call launches without dropout; QBNN_DOWN_R16=0 for the A/B).  The 8-wave kernel above holds two accumulator
+// sets per wave (stem.0 + shortcut: 157 / 181 VGPRs, two waves per SIMD), and two thirds of its work item are vector instructions issued at the
+// two-wave rate (2.9 - 4.8 cycles each; four waves: 2.0 - 3.4, profiles/r05_issue_bench2.txt).  Here a workgroup has 16 waves of ONE accumulator set
+// (<= 128 VGPRs, four per SIMD):
+//   waves 0 - 7  ("A"): stem.0 for pass w (pixel tile x the pass's three channel tiles), its epilogue -> T; stem.3 for channel tiles 0, 1 of the pass
+//   waves 8 - 15 ("S"): the shortcut for pass w - 8, its epilogue -> SC;                                     stem.3 for channel tile 2 of the pass
+// so both first epilogues (48 outputs per lane each) run on all 16 waves, and stem.3's (48 per lane and pass) splits 32 : 16.  The weight ring is the
+// 8-wave kernel's: waves 0 - 7 issue the DMA and keep its vmcnt accounting; every wave passes every ring barrier (a wave without MFMAs in a conv just
+// walks that conv's advances), so the ring state stays in step.  Same tiles, tables, epilogue functors and bits.
+template <class D, int KS, int NBW, int PD, class StepFn, class IssueFn, class InitFn>
+__device__ __forceinline__ void ring_mfma_role(StepFn step, WeightRing& rg, ConvAccMN<1, 3>& A, int nt0, bool issuer, int lane, IssueFn issue, InitFn init) {
+  constexpr int SLK = D::SLK;
+  struct Frag { v4i w[NBW]; v4i x; };
+  Frag f[PD + 1];
+  const uint8_t* wl = nullptr;
+  auto advance = [&]() {
+    if (issuer) wait_vmcnt<(D::NBUF - 2) * D::DMA_PER_WAVE>();
+    lds_barrier();
+    if (issuer) issue(rg.pnext, rg.pbuf);
+    ++rg.pnext;
+    rg.pbuf = rg.pbuf + 1 == D::NBUF ? 0 : rg.pbuf + 1;
+    wl = rg.base + rg.cbuf * D::SLABB + (nt0 * SLK * 64 + lane) * 16;
+    rg.cbuf = rg.cbuf + 1 == D::NBUF ? 0 : rg.cbuf + 1;
+  };
+  auto load = [&](Frag& fr, int ks) {
+    const int j = ks % SLK;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) fr.w[nb] = *reinterpret_cast<const v4i*>(wl + (nb * SLK + j) * 1024);
+    fr.x = *reinterpret_cast<const v4i*>(step(ks));
+  };
+  auto mfma = [&](const Frag& fr) {
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) A.acc[0][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr.w[nb], fr.x, A.acc[0][nb], 0, 0, 0);
+  };
+#pragma unroll
+  for (int p = 0; p < PD && p < KS; ++p) {
+    if (p % SLK == 0) advance();
+    if (p == 0) {
+      const int a0 = init();
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) A.acc[0][nb][i] = a0;
+    }
+    load(f[p % (PD + 1)], p);
+  }
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    const int p = j + PD;
+    if (p < KS) {
+      if (p % SLK == 0) advance();
+      load(f[p % (PD + 1)], p);
+    }
+    mfma(f[j % (PD + 1)]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// a conv this wave has no MFMAs in: its ring advances only (the barriers, and the DMA requests if the wave is an issuer)
+template <class D, int KS, class IssueFn>
+__device__ __forceinline__ void ring_follow(WeightRing& rg, bool issuer, IssueFn issue) {
+#pragma unroll
+  for (int p = 0; p < KS; p += D::SLK) {
+    if (issuer) wait_vmcnt<(D::NBUF - 2) * D::DMA_PER_WAVE>();
+    lds_barrier();
+    if (issuer) issue(rg.pnext, rg.pbuf);
+    ++rg.pnext;
+    rg.pbuf = rg.pbuf + 1 == D::NBUF ? 0 : rg.pbuf + 1;
+    rg.cbuf = rg.cbuf + 1 == D::NBUF ? 0 : rg.cbuf + 1;
+  }
+}
+// conv_epi_phase_with's PRESUB form over NBW of the pass's three channel tiles, starting at tile n0 (accumulator slots 0 .. NBW - 1)
+template <class C, int NBW, class Epi>
+__device__ __forceinline__ void epi_presub_sub(const float* bias_lds, const QConv& p, Epi& epi, ConvAccMN<1, 3>& A, int pass, int lane, int n0) {
+  const int r = lane & 31, h = lane >> 5;
+  const int mblk = pass / C::NBLKS, nblk = pass - mblk * C::NBLKS;
+  const int po = epi.pixel(mblk * 32 + r);
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int cb = (nblk * C::NB + n0 + nb) * 32 + 4 * h;
+    float4 b4[4];
+    uint32_t pre[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias_lds + cb + 8 * g4);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) pre[g4] = epi.load(po, cb + 8 * g4);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 bb = b4[g4];
+      const float v0 = __builtin_fmaf(bb.x, p.rcp, (float)A.acc[0][nb][4 * g4 + 0]) * p.mult;
+      const float v1 = __builtin_fmaf(bb.y, p.rcp, (float)A.acc[0][nb][4 * g4 + 1]) * p.mult;
+      const float v2 = __builtin_fmaf(bb.z, p.rcp, (float)A.acc[0][nb][4 * g4 + 2]) * p.mult;
+      const float v3 = __builtin_fmaf(bb.w, p.rcp, (float)A.acc[0][nb][4 * g4 + 3]) * p.mult;
+      epi.store(po, cb + 8 * g4, v0, v1, v2, v3, pre[g4]);
+    }
+  }
+}
+
+#ifndef QBNN_DOWN_R16_PD
+#define QBNN_DOWN_R16_PD 2
+#endif
+
+template <class D, class EC>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void block_down_ring16_kernel(const ArgsArr<DownArgs, 1> all) {
+  const DownArgs a = args_of(all, 0);
+  constexpr int NTHR = 1024, PD = QBNN_DOWN_R16_PD;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* xt = smem;
+  uint8_t* tt = smem;
+  uint8_t* zline = tt + D::M * D::PIXB_T;
+  uint8_t* sc = smem + D::SC_OFF;
+  uint8_t* rbase = smem + D::X_BYTES;
+  float* bias_lds = reinterpret_cast<float*>(rbase + D::NBUF * D::SLABB);
+  int16_t* sx16 = reinterpret_cast<int16_t*>(bias_lds + 3 * D::COUT);
+  int* stt = reinterpret_cast<int*>(smem + D::ST_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool role_a = wave < 8;                  // also: the waves that feed the weight ring
+  const int pass = wave & 7;
+  const int mblk = pass / D::NBLKS, nblk = pass - mblk * D::NBLKS;
+
+  constexpr int CPP = D::CIN / 16;
+  // input traffic: TPP adjacent lanes share a pixel and move CPT consecutive 16-byte chunks of it each (the pixel's channel sum: thread-local v_dot4
+  // chain + one DPP exchange between the pair, ONE 16-bit store into S_X)
+  constexpr int TPP = NTHR > D::NPX ? NTHR / D::NPX : 1, PPT = NTHR > D::NPX ? 1 : D::NPX / NTHR, CPT = CPP / TPP, PER_T = PPT * CPT, PXS = NTHR / TPP;
+  static_assert(CPP % TPP == 0 && (TPP == 1 || TPP == 2) && PPT * PXS == D::NPX, "every thread moves the same share of whole pixels");
+  constexpr int IMG_IN = D::HIN * D::HIN * D::CIN, IMG_OUT = D::HO * D::HO * D::COUT, U8 = D::COUT / 8;
+  constexpr int NOUT = (D::M * U8 + NTHR - 1) / NTHR;
+  const int groups = (a.B + D::G - 1) / D::G;
+  const ItemWalk walk(a.n_samples * groups, blockIdx.x, gridDim.x);
+  const int count = walk.count;
+
+  load_bias<D::COUT, NTHR>(bias_lds, a.s.bias, tid);
+  load_bias<D::COUT, NTHR>(bias_lds + D::COUT, a.a.bias, tid);
+  load_bias<D::COUT, NTHR>(bias_lds + 2 * D::COUT, a.b.bias, tid);
+  if (count <= 0) return;
+
+  v4i pre[PER_T];
+  auto fetch = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * D::G;
+    const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_IN;
+    const int valid = (a.B - img0 < D::G ? a.B - img0 : D::G) * D::HIN * D::HIN;
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const int px0 = t / TPP, part = t - px0 * TPP;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int px = px0 + j * PXS;
+      const uint8_t* p = xs + (px < valid ? (int64_t)px * D::CIN : 0) + part * (CPT * 16);
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) pre[j * CPT + c] = *reinterpret_cast<const v4i*>(p + 16 * c);
+    }
+  };
+  auto write_tile = [&](int item) {
+    const int s = item / groups, img0 = (item - s * groups) * D::G;
+    const int valid = (a.B - img0 < D::G ? a.B - img0 : D::G) * D::HIN * D::HIN;
+    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const int px0 = t / TPP, part = t - px0 * TPP;
+    {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        const int px = px0 + j * PXS;
+        const int g = px / (D::HIN * D::HIN), rem = px - g * (D::HIN * D::HIN), row = rem / D::HIN, col = rem - row * D::HIN;
+        uint8_t* dst = xt + g * D::XIMG + (row + 1) * D::XROW + (col + 1) * D::CIN + part * (CPT * 16);
+        int sum = 0;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+          const v4i v = pre[j * CPT + c];
+          const v4i q = px < valid ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v4i{0, 0, 0, 0};
+          *reinterpret_cast<v4i*>(dst + 16 * c) = q;
+          sum = __builtin_amdgcn_sdot4(q.x, 0x01010101, sum, false);
+          sum = __builtin_amdgcn_sdot4(q.y, 0x01010101, sum, false);
+          sum = __builtin_amdgcn_sdot4(q.z, 0x01010101, sum, false);
+          sum = __builtin_amdgcn_sdot4(q.w, 0x01010101, sum, false);
+        }
+        if constexpr (TPP == 2) sum += __builtin_amdgcn_update_dpp(0, sum, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]: the pixel's other half
+        if (part == 0) sx16[px] = (int16_t)sum;
+      }
+    }
+    constexpr int TOP = D::XTW * D::CIN / 16, CW = D::CIN / 16;
+    for (int i = t; i < D::G * D::NHALO; i += NTHR) {
+      const int g = i / D::NHALO, q = i - g * D::NHALO;
+      const int off = q < TOP ? q * 16 : (1 + (q - TOP) / CW) * D::XROW + ((q - TOP) % CW) * 16;
+      *reinterpret_cast<v4i*>(xt + g * D::XIMG + off) = v4i{0, 0, 0, 0};
+    }
+  };
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto issue = [&](int q, int buf) {          // (called by waves 0 - 7 only: `wave` is the issuing wave's index among the eight)
+    int itx = q / D::NSI;
+    const int loc = q - itx * D::NSI;
+    itx = itx < count ? itx : count - 1;
+    const int s = walk.item(itx) / groups;
+    const int8_t* wq; int KS, slab;
+    if (loc < D::NS_A) { wq = a.a.w + (int64_t)s * a.a.w_ss; KS = D::KS_A; slab = loc; }
+    else if (loc < D::NS_A + D::NS_S) { wq = a.s.w + (int64_t)s * a.s.w_ss; KS = D::KS_S; slab = loc - D::NS_A; }
+    else { wq = a.b.w + (int64_t)s * a.b.w_ss; KS = D::KS_B; slab = loc - D::NS_A - D::NS_S; }
+    const uint32_t dst = lds_addr_of(rbase + buf * D::SLABB);
+#pragma unroll
+    for (int k = 0; k < D::DMA_PER_WAVE; ++k) {
+      const int f = wave + 8 * k;
+      const int nt = f / D::SLK, u = f - nt * D::SLK;
+      int ks = slab * D::SLK + u;
+      ks = ks < KS ? ks : KS - 1;
+      dma16_s(wq + (int64_t)(nt * KS + ks) * 1024, lane16, dst + f * 1024);
+    }
+  };
+
+  fetch(walk.item(0));
+  write_tile(walk.item(0));
+  WeightRing rg{rbase, 0, D::NBUF - 1, D::NBUF - 1};
+  if (role_a) {
+#pragma unroll
+    for (int q = 0; q < D::NBUF - 1; ++q) issue(q, q);
+  }
+  ConvAccMN<1, 3> A;
+  for (int it = 0; it < count; ++it) {
+    const int item = walk.item(it);
+    const int s = item / groups, img0 = (item - s * groups) * D::G;
+    const bool more = it + 1 < count;
+    const int next = more ? walk.item(it + 1) : item;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int r = ln & 31, h = ln >> 5;
+    const int m = mblk * 32 + r;
+    const int g = m / (D::HO * D::HO), rem = m - g * (D::HO * D::HO), oh = rem / D::HO, ow = rem - oh * D::HO;
+    const uint8_t* xlane = xt + g * D::XIMG + (2 * oh) * D::XROW + (2 * ow) * D::CIN + 16 * h;
+    const int* sb = reinterpret_cast<const int*>(sx16) + (((g * D::HIN + 2 * oh) * D::HIN + 2 * ow) >> 1);
+    // ---- stem.0 (A waves) | shortcut (S waves): both over X
+    if (role_a) {
+      ring_mfma_role<D, D::KS_A, 3, PD>(
+          [&](int ks) {
+            const int kh = ks / D::SPR_A, t = ks - kh * D::SPR_A;
+            return xlane + kh * D::XROW + t * 32;
+          },
+          rg, A, nblk * 3, true, lane, issue,
+          [&] {
+            int ra = 0;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              const int u = sb[(kh - 1) * (D::HIN / 2) - 1], v = sb[(kh - 1) * (D::HIN / 2)];
+              const int row = (ow > 0 ? u >> 16 : 0) + (int)(int16_t)v + (v >> 16);
+              ra += (kh > 0 || oh > 0) ? row : 0;
+            }
+            return -a.a.z_w * ra;
+          });
+      ring_follow<D, D::KS_S>(rg, true, issue);
+    } else {
+      ring_follow<D, D::KS_A>(rg, false, issue);
+      ring_mfma_role<D, D::KS_S, 3, PD>(
+          [&](int ks) { return xlane + D::XROW + D::CIN + ks * 32; },
+          rg, A, nblk * 3, false, lane, issue, [&] { return -a.s.z_w * (int)(int16_t)sb[0]; });
+    }
+    lds_barrier();                       // every wave has read X for the last time: T and SC may overwrite it
+    if (role_a) {
+      EpiDenseTile<D::PIXB_T> epi{tt, a.a, 0};
+      epi_presub<EC>(bias_lds + D::COUT, a.a, epi, A, pass, lane);
+      const int v = half_sum(epi.csum);
+      if (lane < 32) stt[nblk * D::M + mblk * 32 + lane] = v;
+    } else {
+      EpiDense<D::COUT, false, D::SCP> epi{sc, a.s, a.add};
+      epi_presub<EC>(bias_lds, a.s, epi, A, pass, lane);
+    }
+    for (int i = tid; i < D::PIXB_T / 4; i += NTHR) reinterpret_cast<uint32_t*>(zline)[i] = 0u;
+    // ---- stem.3: M over T; A waves channel tiles 0, 1 of the pass, S waves tile 2
+    {
+      int vmask = 0;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        if ((unsigned)(oh + kh - 1) < (unsigned)D::HO && (unsigned)(ow + kw - 1) < (unsigned)D::HO) vmask |= 1 << tap;
+      }
+      const uint8_t* tlane = tt + m * D::PIXB_T + 16 * h;
+      const uint8_t* zl = zline + 16 * h;
+      auto step_b = [&](int ks) {
+        const int tap = ks / D::SPT_B, sub = ks - tap * D::SPT_B, kh = tap / 3, kw = tap - 3 * kh;
+        return ((vmask >> tap) & 1 ? tlane + ((kh - 1) * D::HO + (kw - 1)) * D::PIXB_T : zl) + sub * 32;
+      };
+      auto init_b = [&] {
+        int rb = 0;
+        const int* sp = stt + m;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          int sv = sp[(tap / 3 - 1) * D::HO + (tap % 3 - 1)];
+          if constexpr (D::NBLKS == 2) sv += sp[D::M + (tap / 3 - 1) * D::HO + (tap % 3 - 1)];
+          rb += (vmask >> tap) & 1 ? sv : 0;
+        }
+        return -a.b.z_w * rb;
+      };
+      if (role_a) ring_mfma_role<D, D::KS_B, 2, PD>(step_b, rg, A, nblk * 3, true, lane, issue, init_b);
+      else ring_mfma_role<D, D::KS_B, 1, PD>(step_b, rg, A, nblk * 3 + 2, false, lane, issue, init_b);
+    }
+    fetch(next);
+    {
+      EpiDense<D::COUT, true, D::SCP> epi{sc, a.b, a.add};
+      if (role_a) epi_presub_sub<EC, 2>(bias_lds + 2 * D::COUT, a.b, epi, A, pass, lane, 0);
+      else epi_presub_sub<EC, 1>(bias_lds + 2 * D::COUT, a.b, epi, A, pass, lane, 2);
+    }
+    lds_barrier();
+    {
+      uint8_t* ys = a.y + (int64_t)s * a.y_ss + (int64_t)img0 * IMG_OUT;
+      int t = tid;
+      asm volatile("" : "+v"(t));
+      v2i outv[NOUT];
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const int i = t + j * NTHR;
+        const int px = i / U8, within = i - px * U8;
+        if (i < D::M * U8) outv[j] = *reinterpret_cast<const v2i*>(sc + px * D::SCP + within * 8);
+      }
+      lds_barrier();
+      write_tile(next);
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const int i = t + j * NTHR;
+        if (i < D::M * U8 && img0 + (i * 8) / IMG_OUT < a.B) *reinterpret_cast<v2i*>(ys + (int64_t)i * 8) = outv[j];
+      }
+    }
+  }
+  wait_vmcnt<0>();
+}
+
+template <class D, class EC>
+int launch_r16(const DownArgs& a, hipStream_t st) {
+  static std::atomic<uint64_t> attr{0};
+  if (int rc = ensure_dyn_lds((const void*)block_down_ring16_kernel<D, EC>, attr, D::LDS)) return rc;
+  const int items = a.n_samples * ((a.B + D::G - 1) / D::G);
+  ArgsArr<DownArgs, 1> one;
+  one.m[0] = a;
+  hipLaunchKernelGGL((block_down_ring16_kernel<D, EC>), dim3(items < 256 ? (items > 0 ? items : 1) : 256), dim3(1024), D::LDS, st, one);
+  return check_launch("qbnn_block_down_i8_mc");
+}
+
 template <class D, class EC>
 int launch_by_value(const DownArgs* arr, int n, hipStream_t st) {
   static std::atomic<uint64_t> attr1{0}, attrN{0};
@@ -481,6 +815,9 @@ int qbnn_launch_block_down_ring_drop(const DownArgs& a, const DropSet<3>& dr, in
 
 int qbnn_launch_block_down_ring(const DownArgs* arr, int n, int Cin, hipStream_t st) {
   if (n <= 0 || n > QBNN_FUSED_CALLS) return fail(QBNN_E_INVALID, "qbnn_block_down (ring): 1 .. 8 argument blocks per launch%s");
+  static const int r16 = [] { const char* e = getenv("QBNN_DOWN_R16"); return e ? atoi(e) : 3; }();      // bit 0: 48 -> 96, bit 1: 96 -> 192 (measured on one box: 0.324 -> 0.305 and 0.255 -> 0.245 ms)
+  if (n == 1 && Cin == 48 && (r16 & 1)) return launch_r16<DR48, E48>(arr[0], st);
+  if (n == 1 && Cin == 96 && (r16 & 2)) return launch_r16<DR96, E96>(arr[0], st);
   if (Cin == 48) return launch_by_value<DR48, E48>(arr, n, st);
   if (Cin == 96) return launch_by_value<DR96, E96>(arr, n, st);
   return fail(QBNN_E_INVALID, "qbnn_block_down (ring): 48 -> 96 and 96 -> 192 channels only%s");
