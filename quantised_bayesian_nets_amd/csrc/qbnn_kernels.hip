@@ -277,7 +277,9 @@ struct SamplerLayer {
 struct SamplerTable { SamplerLayer l[QBNN_MAX_SAMPLER_LAYERS]; int n; };
 static_assert(sizeof(SamplerTable) <= 3968, "the sampler table travels as a kernel argument (4 KiB incl. the other arguments)");
 
-#define QBNN_SAMPLER_NS 4           // MC samples per thread: the chunk's mu / sigma are loaded, unpacked and dequantised once for all of them
+#ifndef QBNN_SAMPLER_NS
+#define QBNN_SAMPLER_NS 4
+#endif                              // MC samples per thread: the chunk's mu / sigma are loaded, unpacked and dequantised once for all of them
 // UNALIGNED: the kernel of the layers whose chunks are not aligned to Philox blocks (K or the kernel-row length no multiple of 4) and are
 // large enough to matter (LeNet's 2450-wide Linear); a kernel of its own, because compiled into the same kernel that path costs the
 // aligned one 8 % (register allocation).  Small unaligned layers (layers.0: K = 27) stay on the element-wise path of the main kernel.
