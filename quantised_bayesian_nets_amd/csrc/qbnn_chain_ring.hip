@@ -296,12 +296,13 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<
       else return EpiDenseTileResGlobal<C::PIXB, C::COUT>{xt, resp, valid_px, bp.b, bp.add};
     };
     auto epi_b = make_epi_b();
-    v4i rraw[2][3];
+    constexpr int RES_LOADS = 3;       // vector-memory instructions of one load_res(): the ring's waits of stem.3 count exactly these (EXTRA below)
+    v4i rraw[2][RES_LOADS];
     auto load_res = [&](int mb) {
       const int m = (mblk * C::MB + mb) * 32 + r;
       const uint8_t* p = resp + (int64_t)(m < valid_px ? m : 0) * C::COUT + nblk * 96 + h * 48;      // (pixels beyond a ragged batch: results never leave the tile)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) rraw[mb & 1][j] = *reinterpret_cast<const v4i*>(p + 16 * j);
+      for (int j = 0; j < RES_LOADS; ++j) rraw[mb & 1][j] = *reinterpret_cast<const v4i*>(p + 16 * j);
     };
     uint32_t resq[3][4];             // [nb][g4]: the dword (4 channels at 8 g4 + 4 h) of this lane's pixel, M-tile being requantised
     auto trade_res = [&](int mb) {
@@ -315,7 +316,7 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<
       }
     };
     load_res(0);
-    ring_mfma_dense<D, PD, 3>(tl, vm, zl, stab, bp.b.z_w, mblk, rg, A, nblk, lane, issue, [&] { if (C::MB > 1) load_res(1); });
+    ring_mfma_dense<D, PD, RES_LOADS>(tl, vm, zl, stab, bp.b.z_w, mblk, rg, A, nblk, lane, issue, [&] { if (C::MB > 1) load_res(1); });
     QBNN_STAMP_AT(3);
     lds_barrier();
     QBNN_STAMP_AT(4);

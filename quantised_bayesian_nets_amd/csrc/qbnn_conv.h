@@ -617,8 +617,16 @@ template <int COUT, bool BITS> struct MaskTab {
   }
 };
 // the table of MC sample s, images img0 .. img0 + G - 1 (every thread of the workgroup calls it; a barrier publishes it)
+// (a pointer out of a by-value descriptor is generic to the compiler: read through it as it stands it becomes a FLAT load, which returns out of
+//  order with the ring kernels' counted global loads -- tests/test_host_logic.py disassembles them for exactly this)
+template <class T> __device__ __forceinline__ const T* mask_global(const T* p) {
+  return (const T*)reinterpret_cast<const __attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p));
+}
 template <int G, int COUT, bool BITS, int NTHR>
-__device__ __forceinline__ void fill_mask_tab(void* tab, const PostArgs& q, int s, int img0, int B, int tid) {
+__device__ __forceinline__ void fill_mask_tab(void* tab, const PostArgs& q_, int s, int img0, int B, int tid) {
+  PostArgs q = q_;
+  q.nd = mask_global(q.nd);
+  q.mask_in = mask_global(q.mask_in);
   uint32_t seed_lo = q.seed_lo, seed_hi = q.seed_hi, sample_begin = q.sample_begin;
   if (q.nd) { seed_lo = q.nd[0]; seed_hi = q.nd[1]; sample_begin = q.nd[2]; }
   if constexpr (!BITS) {

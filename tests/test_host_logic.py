@@ -304,3 +304,28 @@ def test_tail_packed_layout_gathers_the_kernel_rows_ragged_ends():
     assert np.array_equal(dense[cout], valid.astype(np.int8)) and not dense[cout + 1:].any() and not dense[:cout][:, ~valid].any()
     assert L.qbnn_packed_weight_bytes(48, 432, 144, 3) == 0              # 16-byte tails x 3 rows do not fit one k-step
     assert L.qbnn_packed_weight_bytes(96, 864, 288, 3) == 0              # no ragged end at all
+
+
+def test_ring_kernels_issue_no_flat_loads(tmp_path):
+    """The LDS-DMA weight rings (csrc/qbnn_chain_ring.hip, qbnn_down_ring.hip) keep their own `s_waitcnt vmcnt` accounting: a wave waits for ITS
+    share of a slab by counting the vector-memory instructions it issued after it (advisor, round 4).  That holds for global_load / global_load_lds,
+    which return in order -- a FLAT load (what a pointer the compiler cannot prove global turns into) returns out of order and would let the MFMAs
+    read a half-landed slab.  Disassemble both units for gfx950 and check: no flat_load in any ring kernel, and the ring's DMA is there."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    n_kernels = 0
+    for unit in ("qbnn_chain_ring.hip", "qbnn_down_ring.hip"):
+        out = tmp_path / (unit + ".s")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-Wno-unused-value", "-I" + os.path.join(root, "include"),
+                               "--cuda-device-only", "-S", "-o", str(out), os.path.join(root, "quantised_bayesian_nets_amd", "csrc", unit)],
+                              stderr=subprocess.DEVNULL)
+        parts = re.split(r"\n(_ZN?\w+):", out.read_text())
+        for name, body in zip(parts[1::2], parts[2::2]):
+            if "ring" not in name or "_kernel" not in name:
+                continue
+            n_kernels += 1
+            assert not re.search(r"^\s+flat_load", body, re.M), name
+            assert "global_load_lds_dwordx4" in body, name
+    assert n_kernels >= 12
