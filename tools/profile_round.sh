@@ -25,7 +25,7 @@ def bench_key(k):
              ("block_chain_ald_kernel<ConvCfg<192", "block_chain_i8 x1 4x4 c192"), ("block_down_ws_kernel<ConvCfg<24", "block_down_i8 32x32 24->48"),
              ("block_down_ws_kernel<ConvCfg<48", "block_down_i8 16x16 48->96"), ("block_down_ws_kernel<ConvCfg<96", "block_down_i8 8x8 96->192"),
              ("block_chain_ring_kernel<ConvCfg<96", "block_chain_i8 x1 8x8 c96"), ("block_chain_ring_kernel<ConvCfg<192", "block_chain_i8 x1 4x4 c192"),
-             ("block_down_ring_kernel<(anonymous namespace)::DRCfg<48", "block_down_i8 16x16 48->96"), ("block_down_ring_kernel<(anonymous namespace)::DRCfg<96", "block_down_i8 8x8 96->192"),
+             ("block_down_ring_kernel<(anonymous namespace)::DRCfg<48", "block_down_i8 16x16 48->96"), ("block_down_ring16_kernel<(anonymous namespace)::DRCfg<48", "block_down_i8 16x16 48->96"), ("block_down_ring16_kernel<(anonymous namespace)::DRCfg<96", "block_down_i8 8x8 96->192"), ("block_down_ring_kernel<(anonymous namespace)::DRCfg<96", "block_down_i8 8x8 96->192"),
              ("sample_weights_multi_kernel", "sample_weights_i8_multi"), ("head_i8_kernel", "head_i8"), ("reduce_moments_kernel", "reduce_moments"),
              ("im2col3x3_c3_kernel", "im2col3x3_c3"), ("quantize_input_kernel", "quantize_input"), ("conv_i8_kernel", "conv_i8 32x32 3->24 k3 s1")]
     for pat, key in rules:
