@@ -266,13 +266,19 @@ __global__ __launch_bounds__(C48_THREADS) void chain48_w16_kernel(const ArgsArr<
 //              barrier | stem.3 (30 MFMAs for the row pair), the next item's X tile written behind its MFMAs (X is not read in this phase),
 //              epilogue: + shortcut registers, ReLU -> HBM.
 // ================================================================================================================================
+#ifndef QBNN_D24_B128
+#define QBNN_D24_B128 1
+#endif
+#ifndef QBNN_X24_PAD
+#define QBNN_X24_PAD (QBNN_D24_B128 ? 160 : 0)      // image stride: the two images' ds_read_b128 lane groups on disjoint banks (tools/lds_conflicts.py: 8 -> 4 cycles)
+#endif
 struct X24 {                                   // 32 x 32 x 24 map with a one-pixel zero halo (the layer-1 kernel's tile)
-  static constexpr int H = 32, CH = 24, TW = 34, PIXB = 24, PITCH = TW * PIXB, TILE_BYTES = TW * TW * PIXB;
+  static constexpr int H = 32, CH = 24, TW = 34, PIXB = 24, PITCH = TW * PIXB, TILE_BYTES = TW * TW * PIXB, STRIDE = TILE_BYTES + QBNN_X24_PAD;      // (image to image)
 };
 constexpr int D24_KSA = 7, D24_WA_HALF = D24_KSA * 1024, D24_WS_HALF = 1024;
 struct WA24 { static constexpr int NT = 2, KS = D24_KSA; };
 struct WS24 { static constexpr int NT = 2, KS = 1; };
-constexpr int D24_XT = C48_G * X24::TILE_BYTES + 2 * X24::PITCH + 64;      // + slack: the tail fragment of the last row pair reads one row past the tile
+constexpr int D24_XT = C48_G * X24::STRIDE + 2 * X24::PITCH + 64;      // + slack: the tail fragment of the last row pair reads one row past the tile
 constexpr int D24_IMG_IN = X24::H * X24::H * X24::CH;
 constexpr int d24_lds() { return D24_XT + C48_TILES + 2 * D24_WA_HALF + 2 * D24_WS_HALF + C48_WCONV + 3 * T48::CH * 4; }
 #define QBNN_MAGIC_BITS48 0x4B400000
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(C48_THREADS) void down24_w16_kernel(const ArgsArr<D
   item_range(a.n_samples * groups, blockIdx.x, gridDim.x, begin, count);
   if (count <= 0) return;
 
-  zero_halo<X24::TW, X24::PIXB, X24::TILE_BYTES, C48_G, C48_THREADS>(xt, tid);
+  zero_halo<X24::TW, X24::PIXB, X24::STRIDE, C48_G, C48_THREADS>(xt, tid);
   zero_halo<T48::TW, T48::PIXB, T48::TILE_BYTES, C48_G, C48_THREADS>(tt, tid);
   load_bias<T48::CH, C48_THREADS>(bias_lds, a.s.bias, tid);
   load_bias<T48::CH, C48_THREADS>(bias_lds + T48::CH, a.a.bias, tid);
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(C48_THREADS) void down24_w16_kernel(const ArgsArr<D
       const int i = t_ + j * C48_THREADS;
       const int g = i / CPI, rem = i - g * CPI, row = rem / RCH, within = rem - row * RCH;
       const v4i v = pre[j];
-      uint8_t* d = xt + g * X24::TILE_BYTES + (row + 1) * X24::PITCH + X24::PIXB + within * 16;      // (24-byte pixels: 8-byte aligned)
+      uint8_t* d = xt + g * X24::STRIDE + (row + 1) * X24::PITCH + X24::PIXB + within * 16;      // (24-byte pixels: 8-byte aligned)
       *reinterpret_cast<v2i*>(d) = v2i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4)};
       *reinterpret_cast<v2i*>(d + 8) = v2i{(int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)};
     }
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(C48_THREADS) void down24_w16_kernel(const ArgsArr<D
       asm volatile("" : "+v"(m));            // the start block is built here, per phase (kept in scratch across the item loop otherwise: qbnn_w16.hip)
       const v16i mg = v16i{m, m, m, m, m, m, m, m, m, m, m, m, m, m, m, m};
       // output pixel (oh, col) reads input rows 2 oh - 1 .. 2 oh + 1 = tile rows 2 oh .. 2 oh + 2, columns 2 col - 1 .. = tile columns 2 col ..
-      const uint8_t* px0 = xt + img * X24::TILE_BYTES + (2 * col) * X24::PIXB;
+      const uint8_t* px0 = xt + img * X24::STRIDE + (2 * col) * X24::PIXB;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int oh = 2 * rp + i;
@@ -406,8 +412,15 @@ __global__ __launch_bounds__(C48_THREADS) void down24_w16_kernel(const ArgsArr<D
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
+#if QBNN_D24_B128
+            // the window starts at an even tile column: 48 col + 16 h + 32 t bytes into a 16-byte-aligned row -- ONE ds_read_b128 (4 - 8 LDS cycles per
+            // wave) where two 8-byte halves compile to ds_read2_b64 (16; tools/lds_pattern_bench.hip, profiles/r05_lds_patterns.txt)
+            const v4i xf = *reinterpret_cast<const v4i*>(base + kh * X24::PITCH + t * 32);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(war[kh * 2 + t], xf, acc, 0, 0, 0);
+#else
             const v2i lo = *reinterpret_cast<const v2i*>(base + kh * X24::PITCH + t * 32), hi = *reinterpret_cast<const v2i*>(base + kh * X24::PITCH + t * 32 + 8);
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(war[kh * 2 + t], v4i{lo.x, lo.y, hi.x, hi.y}, acc, 0, 0, 0);
+#endif
           }
         {
           const v2i lo = *reinterpret_cast<const v2i*>(tbase), hi = *reinterpret_cast<const v2i*>(tbase + X24::PITCH);
