@@ -39,7 +39,13 @@ extern "C" {
 #define QBNN_LAYOUT_MFMA32 0    /* [NT][KS][64 lanes][16 B] fragments */
 #define QBNN_LAYOUT_ROWMAJOR 1  /* [Cout][K]                          */
 #define QBNN_LAYOUT_MFMA32_N24 2 /* fragments with 24 output channels (+ a ones row) per tile: the fused 48-channel kernels of round 5 */
-#define QBNN_LAYOUT_MFMA32_N24_TAIL 4 /* both of the next two: stem.0 (24 -> 48, 3x3) of the first down-sampling block on the 16-wave kernel */
+#define QBNN_LAYOUT_MFMA32_N24_TAIL 4
+
+/* qbnn_block_desc.flags.  POOL_OUT: the block's output leaves as AvgPool2d(H) of it -- y is [S][B][C] quint8 with the block output's (scale, zero
+ * point): q = clamp(rne((sum - H*H z) / (H*H)) + z), the head's first step (models_bbb.py:209, :240: nn.AvgPool2d(4) behind the last BasicBlock), so
+ * the 4 x 4 x 192 map never goes to HBM and qbnn_head_i8_mc runs on the pooled tensor with k = 1.  Served by the 4 x 4 x 192 identity block of
+ * qbnn_block_chain_i8_mc (one block per launch, LDS-ring kernel); any other geometry answers QBNN_E_INVALID. */
+#define QBNN_BLOCK_POOL_OUT 1 /* both of the next two: stem.0 (24 -> 48, 3x3) of the first down-sampling block on the 16-wave kernel */
 #define QBNN_LAYOUT_MFMA32_TAIL 3 /* MFMA32 with the ragged ends of the kernel rows gathered into one k-step (72-byte rows: 7 k-steps instead of
                                    * 9): the 24-channel convs behind the fused stem (qbnn_stem_chain_i8_mc / _drop_ / the multi forms)        */
 
@@ -167,7 +173,7 @@ typedef struct qbnn_block_desc {
                                     *   QBNN_LAYOUT_MFMA32_TAIL -- the two 24-channel blocks behind the fused stem (w_a, w_b in that layout);
                                     *   QBNN_LAYOUT_MFMA32_N24  -- the 16x16x48 identity block (w_a, w_b), and the 24 -> 48 down block:
                                     *                              w_b and w_s as MFMA32_N24, w_a (3x3 on 24 channels) as MFMA32_N24_TAIL */
-  int32_t reserved_;
+  int32_t flags;                 /* QBNN_BLOCK_* bits; 0 for the plain block */
 } qbnn_block_desc;
 
 int qbnn_block_chain_i8_mc(const uint8_t* x, int64_t x_sample_stride, float s_x, int32_t z_x, int32_t B, int32_t H,

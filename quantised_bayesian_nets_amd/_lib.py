@@ -56,7 +56,7 @@ class BlockDesc(C.Structure):
                 ("s_wa", C.c_float), ("z_wa", C.c_int32), ("s_a", C.c_float), ("z_a", C.c_int32),
                 ("w_b", C.c_void_p), ("w_b_sample_stride", C.c_int64), ("bias_b", C.c_void_p),
                 ("s_wb", C.c_float), ("z_wb", C.c_int32), ("s_b", C.c_float), ("z_b", C.c_int32),
-                ("s_o", C.c_float), ("z_o", C.c_int32), ("w_layout", C.c_int32), ("reserved_", C.c_int32)]
+                ("s_o", C.c_float), ("z_o", C.c_int32), ("w_layout", C.c_int32), ("flags", C.c_int32)]
 
 
 class MlpLayer(C.Structure):

@@ -1178,7 +1178,9 @@ static int build_chain_args(ChainArgs<NBLK>& a, const uint8_t* x, int64_t x_ss, 
     d.s_r = s_in; d.z_r = z_in; d.s_o = b.s_o; d.z_o = b.z_o;
     if ((rc = fill_qadd(a.blk[k].add, &d))) return rc;
     s_in = b.s_o; z_in = b.z_o;
+    if ((b.flags & QBNN_BLOCK_POOL_OUT) && k != NBLK - 1) return fail(QBNN_E_INVALID, "qbnn_block_chain: QBNN_BLOCK_POOL_OUT belongs to the chain's last block%s");
   }
+  a.pool = (blk[NBLK - 1].flags & QBNN_BLOCK_POOL_OUT) ? 1 : 0;
   return QBNN_OK;
 }
 
@@ -1197,6 +1199,8 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
                                 hipStream_t st, const int8_t* stem_x = nullptr, const QConv* stem = nullptr) {
   ChainArgs<NBLK> a;
   if (int rc = build_chain_args<NBLK>(a, x, x_ss, s_x, z_x, B, a_hi, blk, y, y_ss, n_samples, stem_x, stem)) return rc;
+  if (a.pool && !(Cc == 192 && H == 4 && NBLK == 1 && !stem && qbnn_use_chain_ring() && blk[0].w_layout == QBNN_LAYOUT_MFMA32))
+    return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: QBNN_BLOCK_POOL_OUT is served by the 4x4x192 identity block (one block per launch, ring kernel)%s");
   if (stem) {
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
     for (int k = 0; k < NBLK; ++k)

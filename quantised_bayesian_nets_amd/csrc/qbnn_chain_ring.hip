@@ -346,7 +346,48 @@ void block_chain_ring_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<
     // ---- read-out: tile -> registers (chunk i of the item's contiguous output block per thread: coalesced stores); barrier; next item's input
     //      over the same bytes (whole pixels per thread, see write_tile); registers -> HBM.  (One loop that reads and rewrites each cell in the
     //      per-pixel mapping needs no barrier, but its 16-byte stores land 96 / 192 bytes apart and slowed the next item's first conv by 8 %.)
-    {
+    bool pooled_out = false;
+    if constexpr (IMG_PX == 16 && !DROP) pooled_out = a.pool != 0;
+    if (pooled_out) {
+      // QBNN_BLOCK_POOL_OUT (the network's last block): the output leaves as AvgPool2d(4) of it -- one byte per (image, channel) instead of 16.
+      // The tile holds q - z_o: q_pool = rne(sum / 16) + z_o (the head's formula, qbnn_misc.hip head_i8_kernel; a mean of values inside
+      // [-z_o, a_hi - z_o] stays inside, so its clamps are no-ops).  One (image, 4 channels) column per thread.
+      if constexpr (IMG_PX == 16) {
+        constexpr int C4 = C::COUT / 4, NCOL = C::G * C4, NIT = (NCOL + NTHR - 1) / NTHR;
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        uint32_t pk[NIT];
+#pragma unroll
+        for (int it2 = 0; it2 < NIT; ++it2) {
+          const int i = t + it2 * NTHR, g = i / C4, c4 = i - g * C4;
+          pk[it2] = 0;
+          if (i < NCOL) {
+            int s4[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int p = 0; p < IMG_PX; ++p) {
+              const int v = *reinterpret_cast<const int*>(xt + (g * IMG_PX + p) * D::PIXB + 4 * c4);
+              s4[0] = __builtin_amdgcn_sdot4(v, 0x00000001, s4[0], false);
+              s4[1] = __builtin_amdgcn_sdot4(v, 0x00000100, s4[1], false);
+              s4[2] = __builtin_amdgcn_sdot4(v, 0x00010000, s4[2], false);
+              s4[3] = __builtin_amdgcn_sdot4(v, 0x01000000, s4[3], false);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              int q = (int)__builtin_rintf((float)s4[j] * 0.0625f) + bp.add.z_o;
+              q = q < 0 ? 0 : (q > 255 ? 255 : q);
+              pk[it2] |= (uint32_t)q << (8 * j);
+            }
+          }
+        }
+        lds_barrier();
+        write_tile(next);
+#pragma unroll
+        for (int it2 = 0; it2 < NIT; ++it2) {
+          const int i = t + it2 * NTHR, g = i / C4, c4 = i - g * C4;
+          if (i < NCOL && img0 + g < a.B) *reinterpret_cast<uint32_t*>(a.y + (int64_t)s * a.y_ss + (int64_t)(img0 + g) * C::COUT + 4 * c4) = pk[it2];
+        }
+      }
+    } else {
       const uint32_t z4o = (uint32_t)bp.add.z_o * 0x01010101u;
       uint8_t* ys = a.y + (int64_t)s * a.y_ss + (int64_t)img0 * IMG_PX * C::COUT;
       const int valid = valid_px * CPP;

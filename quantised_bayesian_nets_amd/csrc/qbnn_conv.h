@@ -845,6 +845,7 @@ struct ChainArgs {
   uint8_t* y; int64_t y_ss;           // block-chain output [S][B][H][H][C] quint8
   int B, n_samples;
   int z_in;                           // zero point of x
+  int pool;                           // QBNN_BLOCK_POOL_OUT of the chain's last block: y is the AvgPool2d(H) of the output, [S][B][C]
   unsigned long long* dbg;            // diagnostic builds only
   BlockParams blk[NBLK];
   const int8_t* stem_x;               // fused layer-0 conv (STEM kernels): centred im2col patches [B][32*32][32], shared by the samples

@@ -101,7 +101,13 @@ def run_down_block(blk, x):
     return MCQTensor(y, blk.add.add.scale, blk.add.add.zero_point)
 
 
-def run_identity_chain(blocks, x, stem=None):
+def pool_out_enabled():
+    """The network's last block hands the head its AvgPool2d(4) instead of the 4 x 4 map (QBNN_BLOCK_POOL_OUT; QBNN_HEAD_POOL=0 for the A/B);
+    the flag is served by the ring form of the 192-channel block only."""
+    return os.environ.get("QBNN_HEAD_POOL", "1") != "0" and os.environ.get("QBNN_CHAIN_RING", "1") != "0"
+
+
+def run_identity_chain(blocks, x, stem=None, pool_out=False):
     """Identity BasicBlocks (no shortcut conv) in ONE persistent fused kernel per call (qbnn_block_chain_i8_mc; 1 or 2 blocks at
     24 / 48 channels, one block per launch at 96 / 192 -- longer lists are walked here):
     activations stay in LDS between stem.0, stem.3 and the residual add.  Same results as calling the blocks.
@@ -112,7 +118,7 @@ def run_identity_chain(blocks, x, stem=None):
         h = x
         step = 1 if x.data.shape[4] >= 96 else 2
         for i in range(0, len(blocks), step):
-            h = run_identity_chain(blocks[i:i + step], h)
+            h = run_identity_chain(blocks[i:i + step], h, pool_out=pool_out and i + step >= len(blocks))
         return h
     dev = x.data.device if stem is None else stem[2].device
     descs = (_lib.BlockDesc * len(blocks))()
@@ -147,7 +153,10 @@ def run_identity_chain(blocks, x, stem=None):
         last = blocks[-1].add.add
         return MCQTensor(y, last.scale, last.zero_point)
     _, B, H, W, Cc = x.data.shape
-    y = torch.empty((S, B, H, W, Cc), dtype=torch.uint8, device=dev)
+    pool_out = pool_out and len(blocks) == 1 and (H, Cc) == (4, 192) and blocks[0].stem[0].layout == LAYOUT_MFMA32
+    if pool_out:
+        descs[0].flags = 1          # QBNN_BLOCK_POOL_OUT: y = AvgPool2d(4) of the block output, [S, B, 1, 1, C]
+    y = torch.empty((S, B, 1, 1, Cc) if pool_out else (S, B, H, W, Cc), dtype=torch.uint8, device=dev)
     key = "block_chain_i8 x%d %dx%d c%d" % (len(blocks), H, W, Cc)
     meta = dict(fused=True, convs=[(H, Cc, Cc, 3, 1, nw(c)) for b in blocks for c in (b.stem[0], b.stem[3])],
                 res_convs=[1 + 2 * i for i in range(len(blocks))])
@@ -331,7 +340,7 @@ class ConvNetwork_ResNet(nn.Module):
                     h = run_identity_chain(blocks, h)
                 else:
                     h = run_down_block(blocks[0], h)
-                    h = run_identity_chain(blocks[1:], h)
+                    h = run_identity_chain(blocks[1:], h, pool_out=(li == 6 and pool_out_enabled()))      # the head pools what the last block leaves
                 continue
             for bi, blk in enumerate(blocks):
                 if not self.fuse_blocks:

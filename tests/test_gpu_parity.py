@@ -1113,7 +1113,7 @@ print("SWITCH-OK")
 
 
 @pytest.mark.parametrize("switch", ["QBNN_NO_PINGPONG", "QBNN_NO_STEM_FUSION", "QBNN_GENERIC_NAIVE", "QBNN_W16=0", "QBNN_DOWN_RING=0", "QBNN_CHAIN_RING=0",
-                                    "QBNN_C48=0", "QBNN_W16_MAGIC=0", "QBNN_D24=0", "QBNN_CHAIN_2WG=0", "QBNN_DOWN_R16=0"])
+                                    "QBNN_C48=0", "QBNN_W16_MAGIC=0", "QBNN_D24=0", "QBNN_CHAIN_2WG=0", "QBNN_DOWN_R16=0", "QBNN_HEAD_POOL=0"])
 def test_environment_switches_give_the_same_results(switch, tmp_path):
     """The A/B switches of README.md select other kernels for the same arithmetic (weights-stationary instead of ping-pong
     48-channel block; layers.0 as its own launch; the scalar any-geometry conv; the 8-wave layer-1 kernel instead of the 16-wave one; the round-3 forms of the wide down-sampling and identity blocks):
@@ -1845,6 +1845,20 @@ def test_fused_blocks_random_qparams_against_oracle(seed, extreme):
                 _lib.check(L.qbnn_block_down_i8_mc(_lib.ptr(xd), xd[0].numel(), s_x, z_x, B, Hi, Ci, a_hi, C.byref(dd), _lib.ptr(y2), y2[0].numel(), S, st))
                 torch.cuda.synchronize()
                 assert np.array_equal(y2.cpu().numpy(), ref), ("down 24 -> 48, N24 set", a_hi, int((y2.cpu().numpy() != ref).sum()))
+            if Cc == 192 and not down:
+                # round 5: QBNN_BLOCK_POOL_OUT -- the block's output leaves as its AvgPool2d(4) (what the head consumes), [S][B][192]
+                blk.flags = 1
+                yp = torch.full((S, B, Co), 0xEE, dtype=torch.uint8, device="cuda")
+                _lib.check(L.qbnn_block_chain_i8_mc(_lib.ptr(xd), xd[0].numel(), s_x, z_x, B, Hi, Ci, a_hi, C.byref(blk), 1, _lib.ptr(yp), yp[0].numel(), S, st))
+                torch.cuda.synchronize()
+                want = np.stack([orc.avgpool_q(ref[s], 4, z_o, a_hi).reshape(B, Co) for s in range(S)])
+                assert np.array_equal(yp.cpu().numpy(), want), ("pooled output", int((yp.cpu().numpy() != want).sum()))
+                blk.flags = 0
+            if Cc == 96 and not down:
+                blk.flags = 1                          # ... and any other geometry refuses the flag
+                rc = L.qbnn_block_chain_i8_mc(_lib.ptr(xd), xd[0].numel(), s_x, z_x, B, Hi, Ci, a_hi, C.byref(blk), 1, _lib.ptr(y), y[0].numel(), S, st)
+                assert rc != 0 and b"POOL_OUT" in L.qbnn_last_error()
+                blk.flags = 0
             if Cc == 48 and not down:
                 # round 5: the same block on the 16-wave kernel (csrc/qbnn_c48.hip) -- weights as (24 + 1)-row tile halves (MFMA32_N24)
                 wa2, nba2 = _pack_per_sample(L, wa, 2)
