@@ -195,7 +195,8 @@ def _wl_resnet_mc_f32(a, world, q, load_golden):
 
 def _wl_resnet_float(kind):
     """SURVEY 8a rows a1 / a2 at the headline's shape (B = 256): the float Bayes-by-backprop ResNet-18 (fp32 MFMA convs, per-sample
-    weights) and its QAT form evaluated with live observers (fake-quantised tensors, fp64 conv sums; the MC samples are sequential
+    weights) and its QAT form evaluated with live observers (fake-quantised tensors; the convs as exact integer sums on the int8 matrix pipe since round 5,
+    fp64 sums with QBNN_QAT_I8=0; the MC samples are sequential
     through the observers' EMA state, so 10 per step).  States recorded from the reference (tests/golden/resnet_bbb_{f32,qat}.npz)."""
     def build(a, world, q, load_golden):
         if kind == "qat":
@@ -209,7 +210,7 @@ def _wl_resnet_float(kind):
         x_host = torch.randn(a.batch, 3, 32, 32, generator=torch.Generator().manual_seed(2))
         what = "QAT fake-quant evaluation with live observers (A7/W8 grids)" if kind == "qat" else "float Bayes-by-backprop"
         return dict(golden=None, model=model, x_host=x_host, units_per_gpu=S, units_global=S * world, resnet=False, cpu_baseline=False,
-                    step=lambda m, x, S_, seed: q.mc_predict(m, x, S_, seed), scaling="weak", dtype="f64" if kind == "qat" else "f32",
+                    step=lambda m, x, S_, seed: q.mc_predict(m, x, S_, seed), scaling="weak", dtype=("int8+f32" if os.environ.get("QBNN_QAT_I8", "1") != "0" else "f64") if kind == "qat" else "f32",
                     metric="MC forward samples/sec, ResNet-18 BBB %s batch=%d" % ("QAT-eval" if kind == "qat" else "fp32", a.batch), unit="MC samples/s",
                     describe="rows a1/a2: CIFAR-10-shaped ResNet-18 (24/48/96/192), %s, %d MC samples per GPU per step, batch=%d" % (what, S, a.batch))
     return build

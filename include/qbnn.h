@@ -458,6 +458,23 @@ int32_t qbnn_conv2d_f32_blocks(int32_t B, int32_t H, int32_t W, int32_t Cout, in
 int qbnn_observe_partials_f32_mc(const float* partials, int32_t n_blocks, int32_t n_samples, float* state, float avg_const,
                                  int32_t qmin, int32_t qmax, float* scale, int32_t* zero_point, void* stream);
 
+/* QAT convs on the int8 matrix pipe (round 5).  In the prepared model both operands of conv_qat.py:150-158's conv are fake-quantised tensors --
+ * integers on a per-sample grid: X = (q_x - z_x) s_x[s] with |q_x - z_x| <= 127 (ReLU and max-pooling keep the grid), W = (q_w - z_w) s_w[s] with q_w an
+ * int8 -- so conv(X, W) = s_x s_w sum (q_x - z_x)(q_w - z_w): an exact integer sum (v_mfma_i32_32x32x32_i8; the weight zero point through the window
+ * sum), scaled once in fp64 and rounded to fp32, then the same fused tail as qbnn_conv2d_f32_fused_mc (Z / c, + bias, bn, ReLU; min / max partials of
+ * qbnn_conv2d_q8_blocks(...) workgroups per sample for the observer).  Against the fp64 sum of the fp32-rounded operands it differs by the operands'
+ * own rounding (<= 1.2e-7 relative).
+ *   qbnn_grid_to_i8_mc: out[s][i] = clamp(rne(x[s][i] / scale[s]) + (zero_point ? zero_point[s] : 0), -128, 127) -- the centred activation integer
+ *   (zero_point NULL) or the raw weight integer q_w;  x_sample_stride 0 shares x.
+ *   qbnn_conv2d_q8_f32_mc: x int8 [S][B][H][W][Cin] centred, w int8 [S][Cout][k][k][Cin] raw, s_x / s_w / z_w per sample; y fp32 [S][B][Ho][Wo][Cout]. */
+int qbnn_grid_to_i8_mc(const float* x, int64_t x_sample_stride, int64_t n, const float* scale, const int32_t* zero_point, int8_t* out,
+                       int32_t n_samples, void* stream);
+int32_t qbnn_conv2d_q8_blocks(int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad);
+int qbnn_conv2d_q8_f32_mc(const int8_t* x, int64_t x_sample_stride, const int8_t* w, int64_t w_sample_stride, const float* s_x, const float* s_w,
+                          const int32_t* z_w, const float* div, const float* bias, const float* alpha, const float* beta, float* y,
+                          int64_t y_sample_stride, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
+                          int32_t pad, int32_t relu, int32_t n_samples, float* minmax_partials, void* stream);
+
 /* Pointwise on [S][n] with the channel as fastest axis:  v = (mode 0) x * p0[c] + p1[c]  |  (mode 1) x / p0[c] + p1[c]
  * (p0 / p1 NULL skip that step), v += res (if given), ReLU (if asked).  nn.BatchNorm2d in eval (x * alpha + beta as ATen
  * computes it), the `Z / scale_factor + bias` of conv_qat.py:159-161, Add (src/utils.py:49-55), nn.ReLU. */

@@ -687,6 +687,194 @@ QBNN_EXPORT int qbnn_fake_quant_f32_mc(const float* x, int64_t x_ss, float* y, i
   return qbnn_check_launch_msg("qbnn_fake_quant_f32_mc");
 }
 
+
+// =====================================================================================
+// QAT convs on the INT8 matrix pipe (round 5).  Both operands of a QAT conv are fake-quantised tensors -- integers on a per-sample grid:
+//   X = (q_x - z_x) s_x[s], |q_x - z_x| <= 127 (7-bit activations; ReLU and max-pooling keep the grid);  W = (q_w - z_w) s_w[s], q_w an int8.
+// So conv(X, W) = s_x s_w sum (q_x - z_x)(q_w - z_w): an exact integer sum on v_mfma_i32_32x32x32_i8 (the weight zero point through the window
+// sum R = sum (q_x - z_x): sum m_x (q_w - z_w) = acc - z_w R), scaled once in fp64 and rounded to fp32 -- against the fp64 sum of the fp32-rounded
+// operands (conv2d_f32_vec_kernel<.., ACC64>) it differs by the operands' own rounding, <= 1.2e-7 relative.
+//   qbnn_grid_to_i8_mc : fp32 grid tensor -> int8  m = rne(x / s[s]) (+ z[s] for weights: the raw q_w), one pass per tensor
+//   qbnn_conv2d_q8_f32_mc: implicit GEMM of conv_generic_mfma_i8_kernel's shape (64 pixels x 64 channels per workgroup, K in 32-byte chunks gathered
+//                          in 4-byte or 1-byte units) with conv2d_f32_vec_kernel's fused tail (Z / c, + bias, bn, ReLU) and min / max partials.
+// =====================================================================================
+__global__ __launch_bounds__(256) void grid_to_i8_kernel(const float* __restrict__ x, int64_t x_ss, int64_t n, const float* __restrict__ scale,
+                                                         const int* __restrict__ zp, int8_t* __restrict__ out) {
+  const int s = blockIdx.y;
+  const float inv = 1.0f / scale[s];
+  const float z = zp ? (float)zp[s] : 0.f;
+  const float* xs = x + (int64_t)s * x_ss;
+  int8_t* os = out + (int64_t)s * n;
+  if ((n & 3) == 0 && (x_ss & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256) {
+      const v4f v = reinterpret_cast<const v4f*>(xs)[i];
+      uint32_t pk = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = (int)fminf(fmaxf(rintf(v[k] * inv) + z, -128.f), 127.f);
+        pk |= ((uint32_t)q & 0xffu) << (8 * k);
+      }
+      reinterpret_cast<uint32_t*>(os)[i] = pk;
+    }
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    os[i] = (int8_t)(int)fminf(fmaxf(rintf(xs[i] * inv) + z, -128.f), 127.f);
+}
+
+QBNN_EXPORT int qbnn_grid_to_i8_mc(const float* x, int64_t x_ss, int64_t n, const float* scale, const int32_t* zero_point, int8_t* out,
+                                   int32_t n_samples, void* stream) {
+  if (!x || !scale || !out || n <= 0 || n_samples <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_grid_to_i8_mc: bad argument");
+  const int blocks = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 + 1 : 2048);
+  hipLaunchKernelGGL(grid_to_i8_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, n, scale, zero_point, out);
+  return qbnn_check_launch_msg("qbnn_grid_to_i8_mc");
+}
+
+struct ConvQ8Args {
+  const int8_t* x; int64_t x_ss;     // centred activations m_x [S][B][H][W][Cin]
+  const int8_t* w; int64_t w_ss;     // raw weights q_w [S][Cout][KH][KW][Cin]
+  const float* s_x; const float* s_w; const int* z_w;      // per sample
+  float* y; int64_t y_ss;
+  int B, H, W, Cin, Cout, KS, stride, pad, Ho, Wo, relu;
+  const float* div; const float* bias; const float* alpha; const float* beta;
+  float* mm_partials;
+};
+typedef int v16i_q8 __attribute__((ext_vector_type(16)));
+typedef int v4i_q8 __attribute__((ext_vector_type(4)));
+typedef int v2i_q8 __attribute__((ext_vector_type(2)));
+
+template <int GB>
+__global__ __launch_bounds__(256) void conv2d_q8_kernel(const ConvQ8Args a) {
+  constexpr int LD = 48;
+  __shared__ __attribute__((aligned(16))) uint8_t As[64 * LD];      // weights [n][k]
+  __shared__ __attribute__((aligned(16))) uint8_t Bs[64 * LD];      // pixels  [p][k]
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int s = blockIdx.z;
+  const int p0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int npix = a.B * a.Ho * a.Wo;
+  const int K = a.KS * a.KS * a.Cin;
+  const int8_t* xs = a.x + (int64_t)s * a.x_ss;
+  const int8_t* ws = a.w + (int64_t)s * a.w_ss;
+  const int row = tid >> 2, kb = (tid & 3) * 8;
+  const int p = p0 + row, n = n0 + row;
+  int pb = -1, ih0 = 0, iw0 = 0;
+  if (p < npix) { pb = p / (a.Ho * a.Wo); const int rem = p - pb * a.Ho * a.Wo; ih0 = (rem / a.Wo) * a.stride - a.pad; iw0 = (rem % a.Wo) * a.stride - a.pad; }
+  const int64_t xbase = (int64_t)(pb < 0 ? 0 : pb) * a.H * a.W * a.Cin;
+  const int8_t* wrow = ws + (int64_t)(n < a.Cout ? n : 0) * K;
+  auto gather = [&](int k0, uint32_t (&xv)[2], uint32_t (&wv)[2]) {
+    int kk = k0 + kb;
+    int tap = kk / a.Cin, c = kk - tap * a.Cin;
+    int kh = tap / a.KS, kw = tap - kh * a.KS;
+    xv[0] = xv[1] = wv[0] = wv[1] = 0u;
+#pragma unroll
+    for (int j = 0; j < 8 / GB; ++j, kk += GB) {
+      uint32_t xb = 0u, wb = 0u;
+      if (kk < K) {
+        if (pb >= 0) {
+          const int ih = ih0 + kh, iw = iw0 + kw;
+          if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {      // a tap outside the map: m_x = 0 (the zero point itself)
+            const int8_t* src = xs + xbase + ((int64_t)ih * a.W + iw) * a.Cin + c;
+            if constexpr (GB == 4) xb = *reinterpret_cast<const uint32_t*>(src);
+            else xb = (uint32_t)(uint8_t)*src;
+          }
+        }
+        if (n < a.Cout) {
+          if constexpr (GB == 4) wb = *reinterpret_cast<const uint32_t*>(wrow + kk);
+          else wb = (uint32_t)(uint8_t)wrow[kk];
+        }
+      }
+      constexpr int PER = 4 / GB;
+      xv[j / PER] |= xb << (8 * GB * (j % PER));
+      wv[j / PER] |= wb << (8 * GB * (j % PER));
+      c += GB;
+      if (c == a.Cin) { c = 0; if (++kw == a.KS) { kw = 0; ++kh; } }
+    }
+  };
+  v16i_q8 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0;
+  int rsum = 0;
+  uint32_t xv[2], wv[2];
+  gather(0, xv, wv);
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    *reinterpret_cast<v2i_q8*>(&Bs[row * LD + kb]) = v2i_q8{(int)xv[0], (int)xv[1]};
+    *reinterpret_cast<v2i_q8*>(&As[row * LD + kb]) = v2i_q8{(int)wv[0], (int)wv[1]};
+    __syncthreads();
+    if (k0 + 32 < K) gather(k0 + 32, xv, wv);
+    const v4i_q8 av = *reinterpret_cast<const v4i_q8*>(&As[(wn * 32 + (lane & 31)) * LD + 16 * (lane >> 5)]);
+    const v4i_q8 bv = *reinterpret_cast<const v4i_q8*>(&Bs[(wm * 32 + (lane & 31)) * LD + 16 * (lane >> 5)]);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rsum = __builtin_amdgcn_sdot4(bv[i], 0x01010101, rsum, false);
+    __syncthreads();
+  }
+  const int R = rsum + __shfl_xor(rsum, 32);              // this lane's pixel (lane & 31): sum of m_x over its window
+  const int po = p0 + wm * 32 + (lane & 31);
+  float vmin = INFINITY, vmax = -INFINITY;
+  if (po < npix) {
+    const double sp = (double)a.s_x[s] * (double)a.s_w[s];
+    const int zwr = a.z_w[s] * R;
+    float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int no = n0 + wn * 32 + 8 * g + 4 * (lane >> 5) + i;
+        if (no < a.Cout) {
+          float v = (float)((double)(acc[4 * g + i] - zwr) * sp);
+          if (a.div) v = v / a.div[no];
+          if (a.bias) v = v + a.bias[no];
+          if (a.alpha) v = v * a.alpha[no];
+          if (a.beta) v = v + a.beta[no];
+          if (a.relu) v = fmaxf(v, 0.f);
+          yp[no] = v; vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+        }
+      }
+  }
+  if (a.mm_partials) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o)); }
+    if (lane == 0) { red[2 * wave] = vmin; red[2 * wave + 1] = vmax; }
+    __syncthreads();
+    if (tid == 0) {
+      const int64_t slot = ((int64_t)s * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      a.mm_partials[2 * slot] = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
+      a.mm_partials[2 * slot + 1] = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+    }
+  }
+}
+
+// workgroups per sample of qbnn_conv2d_q8_f32_mc = length of one sample's row of `minmax_partials`
+QBNN_EXPORT int32_t qbnn_conv2d_q8_blocks(int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad) {
+  const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return 0;
+  return (int32_t)((((int64_t)B * Ho * Wo + 63) / 64) * ((Cout + 63) / 64));
+}
+
+QBNN_EXPORT int qbnn_conv2d_q8_f32_mc(const int8_t* x, int64_t x_ss, const int8_t* w, int64_t w_ss, const float* s_x, const float* s_w,
+                                      const int32_t* z_w, const float* div, const float* bias, const float* alpha, const float* beta, float* y,
+                                      int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
+                                      int32_t pad, int32_t relu, int32_t n_samples, float* minmax_partials, void* stream) {
+  if (!x || !w || !s_x || !s_w || !z_w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || n_samples <= 0)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: bad argument");
+  ConvQ8Args a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.x_ss = x_ss; a.w = w; a.w_ss = w_ss; a.s_x = s_x; a.s_w = s_w; a.z_w = z_w; a.y = y; a.y_ss = y_ss;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = ksize; a.stride = stride; a.pad = pad; a.relu = relu & 1;
+  a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
+  a.div = div; a.bias = bias; a.alpha = alpha; a.beta = beta; a.mm_partials = minmax_partials;
+  if (a.Ho <= 0 || a.Wo <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: empty output");
+  if ((int64_t)ksize * ksize * Cin * 127 * 128 >= (1ll << 31)) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: K too large for int32 sums");
+  const int64_t npix = (int64_t)B * a.Ho * a.Wo;
+  const dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)n_samples);
+  const bool u4 = (Cin % 4) == 0 && (x_ss % 4) == 0 && (w_ss % 4) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 3) == 0;
+  if (u4) hipLaunchKernelGGL(conv2d_q8_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv2d_q8_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return qbnn_check_launch_msg("qbnn_conv2d_q8_f32_mc");
+}
+
 // W[s][i] = mu[s][i] + eps(s, i) * sigma[s][i] with per-sample mu / sigma (the QAT weight pipeline quantises them with
 // per-sample qparams); mu NULL -> the noise term alone (conv_qat.py:45: mul_noise.mul(noise, std)).  Same Philox stream as
 // qbnn_sample_weights_f32: ctr = {i >> 2, layer_id, sample_begin + s, 0}, element i & 3; eps_in [S][n] overrides it.

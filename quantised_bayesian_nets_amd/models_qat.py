@@ -76,6 +76,7 @@ class FakeQuantize(nn.Module):
             _lib.check(L.qbnn_fake_quant_f32_mc(_lib.ptr(x), xs, _lib.ptr(y), n, n, _lib.ptr(scale), _lib.ptr(zp), 1, self.qmin, self.qmax, S,
                                                 _lib.current_stream()))
         self.last_scale, self.last_zero_point = scale, zp
+        y._grid = scale              # y[s] holds integers times scale[s]: what conv2d_q8 (the int8 matrix pipe) needs to know about its input
         return y
 
 
@@ -94,6 +95,44 @@ def prepared_state(model):
             st[m._key + ".activation_post_process.min_val"] = np.float32(mn)
             st[m._key + ".activation_post_process.max_val"] = np.float32(mx)
     return st
+
+
+def qat_i8_enabled():
+    """QAT convs / linears on the int8 matrix pipe where both operands are fake-quantised tensors (QBNN_QAT_I8=0: the fp64 sums)."""
+    return os.environ.get("QBNN_QAT_I8", "1") != "0"
+
+
+def keep_grid(dst, src, gain=None):
+    """`dst` holds the same grid integers as `src` (ReLU, max-pooling, Flatten, a reshape), times `gain` if given (the dropout's 1 / (1 - p))."""
+    g = getattr(src, "_grid", None)
+    if g is not None:
+        dst._grid = g if gain is None else g * float(gain)
+    return dst
+
+
+def conv2d_q8(x, s_x, W, s_w, z_w, cin, cout, k, stride, pad, relu, bias=None, div=None, bn=None):
+    """conv of two fake-quantised tensors as an exact integer sum (qbnn_grid_to_i8_mc x 2 + qbnn_conv2d_q8_f32_mc): x fp32 [S,B,H,W,Cin] on the grid
+    s_x[S], W fp32 [S, Cout*k*k*Cin] (OHWI) on the grid (s_w[S], z_w[S]).  Returns (y fp32 [S,B,Ho,Wo,Cout], (min/max partials, workgroups))."""
+    S, B, H, Wd = x.shape[0], x.shape[1], x.shape[2], x.shape[3]
+    L = _lib.lib()
+    st = _lib.current_stream()
+    x = x.contiguous()
+    n_x, n_w = x[0].numel(), W.shape[1]
+    xq = torch.empty((S, n_x), dtype=torch.int8, device=x.device)
+    wq = torch.empty((S, n_w), dtype=torch.int8, device=x.device)
+    with timed("grid_to_i8"):
+        _lib.check(L.qbnn_grid_to_i8_mc(_lib.ptr(x), n_x, n_x, _lib.ptr(s_x), None, _lib.ptr(xq), S, st))
+        _lib.check(L.qbnn_grid_to_i8_mc(_lib.ptr(W), 0 if W.shape[0] == 1 else n_w, n_w, _lib.ptr(s_w), _lib.ptr(z_w), _lib.ptr(wq), S, st))
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
+    y = torch.empty((S, B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    nblk = int(L.qbnn_conv2d_q8_blocks(B, H, Wd, cout, k, stride, pad))
+    partials = torch.empty(S * nblk * 2, dtype=torch.float32, device=x.device)
+    alpha, beta = bn if bn is not None else (None, None)
+    with timed("conv2d_q8"):
+        _lib.check(L.qbnn_conv2d_q8_f32_mc(_lib.ptr(xq), n_x, _lib.ptr(wq), n_w, _lib.ptr(s_x), _lib.ptr(s_w), _lib.ptr(z_w), _lib.ptr(div), _lib.ptr(bias),
+                                           _lib.ptr(alpha), _lib.ptr(beta), _lib.ptr(y), y[0].numel(), B, H, Wd, cin, cout, k, stride, pad, int(relu), S,
+                                           _lib.ptr(partials), st))
+    return y, (partials, nblk)
 
 
 class _QATBBB(nn.Module):
@@ -125,6 +164,10 @@ class _QATBBB(nn.Module):
 
     def scale_factor(self):
         return None
+
+    def weight_grid(self):
+        """The FakeQuantize whose output the conv's weight operand is (its last per-sample qparams describe W's integer grid)."""
+        return self.add_weight
 
     def sampled_weights(self, dev, eps=None):
         pre = getattr(self, "_presampled", None)
@@ -233,6 +276,19 @@ class Conv2d(_QATBBB):
     def forward(self, x, eps=None):
         dev = x.device
         W = self.sampled_weights(dev, eps)
+        gs, wg = getattr(x, "_grid", None), self.weight_grid()
+        if qat_i8_enabled() and gs is not None and x.shape[0] == _MC.samples and wg.last_scale is not None and wg.qmin >= -128 and wg.qmax <= 127:
+            # both operands are fake-quantised tensors: the conv is an exact integer sum on the int8 matrix pipe (csrc/qbnn_f32.hip, conv2d_q8_kernel)
+            if self.bn is None:
+                b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
+                z, mm = conv2d_q8(x, gs, W, wg.last_scale, wg.last_zero_point, self.in_channels, self.out_channels, self.k, self.stride, self.padding,
+                                  self.relu, bias=b)
+            else:
+                if self._cb is None or self._cb[0].device != dev:
+                    self._cb = (self.scale_factor().to(dev).contiguous(), None if self.bias is None else self.bias.detach().to(dev).contiguous())
+                z, mm = conv2d_q8(x, gs, W, wg.last_scale, wg.last_zero_point, self.in_channels, self.out_channels, self.k, self.stride, self.padding,
+                                  self.relu, bias=self._cb[1], div=self._cb[0], bn=self.bn.coefficients(dev))
+            return self.activation_post_process(z, partials=mm)
         if self.bn is None:
             b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
             z, mm = conv2d_f32(x, W, b, self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True,
@@ -274,6 +330,11 @@ class Linear(_QATBBB):
         b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
         a = (1 if self.relu else 0) if act is None else act
         x = x.contiguous()
+        gs, wg = getattr(x, "_grid", None), self.weight_grid()
+        if a in (0, 1) and qat_i8_enabled() and gs is not None and x.shape[0] == S and wg.last_scale is not None and wg.qmin >= -128 and wg.qmax <= 127:
+            y5, mm = conv2d_q8(x.reshape(S, B, 1, 1, self.in_features), gs, W, wg.last_scale, wg.last_zero_point, self.in_features, self.out_features,
+                               1, 1, 0, bool(a), bias=b)
+            return self.activation_post_process(y5.reshape(S, B, self.out_features), partials=mm)
         if a in (0, 1):      # the 1x1 case of the conv kernel: its workgroups leave the output's (min, max) for the observer
             y5, mm = conv2d_f32(x.reshape(x.shape[0], B, 1, 1, self.in_features), W, b, self.in_features, self.out_features, 1, 1, 0, bool(a),
                                 ohwi=True, minmax=True)
@@ -341,9 +402,11 @@ class ConvNetwork_LeNet(nn.Module):
 
     def forward_mc(self, x):
         h = self.quant(nchw_to_mc_nhwc(x))
-        h = pool2d_f32(self.layers[0](h), 2, avg=False)
-        h = pool2d_f32(self.layers[2](h), 2, avg=False)
-        h = flatten_f32(h)
+        c = self.layers[0](h)
+        h = keep_grid(pool2d_f32(c, 2, avg=False), c)            # max-pooling picks grid values
+        c = self.layers[2](h)
+        h = keep_grid(pool2d_f32(c, 2, avg=False), c)
+        h = keep_grid(flatten_f32(h), h)
         h = self.layers[5](h)
         return softmax_f32(self.layers[7](h))
 
@@ -423,7 +486,8 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         out = self.stem[3](self.stem[0](x))
         sc = self.shortcut[0](x) if len(self.shortcut) else x
-        return affine_f32(self.add(affine_f32(out, res=sc)), relu=True)
+        q = self.add(affine_f32(out, res=sc))
+        return keep_grid(affine_f32(q, relu=True), q)            # ReLU of grid values: still on the grid
 
 
 class ConvNetwork_ResNet(nn.Module):

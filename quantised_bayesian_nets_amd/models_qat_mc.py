@@ -20,7 +20,7 @@ from . import _lib
 from .layers import _MC, bump_state_epoch, mc_context, timed
 from .models_f32 import affine_f32, flatten_f32, nchw_to_mc_nhwc, pool2d_f32, softmax_f32
 from .models_qat import Conv2d as _ConvBBB
-from .models_qat import FakeQuantize, QuantStub, _bounds, prepared_state, presample_weights
+from .models_qat import FakeQuantize, QuantStub, _bounds, keep_grid, prepared_state, presample_weights
 from .models_qat import Linear as _LinearBBB
 
 
@@ -34,6 +34,9 @@ class _Deterministic:
         self.activation_post_process = FakeQuantize(alo, ahi)
         self.layer_id = 0
         self._folded = None
+
+    def weight_grid(self):
+        return self.weight_fake_quant
 
     def _folded_params(self, dev):
         if self._folded is None or self._folded.device != dev:
@@ -113,7 +116,7 @@ class BernoulliDropout(nn.Module):
         y = self.mul_mask(y)
         if self._gain is None or self._gain.device != dev or self._gain.numel() != C:
             self._gain = torch.full((C,), float(np.float32(self.multiplier.item())), dtype=torch.float32, device=dev)
-        return affine_f32(y, p0=self._gain)
+        return keep_grid(affine_f32(y, p0=self._gain), y, gain=np.float32(self.multiplier.item()))      # grid integers x (scale / (1 - p))
 
 
 class _Net(nn.Module):
@@ -213,9 +216,11 @@ class ConvNetwork_LeNet(_Net):
     def forward_mc(self, x):
         d = list(self.drop) if self.p > 0 else [lambda t: t] * 3
         h = self.quant(nchw_to_mc_nhwc(x))
-        h = pool2d_f32(d[0](self.c1(h)), 2, avg=False)
-        h = pool2d_f32(d[1](self.c2(h)), 2, avg=False)
-        h = d[2](self.f1(flatten_f32(h)))
+        c = d[0](self.c1(h))
+        h = keep_grid(pool2d_f32(c, 2, avg=False), c)
+        c = d[1](self.c2(h))
+        h = keep_grid(pool2d_f32(c, 2, avg=False), c)
+        h = d[2](self.f1(keep_grid(flatten_f32(h), h)))
         return softmax_f32(self.f2(h))
 
 
@@ -242,7 +247,8 @@ class _Block(nn.Module):
             sc = self.s(x)
             if self.ds is not None:
                 sc = self.ds(sc)
-        return affine_f32(self.add(affine_f32(out, res=sc)), relu=True)
+        q = self.add(affine_f32(out, res=sc))
+        return keep_grid(affine_f32(q, relu=True), q)
 
 
 class ConvNetwork_ResNet(_Net):
