@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/qbnn.h"
 #include "qbnn_common.h"
@@ -846,6 +847,123 @@ __global__ __launch_bounds__(256) void conv2d_q8_kernel(const ConvQ8Args a) {
   }
 }
 
+
+// The Cin % 4 == 0 form (every conv but layers.0): 64-byte K chunks -- each thread moves 16 bytes per operand and chunk, two MFMAs per wave and barrier
+// pair -- and, as in conv2d_f32_vec_kernel<.., VEC = 2>, a row keeps the offset of its window's tap (0, 0) and one validity bit per tap
+// (KS KS <= 32), so a 4-byte unit costs one offset add and a bit test instead of two bounds compares and a 64-bit address product.
+__global__ __launch_bounds__(256) void conv2d_q8v_kernel(const ConvQ8Args a) {
+  constexpr int LD = 80;                                              // 64 + 16: conflict-free ds_read_b128 fragments (tools/lds_conflicts.py)
+  __shared__ __attribute__((aligned(16))) uint8_t As[64 * LD];
+  __shared__ __attribute__((aligned(16))) uint8_t Bs[64 * LD];
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int s = blockIdx.z;
+  const int p0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int npix = a.B * a.Ho * a.Wo;
+  const int K = a.KS * a.KS * a.Cin;
+  const int8_t* xs = a.x + (int64_t)s * a.x_ss;
+  const int8_t* ws = a.w + (int64_t)s * a.w_ss;
+  const int row = tid >> 2, kb = (tid & 3) * 16;
+  const int p = p0 + row, n = n0 + row;
+  int roff = 0;
+  uint32_t rmask = 0;
+  if (p < npix) {
+    const int pb = p / (a.Ho * a.Wo), rem = p - pb * a.Ho * a.Wo;
+    const int ih0 = (rem / a.Wo) * a.stride - a.pad, iw0 = (rem % a.Wo) * a.stride - a.pad;
+    roff = ((pb * a.H + ih0) * a.W + iw0) * a.Cin;                     // (a sample's input is below 2^31 bytes)
+    for (int kh = 0; kh < a.KS; ++kh)
+      for (int kw = 0; kw < a.KS; ++kw)
+        if ((unsigned)(ih0 + kh) < (unsigned)a.H && (unsigned)(iw0 + kw) < (unsigned)a.W) rmask |= 1u << (kh * a.KS + kw);
+  }
+  const bool wok = n < a.Cout;
+  const int8_t* wrow = ws + (int64_t)(wok ? n : 0) * K;
+  // this thread's first unit of the chunk: k = k0 + kb in tap (gkh, gkw) at channel gc; advanced by 64 per chunk without divisions
+  int gkh, gkw, gc;
+  { const int tap = kb / a.Cin; gc = kb - tap * a.Cin; gkh = tap / a.KS; gkw = tap - gkh * a.KS; }
+  auto gather = [&](int k0, v4i_q8& xv, v4i_q8& wv) {
+    int kh = gkh, kw = gkw, c = gc;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = k0 + kb + 4 * u;
+      int xb = 0, wb = 0;
+      if (kk < K) {
+        const int tap = kh * a.KS + kw;
+        if ((rmask >> tap) & 1u) xb = *reinterpret_cast<const int*>(xs + roff + (kh * a.W + kw) * a.Cin + c);
+        if (wok) wb = *reinterpret_cast<const int*>(wrow + kk);
+      }
+      xv[u] = xb; wv[u] = wb;
+      c += 4;
+      if (c >= a.Cin) { c -= a.Cin; if (++kw == a.KS) { kw = 0; ++kh; } }
+    }
+    // the next chunk's first unit: + 64 channels' worth
+    int cc = gc + 64;
+    while (cc >= a.Cin) { cc -= a.Cin; if (++gkw == a.KS) { gkw = 0; ++gkh; } }
+    gc = cc;
+  };
+  v16i_q8 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0;
+  int rsum = 0;
+  v4i_q8 xv, wv;
+  gather(0, xv, wv);
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    *reinterpret_cast<v4i_q8*>(&Bs[row * LD + kb]) = xv;
+    *reinterpret_cast<v4i_q8*>(&As[row * LD + kb]) = wv;
+    __syncthreads();
+    if (k0 + 64 < K) gather(k0 + 64, xv, wv);
+#pragma unroll
+    for (int hk = 0; hk < 2; ++hk) {
+      const v4i_q8 av = *reinterpret_cast<const v4i_q8*>(&As[(wn * 32 + (lane & 31)) * LD + 32 * hk + 16 * (lane >> 5)]);
+      const v4i_q8 bv = *reinterpret_cast<const v4i_q8*>(&Bs[(wm * 32 + (lane & 31)) * LD + 32 * hk + 16 * (lane >> 5)]);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rsum = __builtin_amdgcn_sdot4(bv[i], 0x01010101, rsum, false);
+    }
+    __syncthreads();
+  }
+  const int R = rsum + __shfl_xor(rsum, 32);
+  const int po = p0 + wm * 32 + (lane & 31);
+  float vmin = INFINITY, vmax = -INFINITY;
+  if (po < npix) {
+    const double sp = (double)a.s_x[s] * (double)a.s_w[s];
+    const int zwr = a.z_w[s] * R;
+    float* yp = a.y + (int64_t)s * a.y_ss + (int64_t)po * a.Cout;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nb = n0 + wn * 32 + 8 * g + 4 * (lane >> 5);
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int no = nb + i, nc = no < a.Cout ? no : 0;
+        float t = (float)((double)(acc[4 * g + i] - zwr) * sp);
+        if (a.div) t = t / a.div[nc];
+        if (a.bias) t = t + a.bias[nc];
+        if (a.alpha) t = t * a.alpha[nc];
+        if (a.beta) t = t + a.beta[nc];
+        if (a.relu) t = fmaxf(t, 0.f);
+        v[i] = t;
+        if (no < a.Cout) { vmin = fminf(vmin, t); vmax = fmaxf(vmax, t); }
+      }
+      if (nb + 3 < a.Cout && (a.Cout & 3) == 0) *reinterpret_cast<v4f*>(yp + nb) = v4f{v[0], v[1], v[2], v[3]};
+      else
+        for (int i = 0; i < 4; ++i)
+          if (nb + i < a.Cout) yp[nb + i] = v[i];
+    }
+  }
+  if (a.mm_partials) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o)); }
+    if (lane == 0) { red[2 * wave] = vmin; red[2 * wave + 1] = vmax; }
+    __syncthreads();
+    if (tid == 0) {
+      const int64_t slot = ((int64_t)s * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      a.mm_partials[2 * slot] = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
+      a.mm_partials[2 * slot + 1] = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+    }
+  }
+}
+
 // workgroups per sample of qbnn_conv2d_q8_f32_mc = length of one sample's row of `minmax_partials`
 QBNN_EXPORT int32_t qbnn_conv2d_q8_blocks(int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad) {
   const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
@@ -870,7 +988,10 @@ QBNN_EXPORT int qbnn_conv2d_q8_f32_mc(const int8_t* x, int64_t x_ss, const int8_
   const int64_t npix = (int64_t)B * a.Ho * a.Wo;
   const dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)n_samples);
   const bool u4 = (Cin % 4) == 0 && (x_ss % 4) == 0 && (w_ss % 4) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 3) == 0;
-  if (u4) hipLaunchKernelGGL(conv2d_q8_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  static const bool wide = [] { const char* e = getenv("QBNN_Q8_WIDE"); return !(e && e[0] == '0'); }();
+  const bool y16 = (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_ss % 4) == 0;
+  if (u4 && wide && ksize * ksize <= 32 && y16 && (int64_t)B * H * W * Cin < (1ll << 31)) hipLaunchKernelGGL(conv2d_q8v_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (u4) hipLaunchKernelGGL(conv2d_q8_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(conv2d_q8_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
   return qbnn_check_launch_msg("qbnn_conv2d_q8_f32_mc");
 }

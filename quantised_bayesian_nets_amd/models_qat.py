@@ -110,6 +110,17 @@ def keep_grid(dst, src, gain=None):
     return dst
 
 
+def weights_to_i8(W, s_w, z_w):
+    """The raw integers q_w = rne(W / s_w) + z_w of a fake-quantised weight tensor W [S, n] (per-sample qparams), int8 [S, n]."""
+    S = s_w.shape[0]
+    n_w = W.shape[1]
+    wq = torch.empty((S, n_w), dtype=torch.int8, device=W.device)
+    with timed("grid_to_i8"):
+        _lib.check(_lib.lib().qbnn_grid_to_i8_mc(_lib.ptr(W), 0 if W.shape[0] == 1 else n_w, n_w, _lib.ptr(s_w), _lib.ptr(z_w), _lib.ptr(wq), S,
+                                                 _lib.current_stream()))
+    return wq
+
+
 def conv2d_q8(x, s_x, W, s_w, z_w, cin, cout, k, stride, pad, relu, bias=None, div=None, bn=None):
     """conv of two fake-quantised tensors as an exact integer sum (qbnn_grid_to_i8_mc x 2 + qbnn_conv2d_q8_f32_mc): x fp32 [S,B,H,W,Cin] on the grid
     s_x[S], W fp32 [S, Cout*k*k*Cin] (OHWI) on the grid (s_w[S], z_w[S]).  Returns (y fp32 [S,B,Ho,Wo,Cout], (min/max partials, workgroups))."""
@@ -119,10 +130,13 @@ def conv2d_q8(x, s_x, W, s_w, z_w, cin, cout, k, stride, pad, relu, bias=None, d
     x = x.contiguous()
     n_x, n_w = x[0].numel(), W.shape[1]
     xq = torch.empty((S, n_x), dtype=torch.int8, device=x.device)
-    wq = torch.empty((S, n_w), dtype=torch.int8, device=x.device)
     with timed("grid_to_i8"):
         _lib.check(L.qbnn_grid_to_i8_mc(_lib.ptr(x), n_x, n_x, _lib.ptr(s_x), None, _lib.ptr(xq), S, st))
-        _lib.check(L.qbnn_grid_to_i8_mc(_lib.ptr(W), 0 if W.shape[0] == 1 else n_w, n_w, _lib.ptr(s_w), _lib.ptr(z_w), _lib.ptr(wq), S, st))
+    for t in (s_x, s_w, z_w):            # (the weight side's qparams may come from a side stream's pipeline: keep them alive for this stream's kernel)
+        t.record_stream(torch.cuda.current_stream())
+    wq = getattr(W, "_q8", None)          # left by the weight pipeline (weights_to_i8: on its side stream when the weights were presampled)
+    if wq is None:
+        wq = weights_to_i8(W, s_w, z_w)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
     y = torch.empty((S, B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
     nblk = int(L.qbnn_conv2d_q8_blocks(B, H, Wd, cout, k, stride, pad))
@@ -179,6 +193,8 @@ class _QATBBB(nn.Module):
             W, ev = pre[0], pre[1]
             torch.cuda.current_stream().wait_event(ev)
             W.record_stream(torch.cuda.current_stream())
+            if getattr(W, "_q8", None) is not None:
+                W._q8.record_stream(torch.cuda.current_stream())
             return W
         S = _MC.samples
         mu0, sg0 = self._folded_params(dev)
@@ -197,7 +213,10 @@ class _QATBBB(nn.Module):
                 _lib.check(_lib.lib().qbnn_sample_weights_f32_strided(None, 0, _lib.ptr(s), n, n, _MC.seed, self.layer_id, _MC.sample_begin, S,
                                                                       _lib.ptr(eps), _lib.ptr(t_pre), _lib.current_stream()))
         t = self.mul_noise(t_pre)
-        return self.add_weight(affine_f32(w.unsqueeze(-1), res=t.unsqueeze(-1)).squeeze(-1))
+        W = self.add_weight(affine_f32(w.unsqueeze(-1), res=t.unsqueeze(-1)).squeeze(-1))
+        if qat_i8_enabled() and self.add_weight.qmin >= -128 and self.add_weight.qmax <= 127:
+            W._q8 = weights_to_i8(W, self.add_weight.last_scale, self.add_weight.last_zero_point)      # the conv's weight operand on the int8 pipe
+        return W
 
     def _load_common(self, st, name):
         self.weight.data = torch.from_numpy(np.asarray(st[name + ".weight"], np.float32).copy()).reshape(self.weight.shape)

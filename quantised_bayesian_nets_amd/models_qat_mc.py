@@ -56,8 +56,14 @@ class _Deterministic:
         if pre is not None and pre[2] == _presample_key(dev) and not torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream().wait_event(pre[1])
             pre[0].record_stream(torch.cuda.current_stream())
+            if getattr(pre[0], "_q8", None) is not None:
+                pre[0]._q8.record_stream(torch.cuda.current_stream())
             return pre[0]
-        return self.weight_fake_quant(self._folded_params(dev))
+        W = self.weight_fake_quant(self._folded_params(dev))
+        from .models_qat import qat_i8_enabled, weights_to_i8
+        if qat_i8_enabled() and self.weight_fake_quant.qmin >= -128 and self.weight_fake_quant.qmax <= 127:
+            W._q8 = weights_to_i8(W, self.weight_fake_quant.last_scale, self.weight_fake_quant.last_zero_point)
+        return W
 
     def _load_common(self, st, name):
         self.weight.data = torch.from_numpy(np.asarray(st[name + ".weight"], np.float32).copy()).reshape(self.weight.shape)
