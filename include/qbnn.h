@@ -467,6 +467,10 @@ int qbnn_observe_partials_f32_mc(const float* partials, int32_t n_blocks, int32_
  *   qbnn_grid_to_i8_mc: out[s][i] = clamp(rne(x[s][i] / scale[s]) + (zero_point ? zero_point[s] : 0), -128, 127) -- the centred activation integer
  *   (zero_point NULL) or the raw weight integer q_w;  x_sample_stride 0 shares x.
  *   qbnn_conv2d_q8_f32_mc: x int8 [S][B][H][W][Cin] centred, w int8 [S][Cout][k][k][Cin] raw, s_x / s_w / z_w per sample; y fp32 [S][B][Ho][Wo][Cout]. */
+/* qbnn_fake_quant_f32_mc with the ReLU that follows it in the graph (BasicBlock: Add -> FakeQuantize -> ReLU) and, optionally, the grid integers
+ * q - z (after the ReLU) as int8 [S][n]: the activation operand of qbnn_conv2d_q8_f32_mc without a qbnn_grid_to_i8_mc pass (qmax - qmin <= 254). */
+int qbnn_fake_quant_ex_f32_mc(const float* x, int64_t x_sample_stride, float* y, int64_t y_sample_stride, int64_t n, const float* scale,
+                              const int32_t* zero_point, int32_t qmin, int32_t qmax, int32_t relu, int8_t* q8_out, int32_t n_samples, void* stream);
 int qbnn_grid_to_i8_mc(const float* x, int64_t x_sample_stride, int64_t n, const float* scale, const int32_t* zero_point, int8_t* out,
                        int32_t n_samples, void* stream);
 int32_t qbnn_conv2d_q8_blocks(int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad);

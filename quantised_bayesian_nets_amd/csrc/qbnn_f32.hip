@@ -677,6 +677,53 @@ __global__ __launch_bounds__(256) void fake_quant_f32_kernel(const float* __rest
   }
 }
 
+// ... with the ReLU that follows it in the graph (BasicBlock: Add -> FakeQuantize -> ReLU; a ReLU of grid values stays on the grid) and, optionally, the
+// grid integers themselves, m = q - z (after the ReLU: max(m, 0)), as int8 [S][n] -- the operand format of qbnn_conv2d_q8_f32_mc, so the consumer conv
+// needs no qbnn_grid_to_i8_mc pass.  q8 requires qmax - qmin <= 254 (|m| <= 127: the 7-bit activation grids).
+__global__ __launch_bounds__(256) void fake_quant_ex_f32_kernel(const float* __restrict__ x, int64_t x_ss, float* __restrict__ y, int64_t y_ss,
+                                                                 int64_t n, const float* __restrict__ scale, const int* __restrict__ zp, int qmin, int qmax,
+                                                                 int relu, int8_t* __restrict__ q8) {
+  const int s = blockIdx.y;
+  const float sc = scale[s], inv = 1.0f / sc;
+  const float z = (float)zp[s], lo = (float)qmin, hi = (float)qmax;
+  const float mlo = relu ? 0.f : -INFINITY;
+  if ((n & 3) == 0 && ((x_ss | y_ss) & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(q8)) & 15) == 0) {
+    const v4f* x4 = reinterpret_cast<const v4f*>(x + (int64_t)s * x_ss);
+    v4f* y4 = reinterpret_cast<v4f*>(y + (int64_t)s * y_ss);
+    uint32_t* q4 = q8 ? reinterpret_cast<uint32_t*>(q8 + (int64_t)s * n) : nullptr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256) {
+      v4f v = x4[i];
+      uint32_t pk = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float m = fmaxf(fminf(fmaxf(rintf(v[k] * inv) + z, lo), hi) - z, mlo);      // the grid integer q - z (ReLU: an integer clamp of it)
+        v[k] = m * sc;
+        pk |= ((uint32_t)(int)m & 0xffu) << (8 * k);
+      }
+      y4[i] = v;
+      if (q4) q4[i] = pk;
+    }
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float m = fmaxf(fminf(fmaxf(rintf(x[(int64_t)s * x_ss + i] * inv) + z, lo), hi) - z, mlo);
+    y[(int64_t)s * y_ss + i] = m * sc;
+    if (q8) q8[(int64_t)s * n + i] = (int8_t)(int)m;
+  }
+}
+
+QBNN_EXPORT int qbnn_fake_quant_ex_f32_mc(const float* x, int64_t x_ss, float* y, int64_t y_ss, int64_t n, const float* scale,
+                                          const int32_t* zero_point, int32_t qmin, int32_t qmax, int32_t relu, int8_t* q8_out, int32_t n_samples,
+                                          void* stream) {
+  if (!x || !y || !scale || !zero_point || n <= 0 || n_samples <= 0 || qmax <= qmin)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_ex_f32_mc: bad argument");
+  if (q8_out && qmax - qmin > 254) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_ex_f32_mc: the int8 output takes grids of at most 255 steps");
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(fake_quant_ex_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, y, y_ss, n, scale, zero_point,
+                     qmin, qmax, relu, q8_out);
+  return qbnn_check_launch_msg("qbnn_fake_quant_ex_f32_mc");
+}
+
 QBNN_EXPORT int qbnn_fake_quant_f32_mc(const float* x, int64_t x_ss, float* y, int64_t y_ss, int64_t n, const float* scale,
                                        const int32_t* zero_point, int32_t qparam_stride, int32_t qmin, int32_t qmax,
                                        int32_t n_samples, void* stream) {

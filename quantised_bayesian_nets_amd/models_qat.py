@@ -48,10 +48,11 @@ class FakeQuantize(nn.Module):
         s = self.state.detach().cpu().numpy()
         return (float(s[0]), float(s[1])) if s[2] else (float("inf"), float("-inf"))
 
-    def forward(self, x, partials=None):
+    def forward(self, x, partials=None, relu=False):
         """x [S or 1, ...] fp32 on the GPU -> [S, ...]: sample s is quantised with the qparams the observer holds after
         having seen samples 0..s (a shared input is observed S times, as S reference forwards would).
-        partials = (buffer, n_blocks): per-workgroup (min, max) the producing conv already wrote -- the min/max pass is skipped."""
+        partials = (buffer, n_blocks): per-workgroup (min, max) the producing conv already wrote -- the min/max pass is skipped.
+        relu: the ReLU that follows this FakeQuantize in the graph, applied in the same pass (a ReLU of grid values stays on the grid)."""
         if x.device.type != "cuda":
             raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
         S = _MC.samples
@@ -72,11 +73,19 @@ class FakeQuantize(nn.Module):
                 _lib.check(L.qbnn_observe_f32_mc(_lib.ptr(x), xs, n, S, _lib.ptr(self.state), AVG_CONST, self.qmin, self.qmax, _lib.ptr(ws),
                                                  _lib.ptr(scale), _lib.ptr(zp), _lib.current_stream()))
         y = torch.empty((S,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        q8 = None
+        if qat_i8_enabled() and self.qmax - self.qmin <= 254:      # an activation grid: leave the integers q - z for a consumer conv on the int8 pipe
+            q8 = torch.empty((S, n), dtype=torch.int8, device=x.device)
         with timed("fake_quant_f32"):
-            _lib.check(L.qbnn_fake_quant_f32_mc(_lib.ptr(x), xs, _lib.ptr(y), n, n, _lib.ptr(scale), _lib.ptr(zp), 1, self.qmin, self.qmax, S,
-                                                _lib.current_stream()))
+            if q8 is not None or relu:
+                _lib.check(L.qbnn_fake_quant_ex_f32_mc(_lib.ptr(x), xs, _lib.ptr(y), n, n, _lib.ptr(scale), _lib.ptr(zp), self.qmin, self.qmax, int(relu),
+                                                       _lib.ptr(q8), S, _lib.current_stream()))
+            else:
+                _lib.check(L.qbnn_fake_quant_f32_mc(_lib.ptr(x), xs, _lib.ptr(y), n, n, _lib.ptr(scale), _lib.ptr(zp), 1, self.qmin, self.qmax, S,
+                                                    _lib.current_stream()))
         self.last_scale, self.last_zero_point = scale, zp
         y._grid = scale              # y[s] holds integers times scale[s]: what conv2d_q8 (the int8 matrix pipe) needs to know about its input
+        y._q8 = q8                   # ... and the integers themselves, [S, n] int8 in y's own element order
         return y
 
 
@@ -107,6 +116,8 @@ def keep_grid(dst, src, gain=None):
     g = getattr(src, "_grid", None)
     if g is not None:
         dst._grid = g if gain is None else g * float(gain)
+        if dst.shape == src.shape and gain is not None:      # an elementwise gain: the same integers in the same order
+            dst._q8 = getattr(src, "_q8", None)
     return dst
 
 
@@ -121,7 +132,7 @@ def weights_to_i8(W, s_w, z_w):
     return wq
 
 
-def conv2d_q8(x, s_x, W, s_w, z_w, cin, cout, k, stride, pad, relu, bias=None, div=None, bn=None):
+def conv2d_q8(x, s_x, W, s_w, z_w, cin, cout, k, stride, pad, relu, bias=None, div=None, bn=None, x_q8=None):
     """conv of two fake-quantised tensors as an exact integer sum (qbnn_grid_to_i8_mc x 2 + qbnn_conv2d_q8_f32_mc): x fp32 [S,B,H,W,Cin] on the grid
     s_x[S], W fp32 [S, Cout*k*k*Cin] (OHWI) on the grid (s_w[S], z_w[S]).  Returns (y fp32 [S,B,Ho,Wo,Cout], (min/max partials, workgroups))."""
     S, B, H, Wd = x.shape[0], x.shape[1], x.shape[2], x.shape[3]
@@ -129,9 +140,11 @@ def conv2d_q8(x, s_x, W, s_w, z_w, cin, cout, k, stride, pad, relu, bias=None, d
     st = _lib.current_stream()
     x = x.contiguous()
     n_x, n_w = x[0].numel(), W.shape[1]
-    xq = torch.empty((S, n_x), dtype=torch.int8, device=x.device)
-    with timed("grid_to_i8"):
-        _lib.check(L.qbnn_grid_to_i8_mc(_lib.ptr(x), n_x, n_x, _lib.ptr(s_x), None, _lib.ptr(xq), S, st))
+    xq = x_q8                              # left by the producing FakeQuantize (same element order as x)
+    if xq is None:
+        xq = torch.empty((S, n_x), dtype=torch.int8, device=x.device)
+        with timed("grid_to_i8"):
+            _lib.check(L.qbnn_grid_to_i8_mc(_lib.ptr(x), n_x, n_x, _lib.ptr(s_x), None, _lib.ptr(xq), S, st))
     for t in (s_x, s_w, z_w):            # (the weight side's qparams may come from a side stream's pipeline: keep them alive for this stream's kernel)
         t.record_stream(torch.cuda.current_stream())
     wq = getattr(W, "_q8", None)          # left by the weight pipeline (weights_to_i8: on its side stream when the weights were presampled)
@@ -301,12 +314,12 @@ class Conv2d(_QATBBB):
             if self.bn is None:
                 b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
                 z, mm = conv2d_q8(x, gs, W, wg.last_scale, wg.last_zero_point, self.in_channels, self.out_channels, self.k, self.stride, self.padding,
-                                  self.relu, bias=b)
+                                  self.relu, bias=b, x_q8=getattr(x, "_q8", None))
             else:
                 if self._cb is None or self._cb[0].device != dev:
                     self._cb = (self.scale_factor().to(dev).contiguous(), None if self.bias is None else self.bias.detach().to(dev).contiguous())
                 z, mm = conv2d_q8(x, gs, W, wg.last_scale, wg.last_zero_point, self.in_channels, self.out_channels, self.k, self.stride, self.padding,
-                                  self.relu, bias=self._cb[1], div=self._cb[0], bn=self.bn.coefficients(dev))
+                                  self.relu, bias=self._cb[1], div=self._cb[0], bn=self.bn.coefficients(dev), x_q8=getattr(x, "_q8", None))
             return self.activation_post_process(z, partials=mm)
         if self.bn is None:
             b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
@@ -352,7 +365,7 @@ class Linear(_QATBBB):
         gs, wg = getattr(x, "_grid", None), self.weight_grid()
         if a in (0, 1) and qat_i8_enabled() and gs is not None and x.shape[0] == S and wg.last_scale is not None and wg.qmin >= -128 and wg.qmax <= 127:
             y5, mm = conv2d_q8(x.reshape(S, B, 1, 1, self.in_features), gs, W, wg.last_scale, wg.last_zero_point, self.in_features, self.out_features,
-                               1, 1, 0, bool(a), bias=b)
+                               1, 1, 0, bool(a), bias=b, x_q8=getattr(x, "_q8", None))
             return self.activation_post_process(y5.reshape(S, B, self.out_features), partials=mm)
         if a in (0, 1):      # the 1x1 case of the conv kernel: its workgroups leave the output's (min, max) for the observer
             y5, mm = conv2d_f32(x.reshape(x.shape[0], B, 1, 1, self.in_features), W, b, self.in_features, self.out_features, 1, 1, 0, bool(a),
@@ -505,8 +518,7 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         out = self.stem[3](self.stem[0](x))
         sc = self.shortcut[0](x) if len(self.shortcut) else x
-        q = self.add(affine_f32(out, res=sc))
-        return keep_grid(affine_f32(q, relu=True), q)            # ReLU of grid values: still on the grid
+        return self.add(affine_f32(out, res=sc), relu=True)      # Add -> FakeQuantize -> ReLU (`end`): the ReLU in the fake-quantiser's pass
 
 
 class ConvNetwork_ResNet(nn.Module):

@@ -253,8 +253,7 @@ class _Block(nn.Module):
             sc = self.s(x)
             if self.ds is not None:
                 sc = self.ds(sc)
-        q = self.add(affine_f32(out, res=sc))
-        return keep_grid(affine_f32(q, relu=True), q)
+        return self.add(affine_f32(out, res=sc), relu=True)
 
 
 class ConvNetwork_ResNet(_Net):
