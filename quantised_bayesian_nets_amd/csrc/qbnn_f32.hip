@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void minmax_f32_kernel(const float* __restrict
 // min += c (cur_min - min), max += c (cur_max - max).  qparams: lo = min(min, 0), hi = max(max, 0),
 // scale = max((hi - lo) / float(qmax - qmin), eps_f32), zp = clamp(qmin - round(lo / scale), qmin, qmax).
 // state[0..1] = (min, max), state[2] = 0 until the observer has seen data (all fp32, read and written back).
-__global__ __launch_bounds__(256) void observer_scan_kernel(const float* __restrict__ partials, int nblk, int n_samples, float* __restrict__ state,
+__global__ __launch_bounds__(1024) void observer_scan_kernel(const float* __restrict__ partials, int nblk, int n_samples, float* __restrict__ state,
                                                              float avg_const, int qmin, int qmax, float* __restrict__ scale, int* __restrict__ zp) {
   // Round 4: every sample's (min, max) over its partials first, all samples in flight at once (wave w takes samples w, w + 4, ...; min / max are
   // exact in any order), then the S-step recurrence on one thread -- instead of S serial rounds of load -> reduce -> two barriers (10.8 us per
@@ -602,10 +602,11 @@ __global__ __launch_bounds__(256) void observer_scan_kernel(const float* __restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int s0 = 0; s0 < n_samples; s0 += 256) {             // (more than 256 samples: in rounds)
     const int ns = n_samples - s0 < 256 ? n_samples - s0 : 256;
-    for (int s = wave; s < ns; s += 4) {
+    const int nw = blockDim.x >> 6;                          // (round 5: 16 waves -- a conv of 4,096 workgroups per sample leaves 40,960 pairs to reduce)
+    for (int s = wave; s < ns; s += nw) {
       float mn = INFINITY, mx = -INFINITY;
-      const float* ps = partials + (int64_t)(s0 + s) * nblk * 2;
-      for (int i = lane; i < nblk; i += 64) { mn = fminf(mn, ps[2 * i]); mx = fmaxf(mx, ps[2 * i + 1]); }
+      const float2* ps = reinterpret_cast<const float2*>(partials + (int64_t)(s0 + s) * nblk * 2);
+      for (int i = lane; i < nblk; i += 64) { const float2 v = ps[i]; mn = fminf(mn, v.x); mx = fmaxf(mx, v.y); }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
       if (lane == 0) { smin[s] = mn; smax[s] = mx; }
@@ -637,7 +638,7 @@ QBNN_EXPORT int qbnn_observe_partials_f32_mc(const float* partials, int32_t n_bl
                                              int32_t qmin, int32_t qmax, float* scale, int32_t* zero_point, void* stream) {
   if (!partials || !state || !scale || !zero_point || n_blocks <= 0 || n_samples <= 0 || qmax <= qmin)
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_observe_partials_f32_mc: bad argument");
-  hipLaunchKernelGGL(observer_scan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_blocks, n_samples, state, avg_const, qmin,
+  hipLaunchKernelGGL(observer_scan_kernel, dim3(1), dim3(n_blocks > 64 ? 1024 : 256), 0, (hipStream_t)stream, partials, n_blocks, n_samples, state, avg_const, qmin,
                      qmax, scale, zero_point);
   return qbnn_check_launch_msg("qbnn_observe_partials_f32_mc");
 }
@@ -648,7 +649,7 @@ QBNN_EXPORT int qbnn_observe_f32_mc(const float* x, int64_t x_ss, int64_t n, int
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_observe_f32_mc: bad argument");
   const int nblk = (int)((n + 255) / 256 < QBNN_OBSERVER_BLOCKS ? (n + 255) / 256 : QBNN_OBSERVER_BLOCKS);
   hipLaunchKernelGGL(minmax_f32_kernel, dim3(nblk, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, n, workspace);
-  hipLaunchKernelGGL(observer_scan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, nblk, n_samples, state, avg_const, qmin,
+  hipLaunchKernelGGL(observer_scan_kernel, dim3(1), dim3(nblk > 64 ? 1024 : 256), 0, (hipStream_t)stream, workspace, nblk, n_samples, state, avg_const, qmin,
                      qmax, scale, zero_point);
   return qbnn_check_launch_msg("qbnn_observe_f32_mc");
 }
