@@ -473,7 +473,7 @@ int qbnn_fake_quant_ex_f32_mc(const float* x, int64_t x_sample_stride, float* y,
                               const int32_t* zero_point, int32_t qmin, int32_t qmax, int32_t relu, int8_t* q8_out, int32_t n_samples, void* stream);
 int qbnn_grid_to_i8_mc(const float* x, int64_t x_sample_stride, int64_t n, const float* scale, const int32_t* zero_point, int8_t* out,
                        int32_t n_samples, void* stream);
-int32_t qbnn_conv2d_q8_blocks(int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad);
+int32_t qbnn_conv2d_q8_blocks(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad);
 int qbnn_conv2d_q8_f32_mc(const int8_t* x, int64_t x_sample_stride, const int8_t* w, int64_t w_sample_stride, const float* s_x, const float* s_w,
                           const int32_t* z_w, const float* div, const float* bias, const float* alpha, const float* beta, float* y,
                           int64_t y_sample_stride, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,

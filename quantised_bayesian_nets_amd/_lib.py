@@ -178,7 +178,7 @@ def lib():
         L.qbnn_observe_partials_f32_mc.argtypes = [vp, i32, i32, vp, f, i32, i32, vp, vp, vp]
         L.qbnn_grid_to_i8_mc.argtypes = [vp, i64, i64, vp, vp, vp, i32, vp]
         L.qbnn_fake_quant_ex_f32_mc.argtypes = [vp, i64, vp, i64, i64, vp, vp, i32, i32, i32, vp, i32, vp]
-        L.qbnn_conv2d_q8_blocks.argtypes = [i32, i32, i32, i32, i32, i32, i32]
+        L.qbnn_conv2d_q8_blocks.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32]
         L.qbnn_conv2d_q8_blocks.restype = i32
         L.qbnn_conv2d_q8_f32_mc.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64] + [i32] * 10 + [vp, vp]
         L.qbnn_conv2d_f32_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]

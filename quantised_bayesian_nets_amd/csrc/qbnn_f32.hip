@@ -899,53 +899,62 @@ __global__ __launch_bounds__(256) void conv2d_q8_kernel(const ConvQ8Args a) {
 // The Cin % 4 == 0 form (every conv but layers.0): 64-byte K chunks -- each thread moves 16 bytes per operand and chunk, two MFMAs per wave and barrier
 // pair -- and, as in conv2d_f32_vec_kernel<.., VEC = 2>, a row keeps the offset of its window's tap (0, 0) and one validity bit per tap
 // (KS KS <= 32), so a 4-byte unit costs one offset add and a bit test instead of two bounds compares and a 64-bit address product.
+// Workgroup tile = PT pixels x NT channels (PT NT = 4096; 4 waves of 32 x 32): 64 x 64, or 128 x 32 where Cout <= 32 would leave half of the waves
+// multiplying padding (the 24-channel layers: five of the twenty convs and the largest by pixels).
+template <int PT, int NT>
 __global__ __launch_bounds__(256) void conv2d_q8v_kernel(const ConvQ8Args a) {
+  static_assert(PT * NT == 4096 && PT % 64 == 0 && NT % 32 == 0, "4 waves of 32 x 32");
   constexpr int LD = 80;                                              // 64 + 16: conflict-free ds_read_b128 fragments (tools/lds_conflicts.py)
-  __shared__ __attribute__((aligned(16))) uint8_t As[64 * LD];
-  __shared__ __attribute__((aligned(16))) uint8_t Bs[64 * LD];
+  constexpr int WN = NT / 32, XP = PT / 64;
+  __shared__ __attribute__((aligned(16))) uint8_t As[NT * LD];
+  __shared__ __attribute__((aligned(16))) uint8_t Bs[PT * LD];
   __shared__ float red[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int s = blockIdx.z;
-  const int p0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int p0 = blockIdx.x * PT, n0 = blockIdx.y * NT;
   const int npix = a.B * a.Ho * a.Wo;
   const int K = a.KS * a.KS * a.Cin;
   const int8_t* xs = a.x + (int64_t)s * a.x_ss;
   const int8_t* ws = a.w + (int64_t)s * a.w_ss;
   const int row = tid >> 2, kb = (tid & 3) * 16;
-  const int p = p0 + row, n = n0 + row;
-  int roff = 0;
-  uint32_t rmask = 0;
-  if (p < npix) {
-    const int pb = p / (a.Ho * a.Wo), rem = p - pb * a.Ho * a.Wo;
-    const int ih0 = (rem / a.Wo) * a.stride - a.pad, iw0 = (rem % a.Wo) * a.stride - a.pad;
-    roff = ((pb * a.H + ih0) * a.W + iw0) * a.Cin;                     // (a sample's input is below 2^31 bytes)
-    for (int kh = 0; kh < a.KS; ++kh)
-      for (int kw = 0; kw < a.KS; ++kw)
-        if ((unsigned)(ih0 + kh) < (unsigned)a.H && (unsigned)(iw0 + kw) < (unsigned)a.W) rmask |= 1u << (kh * a.KS + kw);
+  int roff[XP];
+  uint32_t rmask[XP];
+#pragma unroll
+  for (int j = 0; j < XP; ++j) {
+    const int p = p0 + row + 64 * j;
+    roff[j] = 0; rmask[j] = 0;
+    if (p < npix) {
+      const int pb = p / (a.Ho * a.Wo), rem = p - pb * a.Ho * a.Wo;
+      const int ih0 = (rem / a.Wo) * a.stride - a.pad, iw0 = (rem % a.Wo) * a.stride - a.pad;
+      roff[j] = ((pb * a.H + ih0) * a.W + iw0) * a.Cin;                 // (a sample's input is below 2^31 bytes)
+      uint32_t m = 0;
+      for (int kh = 0; kh < a.KS; ++kh)
+        for (int kw = 0; kw < a.KS; ++kw)
+          if ((unsigned)(ih0 + kh) < (unsigned)a.H && (unsigned)(iw0 + kw) < (unsigned)a.W) m |= 1u << (kh * a.KS + kw);
+      rmask[j] = m;
+    }
   }
-  const bool wok = n < a.Cout;
-  const int8_t* wrow = ws + (int64_t)(wok ? n : 0) * K;
+  const int n = n0 + row;
+  const bool wrow = row < NT, wok = wrow && n < a.Cout;
+  const int8_t* wr = ws + (int64_t)(wok ? n : 0) * K;
   // this thread's first unit of the chunk: k = k0 + kb in tap (gkh, gkw) at channel gc; advanced by 64 per chunk without divisions
   int gkh, gkw, gc;
   { const int tap = kb / a.Cin; gc = kb - tap * a.Cin; gkh = tap / a.KS; gkw = tap - gkh * a.KS; }
-  auto gather = [&](int k0, v4i_q8& xv, v4i_q8& wv) {
+  auto gather = [&](int k0, v4i_q8 (&xv)[XP], v4i_q8& wv) {
     int kh = gkh, kw = gkw, c = gc;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int kk = k0 + kb + 4 * u;
-      int xb = 0, wb = 0;
-      if (kk < K) {
-        const int tap = kh * a.KS + kw;
-        if ((rmask >> tap) & 1u) xb = *reinterpret_cast<const int*>(xs + roff + (kh * a.W + kw) * a.Cin + c);
-        if (wok) wb = *reinterpret_cast<const int*>(wrow + kk);
-      }
-      xv[u] = xb; wv[u] = wb;
+      const bool kok = kk < K;
+      const int tap = kh * a.KS + kw, toff = (kh * a.W + kw) * a.Cin + c;
+#pragma unroll
+      for (int j = 0; j < XP; ++j) xv[j][u] = (kok && ((rmask[j] >> tap) & 1u)) ? *reinterpret_cast<const int*>(xs + roff[j] + toff) : 0;
+      wv[u] = (kok && wok) ? *reinterpret_cast<const int*>(wr + kk) : 0;
       c += 4;
       if (c >= a.Cin) { c -= a.Cin; if (++kw == a.KS) { kw = 0; ++kh; } }
     }
-    // the next chunk's first unit: + 64 channels' worth
-    int cc = gc + 64;
+    int cc = gc + 64;                                                 // the next chunk's first unit
     while (cc >= a.Cin) { cc -= a.Cin; if (++gkw == a.KS) { gkw = 0; ++gkh; } }
     gc = cc;
   };
@@ -953,11 +962,12 @@ __global__ __launch_bounds__(256) void conv2d_q8v_kernel(const ConvQ8Args a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0;
   int rsum = 0;
-  v4i_q8 xv, wv;
+  v4i_q8 xv[XP], wv;
   gather(0, xv, wv);
   for (int k0 = 0; k0 < K; k0 += 64) {
-    *reinterpret_cast<v4i_q8*>(&Bs[row * LD + kb]) = xv;
-    *reinterpret_cast<v4i_q8*>(&As[row * LD + kb]) = wv;
+#pragma unroll
+    for (int j = 0; j < XP; ++j) *reinterpret_cast<v4i_q8*>(&Bs[(row + 64 * j) * LD + kb]) = xv[j];
+    if (wrow) *reinterpret_cast<v4i_q8*>(&As[row * LD + kb]) = wv;
     __syncthreads();
     if (k0 + 64 < K) gather(k0 + 64, xv, wv);
 #pragma unroll
@@ -1013,10 +1023,12 @@ __global__ __launch_bounds__(256) void conv2d_q8v_kernel(const ConvQ8Args a) {
 }
 
 // workgroups per sample of qbnn_conv2d_q8_f32_mc = length of one sample's row of `minmax_partials`
-QBNN_EXPORT int32_t qbnn_conv2d_q8_blocks(int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad) {
+static bool conv_q8_narrow(int Cin, int Cout, int ksize) { return Cout <= 32 && (Cin % 4) == 0 && ksize * ksize <= 32; }
+QBNN_EXPORT int32_t qbnn_conv2d_q8_blocks(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad) {
   const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
   if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return 0;
-  return (int32_t)((((int64_t)B * Ho * Wo + 63) / 64) * ((Cout + 63) / 64));
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  return conv_q8_narrow(Cin, Cout, ksize) ? (int32_t)(((npix + 127) / 128) * ((Cout + 31) / 32)) : (int32_t)(((npix + 63) / 64) * ((Cout + 63) / 64));
 }
 
 QBNN_EXPORT int qbnn_conv2d_q8_f32_mc(const int8_t* x, int64_t x_ss, const int8_t* w, int64_t w_ss, const float* s_x, const float* s_w,
@@ -1034,11 +1046,16 @@ QBNN_EXPORT int qbnn_conv2d_q8_f32_mc(const int8_t* x, int64_t x_ss, const int8_
   if (a.Ho <= 0 || a.Wo <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: empty output");
   if ((int64_t)ksize * ksize * Cin * 127 * 128 >= (1ll << 31)) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: K too large for int32 sums");
   const int64_t npix = (int64_t)B * a.Ho * a.Wo;
-  const dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)n_samples);
+  const bool narrow = conv_q8_narrow(Cin, Cout, ksize);      // (every form launches the grid qbnn_conv2d_q8_blocks promises the observer)
+  const dim3 grid(narrow ? (unsigned)((npix + 127) / 128) : (unsigned)((npix + 63) / 64), narrow ? (unsigned)((Cout + 31) / 32) : (unsigned)((Cout + 63) / 64), (unsigned)n_samples);
   const bool u4 = (Cin % 4) == 0 && (x_ss % 4) == 0 && (w_ss % 4) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 3) == 0;
   static const bool wide = [] { const char* e = getenv("QBNN_Q8_WIDE"); return !(e && e[0] == '0'); }();
   const bool y16 = (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_ss % 4) == 0;
-  if (u4 && wide && ksize * ksize <= 32 && y16 && (int64_t)B * H * W * Cin < (1ll << 31)) hipLaunchKernelGGL(conv2d_q8v_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  const bool v_ok = u4 && ksize * ksize <= 32 && y16 && (int64_t)B * H * W * Cin < (1ll << 31);
+  if (narrow) {
+    if (!v_ok) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: the 128 x 32 form (Cout <= 32, Cin % 4 == 0) takes 4-byte aligned operands and 16-byte aligned outputs");
+    hipLaunchKernelGGL((conv2d_q8v_kernel<128, 32>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else if (v_ok && wide) hipLaunchKernelGGL((conv2d_q8v_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else if (u4) hipLaunchKernelGGL(conv2d_q8_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(conv2d_q8_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
   return qbnn_check_launch_msg("qbnn_conv2d_q8_f32_mc");

@@ -152,7 +152,7 @@ def conv2d_q8(x, s_x, W, s_w, z_w, cin, cout, k, stride, pad, relu, bias=None, d
         wq = weights_to_i8(W, s_w, z_w)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
     y = torch.empty((S, B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
-    nblk = int(L.qbnn_conv2d_q8_blocks(B, H, Wd, cout, k, stride, pad))
+    nblk = int(L.qbnn_conv2d_q8_blocks(B, H, Wd, cin, cout, k, stride, pad))
     partials = torch.empty(S * nblk * 2, dtype=torch.float32, device=x.device)
     alpha, beta = bn if bn is not None else (None, None)
     with timed("conv2d_q8"):
