@@ -2504,3 +2504,61 @@ def test_sampler_n24_layout_draws_the_same_weights(golden_w8):
             assert np.array_equal(dense[0, 24], ones) and not dense[:, 25:].any()
         assert np.array_equal(draws[ql.LAYOUT_MFMA32], draws[ql.LAYOUT_MFMA32_TAIL])
         l24.set_layout(ql.LAYOUT_MFMA32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(3, 24, 3, 1, 1, 32), (24, 24, 3, 1, 1, 16), (24, 48, 3, 2, 1, 16), (48, 96, 1, 2, 0, 8), (96, 192, 3, 1, 1, 4), (20, 50, 5, 1, 2, 14)])
+def test_qat_int8_conv_entry_points_against_numpy(case):
+    """qbnn_grid_to_i8_mc + qbnn_conv2d_q8_f32_mc through the C ABI (round 5: the QAT convs on the int8 matrix pipe) against the same sum in numpy:
+    fake-quantised operands with PER-SAMPLE scales / zero points (activations on 7-bit grids, weights on int8 grids with non-zero zero points),
+    every tile form (128 x 32 for Cout <= 32, 64 x 64, the byte-gather form for Cin = 3), stride 2, 1 x 1 and 5 x 5 kernels, ragged pixel counts, and the
+    fused tail Z / c + b, bn, ReLU with the per-workgroup (min, max) partials.  y = fl32(fl64(N) * fl64(s_x) * fl64(s_w)) with N the exact integer sum:
+    compared at 1e-6 relative (one fp32 rounding of the tail's four steps)."""
+    import ctypes as C
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    cin, cout, k, stride, pad, H = case
+    rng = np.random.default_rng(cin * 1000 + cout)
+    S, B = 3, 3
+    st = _lib.current_stream()
+    s_x = (10 ** rng.uniform(-2, -1, S)).astype(np.float32)
+    z_x = rng.integers(0, 128, S)
+    s_w = (10 ** rng.uniform(-3, -2, S)).astype(np.float32)
+    z_w = rng.integers(-40, 41, S).astype(np.int32)
+    q_x = rng.integers(0, 128, (S, B, H, H, cin))
+    q_w = rng.integers(-128, 128, (S, cout, k, k, cin))
+    xf = ((q_x - z_x[:, None, None, None, None]).astype(np.float32) * s_x[:, None, None, None, None]).astype(np.float32)      # what a FakeQuantize leaves
+    wf = ((q_w - z_w[:, None, None, None, None]).astype(np.float32) * s_w[:, None, None, None, None]).astype(np.float32)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    xd, wd, sxd, swd, zwd = dev(xf), dev(wf.reshape(S, -1)), dev(s_x), dev(s_w), dev(z_w)
+    n_x, n_w = xf[0].size, wf[0].size
+    xq = torch.empty((S, n_x), dtype=torch.int8, device="cuda")
+    wq = torch.empty((S, n_w), dtype=torch.int8, device="cuda")
+    _lib.check(L.qbnn_grid_to_i8_mc(_lib.ptr(xd), n_x, n_x, _lib.ptr(sxd), None, _lib.ptr(xq), S, st))
+    _lib.check(L.qbnn_grid_to_i8_mc(_lib.ptr(wd), n_w, n_w, _lib.ptr(swd), _lib.ptr(zwd), _lib.ptr(wq), S, st))
+    assert np.array_equal(xq.cpu().numpy().reshape(q_x.shape), q_x - z_x[:, None, None, None, None])      # the centred activation integers
+    assert np.array_equal(wq.cpu().numpy().reshape(q_w.shape), q_w)                                        # the raw weight integers
+    div = dev((rng.uniform(0.5, 2.0, cout)).astype(np.float32))
+    bias = dev((rng.normal(size=cout) * 0.1).astype(np.float32))
+    alpha = dev((rng.uniform(0.5, 1.5, cout)).astype(np.float32))
+    beta = dev((rng.normal(size=cout) * 0.1).astype(np.float32))
+    Ho = (H + 2 * pad - k) // stride + 1
+    y = torch.full((S, B, Ho, Ho, cout), float("nan"), dtype=torch.float32, device="cuda")
+    nblk = int(L.qbnn_conv2d_q8_blocks(B, H, H, cin, cout, k, stride, pad))
+    mm = torch.full((S * nblk * 2,), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.check(L.qbnn_conv2d_q8_f32_mc(_lib.ptr(xq), n_x, _lib.ptr(wq), n_w, _lib.ptr(sxd), _lib.ptr(swd), _lib.ptr(zwd), _lib.ptr(div), _lib.ptr(bias),
+                                       _lib.ptr(alpha), _lib.ptr(beta), _lib.ptr(y), y[0].numel(), B, H, H, cin, cout, k, stride, pad, 1, S, _lib.ptr(mm), st))
+    torch.cuda.synchronize()
+    got = y.cpu().numpy()
+    for s in range(S):
+        m_x = torch.from_numpy((q_x[s] - z_x[s]).astype(np.float64)).permute(0, 3, 1, 2)
+        m_w = torch.from_numpy((q_w[s] - int(z_w[s])).astype(np.float64)).permute(0, 3, 1, 2)
+        N = torch.nn.functional.conv2d(m_x, m_w, stride=stride, padding=pad).permute(0, 2, 3, 1).numpy()      # exact in fp64: |N| < 2^53
+        v = (N * (float(s_x[s]) * float(s_w[s]))).astype(np.float32)
+        v = (v / div.cpu().numpy()).astype(np.float32)
+        v = (v + bias.cpu().numpy()).astype(np.float32)
+        v = (v * alpha.cpu().numpy()).astype(np.float32)
+        v = np.maximum((v + beta.cpu().numpy()).astype(np.float32), 0)
+        np.testing.assert_allclose(got[s], v, rtol=1e-6, atol=1e-7)
+        part = mm.cpu().numpy().reshape(S, nblk, 2)[s]
+        assert np.isclose(part[:, 0].min(), got[s].min()) and np.isclose(part[:, 1].max(), got[s].max())
