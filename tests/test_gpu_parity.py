@@ -903,6 +903,39 @@ def test_high_sample_indices_against_oracle(w_bits):
     assert torch.equal(tail[127], p1023[0])
 
 
+@pytest.mark.parametrize("a_bits,w_bits", [(3, 8), (7, 3), (5, 8), (7, 6)], ids=["a3w8", "a7w3", "a5w8", "a7w6"])
+def test_bit_width_sweep_full_batch_against_oracle(a_bits, w_bits):
+    """The reference's sweep (experiments/run_all_quant.sh:11-37) away from the two BASELINE points, at the full batch: A3 and A5
+    move every activation clamp (src/utils.py:25-30: [0, 7] / [0, 31]) and the accumulator bound of the 1.5 * 2^23 start, W3 / W6 the
+    sampled-weight clamp ([-4, 3] / [-32, 31], src/utils.py:32-37).  Fused path and per-block launches, B = 256, two samples, against
+    the CPU oracle: integer block outputs bit-exact, probabilities 1e-5."""
+    import quantised_bayesian_nets_amd as q
+    from conftest import load_golden
+    from oracle import oracle as orc
+    g = load_golden("resnet_bbb_a%dw%d.npz" % (a_bits, w_bits))
+    m = _model(g)
+    x = torch.randn(256, 3, 32, 32, generator=torch.Generator().manual_seed(11 + a_bits + w_bits))
+    xc = x.cuda()
+    S, seed, begin = 2, 3, 40
+    with q.mc_context(S, seed, begin):
+        probs = m.forward_mc(xc)
+        rec = {}
+        m.forward_mc(xc, record=rec)
+    net = orc.Int8ResNetOracle(g["state"], a_bits, w_bits)
+    a_hi, (w_lo, w_hi) = orc.UINT_BOUNDS[a_bits][1], orc.INT_BOUNDS[w_bits]
+    for s in range(S):
+        orec = {}
+        p_or = net.forward(x.numpy(), seed, begin + s, record=orec)
+        for k in ("layers.0.out", "layers.3.1.out", "layers.4.0.out", "layers.4.1.out", "layers.5.0.out", "layers.5.1.out", "layers.6.0.out",
+                  "layers.6.1.out"):
+            got = rec[k][s].cpu().numpy()
+            assert np.array_equal(got, orec[k]), (k, s)
+            assert got.max() <= a_hi
+        np.testing.assert_allclose(probs[s].cpu().numpy(), p_or, rtol=RTOL, atol=1e-8)
+        w = orec["layers.5.1.stem.0.w_q"]
+        assert w.min() >= w_lo and w.max() <= w_hi and (w_bits == 8 or (w.min() == w_lo and w.max() == w_hi))
+
+
 def test_ensemble_16_members_full_batch_against_oracle(golden_ensemble):
     """BASELINE config 4 size: 16 members at B = 256.  Every member's probabilities against the deterministic-member oracle
     (integer logits path bit-exact -> 1e-5 on probabilities), through forward_mc (all members of the mc_context) -- first
@@ -1795,7 +1828,7 @@ def test_fused_blocks_random_qparams_against_oracle(seed, extreme):
         for down in (False, True):
             if down and Cc == 192:
                 continue
-            a_hi = int(rng.choice([127, 127, 63, 31]))
+            a_hi = int(rng.choice([127, 127, 63, 31, 15, 7]))          # src/utils.py:18: UINT_BOUNDS of A7 ... A3
             ext = extreme and Cc == 24
             if extreme and not ext:
                 continue
@@ -1805,7 +1838,7 @@ def test_fused_blocks_random_qparams_against_oracle(seed, extreme):
             Ho = Hi // 2 if down else Hi
             use_bias = bool(rng.integers(0, 2))
             s_x = float(np.float32(10 ** rng.uniform(-2, -1)))
-            z_x = int(rng.integers(0, a_hi + 1)) if use_bias else int(a_hi // 2 + rng.integers(-4, 5))
+            z_x = int(rng.integers(0, a_hi + 1)) if use_bias else int(np.clip(a_hi // 2 + rng.integers(-4, 5), 0, a_hi))
             x = rng.integers(0, a_hi + 1, (S, B, Hi, Hi, Ci), dtype=np.uint8)
             wa = rng.integers(-128, 128, (S, Co, 3, 3, Ci), dtype=np.int8)
             wb = rng.integers(-128, 128, (S, Co, 3, 3, Co), dtype=np.int8)
@@ -1909,7 +1942,7 @@ def test_sampler_random_qparams_against_oracle(seed):
     from oracle import oracle as orc
     rng = np.random.default_rng(500 + seed)
     for (cin, cout, k) in ((48, 48, 3), (96, 192, 3), (3, 24, 3), (24, 48, 1)):
-        w_bits = int(rng.choice([8, 4]))
+        w_bits = int(rng.choice([8, 4, 3, 5, 6, 7]))                   # the reference's sweep: experiments/run_all_quant.sh:11-24
         args = types.SimpleNamespace(activation_precision=7, weight_precision=w_bits)
         layer = QConv(cin, cout, (k, k), stride=1, padding=k // 2, bias=False, args=args)
         layer.layer_id = int(rng.integers(0, 21))
@@ -1932,7 +1965,7 @@ def test_sampler_random_qparams_against_oracle(seed):
             ref = orc.sample_weights_i8_philox(mu_l, sg_l, p, sd, layer.layer_id, sb + s)
             seen.update(np.unique(ref).tolist())
             assert np.array_equal(w[s], _pack(layer, ref)), (cin, cout, k, w_bits, s)
-        assert len(seen) > (8 if w_bits == 4 else 40), "degenerate case: the sampled weights barely vary"
+        assert len(seen) > min(40, 2 ** w_bits // 2), "degenerate case: the sampled weights barely vary"
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
