@@ -27,15 +27,54 @@ from oracle import oracle as orc  # noqa: E402
 from oracle.fbgemm_baseline import FbgemmResNetBBB  # noqa: E402
 
 
+def weight_chain(a):
+    """conv_q.py:113-118 / linear_q.py:86-91 on the 21 stochastic layers' own (mu_q, sigma_q): ATen's quantized::mul and quantized::add
+    (tensors of 648 ... 331,776 elements: every one has a scalar tail on AVX-512 / AVX2, per thread chunk) against the oracle's
+    vector-body formulas on the same injected eps.  `t` isolates the mul, `w` given an equal `t` the add."""
+    from oracle.fbgemm_baseline import NOISE_SCALE, NOISE_ZERO_POINT
+    g = load_golden(f"resnet_bbb_a7w{a.w_bits}.npz")
+    st = g["state"]
+    net = orc.Int8ResNetOracle(st, 7, 8)            # W8: the clamp is the identity, so the add's own output is compared
+    fb = FbgemmResNetBBB(st, 7, 8)
+    seed = 3
+    n_t = n_w = n_el = 0
+    per_layer = {}
+    for s in range(a.samples):
+        for i, (pfx, *_) in enumerate(net.table):
+            L, F = net.layers[pfx], fb.layers[pfx]
+            eps_ohwi = orc.fill_eps_i8(L.mu_q.size, seed, i, s).reshape(L.mu_q.shape)
+            t_or, w_or = orc.sample_weights_i8(L.mu_q, L.sigma_q, eps_ohwi, L.sp, want_t=True)
+            e = eps_ohwi.transpose(0, 3, 1, 2) if eps_ohwi.ndim == 4 else eps_ohwi
+            e = torch.from_numpy(np.array(e, order="C", copy=True).reshape(-1)).view(tuple(F.std.shape))
+            eps_q = torch.quantize_per_tensor(e, NOISE_SCALE, NOISE_ZERO_POINT, torch.qint8)
+            t_at = torch.ops.quantized.mul(F.std, eps_q, F.s_m, F.z_m)
+            w_at = torch.ops.quantized.add(F.weight, t_at, F.s_a, F.z_a)
+            to_ohwi = (lambda v: v.transpose(0, 2, 3, 1)) if eps_ohwi.ndim == 4 else (lambda v: v)
+            dt = int((to_ohwi(t_at.int_repr().numpy()) != t_or).sum())
+            dw = int((to_ohwi(w_at.int_repr().numpy()) != w_or).sum())
+            n_t += dt
+            n_w += dw
+            n_el += t_or.size
+            if dt or dw:
+                per_layer[pfx] = tuple(np.add(per_layer.get(pfx, (0, 0)), (dt, dw)))
+    print(f"threads={torch.get_num_threads()} cpu_capability={torch.backends.cpu.get_cpu_capability()} S={a.samples} layers=21 (648 ... 331,776 elements)")
+    print(f"weight chain: quantized::mul differs in {n_t}, quantized::add in {n_w} of {n_el} elements")
+    for k, v in per_layer.items():
+        print("  ", k, "mul", v[0], "add", v[1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--w-bits", type=int, default=8)
+    ap.add_argument("--weights", action="store_true", help="the WEIGHT chain's quantized::mul / quantized::add (conv_q.py:118) instead of the activations' Add")
     a = ap.parse_args()
     if a.threads:
         torch.set_num_threads(a.threads)
+    if a.weights:
+        return weight_chain(a)
     g = load_golden(f"resnet_bbb_a7w{a.w_bits}.npz")
     st = g["state"]
     net = orc.Int8ResNetOracle(st, 7, a.w_bits)
