@@ -221,24 +221,63 @@ WORKLOADS = {"resnet_bbb": _wl_resnet(0, 100, "configs[2]"), "resnet_f32": _wl_r
              "mlp_mc": _wl_mlp_mc, "resnet_mc_f32": _wl_resnet_mc_f32}
 
 
+def usable_cpus():
+    """Threads the CPU leg may really run on: the smallest of the scheduler affinity, the cgroup CPU quota (a GPU box gives a one-GPU job a
+    share of its host, not the 256 hardware threads os.cpu_count() reports) and the physical core count (SMT siblings add nothing to an
+    int8 GEMM).  Returns (threads, how)."""
+    how = {}
+    how["affinity"] = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        import psutil
+        how["physical"] = psutil.cpu_count(logical=False) or how["affinity"]
+    except Exception:                        # noqa: BLE001
+        how["physical"] = how["affinity"]
+    quota = None
+    try:
+        q_, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q_ != "max":
+            quota = max(1, int(float(q_) / float(per)))
+    except Exception:                        # noqa: BLE001
+        try:
+            q_, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q_ > 0:
+                quota = max(1, q_ // per)
+        except Exception:                    # noqa: BLE001
+            pass
+    if quota:
+        how["cgroup_quota"] = quota
+    return max(1, min(how.values())), how
+
+
 def cpu_baseline(a, g, x_host, seed):
     """The reference's CPU path timed on this host, on a bounded sample of the same workload (same batch, a few MC samples).
     Primary leg, kind "port", engine "torch-fbgemm" (oracle/fbgemm_baseline.py): the op sequence of the reference's int8 layers through PyTorch's own quantised CPU
     operators (ATen + FBGEMM) -- oracle/fbgemm_baseline.py, which reproduces the golden vectors recorded from the reference.
-    Second leg, kind "port": the plain-C restatement oracle/qbnn_oracle.c (OpenMP), the parity checker."""
+    Second leg, kind "port": the plain-C restatement oracle/qbnn_oracle.c (OpenMP), the parity checker.
+    Round 6: the thread count is PINNED to the cores this process may use (usable_cpus: affinity, cgroup quota, physical cores) -- torch's
+    default of one thread per hardware thread of the host oversubscribed the box's share and the single-sample times swung 0.6 - 5.6 s
+    inside one run --, two warm-up samples, then 9 single-sample timings; value = 1 / median, the minimum beside it."""
     from oracle import oracle as orc
     from oracle.fbgemm_baseline import FbgemmResNetBBB
+    threads, how = usable_cpus()
+    if a.cpu_threads:
+        threads = a.cpu_threads
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
     xn = x_host.numpy()
     fb = FbgemmResNetBBB(g["state"], 7, a.w_bits)
-    fb.forward(xn)                                         # warm-up (thread pool, allocator)
-    n_fb = a.cpu_samples or 5
+    for _ in range(2):                                     # warm-up (thread pool, allocator, fbgemm's packing caches)
+        fb.forward(xn)
+    n_fb = a.cpu_samples or 9
     ts = []
     for _ in range(n_fb):
         t = time.perf_counter()
         fb.forward(xn)
         ts.append(time.perf_counter() - t)
     med = sorted(ts)[len(ts) // 2]
+    torch.set_num_threads(prev_threads)
     net = orc.Int8ResNetOracle(g["state"], 7, a.w_bits)
+    orc.lib().qbo_set_num_threads(threads)
     t = time.perf_counter()
     p_or = net.forward(xn, seed, 0)
     one = time.perf_counter() - t
@@ -247,12 +286,13 @@ def cpu_baseline(a, g, x_host, seed):
     for s in range(1, 1 + n_cpu):
         net.forward(xn, seed, s)
     el = time.perf_counter() - t
-    return {"value": round(1.0 / med, 4), "unit": "MC samples/s", "cores": torch.get_num_threads(), "kind": "port", "engine": "torch-fbgemm",
+    return {"value": round(1.0 / med, 4), "unit": "MC samples/s", "cores": threads, "kind": "port", "engine": "torch-fbgemm",
             "sample": f"median of {n_fb} single MC samples of the same batch ({a.batch} images) through torch's quantised CPU ops "
                       f"(fbgemm engine; per layer normal_ -> quantize_per_tensor -> quantized.mul/add -> clamp -> conv2d_prepack -> "
-                      f"quantized.conv2d(_relu) -> clamp), after 1 warm-up sample",
+                      f"quantized.conv2d(_relu) -> clamp), after 2 warm-up samples, torch.set_num_threads({threads}) = the cores this process may use",
+            "value_best": round(1.0 / min(ts), 4),
             "seconds_per_sample_min_med_max": [round(min(ts), 4), round(med, 4), round(max(ts), 4)],
-            "host_cpus": os.cpu_count(),
+            "host_cpus": os.cpu_count(), "usable_cpus": how,
             "port": {"value": round(n_cpu / el, 4), "unit": "MC samples/s", "cores": orc.lib().qbo_num_threads(), "kind": "port", "engine": "plain C (oracle/qbnn_oracle.c, OpenMP)",
                      "sample": f"{n_cpu} MC samples of the same batch through oracle/qbnn_oracle.c (OpenMP), after 1 warm-up sample"},
             "_p_oracle_sample0": p_or}
@@ -297,6 +337,51 @@ def secondary_workloads(a, q, load_golden, seed):
             torch.cuda.empty_cache()
         except Exception as e:                                       # noqa: BLE001 -- a secondary workload must not take the headline line down
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+SECONDARY_MULTI = (("resnet_bbb_w4", 1024), ("ensemble16", 16))
+
+
+def secondary_multi(a, world, rank, q, load_golden, seed, fence):
+    """N > 1: BASELINE.json's two multi-GPU configs in the SAME driver command as the headline line, after its timed region, on every
+    rank -- configs[4] (A7/W4, 1024 MC samples sharded `shard_samples(1024, r, N)`, one RCCL all-reduce of the moments per step) and
+    configs[3] (16 SGHMC members over the N ranks).  Strong scaling both (fixed global work); value = global units / MAX-over-ranks time,
+    bracketed by barrier + synchronize like the headline."""
+    from quantised_bayesian_nets_amd.mc import shard_samples
+    out = {}
+    for name, units in SECONDARY_MULTI:
+        err = None
+        dt = 0.0
+        n = 10
+        try:
+            b = argparse.Namespace(**vars(a))
+            b.workload, b.samples, b.batch, b.w_bits = name, 0, 256, 8
+            wl = WORKLOADS[name](b, world, q, load_golden)
+            model, x = wl["model"], wl["x_host"].cuda()
+            for _ in range(4):
+                wl["step"](model, x, units, seed)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                wl["step"](model, x, units, seed)
+            fence()
+            dt = time.perf_counter() - t0
+        except Exception as e:                                       # noqa: BLE001 -- reported below; the collectives that follow keep every rank in step
+            err = "%s: %s" % (type(e).__name__, e)
+        t = torch.tensor([dt, 1.0 if err else 0.0], dtype=torch.float64, device="cuda")
+        tall = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(tall, t)
+        if any(float(v[1].item()) for v in tall):
+            out[name] = {"error": err or "failed on another rank"}
+            continue
+        tmax = max(float(v[0].item()) for v in tall)
+        out[name] = {"metric": wl["metric"], "value": round(units * n / tmax, 2), "unit": wl["unit"], "ms_per_step": round(tmax / n * 1e3, 3), "steps": n,
+                     "units_per_step_global": units, "units_this_rank": shard_samples(units, rank, world)[1], "n_gpus": world, "scaling": "strong",
+                     "batch": int(x.shape[0]), "dtype": wl["dtype"], "ms_per_step_by_rank": [round(float(v[0].item()) / n * 1e3, 4) for v in tall],
+                     "shards": [list(shard_samples(units, r, world)) for r in range(world)], "workload": wl["describe"]}
+        del wl, model, x
+        torch.cuda.empty_cache()
     return out
 
 
@@ -374,8 +459,9 @@ def main():
     ap.add_argument("--prime", type=int, default=12, help="setup steps before the W warm-up steps (clock ramp, allocator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=0, help="oracle samples to time (0 = auto, about 10-30 s)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's torch leg (0 = the cores this process may use: affinity, cgroup quota, physical cores)")
     ap.add_argument("--no-graph", action="store_true", help="mlp_f32 (the launch-bound workload: ~25 launches of microseconds): launch eagerly instead of replaying its captured HIP graph")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (BASELINE.json's other configs, N = 1, default workload only)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (default workload only; N = 1: BASELINE.json's other configs on one GPU; N > 1: configs[4] = A7/W4 with 1024 global samples and configs[3] = 16 ensemble members, sharded over the N ranks)")
     ap.add_argument("--no-rccl-probe", action="store_true", help="skip the one-rank RCCL all-reduce latency probe of the N = 1 run")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launcher test (no GPU, gloo): ranks rendezvous, all-reduce their rank, rank 0 prints one JSON line")
@@ -404,7 +490,10 @@ def main():
         if rank == 0:
             # (no RCCL call happens here: the line names the backend it ran on; `rccl_ranks` appears only on lines that used nccl)
             print(json.dumps({"plumbing_check": True, "ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank_sum": float(t.item()),
-                              "moments_sum": float(mom[0, 0, 0].item()), "shards": shards}))
+                              "moments_sum": float(mom[0, 0, 0].item()), "shards": shards,
+                              # what `secondary` will hold on a GPU run at this N (secondary_multi): BASELINE configs[4] and configs[3]
+                              "secondary_multi": [{"workload": nm, "units_global": u, "shards": [list(shard_samples(u, r, world)) for r in range(world)]}
+                                                  for nm, u in SECONDARY_MULTI]}))
         dist.destroy_process_group()
         return
     # rehearsal on a one-GPU box: QBNN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and QBNN_BENCH_BACKEND=gloo replaces RCCL (which
@@ -562,6 +651,9 @@ def main():
     secondary = None
     if rank == 0 and world == 1 and a.workload == "resnet_bbb" and not a.no_secondary:
         secondary = secondary_workloads(a, q, load_golden, seed)
+
+    if use_dist and world > 1 and a.workload == "resnet_bbb" and not a.no_secondary:
+        secondary = secondary_multi(a, world, rank, q, load_golden, seed, fence)
 
     rccl = None
     if use_dist:

@@ -480,3 +480,12 @@ QBO_API int qbo_num_threads(void) {
   return 1;
 #endif
 }
+
+/* bench.py's cpu_baseline pins the team to the cores the process may use (a GPU box reports every hardware thread of its host) */
+QBO_API void qbo_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}

@@ -1503,6 +1503,32 @@ def test_two_ranks_sharing_the_gpu_equal_one_rank(tmp_path):
     assert r.returncode == 0 and "TWO-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_bench_two_ranks_measure_both_multi_gpu_configs():
+    """`bench.py --gpus 2` as the driver launches it (self-launch -> torch.distributed.run), rehearsed on the one GPU of this box (both ranks
+    on cuda:0, gloo in place of RCCL): the ONE line of the N > 1 run carries BASELINE configs[4] (A7/W4, 1024 global samples, 512 per rank)
+    and configs[3] (16 members, 8 per rank) in `secondary`, beside the weak-scaling headline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(QBNN_BENCH_SHARE_GPU="1", QBNN_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prime", "2", "--samples", "20"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_samples"] == 40 and out["rccl_ranks"] == 0          # gloo: no RCCL claim
+    sec = out["secondary"]
+    w4, ens = sec["resnet_bbb_w4"], sec["ensemble16"]
+    assert "error" not in w4 and "error" not in ens, sec
+    assert w4["units_per_step_global"] == 1024 and w4["shards"] == [[0, 512], [512, 512]] and w4["value"] > 0 and len(w4["ms_per_step_by_rank"]) == 2
+    assert ens["units_per_step_global"] == 16 and ens["shards"] == [[0, 8], [8, 8]] and ens["value"] > 0
+    assert w4["scaling"] == "strong" and ens["scaling"] == "strong" and out["scaling"] == "weak"
+
+
 def test_resnet_mc_fused_post_ops_equal_separate_launches():
     """`conv_resnet_mc`: dropout (+ Add + ReLU) in the convs' store passes (qbnn_conv2d_i8_post_mc) against one launch per op --
     bit-identical with Philox masks and with injected masks, on a batch that leaves ragged image groups in every layer."""

@@ -248,6 +248,10 @@ def test_bench_self_launches_eight_ranks_with_the_baseline_partitions():
     by_rank = sorted(out["shards"], key=lambda d: d["rank"])
     assert [d["samples_1024"] for d in by_rank] == [[128 * r, 128] for r in range(8)]
     assert [d["members_16"] for d in by_rank] == [[2 * r, 2] for r in range(8)]
+    # the one driver command at N = 8 also measures BASELINE configs[4] and configs[3] (bench.py: secondary_multi), partitioned the same way
+    sec = {d["workload"]: d for d in out["secondary_multi"]}
+    assert sec["resnet_bbb_w4"]["units_global"] == 1024 and sec["resnet_bbb_w4"]["shards"] == [[128 * r, 128] for r in range(8)]
+    assert sec["ensemble16"]["units_global"] == 16 and sec["ensemble16"]["shards"] == [[2 * r, 2] for r in range(8)]
 
 
 def test_n24_packed_layout_places_every_weight_and_a_ones_row_per_tile():
