@@ -39,15 +39,17 @@ extern "C" {
 #define QBNN_LAYOUT_MFMA32 0    /* [NT][KS][64 lanes][16 B] fragments */
 #define QBNN_LAYOUT_ROWMAJOR 1  /* [Cout][K]                          */
 #define QBNN_LAYOUT_MFMA32_N24 2 /* fragments with 24 output channels (+ a ones row) per tile: the fused 48-channel kernels of round 5 */
-#define QBNN_LAYOUT_MFMA32_N24_TAIL 4
+#define QBNN_LAYOUT_MFMA32_TAIL 3 /* MFMA32 with the ragged ends of the kernel rows gathered into one k-step (72-byte rows: 7 k-steps instead of
+                                   * 9): the 24-channel convs behind the fused stem (qbnn_stem_chain_i8_mc / _drop_ / the multi forms)        */
+#define QBNN_LAYOUT_MFMA32_N24_TAIL 4 /* both of the previous two: stem.0 (24 -> 48, 3x3) of the first down-sampling block on the 16-wave kernel
+                                       * (24 + 1 channel tiles AND the gathered tails k-step)                                                    */
 
 /* qbnn_block_desc.flags.  POOL_OUT: the block's output leaves as AvgPool2d(H) of it -- y is [S][B][C] quint8 with the block output's (scale, zero
  * point): q = clamp(rne((sum - H*H z) / (H*H)) + z), the head's first step (models_bbb.py:209, :240: nn.AvgPool2d(4) behind the last BasicBlock), so
  * the 4 x 4 x 192 map never goes to HBM and qbnn_head_i8_mc runs on the pooled tensor with k = 1.  Served by the 4 x 4 x 192 identity block of
- * qbnn_block_chain_i8_mc (one block per launch, LDS-ring kernel); any other geometry answers QBNN_E_INVALID. */
-#define QBNN_BLOCK_POOL_OUT 1 /* both of the next two: stem.0 (24 -> 48, 3x3) of the first down-sampling block on the 16-wave kernel */
-#define QBNN_LAYOUT_MFMA32_TAIL 3 /* MFMA32 with the ragged ends of the kernel rows gathered into one k-step (72-byte rows: 7 k-steps instead of
-                                   * 9): the 24-channel convs behind the fused stem (qbnn_stem_chain_i8_mc / _drop_ / the multi forms)        */
+ * qbnn_block_chain_i8_mc (one block per launch, LDS-ring kernel, MFMA32 weights); any other geometry AND every other entry point (the _multi,
+ * _multi_prepare and _drop_ forms) answers QBNN_E_INVALID. */
+#define QBNN_BLOCK_POOL_OUT 1
 
 /* Scalars of the int8 weight-sampling chain
  *   noise  = quantize_per_tensor(eps, NOISE_SCALE, 0, qint8)      conv_q.py:113-115, linear_q.py:86-88
@@ -269,7 +271,10 @@ int qbnn_block_down_i8_multi(const qbnn_down_call* calls, int32_t n_calls, int32
  * that dies with the call): do not call it under stream capture), _launch then runs them in ONE grid however many they are (the by-value
  * forms above are limited to 8 / 4 calls per launch by the 4 KiB of kernel arguments): with 16 members every workgroup walks 2 - 16
  * work items of its member instead of 1 - 4, and a stage is one launch instead of two or four.  max_samples = the largest n_samples
- * of the calls.  Same results as the by-value forms. */
+ * of the calls.  Same results as the by-value forms.
+ * _prepare remembers, per dev_args pointer, what it baked into the blocks (n_calls, B, a_hi, the one w_layout of the call array, n_blocks /
+ * with_stem); _launch answers QBNN_E_INVALID for a dev_args it did not prepare and for arguments that differ from those (they pick the
+ * kernel: a mismatching w_layout would read the weights in the wrong fragment order).  n_calls may be smaller at launch (a prefix of the calls). */
 size_t qbnn_chain_multi_args_bytes(int32_t n_calls, int32_t n_blocks);
 size_t qbnn_down_multi_args_bytes(int32_t n_calls);
 int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, int32_t n_calls, int32_t with_stem, int32_t B, int32_t a_hi,
@@ -468,7 +473,8 @@ int qbnn_observe_partials_f32_mc(const float* partials, int32_t n_blocks, int32_
  *   (zero_point NULL) or the raw weight integer q_w;  x_sample_stride 0 shares x.
  *   qbnn_conv2d_q8_f32_mc: x int8 [S][B][H][W][Cin] centred, w int8 [S][Cout][k][k][Cin] raw, s_x / s_w / z_w per sample; y fp32 [S][B][Ho][Wo][Cout]. */
 /* qbnn_fake_quant_f32_mc with the ReLU that follows it in the graph (BasicBlock: Add -> FakeQuantize -> ReLU) and, optionally, the grid integers
- * q - z (after the ReLU) as int8 [S][n]: the activation operand of qbnn_conv2d_q8_f32_mc without a qbnn_grid_to_i8_mc pass (qmax - qmin <= 254). */
+ * q - z (after the ReLU) as int8 [S][n]: the activation operand of qbnn_conv2d_q8_f32_mc without a qbnn_grid_to_i8_mc pass (qmax - qmin <= 127, as q - z
+ * spans +-(qmax - qmin); QBNN_E_INVALID for a wider grid). */
 int qbnn_fake_quant_ex_f32_mc(const float* x, int64_t x_sample_stride, float* y, int64_t y_sample_stride, int64_t n, const float* scale,
                               const int32_t* zero_point, int32_t qmin, int32_t qmax, int32_t relu, int8_t* q8_out, int32_t n_samples, void* stream);
 int qbnn_grid_to_i8_mc(const float* x, int64_t x_sample_stride, int64_t n, const float* scale, const int32_t* zero_point, int8_t* out,

@@ -2,6 +2,8 @@
 // block's convs) and their C ABI: qbnn_block_chain_i8_mc / qbnn_stem_chain_i8_mc / qbnn_block_down_i8_mc and the
 // multi-call (ensemble) forms.  Shared device code: qbnn_conv.h.
 #include "qbnn_host.h"
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #ifdef QBNN_STAMP
@@ -1156,7 +1158,7 @@ static int fill_drop(PostArgs& o, const qbnn_drop_desc& q, float s_conv, int a_h
 template <int NBLK>
 static int build_chain_args(ChainArgs<NBLK>& a, const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t a_hi,
                             const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples, const int8_t* stem_x, const QConv* stem,
-                            const qbnn_drop_desc* drops = nullptr) {
+                            const qbnn_drop_desc* drops = nullptr, bool pool_ok = false) {
   memset(&a, 0, sizeof(a));
   if (stem) { a.stem_x = stem_x; a.stem = *stem; }
   a.x = x; a.x_ss = x_ss; a.y = y; a.y_ss = y_ss; a.B = B; a.n_samples = n_samples; a.z_in = z_x;
@@ -1181,6 +1183,10 @@ static int build_chain_args(ChainArgs<NBLK>& a, const uint8_t* x, int64_t x_ss, 
     if ((b.flags & QBNN_BLOCK_POOL_OUT) && k != NBLK - 1) return fail(QBNN_E_INVALID, "qbnn_block_chain: QBNN_BLOCK_POOL_OUT belongs to the chain's last block%s");
   }
   a.pool = (blk[NBLK - 1].flags & QBNN_BLOCK_POOL_OUT) ? 1 : 0;
+  // Only qbnn_block_chain_i8_mc's 4 x 4 x 192 single-block launch on the ring kernel writes the pooled [S][B][C] tensor (pool_ok); the multi-call,
+  // prepared and dropout entry points run kernels that would write the full H x W x C map into a y the caller sized for the pooled one.
+  if (a.pool && !pool_ok)
+    return fail(QBNN_E_INVALID, "QBNN_BLOCK_POOL_OUT is served by qbnn_block_chain_i8_mc's 4x4x192 identity block only (one block per launch, ring kernel, MFMA32 weights)%s");
   return QBNN_OK;
 }
 
@@ -1198,9 +1204,8 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
                                 int32_t a_hi, const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples,
                                 hipStream_t st, const int8_t* stem_x = nullptr, const QConv* stem = nullptr) {
   ChainArgs<NBLK> a;
-  if (int rc = build_chain_args<NBLK>(a, x, x_ss, s_x, z_x, B, a_hi, blk, y, y_ss, n_samples, stem_x, stem)) return rc;
-  if (a.pool && !(Cc == 192 && H == 4 && NBLK == 1 && !stem && qbnn_use_chain_ring() && blk[0].w_layout == QBNN_LAYOUT_MFMA32))
-    return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: QBNN_BLOCK_POOL_OUT is served by the 4x4x192 identity block (one block per launch, ring kernel)%s");
+  const bool pool_ok = Cc == 192 && H == 4 && NBLK == 1 && !stem && qbnn_use_chain_ring() && blk[0].w_layout == QBNN_LAYOUT_MFMA32;
+  if (int rc = build_chain_args<NBLK>(a, x, x_ss, s_x, z_x, B, a_hi, blk, y, y_ss, n_samples, stem_x, stem, nullptr, pool_ok)) return rc;
   if (stem) {
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
     for (int k = 0; k < NBLK; ++k)
@@ -1303,6 +1308,27 @@ QBNN_EXPORT size_t qbnn_down_multi_args_bytes(int32_t n_calls) { return (size_t)
 // The argument blocks go up ON the caller's stream (the destination comes from a stream-ordered allocator: a recycled block may still be
 // read by earlier work of that stream, which a null-stream copy would not wait for) and the call returns when they have landed (the
 // staging vector dies with the caller's frame).
+// What a _multi_prepare call baked into the device-resident argument blocks, remembered per `dev_args` pointer so that _multi_launch can refuse a
+// mismatching (a_hi, w_layout, n_calls, n_blocks / with_stem): those pick the kernel, and a kernel that reads the weights in another fragment
+// layout than the sampler wrote gives silently wrong sums.  (A launch on a pointer this library never prepared is refused too.)
+struct PreparedArgs { int32_t n_calls, a_hi, w_layout, n_blocks, with_stem, B; };
+static std::mutex g_prepared_mu;
+static std::unordered_map<const void*, PreparedArgs> g_prepared;
+static void remember_prepared(const void* dev, const PreparedArgs& p) {
+  std::lock_guard<std::mutex> lk(g_prepared_mu);
+  if (g_prepared.size() > 4096) g_prepared.clear();      // (stale pointers of freed blocks: a re-prepare re-registers)
+  g_prepared[dev] = p;
+}
+static int check_prepared(const void* dev, const PreparedArgs& want, const char* what) {
+  std::lock_guard<std::mutex> lk(g_prepared_mu);
+  auto it = g_prepared.find(dev);
+  if (it == g_prepared.end()) return fail(QBNN_E_INVALID, "%s: dev_args was not written by the matching _multi_prepare call", what);
+  const PreparedArgs& p = it->second;
+  if (p.n_calls < want.n_calls || p.a_hi != want.a_hi || p.w_layout != want.w_layout || p.n_blocks != want.n_blocks || p.with_stem != want.with_stem || p.B != want.B)
+    return fail(QBNN_E_INVALID, "%s: n_calls / B / a_hi / w_layout / n_blocks differ from what _multi_prepare baked into dev_args", what);
+  return QBNN_OK;
+}
+
 static int upload_args(void* dev, const void* host, size_t bytes, const char* what, hipStream_t st) {
   if (hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
     return fail(QBNN_E_LAUNCH, "%s: copying the argument blocks to the device failed", what);
@@ -1322,8 +1348,12 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, 
       QConv stem;
       if ((rc = build_stem_qconv(stem, k.w0_packed, k.w0_sample_stride, k.bias0, k.s_in, k.s_w0, k.z_w0, k.s_y0, k.z_y0, a_hi))) return rc;
       if ((rc = build_chain_args<2>(arr[i], nullptr, 0, k.s_y0, k.z_y0, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, k.im2col, &stem))) return rc;
+      for (int b = 0; b < 2; ++b)
+        if (k.blocks[b].w_layout != calls[0].blocks[0].w_layout) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: one weight layout per call array%s");
     }
-    return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_chain_i8_multi_prepare", (hipStream_t)stream);
+    if ((rc = upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_chain_i8_multi_prepare", (hipStream_t)stream))) return rc;
+    remember_prepared(dev_args, PreparedArgs{n_calls, a_hi, calls[0].blocks[0].w_layout, 2, 1, B});
+    return QBNN_OK;
   }
   if (n_blocks != 1) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: one block per call (two only behind the fused stem)%s");
   std::vector<ChainArgs<1>> arr(n_calls);
@@ -1331,13 +1361,17 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_prepare(const qbnn_chain_call* calls, 
     const qbnn_chain_call& k = calls[i];
     if (!k.x || !k.blocks || !k.y || k.n_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: bad call entry%s");
     if ((rc = build_chain_args<1>(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.blocks, k.y, k.y_sample_stride, k.n_samples, nullptr, nullptr))) return rc;
+    if (k.blocks[0].w_layout != calls[0].blocks[0].w_layout) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_prepare: one weight layout per call array%s");
   }
-  return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_chain_i8_multi_prepare", (hipStream_t)stream);
+  if ((rc = upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_chain_i8_multi_prepare", (hipStream_t)stream))) return rc;
+  remember_prepared(dev_args, PreparedArgs{n_calls, a_hi, calls[0].blocks[0].w_layout, 1, 0, B});
+  return QBNN_OK;
 }
 
 QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t with_stem, int32_t B, int32_t H, int32_t Cc,
                                                  int32_t a_hi, int32_t w_layout, int32_t n_blocks, int32_t max_samples, void* stream) {
   if (!dev_args || n_calls <= 0 || B <= 0 || max_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: bad argument%s");
+  if (int rc = check_prepared(dev_args, PreparedArgs{n_calls, a_hi, w_layout, n_blocks, with_stem ? 1 : 0, B}, "qbnn_block_chain_i8_multi_launch")) return rc;
   hipStream_t st = (hipStream_t)stream;
   auto items = [&](int G) { return max_samples * ((B + G - 1) / G); };
   if (with_stem) {
@@ -1371,13 +1405,17 @@ QBNN_EXPORT int qbnn_block_down_i8_multi_prepare(const qbnn_down_call* calls, in
     if (!k.x || !k.y || !k.desc || k.n_samples <= 0 || !k.desc->blk.w_a || !k.desc->blk.w_b || !k.desc->w_s)
       return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_prepare: bad call entry%s");
     if (int rc = build_down_args(arr[i], k.x, k.x_sample_stride, k.s_x, k.z_x, B, a_hi, k.desc, k.y, k.y_sample_stride, k.n_samples)) return rc;
+    if (k.desc->blk.w_layout != calls[0].desc->blk.w_layout) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_prepare: one weight layout per call array%s");
   }
-  return upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_down_i8_multi_prepare", (hipStream_t)stream);
+  if (int rc = upload_args(dev_args, arr.data(), arr.size() * sizeof(arr[0]), "qbnn_block_down_i8_multi_prepare", (hipStream_t)stream)) return rc;
+  remember_prepared(dev_args, PreparedArgs{n_calls, 0, calls[0].desc->blk.w_layout, 1, 0, B});      // (the down launch takes no a_hi: it is baked in)
+  return QBNN_OK;
 }
 
 QBNN_EXPORT int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_calls, int32_t B, int32_t H, int32_t Cin, int32_t w_layout,
                                                 int32_t max_samples, void* stream) {
   if (!dev_args || n_calls <= 0 || B <= 0 || max_samples <= 0) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_launch: bad argument%s");
+  if (int rc = check_prepared(dev_args, PreparedArgs{n_calls, 0, w_layout, 1, 0, B}, "qbnn_block_down_i8_multi_launch")) return rc;
   hipStream_t st = (hipStream_t)stream;
   const DownArgs* dev = reinterpret_cast<const DownArgs*>(dev_args);
   auto items = [&](int G) { return max_samples * ((B + G - 1) / G); };

@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void fake_quant_f32_kernel(const float* __rest
 
 // ... with the ReLU that follows it in the graph (BasicBlock: Add -> FakeQuantize -> ReLU; a ReLU of grid values stays on the grid) and, optionally, the
 // grid integers themselves, m = q - z (after the ReLU: max(m, 0)), as int8 [S][n] -- the operand format of qbnn_conv2d_q8_f32_mc, so the consumer conv
-// needs no qbnn_grid_to_i8_mc pass.  q8 requires qmax - qmin <= 254 (|m| <= 127: the 7-bit activation grids).
+// needs no qbnn_grid_to_i8_mc pass.  q8 requires qmax - qmin <= 127 (m = q - z spans +-(qmax - qmin): |m| <= 127 for the 2- to 7-bit activation grids).
 __global__ __launch_bounds__(256) void fake_quant_ex_f32_kernel(const float* __restrict__ x, int64_t x_ss, float* __restrict__ y, int64_t y_ss,
                                                                  int64_t n, const float* __restrict__ scale, const int* __restrict__ zp, int qmin, int qmax,
                                                                  int relu, int8_t* __restrict__ q8) {
@@ -718,7 +718,7 @@ QBNN_EXPORT int qbnn_fake_quant_ex_f32_mc(const float* x, int64_t x_ss, float* y
                                           void* stream) {
   if (!x || !y || !scale || !zero_point || n <= 0 || n_samples <= 0 || qmax <= qmin)
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_ex_f32_mc: bad argument");
-  if (q8_out && qmax - qmin > 254) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_ex_f32_mc: the int8 output takes grids of at most 255 steps");
+  if (q8_out && qmax - qmin > 127) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_ex_f32_mc: the int8 output (q - z) takes grids of at most 128 steps (qmax - qmin <= 127)");
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(fake_quant_ex_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, y, y_ss, n, scale, zero_point,
                      qmin, qmax, relu, q8_out);
@@ -1050,10 +1050,11 @@ QBNN_EXPORT int qbnn_conv2d_q8_f32_mc(const int8_t* x, int64_t x_ss, const int8_
   const dim3 grid(narrow ? (unsigned)((npix + 127) / 128) : (unsigned)((npix + 63) / 64), narrow ? (unsigned)((Cout + 31) / 32) : (unsigned)((Cout + 63) / 64), (unsigned)n_samples);
   const bool u4 = (Cin % 4) == 0 && (x_ss % 4) == 0 && (w_ss % 4) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 3) == 0;
   static const bool wide = [] { const char* e = getenv("QBNN_Q8_WIDE"); return !(e && e[0] == '0'); }();
-  const bool y16 = (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_ss % 4) == 0;
+  // (the 16-byte output stores are taken only when Cout % 4 == 0 -- a head Linear(100, 1) / Linear(500, 10) stores scalars, whatever y_ss = Cout B is)
+  const bool y16 = (Cout & 3) != 0 || ((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_ss % 4) == 0);
   const bool v_ok = u4 && ksize * ksize <= 32 && y16 && (int64_t)B * H * W * Cin < (1ll << 31);
   if (narrow) {
-    if (!v_ok) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: the 128 x 32 form (Cout <= 32, Cin % 4 == 0) takes 4-byte aligned operands and 16-byte aligned outputs");
+    if (!v_ok) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: the 128 x 32 form (Cout <= 32, Cin % 4 == 0) takes 4-byte aligned operands, fewer than 2^31 input elements and, when Cout % 4 == 0, 16-byte aligned outputs");
     hipLaunchKernelGGL((conv2d_q8v_kernel<128, 32>), grid, dim3(256), 0, (hipStream_t)stream, a);
   } else if (v_ok && wide) hipLaunchKernelGGL((conv2d_q8v_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else if (u4) hipLaunchKernelGGL(conv2d_q8_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -423,6 +423,12 @@ class Network(nn.Module):
             raise RuntimeError(f"found {len(self.sample_names)} member checkpoints under {path}, need {len(self.ensemble)}")
         return self.load_reference_state([load_state(os.path.join(path, n)) for n in self.sample_names])
 
+    @staticmethod
+    def _graph_key(idx, x):
+        """(the epoch: a layout switch or a reloaded state drops the packed weights a captured chain points at)"""
+        from .layers import state_epoch
+        return (idx, tuple(x.shape), x.dtype, x.device.index, state_epoch())
+
     def _member_forward(self, idx, x, record=None):
         """[1, B, C] probabilities of member `idx`; replays the member's captured launch chain when there is one."""
         from . import layers as _layers
@@ -430,10 +436,7 @@ class Network(nn.Module):
         if record is not None or not self.use_graphs or self.regression or _layers.PROFILE is not None or x.device.type != "cuda":
             with mc_context(1, 0, 0):
                 return member.forward_mc(x, record=record)
-        from .layers import state_epoch
-        # (the epoch: a layout switch or a reloaded state drops the packed weights a captured chain points at)
-        key = (idx, tuple(x.shape), x.dtype, x.device.index, state_epoch())
-        ent = self._graphs.get(key)
+        ent = self._graphs.get(self._graph_key(idx, x))
         if ent is None:
             with mc_context(1, 0, 0):
                 member.forward_mc(x)                        # eager once: packs the weights, fills every cache the chain reads
@@ -449,6 +452,10 @@ class Network(nn.Module):
                     GRAPH_FALLBACKS.append(f"member {idx}: {e!r}")     # a benchmark must not time the fallback silently: bench.py exits non-zero
                     torch.cuda.synchronize()
                     ent = False
+            # the key AFTER the warm-up forward (it may switch layouts and bump the epoch itself: a key taken before it would be dead on arrival
+            # and the chain captured twice); entries of older epochs go -- each pins a captured graph with its static input / output
+            key = self._graph_key(idx, x)
+            self._graphs = {k: v for k, v in self._graphs.items() if k[-1] == key[-1]}
             self._graphs[key] = ent
         if ent is False:
             with mc_context(1, 0, 0):
@@ -550,6 +557,7 @@ class Network(nn.Module):
                     _lib.check(L.qbnn_block_chain_i8_multi_prepare(step[1], M, int(step[0] == "stem"), B, a_hi, nb, _lib.ptr(buf), _lib.current_stream()))
                 dev_steps.append(buf)
         plan = dict(M=M, col=col, acts=acts, probs=probs, scales=scales, zps=zps, steps=steps, dev_steps=dev_steps, head=hcalls, keep=keep, a_hi=a_hi)
+        self._plans = {k: v for k, v in self._plans.items() if k[-1] == key[-1]}      # plans of older epochs pin activation buffers and device argument blocks
         self._plans[key] = plan
         return plan
 
@@ -597,7 +605,7 @@ class Network(nn.Module):
         if record is None and self.fused_members and x.device.type == "cuda" and len(set(idx)) == len(idx):
             return self._forward_members_fused(idx, x)
         graphed = (record is None and self.use_graphs and not self.regression and x.device.type == "cuda" and len(idx) > 1 and
-                   all(self._graphs.get((j, tuple(x.shape), x.dtype, x.device.index)) for j in idx))
+                   all(self._graphs.get(self._graph_key(j, x)) for j in idx))
         if not graphed:
             outs = [self._member_forward(j, x, record=record if i == 0 else None) for i, j in enumerate(idx)]
             if self.regression:

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from . import _lib
 from .layers import _MC, bump_state_epoch, mc_context, timed
 from .models_f32 import (affine_f32, conv2d_f32, flatten_f32, nchw_to_mc_nhwc, pool2d_f32, sample_conv_weights_f32, softmax_f32)
-from .quant import INT_BOUNDS, UINT_BOUNDS
+from .quant import INT_BOUNDS, UINT_BOUNDS, check_bits
 
 OBS_BLOCKS = 512            # QBNN_OBSERVER_BLOCKS (include/qbnn.h)
 AVG_CONST = 0.01            # MovingAverageMinMaxObserver default, never overridden by the reference
@@ -74,7 +74,9 @@ class FakeQuantize(nn.Module):
                                                  _lib.ptr(scale), _lib.ptr(zp), _lib.current_stream()))
         y = torch.empty((S,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
         q8 = None
-        if qat_i8_enabled() and self.qmax - self.qmin <= 254:      # an activation grid: leave the integers q - z for a consumer conv on the int8 pipe
+        # q - z spans +-(qmax - qmin): an int8 holds it for grids of at most 128 steps (the 2- to 7-bit activation grids, quant_utils.py:120)
+        int8_grid = self.qmax - self.qmin <= 127
+        if qat_i8_enabled() and int8_grid:      # an activation grid: leave the integers q - z for a consumer conv on the int8 pipe
             q8 = torch.empty((S, n), dtype=torch.int8, device=x.device)
         with timed("fake_quant_f32"):
             if q8 is not None or relu:
@@ -84,12 +86,15 @@ class FakeQuantize(nn.Module):
                 _lib.check(L.qbnn_fake_quant_f32_mc(_lib.ptr(x), xs, _lib.ptr(y), n, n, _lib.ptr(scale), _lib.ptr(zp), 1, self.qmin, self.qmax, S,
                                                     _lib.current_stream()))
         self.last_scale, self.last_zero_point = scale, zp
-        y._grid = scale              # y[s] holds integers times scale[s]: what conv2d_q8 (the int8 matrix pipe) needs to know about its input
+        # y[s] holds integers times scale[s]: what conv2d_q8 (the int8 matrix pipe) needs to know about its ACTIVATION operand -- only where
+        # those integers fit an int8 (a wider grid sends the consumer conv down the fp64 path; the weight operand goes by weight_grid())
+        y._grid = scale if int8_grid else None
         y._q8 = q8                   # ... and the integers themselves, [S, n] int8 in y's own element order
         return y
 
 
 def _bounds(args):
+    check_bits(args)                 # quant_utils.py:120-121: 2..7-bit activations, 2..8-bit weights (every QAT model constructor comes through here)
     return UINT_BOUNDS[args.activation_precision], INT_BOUNDS[args.weight_precision]
 
 

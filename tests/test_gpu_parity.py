@@ -2621,3 +2621,108 @@ def test_qat_int8_conv_entry_points_against_numpy(case):
         np.testing.assert_allclose(got[s], v, rtol=1e-6, atol=1e-7)
         part = mm.cpu().numpy().reshape(S, nblk, 2)[s]
         assert np.isclose(part[:, 0].min(), got[s].min()) and np.isclose(part[:, 1].max(), got[s].max())
+
+
+# ------------------------------------------------------------------------------------------ round 6: advisor findings of round 5
+@pytest.mark.parametrize("name,model,B", [("mlp_bbb_qat.npz", "linear_bbb", 7), ("mlp_bbb_qat.npz", "linear_bbb", 1), ("lenet_bbb_qat.npz", "conv_lenet_bbb", 7),
+                                          ("lenet_bbb_qat.npz", "conv_lenet_bbb", 3)])
+def test_qat_eval_odd_batches_against_oracle(name, model, B):
+    """The QAT Linears run through qbnn_conv2d_q8_f32_mc (1 x 1 conv form): its 128 x 32 tile must take the heads' outputs -- Linear(100, 1) with
+    y_ss = B, Linear(500, 10) with y_ss = 10 B -- for ANY batch (a ragged last batch: B % 4 != 0, odd B), where round 5 answered QBNN_E_INVALID.
+    Live-observer evaluation of the MLP / LeNet against the CPU oracle (conv_qat.py:139-167, linear_qat.py:18-41), sample after sample."""
+    import os
+    import quantised_bayesian_nets_amd as q
+    from oracle import oracle as orc
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    st = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    args = types.SimpleNamespace(sigma_prior=-2.0, activation_precision=7, weight_precision=8, qat_eval=True)
+    shape = {"linear_bbb": [13], "conv_lenet_bbb": [1, 28, 28]}[model]
+    m = q.ModelFactory.get_model(model, shape, 1 if model == "linear_bbb" else 10, True, args).load_reference_state(st)
+    gen = torch.Generator().manual_seed(40 + B)
+    x = torch.randn(B, 13, generator=gen) if model == "linear_bbb" else torch.rand(B, 1, 28, 28, generator=gen)
+    S, seed = 3, 17
+    net = orc.QATOracle(st)
+    with q.mc_context(S, seed, 0):
+        out = m.forward_mc(x.cuda())
+    for s in range(S):
+        if model == "linear_bbb":
+            mu, var = net.mlp(x.numpy(), seed, s)
+            np.testing.assert_allclose(out[0][s].cpu().numpy(), mu, rtol=1e-5, atol=4e-6)
+            np.testing.assert_allclose(out[1][s].cpu().numpy(), var, rtol=1e-5, atol=1e-8)
+        else:
+            np.testing.assert_allclose(out[s].cpu().numpy(), net.lenet(x.numpy(), seed, s), rtol=1e-5, atol=2e-6)
+
+
+def test_int8_grid_output_needs_a_grid_of_at_most_128_steps():
+    """q - z spans +-(qmax - qmin): qbnn_fake_quant_ex_f32_mc's int8 output (the activation operand of the int8-pipe QAT convs) is refused for a
+    grid wider than 128 steps instead of wrapping silently, the Python FakeQuantize then leaves no `_grid` (its consumer takes the fp64 path),
+    and the QAT constructors hold the reference's bit-width contract (quant_utils.py:120-121)."""
+    import quantised_bayesian_nets_amd as q
+    from quantised_bayesian_nets_amd import _lib, models_qat
+    L = _lib.lib()
+    S, n = 2, 64
+    x = torch.randn(S, n, device="cuda")
+    y = torch.empty_like(x)
+    q8 = torch.empty((S, n), dtype=torch.int8, device="cuda")
+    sc = torch.full((S,), 0.05, device="cuda")
+    zp = torch.full((S,), 100, dtype=torch.int32, device="cuda")
+    st = _lib.current_stream()
+    assert L.qbnn_fake_quant_ex_f32_mc(_lib.ptr(x), n, _lib.ptr(y), n, n, _lib.ptr(sc), _lib.ptr(zp), 0, 255, 0, _lib.ptr(q8), S, st) == -1
+    assert b"128 steps" in L.qbnn_last_error()
+    assert L.qbnn_fake_quant_ex_f32_mc(_lib.ptr(x), n, _lib.ptr(y), n, n, _lib.ptr(sc), _lib.ptr(zp), 0, 255, 0, None, S, st) == 0      # fp32 output only: any grid
+    assert L.qbnn_fake_quant_ex_f32_mc(_lib.ptr(x), n, _lib.ptr(y), n, n, _lib.ptr(sc), _lib.ptr(zp), 0, 127, 0, _lib.ptr(q8), S, st) == 0
+    torch.cuda.synchronize()
+    got = q8.cpu().numpy().astype(np.int32)
+    want = np.clip(np.rint(x.cpu().numpy() * np.float32(1.0 / np.float32(0.05))) + 100, 0, 127) - 100
+    assert np.array_equal(got, want.astype(np.int32))
+    with pytest.raises(AssertionError):
+        q.ModelFactory.get_model("linear_bbb", [13], 1, True, types.SimpleNamespace(sigma_prior=-2.0, activation_precision=8, weight_precision=8, qat_eval=True))
+    with q.mc_context(S, 1, 0):
+        fq = models_qat.FakeQuantize(0, 255)
+        assert getattr(fq(torch.randn(S, 4, 8, device="cuda")), "_grid", None) is None
+        fq7 = models_qat.FakeQuantize(0, 127)
+        assert getattr(fq7(torch.randn(S, 4, 8, device="cuda")), "_grid", None) is not None
+
+
+def test_prepared_multi_launch_refuses_what_prepare_did_not_bake(golden_ensemble):
+    """qbnn_block_*_i8_multi_launch picks its kernel from (a_hi, w_layout, n_blocks, with_stem): the library remembers what _multi_prepare baked into
+    each dev_args block and answers QBNN_E_INVALID for anything else (another fragment layout would read the weights scrambled), for a device
+    block it never prepared, and for QBNN_BLOCK_POOL_OUT on the multi-call forms (they write the full map)."""
+    import quantised_bayesian_nets_amd as q
+    from quantised_bayesian_nets_amd import _lib
+    from conftest import synth_ensemble_members
+    n = 4
+    members = synth_ensemble_members(golden_ensemble, n)
+    args = types.SimpleNamespace(activation_precision=7, weight_precision=8, model="conv_resnet_sgld", samples=n)
+    net = q.ModelFactory.get_model("conv_resnet_sgld", [1, 3, 32, 32], 10, True, args, training_mode=False).load_reference_state(members)
+    x = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(2)).cuda()
+    with q.mc_context(n, 0, 0):
+        want = net.forward_mc(x)
+    (plan,) = net._plans.values()
+    assert plan["dev_steps"], "the prepared-launch path is the default"
+    L, st, M, B, a_hi = _lib.lib(), _lib.current_stream(), plan["M"], 8, plan["a_hi"]
+    stem, dargs = plan["steps"][0], _lib.ptr(plan["dev_steps"][0])
+    lay = stem[1][0].blocks[0].w_layout
+    assert stem[0] == "stem"
+    assert L.qbnn_block_chain_i8_multi_launch(dargs, M, 1, B, 32, 24, a_hi, lay, 2, 1, st) == 0
+    for bad in (dict(w_layout=0 if lay != 0 else 3), dict(a_hi=a_hi // 2), dict(B=B + 1), dict(M=M + 1)):
+        kw = dict(M=M, B=B, a_hi=a_hi, w_layout=lay)
+        kw.update(bad)
+        assert L.qbnn_block_chain_i8_multi_launch(dargs, kw["M"], 1, kw["B"], 32, 24, kw["a_hi"], kw["w_layout"], 2, 1, st) == -1, bad
+        assert b"_multi_prepare" in L.qbnn_last_error()
+    stray = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    assert L.qbnn_block_chain_i8_multi_launch(_lib.ptr(stray), M, 1, B, 32, 24, a_hi, lay, 2, 1, st) == -1
+    down, ddown = plan["steps"][1], _lib.ptr(plan["dev_steps"][1])
+    dlay = down[1][0].desc.contents.blk.w_layout
+    assert down[0] == "down" and L.qbnn_block_down_i8_multi_launch(ddown, M, B, down[2], down[3], dlay + 1, 1, st) == -1
+    # POOL_OUT on a multi-call form: refused at argument-building time
+    chain = [s for s in plan["steps"] if s[0] == "chain"][-1]
+    chain[1][0].blocks[0].flags = 1
+    try:
+        assert L.qbnn_block_chain_i8_multi(chain[1], M, 0, B, chain[2], chain[3], a_hi, 1, st) == -1 and b"POOL_OUT" in L.qbnn_last_error()
+        buf = torch.empty(int(L.qbnn_chain_multi_args_bytes(M, 1)), dtype=torch.uint8, device="cuda")
+        assert L.qbnn_block_chain_i8_multi_prepare(chain[1], M, 0, B, a_hi, 1, _lib.ptr(buf), st) == -1 and b"POOL_OUT" in L.qbnn_last_error()
+    finally:
+        chain[1][0].blocks[0].flags = 0
+    with q.mc_context(n, 0, 0):                 # the plan still runs, same bits
+        assert torch.equal(net.forward_mc(x), want)
