@@ -19,8 +19,7 @@ def pytest_configure(config):
 
 
 # The reference's bit-width sweep (experiments/run_all_quant.sh:11-37: W in 3..8 at A7, A in 3..6 at W8; src/utils.py:18-20,
-# asserts src/quant_utils.py:120-121): one recorded fixture per point (make_golden.py --a-bits / --w-bits; B = 4, S = 3 for the two
-# BASELINE configurations, S = 2 for the rest of the sweep).
+# asserts src/quant_utils.py:120-121): one recorded fixture per point (make_golden.py --a-bits / --w-bits; B = 4, S = 3).
 SWEEP = [(7, 8), (7, 4), (7, 3), (7, 5), (7, 6), (7, 7), (3, 8), (4, 8), (5, 8), (6, 8)]
 
 
