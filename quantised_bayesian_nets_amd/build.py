@@ -7,8 +7,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-UNITS = ["qbnn_kernels.hip", "qbnn_blocks.hip", "qbnn_down_ring.hip", "qbnn_chain_ring.hip", "qbnn_w16.hip", "qbnn_c48.hip", "qbnn_misc.hip", "qbnn_f32.hip", "qbnn_small.hip"]
-HEADERS = ["qbnn_conv.h", "qbnn_host.h", "qbnn_rng.h", "qbnn_common.h", "qbnn_eps_table.h"]
+UNITS = ["qbnn_kernels.hip", "qbnn_blocks.hip", "qbnn_down_ring.hip", "qbnn_chain_ring.hip", "qbnn_w16.hip", "qbnn_c48.hip", "qbnn_misc.hip", "qbnn_f32.hip", "qbnn_q8t.hip", "qbnn_small.hip"]
+HEADERS = ["qbnn_conv.h", "qbnn_host.h", "qbnn_rng.h", "qbnn_common.h", "qbnn_eps_table.h", "qbnn_q8.h"]
 SRC = [os.path.join(CSRC, u) for u in UNITS if os.path.exists(os.path.join(CSRC, u))]
 DEPS = SRC + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(os.path.dirname(HERE), "include", "qbnn.h")]
 LIB = os.environ.get("QBNN_LIB_OVERRIDE") or os.path.join(HERE, "libqbnn_hip.so")   # override: scratch ablation builds

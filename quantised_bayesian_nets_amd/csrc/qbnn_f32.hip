@@ -17,6 +17,7 @@
 #include "../../include/qbnn.h"
 #include "qbnn_common.h"
 #include "qbnn_rng.h"
+#include "qbnn_q8.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -779,18 +780,7 @@ QBNN_EXPORT int qbnn_grid_to_i8_mc(const float* x, int64_t x_ss, int64_t n, cons
   return qbnn_check_launch_msg("qbnn_grid_to_i8_mc");
 }
 
-struct ConvQ8Args {
-  const int8_t* x; int64_t x_ss;     // centred activations m_x [S][B][H][W][Cin]
-  const int8_t* w; int64_t w_ss;     // raw weights q_w [S][Cout][KH][KW][Cin]
-  const float* s_x; const float* s_w; const int* z_w;      // per sample
-  float* y; int64_t y_ss;
-  int B, H, W, Cin, Cout, KS, stride, pad, Ho, Wo, relu;
-  const float* div; const float* bias; const float* alpha; const float* beta;
-  float* mm_partials;
-};
-typedef int v16i_q8 __attribute__((ext_vector_type(16)));
-typedef int v4i_q8 __attribute__((ext_vector_type(4)));
-typedef int v2i_q8 __attribute__((ext_vector_type(2)));
+// (ConvQ8Args and the int vector types: qbnn_q8.h, shared with the LDS-tiled form of the 3 x 3 convs in qbnn_q8t.hip)
 
 template <int GB>
 __global__ __launch_bounds__(256) void conv2d_q8_kernel(const ConvQ8Args a) {
@@ -1028,6 +1018,7 @@ QBNN_EXPORT int32_t qbnn_conv2d_q8_blocks(int32_t B, int32_t H, int32_t W, int32
   const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
   if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return 0;
   const int64_t npix = (int64_t)B * Ho * Wo;
+  if (const int tiled = qbnn_conv_q8t_blocks(B, H, W, Cin, Cout, ksize, stride, pad)) return tiled;      // the ResNet's 3 x 3 convs: LDS-tiled (qbnn_q8t.hip)
   return conv_q8_narrow(Cin, Cout, ksize) ? (int32_t)(((npix + 127) / 128) * ((Cout + 31) / 32)) : (int32_t)(((npix + 63) / 64) * ((Cout + 63) / 64));
 }
 
@@ -1045,6 +1036,13 @@ QBNN_EXPORT int qbnn_conv2d_q8_f32_mc(const int8_t* x, int64_t x_ss, const int8_
   a.div = div; a.bias = bias; a.alpha = alpha; a.beta = beta; a.mm_partials = minmax_partials;
   if (a.Ho <= 0 || a.Wo <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: empty output");
   if ((int64_t)ksize * ksize * Cin * 127 * 128 >= (1ll << 31)) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: K too large for int32 sums");
+  if (qbnn_conv_q8t_blocks(B, H, W, Cin, Cout, ksize, stride, pad) > 0) {
+    // (the grid qbnn_conv2d_q8_blocks promises the observer is the tiled form's: no other form may serve this geometry)
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 && (x_ss % 16) == 0 && (w_ss % 16) == 0 &&
+                    ((Cout & 3) != 0 || ((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_ss % 4) == 0));
+    if (!al) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: the tiled 3 x 3 form takes 16-byte aligned operands (and outputs when Cout % 4 == 0)");
+    return qbnn_launch_conv_q8t(a, n_samples, (hipStream_t)stream);
+  }
   const int64_t npix = (int64_t)B * a.Ho * a.Wo;
   const bool narrow = conv_q8_narrow(Cin, Cout, ksize);      // (every form launches the grid qbnn_conv2d_q8_blocks promises the observer)
   const dim3 grid(narrow ? (unsigned)((npix + 127) / 128) : (unsigned)((npix + 63) / 64), narrow ? (unsigned)((Cout + 31) / 32) : (unsigned)((Cout + 63) / 64), (unsigned)n_samples);

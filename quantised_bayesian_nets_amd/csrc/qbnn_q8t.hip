@@ -1,0 +1,259 @@
+// libqbnn_hip.so -- the QAT evaluation's 3 x 3 convs on the int8 matrix pipe, LDS-tiled (round 6).
+//
+// Reference: quantized/conv_qat.py:139-167 in eval mode -- Z = conv(FQ(X), FQ(W)), Z / scale_factor (+ bias), BatchNorm, (ReLU), then the
+// activation FakeQuantize whose observer needs Z's (min, max).  Both operands are integers on a per-sample grid (qbnn_q8.h), so the conv is the
+// exact integer sum  s_x s_w * (sum m_x q_w - z_w sum m_x)  on v_mfma_i32_32x32x32_i8, scaled once in fp64 and followed by the fp32 conv's
+// own tail -- the arithmetic of conv2d_q8v_kernel (qbnn_f32.hip), bit for bit; what changes is how the operands reach the matrix pipe.
+//
+// The gather forms move every input byte nine times (once per tap) from L2 in 4-byte units, 64 bytes of K per barrier pair: two MFMAs per
+// wave between barriers, 2.3 % of the int8 peak (round 5: the convs were 2.7 of the 6.9 ms of a 10-sample pass).  Here a workgroup stages
+//   * an input tile WITH its halo in LDS once per pixel block -- G images x RI rows x (W + 2) pixels x Cin bytes, NHWC, so the KW Cin bytes of a
+//     kernel row are contiguous for every output pixel (the layout idea of the int8 product kernels: a k-step is 32 contiguous bytes of that
+//     window; the row is padded to a multiple of 32 with ZERO WEIGHTS, whatever activation bytes the overrun reads),
+//   * the sample's weights as [channel][k-step][32 B] rows (pitch + 16 B: conflict-free ds_read_b128), whole (NCHUNK = 1: K <= 432) or one
+//     kernel row / half row per chunk (Cin = 96 / 192),
+// and each wave owns one 32-pixel tile x NTW channel tiles: a pixel fragment is read once per k-step for NTW MFMAs.  The window sum sum m_x (the
+// weights' zero point is not 0) comes from v_dot4 on the same fragments, the padded bytes masked.  HBM: the int8 input once, the fp32 output once.
+#include <math.h>
+#include <stdlib.h>
+
+#include "../../include/qbnn.h"
+#include "qbnn_common.h"
+#include "qbnn_q8.h"
+
+namespace {
+
+typedef float v4f_q8 __attribute__((ext_vector_type(4)));
+
+template <int CIN_, int STRIDE_, int WO_, int G_, int ROWS_, int NTW_, int CW_, int NCHUNK_, int IT_, int WPE_>
+struct Q8TCfg {
+  static constexpr int WPE = WPE_;            // waves per SIMD the kernel is compiled for (= workgroups per CU: 512 / WPE registers, 160 KiB / WPE of LDS)
+  static constexpr int CIN = CIN_, STRIDE = STRIDE_, WO = WO_, HO = WO_, G = G_, ROWS = ROWS_, NTW = NTW_, CW = CW_, NCHUNK = NCHUNK_, IT = IT_;
+  static constexpr int PIX = G * ROWS * WO, PW = PIX / 32;             // output pixels / 32-pixel tiles per block
+  static_assert(PIX % 32 == 0 && PW * CW == 4, "four waves: PW pixel tiles x CW channel groups");
+  static_assert(G == 1 || ROWS == HO, "several images per block only as whole images");
+  static_assert(HO % ROWS == 0, "whole row blocks per image");
+  static constexpr int W_IN = WO * STRIDE, H_IN = W_IN, CI = W_IN + 2, RI = (ROWS - 1) * STRIDE + 3;      // tile: RI rows x CI pixels (halo 1)
+  static constexpr int ROWB = 3 * CIN, ROWPAD = (ROWB + 31) / 32 * 32, RSTEPS = ROWPAD / 32;               // a kernel row: bytes, padded, k-steps
+  static constexpr int U = (CIN % 16 == 0) ? 16 : 8;                                                        // staging unit (bytes)
+  static_assert(CIN % 8 == 0 && ROWB % U == 0, "kernel rows are whole staging units");
+  static constexpr int TILE = G * RI * CI * CIN, TILE_LDS = (TILE + 64 + 15) / 16 * 16;                    // + slack: the last window's padded k-step
+  static constexpr int COUT_WG = 32 * NTW * CW;
+  static_assert(NCHUNK == 1 || NCHUNK == 3 || (NCHUNK == 6 && RSTEPS % 2 == 0 && ROWB == ROWPAD), "whole conv, kernel row, or half row per chunk");
+  static constexpr int STEPS = NCHUNK == 1 ? 3 * RSTEPS : (NCHUNK == 3 ? RSTEPS : RSTEPS / 2);              // k-steps per chunk
+  static constexpr int WPITCH = STEPS * 32 + 16;
+  static constexpr int W_LDS = COUT_WG * WPITCH;
+  static constexpr int LDS = TILE_LDS + W_LDS;
+  static constexpr int BPI = HO / ROWS;                                                                     // blocks per image (G = 1)
+  static_assert(LDS * WPE <= 160 * 1024, "LDS budget of WPE workgroups per CU");
+};
+
+// (HIP's second launch-bounds argument: minimum waves per execution unit -- without it the fully unrolled k loop takes all 512 registers)
+template <class C>
+__global__ __launch_bounds__(256, C::WPE) void conv2d_q8t_kernel(const ConvQ8Args a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float red[8];
+  uint8_t* tile = smem;
+  uint8_t* wl = smem + C::TILE_LDS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pt = wave % C::PW, cw = wave / C::PW;
+  const int s = blockIdx.z, cg = blockIdx.y;
+  constexpr int K = 9 * C::CIN;
+  const int8_t* xs = a.x + (int64_t)s * a.x_ss;
+  const int8_t* ws = a.w + (int64_t)s * a.w_ss;
+  const int nblocks = C::G == 1 ? a.B * C::BPI : (a.B + C::G - 1) / C::G;
+  const int b0 = blockIdx.x * C::IT;
+
+  for (int i = tid; i < C::TILE_LDS / 16; i += 256) reinterpret_cast<v4i_q8*>(tile)[i] = v4i_q8{0, 0, 0, 0};      // halo columns + slack stay 0
+
+  // this lane's output pixel inside a block, its window's tap (0, 0) in the tile, its weight row
+  const int q = pt * 32 + (lane & 31), h = lane >> 5;
+  const int qg = q / (C::ROWS * C::WO), qr = (q / C::WO) % C::ROWS, qc = q % C::WO;
+  const int boff = ((qg * C::RI + qr * C::STRIDE) * C::CI + qc * C::STRIDE) * C::CIN + 16 * h;
+  const int aoff = (lane & 31) * C::WPITCH + 16 * h;
+  const double sp = (double)a.s_x[s] * (double)a.s_w[s];
+  const int zw = a.z_w[s];
+  float vmin = INFINITY, vmax = -INFINITY;
+
+  auto stage_w = [&](int ch) {
+    constexpr int ROWS_CH = C::NCHUNK == 1 ? 3 : 1;
+    constexpr int SEG = C::NCHUNK == 6 ? C::ROWPAD / 2 : C::ROWPAD;             // LDS bytes per (channel, kernel row) of a chunk
+    constexpr int SEG_VALID = C::NCHUNK == 6 ? C::ROWB / 2 : C::ROWB;           // ... of which come from the weights (the rest: zeros)
+    constexpr int UPS = SEG / C::U;
+    for (int u = tid; u < C::COUT_WG * ROWS_CH * UPS; u += 256) {
+      const int n = u / (ROWS_CH * UPS), rr = (u / UPS) % ROWS_CH, j = u % UPS;
+      const int kh = C::NCHUNK == 1 ? rr : (C::NCHUNK == 3 ? ch : ch / 2);
+      const int srcoff = (C::NCHUNK == 6 ? (ch % 2) * SEG_VALID : 0) + j * C::U;
+      const int ng = cg * C::COUT_WG + n;
+      const bool ok = j * C::U < SEG_VALID && ng < a.Cout;
+      const int8_t* src = ws + (int64_t)(ok ? ng : 0) * K + kh * C::ROWB + (ok ? srcoff : 0);
+      uint8_t* dst = wl + n * C::WPITCH + rr * C::ROWPAD + j * C::U;
+      if constexpr (C::U == 16) {
+        v4i_q8 v = *reinterpret_cast<const v4i_q8*>(src);
+        if (!ok) v = v4i_q8{0, 0, 0, 0};
+        *reinterpret_cast<v4i_q8*>(dst) = v;
+      } else {
+        v2i_q8 v = *reinterpret_cast<const v2i_q8*>(src);
+        if (!ok) v = v2i_q8{0, 0};
+        *reinterpret_cast<v2i_q8*>(dst) = v;
+      }
+    }
+  };
+
+  for (int it = 0; it < C::IT; ++it) {
+    const int blk = b0 + it;
+    if (blk >= nblocks) break;                                  // workgroup-uniform
+    const int img0 = C::G == 1 ? blk / C::BPI : blk * C::G;
+    const int oh0 = C::G == 1 ? (blk % C::BPI) * C::ROWS : 0;
+    __syncthreads();                                            // the previous block's fragment reads (first block: the zero fill) are done
+    {
+      constexpr int UPR = C::W_IN * C::CIN / C::U;             // staging units per input row
+      for (int u = tid; u < C::G * C::RI * UPR; u += 256) {
+        const int g = u / (C::RI * UPR), r = (u / UPR) % C::RI, j = u % UPR;
+        const int ih = oh0 * C::STRIDE - 1 + r, img = img0 + g;
+        const bool ok = (unsigned)ih < (unsigned)C::H_IN && img < a.B;      // rows above / below the map, images beyond a ragged batch: m_x = 0
+        const int8_t* src = xs + (((int64_t)(ok ? img : 0) * C::H_IN + (ok ? ih : 0)) * C::W_IN) * C::CIN + j * C::U;
+        uint8_t* dst = tile + ((g * C::RI + r) * C::CI + 1) * C::CIN + j * C::U;
+        if constexpr (C::U == 16) {
+          v4i_q8 v = *reinterpret_cast<const v4i_q8*>(src);
+          if (!ok) v = v4i_q8{0, 0, 0, 0};
+          *reinterpret_cast<v4i_q8*>(dst) = v;
+        } else {
+          v2i_q8 v = *reinterpret_cast<const v2i_q8*>(src);
+          if (!ok) v = v2i_q8{0, 0};
+          *reinterpret_cast<v2i_q8*>(dst) = v;
+        }
+      }
+    }
+    if (C::NCHUNK == 1 && it == 0) stage_w(0);                 // the whole conv's weights: once per workgroup
+
+    v16i_q8 acc[C::NTW];
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[j][i] = 0;
+    int rsum = 0;
+#pragma unroll
+    for (int ch = 0; ch < C::NCHUNK; ++ch) {
+      if (C::NCHUNK > 1) {
+        if (ch > 0) __syncthreads();                            // the previous chunk's weight reads are done
+        stage_w(ch);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < C::STEPS; ++i) {
+        const int kh = C::NCHUNK == 1 ? i / C::RSTEPS : (C::NCHUNK == 3 ? ch : ch / 2);
+        const int t = C::NCHUNK == 1 ? i % C::RSTEPS : (C::NCHUNK == 3 ? i : (ch % 2) * C::STEPS + i);
+        const uint8_t* bp = tile + boff + kh * C::CI * C::CIN + 32 * t;
+        v4i_q8 bv;
+        if constexpr (C::U == 16) bv = *reinterpret_cast<const v4i_q8*>(bp);
+        else {
+          const v2i_q8 lo = *reinterpret_cast<const v2i_q8*>(bp), hi = *reinterpret_cast<const v2i_q8*>(bp + 8);
+          bv = v4i_q8{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          int v = bv[d];
+          if (32 * t + 32 > C::ROWB) v = (32 * t + 16 * h + 4 * d + 4 <= C::ROWB) ? v : 0;      // the row's padded tail reads the next pixels: not in the window
+          rsum = __builtin_amdgcn_sdot4(v, 0x01010101, rsum, false);
+        }
+#pragma unroll
+        for (int j = 0; j < C::NTW; ++j) {
+          const v4i_q8 av = *reinterpret_cast<const v4i_q8*>(wl + aoff + (cw + C::CW * j) * 32 * C::WPITCH + 32 * i);
+          acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    // epilogue: conv2d_q8v_kernel's, step for step
+    const int R = rsum + __shfl_xor(rsum, 32);
+    const int img = img0 + qg;
+    if (img < a.B) {
+      const int64_t po = ((int64_t)img * C::HO + oh0 + qr) * C::WO + qc;
+      const int zwr = zw * R;
+      float* yp = a.y + (int64_t)s * a.y_ss + po * a.Cout;
+#pragma unroll
+      for (int j = 0; j < C::NTW; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = cg * C::COUT_WG + (cw + C::CW * j) * 32 + 8 * g + 4 * h;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int no = nb + i, nc = no < a.Cout ? no : 0;
+            float tt = (float)((double)(acc[j][4 * g + i] - zwr) * sp);
+            if (a.div) tt = tt / a.div[nc];
+            if (a.bias) tt = tt + a.bias[nc];
+            if (a.alpha) tt = tt * a.alpha[nc];
+            if (a.beta) tt = tt + a.beta[nc];
+            if (a.relu) tt = fmaxf(tt, 0.f);
+            v[i] = tt;
+            if (no < a.Cout) { vmin = fminf(vmin, tt); vmax = fmaxf(vmax, tt); }
+          }
+          if (nb + 3 < a.Cout && (a.Cout & 3) == 0) *reinterpret_cast<v4f_q8*>(yp + nb) = v4f_q8{v[0], v[1], v[2], v[3]};
+          else
+            for (int i = 0; i < 4; ++i)
+              if (nb + i < a.Cout) yp[nb + i] = v[i];
+        }
+    }
+  }
+  if (a.mm_partials) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o)); }
+    if (lane == 0) { red[2 * wave] = vmin; red[2 * wave + 1] = vmax; }
+    __syncthreads();
+    if (tid == 0) {
+      const int64_t slot = ((int64_t)s * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      a.mm_partials[2 * slot] = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
+      a.mm_partials[2 * slot + 1] = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+    }
+  }
+}
+
+//                   Cin  s  Wo  G rows NTW CW chunks IT WPE
+using T_L1 = Q8TCfg<24, 1, 32, 1, 4, 1, 1, 1, 8, 4>;        // 32 x 32 x 24 -> 24 (.. 32 channels): one image per workgroup
+using T_D24 = Q8TCfg<24, 2, 16, 1, 8, 2, 1, 1, 2, 4>;       // 32 x 32 x 24 -> 16 x 16 x 48 (.. 64)
+using T_C48 = Q8TCfg<48, 1, 16, 1, 8, 2, 1, 1, 2, 3>;       // 16 x 16 x 48 -> 48 (.. 64)
+using T_D48 = Q8TCfg<48, 2, 8, 2, 8, 3, 1, 1, 1, 2>;        // 16 x 16 x 48 -> 8 x 8 x 96
+using T_C96 = Q8TCfg<96, 1, 8, 2, 8, 3, 1, 3, 1, 3>;        // 8 x 8 x 96 -> 96
+using T_D96 = Q8TCfg<96, 2, 4, 8, 4, 3, 1, 3, 1, 1>;        // 8 x 8 x 96 -> 4 x 4 x 192: two channel groups of 96
+using T_C192 = Q8TCfg<192, 1, 4, 8, 4, 3, 1, 6, 1, 1>;      // 4 x 4 x 192 -> 192: two channel groups of 96
+
+bool tiled_on() {
+  static const bool on = [] { const char* e = getenv("QBNN_Q8_TILED"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+template <class C> bool match(int H, int W, int Cin, int stride) { return H == C::H_IN && W == C::W_IN && Cin == C::CIN && stride == C::STRIDE; }
+template <class C> void grid_of(int B, int Cout, int& gx, int& gy) {
+  const int nblocks = C::G == 1 ? B * C::BPI : (B + C::G - 1) / C::G;
+  gx = (nblocks + C::IT - 1) / C::IT;
+  gy = (Cout + C::COUT_WG - 1) / C::COUT_WG;
+}
+template <class C> int launch(const ConvQ8Args& a, int n_samples, hipStream_t st) {
+  static std::atomic<uint64_t> attr{0};
+  if (int rc = qbnn_ensure_dyn_lds((const void*)conv2d_q8t_kernel<C>, &attr, C::LDS)) return rc;
+  int gx, gy;
+  grid_of<C>(a.B, a.Cout, gx, gy);
+  hipLaunchKernelGGL(conv2d_q8t_kernel<C>, dim3(gx, gy, n_samples), dim3(256), C::LDS, st, a);
+  return qbnn_check_launch_msg("qbnn_conv2d_q8_f32_mc");
+}
+
+#define Q8T_FOR_EACH(X) X(T_L1) X(T_D24) X(T_C48) X(T_D48) X(T_C96) X(T_D96) X(T_C192)
+
+}  // namespace
+
+int qbnn_conv_q8t_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad) {
+  if (!tiled_on() || ksize != 3 || pad != 1 || B <= 0 || Cout <= 0) return 0;
+  int gx = 0, gy = 0;
+#define X(C) if (match<C>(H, W, Cin, stride)) { grid_of<C>(B, Cout, gx, gy); return gx * gy; }
+  Q8T_FOR_EACH(X)
+#undef X
+  return 0;
+}
+
+int qbnn_launch_conv_q8t(const ConvQ8Args& a, int n_samples, hipStream_t st) {
+#define X(C) if (match<C>(a.H, a.W, a.Cin, a.stride)) return launch<C>(a, n_samples, st);
+  Q8T_FOR_EACH(X)
+#undef X
+  return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: no tiled form for this geometry");
+}
