@@ -474,7 +474,8 @@ int qbnn_observe_partials_f32_mc(const float* partials, int32_t n_blocks, int32_
  *   qbnn_conv2d_q8_f32_mc: x int8 [S][B][H][W][Cin] centred, w int8 [S][Cout][k][k][Cin] raw, s_x / s_w / z_w per sample; y fp32 [S][B][Ho][Wo][Cout]. */
 /* qbnn_fake_quant_f32_mc with the ReLU that follows it in the graph (BasicBlock: Add -> FakeQuantize -> ReLU) and, optionally, the grid integers
  * q - z (after the ReLU) as int8 [S][n]: the activation operand of qbnn_conv2d_q8_f32_mc without a qbnn_grid_to_i8_mc pass (qmax - qmin <= 127, as q - z
- * spans +-(qmax - qmin); QBNN_E_INVALID for a wider grid). */
+ * spans +-(qmax - qmin); QBNN_E_INVALID for a wider grid).  y may be NULL when q8_out is given (round 6): where every consumer takes the grid
+ * integers -- a conv on the int8 pipe, qbnn_add_q8_f32_mc -- the fp32 tensor is never written. */
 int qbnn_fake_quant_ex_f32_mc(const float* x, int64_t x_sample_stride, float* y, int64_t y_sample_stride, int64_t n, const float* scale,
                               const int32_t* zero_point, int32_t qmin, int32_t qmax, int32_t relu, int8_t* q8_out, int32_t n_samples, void* stream);
 int qbnn_grid_to_i8_mc(const float* x, int64_t x_sample_stride, int64_t n, const float* scale, const int32_t* zero_point, int8_t* out,
@@ -484,6 +485,14 @@ int qbnn_conv2d_q8_f32_mc(const int8_t* x, int64_t x_sample_stride, const int8_t
                           const int32_t* z_w, const float* div, const float* bias, const float* alpha, const float* beta, float* y,
                           int64_t y_sample_stride, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
                           int32_t pad, int32_t relu, int32_t n_samples, float* minmax_partials, void* stream);
+
+/* FloatFunctional.add (src/utils.py:49-55 `Add`; models_bbb.py:178 out + shortcut) of two fake-quantised tensors given as grid integers (round 6):
+ * y[s][i] = fl32((float)a[s][i] * s_a[s]) + fl32((float)b[s][i] * s_b[s]) -- each addend is the fp32 value its FakeQuantize would have written, so
+ * the sum equals the fp32 Add bit for bit --, plus the (min, max) of each of the qbnn_add_q8_blocks(n) workgroups' sums per sample for the Add's observer
+ * (minmax_partials [S][blocks][2], may be NULL).  a / b sample stride 0 shares the operand. */
+int32_t qbnn_add_q8_blocks(int64_t n);
+int qbnn_add_q8_f32_mc(const int8_t* a, int64_t a_sample_stride, const float* s_a, const int8_t* b, int64_t b_sample_stride, const float* s_b, float* y,
+                       int64_t y_sample_stride, int64_t n, int32_t n_samples, float* minmax_partials, void* stream);
 
 /* Pointwise on [S][n] with the channel as fastest axis:  v = (mode 0) x * p0[c] + p1[c]  |  (mode 1) x / p0[c] + p1[c]
  * (p0 / p1 NULL skip that step), v += res (if given), ReLU (if asked).  nn.BatchNorm2d in eval (x * alpha + beta as ATen

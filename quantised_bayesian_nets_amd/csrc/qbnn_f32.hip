@@ -702,14 +702,14 @@ __global__ __launch_bounds__(256) void fake_quant_ex_f32_kernel(const float* __r
         v[k] = m * sc;
         pk |= ((uint32_t)(int)m & 0xffu) << (8 * k);
       }
-      y4[i] = v;
+      if (y) y4[i] = v;            // (y NULL: the consumers take the int8 grid tensor + the per-sample scale -- round 6)
       if (q4) q4[i] = pk;
     }
     return;
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float m = fmaxf(fminf(fmaxf(rintf(x[(int64_t)s * x_ss + i] * inv) + z, lo), hi) - z, mlo);
-    y[(int64_t)s * y_ss + i] = m * sc;
+    if (y) y[(int64_t)s * y_ss + i] = m * sc;
     if (q8) q8[(int64_t)s * n + i] = (int8_t)(int)m;
   }
 }
@@ -717,13 +717,77 @@ __global__ __launch_bounds__(256) void fake_quant_ex_f32_kernel(const float* __r
 QBNN_EXPORT int qbnn_fake_quant_ex_f32_mc(const float* x, int64_t x_ss, float* y, int64_t y_ss, int64_t n, const float* scale,
                                           const int32_t* zero_point, int32_t qmin, int32_t qmax, int32_t relu, int8_t* q8_out, int32_t n_samples,
                                           void* stream) {
-  if (!x || !y || !scale || !zero_point || n <= 0 || n_samples <= 0 || qmax <= qmin)
+  if (!x || (!y && !q8_out) || !scale || !zero_point || n <= 0 || n_samples <= 0 || qmax <= qmin)
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_ex_f32_mc: bad argument");
   if (q8_out && qmax - qmin > 127) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_ex_f32_mc: the int8 output (q - z) takes grids of at most 128 steps (qmax - qmin <= 127)");
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(fake_quant_ex_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, y, y_ss, n, scale, zero_point,
                      qmin, qmax, relu, q8_out);
   return qbnn_check_launch_msg("qbnn_fake_quant_ex_f32_mc");
+}
+
+// FloatFunctional.add of two fake-quantised tensors given as their grid integers (src/utils.py:49-55 `Add`, BasicBlock's out + shortcut in the prepared
+// graph): y[s][i] = fl32((float)a[s][i] * s_a[s]) + fl32((float)b[s][i] * s_b[s]) -- each addend is exactly the fp32 value its FakeQuantize would have
+// written ((q - z) * scale), so the sum equals the fp32 Add bit for bit while the operands cost 1 byte per element instead of 4 --, with the
+// per-workgroup (min, max) of the sums for the Add's own observer (no separate min / max pass over y).
+__global__ __launch_bounds__(256) void add_q8_f32_kernel(const int8_t* __restrict__ a, int64_t a_ss, const float* __restrict__ sa, const int8_t* __restrict__ b,
+                                                          int64_t b_ss, const float* __restrict__ sb, float* __restrict__ y, int64_t y_ss, int64_t n,
+                                                          float* __restrict__ partials) {
+  __shared__ float red[8];
+  const int s = blockIdx.y, tid = threadIdx.x;
+  const float fa = sa[s], fb = sb[s];
+  const int8_t* as = a + (int64_t)s * a_ss;
+  const int8_t* bs = b + (int64_t)s * b_ss;
+  float* ys = y + (int64_t)s * y_ss;
+  float vmin = INFINITY, vmax = -INFINITY;
+  const bool vec = (n & 15) == 0 && ((a_ss | b_ss) & 15) == 0 && (y_ss & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  if (vec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n / 16; i += (int64_t)gridDim.x * 256) {
+      const v4i_q8 av = reinterpret_cast<const v4i_q8*>(as)[i], bv = reinterpret_cast<const v4i_q8*>(bs)[i];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        v4f o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float t = (float)(int8_t)(av[d] >> (8 * k)) * fa + (float)(int8_t)(bv[d] >> (8 * k)) * fb;
+          o[k] = t;
+          vmin = fminf(vmin, t); vmax = fmaxf(vmax, t);
+        }
+        reinterpret_cast<v4f*>(ys)[i * 4 + d] = o;
+      }
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+      const float t = (float)as[i] * fa + (float)bs[i] * fb;
+      ys[i] = t;
+      vmin = fminf(vmin, t); vmax = fmaxf(vmax, t);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o)); }
+  if ((tid & 63) == 0) { red[2 * (tid >> 6)] = vmin; red[2 * (tid >> 6) + 1] = vmax; }
+  __syncthreads();
+  if (tid == 0 && partials) {
+    const int64_t slot = (int64_t)s * gridDim.x + blockIdx.x;
+    partials[2 * slot] = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
+    partials[2 * slot + 1] = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+  }
+}
+
+// workgroups per sample of qbnn_add_q8_f32_mc = length of one sample's row of `minmax_partials`
+QBNN_EXPORT int32_t qbnn_add_q8_blocks(int64_t n) {
+  if (n <= 0) return 0;
+  const int64_t b = (n / 16 + 255) / 256;
+  return (int32_t)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+
+QBNN_EXPORT int qbnn_add_q8_f32_mc(const int8_t* a, int64_t a_ss, const float* s_a, const int8_t* b, int64_t b_ss, const float* s_b, float* y, int64_t y_ss,
+                                   int64_t n, int32_t n_samples, float* minmax_partials, void* stream) {
+  if (!a || !b || !s_a || !s_b || !y || n <= 0 || n_samples <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_add_q8_f32_mc: bad argument");
+  hipLaunchKernelGGL(add_q8_f32_kernel, dim3(qbnn_add_q8_blocks(n), n_samples), dim3(256), 0, (hipStream_t)stream, a, a_ss, s_a, b, b_ss, s_b, y, y_ss, n,
+                     minmax_partials);
+  return qbnn_check_launch_msg("qbnn_add_q8_f32_mc");
 }
 
 QBNN_EXPORT int qbnn_fake_quant_f32_mc(const float* x, int64_t x_ss, float* y, int64_t y_ss, int64_t n, const float* scale,
@@ -1038,9 +1102,8 @@ QBNN_EXPORT int qbnn_conv2d_q8_f32_mc(const int8_t* x, int64_t x_ss, const int8_
   if ((int64_t)ksize * ksize * Cin * 127 * 128 >= (1ll << 31)) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: K too large for int32 sums");
   if (qbnn_conv_q8t_blocks(B, H, W, Cin, Cout, ksize, stride, pad) > 0) {
     // (the grid qbnn_conv2d_q8_blocks promises the observer is the tiled form's: no other form may serve this geometry)
-    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 && (x_ss % 16) == 0 && (w_ss % 16) == 0 &&
-                    ((Cout & 3) != 0 || ((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_ss % 4) == 0));
-    if (!al) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: the tiled 3 x 3 form takes 16-byte aligned operands (and outputs when Cout % 4 == 0)");
+    if (!qbnn_conv_q8t_aligned(a))
+      return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_conv2d_q8_f32_mc: the tiled 3 x 3 form takes 16-byte aligned operands, outputs and per-channel parameters (8-byte operands at Cin = 24)");
     return qbnn_launch_conv_q8t(a, n_samples, (hipStream_t)stream);
   }
   const int64_t npix = (int64_t)B * a.Ho * a.Wo;

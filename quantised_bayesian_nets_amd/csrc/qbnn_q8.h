@@ -21,6 +21,7 @@ typedef int v2i_q8 __attribute__((ext_vector_type(2)));
 
 // qbnn_q8t.hip: workgroups per sample of the tiled form for this geometry, 0 where it has none (the caller then takes a gather form)
 int qbnn_conv_q8t_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad);
-// launches it (grid = qbnn_conv_q8t_blocks x n_samples); the caller has checked pointers and alignment (conv_q8t_aligned)
+bool qbnn_conv_q8t_aligned(const ConvQ8Args& a);      // operand / output alignment that form needs
+// launches it (grid = qbnn_conv_q8t_blocks x n_samples); the caller has checked pointers and qbnn_conv_q8t_aligned
 int qbnn_launch_conv_q8t(const ConvQ8Args& a, int n_samples, hipStream_t st);
 #endif

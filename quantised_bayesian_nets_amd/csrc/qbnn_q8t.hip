@@ -25,6 +25,51 @@ namespace {
 
 typedef float v4f_q8 __attribute__((ext_vector_type(4)));
 
+// One accumulator tile (this lane: pixel `lane & 31`, channels nb0 + 8 g + 4 h + {0..3}) through conv2d_q8v_kernel's tail, step for step:
+// fl32(fl64(N - z_w R) * fl64(s_x s_w)), / div, + bias, * alpha, + beta, ReLU; float4 stores; running (min, max) of what was stored.
+__device__ __forceinline__ void q8_tail_tile(const ConvQ8Args& a, const v16i_q8& acc, int zwr, double sp, int nb0, int h, float* yp, float& vmin, float& vmax) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int nb = nb0 + 8 * g + 4 * h;
+    const bool full = nb < a.Cout;          // Cout % 4 == 0 (the launcher checks): this lane's four channels exist together, as 16-byte aligned float4s
+    const int np = full ? nb : 0;
+    v4f_q8 pd{1.f, 1.f, 1.f, 1.f}, pb{0.f, 0.f, 0.f, 0.f}, pa = pb, pe = pb;
+    if (a.div) pd = *reinterpret_cast<const v4f_q8*>(a.div + np);
+    if (a.bias) pb = *reinterpret_cast<const v4f_q8*>(a.bias + np);
+    if (a.alpha) pa = *reinterpret_cast<const v4f_q8*>(a.alpha + np);
+    if (a.beta) pe = *reinterpret_cast<const v4f_q8*>(a.beta + np);
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float tt = (float)((double)(acc[4 * g + i] - zwr) * sp);
+      if (a.div) tt = tt / pd[i];
+      if (a.bias) tt = tt + pb[i];
+      if (a.alpha) tt = tt * pa[i];
+      if (a.beta) tt = tt + pe[i];
+      if (a.relu) tt = fmaxf(tt, 0.f);
+      v[i] = tt;
+      if (full) { vmin = fminf(vmin, tt); vmax = fmaxf(vmax, tt); }
+    }
+    if (full) *reinterpret_cast<v4f_q8*>(yp + nb) = v4f_q8{v[0], v[1], v[2], v[3]};
+    __builtin_amdgcn_sched_barrier(0);      // one channel group at a time (the unrolled tail otherwise loads every group's parameters up front)
+  }
+}
+
+// the workgroup's (min, max) of everything it stored -> its slot of the observer's partials
+__device__ __forceinline__ void q8_write_partials(const ConvQ8Args& a, float vmin, float vmax, float* red, int s) {
+  if (!a.mm_partials) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o)); }
+  if (lane == 0) { red[2 * wave] = vmin; red[2 * wave + 1] = vmax; }
+  __syncthreads();
+  if (tid == 0) {
+    const int64_t slot = ((int64_t)s * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    a.mm_partials[2 * slot] = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
+    a.mm_partials[2 * slot + 1] = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+  }
+}
+
 template <int CIN_, int STRIDE_, int WO_, int G_, int ROWS_, int NTW_, int CW_, int NCHUNK_, int IT_, int WPE_>
 struct Q8TCfg {
   static constexpr int WPE = WPE_;            // waves per SIMD the kernel is compiled for (= workgroups per CU: 512 / WPE registers, 160 KiB / WPE of LDS)
@@ -140,17 +185,27 @@ __global__ __launch_bounds__(256, C::WPE) void conv2d_q8t_kernel(const ConvQ8Arg
         stage_w(ch);
       }
       __syncthreads();
-#pragma unroll
-      for (int i = 0; i < C::STEPS; ++i) {
+      // One k-step ahead: the fragments of step i + 1 are requested before the MFMAs of step i (a scheduling fence per step keeps the compiler
+      // from hoisting every LDS read of the unrolled chunk to its top -- 500+ registers, or spills under the occupancy bound).
+      v4i_q8 bq[2], aq[2][C::NTW];
+      auto fetch = [&](int i, int slot) {
         const int kh = C::NCHUNK == 1 ? i / C::RSTEPS : (C::NCHUNK == 3 ? ch : ch / 2);
         const int t = C::NCHUNK == 1 ? i % C::RSTEPS : (C::NCHUNK == 3 ? i : (ch % 2) * C::STEPS + i);
         const uint8_t* bp = tile + boff + kh * C::CI * C::CIN + 32 * t;
-        v4i_q8 bv;
-        if constexpr (C::U == 16) bv = *reinterpret_cast<const v4i_q8*>(bp);
+        if constexpr (C::U == 16) bq[slot] = *reinterpret_cast<const v4i_q8*>(bp);
         else {
           const v2i_q8 lo = *reinterpret_cast<const v2i_q8*>(bp), hi = *reinterpret_cast<const v2i_q8*>(bp + 8);
-          bv = v4i_q8{lo.x, lo.y, hi.x, hi.y};
+          bq[slot] = v4i_q8{lo.x, lo.y, hi.x, hi.y};
         }
+#pragma unroll
+        for (int j = 0; j < C::NTW; ++j) aq[slot][j] = *reinterpret_cast<const v4i_q8*>(wl + aoff + (cw + C::CW * j) * 32 * C::WPITCH + 32 * i);
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int i = 0; i < C::STEPS; ++i) {
+        const int t = C::NCHUNK == 1 ? i % C::RSTEPS : (C::NCHUNK == 3 ? i : (ch % 2) * C::STEPS + i);
+        if (i + 1 < C::STEPS) fetch(i + 1, (i + 1) & 1);
+        const v4i_q8 bv = bq[i & 1];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           int v = bv[d];
@@ -158,10 +213,8 @@ __global__ __launch_bounds__(256, C::WPE) void conv2d_q8t_kernel(const ConvQ8Arg
           rsum = __builtin_amdgcn_sdot4(v, 0x01010101, rsum, false);
         }
 #pragma unroll
-        for (int j = 0; j < C::NTW; ++j) {
-          const v4i_q8 av = *reinterpret_cast<const v4i_q8*>(wl + aoff + (cw + C::CW * j) * 32 * C::WPITCH + 32 * i);
-          acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc[j], 0, 0, 0);
-        }
+        for (int j = 0; j < C::NTW; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[i & 1][j], bv, acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // epilogue: conv2d_q8v_kernel's, step for step
@@ -172,49 +225,87 @@ __global__ __launch_bounds__(256, C::WPE) void conv2d_q8t_kernel(const ConvQ8Arg
       const int zwr = zw * R;
       float* yp = a.y + (int64_t)s * a.y_ss + po * a.Cout;
 #pragma unroll
-      for (int j = 0; j < C::NTW; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nb = cg * C::COUT_WG + (cw + C::CW * j) * 32 + 8 * g + 4 * h;
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int no = nb + i, nc = no < a.Cout ? no : 0;
-            float tt = (float)((double)(acc[j][4 * g + i] - zwr) * sp);
-            if (a.div) tt = tt / a.div[nc];
-            if (a.bias) tt = tt + a.bias[nc];
-            if (a.alpha) tt = tt * a.alpha[nc];
-            if (a.beta) tt = tt + a.beta[nc];
-            if (a.relu) tt = fmaxf(tt, 0.f);
-            v[i] = tt;
-            if (no < a.Cout) { vmin = fminf(vmin, tt); vmax = fmaxf(vmax, tt); }
-          }
-          if (nb + 3 < a.Cout && (a.Cout & 3) == 0) *reinterpret_cast<v4f_q8*>(yp + nb) = v4f_q8{v[0], v[1], v[2], v[3]};
-          else
-            for (int i = 0; i < 4; ++i)
-              if (nb + i < a.Cout) yp[nb + i] = v[i];
-        }
+      for (int j = 0; j < C::NTW; ++j) q8_tail_tile(a, acc[j], zwr, sp, cg * C::COUT_WG + (cw + C::CW * j) * 32, h, yp, vmin, vmax);
     }
   }
-  if (a.mm_partials) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o)); }
-    if (lane == 0) { red[2 * wave] = vmin; red[2 * wave + 1] = vmax; }
+  q8_write_partials(a, vmin, vmax, red, s);
+}
+
+// layers.0: 3 -> Cout <= 32 channels on a 32 x 32 map (K = 27: one k-step).  A 3-channel pixel is 3 bytes, so nothing about a window is aligned;
+// the workgroup stages 6 input rows (96 B each, at a 16-byte aligned interior offset of a 128-byte pitch, halo bytes zero), every thread then
+// assembles half of one output pixel's 27-byte patch (+ 5 zeros) from LDS bytes into a [128 pixels][32 B] operand matrix -- the im2col the
+// int8 product path does once per batch (qbnn_im2col3x3_c3), here per block in LDS because every MC sample has its own input grid.
+struct T_C3 { static constexpr int IT = 8, ROWS = 4, HW = 32, PITCH = 128, IN0 = 16, RI = 6, PP = 48, WPITCH = 48; };
+__global__ __launch_bounds__(256, 4) void conv2d_q8_c3_kernel(const ConvQ8Args a) {
+  using C = T_C3;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[C::RI * C::PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t pm[128 * C::PP];          // patches [pixel][32 B] (pitch 48)
+  __shared__ __attribute__((aligned(16))) uint8_t wl[32 * C::WPITCH];        // weights [channel][32 B]
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int s = blockIdx.z;
+  const int8_t* xs = a.x + (int64_t)s * a.x_ss;
+  const int8_t* ws = a.w + (int64_t)s * a.w_ss;
+  const int nblocks = a.B * (C::HW / C::ROWS), b0 = blockIdx.x * C::IT;
+  for (int i = tid; i < C::RI * C::PITCH / 4; i += 256) reinterpret_cast<int*>(tile)[i] = 0;
+  for (int i = tid; i < 32 * C::WPITCH / 4; i += 256) reinterpret_cast<int*>(wl)[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < 32 * 27; i += 256) {
+    const int n = i / 27, k = i - n * 27;
+    if (n < a.Cout) wl[n * C::WPITCH + k] = (uint8_t)ws[n * 27 + k];
+  }
+  const double sp = (double)a.s_x[s] * (double)a.s_w[s];
+  const int zw = a.z_w[s];
+  float vmin = INFINITY, vmax = -INFINITY;
+  for (int it = 0; it < C::IT; ++it) {
+    const int blk = b0 + it;
+    if (blk >= nblocks) break;
+    const int img = blk / (C::HW / C::ROWS), oh0 = (blk % (C::HW / C::ROWS)) * C::ROWS;
+    __syncthreads();                              // the previous block's patch assembly is done with the tile (first block: zero fill, weights)
+    if (tid < C::RI * 6) {                        // 6 rows x 6 units of 16 B
+      const int r = tid / 6, j = tid - r * 6, ih = oh0 - 1 + r;
+      const bool ok = (unsigned)ih < (unsigned)C::HW;
+      v4i_q8 v = *reinterpret_cast<const v4i_q8*>(xs + (((int64_t)img * C::HW + (ok ? ih : 0)) * C::HW) * 3 + j * 16);
+      if (!ok) v = v4i_q8{0, 0, 0, 0};
+      *reinterpret_cast<v4i_q8*>(tile + r * C::PITCH + C::IN0 + j * 16) = v;
+    }
     __syncthreads();
-    if (tid == 0) {
-      const int64_t slot = ((int64_t)s * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      a.mm_partials[2 * slot] = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
-      a.mm_partials[2 * slot + 1] = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+    {                                             // patch bytes [16 part, 16 part + 16) of pixel q: k = kh 9 + kw 3 + c  <-  tile[(r + kh)][IN0 - 3 + 3 c0 + (k - 9 kh)]
+      const int q = tid & 127, part = tid >> 7, r = q >> 5, c0 = q & 31;
+      uint32_t wds[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const int k = 16 * part + b;
+        if (k < 27) {
+          const int kh = k / 9, j = k - 9 * kh;
+          wds[b >> 2] |= (uint32_t)tile[(r + kh) * C::PITCH + C::IN0 - 3 + 3 * c0 + j] << (8 * (b & 3));
+        }
+      }
+      *reinterpret_cast<v4i_q8*>(pm + q * C::PP + 16 * part) = v4i_q8{(int)wds[0], (int)wds[1], (int)wds[2], (int)wds[3]};
     }
+    __syncthreads();
+    const v4i_q8 bv = *reinterpret_cast<const v4i_q8*>(pm + (wave * 32 + (lane & 31)) * C::PP + 16 * h);
+    const v4i_q8 av = *reinterpret_cast<const v4i_q8*>(wl + (lane & 31) * C::WPITCH + 16 * h);
+    v16i_q8 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc, 0, 0, 0);
+    int rsum = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) rsum = __builtin_amdgcn_sdot4(bv[d], 0x01010101, rsum, false);      // (the pad bytes are zeros)
+    const int R = rsum + __shfl_xor(rsum, 32);
+    const int64_t po = ((int64_t)img * C::HW + oh0 + wave) * C::HW + (lane & 31);
+    q8_tail_tile(a, acc, zw * R, sp, 0, h, a.y + (int64_t)s * a.y_ss + po * a.Cout, vmin, vmax);
   }
+  q8_write_partials(a, vmin, vmax, red, s);
 }
 
 //                   Cin  s  Wo  G rows NTW CW chunks IT WPE
 using T_L1 = Q8TCfg<24, 1, 32, 1, 4, 1, 1, 1, 8, 4>;        // 32 x 32 x 24 -> 24 (.. 32 channels): one image per workgroup
-using T_D24 = Q8TCfg<24, 2, 16, 1, 8, 2, 1, 1, 2, 4>;       // 32 x 32 x 24 -> 16 x 16 x 48 (.. 64)
+using T_D24 = Q8TCfg<24, 2, 16, 1, 8, 2, 1, 1, 2, 3>;       // 32 x 32 x 24 -> 16 x 16 x 48 (.. 64)
 using T_C48 = Q8TCfg<48, 1, 16, 1, 8, 2, 1, 1, 2, 3>;       // 16 x 16 x 48 -> 48 (.. 64)
 using T_D48 = Q8TCfg<48, 2, 8, 2, 8, 3, 1, 1, 1, 2>;        // 16 x 16 x 48 -> 8 x 8 x 96
-using T_C96 = Q8TCfg<96, 1, 8, 2, 8, 3, 1, 3, 1, 3>;        // 8 x 8 x 96 -> 96
+using T_C96 = Q8TCfg<96, 1, 8, 2, 8, 3, 1, 3, 1, 2>;        // 8 x 8 x 96 -> 96
 using T_D96 = Q8TCfg<96, 2, 4, 8, 4, 3, 1, 3, 1, 1>;        // 8 x 8 x 96 -> 4 x 4 x 192: two channel groups of 96
 using T_C192 = Q8TCfg<192, 1, 4, 8, 4, 3, 1, 6, 1, 1>;      // 4 x 4 x 192 -> 192: two channel groups of 96
 
@@ -242,8 +333,11 @@ template <class C> int launch(const ConvQ8Args& a, int n_samples, hipStream_t st
 
 }  // namespace
 
+static bool match_c3(int H, int W, int Cin, int Cout, int stride) { return H == 32 && W == 32 && Cin == 3 && stride == 1 && Cout <= 32; }
+
 int qbnn_conv_q8t_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad) {
-  if (!tiled_on() || ksize != 3 || pad != 1 || B <= 0 || Cout <= 0) return 0;
+  if (!tiled_on() || ksize != 3 || pad != 1 || B <= 0 || Cout <= 0 || (Cout & 3) != 0) return 0;
+  if (match_c3(H, W, Cin, Cout, stride)) return (B * (T_C3::HW / T_C3::ROWS) + T_C3::IT - 1) / T_C3::IT;
   int gx = 0, gy = 0;
 #define X(C) if (match<C>(H, W, Cin, stride)) { grid_of<C>(B, Cout, gx, gy); return gx * gy; }
   Q8T_FOR_EACH(X)
@@ -251,7 +345,23 @@ int qbnn_conv_q8t_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int 
   return 0;
 }
 
+// operand alignment the matching form needs (16-byte staging units; 8-byte ones at Cin = 24; the 3-channel form reads its weights bytewise);
+// float4 output / parameter accesses: Cout % 4 == 0 is part of the match, y and y_ss are checked here
+bool qbnn_conv_q8t_aligned(const ConvQ8Args& a) {
+  auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(n - 1)) == 0; };
+  if (!al(a.y, 16) || (a.y_ss & 3) != 0 || (a.div && !al(a.div, 16)) || (a.bias && !al(a.bias, 16)) || (a.alpha && !al(a.alpha, 16)) || (a.beta && !al(a.beta, 16)))
+    return false;
+  if (match_c3(a.H, a.W, a.Cin, a.Cout, a.stride)) return al(a.x, 16) && (a.x_ss & 15) == 0;
+  const int u = (a.Cin % 16 == 0) ? 16 : 8;
+  return al(a.x, u) && al(a.w, u) && (a.x_ss % u) == 0 && (a.w_ss % u) == 0;
+}
+
 int qbnn_launch_conv_q8t(const ConvQ8Args& a, int n_samples, hipStream_t st) {
+  if (match_c3(a.H, a.W, a.Cin, a.Cout, a.stride)) {
+    const int gx = (a.B * (T_C3::HW / T_C3::ROWS) + T_C3::IT - 1) / T_C3::IT;
+    hipLaunchKernelGGL(conv2d_q8_c3_kernel, dim3(gx, 1, n_samples), dim3(256), 0, st, a);
+    return qbnn_check_launch_msg("qbnn_conv2d_q8_f32_mc");
+  }
 #define X(C) if (match<C>(a.H, a.W, a.Cin, a.stride)) return launch<C>(a, n_samples, st);
   Q8T_FOR_EACH(X)
 #undef X

@@ -48,11 +48,13 @@ class FakeQuantize(nn.Module):
         s = self.state.detach().cpu().numpy()
         return (float(s[0]), float(s[1])) if s[2] else (float("inf"), float("-inf"))
 
-    def forward(self, x, partials=None, relu=False):
+    def forward(self, x, partials=None, relu=False, f32_out=True):
         """x [S or 1, ...] fp32 on the GPU -> [S, ...]: sample s is quantised with the qparams the observer holds after
         having seen samples 0..s (a shared input is observed S times, as S reference forwards would).
         partials = (buffer, n_blocks): per-workgroup (min, max) the producing conv already wrote -- the min/max pass is skipped.
-        relu: the ReLU that follows this FakeQuantize in the graph, applied in the same pass (a ReLU of grid values stays on the grid)."""
+        relu: the ReLU that follows this FakeQuantize in the graph, applied in the same pass (a ReLU of grid values stays on the grid).
+        f32_out = False (round 6): every consumer of the result takes its grid integers (`_q8`, with `_grid` = the per-sample scale) -- a conv on
+        the int8 pipe, add_q8 -- so the fp32 tensor is allocated for its shape but NEVER WRITTEN (`_no_f32`); honoured only where `_q8` exists."""
         if x.device.type != "cuda":
             raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
         S = _MC.samples
@@ -78,10 +80,11 @@ class FakeQuantize(nn.Module):
         int8_grid = self.qmax - self.qmin <= 127
         if qat_i8_enabled() and int8_grid:      # an activation grid: leave the integers q - z for a consumer conv on the int8 pipe
             q8 = torch.empty((S, n), dtype=torch.int8, device=x.device)
+        skip_f32 = q8 is not None and not f32_out
         with timed("fake_quant_f32"):
             if q8 is not None or relu:
-                _lib.check(L.qbnn_fake_quant_ex_f32_mc(_lib.ptr(x), xs, _lib.ptr(y), n, n, _lib.ptr(scale), _lib.ptr(zp), self.qmin, self.qmax, int(relu),
-                                                       _lib.ptr(q8), S, _lib.current_stream()))
+                _lib.check(L.qbnn_fake_quant_ex_f32_mc(_lib.ptr(x), xs, None if skip_f32 else _lib.ptr(y), n, n, _lib.ptr(scale), _lib.ptr(zp), self.qmin,
+                                                       self.qmax, int(relu), _lib.ptr(q8), S, _lib.current_stream()))
             else:
                 _lib.check(L.qbnn_fake_quant_f32_mc(_lib.ptr(x), xs, _lib.ptr(y), n, n, _lib.ptr(scale), _lib.ptr(zp), 1, self.qmin, self.qmax, S,
                                                     _lib.current_stream()))
@@ -90,6 +93,7 @@ class FakeQuantize(nn.Module):
         # those integers fit an int8 (a wider grid sends the consumer conv down the fp64 path; the weight operand goes by weight_grid())
         y._grid = scale if int8_grid else None
         y._q8 = q8                   # ... and the integers themselves, [S, n] int8 in y's own element order
+        y._no_f32 = skip_f32         # y's own storage holds nothing: fp32 consumers must not touch it (need_f32)
         return y
 
 
@@ -109,6 +113,32 @@ def prepared_state(model):
             st[m._key + ".activation_post_process.min_val"] = np.float32(mn)
             st[m._key + ".activation_post_process.max_val"] = np.float32(mx)
     return st
+
+
+def need_f32(x):
+    """Guard of every fp32 consumer: a FakeQuantize output produced with f32_out = False has no fp32 values."""
+    if getattr(x, "_no_f32", False):
+        raise RuntimeError("qbnn QAT: this tensor was produced as grid integers only (f32_out=False); its fp32 storage was never written")
+    return x
+
+
+def add_q8(a, b):
+    """out + shortcut of two grid tensors from their integers: (fp32 sum [S, ...], (min / max partials, workgroups)) -- qbnn_add_q8_f32_mc."""
+    S, n = a.shape[0], a[0].numel()
+    L = _lib.lib()
+    y = torch.empty(tuple(a.shape), dtype=torch.float32, device=a.device)
+    nblk = int(L.qbnn_add_q8_blocks(n))
+    partials = torch.empty(S * nblk * 2, dtype=torch.float32, device=a.device)
+    with timed("add_q8"):
+        _lib.check(L.qbnn_add_q8_f32_mc(_lib.ptr(a._q8), n, _lib.ptr(a._grid), _lib.ptr(b._q8), n, _lib.ptr(b._grid), _lib.ptr(y), n, n, S,
+                                        _lib.ptr(partials), _lib.current_stream()))
+    return y, (partials, nblk)
+
+
+def _grid_pair(a, b):
+    """Both operands carry their grid integers for all S samples in the same element order."""
+    return (getattr(a, "_q8", None) is not None and getattr(b, "_q8", None) is not None and getattr(a, "_grid", None) is not None
+            and getattr(b, "_grid", None) is not None and a.shape == b.shape and a._q8.shape == b._q8.shape)
 
 
 def qat_i8_enabled():
@@ -207,7 +237,7 @@ class _QATBBB(nn.Module):
         # produced ahead of the activation path on a side stream (presample_weights) -- for THIS MC context on THIS device: an entry left
         # behind by a forward that raised, or drawn under another (samples, seed, first sample index), is dropped, and nothing recorded
         # outside a capture is waited on inside one
-        if pre is not None and eps is None and pre[2] == _presample_key(dev) and not torch.cuda.is_current_stream_capturing():
+        if pre is not None and eps is None and pre[2] == _presample_key(dev) and pre[3] == torch.cuda.is_current_stream_capturing():
             W, ev = pre[0], pre[1]
             torch.cuda.current_stream().wait_event(ev)
             W.record_stream(torch.cuda.current_stream())
@@ -252,6 +282,13 @@ class _QATBBB(nn.Module):
 _SIDE_STREAMS = {}          # device index -> side streams
 
 
+def _presample_in_capture():
+    """Fork the weight pipelines onto the side streams INSIDE a stream capture too (QBNN_QAT_PRESAMPLE_CAPTURE=0: in line): every wait / record
+    then happens between streams of the same capture, the side streams join the capturing stream again through each layer's event, and the
+    replayed graph keeps the pipelines beside the activation path instead of ~300 small launches in front of the convs."""
+    return os.environ.get("QBNN_QAT_PRESAMPLE_CAPTURE", "1") != "0"
+
+
 def _presample_key(dev):
     dev = torch.device(dev)
     return (_MC.samples, _MC.seed, _MC.sample_begin, dev.index if dev.index is not None else torch.cuda.current_device())
@@ -262,7 +299,8 @@ def presample_weights(layers, dev, n_streams=4):
     which depends on an activation) up front on side streams, so that they run beside the activation path's convs instead of in
     front of each of them.  Each layer's own observers are only touched by its own pipeline: the order across layers is free."""
     from . import layers as _layers
-    if (os.environ.get("QBNN_QAT_PRESAMPLE", "1") == "0" or _MC.eps is not None or torch.cuda.is_current_stream_capturing()
+    capturing = torch.cuda.is_current_stream_capturing()
+    if (os.environ.get("QBNN_QAT_PRESAMPLE", "1") == "0" or _MC.eps is not None or (capturing and not _presample_in_capture())
             or _layers.PROFILE is not None):      # (profiling pairs events on ONE stream: keep everything in line)
         for m in layers:
             m._presampled = None
@@ -281,7 +319,7 @@ def presample_weights(layers, dev, n_streams=4):
             W = m.sampled_weights(dev)
             ev = torch.cuda.Event()
             ev.record(st)
-            m._presampled = (W, ev, key)
+            m._presampled = (W, ev, key, capturing)      # (an entry recorded outside a capture is never waited on inside one, and vice versa)
 
 
 class Conv2d(_QATBBB):
@@ -310,7 +348,7 @@ class Conv2d(_QATBBB):
         running_std = torch.sqrt(self.bn.running_var.float().cpu() + self.bn.eps)          # conv_qat.py:140-141
         return self.bn.weight.detach().float().cpu() / running_std
 
-    def forward(self, x, eps=None):
+    def forward(self, x, eps=None, f32_out=True):
         dev = x.device
         W = self.sampled_weights(dev, eps)
         gs, wg = getattr(x, "_grid", None), self.weight_grid()
@@ -325,7 +363,8 @@ class Conv2d(_QATBBB):
                     self._cb = (self.scale_factor().to(dev).contiguous(), None if self.bias is None else self.bias.detach().to(dev).contiguous())
                 z, mm = conv2d_q8(x, gs, W, wg.last_scale, wg.last_zero_point, self.in_channels, self.out_channels, self.k, self.stride, self.padding,
                                   self.relu, bias=self._cb[1], div=self._cb[0], bn=self.bn.coefficients(dev), x_q8=getattr(x, "_q8", None))
-            return self.activation_post_process(z, partials=mm)
+            return self.activation_post_process(z, partials=mm, f32_out=f32_out)
+        need_f32(x)
         if self.bn is None:
             b = None if self.bias is None else self.bias.detach().to(dev).contiguous()
             z, mm = conv2d_f32(x, W, b, self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True,
@@ -336,7 +375,7 @@ class Conv2d(_QATBBB):
                 self._cb = (self.scale_factor().to(dev).contiguous(), None if self.bias is None else self.bias.detach().to(dev).contiguous())
             z, mm = conv2d_f32(x, W, self._cb[1], self.in_channels, self.out_channels, self.k, self.stride, self.padding, self.relu, acc64=True,
                                ohwi=True, div=self._cb[0], bn=self.bn.coefficients(dev), minmax=True)
-        return self.activation_post_process(z, partials=mm)
+        return self.activation_post_process(z, partials=mm, f32_out=f32_out)
 
     def load(self, st, name):
         self._load_common(st, name)
@@ -394,8 +433,8 @@ class QuantStub(nn.Module):
         (alo, ahi), _ = _bounds(args)
         self.activation_post_process = FakeQuantize(alo, ahi)
 
-    def forward(self, x):
-        return self.activation_post_process(x)
+    def forward(self, x, f32_out=True):
+        return self.activation_post_process(x, f32_out=f32_out)
 
 
 class ConvNetwork_LeNet(nn.Module):
@@ -520,10 +559,15 @@ class BasicBlock(nn.Module):
             self.shortcut.append(nn.Identity())
         self.add = FakeQuantize(alo, ahi)          # add.add.activation_post_process
 
-    def forward(self, x):
-        out = self.stem[3](self.stem[0](x))
-        sc = self.shortcut[0](x) if len(self.shortcut) else x
-        return self.add(affine_f32(out, res=sc), relu=True)      # Add -> FakeQuantize -> ReLU (`end`): the ReLU in the fake-quantiser's pass
+    def forward(self, x, f32_out=True):
+        """f32_out = False: the block's consumers (the next block's convs and Add) take its grid integers."""
+        grid_in = getattr(x, "_q8", None) is not None            # then every tensor inside the block travels as grid integers + scale
+        out = self.stem[3](self.stem[0](x, f32_out=not grid_in), f32_out=not grid_in)
+        sc = self.shortcut[0](x, f32_out=not grid_in) if len(self.shortcut) else x
+        if _grid_pair(out, sc):                                   # Add from the integers, its (min, max) for the observer in the same pass
+            z, mm = add_q8(out, sc)
+            return self.add(z, partials=mm, relu=True, f32_out=f32_out)
+        return self.add(affine_f32(need_f32(out), res=need_f32(sc)), relu=True, f32_out=f32_out)      # Add -> FakeQuantize -> ReLU (`end`): the ReLU in the fake-quantiser's pass
 
 
 class ConvNetwork_ResNet(nn.Module):
@@ -575,11 +619,13 @@ class ConvNetwork_ResNet(nn.Module):
 
     def forward_mc(self, x):
         presample_weights([m for _, m in self.stochastic_named()], x.device)
-        h = self.layers[0](self.quant(nchw_to_mc_nhwc(x)))
+        # every tensor between the input FakeQuantize and the last block's Add is consumed as grid integers (convs on the int8 pipe, add_q8):
+        # their fp32 forms are never written (f32_out=False; FakeQuantize honours it only where the integers exist, i.e. not with QBNN_QAT_I8=0)
+        h = self.layers[0](self.quant(nchw_to_mc_nhwc(x), f32_out=False), f32_out=False)
         for li in (3, 4, 5, 6):
-            for blk in self.layers[li]:
-                h = blk(h)
-        h = flatten_f32(pool2d_f32(h, 4, avg=True))
+            for bi, blk in enumerate(self.layers[li]):
+                h = blk(h, f32_out=(li == 6 and bi == 1))        # the average pool reads fp32
+        h = flatten_f32(pool2d_f32(need_f32(h), 4, avg=True))
         return softmax_f32(self.layers[9](h))
 
     def forward(self, x):

@@ -53,7 +53,7 @@ class _Deterministic:
         pre = getattr(self, "_presampled", None)
         self._presampled = None
         from .models_qat import _presample_key
-        if pre is not None and pre[2] == _presample_key(dev) and not torch.cuda.is_current_stream_capturing():
+        if pre is not None and pre[2] == _presample_key(dev) and pre[3] == torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream().wait_event(pre[1])
             pre[0].record_stream(torch.cuda.current_stream())
             if getattr(pre[0], "_q8", None) is not None:

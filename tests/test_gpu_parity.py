@@ -1184,10 +1184,10 @@ print("F32-SWITCH-OK")
 """
 
 
-@pytest.mark.parametrize("switch", ["QBNN_F32_TAPMASK=0", "QBNN_QAT_PRESAMPLE=0"])
+@pytest.mark.parametrize("switch", ["QBNN_F32_TAPMASK=0", "QBNN_QAT_PRESAMPLE=0", "QBNN_Q8_TILED=0"])
 def test_float_path_switches_give_the_same_bits(switch, tmp_path):
-    """The fp32 / fp64 conv's two gather forms (per-row tap masks against per-element bounds compares) and the QAT weight pipelines on side
-    streams against in line: the float BBB ResNet and the QAT evaluation, ragged batch of 70, give bit-identical probabilities either way."""
+    """The fp32 / fp64 conv's two gather forms (per-row tap masks against per-element bounds compares), the QAT weight pipelines on side
+    streams against in line, and the QAT 3 x 3 convs LDS-tiled (round 6, csrc/qbnn_q8t.hip) against the gather forms of round 5 (same integer sums, same tail): the float BBB ResNet and the QAT evaluation, ragged batch of 70, give bit-identical probabilities either way."""
     import os
     import subprocess
     import sys
@@ -2567,7 +2567,11 @@ def test_sampler_n24_layout_draws_the_same_weights(golden_w8):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(3, 24, 3, 1, 1, 32), (24, 24, 3, 1, 1, 16), (24, 48, 3, 2, 1, 16), (48, 96, 1, 2, 0, 8), (96, 192, 3, 1, 1, 4), (20, 50, 5, 1, 2, 14)])
+@pytest.mark.parametrize("case", [(3, 24, 3, 1, 1, 32), (24, 24, 3, 1, 1, 16), (24, 48, 3, 2, 1, 16), (48, 96, 1, 2, 0, 8), (96, 192, 3, 1, 1, 4), (20, 50, 5, 1, 2, 14),
+                                  # round 6: the LDS-tiled forms (csrc/qbnn_q8t.hip) -- the ResNet's seven 3 x 3 geometries, the 3-channel stem, ragged image groups (B = 3
+                                  # against 2 / 8 images per block), ragged channel groups (40 of 2 x 32, 100 of 2 x 96) and a 3 x 3 conv no tiled form matches
+                                  (24, 24, 3, 1, 1, 32), (24, 48, 3, 2, 1, 32), (48, 48, 3, 1, 1, 16), (48, 96, 3, 2, 1, 16), (96, 96, 3, 1, 1, 8), (96, 192, 3, 2, 1, 8),
+                                  (192, 192, 3, 1, 1, 4), (3, 32, 3, 1, 1, 32), (3, 8, 3, 1, 1, 32), (24, 40, 3, 1, 1, 32), (96, 100, 3, 1, 1, 8), (192, 24, 3, 1, 1, 4), (48, 48, 3, 1, 1, 8)])
 def test_qat_int8_conv_entry_points_against_numpy(case):
     """qbnn_grid_to_i8_mc + qbnn_conv2d_q8_f32_mc through the C ABI (round 5: the QAT convs on the int8 matrix pipe) against the same sum in numpy:
     fake-quantised operands with PER-SAMPLE scales / zero points (activations on 7-bit grids, weights on int8 grids with non-zero zero points),
