@@ -494,6 +494,28 @@ int32_t qbnn_add_q8_blocks(int64_t n);
 int qbnn_add_q8_f32_mc(const int8_t* a, int64_t a_sample_stride, const float* s_a, const int8_t* b, int64_t b_sample_stride, const float* s_b, float* y,
                        int64_t y_sample_stride, int64_t n, int32_t n_samples, float* minmax_partials, void* stream);
 
+/* The QAT weight pipelines of all stochastic layers at once (round 6; conv_qat.py:26-49, linear_qat.py:18-41 in eval): per layer and MC sample
+ *   w = FQ_w(mu c), s = FQ_s(softplus(rho) c), t = FQ_m(eps * s), W = FQ_a(w + t)      (FQ_x: live MovingAverageMinMax observer + fake_quantize)
+ * in four launches instead of ~15 per layer; bit-identical to the per-layer calls (qbnn_observe_f32_mc, qbnn_fake_quant_f32_mc,
+ * qbnn_sample_weights_f32_ohwi / _strided, qbnn_affine_f32_mc, qbnn_grid_to_i8_mc).  `dev_layers`: n_layers descriptors IN DEVICE MEMORY, every pointer
+ * a device pointer: mu = mu c in the output element order ([Cout][kh][kw][Cin] for a conv: KS > 0; the reference's order for a linear: KS = 0), sg =
+ * softplus(rho) c in the reference's element order (the noise stream's index), st_* the four observers' (min, max, seen) states, cmm = (min mu, max mu,
+ * min sg, max sg), [blk0, blk0 + nblk) the layer's workgroups in the launch (nblk <= 64, consecutive layers, total_blocks in all), pm / pa workspaces of
+ * n_samples * nblk * 2 floats, outputs W fp32 [S][n], its raw integers q8 [S][n] and FQ_a's per-sample (scale, zero point).  1 <= n_samples <= 64. */
+typedef struct qbnn_qat_wlayer {
+  const float* mu; const float* sg;
+  float* st_w; float* st_s; float* st_m; float* st_a;
+  float cmm[4];
+  int32_t n, Cout, Cin, KS;
+  uint32_t layer_id;
+  int32_t qmin, qmax;
+  int32_t blk0, nblk;
+  float* pm; float* pa;
+  float* W; int8_t* q8; float* scale; int32_t* zp;
+} qbnn_qat_wlayer;
+int qbnn_qat_weights_mc(const qbnn_qat_wlayer* dev_layers, int32_t n_layers, int32_t total_blocks, float avg_const, uint64_t seed,
+                        uint32_t sample_begin, int32_t n_samples, void* stream);
+
 /* Pointwise on [S][n] with the channel as fastest axis:  v = (mode 0) x * p0[c] + p1[c]  |  (mode 1) x / p0[c] + p1[c]
  * (p0 / p1 NULL skip that step), v += res (if given), ReLU (if asked).  nn.BatchNorm2d in eval (x * alpha + beta as ATen
  * computes it), the `Z / scale_factor + bias` of conv_qat.py:159-161, Add (src/utils.py:49-55), nn.ReLU. */

@@ -1215,6 +1215,191 @@ QBNN_EXPORT int qbnn_sample_weights_f32_ohwi(const float* mu, int64_t mu_ss, con
   return qbnn_check_launch_msg("qbnn_sample_weights_f32_ohwi");
 }
 
+// =====================================================================================
+// The QAT weight pipelines of ALL stochastic layers in four launches (round 6).
+//
+// conv_qat.py:26-49 / linear_qat.py:18-41 in eval, per layer:  w = FQ_w(mu c), s = FQ_s(softplus(rho) c), t = FQ_m(eps * s), W = FQ_a(w + t), every
+// FQ a live MovingAverageMinMax observer + fake_quantize.  Layer by layer that is ~15 launches of a few microseconds each (min / max, observer scan,
+// fake-quantise x 4; the noise draw; the sum; the int8 view) -- ~300 per forward of the ResNet, 1.6 of the 4.9 ms a 10-sample pass spent on the GPU.
+// Nothing here depends on an activation, and the only cross-element dependences are the observers' (min, max): so
+//   stage 0  draws eps, fake-quantises sigma, leaves per-workgroup (min, max) of t_pre = eps * s                      -> partials `pm`
+//   stage 1  recomputes t_pre, t = FQ_m(t_pre) with FQ_m's per-sample qparams, w = FQ_w(mu), (min, max) of w + t      -> partials `pa`
+//   stage 2  recomputes w + t, W = FQ_a(w + t): writes W (fp32), its raw integers (int8) and FQ_a's per-sample (scale, zero point)
+//   commit   advances the four observers' states (the only writer of a state; stages 0 - 2 only read them)
+// for every layer and MC sample at once.  Each workgroup derives the qparams it needs itself: the EMA recurrence over samples 0..s is a few flops --
+// from the constant (min, max) of mu c / sigma c for FQ_w / FQ_s (they see the same tensor S times), from the <= 64 partial pairs per sample of the
+// previous stage for FQ_m / FQ_a.  Recomputing eps costs three Philox + Box-Muller evaluations per weight instead of three tensor round trips.
+// Same arithmetic, step for step, as minmax_f32_kernel / observer_scan_kernel / fake_quant_f32_kernel / sample_weights_f32_(ohwi|strided)_kernel /
+// affine_f32 / grid_to_i8: the results are bit-identical (tests: QBNN_QAT_WBATCH=0 switch).
+// =====================================================================================
+struct QatWLayer {            // mirrors qbnn_qat_wlayer (include/qbnn.h)
+  const float* mu; const float* sg;
+  float* st_w; float* st_s; float* st_m; float* st_a;
+  float cmm[4];
+  int32_t n, Cout, Cin, KS;
+  uint32_t layer_id;
+  int32_t qmin, qmax;
+  int32_t blk0, nblk;
+  float* pm; float* pa;
+  float* W; int8_t* q8; float* scale; int32_t* zp;
+};
+static_assert(sizeof(QatWLayer) == sizeof(qbnn_qat_wlayer), "qbnn_qat_wlayer layout");
+
+struct ObsQ { float sc, inv, z; };
+__device__ __forceinline__ void obs_step(float& mn_s, float& mx_s, bool& init, float mn, float mx, float c) {
+  if (!init) { mn_s = mn; mx_s = mx; init = true; }
+  else { mn_s = mn_s + c * (mn - mn_s); mx_s = mx_s + c * (mx - mx_s); }
+}
+__device__ __forceinline__ ObsQ obs_qparams(float mn_s, float mx_s, int qmin, int qmax) {      // observer_scan_kernel's calculate_qparams
+  const float lo = fminf(mn_s, 0.f), hi = fmaxf(mx_s, 0.f);
+  float sc = (hi - lo) / (float)(qmax - qmin);
+  sc = fmaxf(sc, 1.1920928955078125e-07f);
+  float z = (float)qmin - rintf(lo / sc);
+  z = fminf(fmaxf(z, (float)qmin), (float)qmax);
+  return ObsQ{sc, 1.0f / sc, z};
+}
+// the observer's qparams for sample s after having seen the SAME (mn, mx) s + 1 times, starting from `state`
+__device__ __forceinline__ ObsQ obs_const(const float* state, float mn, float mx, int s, float c, int qmin, int qmax) {
+  float a = state[0], b = state[1];
+  bool init = state[2] != 0.f;
+  for (int i = 0; i <= s; ++i) obs_step(a, b, init, mn, mx, c);
+  return obs_qparams(a, b, qmin, qmax);
+}
+// ... after having seen samples 0..s whose (min, max) come from [S][nblk][2] partials; `red` = 2 * 64 floats of LDS.  All threads return the same value.
+__device__ __forceinline__ ObsQ obs_partials(const float* state, const float* partials, int nblk, int s, float c, int qmin, int qmax, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();                                  // `red` may still be read from a previous call
+  for (int i = wave; i <= s; i += 4) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int k = lane; k < nblk; k += 64) { mn = fminf(mn, partials[((int64_t)i * nblk + k) * 2]); mx = fmaxf(mx, partials[((int64_t)i * nblk + k) * 2 + 1]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if (lane == 0) { red[i] = mn; red[64 + i] = mx; }
+  }
+  __syncthreads();
+  float a = state[0], b = state[1];
+  bool init = state[2] != 0.f;
+  for (int i = 0; i <= s; ++i) obs_step(a, b, init, red[i], red[64 + i], c);
+  return obs_qparams(a, b, qmin, qmax);
+}
+__device__ __forceinline__ float fq_q(float x, const ObsQ& q, float lo, float hi) { return fminf(fmaxf(rintf(x * q.inv) + q.z, lo), hi); }
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void qat_weights_kernel(const QatWLayer* __restrict__ layers, int n_layers, float avg_const, uint32_t seed_lo, uint32_t seed_hi,
+                                                          uint32_t sample_begin, const uint32_t* __restrict__ nd) {
+  __shared__ float red[128];
+  __shared__ float bred[8];
+  if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }
+  int li = 0;
+  for (int i = 1; i < n_layers; ++i) li = (int)blockIdx.x >= layers[i].blk0 ? i : li;
+  const QatWLayer L = layers[li];
+  const int b = blockIdx.x - L.blk0, s = blockIdx.y, tid = threadIdx.x;
+  const float lo = (float)L.qmin, hi = (float)L.qmax;
+  const ObsQ qs = obs_const(L.st_s, L.cmm[2], L.cmm[3], s, avg_const, L.qmin, L.qmax);
+  ObsQ qw{}, qm{}, qa{};
+  if (STAGE >= 1) {
+    qw = obs_const(L.st_w, L.cmm[0], L.cmm[1], s, avg_const, L.qmin, L.qmax);
+    qm = obs_partials(L.st_m, L.pm, L.nblk, s, avg_const, L.qmin, L.qmax, red);
+  }
+  if (STAGE >= 2) qa = obs_partials(L.st_a, L.pa, L.nblk, s, avg_const, L.qmin, L.qmax, red);
+  const int64_t n = L.n, groups = (n + 3) / 4;
+  const int64_t per = (groups + L.nblk - 1) / L.nblk, g0 = (int64_t)b * per, g1 = g0 + per < groups ? g0 + per : groups;
+  float vmin = INFINITY, vmax = -INFINITY;
+  for (int64_t g = g0 + tid; g < g1; g += 256) {
+    float e[4];
+    qbnn::normal4(qbnn::philox4x32_10((uint32_t)g, L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi), e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = g * 4 + j;
+      if (i >= n) break;
+      const float sgq = (fq_q(L.sg[i], qs, lo, hi) - qs.z) * qs.sc;       // s = FQ_s(sigma c)
+      const float tp = e[j] * sgq;                                          // eps * s
+      if (STAGE == 0) { vmin = fminf(vmin, tp); vmax = fmaxf(vmax, tp); continue; }
+      int64_t o = i;                                                        // the output element: [Cout][kh][kw][Cin] for a conv, the reference's order for a linear
+      if (L.KS > 0) {
+        const int kw = (int)(i % L.KS);
+        int64_t r = i / L.KS;
+        const int kh = (int)(r % L.KS); r /= L.KS;
+        const int c = (int)(r % L.Cin);
+        const int oc = (int)(r / L.Cin);
+        o = (((int64_t)oc * L.KS + kh) * L.KS + kw) * L.Cin + c;
+      }
+      const float t = (fq_q(tp, qm, lo, hi) - qm.z) * qm.sc;               // t = FQ_m(eps * s)
+      const float wq = (fq_q(L.mu[o], qw, lo, hi) - qw.z) * qw.sc;         // w = FQ_w(mu c)
+      const float sum = wq + t;
+      if (STAGE == 1) { vmin = fminf(vmin, sum); vmax = fmaxf(vmax, sum); continue; }
+      const float q = fq_q(sum, qa, lo, hi);
+      L.W[(int64_t)s * n + o] = (q - qa.z) * qa.sc;
+      L.q8[(int64_t)s * n + o] = (int8_t)(int)fminf(fmaxf(q, -128.f), 127.f);
+    }
+  }
+  if (STAGE <= 1) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o)); }
+    if ((tid & 63) == 0) { bred[2 * (tid >> 6)] = vmin; bred[2 * (tid >> 6) + 1] = vmax; }
+    __syncthreads();
+    if (tid == 0) {
+      float* p = (STAGE == 0 ? L.pm : L.pa) + ((int64_t)s * L.nblk + b) * 2;
+      p[0] = fminf(fminf(bred[0], bred[2]), fminf(bred[4], bred[6]));
+      p[1] = fmaxf(fmaxf(bred[1], bred[3]), fmaxf(bred[5], bred[7]));
+    }
+  } else if (b == 0 && tid == 0) {
+    L.scale[s] = qa.sc; L.zp[s] = (int)qa.z;
+  }
+}
+
+// one workgroup per layer: the four observers after all S samples
+__global__ __launch_bounds__(256) void qat_weights_commit_kernel(const QatWLayer* __restrict__ layers, int n_samples, float avg_const) {
+  __shared__ float red[128];
+  const QatWLayer L = layers[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float fin[4][2];
+  for (int k = 0; k < 2; ++k) {             // mul_noise, add_weight: per-sample (min, max) over the partials, then the recurrence
+    const float* partials = k == 0 ? L.pm : L.pa;
+    const float* st = k == 0 ? L.st_m : L.st_a;
+    __syncthreads();
+    for (int i = wave; i < n_samples; i += 4) {
+      float mn = INFINITY, mx = -INFINITY;
+      for (int j = lane; j < L.nblk; j += 64) { mn = fminf(mn, partials[((int64_t)i * L.nblk + j) * 2]); mx = fmaxf(mx, partials[((int64_t)i * L.nblk + j) * 2 + 1]); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+      if (lane == 0) { red[i] = mn; red[64 + i] = mx; }
+    }
+    __syncthreads();
+    float a = st[0], b = st[1];
+    bool init = st[2] != 0.f;
+    for (int i = 0; i < n_samples; ++i) obs_step(a, b, init, red[i], red[64 + i], avg_const);
+    fin[2 + k][0] = a; fin[2 + k][1] = b;
+  }
+  for (int k = 0; k < 2; ++k) {             // weight_fake_quant, std_fake_quant: the same tensor S times
+    const float* st = k == 0 ? L.st_w : L.st_s;
+    float a = st[0], b = st[1];
+    bool init = st[2] != 0.f;
+    for (int i = 0; i < n_samples; ++i) obs_step(a, b, init, L.cmm[2 * k], L.cmm[2 * k + 1], avg_const);
+    fin[k][0] = a; fin[k][1] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* sts[4] = {L.st_w, L.st_s, L.st_m, L.st_a};
+    for (int k = 0; k < 4; ++k) { sts[k][0] = fin[k][0]; sts[k][1] = fin[k][1]; sts[k][2] = 1.f; }
+  }
+}
+
+QBNN_EXPORT int qbnn_qat_weights_mc(const qbnn_qat_wlayer* dev_layers, int32_t n_layers, int32_t total_blocks, float avg_const, uint64_t seed,
+                                    uint32_t sample_begin, int32_t n_samples, void* stream) {
+  if (!dev_layers || n_layers <= 0 || total_blocks <= 0 || n_samples <= 0 || n_samples > 64)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_qat_weights_mc: bad argument (1 to 64 samples per call)");
+  const QatWLayer* L = reinterpret_cast<const QatWLayer*>(dev_layers);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(total_blocks, n_samples);
+  const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+  hipLaunchKernelGGL(qat_weights_kernel<0>, grid, dim3(256), 0, st, L, n_layers, avg_const, lo, hi, sample_begin, qbnn_noise_dev());
+  hipLaunchKernelGGL(qat_weights_kernel<1>, grid, dim3(256), 0, st, L, n_layers, avg_const, lo, hi, sample_begin, qbnn_noise_dev());
+  hipLaunchKernelGGL(qat_weights_kernel<2>, grid, dim3(256), 0, st, L, n_layers, avg_const, lo, hi, sample_begin, qbnn_noise_dev());
+  hipLaunchKernelGGL(qat_weights_commit_kernel, dim3(n_layers), dim3(256), 0, st, L, n_samples, avg_const);
+  return qbnn_check_launch_msg("qbnn_qat_weights_mc");
+}
+
 QBNN_EXPORT int qbnn_conv2d_f32_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* bias, float* y,
                                    int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                                    int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream) {

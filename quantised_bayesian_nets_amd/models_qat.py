@@ -239,6 +239,8 @@ class _QATBBB(nn.Module):
         # outside a capture is waited on inside one
         if pre is not None and eps is None and pre[2] == _presample_key(dev) and pre[3] == torch.cuda.is_current_stream_capturing():
             W, ev = pre[0], pre[1]
+            if ev is None:          # batch_weights: drawn on this stream, in a static buffer
+                return W
             torch.cuda.current_stream().wait_event(ev)
             W.record_stream(torch.cuda.current_stream())
             if getattr(W, "_q8", None) is not None:
@@ -283,10 +285,11 @@ _SIDE_STREAMS = {}          # device index -> side streams
 
 
 def _presample_in_capture():
-    """Fork the weight pipelines onto the side streams INSIDE a stream capture too (QBNN_QAT_PRESAMPLE_CAPTURE=0: in line): every wait / record
-    then happens between streams of the same capture, the side streams join the capturing stream again through each layer's event, and the
-    replayed graph keeps the pipelines beside the activation path instead of ~300 small launches in front of the convs."""
-    return os.environ.get("QBNN_QAT_PRESAMPLE_CAPTURE", "1") != "0"
+    """Inside a stream capture the weight pipelines run IN LINE by default: measured on the QAT ResNet (B = 256, S = 10) the captured pass replays in
+    4.36 ms with them in line and 5.02 ms with them forked onto the side streams (QBNN_QAT_PRESAMPLE_CAPTURE=1: every wait / record then happens
+    between streams of the same capture) -- a replayed graph launches the ~300 small kernels back to back, and the fork / join edges cost more than the
+    overlap gives.  Eager launches keep the side streams (there the host's launch rate is the bound)."""
+    return os.environ.get("QBNN_QAT_PRESAMPLE_CAPTURE", "0") == "1"
 
 
 def _presample_key(dev):
@@ -294,11 +297,98 @@ def _presample_key(dev):
     return (_MC.samples, _MC.seed, _MC.sample_begin, dev.index if dev.index is not None else torch.cuda.current_device())
 
 
+def _wbatch_enabled():
+    return os.environ.get("QBNN_QAT_WBATCH", "1") != "0"
+
+
+class _WeightBatch:
+    """Static state of qbnn_qat_weights_mc for one (layer list, device, S): the layer descriptors in device memory, the observers' constant
+    (min, max) of mu c / sigma c, the workspaces and the output buffers (overwritten by every forward; consumed by the same forward's convs on the
+    same stream)."""
+
+    def __init__(self, layers, dev, S):
+        import ctypes as C
+        self.S, self.n_layers = S, len(layers)
+        arr = (_lib.QatWLayer * len(layers))()
+        self.keep, self.out = [], []
+        blk0 = 0
+        for i, m in enumerate(layers):
+            mu0, sg0 = m._folded_params(dev)
+            fqs = (m.weight_fake_quant, m.std_fake_quant, m.mul_noise, m.add_weight)
+            for fq in fqs:
+                if fq.state.device != mu0.device:
+                    fq.state = fq.state.to(mu0.device)
+            n = mu0.numel()
+            d = arr[i]
+            d.mu, d.sg = mu0.data_ptr(), sg0.data_ptr()
+            d.st_w, d.st_s, d.st_m, d.st_a = (fq.state.data_ptr() for fq in fqs)
+            d.cmm[0], d.cmm[1], d.cmm[2], d.cmm[3] = float(mu0.min()), float(mu0.max()), float(sg0.min()), float(sg0.max())
+            conv = m.weight.dim() == 4
+            d.n, d.Cout, d.Cin, d.KS = n, m.weight.shape[0], m.weight.shape[1], (m.k if conv else 0)
+            d.layer_id, d.qmin, d.qmax = m.layer_id, m.add_weight.qmin, m.add_weight.qmax
+            d.nblk = max(1, min(64, ((n + 3) // 4 + 511) // 512))
+            d.blk0 = blk0
+            blk0 += d.nblk
+            pm = torch.empty(S * d.nblk * 2, dtype=torch.float32, device=dev)
+            pa = torch.empty(S * d.nblk * 2, dtype=torch.float32, device=dev)
+            W = torch.empty((S, n), dtype=torch.float32, device=dev)
+            q8 = torch.empty((S, n), dtype=torch.int8, device=dev)
+            sc = torch.empty(S, dtype=torch.float32, device=dev)
+            zp = torch.empty(S, dtype=torch.int32, device=dev)
+            d.pm, d.pa, d.W, d.q8, d.scale, d.zp = pm.data_ptr(), pa.data_ptr(), W.data_ptr(), q8.data_ptr(), sc.data_ptr(), zp.data_ptr()
+            self.keep += [mu0, sg0, pm, pa] + [fq.state for fq in fqs]
+            self.out.append((W, q8, sc, zp))
+        self.total_blocks = blk0
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.desc = host.to(dev)
+        self.ptrs = self.pointers(layers, dev)
+
+    @staticmethod
+    def pointers(layers, dev):
+        """What the descriptors point at that a reload / a device move would replace."""
+        out = []
+        for m in layers:
+            f = m._folded
+            out.append((None if f is None else f[0].data_ptr(), None if f is None else f[1].data_ptr(), m.weight_fake_quant.state.data_ptr(), m.std_fake_quant.state.data_ptr(),
+                        m.mul_noise.state.data_ptr(), m.add_weight.state.data_ptr(), m.layer_id))
+        return out
+
+
+_WBATCH = {}          # (ids of the layers, device index, S) -> _WeightBatch
+
+
+def batch_weights(layers, dev):
+    """All layers' weight pipelines in four launches (qbnn_qat_weights_mc): leaves each layer's sampled weights where `sampled_weights` picks them up.
+    False where the batched form does not apply (injected eps, QBNN_QAT_WBATCH=0, more than 64 samples, a layer of another kind)."""
+    S = _MC.samples
+    if not _wbatch_enabled() or _MC.eps is not None or S > 64 or not all(isinstance(m, _QATBBB) and hasattr(m, "add_weight") and hasattr(m, "mul_noise") for m in layers):
+        return False
+    dev = torch.device(dev)
+    key = (tuple(id(m) for m in layers), dev.index if dev.index is not None else torch.cuda.current_device(), S)
+    wb = _WBATCH.get(key)
+    if wb is None or wb.ptrs != _WeightBatch.pointers(layers, dev):
+        if torch.cuda.is_current_stream_capturing():
+            return False          # (descriptors go up with a host copy: built by the eager pass that precedes every capture)
+        if len(_WBATCH) > 16:
+            _WBATCH.clear()
+        wb = _WBATCH[key] = _WeightBatch(layers, dev, S)
+    with timed("qat_weights"):
+        _lib.check(_lib.lib().qbnn_qat_weights_mc(_lib.ptr(wb.desc), wb.n_layers, wb.total_blocks, AVG_CONST, _MC.seed, _MC.sample_begin, S, _lib.current_stream()))
+    pkey, capturing = _presample_key(dev), torch.cuda.is_current_stream_capturing()
+    for m, (W, q8, sc, zp) in zip(layers, wb.out):
+        W._q8 = q8 if (qat_i8_enabled() and m.add_weight.qmin >= -128 and m.add_weight.qmax <= 127) else None
+        m.add_weight.last_scale, m.add_weight.last_zero_point = sc, zp
+        m._presampled = (W, None, pkey, capturing)
+    return True
+
+
 def presample_weights(layers, dev, n_streams=4):
     """The weight pipelines of all stochastic layers (4 fake-quantisers each: 12 launches of a few microseconds per layer, none of
     which depends on an activation) up front on side streams, so that they run beside the activation path's convs instead of in
     front of each of them.  Each layer's own observers are only touched by its own pipeline: the order across layers is free."""
     from . import layers as _layers
+    if batch_weights(layers, dev):
+        return
     capturing = torch.cuda.is_current_stream_capturing()
     if (os.environ.get("QBNN_QAT_PRESAMPLE", "1") == "0" or _MC.eps is not None or (capturing and not _presample_in_capture())
             or _layers.PROFILE is not None):      # (profiling pairs events on ONE stream: keep everything in line)
@@ -477,6 +567,7 @@ class ConvNetwork_LeNet(nn.Module):
         return self
 
     def forward_mc(self, x):
+        batch_weights(self.stochastic_layers(), x.device)         # all four weight pipelines in four launches
         h = self.quant(nchw_to_mc_nhwc(x))
         c = self.layers[0](h)
         h = keep_grid(pool2d_f32(c, 2, avg=False), c)            # max-pooling picks grid values
@@ -531,6 +622,7 @@ class LinearNetwork(nn.Module):
         return self
 
     def forward_mc(self, x):
+        batch_weights(self.stochastic_layers(), x.device)         # all five weight pipelines in four launches
         h = self.quant(x.to(torch.float32).reshape(1, x.shape[0], -1))
         for m in (self.layers[0], self.layers[2], self.layers[4]):
             h = m(h)

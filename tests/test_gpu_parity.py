@@ -1179,15 +1179,29 @@ qa = types.SimpleNamespace(sigma_prior=-2.0, activation_precision=7, weight_prec
 mq = q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, qa).load_reference_state(gq["state"])
 with q.mc_context(3, 11, 2):
     res["qat"] = mq.forward_mc(x).cpu().numpy()
+with q.mc_context(2, 12, 0):                                  # a second pass: the observers' states after the first one matter
+    res["qat2"] = mq.forward_mc(x).cpu().numpy()
+res["qat_observers"] = np.array([v for k, v in sorted(mq.prepared_state().items()) if k.endswith("min_val") or k.endswith("max_val")], np.float32)
+import numpy as _np, os as _os
+for name, model, shape, xin in (("lenet_bbb_qat.npz", "conv_lenet_bbb", [1, 28, 28], torch.rand(5, 1, 28, 28, generator=torch.Generator().manual_seed(3))),
+                                ("mlp_bbb_qat.npz", "linear_bbb", [13], torch.randn(9, 13, generator=torch.Generator().manual_seed(4)))):
+    d = _np.load(_os.path.join(root, "tests", "golden", name))
+    st = {k[len("state/"):]: d[k] for k in d.files if k.startswith("state/")}
+    ms = q.ModelFactory.get_model(model, shape, 1 if model == "linear_bbb" else 10, True, qa).load_reference_state(st)
+    for rep in range(2):
+        with q.mc_context(3, 21 + rep, 0):
+            o = ms.forward_mc(xin.cuda())
+        res["%s_%d" % (model, rep)] = (torch.cat(list(o), -1) if isinstance(o, tuple) else o).cpu().numpy()
 np.savez(out, **res)
 print("F32-SWITCH-OK")
 """
 
 
-@pytest.mark.parametrize("switch", ["QBNN_F32_TAPMASK=0", "QBNN_QAT_PRESAMPLE=0", "QBNN_Q8_TILED=0"])
+@pytest.mark.parametrize("switch", ["QBNN_F32_TAPMASK=0", "QBNN_QAT_PRESAMPLE=0", "QBNN_Q8_TILED=0", "QBNN_QAT_WBATCH=0"])
 def test_float_path_switches_give_the_same_bits(switch, tmp_path):
     """The fp32 / fp64 conv's two gather forms (per-row tap masks against per-element bounds compares), the QAT weight pipelines on side
-    streams against in line, and the QAT 3 x 3 convs LDS-tiled (round 6, csrc/qbnn_q8t.hip) against the gather forms of round 5 (same integer sums, same tail): the float BBB ResNet and the QAT evaluation, ragged batch of 70, give bit-identical probabilities either way."""
+    streams against in line, the QAT 3 x 3 convs LDS-tiled (round 6, csrc/qbnn_q8t.hip) against the gather forms of round 5 (same integer sums, same tail),
+    and all layers' weight pipelines in four launches (qbnn_qat_weights_mc) against ~15 launches per layer: the float BBB ResNet and the QAT evaluation, ragged batch of 70, give bit-identical probabilities either way."""
     import os
     import subprocess
     import sys
@@ -1196,12 +1210,13 @@ def test_float_path_switches_give_the_same_bits(switch, tmp_path):
     script.write_text(_F32_SWITCH_WORKER)
     outs = []
     name, _, value = switch.partition("=")
-    for env in ({}, {name: value}):
+    base = {"QBNN_QAT_WBATCH": "0"} if name == "QBNN_QAT_PRESAMPLE" else {}      # (the side-stream pipelines are what runs when the batched form is off)
+    for env in (base, dict(base, **{name: value})):
         out = tmp_path / ("probs_%d.npz" % len(outs))
         r = subprocess.run([sys.executable, str(script), root, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "F32-SWITCH-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
         outs.append(np.load(out))
-    for k in ("f32", "qat"):
+    for k in outs[0].files:                  # float ResNet, QAT ResNet (two passes + every observer's state), QAT LeNet and MLP (two passes each)
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
@@ -2731,3 +2746,27 @@ def test_prepared_multi_launch_refuses_what_prepare_did_not_bake(golden_ensemble
         chain[1][0].blocks[0].flags = 0
     with q.mc_context(n, 0, 0):                 # the plan still runs, same bits
         assert torch.equal(net.forward_mc(x), want)
+
+
+def test_qat_resnet_graph_replay_equals_eager():
+    """The QAT evaluation pass (live observers, ~100 launches since the weight pipelines come batched) as ONE captured HIP graph: replays with new
+    seeds equal eager evaluations of a model whose observers have the same history (GraphedPredictor's warm-up pass runs eagerly with seed 0; the
+    capture itself executes nothing) -- bit for bit, observer states included."""
+    import quantised_bayesian_nets_amd as q
+    from conftest import load_golden
+    g = load_golden("resnet_bbb_qat.npz")
+    args = types.SimpleNamespace(sigma_prior=-2.0, activation_precision=7, weight_precision=8, qat_eval=True)
+    mk = lambda: q.ModelFactory.get_model("conv_resnet_bbb", [1, 3, 32, 32], 10, True, args).load_reference_state(g["state"])
+    x = torch.randn(37, 3, 32, 32, generator=torch.Generator().manual_seed(6)).cuda()
+    S = 4
+    mg, me = mk(), mk()
+    gp = q.GraphedPredictor(mg, S)
+    a = [gp(x, seed).cpu().numpy() for seed in (5, 6)]
+    with q.mc_context(S, 0, 0):
+        me.forward_mc(x)
+    b = [q.mc_predict(me, x, S, seed).cpu().numpy() for seed in (5, 6)]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    sg, se = mg.prepared_state(), me.prepared_state()
+    for k in sg:
+        if k.endswith("min_val") or k.endswith("max_val"):
+            assert float(sg[k]) == float(se[k]), k
