@@ -624,6 +624,19 @@ def test_qat_eval_of_the_non_bbb_graphs_matches_reference(name, model):
         with q.mc_context(S, seed, 0):
             p = m.forward_mc(x)
         np.testing.assert_allclose(p.cpu().numpy(), d["probs"], rtol=1e-5, atol=atol)
+        if atol > 1e-5:
+            # Round 6: the loose floor above cannot catch an error of 1e-4, so the build is also held to the reference's OWN statistics on this fixture
+            # (tests/golden/qat_refspread_counts.json, from make_golden_qat_counts.py: the reference's second run on another CPU code path against its
+            # recorded first): no more probabilities outside 1e-5 + 1e-6 than the reference shows against itself, a mean deviation no larger than its
+            # own, and the same arg-max class in every row.
+            import json
+            ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "qat_refspread_counts.json")))[name]
+            dev = np.abs(p.cpu().numpy().astype(np.float64) - d["probs"])
+            n_out = int((dev > 1e-6 + 1e-5 * np.abs(d["probs"])).sum())
+            print("%s: %d of %d probabilities outside 1e-5 + 1e-6 (reference vs itself: %d), mean |d| %.3g (reference: %.3g), max %.3g (%.3g)"
+                  % (name, n_out, dev.size, ref["n_outside_1e-5_1e-6"], dev.mean(), ref["mean_abs"], dev.max(), ref["max_abs"]))
+            assert n_out <= ref["n_outside_1e-5_1e-6"] and dev.mean() <= ref["mean_abs"]
+            assert int((p.cpu().numpy().argmax(-1) == d["probs"].argmax(-1)).sum()) == ref["rows"]
     otol = 1e-5 if atol < 1e-5 else 1e-2
     st2 = m.prepared_state()
     checked = 0
