@@ -298,6 +298,36 @@ def cpu_baseline(a, g, x_host, seed):
             "_p_oracle_sample0": p_or}
 
 
+# algorithmic work per MC sample at the workload's own batch (ops = 2 MAC; layer-granular bytes: each conv / linear reads its input and
+# writes its output once).  ResNet-18 24/48/96/192: 78,522,240 MAC and 482,506 activation elements per image; LeNet: 6,522,000 MAC per image.
+RESNET_MAC_PER_IMG, RESNET_ELTS_PER_IMG, LENET_MAC_PER_IMG = 78522240, 482506, 6522000
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2f32), dense
+
+
+def secondary_roofline(name, units_per_s, batch):
+    """The whole-workload roofline view of a secondary row (no per-kernel HIP events here: one number per workload): achieved = algorithmic ops (or
+    bytes) per MC sample x samples/s against the pipe that bounds it.  None for the launch-bound MLP workloads."""
+    if name in ("resnet_f32", "resnet_mc_f32"):
+        a = units_per_s * 2.0 * RESNET_MAC_PER_IMG * batch / 1e12
+        return {"bound": "mfma", "achieved": round(a, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(a / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "note": "fp32 matrix pipe (v_mfma_f32_32x32x2f32); channel padding (24 -> 32, 48 -> 64) leaves ~125 TFLOP/s of useful work at full issue"}
+    if name == "resnet_qat":
+        a = units_per_s * 2.0 * RESNET_MAC_PER_IMG * batch / 1e12
+        gb = units_per_s * (RESNET_ELTS_PER_IMG * batch * (4 + 4 + 1) + 2 * 1571592 * 4) / 1e9      # every conv output: fp32 written, read by its fake-quantiser, int8 written
+        return {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4), "traffic": None,
+                "mfma_achieved_tops": round(a, 2), "mfma_frac_of_i8_peak": round(a / MFMA_I8_PEAK_TOPS, 5),
+                "note": "live observers force two passes per tensor (conv -> fp32 Z with its min / max, then the fake-quantiser): 9 B per activation element; "
+                        "the integer sums themselves use a few per cent of the int8 pipe"}
+    if name in ("resnet_bbb_w4", "ensemble16", "resnet_mc"):
+        a = units_per_s * 2.0 * RESNET_MAC_PER_IMG * batch / 1e12
+        return {"bound": "mfma", "achieved": round(a, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": round(a / MFMA_I8_PEAK_TOPS, 4), "traffic": None}
+    if name in ("lenet_mc", "lenet_bbb"):
+        a = units_per_s * 2.0 * LENET_MAC_PER_IMG * batch / 1e12
+        return {"bound": "mfma", "achieved": round(a, 2), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": round(a / MFMA_I8_PEAK_TOPS, 5), "traffic": None,
+                "note": "launch-bound by design at this size (a 100-sample step is a fraction of a millisecond)"}
+    return None
+
+
 SECONDARY = ("resnet_bbb_w4", "ensemble16", "lenet_mc", "lenet_bbb", "mlp_f32", "mlp_bbb", "mlp_mc", "resnet_mc", "resnet_f32", "resnet_qat", "resnet_mc_f32")
 
 
@@ -332,7 +362,7 @@ def secondary_workloads(a, q, load_golden, seed):
             dt = time.perf_counter() - t0
             out[name] = {"metric": wl["metric"], "value": round(S * n / dt, 2), "unit": wl["unit"], "ms_per_step": round(dt / n * 1e3, 3),
                          "steps": n, "units_per_step": S, "batch": int(x.shape[0]), "dtype": wl["dtype"], "graph_replay": graphed is not None,
-                         "workload": wl["describe"]}
+                         "workload": wl["describe"], "roofline": secondary_roofline(name, S * n / dt, int(x.shape[0]))}
             del wl, model, x, graphed, run
             torch.cuda.empty_cache()
         except Exception as e:                                       # noqa: BLE001 -- a secondary workload must not take the headline line down

@@ -165,7 +165,7 @@ template <class E> __device__ __forceinline__ void epi_set_row(const E&, int, in
 // under the last epilogue instead of heading the next phase, where all 16 waves would burst it).
 template <int RW, bool MAGIC, class Epi>
 __device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[W16_KS], const uint8_t* wnext, const float* bias_lds,
-                                                 const QConv& p, const Epi& epi, int g, int oh0, int lane W16_STAMP_ARGS) {
+                                                 const QConv& p, const Epi& epi, int g, int oh0, int lane, const v16i& mg_item W16_STAMP_ARGS) {
   int l_ = lane;
   asm volatile("" : "+v"(l_));     // per-lane offsets are recomputed per phase (hoisted out of the item loop they spill)
   const int r = l_ & 31, h = l_ >> 5;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void conv3x3_rows_w16(const uint8_t* tile, v4i (&w)[W
     // ONE live copy of the start block, one accumulator, the rows one after the other (a scheduling fence per row: with all four rows'
     // MFMAs run ahead, as the compiler schedules the plain form, 4 x 16 accumulators + the start block do not fit 128 VGPRs); an input
     // row is read when its first output row needs it.
-    const v16i mg = magic_block();
+    const v16i& mg = mg_item;
     load_row(0); load_row(1);
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
@@ -331,6 +331,8 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
 #pragma unroll
       for (int ks = 0; ks < W16_KS; ++ks) w[ks] = *reinterpret_cast<const v4i*>(wl + l_ * 16 + ks * 1024);
     }
+    v16i mg_item = acc_start<false>();
+    if constexpr (MAGIC) mg_item = magic_block();          // ONE copy of the start block per item (round 6 trial)
     W16_STAMP();
     // (the item's last epilogue -- straight to HBM -- is not followed by a barrier: a wave may fill the next item's tables while
     //  another still reads this item's, so consecutive items use different table sets)
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
 #pragma unroll
       for (int g4 = 0; g4 < 3; ++g4) b4[g4] = *reinterpret_cast<const float4*>(bias0 + 8 * g4 + 4 * h);
       v16i zero16 = acc_start<false>();
-      if constexpr (MAGIC) zero16 = magic_block();
+      if constexpr (MAGIC) zero16 = mg_item;
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
         W16_PRIO(i);
@@ -370,11 +372,11 @@ __global__ __launch_bounds__(W16_THREADS) void stem_chain_w16_kernel(const ArgsA
     for (int k = 0; k < NBLK; ++k) {
       const BlockParams& bp = a.blk[k];
       auto conv_a = [&](const auto& epi) {
-        conv3x3_rows_w16<RW, MAGIC>(xt, w, wl + (2 * k + 1) * WB, bias_lds + (2 * k) * L1::COUT, bp.a, epi, wg, woh0, lane W16_STAMP_PASS);
+        conv3x3_rows_w16<RW, MAGIC>(xt, w, wl + (2 * k + 1) * WB, bias_lds + (2 * k) * L1::COUT, bp.a, epi, wg, woh0, lane, mg_item W16_STAMP_PASS);
       };
       auto conv_b = [&](const auto& epi) {
         conv3x3_rows_w16<RW, MAGIC>(tt, w, k + 1 < NBLK ? wl + (2 * k + 2) * WB : nullptr, bias_lds + (2 * k + 1) * L1::COUT, bp.b, epi, wg, woh0,
-                             lane W16_STAMP_PASS);
+                             lane, mg_item W16_STAMP_PASS);
       };
       if constexpr (DROP) conv_a(EpiTileDrop<L1::HO, L1::PIXB, L1::TILE_BYTES, L1::COUT>{tt, bp.a, dr.d[1 + 2 * k], {mtab + (1 + 2 * k) * MTB, 0.f}});
       else conv_a(EpiTile<L1::HO, L1::PIXB, L1::TILE_BYTES>{tt, bp.a});
