@@ -36,11 +36,7 @@ using D24_a = ConvCfg<24, 48, 3, 2, 32, 1, 1, 1, 2>;
 using D24_s = ConvCfg<24, 48, 1, 2, 32, 1, 1, 1, 2>;
 using D24_b = ConvCfg<48, 48, 3, 1, 16, 1, 1, 1, 2>;
 using D48_a = ConvCfg<48, 96, 3, 2, 16, 1, 4, 1, 3, false>;
-using D48_s = ConvCfg<48, 96, 1, 2, 16, 1, 4, 1, 3, false>;
-using D48_b = ConvCfg<96, 96, 3, 1, 8, 1, 4, 1, 3, false, 36, 8>;
 using D96_a = ConvCfg<96, 192, 3, 2, 8, 1, 8, 1, 3, false>;
-using D96_s = ConvCfg<96, 192, 1, 2, 8, 1, 8, 1, 3, false>;
-using D96_b = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, false>;
 
 static int build_down_args(DownArgs& a, const uint8_t* x, int64_t x_ss, float s_x, int32_t z_x, int32_t B, int32_t a_hi, const qbnn_down_desc* d,
                            uint8_t* y, int64_t y_ss, int32_t n_samples, const qbnn_drop_desc* drops = nullptr) {
@@ -84,8 +80,8 @@ QBNN_EXPORT int qbnn_block_down_i8_multi(const qbnn_down_call* calls, int32_t n_
     if (lay != QBNN_LAYOUT_MFMA32 && !(lay == QBNN_LAYOUT_MFMA32_N24 && Cin == 24 && H == 32))
       return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: MFMA32 weights (MFMA32_N24 set: the 24 -> 48 block)%s");
     if (Cin == 24 && H == 32) rc = lay == QBNN_LAYOUT_MFMA32_N24 ? qbnn_launch_down24_w16(arr, n, st) : launch_block_down_ws_multi<D24_a, D24_s, D24_b, true>(arr, n, st);
-    else if (Cin == 48 && H == 16) rc = qbnn_use_down_ring() ? qbnn_launch_block_down_ring(arr, n, 48, st) : launch_block_down_ws_multi<D48_a, D48_s, D48_b, false>(arr, n, st);
-    else if (Cin == 96 && H == 8) rc = qbnn_use_down_ring() ? qbnn_launch_block_down_ring(arr, n, 96, st) : launch_block_down_ws_multi<D96_a, D96_s, D96_b, false>(arr, n, st);
+    else if (Cin == 48 && H == 16) rc = qbnn_launch_block_down_ring(arr, n, 48, st);
+    else if (Cin == 96 && H == 8) rc = qbnn_launch_block_down_ring(arr, n, 96, st);
     else return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
     if (rc) return rc;
     c0 += n;
@@ -110,8 +106,8 @@ QBNN_EXPORT int qbnn_block_down_i8_mc(const uint8_t* x, int64_t x_ss, float s_x,
   //  than the weights-stationary kernel: five barrier intervals per image, each as long as the slower group's phase)
   if (Cin == 24 && H == 32) return launch_block_down_ws<D24_a, D24_s, D24_b, true>(a, st);
   // 48 -> 96 and 96 -> 192: the block's weights through the LDS slab ring (qbnn_down_ring.hip, round 4); QBNN_DOWN_RING=0: per-wave L2 streaming
-  if (Cin == 48 && H == 16) return qbnn_use_down_ring() ? qbnn_launch_block_down_ring(&a, 1, 48, st) : launch_block_down_ws<D48_a, D48_s, D48_b, false>(a, st);
-  if (Cin == 96 && H == 8) return qbnn_use_down_ring() ? qbnn_launch_block_down_ring(&a, 1, 96, st) : launch_block_down_ws<D96_a, D96_s, D96_b, false>(a, st);
+  if (Cin == 48 && H == 16) return qbnn_launch_block_down_ring(&a, 1, 48, st);
+  if (Cin == 96 && H == 8) return qbnn_launch_block_down_ring(&a, 1, 96, st);
   return fail(QBNN_E_INVALID, "qbnn_block_down_i8_mc: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
 }
 
@@ -480,362 +476,13 @@ static int launch_block_chain_pp(const ChainArgs<NBLK>& a, hipStream_t st) {
   return check_launch("qbnn_block_chain_i8_mc");
 }
 
-// =====================================================================================
-// Wide identity block (96 / 192 channels): the block's weights (162 / 663 KiB per MC sample) neither fit in LDS nor
-// can every wave afford to stream its own copy from L2, so they pass ONCE per work item through a two-slab LDS ring
-// (global_load_lds) shared by the 8 waves.  To leave room for the ring the stem.0 output T overwrites the input tile X
-// IN PLACE: each conv runs as two workgroup-wide phases,
-//     M: every wave accumulates its MB x NB output tiles over all weight slabs (reads the tile),
-//     E: after a barrier, every wave requantises its accumulators and writes them over the tile,
-// and the residual operand of the Add is re-read from global memory (the block input, L2-hot, quint8) instead of
-// being kept in LDS.  One pass per wave: C::NPASS == 8.
-// The tile is DENSE.  With the 1-pixel halo an 8x8 / 4x4 map costs 1.56x / 2.25x its size
-// in LDS; stored dense ([image][oh][ow][C + 16]) twice as many images fit next to the weight ring (8 at 96 channels,
-// 16 at 192), which doubles the MFMA work per weight slab (the slab's LDS-DMA latency hides behind it) and halves the
-// weight bytes moved per image.  (A halo'd variant with 8 images per item was 15 % slower at 192 channels.)  Zero padding is then a per-lane address choice: a tap that falls outside the map
-// reads a line of zeros instead.  The tap's position is a function of the slab / k-step only, so this costs a few
-// VALU operations per slab.
-// =====================================================================================
-template <class C> struct DenseTile {
-  static constexpr int IMG = C::HO * C::HO * C::PIXB;
-  static constexpr int BYTES = C::G * IMG;                  // followed by the zero line (C::PIXB bytes)
-  static constexpr int TPS = C::SLK / C::SPT;               // taps per weight slab
-  static_assert(C::PADB > 0 && C::SLK % C::SPT == 0 && C::STRIDE == 1 && C::KSZ == 3, "slabs are whole taps");
-};
-
-template <class C, int NWV, class FNext>
-__device__ __forceinline__ void conv_ring_mfma_dense(const uint8_t* tile, uint8_t* rbase, int& rcur, const int8_t* wq, ConvAcc<C>& A,
-                                                     int wave, int lane, FNext prefetch_next) {
-  static_assert(C::NPASS == NWV, "one pass per wave");
-  using DT = DenseTile<C>;
-  const int r = lane & 31, h = lane >> 5;
-  const int mblk = wave / C::NBLKS, nblk = wave - mblk * C::NBLKS;
-  int pix0[C::MB], poh[C::MB], pow_[C::MB];               // this lane's pixel per M-tile: byte offset, row, column
-#pragma unroll
-  for (int mb = 0; mb < C::MB; ++mb) {
-    const int m = (mblk * C::MB + mb) * 32 + r;
-    const int rem = m % (C::HO * C::HO);
-    poh[mb] = rem / C::HO; pow_[mb] = rem % C::HO;
-    pix0[mb] = m * C::PIXB + 16 * h;
-  }
-  const uint8_t* zline = tile + DT::BYTES + 16 * h;
-#pragma unroll
-  for (int mb = 0; mb < C::MB; ++mb) {
-    A.rsum[mb] = 0;
-#pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) A.acc[mb][nb][i] = 0;
-  }
-  struct Frags { v4i w[C::NB]; v4i x[C::MB]; };              // one k-step per buffer
-  QBNN_INNER_T0();
-#pragma unroll 1
-  for (int slab = 0; slab < C::NSLAB; ++slab) {
-    dma_barrier();            // slab landed; everyone is done with the other buffer; slab 0: tile complete
-    QBNN_INNER_AT(0);
-    uint8_t* other = rbase + (rcur ^ 1) * C::SLAB_BYTES;
-    if (slab + 1 < C::NSLAB) dma_slab<C, NWV>(other, wq, slab + 1, wave, lane);
-    else prefetch_next(other);
-    const uint8_t* wl = rbase + rcur * C::SLAB_BYTES + ((nblk * C::NB) * C::SLK * 64 + lane) * 16;
-    rcur ^= 1;
-    const uint8_t* tb[C::MB][DT::TPS];
-#pragma unroll
-    for (int tp = 0; tp < DT::TPS; ++tp) {
-      const int tap = slab * DT::TPS + tp, kh = tap / 3, kw = tap - 3 * kh;
-#pragma unroll
-      for (int mb = 0; mb < C::MB; ++mb) {
-        const bool ok = (unsigned)(poh[mb] + kh - 1) < (unsigned)C::HO && (unsigned)(pow_[mb] + kw - 1) < (unsigned)C::HO;
-        tb[mb][tp] = ok ? tile + pix0[mb] + ((kh - 1) * C::HO + (kw - 1)) * C::PIXB : zline;
-      }
-    }
-    auto load_step = [&](Frags& f, int j) {
-#pragma unroll
-      for (int nb = 0; nb < C::NB; ++nb) f.w[nb] = *reinterpret_cast<const v4i*>(wl + (nb * C::SLK + j) * 1024);
-#pragma unroll
-      for (int mb = 0; mb < C::MB; ++mb) f.x[mb] = load_xfrag<C>(tb[mb][j / C::SPT] + (j % C::SPT) * 32);
-    };
-    auto mfma_step = [&](const Frags& f) {
-#pragma unroll
-      for (int mb = 0; mb < C::MB; ++mb) {
-        // (no window sum here: 4 v_dot4 per fragment cost 11 % of the kernel; the epilogue gathers it from the
-        //  per-pixel channel sums kept beside the tile, see window_sum_from_table)
-#pragma unroll
-        for (int nb = 0; nb < C::NB; ++nb)
-          A.acc[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[nb], f.x[mb], A.acc[mb][nb], 0, 0, 0);
-      }
-    };
-    Frags f0, f1;
-    load_step(f0, 0);
-#pragma unroll
-    for (int j = 0; j < C::SLK; ++j) {
-      Frags& cur = (j & 1) ? f1 : f0;
-      Frags& nxt = (j & 1) ? f0 : f1;
-      if (j + 1 < C::SLK) load_step(nxt, j + 1);
-      mfma_step(cur);
-    }
-    QBNN_INNER_AT(1);
-  }
-  QBNN_INNER_FLUSH();
-}
-
-// (EpiDenseTile, window_sum_from_table and EpiDenseTileResGlobal live in qbnn_conv.h: qbnn_chain_ring.hip uses them too)
-
-// (EpiDenseTileDrop / EpiDenseTileResGlobalDrop: qbnn_conv.h)
-
-// NWV = 8: two waves per SIMD, 256 VGPRs each (MB x NB = 2 x 3 tiles per wave).  Measured alternatives, all slower:
-// NWV = 4 (one wave per SIMD, 4 x 3 tiles in the 512-register file: -25 %, the epilogues read accumulators out of AGPRs
-// and a lone wave hides no latency); NWV = 12 (4 x 1 tiles, 168 VGPRs: -12 %) and NWV = 16 (1 x 3 tiles, 128 VGPRs:
-// -5 %; round 3 re-ran it at 96 channels with the per-lane addresses kept out of the item loop -- 126 VGPRs, no spills -- and it takes the
-// same 0.343 ms as 8 waves: four waves per SIMD buy these kernels nothing), both of which spill the next item's input prefetch and so put its HBM latency back on the critical path; and two
-// independent 4-wave workgroups per CU (4 images each, 9 KiB slabs) whose M and E phases drift apart on their own: equal
-// time at 96 channels -- overlapping the phases is not what this kernel lacks.
-// Round 2 re-tested that with a full ping-pong kernel (two 4-wave groups in anti-phase sharing ONE weight ring, the E group
-// taking its epilogue in slices between the M group's slab barriers; bit-exact, no spills): 0.399 ms at 96 channels and
-// 0.454 ms at 192 against 0.341 / 0.298 ms here.  The wall is accumulator capacity: the 8 waves' 48 accumulator tiles ARE the
-// item (8 / 16 images); a group that drains its accumulators while the other multiplies halves the images per pass of the
-// block's weights (162 / 663 KiB), and the L2 -> LDS weight stream (3.5 TB/s chip-wide here, 4.7 TB/s there) is what the M
-// phase waits for.  More images per weight pass needs more accumulator registers, not more LDS.
-template <class C, int NWV, int NM = 1, bool DROP = false>
-__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 4, NWV / 4)))
-void block_chain_ald_kernel(const ArgsArr<ChainArgs<1>, NM> all, const DropSet<DROP ? 2 : 0> dr) {
-  const ChainArgs<1> a = args_of(all, blockIdx.y);
-  static_assert(!DROP || NM == 1, "dropout variants are single-call");
-  constexpr int MTB = MaskTab<C::COUT, false>::bytes(C::G);
-  static_assert(C::CIN == C::COUT && C::CIN % 32 == 0, "wide identity BasicBlock");
-  using DT = DenseTile<C>;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr int NTHR = 64 * NWV;
-  uint8_t* xt = smem;                                                        // dense tile + zero line
-  uint8_t* rbase = smem + DT::BYTES + C::PIXB;                               // two weight slabs
-  static_assert((DT::BYTES + C::PIXB) % 16 == 0, "ring alignment");
-  int rcur = 0;
-  float* bias_lds = reinterpret_cast<float*>(rbase + 2 * C::SLAB_BYTES);     // [2][COUT]
-  int* sx = reinterpret_cast<int*>(bias_lds + 2 * C::COUT);                  // channel sums of the X tile  [G * HO * HO]
-  int* stab = sx + C::G * C::HO * C::HO;                                     // ... of the T tile
-  uint8_t* mtab = reinterpret_cast<uint8_t*>(stab + C::G * C::HO * C::HO);   // DROP: mask tables of stem.3 and stem.6, fp32 [G][COUT] each
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar control flow and addresses
-  const BlockParams& bp = a.blk[0];
-
-  constexpr int IMG_PX = C::HO * C::HO;
-  constexpr int CPP = C::CIN / 16;                                           // 16-byte chunks per pixel
-  constexpr int NCH = C::G * IMG_PX * CPP;
-  constexpr int PER_T = (NCH + NTHR - 1) / NTHR;
-  const int groups = (a.B + C::G - 1) / C::G;
-  const ItemWalk walk(a.n_samples * groups, blockIdx.x, gridDim.x);     // interleaved per XCD: a sample's weights stay in ONE L2
-  const int count = walk.count;
-
-  for (int i = tid; i < C::PIXB / 4; i += NTHR) reinterpret_cast<uint32_t*>(xt + DT::BYTES)[i] = 0u;
-  for (int i = tid; i < 2 * C::G * C::HO * C::HO; i += NTHR) sx[i] = 0;
-  load_bias<C::COUT, NTHR>(bias_lds, bp.a.bias, tid);
-  load_bias<C::COUT, NTHR>(bias_lds + C::COUT, bp.b.bias, tid);
-  if (count <= 0) return;
-  __syncthreads();                                   // tables are zero before the first tile write adds into them
-  auto dot16 = [](const v4i& c) {
-    int d = __builtin_amdgcn_sdot4(c.x, 0x01010101, 0, false);
-    d = __builtin_amdgcn_sdot4(c.y, 0x01010101, d, false);
-    d = __builtin_amdgcn_sdot4(c.z, 0x01010101, d, false);
-    return __builtin_amdgcn_sdot4(c.w, 0x01010101, d, false);
-  };
-
-  // an item's images are contiguous in HBM: chunk i of the item is byte 16 i of that block
-  v4i pre[PER_T];
-  auto fetch = [&](int item) {
-    const int s = item / groups, img0 = (item - s * groups) * C::G;
-    const uint8_t* xs = a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_PX * C::CIN;
-    const int valid = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX * CPP;
-    int t = tid;
-    asm volatile("" : "+v"(t));         // per-thread addresses are recomputed here, not hoisted out of the item loop (spills)
-#pragma unroll
-    for (int j = 0; j < PER_T; ++j) {
-      const int i = t + j * NTHR;
-      pre[j] = *reinterpret_cast<const v4i*>(xs + (i < valid ? (int64_t)i * 16 : 0));
-    }
-  };
-  auto write_tile = [&](int item) {
-    const int s = item / groups, img0 = (item - s * groups) * C::G;
-    const int valid = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX * CPP;
-    const uint32_t z4 = (uint32_t)a.z_in * 0x01010101u;
-    int t = tid;
-    asm volatile("" : "+v"(t));
-#pragma unroll
-    for (int j = 0; j < PER_T; ++j) {
-      const int i = t + j * NTHR;
-      if (i < NCH) {
-        const int px = i / CPP, within = i - px * CPP;
-        const v4i v = pre[j];
-        const v4i c = i < valid ? v4i{(int)sub_bytes(v.x, z4), (int)sub_bytes(v.y, z4), (int)sub_bytes(v.z, z4), (int)sub_bytes(v.w, z4)} : v4i{0, 0, 0, 0};
-        *reinterpret_cast<v4i*>(xt + px * C::PIXB + within * 16) = c;
-        __hip_atomic_fetch_add(&sx[px], dot16(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-  };
-  auto wbase = [&](const QConv& q, int item) { return q.w + (int64_t)(item / groups) * q.w_ss; };
-
-  fetch(walk.item(0));
-  write_tile(walk.item(0));
-  dma_slab<C, NWV>(rbase, wbase(bp.a, walk.item(0)), 0, wave, lane);
-  ConvAcc<C> A;
-  QBNN_STAMP_DECL
-  for (int it = 0; it < count; ++it) {
-    QBNN_STAMP_START();
-    const int item = walk.item(it);
-    const int s = item / groups, img0 = (item - s * groups) * C::G;
-    const bool more = it + 1 < count;
-    const int next = more ? walk.item(it + 1) : item;
-    if constexpr (DROP) {        // this item's masks: published by the slab barriers of the M phase that follows, first read in its epilogue
-      fill_mask_tab<C::G, C::COUT, false, NTHR>(mtab, dr.d[0], s, img0, a.B, tid);
-      fill_mask_tab<C::G, C::COUT, false, NTHR>(mtab + MTB, dr.d[1], s, img0, a.B, tid);
-    }
-    // ---- stem.0: M over the X tile, then T over it
-    conv_ring_mfma_dense<C, NWV>(xt, rbase, rcur, wbase(bp.a, item), A, wave, lane,
-                            [&](uint8_t* dst) { dma_slab<C, NWV>(dst, wbase(bp.b, item), 0, wave, lane); });
-    QBNN_STAMP_AT(0);
-    lds_barrier();                                       // every wave has read its last X fragment
-    QBNN_STAMP_AT(1);
-    {
-      // stem.0 epilogue: window sums from the X table; the T table collects the channel sums of what is written
-      window_sum_from_table<C>(sx, A, wave, lane);
-      auto run = [&](auto& epi) {
-        auto flush = [&](int mb) {
-          const int v = half_sum(epi.csum);
-          epi.csum = 0;
-          if (lane < 32) __hip_atomic_fetch_add(&stab[((wave / C::NBLKS) * C::MB + mb) * 32 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        conv_epi_phase_with<C, std::remove_reference_t<decltype(epi)>>(bias_lds, bp.a, epi, A, wave, lane, [&](int, int, int, int, int) { return 0u; },
-                                                                       [&](int mb) { if (mb > 0) flush(mb - 1); });
-        flush(C::MB - 1);
-      };
-      if constexpr (DROP) {
-        EpiDenseTileDrop<C::PIXB, C::COUT, IMG_PX> epi{xt, bp.a, dr.d[0], {mtab, 0.f}, 0};
-        run(epi);
-      } else {
-        EpiDenseTile<C::PIXB> epi{xt, bp.a, 0};
-        run(epi);
-      }
-    }
-    QBNN_STAMP_AT(2);
-    // ---- stem.3: M over T; residual and next input are requested during the last slab
-    const int valid_px = (a.B - img0 < C::G ? a.B - img0 : C::G) * IMG_PX;
-    const uint8_t* resp = a.x + (int64_t)s * a.x_ss + (int64_t)img0 * IMG_PX * C::COUT;
-    auto make_epi_b = [&]() {
-      if constexpr (DROP) return EpiDenseTileResGlobalDrop<C::PIXB, C::COUT, IMG_PX>{xt, resp, valid_px, bp.b, bp.add, dr.d[1], {mtab + MTB, 0.f}};
-      else return EpiDenseTileResGlobal<C::PIXB, C::COUT>{xt, resp, valid_px, bp.b, bp.add};
-    };
-    auto epi_b = make_epi_b();
-    uint32_t resq[2][C::NB][4];
-    auto load_res = [&](int mb) {
-      const int mblk = wave / C::NBLKS, nblk = wave - mblk * C::NBLKS;
-#pragma unroll
-      for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-          resq[mb & 1][nb][g4] = epi_b.load_px((mblk * C::MB + mb) * 32 + (lane & 31), (nblk * C::NB + nb) * 32 + 8 * g4 + 4 * (lane >> 5));
-    };
-    conv_ring_mfma_dense<C, NWV>(xt, rbase, rcur, wbase(bp.b, item), A, wave, lane,
-                            [&](uint8_t* dst) { if (more) dma_slab<C, NWV>(dst, wbase(bp.a, next), 0, wave, lane); load_res(0); fetch(next); });
-    QBNN_STAMP_AT(3);
-    lds_barrier();
-    QBNN_STAMP_AT(4);
-    for (int i = tid; i < C::G * IMG_PX; i += NTHR) sx[i] = 0;          // X table: last read in the stem.0 epilogue; refilled by the tile write below
-    window_sum_from_table<C>(stab, A, wave, lane);
-    conv_epi_phase_with<C, decltype(epi_b)>(bias_lds + C::COUT, bp.b, epi_b, A, wave, lane,
-                                            [&](int mb, int nb, int g4, int, int) { return resq[mb & 1][nb][g4]; },
-                                            [&](int mb) {
-#ifdef QBNN_STAMP_EB
-                                              QBNN_STAMP_AT(4 + mb);
-#endif
-                                              if (mb + 1 < C::MB) load_res(mb + 1); });
-#ifdef QBNN_STAMP_EB
-    QBNN_STAMP_AT(6);
-#else
-    QBNN_STAMP_AT(5);
-#endif
-    lds_barrier();
-#ifndef QBNN_STAMP_EB
-    QBNN_STAMP_AT(6);
-#endif
-    for (int i = tid; i < C::G * IMG_PX; i += NTHR) stab[i] = 0;        // T table: every wave has gathered from it
-    // ---- per 16-byte chunk: tile -> quint8 register, next item's input -> the same tile bytes, register -> HBM (the
-    //      item's output block is contiguous).  The next input is written unconditionally (the last item rewrites
-    //      itself): a prefetch left unconsumed on one path makes the compiler guard later reuses with vmcnt(0).
-    {
-      const uint32_t z4o = (uint32_t)bp.add.z_o * 0x01010101u, z4i = (uint32_t)a.z_in * 0x01010101u;
-      uint8_t* ys = a.y + (int64_t)s * a.y_ss + (int64_t)img0 * IMG_PX * C::COUT;
-      const int valid = valid_px * CPP;
-      const int nimg0 = (next - (next / groups) * groups) * C::G;
-      const int nvalid = (a.B - nimg0 < C::G ? a.B - nimg0 : C::G) * IMG_PX * CPP;
-      int t = tid;
-      asm volatile("" : "+v"(t));
-#pragma unroll
-      for (int j = 0; j < PER_T; ++j) {
-        const int i = t + j * NTHR;
-        if (i < NCH) {
-          const int px = i / CPP, within = i - px * CPP;
-          v4i* cell = reinterpret_cast<v4i*>(xt + px * C::PIXB + within * 16);
-          const v4i v = *cell, n = pre[j];
-          const v4i c = i < nvalid ? v4i{(int)sub_bytes(n.x, z4i), (int)sub_bytes(n.y, z4i), (int)sub_bytes(n.z, z4i), (int)sub_bytes(n.w, z4i)} : v4i{0, 0, 0, 0};
-          *cell = c;
-          __hip_atomic_fetch_add(&sx[px], dot16(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (i < valid)
-            *reinterpret_cast<v4i*>(ys + (int64_t)i * 16) = v4i{(int)add_bytes(v.x, z4o), (int)add_bytes(v.y, z4o), (int)add_bytes(v.z, z4o), (int)add_bytes(v.w, z4o)};
-        }
-      }
-    }
-    QBNN_STAMP_AT(7);
-  }
-#ifdef QBNN_STAMP
-  if (a.dbg && (tid & 63) == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(a.dbg + wave * 8 + i, st_acc[i]);
-#endif
-}
-
-template <class C, int NWV>
-static int launch_block_chain_ald(const ChainArgs<1>& a, hipStream_t st) {
-  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4;
-  static_assert(LDS <= 160 * 1024, "LDS budget");
-  static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV, 1>, attr, LDS)) return rc_attr;
-  const int groups = (a.B + C::G - 1) / C::G;
-  const int n_items = a.n_samples * groups;
-  const int grid = n_items < 256 ? n_items : 256;
-  ArgsArr<ChainArgs<1>, 1> one;
-  one.m[0] = a;
-  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, 1>), dim3(grid), dim3(64 * NWV), LDS, st, one, DropSet<0>{});
-  return check_launch("qbnn_block_chain_i8_mc");
-}
-
-template <class C, int NWV>
-static int launch_block_chain_ald_drop(const ChainArgs<1>& a, const DropSet<2>& dr, hipStream_t st) {
-  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4 + 2 * MaskTab<C::COUT, false>::bytes(C::G);
-  static_assert(LDS <= 160 * 1024, "LDS budget");
-  static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV, 1, true>, attr, LDS)) return rc_attr;
-  const int groups = (a.B + C::G - 1) / C::G;
-  const int n_items = a.n_samples * groups;
-  const int grid = n_items < 256 ? n_items : 256;
-  ArgsArr<ChainArgs<1>, 1> one;
-  one.m[0] = a;
-  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, 1, true>), dim3(grid), dim3(64 * NWV), LDS, st, one, dr);
-  return check_launch("qbnn_block_chain_drop_i8_mc");
-}
+// (Round 3's two-slab form of the 96 / 192-channel identity block -- block_chain_ald_kernel, the QBNN_CHAIN_RING=0 path of rounds 4 - 5 -- left the build in
+//  round 6: tools/experiments/r03_block_chain_ald_kernel.hip.txt.  Those blocks run on csrc/qbnn_chain_ring.hip.)
 
 // grid of a fused multi-call launch: every call gets the same number of workgroups (<= its item count), 256 in total
 static int fused_grid_x(int max_items, int n_calls) {
   const int per = 256 / n_calls > 0 ? 256 / n_calls : 1;
   return max_items < per ? (max_items > 0 ? max_items : 1) : per;
-}
-
-template <class C, int NWV>
-static int launch_block_chain_ald_multi(const ChainArgs<1>* arr, int n, hipStream_t st) {
-  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4;
-  static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV, QBNN_FUSED_CALLS>, attr, LDS)) return rc_attr;
-  ArgsArr<ChainArgs<1>, QBNN_FUSED_CALLS> all;
-  memset(&all, 0, sizeof(all));                   // unused blocks: n_samples = 0 -> their workgroups (none launched) would exit at once
-  int items = 0;
-  for (int i = 0; i < n; ++i) { all.m[i] = arr[i]; const int it = arr[i].n_samples * ((arr[i].B + C::G - 1) / C::G); items = it > items ? it : items; }
-  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, QBNN_FUSED_CALLS>), dim3(fused_grid_x(items, n), n), dim3(64 * NWV), LDS, st, all, DropSet<0>{});
-  return check_launch("qbnn_block_chain_i8_multi");
 }
 
 
@@ -1127,9 +774,6 @@ static int launch_block_down_ws_multi(const DownArgs* arr, int n, hipStream_t st
 //                          CIN COUT K  S  HIN HALO G  MB NB
 using Blk_24  = ConvCfg<24, 24, 3, 1, 32, 1, 1, 4, 1>;
 using Blk_48  = ConvCfg<48, 48, 3, 1, 16, 1, 2, 2, 2>;
-using ALD_96  = ConvCfg<96, 96, 3, 1, 8, 1, 8, 2, 3, true, 36, 16>;      // dense aliased-tile ring kernel
-using ALD_192 = ConvCfg<192, 192, 3, 1, 4, 1, 16, 2, 3, true, 36, 16>;
-using ALD_192_G8 = ConvCfg<192, 192, 3, 1, 4, 1, 8, 1, 3, true, 36, 16>;  // 8 images per item: ensemble members at B <= 256 (16 items per member leave half the CUs idle)
 using PP_48   = ConvCfg<48, 48, 3, 1, 16, 1, 1, 2, 2>;          // per wave group of the ping-pong kernel
 // (A 16-wave instantiation of the 48-channel chain -- ConvCfg<48, 48, 3, 1, 16, 1, 2, 1, 2> at 1024 threads, 88 VGPRs, one pass per
 //  wave and conv -- takes the same 0.389 ms as the 8-wave kernels (0.391): occupancy alone does not buy the overlap, round 3.)
@@ -1204,7 +848,7 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
                                 int32_t a_hi, const qbnn_block_desc* blk, uint8_t* y, int64_t y_ss, int32_t n_samples,
                                 hipStream_t st, const int8_t* stem_x = nullptr, const QConv* stem = nullptr) {
   ChainArgs<NBLK> a;
-  const bool pool_ok = Cc == 192 && H == 4 && NBLK == 1 && !stem && qbnn_use_chain_ring() && blk[0].w_layout == QBNN_LAYOUT_MFMA32;
+  const bool pool_ok = Cc == 192 && H == 4 && NBLK == 1 && !stem && blk[0].w_layout == QBNN_LAYOUT_MFMA32;
   if (int rc = build_chain_args<NBLK>(a, x, x_ss, s_x, z_x, B, a_hi, blk, y, y_ss, n_samples, stem_x, stem, nullptr, pool_ok)) return rc;
   if (stem) {
     if (Cc != 24 || H != 32) return fail(QBNN_E_INVALID, "qbnn_stem_chain_i8_mc: the fused stem feeds the 32x32x24 chain only%s");
@@ -1234,11 +878,11 @@ static int block_chain_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32
     else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one 48-channel block per launch for this batch size%s");
   }
   if (Cc == 96 && H == 8) {
-    if constexpr (NBLK == 1) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring(&a, 1, 96, false, st) : launch_block_chain_ald<ALD_96, 8>(a, st);
+    if constexpr (NBLK == 1) return qbnn_launch_block_chain_ring(&a, 1, 96, false, st);
     else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one block per launch at 96 channels (its weights stream through the LDS ring)%s");
   }
   if (Cc == 192 && H == 4) {
-    if constexpr (NBLK == 1) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring(&a, 1, 192, false, st) : launch_block_chain_ald<ALD_192, 8>(a, st);
+    if constexpr (NBLK == 1) return qbnn_launch_block_chain_ring(&a, 1, 192, false, st);
     else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: one block per launch at 192 channels (its weights stream through the LDS ring)%s");
   }
   return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_mc: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
@@ -1273,14 +917,6 @@ QBNN_EXPORT int qbnn_stem_chain_i8_mc(const int8_t* im2col, int32_t B, const int
 }
 
 // ---- prepared multi-call launches: the argument blocks live in device memory (ArgsArr<A, 0>) ---------------------------------------
-template <class C, int NWV>
-static int launch_block_chain_ald_dev(const ChainArgs<1>* dev, int n, int items, hipStream_t st) {
-  constexpr int LDS = DenseTile<C>::BYTES + C::PIXB + 2 * C::SLAB_BYTES + 2 * C::COUT * 4 + 2 * C::G * C::HO * C::HO * 4;
-  static std::atomic<uint64_t> attr{0};
-  if (int rc_attr = ensure_dyn_lds((const void*)block_chain_ald_kernel<C, NWV, 0>, attr, LDS)) return rc_attr;
-  hipLaunchKernelGGL((block_chain_ald_kernel<C, NWV, 0>), dim3(fused_grid_x(items, n), n), dim3(64 * NWV), LDS, st, ArgsArr<ChainArgs<1>, 0>{dev}, DropSet<0>{});
-  return check_launch("qbnn_block_chain_i8_multi_launch");
-}
 template <class C, int NBLK, bool STEM = false>
 static int launch_block_chain_ws_dev(const ChainArgs<NBLK>* dev, int n, int items, hipStream_t st) {
   constexpr int LDS = chain_ws_lds<C, NBLK, true, STEM>();
@@ -1388,11 +1024,10 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi_launch(const void* dev_args, int32_t n
   }
   if (w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: unknown weight layout%s");
   if (Cc == 48 && H == 16) return launch_block_chain_ws_dev<Blk_48, 1>(dev, n_calls, items(Blk_48::G), st);
-  if (Cc == 96 && H == 8) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring_dev(dev, n_calls, B, max_samples, 96, false, st) : launch_block_chain_ald_dev<ALD_96, 8>(dev, n_calls, items(ALD_96::G), st);
+  if (Cc == 96 && H == 8) return qbnn_launch_block_chain_ring_dev(dev, n_calls, B, max_samples, 96, false, st);
   if (Cc == 192 && H == 4) {
     const bool small_items = ((B + 15) / 16) * n_calls * max_samples <= 128;
-    if (qbnn_use_chain_ring()) return qbnn_launch_block_chain_ring_dev(dev, n_calls, B, max_samples, 192, small_items, st);
-    return small_items ? launch_block_chain_ald_dev<ALD_192_G8, 8>(dev, n_calls, items(8), st) : launch_block_chain_ald_dev<ALD_192, 8>(dev, n_calls, items(16), st);
+    return qbnn_launch_block_chain_ring_dev(dev, n_calls, B, max_samples, 192, small_items, st);
   }
   return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi_launch: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
 }
@@ -1426,9 +1061,9 @@ QBNN_EXPORT int qbnn_block_down_i8_multi_launch(const void* dev_args, int32_t n_
   if (w_layout != QBNN_LAYOUT_MFMA32) return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_launch: unknown weight layout%s");
   if (Cin == 24 && H == 32) return launch_block_down_ws_dev<D24_a, D24_s, D24_b, true>(dev, n_calls, items(D24_a::G), st);
   if (Cin == 48 && H == 16)
-    return qbnn_use_down_ring() ? qbnn_launch_block_down_ring_dev(dev, n_calls, items(D48_a::G), 48, st) : launch_block_down_ws_dev<D48_a, D48_s, D48_b, false>(dev, n_calls, items(D48_a::G), st);
+    return qbnn_launch_block_down_ring_dev(dev, n_calls, items(D48_a::G), 48, st);
   if (Cin == 96 && H == 8)
-    return qbnn_use_down_ring() ? qbnn_launch_block_down_ring_dev(dev, n_calls, items(D96_a::G), 96, st) : launch_block_down_ws_dev<D96_a, D96_s, D96_b, false>(dev, n_calls, items(D96_a::G), st);
+    return qbnn_launch_block_down_ring_dev(dev, n_calls, items(D96_a::G), 96, st);
   return fail(QBNN_E_INVALID, "qbnn_block_down_i8_multi_launch: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
 }
 
@@ -1463,8 +1098,8 @@ static int chain_drop_dispatch(const uint8_t* x, int64_t x_ss, float s_x, int32_
       else return fail(QBNN_E_INVALID, "qbnn_block_chain_drop_i8_mc: one 48-channel block per launch%s");
     }
     if constexpr (NBLK == 1) {
-      if (Cc == 96 && H == 8) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring_drop(a, dr, 96, st) : launch_block_chain_ald_drop<ALD_96, 8>(a, dr, st);
-      if (Cc == 192 && H == 4) return qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring_drop(a, dr, 192, st) : launch_block_chain_ald_drop<ALD_192, 8>(a, dr, st);
+      if (Cc == 96 && H == 8) return qbnn_launch_block_chain_ring_drop(a, dr, 96, st);
+      if (Cc == 192 && H == 4) return qbnn_launch_block_chain_ring_drop(a, dr, 192, st);
     }
     return fail(QBNN_E_INVALID, "qbnn_block_chain_drop_i8_mc: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
   }
@@ -1515,8 +1150,8 @@ QBNN_EXPORT int qbnn_block_down_drop_i8_mc(const uint8_t* x, int64_t x_ss, float
   hipStream_t st = (hipStream_t)stream;
   if (Cin == 24 && H == 32) return launch_block_down_ws_drop<D24_a, D24_s, D24_b, true, false>(a, dr, st);
   // 48 -> 96 and 96 -> 192: the ring form with one-bit mask tables (round 5); QBNN_DOWN_RING=0: the per-wave L2-streaming kernels
-  if (Cin == 48 && H == 16) return qbnn_use_down_ring() ? qbnn_launch_block_down_ring_drop(a, dr, 48, st) : launch_block_down_ws_drop<D48_a, D48_s, D48_b, false, false>(a, dr, st);
-  if (Cin == 96 && H == 8) return qbnn_use_down_ring() ? qbnn_launch_block_down_ring_drop(a, dr, 96, st) : launch_block_down_ws_drop<D96_a, D96_s, D96_b, false, true>(a, dr, st);
+  if (Cin == 48 && H == 16) return qbnn_launch_block_down_ring_drop(a, dr, 48, st);
+  if (Cin == 96 && H == 8) return qbnn_launch_block_down_ring_drop(a, dr, 96, st);
   return fail(QBNN_E_INVALID, "qbnn_block_down_drop_i8_mc: unsupported geometry%s Cin=%ld H=%ld", "", Cin, H);
 }
 
@@ -1564,11 +1199,10 @@ QBNN_EXPORT int qbnn_block_chain_i8_multi(const qbnn_chain_call* calls, int32_t 
       }
       if (n24 && !(Cc == 48 && H == 16)) return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: the MFMA32_N24 layout serves the 16x16x48 identity block%s");
       if (Cc == 48 && H == 16) rc = n24 ? qbnn_launch_chain48_w16(arr, n, st) : launch_block_chain_ws_multi<Blk_48, 1, false, QBNN_FUSED_CALLS>(arr, n, st);
-      else if (Cc == 96 && H == 8) rc = qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring(arr, n, 96, false, st) : launch_block_chain_ald_multi<ALD_96, 8>(arr, n, st);
+      else if (Cc == 96 && H == 8) rc = qbnn_launch_block_chain_ring(arr, n, 96, false, st);
       else if (Cc == 192 && H == 4) {
         const bool small_items = ((B + 15) / 16) * n <= 128;
-        rc = qbnn_use_chain_ring() ? qbnn_launch_block_chain_ring(arr, n, 192, small_items, st)
-                                   : small_items ? launch_block_chain_ald_multi<ALD_192_G8, 8>(arr, n, st) : launch_block_chain_ald_multi<ALD_192, 8>(arr, n, st);
+        rc = qbnn_launch_block_chain_ring(arr, n, 192, small_items, st);
       }
       else return fail(QBNN_E_INVALID, "qbnn_block_chain_i8_multi: unsupported geometry%s C=%ld H=%ld", "", Cc, H);
     }

@@ -1,9 +1,8 @@
 // libqbnn_hip.so -- the WIDE identity BasicBlocks (reference models_bbb.py:146-183, stride 1: stem.0 3x3 ConvReLU, stem.3 3x3 conv, Add,
 // ReLU) at 96 channels (8 x 8 maps) and 192 channels (4 x 4) with the K loop of qbnn_down_ring.hip.  Tile, epilogues, channel-sum tables
-// and argument block are those of block_chain_ald_kernel (qbnn_blocks.hip), which stays as the MC-Dropout (DROP) instantiation and as the
-// QBNN_CHAIN_RING=0 A/B path.
+// and argument block are those of round 3's block_chain_ald_kernel (out of the build since round 6: tools/experiments/r03_block_chain_ald_kernel.hip.txt).
 //
-// What changes (round 4): block_chain_ald_kernel runs a conv's K loop slab by slab over a TWO-slab ring -- `s_waitcnt vmcnt(0)`, barrier,
+// What changed (round 4): block_chain_ald_kernel ran a conv's K loop slab by slab over a TWO-slab ring -- `s_waitcnt vmcnt(0)`, barrier,
 // request the next slab, then the slab's k-steps with their LDS fragment reads one step ahead: at every slab the software pipeline restarts
 // from an empty state and the one slab in flight has to land within one slab's worth of MFMAs (stamps: 15.4 k / 35.2 k cycles per M phase
 // against 10.4 k / 20.7 k of MFMAs at 96 / 192 channels).  Here, as in the ring form of the down-sampling blocks:

@@ -62,23 +62,15 @@ int qbnn_launch_chain48_w16_dev(const ChainArgs<1>* dev, int n, int items, hipSt
 int qbnn_launch_down24_w16(const DownArgs* arr, int n, hipStream_t st);
 int qbnn_launch_down24_w16_dev(const DownArgs* dev, int n, int items, hipStream_t st);
 // Ring form of the wide down-sampling blocks (qbnn_down_ring.hip): 48 -> 96 at 16 x 16 and 96 -> 192 at 8 x 8; `n` argument blocks by value
-// (n <= QBNN_FUSED_CALLS) or any number in device memory.  QBNN_DOWN_RING=0 selects the L2-streaming kernels of qbnn_blocks.hip (A/B checks).
+// (n <= QBNN_FUSED_CALLS) or any number in device memory.  (Round 6: the only form -- the L2-streaming instantiations of rounds 1 - 3 left the build.)
 int qbnn_launch_block_down_ring(const DownArgs* arr, int n, int Cin, hipStream_t st);
 int qbnn_launch_block_down_ring_dev(const DownArgs* dev, int n, int items, int Cin, hipStream_t st);
 int qbnn_launch_block_down_ring_drop(const DownArgs& a, const DropSet<3>& dr, int Cin, hipStream_t st);      // ... with the block's three dropouts (conv_resnet_mc)
-static inline bool qbnn_use_down_ring() {
-  static const bool v = [] { const char* e = getenv("QBNN_DOWN_RING"); return !(e && e[0] == '0'); }();
-  return v;
-}
 // The wide identity blocks with the same K loop (qbnn_chain_ring.hip): 96 channels at 8 x 8, 192 at 4 x 4 (`small_items`: 8 instead of 16 images per
-// work item).  QBNN_CHAIN_RING=0 selects block_chain_ald_kernel (qbnn_blocks.hip).
+// work item).  (Round 6: the only form; round 3's block_chain_ald_kernel is tools/experiments/r03_block_chain_ald_kernel.hip.txt.)
 int qbnn_launch_block_chain_ring(const ChainArgs<1>* arr, int n, int Cc, bool small_items, hipStream_t st);
 int qbnn_launch_block_chain_ring_dev(const ChainArgs<1>* dev, int n, int B, int max_samples, int Cc, bool small_items, hipStream_t st);
 int qbnn_launch_block_chain_ring_drop(const ChainArgs<1>& a, const DropSet<2>& dr, int Cc, hipStream_t st);      // ... with the block's two dropouts (conv_resnet_mc)
-static inline bool qbnn_use_chain_ring() {
-  static const bool v = [] { const char* e = getenv("QBNN_CHAIN_RING"); return !(e && e[0] == '0'); }();
-  return v;
-}
 // QBNN_W16=0 selects the 8-wave kernels of qbnn_blocks.hip everywhere (A/B checks)
 static inline bool qbnn_use_w16() {
   static const bool v = [] { const char* e = getenv("QBNN_W16"); return !(e && e[0] == '0'); }();

@@ -104,7 +104,7 @@ def run_down_block(blk, x):
 def pool_out_enabled():
     """The network's last block hands the head its AvgPool2d(4) instead of the 4 x 4 map (QBNN_BLOCK_POOL_OUT; QBNN_HEAD_POOL=0 for the A/B);
     the flag is served by the ring form of the 192-channel block only."""
-    return os.environ.get("QBNN_HEAD_POOL", "1") != "0" and os.environ.get("QBNN_CHAIN_RING", "1") != "0"
+    return os.environ.get("QBNN_HEAD_POOL", "1") != "0"
 
 
 def run_identity_chain(blocks, x, stem=None, pool_out=False):

@@ -1158,7 +1158,7 @@ print("SWITCH-OK")
 """
 
 
-@pytest.mark.parametrize("switch", ["QBNN_NO_PINGPONG", "QBNN_NO_STEM_FUSION", "QBNN_GENERIC_NAIVE", "QBNN_W16=0", "QBNN_DOWN_RING=0", "QBNN_CHAIN_RING=0",
+@pytest.mark.parametrize("switch", ["QBNN_NO_PINGPONG", "QBNN_NO_STEM_FUSION", "QBNN_GENERIC_NAIVE", "QBNN_W16=0",
                                     "QBNN_C48=0", "QBNN_W16_MAGIC=0", "QBNN_D24=0", "QBNN_CHAIN_2WG=0", "QBNN_DOWN_R16=0", "QBNN_HEAD_POOL=0"])
 def test_environment_switches_give_the_same_results(switch, tmp_path):
     """The A/B switches of README.md select other kernels for the same arithmetic (weights-stationary instead of ping-pong
