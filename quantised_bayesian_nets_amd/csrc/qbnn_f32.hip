@@ -1315,14 +1315,13 @@ __global__ __launch_bounds__(256) void qat_weights_kernel(const QatWLayer* __res
       const float sgq = (fq_q(L.sg[i], qs, lo, hi) - qs.z) * qs.sc;       // s = FQ_s(sigma c)
       const float tp = e[j] * sgq;                                          // eps * s
       if (STAGE == 0) { vmin = fminf(vmin, tp); vmax = fmaxf(vmax, tp); continue; }
-      int64_t o = i;                                                        // the output element: [Cout][kh][kw][Cin] for a conv, the reference's order for a linear
+      uint32_t o = (uint32_t)i;                                             // the output element: [Cout][kh][kw][Cin] for a conv, the reference's order for a linear
       if (L.KS > 0) {
-        const int kw = (int)(i % L.KS);
-        int64_t r = i / L.KS;
-        const int kh = (int)(r % L.KS); r /= L.KS;
-        const int c = (int)(r % L.Cin);
-        const int oc = (int)(r / L.Cin);
-        o = (((int64_t)oc * L.KS + kh) * L.KS + kw) * L.Cin + c;
+        // i = ((oc Cin + c) KK + t), t = kh KS + kw  ->  o = (oc KK + t) Cin + c.  32-bit unsigned divisions (n < 2^31: the launcher checks); the 64-bit
+        // forms of sample_weights_f32_ohwi_kernel cost ~150 instructions each and were three quarters of this kernel
+        const uint32_t kk = (uint32_t)(L.KS * L.KS), ckk = (uint32_t)L.Cin * kk, iu = (uint32_t)i;
+        const uint32_t oc = iu / ckk, rem = iu - oc * ckk, c = rem / kk, t = rem - c * kk;
+        o = (oc * kk + t) * (uint32_t)L.Cin + c;
       }
       const float t = (fq_q(tp, qm, lo, hi) - qm.z) * qm.sc;               // t = FQ_m(eps * s)
       const float wq = (fq_q(L.mu[o], qw, lo, hi) - qw.z) * qw.sc;         // w = FQ_w(mu c)

@@ -145,6 +145,37 @@ __global__ __launch_bounds__(256, C::WPE) void conv2d_q8t_kernel(const ConvQ8Arg
     }
   };
 
+  // Chunked weights (Cin = 96 / 192): chunk ch + 1 is fetched into registers while chunk ch multiplies, so a chunk's L2 latency hides under the
+  // previous chunk's MFMAs instead of heading every chunk behind a barrier (the 4 x 4 x 192 layer staged six chunks back to back: 113 us per launch).
+  constexpr int WCH_ROWS = C::NCHUNK == 1 ? 3 : 1;
+  constexpr int WCH_SEG = C::NCHUNK == 6 ? C::ROWPAD / 2 : C::ROWPAD;
+  constexpr int WCH_UPS = WCH_SEG / C::U;
+  constexpr int WCH_UNITS = C::COUT_WG * WCH_ROWS * WCH_UPS, WCH_PER = (WCH_UNITS + 255) / 256;
+  v4i_q8 wreg[C::NCHUNK > 1 ? WCH_PER : 1];
+  auto load_w = [&](int ch) {
+    static_assert(C::NCHUNK == 1 || C::U == 16, "chunked weights move 16-byte units");
+#pragma unroll
+    for (int k = 0; k < WCH_PER; ++k) {
+      const int u = tid + 256 * k;
+      const int n = u / WCH_UPS, j = u % WCH_UPS;
+      const int kh = C::NCHUNK == 3 ? ch : ch / 2;
+      const int seg_valid = C::NCHUNK == 6 ? C::ROWB / 2 : C::ROWB;
+      const int srcoff = (C::NCHUNK == 6 ? (ch % 2) * seg_valid : 0) + j * C::U;
+      const int ng = cg * C::COUT_WG + n;
+      const bool ok = u < WCH_UNITS && j * C::U < seg_valid && ng < a.Cout;
+      v4i_q8 v = *reinterpret_cast<const v4i_q8*>(ws + (int64_t)(ok ? ng : 0) * K + kh * C::ROWB + (ok ? srcoff : 0));
+      if (!ok) v = v4i_q8{0, 0, 0, 0};
+      wreg[k] = v;
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int k = 0; k < WCH_PER; ++k) {
+      const int u = tid + 256 * k;
+      if (u < WCH_UNITS) *reinterpret_cast<v4i_q8*>(wl + (u / WCH_UPS) * C::WPITCH + (u % WCH_UPS) * C::U) = wreg[k];
+    }
+  };
+
   for (int it = 0; it < C::IT; ++it) {
     const int blk = b0 + it;
     if (blk >= nblocks) break;                                  // workgroup-uniform
@@ -171,6 +202,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv2d_q8t_kernel(const ConvQ8Arg
       }
     }
     if (C::NCHUNK == 1 && it == 0) stage_w(0);                 // the whole conv's weights: once per workgroup
+    if constexpr (C::NCHUNK > 1) load_w(0);
 
     v16i_q8 acc[C::NTW];
 #pragma unroll
@@ -180,9 +212,10 @@ __global__ __launch_bounds__(256, C::WPE) void conv2d_q8t_kernel(const ConvQ8Arg
     int rsum = 0;
 #pragma unroll
     for (int ch = 0; ch < C::NCHUNK; ++ch) {
-      if (C::NCHUNK > 1) {
+      if constexpr (C::NCHUNK > 1) {
         if (ch > 0) __syncthreads();                            // the previous chunk's weight reads are done
-        stage_w(ch);
+        store_w();
+        if (ch + 1 < C::NCHUNK) load_w(ch + 1);                 // in flight under this chunk's MFMAs
       }
       __syncthreads();
       // One k-step ahead: the fragments of step i + 1 are requested before the MFMAs of step i (a scheduling fence per step keeps the compiler
@@ -301,7 +334,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_q8_c3_kernel(const ConvQ8Args a
 }
 
 //                   Cin  s  Wo  G rows NTW CW chunks IT WPE
-using T_L1 = Q8TCfg<24, 1, 32, 1, 4, 1, 1, 1, 8, 4>;        // 32 x 32 x 24 -> 24 (.. 32 channels): one image per workgroup
+using T_L1 = Q8TCfg<24, 1, 32, 1, 4, 1, 1, 1, 8, 5>;        // 32 x 32 x 24 -> 24 (.. 32 channels): one image per workgroup
 using T_D24 = Q8TCfg<24, 2, 16, 1, 8, 2, 1, 1, 2, 3>;       // 32 x 32 x 24 -> 16 x 16 x 48 (.. 64)
 using T_C48 = Q8TCfg<48, 1, 16, 1, 8, 2, 1, 1, 2, 3>;       // 16 x 16 x 48 -> 48 (.. 64)
 using T_D48 = Q8TCfg<48, 2, 8, 2, 8, 3, 1, 1, 1, 2>;        // 16 x 16 x 48 -> 8 x 8 x 96
