@@ -354,8 +354,6 @@ class _WeightBatch:
         return out
 
 
-_WBATCH = {}          # (ids of the layers, device index, S) -> _WeightBatch
-
 
 def batch_weights(layers, dev):
     """All layers' weight pipelines in four launches (qbnn_qat_weights_mc): leaves each layer's sampled weights where `sampled_weights` picks them up.
@@ -364,14 +362,16 @@ def batch_weights(layers, dev):
     if not _wbatch_enabled() or _MC.eps is not None or S > 64 or not all(isinstance(m, _QATBBB) and hasattr(m, "add_weight") and hasattr(m, "mul_noise") for m in layers):
         return False
     dev = torch.device(dev)
+    # the batch lives on the first layer (it dies with the model): (ids of the layers, device index, S) -> _WeightBatch
+    cache = layers[0].__dict__.setdefault("_wbatch_cache", {})
     key = (tuple(id(m) for m in layers), dev.index if dev.index is not None else torch.cuda.current_device(), S)
-    wb = _WBATCH.get(key)
+    wb = cache.get(key)
     if wb is None or wb.ptrs != _WeightBatch.pointers(layers, dev):
         if torch.cuda.is_current_stream_capturing():
             return False          # (descriptors go up with a host copy: built by the eager pass that precedes every capture)
-        if len(_WBATCH) > 16:
-            _WBATCH.clear()
-        wb = _WBATCH[key] = _WeightBatch(layers, dev, S)
+        if len(cache) > 4:
+            cache.clear()
+        wb = cache[key] = _WeightBatch(layers, dev, S)
     with timed("qat_weights"):
         _lib.check(_lib.lib().qbnn_qat_weights_mc(_lib.ptr(wb.desc), wb.n_layers, wb.total_blocks, AVG_CONST, _MC.seed, _MC.sample_begin, S, _lib.current_stream()))
     pkey, capturing = _presample_key(dev), torch.cuda.is_current_stream_capturing()
