@@ -693,8 +693,7 @@ __global__ __launch_bounds__(256) void fake_quant_ex_f32_kernel(const float* __r
     const v4f* x4 = reinterpret_cast<const v4f*>(x + (int64_t)s * x_ss);
     v4f* y4 = reinterpret_cast<v4f*>(y + (int64_t)s * y_ss);
     uint32_t* q4 = q8 ? reinterpret_cast<uint32_t*>(q8 + (int64_t)s * n) : nullptr;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256) {
-      v4f v = x4[i];
+    auto quant4 = [&](v4f& v) {
       uint32_t pk = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -702,7 +701,26 @@ __global__ __launch_bounds__(256) void fake_quant_ex_f32_kernel(const float* __r
         v[k] = m * sc;
         pk |= ((uint32_t)(int)m & 0xffu) << (8 * k);
       }
-      if (y) y4[i] = v;            // (y NULL: the consumers take the int8 grid tensor + the per-sample scale -- round 6)
+      return pk;
+    };
+    // four float4s per thread and trip, all four loads in flight before the first is used (round 6: the pass is HBM-bound and ran at 3.5 TB/s with one)
+    const int64_t T = (int64_t)gridDim.x * 256, n4 = n / 4;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * T < n4; i += 4 * T) {
+      v4f v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = x4[i + u * T];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t pk = quant4(v[u]);
+        if (y) y4[i + u * T] = v[u];            // (y NULL: the consumers take the int8 grid tensor + the per-sample scale -- round 6)
+        if (q4) q4[i + u * T] = pk;
+      }
+    }
+    for (; i < n4; i += T) {
+      v4f v = x4[i];
+      const uint32_t pk = quant4(v);
+      if (y) y4[i] = v;
       if (q4) q4[i] = pk;
     }
     return;
@@ -720,7 +738,8 @@ QBNN_EXPORT int qbnn_fake_quant_ex_f32_mc(const float* x, int64_t x_ss, float* y
   if (!x || (!y && !q8_out) || !scale || !zero_point || n <= 0 || n_samples <= 0 || qmax <= qmin)
     return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_ex_f32_mc: bad argument");
   if (q8_out && qmax - qmin > 127) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_ex_f32_mc: the int8 output (q - z) takes grids of at most 128 steps (qmax - qmin <= 127)");
-  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  const int64_t want = (n / 16 + 255) / 256;          // 16 elements per thread and trip
+  const int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
   hipLaunchKernelGGL(fake_quant_ex_f32_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, x, x_ss, y, y_ss, n, scale, zero_point,
                      qmin, qmax, relu, q8_out);
   return qbnn_check_launch_msg("qbnn_fake_quant_ex_f32_mc");

@@ -32,25 +32,26 @@ __device__ __forceinline__ void q8_tail_tile(const ConvQ8Args& a, const v16i_q8&
   for (int g = 0; g < 4; ++g) {
     const int nb = nb0 + 8 * g + 4 * h;
     const bool full = nb < a.Cout;          // Cout % 4 == 0 (the launcher checks): this lane's four channels exist together, as 16-byte aligned float4s
-    const int np = full ? nb : 0;
-    v4f_q8 pd{1.f, 1.f, 1.f, 1.f}, pb{0.f, 0.f, 0.f, 0.f}, pa = pb, pe = pb;
-    if (a.div) pd = *reinterpret_cast<const v4f_q8*>(a.div + np);
-    if (a.bias) pb = *reinterpret_cast<const v4f_q8*>(a.bias + np);
-    if (a.alpha) pa = *reinterpret_cast<const v4f_q8*>(a.alpha + np);
-    if (a.beta) pe = *reinterpret_cast<const v4f_q8*>(a.beta + np);
-    float v[4];
+    if (full) {                             // (a padded channel group -- 24 .. 31 of a 24-channel layer -- costs nothing: a quarter of that layer's tail)
+      v4f_q8 pd{1.f, 1.f, 1.f, 1.f}, pb{0.f, 0.f, 0.f, 0.f}, pa = pb, pe = pb;
+      if (a.div) pd = *reinterpret_cast<const v4f_q8*>(a.div + nb);
+      if (a.bias) pb = *reinterpret_cast<const v4f_q8*>(a.bias + nb);
+      if (a.alpha) pa = *reinterpret_cast<const v4f_q8*>(a.alpha + nb);
+      if (a.beta) pe = *reinterpret_cast<const v4f_q8*>(a.beta + nb);
+      float v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float tt = (float)((double)(acc[4 * g + i] - zwr) * sp);
-      if (a.div) tt = tt / pd[i];
-      if (a.bias) tt = tt + pb[i];
-      if (a.alpha) tt = tt * pa[i];
-      if (a.beta) tt = tt + pe[i];
-      if (a.relu) tt = fmaxf(tt, 0.f);
-      v[i] = tt;
-      if (full) { vmin = fminf(vmin, tt); vmax = fmaxf(vmax, tt); }
+      for (int i = 0; i < 4; ++i) {
+        float tt = (float)((double)(acc[4 * g + i] - zwr) * sp);
+        if (a.div) tt = tt / pd[i];
+        if (a.bias) tt = tt + pb[i];
+        if (a.alpha) tt = tt * pa[i];
+        if (a.beta) tt = tt + pe[i];
+        if (a.relu) tt = fmaxf(tt, 0.f);
+        v[i] = tt;
+        vmin = fminf(vmin, tt); vmax = fmaxf(vmax, tt);
+      }
+      *reinterpret_cast<v4f_q8*>(yp + nb) = v4f_q8{v[0], v[1], v[2], v[3]};
     }
-    if (full) *reinterpret_cast<v4f_q8*>(yp + nb) = v4f_q8{v[0], v[1], v[2], v[3]};
     __builtin_amdgcn_sched_barrier(0);      // one channel group at a time (the unrolled tail otherwise loads every group's parameters up front)
   }
 }

@@ -577,8 +577,11 @@ def test_fused_blocks_random_qparams_against_oracle(seed, extreme):
             real = (u.astype(np.float64) - z_b) * s_b + (other.astype(np.float64) - z_r) * s_r
             s_o = float(np.float32(real.std() * 6.0 / a_hi * rng.uniform(0.7, 1.5)))       # the Add's output scale: its real values over the range
             ref = orc.qadd_relu(u, s_b, z_b, other, s_r, z_r, s_o, z_o, True, a_hi)
-            lv = min(8, a_hi // 2)                  # (A3 has 8 levels in all)
-            assert len(np.unique(t)) > lv and len(np.unique(u)) > lv and len(np.unique(ref)) > min(3, a_hi // 4), "degenerate case: outputs saturated"
+            # the case must exercise the requantisation, not saturate it: each tensor uses more than a third of the levels its clamp leaves it (capped at 8 / 3;
+            # a ReLU-fused output lives on [z, a_hi]: A3 with z = 5 has three levels in all)
+            need = lambda levels, cap: min(cap, max(1, levels // 3))
+            assert len(np.unique(t)) > need(a_hi - z_a + 1, 8) and len(np.unique(u)) > need(a_hi + 1, 8) and len(np.unique(ref)) > need(a_hi - z_o + 1, 3) - 1, \
+                "degenerate case: outputs saturated"
             # ---- fused kernel
             wa_d, nba = _pack_per_sample(L, wa)
             wb_d, nbb = _pack_per_sample(L, wb)
