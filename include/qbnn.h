@@ -489,10 +489,16 @@ int qbnn_conv2d_q8_f32_mc(const int8_t* x, int64_t x_sample_stride, const int8_t
 /* FloatFunctional.add (src/utils.py:49-55 `Add`; models_bbb.py:178 out + shortcut) of two fake-quantised tensors given as grid integers (round 6):
  * y[s][i] = fl32((float)a[s][i] * s_a[s]) + fl32((float)b[s][i] * s_b[s]) -- each addend is the fp32 value its FakeQuantize would have written, so
  * the sum equals the fp32 Add bit for bit --, plus the (min, max) of each of the qbnn_add_q8_blocks(n) workgroups' sums per sample for the Add's observer
- * (minmax_partials [S][blocks][2], may be NULL).  a / b sample stride 0 shares the operand. */
+ * (minmax_partials [S][blocks][2], may be NULL; y may be NULL when the partials are asked for).  a / b sample stride 0 shares the operand. */
 int32_t qbnn_add_q8_blocks(int64_t n);
 int qbnn_add_q8_f32_mc(const int8_t* a, int64_t a_sample_stride, const float* s_a, const int8_t* b, int64_t b_sample_stride, const float* s_b, float* y,
                        int64_t y_sample_stride, int64_t n, int32_t n_samples, float* minmax_partials, void* stream);
+/* ... and the Add's own FakeQuantize (+ ReLU) from the same two operands: with y = NULL above (partials only) and this call after the observer scan, the fp32
+ * sum is never written nor read -- x = fl32((float)a s_a) + fl32((float)b s_b) is recomputed per element, then qbnn_fake_quant_ex_f32_mc's arithmetic and
+ * outputs (fp32 y and / or the grid integers q8_out, either may be NULL but not both). */
+int qbnn_fake_quant_add_q8_mc(const int8_t* a, int64_t a_sample_stride, const float* s_a, const int8_t* b, int64_t b_sample_stride, const float* s_b, float* y,
+                              int64_t y_sample_stride, int64_t n, const float* scale, const int32_t* zero_point, int32_t qmin, int32_t qmax, int32_t relu,
+                              int8_t* q8_out, int32_t n_samples, void* stream);
 
 /* The QAT weight pipelines of all stochastic layers at once (round 6; conv_qat.py:26-49, linear_qat.py:18-41 in eval): per layer and MC sample
  *   w = FQ_w(mu c), s = FQ_s(softplus(rho) c), t = FQ_m(eps * s), W = FQ_a(w + t)      (FQ_x: live MovingAverageMinMax observer + fake_quantize)

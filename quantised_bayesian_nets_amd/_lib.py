@@ -106,7 +106,7 @@ EXPORTS = ["qbnn_mlp_bbb_f32_mc", "qbnn_mlp_bbb_f32_workspace_floats", "qbnn_pac
            "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_drop_i8_mc", "qbnn_stem_chain_drop_i8_mc", "qbnn_block_down_drop_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_chain_multi_args_bytes", "qbnn_down_multi_args_bytes", "qbnn_block_chain_i8_multi_prepare", "qbnn_block_chain_i8_multi_launch", "qbnn_block_down_i8_multi_prepare", "qbnn_block_down_i8_multi_launch", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_conv2d_i8_generic_mc", "qbnn_conv2d_i8_generic_scalar_mc", "qbnn_dropout_q_mc", "qbnn_maxpool2_q_mc",
            "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_flatten_nchw_rows_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
-           "qbnn_conv2d_f32_mc", "qbnn_conv2d_f32_fused_mc", "qbnn_conv2d_f32_blocks", "qbnn_observe_partials_f32_mc", "qbnn_grid_to_i8_mc", "qbnn_fake_quant_ex_f32_mc", "qbnn_conv2d_q8_blocks", "qbnn_conv2d_q8_f32_mc", "qbnn_add_q8_blocks", "qbnn_add_q8_f32_mc", "qbnn_qat_weights_mc", "qbnn_affine_f32_mc", "qbnn_pool2d_f32_mc", "qbnn_flatten_nchw_f32_mc", "qbnn_softmax_f32_mc", "qbnn_observe_f32_mc", "qbnn_fake_quant_f32_mc", "qbnn_sample_weights_f32_strided", "qbnn_sample_weights_f32_ohwi",
+           "qbnn_conv2d_f32_mc", "qbnn_conv2d_f32_fused_mc", "qbnn_conv2d_f32_blocks", "qbnn_observe_partials_f32_mc", "qbnn_grid_to_i8_mc", "qbnn_fake_quant_ex_f32_mc", "qbnn_conv2d_q8_blocks", "qbnn_conv2d_q8_f32_mc", "qbnn_add_q8_blocks", "qbnn_add_q8_f32_mc", "qbnn_fake_quant_add_q8_mc", "qbnn_qat_weights_mc", "qbnn_affine_f32_mc", "qbnn_pool2d_f32_mc", "qbnn_flatten_nchw_f32_mc", "qbnn_softmax_f32_mc", "qbnn_observe_f32_mc", "qbnn_fake_quant_f32_mc", "qbnn_sample_weights_f32_strided", "qbnn_sample_weights_f32_ohwi",
            "qbnn_dropout_mask_f32_mc", "qbnn_dropout_f32_mc", "qbnn_conv2d_f32_drop_mc",
            "qbnn_last_error", "qbnn_version"]
 
@@ -192,6 +192,7 @@ def lib():
         L.qbnn_add_q8_blocks.argtypes = [i64]
         L.qbnn_add_q8_blocks.restype = i32
         L.qbnn_add_q8_f32_mc.argtypes = [vp, i64, vp, vp, i64, vp, vp, i64, i64, i32, vp, vp]
+        L.qbnn_fake_quant_add_q8_mc.argtypes = [vp, i64, vp, vp, i64, vp, vp, i64, i64, vp, vp, i32, i32, i32, vp, i32, vp]
         L.qbnn_conv2d_q8_f32_mc.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64] + [i32] * 10 + [vp, vp]
         L.qbnn_conv2d_f32_mc.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         L.qbnn_affine_f32_mc.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp]

@@ -773,13 +773,13 @@ __global__ __launch_bounds__(256) void add_q8_f32_kernel(const int8_t* __restric
           o[k] = t;
           vmin = fminf(vmin, t); vmax = fmaxf(vmax, t);
         }
-        reinterpret_cast<v4f*>(ys)[i * 4 + d] = o;
+        if (y) reinterpret_cast<v4f*>(ys)[i * 4 + d] = o;      // (y NULL: only the observer's partials; the fake-quantiser recomputes the sums, qbnn_fake_quant_add_q8_mc)
       }
     }
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
       const float t = (float)as[i] * fa + (float)bs[i] * fb;
-      ys[i] = t;
+      if (y) ys[i] = t;
       vmin = fminf(vmin, t); vmax = fmaxf(vmax, t);
     }
   }
@@ -803,10 +803,69 @@ QBNN_EXPORT int32_t qbnn_add_q8_blocks(int64_t n) {
 
 QBNN_EXPORT int qbnn_add_q8_f32_mc(const int8_t* a, int64_t a_ss, const float* s_a, const int8_t* b, int64_t b_ss, const float* s_b, float* y, int64_t y_ss,
                                    int64_t n, int32_t n_samples, float* minmax_partials, void* stream) {
-  if (!a || !b || !s_a || !s_b || !y || n <= 0 || n_samples <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_add_q8_f32_mc: bad argument");
+  if (!a || !b || !s_a || !s_b || (!y && !minmax_partials) || n <= 0 || n_samples <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_add_q8_f32_mc: bad argument");
   hipLaunchKernelGGL(add_q8_f32_kernel, dim3(qbnn_add_q8_blocks(n), n_samples), dim3(256), 0, (hipStream_t)stream, a, a_ss, s_a, b, b_ss, s_b, y, y_ss, n,
                      minmax_partials);
   return qbnn_check_launch_msg("qbnn_add_q8_f32_mc");
+}
+
+// The Add's FakeQuantize (+ the ReLU behind it) straight from the Add's OPERANDS: x = fl32((float)a s_a) + fl32((float)b s_b) is recomputed per element --
+// exactly add_q8_f32_kernel's sum -- so the fp32 sum tensor is neither written by the Add nor read here: 2 + 2 + 1 bytes per element for Add + observer +
+// fake-quantise instead of 2 + 4 + 4 + 1.  Outputs as qbnn_fake_quant_ex_f32_mc: the grid integers q - z (int8) and / or the fp32 values.
+__global__ __launch_bounds__(256) void fake_quant_add_q8_kernel(const int8_t* __restrict__ a, int64_t a_ss, const float* __restrict__ sa, const int8_t* __restrict__ b,
+                                                                 int64_t b_ss, const float* __restrict__ sb, float* __restrict__ y, int64_t y_ss, int64_t n,
+                                                                 const float* __restrict__ scale, const int* __restrict__ zp, int qmin, int qmax, int relu,
+                                                                 int8_t* __restrict__ q8) {
+  const int s = blockIdx.y, tid = threadIdx.x;
+  const float fa = sa[s], fb = sb[s];
+  const float sc = scale[s], inv = 1.0f / sc;
+  const float z = (float)zp[s], lo = (float)qmin, hi = (float)qmax;
+  const float mlo = relu ? 0.f : -INFINITY;
+  const int8_t* as = a + (int64_t)s * a_ss;
+  const int8_t* bs = b + (int64_t)s * b_ss;
+  const bool vec = (n & 15) == 0 && ((a_ss | b_ss) & 15) == 0 && (y_ss & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(q8)) & 15) == 0;
+  if (vec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n / 16; i += (int64_t)gridDim.x * 256) {
+      const v4i_q8 av = reinterpret_cast<const v4i_q8*>(as)[i], bv = reinterpret_cast<const v4i_q8*>(bs)[i];
+      v4i_q8 qv;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        v4f o;
+        uint32_t pk = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float x = (float)(int8_t)(av[d] >> (8 * k)) * fa + (float)(int8_t)(bv[d] >> (8 * k)) * fb;
+          const float m = fmaxf(fminf(fmaxf(rintf(x * inv) + z, lo), hi) - z, mlo);
+          o[k] = m * sc;
+          pk |= ((uint32_t)(int)m & 0xffu) << (8 * k);
+        }
+        qv[d] = (int)pk;
+        if (y) reinterpret_cast<v4f*>(y + (int64_t)s * y_ss)[i * 4 + d] = o;
+      }
+      if (q8) reinterpret_cast<v4i_q8*>(q8 + (int64_t)s * n)[i] = qv;
+    }
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+    const float x = (float)as[i] * fa + (float)bs[i] * fb;
+    const float m = fmaxf(fminf(fmaxf(rintf(x * inv) + z, lo), hi) - z, mlo);
+    if (y) y[(int64_t)s * y_ss + i] = m * sc;
+    if (q8) q8[(int64_t)s * n + i] = (int8_t)(int)m;
+  }
+}
+
+QBNN_EXPORT int qbnn_fake_quant_add_q8_mc(const int8_t* a, int64_t a_ss, const float* s_a, const int8_t* b, int64_t b_ss, const float* s_b, float* y, int64_t y_ss,
+                                          int64_t n, const float* scale, const int32_t* zero_point, int32_t qmin, int32_t qmax, int32_t relu, int8_t* q8_out,
+                                          int32_t n_samples, void* stream) {
+  if (!a || !b || !s_a || !s_b || (!y && !q8_out) || !scale || !zero_point || n <= 0 || n_samples <= 0 || qmax <= qmin)
+    return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_add_q8_mc: bad argument");
+  if (q8_out && qmax - qmin > 127) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_fake_quant_add_q8_mc: the int8 output (q - z) takes grids of at most 128 steps (qmax - qmin <= 127)");
+  const int64_t want = (n / 16 + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(fake_quant_add_q8_kernel, dim3(blocks, n_samples), dim3(256), 0, (hipStream_t)stream, a, a_ss, s_a, b, b_ss, s_b, y, y_ss, n, scale, zero_point,
+                     qmin, qmax, relu, q8_out);
+  return qbnn_check_launch_msg("qbnn_fake_quant_add_q8_mc");
 }
 
 QBNN_EXPORT int qbnn_fake_quant_f32_mc(const float* x, int64_t x_ss, float* y, int64_t y_ss, int64_t n, const float* scale,

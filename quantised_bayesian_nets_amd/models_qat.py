@@ -96,6 +96,30 @@ class FakeQuantize(nn.Module):
         y._no_f32 = skip_f32         # y's own storage holds nothing: fp32 consumers must not touch it (need_f32)
         return y
 
+    def forward_add(self, a, b, relu=False, f32_out=True):
+        """FakeQuantize(a + b) for two grid tensors (BasicBlock's Add, src/utils.py:49-55) WITHOUT the fp32 sum tensor (round 6): one pass over the
+        operands' integers for the observer's (min, max) (add_q8, sums not stored), the scan, then qbnn_fake_quant_add_q8_mc recomputes each sum --
+        the same two fp32 products and one fp32 add -- and quantises it.  Bit-identical to forward(add_q8(a, b)[0], ...)."""
+        S, n = a.shape[0], a[0].numel()
+        dev = a.device
+        if self.state.device != dev:
+            self.state = self.state.to(dev)
+        L = _lib.lib()
+        _, (partials, nblk) = add_q8(a, b, want_sum=False)
+        scale = torch.empty(S, dtype=torch.float32, device=dev)
+        zp = torch.empty(S, dtype=torch.int32, device=dev)
+        with timed("observe_f32"):
+            _lib.check(L.qbnn_observe_partials_f32_mc(_lib.ptr(partials), nblk, S, _lib.ptr(self.state), AVG_CONST, self.qmin, self.qmax, _lib.ptr(scale),
+                                                      _lib.ptr(zp), _lib.current_stream()))
+        y = torch.empty(tuple(a.shape), dtype=torch.float32, device=dev)
+        q8 = torch.empty((S, n), dtype=torch.int8, device=dev)
+        with timed("fake_quant_add_q8"):
+            _lib.check(L.qbnn_fake_quant_add_q8_mc(_lib.ptr(a._q8), n, _lib.ptr(a._grid), _lib.ptr(b._q8), n, _lib.ptr(b._grid), _lib.ptr(y) if f32_out else None, n, n,
+                                                   _lib.ptr(scale), _lib.ptr(zp), self.qmin, self.qmax, int(relu), _lib.ptr(q8), S, _lib.current_stream()))
+        self.last_scale, self.last_zero_point = scale, zp
+        y._grid, y._q8, y._no_f32 = scale, q8, not f32_out
+        return y
+
 
 def _bounds(args):
     check_bits(args)                 # quant_utils.py:120-121: 2..7-bit activations, 2..8-bit weights (every QAT model constructor comes through here)
@@ -122,11 +146,12 @@ def need_f32(x):
     return x
 
 
-def add_q8(a, b):
-    """out + shortcut of two grid tensors from their integers: (fp32 sum [S, ...], (min / max partials, workgroups)) -- qbnn_add_q8_f32_mc."""
+def add_q8(a, b, want_sum=True):
+    """out + shortcut of two grid tensors from their integers: (fp32 sum [S, ...], (min / max partials, workgroups)) -- qbnn_add_q8_f32_mc.
+    want_sum = False: only the partials (the sum tensor is None; FakeQuantize.forward_add recomputes the sums)."""
     S, n = a.shape[0], a[0].numel()
     L = _lib.lib()
-    y = torch.empty(tuple(a.shape), dtype=torch.float32, device=a.device)
+    y = torch.empty(tuple(a.shape), dtype=torch.float32, device=a.device) if want_sum else None
     nblk = int(L.qbnn_add_q8_blocks(n))
     partials = torch.empty(S * nblk * 2, dtype=torch.float32, device=a.device)
     with timed("add_q8"):
@@ -656,8 +681,10 @@ class BasicBlock(nn.Module):
         grid_in = getattr(x, "_q8", None) is not None            # then every tensor inside the block travels as grid integers + scale
         out = self.stem[3](self.stem[0](x, f32_out=not grid_in), f32_out=not grid_in)
         sc = self.shortcut[0](x, f32_out=not grid_in) if len(self.shortcut) else x
-        if _grid_pair(out, sc):                                   # Add from the integers, its (min, max) for the observer in the same pass
-            z, mm = add_q8(out, sc)
+        if _grid_pair(out, sc) and self.add.qmax - self.add.qmin <= 127:
+            if os.environ.get("QBNN_QAT_ADDFQ", "1") != "0":      # Add -> observer -> FakeQuantize from the integers: the fp32 sum is never stored
+                return self.add.forward_add(out, sc, relu=True, f32_out=f32_out)
+            z, mm = add_q8(out, sc)                               # (A/B: the sum as a tensor, its (min, max) for the observer in the same pass)
             return self.add(z, partials=mm, relu=True, f32_out=f32_out)
         return self.add(affine_f32(need_f32(out), res=need_f32(sc)), relu=True, f32_out=f32_out)      # Add -> FakeQuantize -> ReLU (`end`): the ReLU in the fake-quantiser's pass
 
