@@ -16,6 +16,7 @@
 // weights' zero point is not 0) comes from v_dot4 on the same fragments, the padded bytes masked.  HBM: the int8 input once, the fp32 output once.
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/qbnn.h"
 #include "qbnn_common.h"
@@ -24,6 +25,15 @@
 namespace {
 
 typedef float v4f_q8 __attribute__((ext_vector_type(4)));
+
+// Workgroup barrier that orders LDS traffic only (qbnn_conv.h: lds_barrier): __syncthreads() also waits for every vector-memory operation of the wave --
+// here the previous block's 16-byte output stores and the next block's input / the next chunk's weights on their way into registers, which nothing
+// behind the barrier depends on (a register filled by a load is waited for where it is used).
+__device__ __forceinline__ void q8t_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // One accumulator tile (this lane: pixel `lane & 31`, channels nb0 + 8 g + 4 h + {0..3}) through conv2d_q8v_kernel's tail, step for step:
 // fl32(fl64(N - z_w R) * fl64(s_x s_w)), / div, + bias, * alpha, + beta, ReLU; float4 stores; running (min, max) of what was stored.
@@ -177,31 +187,44 @@ __global__ __launch_bounds__(256, C::WPE) void conv2d_q8t_kernel(const ConvQ8Arg
     }
   };
 
+  // A block's input tile goes global -> registers -> LDS: the loads of block it + 1 are issued right after block it's tile is in LDS, so their latency
+  // hides under a whole block of MFMAs and tail arithmetic instead of standing between two barriers (IT > 1: the 24- and 48-channel layers).
+  constexpr int T_UPR = C::W_IN * C::CIN / C::U;               // staging units per input row
+  constexpr int T_UNITS = C::G * C::RI * T_UPR, T_PER = (T_UNITS + 255) / 256;
+  typedef typename std::conditional<C::U == 16, v4i_q8, v2i_q8>::type tunit;
+  tunit treg[T_PER];
+  auto load_tile = [&](int blk) {
+    const int img0 = C::G == 1 ? blk / C::BPI : blk * C::G;
+    const int oh0 = C::G == 1 ? (blk % C::BPI) * C::ROWS : 0;
+#pragma unroll
+    for (int k = 0; k < T_PER; ++k) {
+      const int u = tid + 256 * k;
+      const int g = u / (C::RI * T_UPR), r = (u / T_UPR) % C::RI, j = u % T_UPR;
+      const int ih = oh0 * C::STRIDE - 1 + r, img = img0 + g;
+      const bool ok = u < T_UNITS && (unsigned)ih < (unsigned)C::H_IN && img < a.B;      // rows above / below the map, images beyond a ragged batch: m_x = 0
+      tunit v = *reinterpret_cast<const tunit*>(xs + (((int64_t)(ok ? img : 0) * C::H_IN + (ok ? ih : 0)) * C::W_IN) * C::CIN + (ok ? j : 0) * C::U);
+      if (!ok) v = tunit{};
+      treg[k] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < T_PER; ++k) {
+      const int u = tid + 256 * k;
+      const int g = u / (C::RI * T_UPR), r = (u / T_UPR) % C::RI, j = u % T_UPR;
+      if (u < T_UNITS) *reinterpret_cast<tunit*>(tile + ((g * C::RI + r) * C::CI + 1) * C::CIN + j * C::U) = treg[k];
+    }
+  };
+  if (b0 < nblocks) load_tile(b0);
+
   for (int it = 0; it < C::IT; ++it) {
     const int blk = b0 + it;
     if (blk >= nblocks) break;                                  // workgroup-uniform
     const int img0 = C::G == 1 ? blk / C::BPI : blk * C::G;
     const int oh0 = C::G == 1 ? (blk % C::BPI) * C::ROWS : 0;
-    __syncthreads();                                            // the previous block's fragment reads (first block: the zero fill) are done
-    {
-      constexpr int UPR = C::W_IN * C::CIN / C::U;             // staging units per input row
-      for (int u = tid; u < C::G * C::RI * UPR; u += 256) {
-        const int g = u / (C::RI * UPR), r = (u / UPR) % C::RI, j = u % UPR;
-        const int ih = oh0 * C::STRIDE - 1 + r, img = img0 + g;
-        const bool ok = (unsigned)ih < (unsigned)C::H_IN && img < a.B;      // rows above / below the map, images beyond a ragged batch: m_x = 0
-        const int8_t* src = xs + (((int64_t)(ok ? img : 0) * C::H_IN + (ok ? ih : 0)) * C::W_IN) * C::CIN + j * C::U;
-        uint8_t* dst = tile + ((g * C::RI + r) * C::CI + 1) * C::CIN + j * C::U;
-        if constexpr (C::U == 16) {
-          v4i_q8 v = *reinterpret_cast<const v4i_q8*>(src);
-          if (!ok) v = v4i_q8{0, 0, 0, 0};
-          *reinterpret_cast<v4i_q8*>(dst) = v;
-        } else {
-          v2i_q8 v = *reinterpret_cast<const v2i_q8*>(src);
-          if (!ok) v = v2i_q8{0, 0};
-          *reinterpret_cast<v2i_q8*>(dst) = v;
-        }
-      }
-    }
+    q8t_lds_barrier();                                            // the previous block's fragment reads (first block: the zero fill) are done
+    store_tile();
+    if (C::IT > 1 && it + 1 < C::IT && blk + 1 < nblocks) load_tile(blk + 1);      // the next block's input: in flight under this block's MFMAs and tail
     if (C::NCHUNK == 1 && it == 0) stage_w(0);                 // the whole conv's weights: once per workgroup
     if constexpr (C::NCHUNK > 1) load_w(0);
 
@@ -214,11 +237,11 @@ __global__ __launch_bounds__(256, C::WPE) void conv2d_q8t_kernel(const ConvQ8Arg
 #pragma unroll
     for (int ch = 0; ch < C::NCHUNK; ++ch) {
       if constexpr (C::NCHUNK > 1) {
-        if (ch > 0) __syncthreads();                            // the previous chunk's weight reads are done
+        if (ch > 0) q8t_lds_barrier();                            // the previous chunk's weight reads are done
         store_w();
         if (ch + 1 < C::NCHUNK) load_w(ch + 1);                 // in flight under this chunk's MFMAs
       }
-      __syncthreads();
+      q8t_lds_barrier();
       // One k-step ahead: the fragments of step i + 1 are requested before the MFMAs of step i (a scheduling fence per step keeps the compiler
       // from hoisting every LDS read of the unrolled chunk to its top -- 500+ registers, or spills under the occupancy bound).
       v4i_q8 bq[2], aq[2][C::NTW];
@@ -283,7 +306,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_q8_c3_kernel(const ConvQ8Args a
   const int nblocks = a.B * (C::HW / C::ROWS), b0 = blockIdx.x * C::IT;
   for (int i = tid; i < C::RI * C::PITCH / 4; i += 256) reinterpret_cast<int*>(tile)[i] = 0;
   for (int i = tid; i < 32 * C::WPITCH / 4; i += 256) reinterpret_cast<int*>(wl)[i] = 0;
-  __syncthreads();
+  q8t_lds_barrier();
   for (int i = tid; i < 32 * 27; i += 256) {
     const int n = i / 27, k = i - n * 27;
     if (n < a.Cout) wl[n * C::WPITCH + k] = (uint8_t)ws[n * 27 + k];
@@ -295,7 +318,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_q8_c3_kernel(const ConvQ8Args a
     const int blk = b0 + it;
     if (blk >= nblocks) break;
     const int img = blk / (C::HW / C::ROWS), oh0 = (blk % (C::HW / C::ROWS)) * C::ROWS;
-    __syncthreads();                              // the previous block's patch assembly is done with the tile (first block: zero fill, weights)
+    q8t_lds_barrier();                              // the previous block's patch assembly is done with the tile (first block: zero fill, weights)
     if (tid < C::RI * 6) {                        // 6 rows x 6 units of 16 B
       const int r = tid / 6, j = tid - r * 6, ih = oh0 - 1 + r;
       const bool ok = (unsigned)ih < (unsigned)C::HW;
@@ -303,7 +326,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_q8_c3_kernel(const ConvQ8Args a
       if (!ok) v = v4i_q8{0, 0, 0, 0};
       *reinterpret_cast<v4i_q8*>(tile + r * C::PITCH + C::IN0 + j * 16) = v;
     }
-    __syncthreads();
+    q8t_lds_barrier();
     {                                             // patch bytes [16 part, 16 part + 16) of pixel q: k = kh 9 + kw 3 + c  <-  tile[(r + kh)][IN0 - 3 + 3 c0 + (k - 9 kh)]
       const int q = tid & 127, part = tid >> 7, r = q >> 5, c0 = q & 31;
       uint32_t wds[4] = {0u, 0u, 0u, 0u};
@@ -317,7 +340,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_q8_c3_kernel(const ConvQ8Args a
       }
       *reinterpret_cast<v4i_q8*>(pm + q * C::PP + 16 * part) = v4i_q8{(int)wds[0], (int)wds[1], (int)wds[2], (int)wds[3]};
     }
-    __syncthreads();
+    q8t_lds_barrier();
     const v4i_q8 bv = *reinterpret_cast<const v4i_q8*>(pm + (wave * 32 + (lane & 31)) * C::PP + 16 * h);
     const v4i_q8 av = *reinterpret_cast<const v4i_q8*>(wl + (lane & 31) * C::WPITCH + 16 * h);
     v16i_q8 acc;
