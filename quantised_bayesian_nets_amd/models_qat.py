@@ -166,6 +166,18 @@ def _grid_pair(a, b):
             and getattr(b, "_grid", None) is not None and a.shape == b.shape and a._q8.shape == b._q8.shape)
 
 
+def block_add(fq, out, sc, f32_out=True, from_integers=True):
+    """BasicBlock's Add -> FakeQuantize -> ReLU (`end`; the ReLU in the fake-quantiser's pass) for the block's two branches.
+    from_integers = False: the operands' fp32 values are not (integer * `_grid`) in ONE rounding -- behind a BernoulliDropout they are
+    fl(fl(m s) gain), while `_grid` holds fl(s gain) -- so the Add must read them."""
+    if from_integers and _grid_pair(out, sc) and fq.qmax - fq.qmin <= 127:
+        if os.environ.get("QBNN_QAT_ADDFQ", "1") != "0":      # Add -> observer -> FakeQuantize from the integers: the fp32 sum is never stored
+            return fq.forward_add(out, sc, relu=True, f32_out=f32_out)
+        z, mm = add_q8(out, sc)                               # (A/B: the sum as a tensor, its (min, max) for the observer in the same pass)
+        return fq(z, partials=mm, relu=True, f32_out=f32_out)
+    return fq(affine_f32(need_f32(out), res=need_f32(sc)), relu=True, f32_out=f32_out)
+
+
 def qat_i8_enabled():
     """QAT convs / linears on the int8 matrix pipe where both operands are fake-quantised tensors (QBNN_QAT_I8=0: the fp64 sums)."""
     return os.environ.get("QBNN_QAT_I8", "1") != "0"
@@ -681,12 +693,7 @@ class BasicBlock(nn.Module):
         grid_in = getattr(x, "_q8", None) is not None            # then every tensor inside the block travels as grid integers + scale
         out = self.stem[3](self.stem[0](x, f32_out=not grid_in), f32_out=not grid_in)
         sc = self.shortcut[0](x, f32_out=not grid_in) if len(self.shortcut) else x
-        if _grid_pair(out, sc) and self.add.qmax - self.add.qmin <= 127:
-            if os.environ.get("QBNN_QAT_ADDFQ", "1") != "0":      # Add -> observer -> FakeQuantize from the integers: the fp32 sum is never stored
-                return self.add.forward_add(out, sc, relu=True, f32_out=f32_out)
-            z, mm = add_q8(out, sc)                               # (A/B: the sum as a tensor, its (min, max) for the observer in the same pass)
-            return self.add(z, partials=mm, relu=True, f32_out=f32_out)
-        return self.add(affine_f32(need_f32(out), res=need_f32(sc)), relu=True, f32_out=f32_out)      # Add -> FakeQuantize -> ReLU (`end`): the ReLU in the fake-quantiser's pass
+        return block_add(self.add, out, sc, f32_out)
 
 
 class ConvNetwork_ResNet(nn.Module):

@@ -20,7 +20,7 @@ from . import _lib
 from .layers import _MC, bump_state_epoch, mc_context, timed
 from .models_f32 import affine_f32, flatten_f32, nchw_to_mc_nhwc, pool2d_f32, softmax_f32
 from .models_qat import Conv2d as _ConvBBB
-from .models_qat import FakeQuantize, QuantStub, _bounds, keep_grid, prepared_state, presample_weights
+from .models_qat import FakeQuantize, QuantStub, _bounds, block_add, keep_grid, need_f32, prepared_state, presample_weights
 from .models_qat import Linear as _LinearBBB
 
 
@@ -241,19 +241,22 @@ class _Block(nn.Module):
         self.ds = BernoulliDropout(p, args) if (p > 0 and self.s is not None) else None
         self.add = FakeQuantize(alo, ahi)          # add.add.activation_post_process
 
-    def forward(self, x):
-        out = self.a(x)
+    def forward(self, x, f32_out=True):
+        # Without dropouts (the SGHMC member template) every tensor inside the block is consumed by a conv on the int8 pipe or by the Add: it travels as
+        # grid integers + scale, as in models_qat.BasicBlock (round 6).  A BernoulliDropout works on the fp32 values: those graphs keep them.
+        grid = self.da is None and self.db is None and self.ds is None and getattr(x, "_q8", None) is not None
+        out = self.a(x, f32_out=not grid)
         if self.da is not None:
             out = self.da(out)
-        out = self.b(out)
+        out = self.b(out, f32_out=not grid)
         if self.db is not None:
             out = self.db(out)
         sc = x
         if self.s is not None:
-            sc = self.s(x)
+            sc = self.s(x, f32_out=not grid)
             if self.ds is not None:
                 sc = self.ds(sc)
-        return self.add(affine_f32(out, res=sc), relu=True)
+        return block_add(self.add, out, sc, f32_out, from_integers=grid)
 
 
 class ConvNetwork_ResNet(_Net):
@@ -304,12 +307,13 @@ class ConvNetwork_ResNet(_Net):
 
     def forward_mc(self, x):
         presample_weights([m for _, m in self.weighted()], x.device)
-        h = self.c0(self.quant(nchw_to_mc_nhwc(x)))
+        nodrop = self.d0 is None                 # (the template: grid integers only between the input FakeQuantize and the last block's Add)
+        h = self.c0(self.quant(nchw_to_mc_nhwc(x), f32_out=not nodrop), f32_out=not nodrop)
         if self.d0 is not None:
             h = self.d0(h)
-        for blk in self.blocks:
-            h = blk(h)
-        return softmax_f32(self.fc(flatten_f32(pool2d_f32(h, 4, avg=True))))
+        for i, blk in enumerate(self.blocks):
+            h = blk(h, f32_out=(not nodrop) or i == len(self.blocks) - 1)
+        return softmax_f32(self.fc(flatten_f32(pool2d_f32(need_f32(h), 4, avg=True))))
 
 
 def get_model(model, input_size, output_size, q, args):
