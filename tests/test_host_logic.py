@@ -333,3 +333,12 @@ def test_ring_kernels_issue_no_flat_loads(tmp_path):
             assert not re.search(r"^\s+flat_load", body, re.M), name
             assert "global_load_lds_dwordx4" in body, name
     assert n_kernels >= 12
+
+
+def test_design_table_is_what_the_generator_prints():
+    """DESIGN.md section 4.3's per-kernel table is generated from profiles/r06_*.json (tools/design_table.py --write): the committed block must be
+    what the generator prints from the committed measurement files, so the prose cannot drift from the counters (verdict round 5, item 6)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_table.py"), "r06", "r05"], capture_output=True, text=True, check=True).stdout.strip()
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    a, b = design.index("<!-- GENERATED: tools/design_table.py -->"), design.index("<!-- END GENERATED -->") + len("<!-- END GENERATED -->")
+    assert design[a:b].strip() == out
