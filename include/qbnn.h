@@ -500,6 +500,19 @@ int qbnn_fake_quant_add_q8_mc(const int8_t* a, int64_t a_sample_stride, const fl
                               int64_t y_sample_stride, int64_t n, const float* scale, const int32_t* zero_point, int32_t qmin, int32_t qmax, int32_t relu,
                               int8_t* q8_out, int32_t n_samples, void* stream);
 
+/* The float Bayes-by-backprop draw of ALL layers and MC samples in one launch (round 6; bbb/conv.py:33-39, bbb/linear.py:42-50): per layer
+ * W[s] = mu + eps_s * sigma, bit-identical to qbnn_sample_weights_f32_ohwi (KS > 0: mu / sigma in the reference's [Cout][Cin][kh][kw] order, W written
+ * [Cout][kh][kw][Cin]) / qbnn_sample_weights_f32 (KS = 0).  `dev_layers`: descriptors IN DEVICE MEMORY (device pointers; w = [n_samples][n] output;
+ * [blk0, blk0 + nblk) the layer's workgroups, consecutive layers, total_blocks in all). */
+typedef struct qbnn_f32_wlayer {
+  const float* mu; const float* sigma; float* w;
+  int32_t n, Cout, Cin, KS;
+  uint32_t layer_id;
+  int32_t blk0, nblk;
+} qbnn_f32_wlayer;
+int qbnn_sample_weights_f32_batch(const qbnn_f32_wlayer* dev_layers, int32_t n_layers, int32_t total_blocks, uint64_t seed, uint32_t sample_begin,
+                                  int32_t n_samples, void* stream);
+
 /* The QAT weight pipelines of all stochastic layers at once (round 6; conv_qat.py:26-49, linear_qat.py:18-41 in eval): per layer and MC sample
  *   w = FQ_w(mu c), s = FQ_s(softplus(rho) c), t = FQ_m(eps * s), W = FQ_a(w + t)      (FQ_x: live MovingAverageMinMax observer + fake_quantize)
  * in four launches instead of ~15 per layer; bit-identical to the per-layer calls (qbnn_observe_f32_mc, qbnn_fake_quant_f32_mc,

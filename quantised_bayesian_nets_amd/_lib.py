@@ -59,6 +59,12 @@ class QatWLayer(C.Structure):
                 ("W", C.c_void_p), ("q8", C.c_void_p), ("scale", C.c_void_p), ("zp", C.c_void_p)]
 
 
+class F32WLayer(C.Structure):
+    """qbnn_f32_wlayer (include/qbnn.h): one layer of qbnn_sample_weights_f32_batch."""
+    _fields_ = [("mu", C.c_void_p), ("sigma", C.c_void_p), ("w", C.c_void_p), ("n", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32), ("KS", C.c_int32),
+                ("layer_id", C.c_uint32), ("blk0", C.c_int32), ("nblk", C.c_int32)]
+
+
 class BlockDesc(C.Structure):
     _fields_ = [("w_a", C.c_void_p), ("w_a_sample_stride", C.c_int64), ("bias_a", C.c_void_p),
                 ("s_wa", C.c_float), ("z_wa", C.c_int32), ("s_a", C.c_float), ("z_a", C.c_int32),
@@ -106,7 +112,7 @@ EXPORTS = ["qbnn_mlp_bbb_f32_mc", "qbnn_mlp_bbb_f32_workspace_floats", "qbnn_pac
            "qbnn_block_chain_i8_mc", "qbnn_stem_chain_i8_mc", "qbnn_block_down_i8_mc", "qbnn_block_chain_drop_i8_mc", "qbnn_stem_chain_drop_i8_mc", "qbnn_block_down_drop_i8_mc", "qbnn_block_chain_i8_multi", "qbnn_block_down_i8_multi", "qbnn_chain_multi_args_bytes", "qbnn_down_multi_args_bytes", "qbnn_block_chain_i8_multi_prepare", "qbnn_block_chain_i8_multi_launch", "qbnn_block_down_i8_multi_prepare", "qbnn_block_down_i8_multi_launch", "qbnn_head_i8_multi", "qbnn_quantize_im2col3x3_c3_multi",
            "qbnn_quantize_input_nchw", "qbnn_im2col3x3_c3", "qbnn_conv2d_i8_generic_mc", "qbnn_conv2d_i8_generic_scalar_mc", "qbnn_dropout_q_mc", "qbnn_maxpool2_q_mc",
            "qbnn_dequant_softmax_mc", "qbnn_flatten_nchw_mc", "qbnn_flatten_nchw_rows_mc", "qbnn_add_relu_q_mc", "qbnn_sample_weights_f32", "qbnn_linear_f32_mc", "qbnn_head_i8_mc", "qbnn_reduce_moments", "qbnn_finalize_moments", "qbnn_classification_metrics", "qbnn_regression_metrics",
-           "qbnn_conv2d_f32_mc", "qbnn_conv2d_f32_fused_mc", "qbnn_conv2d_f32_blocks", "qbnn_observe_partials_f32_mc", "qbnn_grid_to_i8_mc", "qbnn_fake_quant_ex_f32_mc", "qbnn_conv2d_q8_blocks", "qbnn_conv2d_q8_f32_mc", "qbnn_add_q8_blocks", "qbnn_add_q8_f32_mc", "qbnn_fake_quant_add_q8_mc", "qbnn_qat_weights_mc", "qbnn_affine_f32_mc", "qbnn_pool2d_f32_mc", "qbnn_flatten_nchw_f32_mc", "qbnn_softmax_f32_mc", "qbnn_observe_f32_mc", "qbnn_fake_quant_f32_mc", "qbnn_sample_weights_f32_strided", "qbnn_sample_weights_f32_ohwi",
+           "qbnn_conv2d_f32_mc", "qbnn_conv2d_f32_fused_mc", "qbnn_conv2d_f32_blocks", "qbnn_observe_partials_f32_mc", "qbnn_grid_to_i8_mc", "qbnn_fake_quant_ex_f32_mc", "qbnn_conv2d_q8_blocks", "qbnn_conv2d_q8_f32_mc", "qbnn_add_q8_blocks", "qbnn_add_q8_f32_mc", "qbnn_fake_quant_add_q8_mc", "qbnn_qat_weights_mc", "qbnn_sample_weights_f32_batch", "qbnn_affine_f32_mc", "qbnn_pool2d_f32_mc", "qbnn_flatten_nchw_f32_mc", "qbnn_softmax_f32_mc", "qbnn_observe_f32_mc", "qbnn_fake_quant_f32_mc", "qbnn_sample_weights_f32_strided", "qbnn_sample_weights_f32_ohwi",
            "qbnn_dropout_mask_f32_mc", "qbnn_dropout_f32_mc", "qbnn_conv2d_f32_drop_mc",
            "qbnn_last_error", "qbnn_version"]
 
@@ -189,6 +195,7 @@ def lib():
         L.qbnn_conv2d_q8_blocks.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32]
         L.qbnn_conv2d_q8_blocks.restype = i32
         L.qbnn_qat_weights_mc.argtypes = [vp, i32, i32, C.c_float, u64, u32, i32, vp]
+        L.qbnn_sample_weights_f32_batch.argtypes = [vp, i32, i32, u64, u32, i32, vp]
         L.qbnn_add_q8_blocks.argtypes = [i64]
         L.qbnn_add_q8_blocks.restype = i32
         L.qbnn_add_q8_f32_mc.argtypes = [vp, i64, vp, vp, i64, vp, vp, i64, i64, i32, vp, vp]

@@ -1477,6 +1477,53 @@ QBNN_EXPORT int qbnn_qat_weights_mc(const qbnn_qat_wlayer* dev_layers, int32_t n
   return qbnn_check_launch_msg("qbnn_qat_weights_mc");
 }
 
+// The float Bayes-by-backprop draw W_s = mu + eps_s * softplus(rho) (bbb/conv.py:33-39, bbb/linear.py:42-50) of ALL layers and samples in one launch
+// (round 6): qbnn_sample_weights_f32_ohwi / qbnn_sample_weights_f32 layer by layer are 21 launches of 5 - 18 us for the ResNet -- 6 % of a 10-sample pass.
+// Same Philox stream (ctr = {i >> 2, layer_id, sample_begin + s, 0}, element i & 3 of the reference's element order), same two roundings (t = eps * sigma;
+// mu + t), a conv's result written in [Cout][kh][kw][Cin] order: bit-identical to the per-layer calls.
+struct F32WLayer {            // mirrors qbnn_f32_wlayer (include/qbnn.h)
+  const float* mu; const float* sigma; float* w;
+  int32_t n, Cout, Cin, KS;
+  uint32_t layer_id;
+  int32_t blk0, nblk;
+};
+static_assert(sizeof(F32WLayer) == sizeof(qbnn_f32_wlayer), "qbnn_f32_wlayer layout");
+
+__global__ __launch_bounds__(256) void sample_weights_f32_batch_kernel(const F32WLayer* __restrict__ layers, int n_layers, uint32_t seed_lo, uint32_t seed_hi,
+                                                                       uint32_t sample_begin, const uint32_t* __restrict__ nd) {
+  if (nd) { seed_lo = nd[0]; seed_hi = nd[1]; sample_begin = nd[2]; }
+  int li = 0;
+  for (int i = 1; i < n_layers; ++i) li = (int)blockIdx.x >= layers[i].blk0 ? i : li;
+  const F32WLayer L = layers[li];
+  const int b = blockIdx.x - L.blk0, s = blockIdx.y;
+  const uint32_t n = (uint32_t)L.n, groups = (n + 3) / 4;
+  const uint32_t kk = (uint32_t)(L.KS * L.KS), ckk = (uint32_t)L.Cin * kk;
+  for (uint32_t g = (uint32_t)b * 256 + threadIdx.x; g < groups; g += (uint32_t)L.nblk * 256) {
+    float e[4];
+    qbnn::normal4(qbnn::philox4x32_10(g, L.layer_id, sample_begin + s, 0u, seed_lo, seed_hi), e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t i = g * 4 + j;
+      if (i >= n) break;
+      uint32_t o = i;
+      if (L.KS > 0) {        // i = (oc Cin + c) KK + t  ->  o = (oc KK + t) Cin + c
+        const uint32_t oc = i / ckk, rem = i - oc * ckk, c = rem / kk, t = rem - c * kk;
+        o = (oc * kk + t) * (uint32_t)L.Cin + c;
+      }
+      const float t = e[j] * L.sigma[i];
+      L.w[(int64_t)s * n + o] = L.mu[i] + t;
+    }
+  }
+}
+
+QBNN_EXPORT int qbnn_sample_weights_f32_batch(const qbnn_f32_wlayer* dev_layers, int32_t n_layers, int32_t total_blocks, uint64_t seed, uint32_t sample_begin,
+                                              int32_t n_samples, void* stream) {
+  if (!dev_layers || n_layers <= 0 || total_blocks <= 0 || n_samples <= 0) return qbnn_fail_msg(QBNN_E_INVALID, "qbnn_sample_weights_f32_batch: bad argument");
+  hipLaunchKernelGGL(sample_weights_f32_batch_kernel, dim3(total_blocks, n_samples), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const F32WLayer*>(dev_layers),
+                     n_layers, (uint32_t)seed, (uint32_t)(seed >> 32), sample_begin, qbnn_noise_dev());
+  return qbnn_check_launch_msg("qbnn_sample_weights_f32_batch");
+}
+
 QBNN_EXPORT int qbnn_conv2d_f32_mc(const float* x, int64_t x_ss, const float* w, int64_t w_ss, const float* bias, float* y,
                                    int64_t y_ss, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                                    int32_t stride, int32_t pad, int32_t relu, int32_t n_samples, void* stream) {

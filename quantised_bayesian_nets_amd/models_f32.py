@@ -3,6 +3,8 @@
 Mirror of reference src/models/stochastic/bbb/linear.py (`Linear`, :8-50, eval branch) and models_bbb.py
 (`LinearNetwork`, :32-90).  Parameters keep the reference names: `weight` (mu), `std` (rho, pre-softplus), `bias`.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -43,12 +45,14 @@ class Linear(nn.Module):
             self._bias_dev = None if self.bias is None else self.bias.detach().to(x.device).contiguous()   # re-uploaded on every call)
         mu = self._mu_dev
         n = mu.numel()
-        w = torch.empty((S, n), dtype=torch.float32, device=x.device)
-        if eps is not None:
-            eps = eps.to(device=x.device, dtype=torch.float32).contiguous()
-        with timed("sample_weights_f32"):
-            _lib.check(_lib.lib().qbnn_sample_weights_f32(_lib.ptr(mu), _lib.ptr(self._sigma), n, _MC.seed, self.layer_id,
-                                                          _MC.sample_begin, S, _lib.ptr(eps), _lib.ptr(w), _lib.current_stream()))
+        w = _take_presampled(self, x.device) if eps is None else None
+        if w is None:
+            w = torch.empty((S, n), dtype=torch.float32, device=x.device)
+            if eps is not None:
+                eps = eps.to(device=x.device, dtype=torch.float32).contiguous()
+            with timed("sample_weights_f32"):
+                _lib.check(_lib.lib().qbnn_sample_weights_f32(_lib.ptr(mu), _lib.ptr(self._sigma), n, _MC.seed, self.layer_id,
+                                                              _MC.sample_begin, S, _lib.ptr(eps), _lib.ptr(w), _lib.current_stream()))
         B = x.shape[1]
         y = torch.empty((S, B, self.out_features), dtype=torch.float32, device=x.device)
         xs = 0 if x.shape[0] == 1 else x[0].numel()
@@ -240,6 +244,71 @@ def nchw_to_mc_nhwc(x):
     return x.to(torch.float32).permute(0, 2, 3, 1).contiguous().unsqueeze(0)
 
 
+class _WeightBatchF32:
+    """Static state of qbnn_sample_weights_f32_batch for one (layer list, device, S): device copies of mu / softplus(rho), the layer descriptors in
+    device memory and the [S, n] output buffers (overwritten by every forward, consumed by the same forward's convs on the same stream)."""
+
+    def __init__(self, layers, dev, S):
+        arr = (_lib.F32WLayer * len(layers))()
+        self.keep, self.out, self.n_layers = [], [], len(layers)
+        blk0 = 0
+        for i, m in enumerate(layers):
+            mu = m.weight.detach().to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
+            sg = F.softplus(m.std.detach().cpu().float()).to(dev).contiguous().reshape(-1)          # the reference's own op, once
+            n = mu.numel()
+            W = torch.empty((S, n), dtype=torch.float32, device=dev)
+            d = arr[i]
+            d.mu, d.sigma, d.w = mu.data_ptr(), sg.data_ptr(), W.data_ptr()
+            conv = m.weight.dim() == 4
+            d.n, d.Cout, d.Cin, d.KS = n, m.weight.shape[0], m.weight.shape[1], (m.k if conv else 0)
+            d.layer_id = m.layer_id
+            d.nblk = max(1, min(128, ((n + 3) // 4 + 255) // 256))
+            d.blk0 = blk0
+            blk0 += d.nblk
+            self.keep += [mu, sg]
+            self.out.append(W)
+        self.total_blocks = blk0
+        self.desc = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.versions = self.param_versions(layers)
+
+    @staticmethod
+    def param_versions(layers):
+        return [(m.weight.data_ptr(), m.weight._version, m.std.data_ptr(), m.std._version, m.layer_id) for m in layers]
+
+
+def batch_weights_f32(layers, dev):
+    """Every layer's W_s = mu + eps_s * softplus(rho) for the S samples of the active mc_context in ONE launch; each layer's forward then picks its
+    weights up.  False where it does not apply (injected eps, QBNN_F32_WBATCH=0)."""
+    if os.environ.get("QBNN_F32_WBATCH", "1") == "0" or _MC.eps is not None or not layers:
+        return False
+    dev = torch.device(dev)
+    S = _MC.samples
+    cache = layers[0].__dict__.setdefault("_wbatch_cache", {})
+    key = (tuple(id(m) for m in layers), dev.index if dev.index is not None else torch.cuda.current_device(), S)
+    wb = cache.get(key)
+    if wb is None or wb.versions != _WeightBatchF32.param_versions(layers):
+        if torch.cuda.is_current_stream_capturing():
+            return False          # (descriptors go up with a host copy: built by the eager pass that precedes every capture)
+        if len(cache) > 4:
+            cache.clear()
+        wb = cache[key] = _WeightBatchF32(layers, dev, S)
+    with timed("sample_weights_f32"):
+        _lib.check(_lib.lib().qbnn_sample_weights_f32_batch(_lib.ptr(wb.desc), wb.n_layers, wb.total_blocks, _MC.seed, _MC.sample_begin, S, _lib.current_stream()))
+    tag = (_MC.samples, _MC.seed, _MC.sample_begin, key[1])
+    for m, W in zip(layers, wb.out):
+        m._presampled = (W, tag)
+    return True
+
+
+def _take_presampled(m, dev):
+    """The weights batch_weights_f32 drew for THIS MC context on this device, or None."""
+    pre = m.__dict__.pop("_presampled", None)
+    dev = torch.device(dev)
+    if pre is not None and pre[1] == (_MC.samples, _MC.seed, _MC.sample_begin, dev.index if dev.index is not None else torch.cuda.current_device()) and _MC.eps is None:
+        return pre[0]
+    return None
+
+
 class Conv2d(nn.Module):
     """reference bbb.conv.Conv2d(in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
     bias=False, padding_mode='zeros', sigma_prior=-2, args=None), eval branch (conv.py:33-39)."""
@@ -268,10 +337,12 @@ class Conv2d(nn.Module):
         conv kernel's epilogue, rounded step by step like the separate modules of the reference graph."""
         if x.device.type != "cuda":
             raise RuntimeError("qbnn layers run on an MI355X only (no CPU fallback)")
-        if self._sigma is None or self._sigma.device != x.device:
-            self._sigma = F.softplus(self.std.detach().cpu().float()).to(x.device).contiguous().reshape(-1)
-        w = sample_conv_weights_f32(_f32(self.weight, x.device).reshape(-1), self._sigma, self.out_channels, self.in_channels, self.k,
-                                    self.layer_id, eps)
+        w = _take_presampled(self, x.device) if eps is None else None
+        if w is None:
+            if self._sigma is None or self._sigma.device != x.device:
+                self._sigma = F.softplus(self.std.detach().cpu().float()).to(x.device).contiguous().reshape(-1)
+            w = sample_conv_weights_f32(_f32(self.weight, x.device).reshape(-1), self._sigma, self.out_channels, self.in_channels, self.k,
+                                        self.layer_id, eps)
         return conv2d_f32(x, w, _f32(self.bias, x.device), self.in_channels, self.out_channels, self.k, self.stride, self.padding, relu,
                           ohwi=True, bn=None if bn is None else bn.coefficients(x.device), res=res)
 
@@ -432,6 +503,7 @@ class ConvNetwork_ResNet(nn.Module):
         return sum(m.get_kl_divergence() for _, m in self.stochastic_named())
 
     def forward_mc(self, x):
+        batch_weights_f32([m for _, m in self.stochastic_named()], x.device)      # all 21 layers' weight draws in one launch
         h = nchw_to_mc_nhwc(x)
         h = self.layers[0](h, relu=True, bn=self.layers[1])
         for li in (3, 4, 5, 6):

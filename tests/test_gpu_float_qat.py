@@ -369,12 +369,12 @@ def test_fp32_conv_kernels_every_path_against_torch(acc64):
         assert float((got - ref).abs().max()) <= tol, ((S, B, H, ci, co, k, st), float((got - ref).abs().max()), tol)
 
 
-@pytest.mark.parametrize("switch", ["QBNN_F32_TAPMASK=0", "QBNN_QAT_PRESAMPLE=0", "QBNN_Q8_TILED=0", "QBNN_QAT_WBATCH=0", "QBNN_QAT_ADDFQ=0"])
+@pytest.mark.parametrize("switch", ["QBNN_F32_TAPMASK=0", "QBNN_QAT_PRESAMPLE=0", "QBNN_Q8_TILED=0", "QBNN_QAT_WBATCH=0", "QBNN_QAT_ADDFQ=0", "QBNN_F32_WBATCH=0"])
 def test_float_path_switches_give_the_same_bits(switch, tmp_path):
     """The fp32 / fp64 conv's two gather forms (per-row tap masks against per-element bounds compares), the QAT weight pipelines on side
     streams against in line, the QAT 3 x 3 convs LDS-tiled (round 6, csrc/qbnn_q8t.hip) against the gather forms of round 5 (same integer sums, same tail),
     all layers' weight pipelines in four launches (qbnn_qat_weights_mc) against ~15 launches per layer, and the Add's FakeQuantize from its operands' integers
-    (qbnn_fake_quant_add_q8_mc) against the stored fp32 sum: the float BBB ResNet and the QAT evaluation, ragged batch of 70, give bit-identical probabilities either way."""
+    (qbnn_fake_quant_add_q8_mc) against the stored fp32 sum, and the float ResNet's 21 weight draws in one launch (qbnn_sample_weights_f32_batch) against one per layer: the float BBB ResNet and the QAT evaluation, ragged batch of 70, give bit-identical probabilities either way."""
     import os
     import subprocess
     import sys
