@@ -422,6 +422,7 @@ class ConvNetwork_LeNet(nn.Module):
         return sum(m.get_kl_divergence() for m in self.stochastic_layers())
 
     def forward_mc(self, x):
+        batch_weights_f32(self.stochastic_layers(), x.device)      # the four layers' weight draws in one launch
         h = nchw_to_mc_nhwc(x)
         h = pool2d_f32(self.layers[0](h), 2, avg=False)
         h = pool2d_f32(self.layers[2](h), 2, avg=False)
