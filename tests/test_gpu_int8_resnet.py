@@ -382,11 +382,11 @@ def test_high_sample_indices_against_oracle(w_bits):
     assert torch.equal(tail[127], p1023[0])
 
 
-@pytest.mark.parametrize("a_bits,w_bits", [(3, 8), (7, 3), (5, 8), (7, 6)], ids=["a3w8", "a7w3", "a5w8", "a7w6"])
+@pytest.mark.parametrize("a_bits,w_bits", [(3, 8), (4, 8), (5, 8), (6, 8), (7, 3), (7, 5), (7, 6), (7, 7)], ids=lambda v: str(v))
 def test_bit_width_sweep_full_batch_against_oracle(a_bits, w_bits):
-    """The reference's sweep (experiments/run_all_quant.sh:11-37) away from the two BASELINE points, at the full batch: A3 and A5
-    move every activation clamp (src/utils.py:25-30: [0, 7] / [0, 31]) and the accumulator bound of the 1.5 * 2^23 start, W3 / W6 the
-    sampled-weight clamp ([-4, 3] / [-32, 31], src/utils.py:32-37).  Fused path and per-block launches, B = 256, two samples, against
+    """EVERY point of the reference's sweep (experiments/run_all_quant.sh:11-37) away from the two BASELINE points, at the full batch: A3 ... A6
+    move every activation clamp (src/utils.py:25-30: [0, 7] ... [0, 63]) and the accumulator bound of the 1.5 * 2^23 start, W3 ... W7 the
+    sampled-weight clamp ([-4, 3] ... [-64, 63], src/utils.py:32-37).  Fused path and per-block launches, B = 256, two samples, against
     the CPU oracle: integer block outputs bit-exact, probabilities 1e-5."""
     import quantised_bayesian_nets_amd as q
     from conftest import load_golden
