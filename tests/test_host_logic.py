@@ -342,3 +342,22 @@ def test_design_table_is_what_the_generator_prints():
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     a, b = design.index("<!-- GENERATED: tools/design_table.py -->"), design.index("<!-- END GENERATED -->") + len("<!-- END GENERATED -->")
     assert design[a:b].strip() == out
+
+
+def test_qat_conv_grid_contract_without_a_gpu():
+    """qbnn_conv2d_q8_blocks is host logic: the number of (min, max) partial pairs per sample the chosen conv form will write, which the caller sizes the
+    observer's buffer by.  The ResNet's 3 x 3 geometries and its 3-channel stem take the LDS-tiled forms of csrc/qbnn_q8t.hip (blocks of whole output rows /
+    images x channel groups); anything else -- other map sizes, 1 x 1 convs, Cout % 4 != 0 -- the gather forms' 64 x 64 / 128 x 32 tiles."""
+    from quantised_bayesian_nets_amd import _lib
+    L = _lib.lib()
+    B = 256
+    tiled = {(32, 3, 24, 1): B * 8 // 8, (32, 24, 24, 1): B * 8 // 8, (32, 24, 48, 2): B * 2 // 2, (16, 48, 48, 1): B * 2 // 2, (16, 48, 96, 2): B // 2,
+             (8, 96, 96, 1): B // 2, (8, 96, 192, 2): (B // 8) * 2, (4, 192, 192, 1): (B // 8) * 2, (32, 24, 40, 1): (B * 8 // 8) * 2, (8, 96, 100, 1): (B // 2) * 2}
+    for (H, cin, cout, stride), want in tiled.items():
+        assert L.qbnn_conv2d_q8_blocks(B, H, H, cin, cout, 3, stride, 1) == want, (H, cin, cout, stride)
+    assert L.qbnn_conv2d_q8_blocks(3, 8, 8, 96, 96, 3, 1, 1) == 2                      # a ragged image group still gets its block
+    gather = lambda npix, cout, narrow: ((npix + 127) // 128) * ((cout + 31) // 32) if narrow else ((npix + 63) // 64) * ((cout + 63) // 64)
+    assert L.qbnn_conv2d_q8_blocks(B, 16, 16, 24, 24, 3, 1, 1) == gather(B * 256, 24, True)       # a 16 x 16 map at 24 channels: no tiled form
+    assert L.qbnn_conv2d_q8_blocks(B, 16, 16, 48, 96, 1, 2, 0) == gather(B * 64, 96, False)       # the 1 x 1 shortcut
+    assert L.qbnn_conv2d_q8_blocks(B, 32, 32, 24, 22, 3, 1, 1) == gather(B * 1024, 22, True)      # Cout % 4 != 0
+    assert L.qbnn_add_q8_blocks(16) == 1 and L.qbnn_add_q8_blocks(256 * 32 * 32 * 24) == 512
